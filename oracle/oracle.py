@@ -1,0 +1,314 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/reflexiv_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by reflexiv_amd/.  See reflexiv_oracle.h
+for what pins it (docs/example.html known answer) and what does not.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import gzip
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+TWIN_DS, TWIN_RDD = 0, 1
+
+
+class Params(C.Structure):
+    """orc_params (mirrors U/DefaultParam.java:74-120 for the hot path)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "k", "min_cov", "max_cov", "min_error_cov", "min_contig", "min_iter", "max_iter",
+        "front_clip", "end_clip", "partitions", "twin", "coalesce")]
+
+
+class _Records(C.Structure):
+    _fields_ = [("n", C.c_int64), ("key", C.c_void_p), ("marker", C.c_void_p),
+                ("ext_off", C.c_void_p), ("ext", C.c_void_p), ("left", C.c_void_p),
+                ("right", C.c_void_p)]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liborc.so")
+    src = os.path.join(_HERE, "reflexiv_oracle.c")
+    hdr = os.path.join(_HERE, "reflexiv_oracle.h")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liborc.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.orc_fastq_group.restype = C.c_int64
+        L.orc_extract_canon.restype = C.c_int64
+        L.orc_count_filter.restype = C.c_int64
+        L.orc_revcomp.restype = C.c_uint64
+        L.orc_revcomp.argtypes = [C.c_uint64, C.c_int]
+        L.orc_fork_filter_forward.restype = C.c_int64
+        L.orc_fork_filter_reflected.restype = C.c_int64
+        L.orc_extend_pass.restype = C.c_int64
+        L.orc_contigs_text.restype = C.c_int64
+        L.orc_assemble_from_counts.restype = C.c_int64
+        L.orc_splitmix64.restype = C.c_uint64
+        L.orc_splitmix64.argtypes = [C.c_uint64]
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    lib().orc_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+# ------------------------------------------------------------------ records
+
+@dataclass
+class Records:
+    """Flat SoA in the reference's record layout."""
+    key: np.ndarray       # uint64 [n]
+    marker: np.ndarray    # int32  [n]
+    ext_off: np.ndarray   # int64  [n+1]
+    ext: np.ndarray       # uint64 [ext_off[n]]
+    left: np.ndarray      # int32  [n]
+    right: np.ndarray     # int32  [n]
+
+    @property
+    def n(self) -> int:
+        return int(self.key.shape[0])
+
+    @staticmethod
+    def from_single(key, marker, ext, left, right) -> "Records":
+        n = len(key)
+        return Records(np.ascontiguousarray(key, np.uint64), np.ascontiguousarray(marker, np.int32),
+                       np.arange(n + 1, dtype=np.int64), np.ascontiguousarray(ext, np.uint64),
+                       np.ascontiguousarray(left, np.int32), np.ascontiguousarray(right, np.int32))
+
+    def tuple_list(self):
+        return [(int(self.key[i]), int(self.marker[i]),
+                 tuple(int(x) for x in self.ext[self.ext_off[i]:self.ext_off[i + 1]]),
+                 int(self.left[i]), int(self.right[i])) for i in range(self.n)]
+
+
+# ---------------------------------------------------------------- operators
+
+def fastq_group(text: bytes):
+    """a-1 FastqFilterWithQual (P/ReflexivMain.java:3089-3113) -> (seq_off, seq_len)."""
+    buf = np.frombuffer(text, dtype=np.uint8)
+    n = lib().orc_fastq_group(_p(buf), C.c_int64(len(text)), None, None, C.c_int64(0))
+    off = np.empty(n, np.int64)
+    ln = np.empty(n, np.int32)
+    lib().orc_fastq_group(_p(buf), C.c_int64(len(text)), _p(off), _p(ln), C.c_int64(n))
+    return off, ln
+
+
+def load_fastq(paths):
+    """Concatenate the reads of FASTQ(.gz) files -> (bases uint8[], read_off int64[n+1])."""
+    seqs, lens = [], []
+    for path in paths:
+        opener = gzip.open if path.endswith(".gz") else open
+        with opener(path, "rb") as fh:
+            text = fh.read()
+        off, ln = fastq_group(text)
+        tb = np.frombuffer(text, dtype=np.uint8)
+        for o, l in zip(off, ln):
+            seqs.append(tb[o:o + l])
+        lens.extend(int(x) for x in ln)
+    read_off = np.zeros(len(lens) + 1, np.int64)
+    np.cumsum(np.asarray(lens, np.int64), out=read_off[1:])
+    bases = np.concatenate(seqs) if seqs else np.zeros(0, np.uint8)
+    return np.ascontiguousarray(bases), read_off
+
+
+def extract_canon(bases: np.ndarray, read_off: np.ndarray, k=31, front_clip=0, end_clip=0) -> np.ndarray:
+    bases = np.ascontiguousarray(bases, np.uint8)
+    read_off = np.ascontiguousarray(read_off, np.int64)
+    nr = len(read_off) - 1
+    n = lib().orc_extract_canon(_p(bases), _p(read_off), C.c_int64(nr), k, front_clip, end_clip,
+                                None, C.c_int64(0))
+    out = np.empty(n, np.uint64)
+    lib().orc_extract_canon(_p(bases), _p(read_off), C.c_int64(nr), k, front_clip, end_clip,
+                            _p(out), C.c_int64(n))
+    return out
+
+
+def count_filter(kmers: np.ndarray, min_cov=2, max_cov=10_000_000, twin=TWIN_DS):
+    """-> (keys uint64[], counts int32[], n_distinct); kmers is not modified."""
+    work = np.array(kmers, dtype=np.uint64, copy=True)
+    n = len(work)
+    keys = np.empty(n, np.uint64)
+    counts = np.empty(n, np.int32)
+    nd = C.c_int64(0)
+    m = lib().orc_count_filter(_p(work), C.c_int64(n), min_cov, max_cov, twin,
+                               _p(keys), _p(counts), C.c_int64(n), C.byref(nd))
+    return keys[:m].copy(), counts[:m].copy(), int(nd.value)
+
+
+def revcomp(kmer: int, k: int) -> int:
+    return int(lib().orc_revcomp(C.c_uint64(kmer), k))
+
+
+def rc_expand_subkmer(keys, counts, k=31) -> Records:
+    keys = np.ascontiguousarray(keys, np.uint64)
+    counts = np.ascontiguousarray(counts, np.int32)
+    n = len(keys)
+    key = np.empty(2 * n, np.uint64); ext = np.empty(2 * n, np.uint64)
+    marker = np.empty(2 * n, np.int32); left = np.empty(2 * n, np.int32); right = np.empty(2 * n, np.int32)
+    lib().orc_rc_expand_subkmer(_p(keys), _p(counts), C.c_int64(n), k, _p(key), _p(marker), _p(ext),
+                                _p(left), _p(right))
+    return Records.from_single(key, marker, ext, left, right)
+
+
+def sort_perm(key: np.ndarray) -> np.ndarray:
+    key = np.ascontiguousarray(key, np.uint64)
+    perm = np.empty(len(key), np.int64)
+    lib().orc_sort_perm(_p(key), C.c_int64(len(key)), _p(perm))
+    return perm
+
+
+def partition_starts(sorted_key: np.ndarray, P: int) -> np.ndarray:
+    sorted_key = np.ascontiguousarray(sorted_key, np.uint64)
+    st = np.empty(P + 1, np.int64)
+    lib().orc_partition_starts(_p(sorted_key), C.c_int64(len(sorted_key)), P, _p(st))
+    return st
+
+
+def gather(r: Records, perm: np.ndarray) -> Records:
+    perm = np.ascontiguousarray(perm, np.int64)
+    n = len(perm)
+    out = Records(np.empty(n, np.uint64), np.empty(n, np.int32), np.empty(n + 1, np.int64),
+                  np.empty(max(1, len(r.ext)), np.uint64), np.empty(n, np.int32), np.empty(n, np.int32))
+    lib().orc_gather(_p(perm), C.c_int64(n), _p(r.key), _p(r.marker), _p(r.ext_off), _p(r.ext),
+                     _p(r.left), _p(r.right), _p(out.key), _p(out.marker), _p(out.ext_off),
+                     _p(out.ext), _p(out.left), _p(out.right))
+    out.ext = out.ext[:out.ext_off[n]].copy()
+    return out
+
+
+def sort_records(r: Records) -> Records:
+    return gather(r, sort_perm(r.key))
+
+
+def _fork(fn, r: Records, part_start, k, min_error_cov, twin):
+    n = r.n
+    P = len(part_start) - 1
+    part_start = np.ascontiguousarray(part_start, np.int64)
+    o = [np.empty(n, np.uint64), np.empty(n, np.int32), np.empty(n, np.uint64),
+         np.empty(n, np.int32), np.empty(n, np.int32)]
+    ops = np.empty(P + 1, np.int64)
+    m = fn(_p(r.key), _p(r.marker), _p(r.ext), _p(r.left), _p(r.right), C.c_int64(n),
+           _p(part_start), P, k, min_error_cov, twin,
+           _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(o[4]), _p(ops))
+    return Records.from_single(o[0][:m].copy(), o[1][:m].copy(), o[2][:m].copy(),
+                               o[3][:m].copy(), o[4][:m].copy()), ops
+
+
+def fork_filter_forward(r, part_start, k=31, min_error_cov=8, twin=TWIN_DS):
+    return _fork(lib().orc_fork_filter_forward, r, part_start, k, min_error_cov, twin)
+
+
+def fork_filter_reflected(r, part_start, k=31, min_error_cov=8, twin=TWIN_DS):
+    return _fork(lib().orc_fork_filter_reflected, r, part_start, k, min_error_cov, twin)
+
+
+def reflect_from_forward(r: Records, k=31) -> Records:
+    n = r.n
+    key = np.empty(n, np.uint64); marker = np.empty(n, np.int32); ext = np.empty(n, np.uint64)
+    lib().orc_reflect_from_forward(_p(r.key), _p(r.ext), C.c_int64(n), k, _p(key), _p(marker), _p(ext))
+    return Records.from_single(key, marker, ext, r.left.copy(), r.right.copy())
+
+
+def random_reflection(r: Records, part_start, k=31) -> Records:
+    part_start = np.ascontiguousarray(part_start, np.int64)
+    out = Records.from_single(r.key.copy(), r.marker.copy(), r.ext.copy(), r.left.copy(), r.right.copy())
+    lib().orc_random_reflection(_p(out.key), _p(out.marker), _p(out.ext), C.c_int64(out.n),
+                                _p(part_start), len(part_start) - 1, k)
+    return out
+
+
+def extend_pass(r: Records, part_start, k=31, twin=TWIN_DS):
+    """One extend pass over records already sorted by key -> (Records, out_part_start)."""
+    n = r.n
+    P = len(part_start) - 1
+    part_start = np.ascontiguousarray(part_start, np.int64)
+    words = max(1, int(r.ext_off[n]))
+    o = Records(np.empty(max(1, n), np.uint64), np.empty(max(1, n), np.int32),
+                np.empty(n + 1, np.int64), np.empty(words, np.uint64),
+                np.empty(max(1, n), np.int32), np.empty(max(1, n), np.int32))
+    ops = np.empty(P + 1, np.int64)
+    m = lib().orc_extend_pass(_p(r.key), _p(r.marker), _p(r.ext_off), _p(r.ext), _p(r.left), _p(r.right),
+                              C.c_int64(n), _p(part_start), P, k, twin,
+                              _p(o.key), _p(o.marker), _p(o.ext_off), _p(o.ext), _p(o.left), _p(o.right),
+                              _p(ops))
+    return Records(o.key[:m].copy(), o.marker[:m].copy(), o.ext_off[:m + 1].copy(),
+                   o.ext[:o.ext_off[m]].copy(), o.left[:m].copy(), o.right[:m].copy()), ops
+
+
+def contigs_text(r: Records, k=31, min_contig=500, twin=TWIN_DS):
+    n = r.n
+    nc = C.c_int64(0)
+    args = (_p(r.key), _p(r.marker), _p(r.ext_off), _p(r.ext), _p(r.left), _p(r.right),
+            C.c_int64(n), k, min_contig, twin)
+    ln = lib().orc_contigs_text(*args, None, C.c_int64(0), C.byref(nc))
+    buf = np.empty(max(1, ln), np.uint8)
+    lib().orc_contigs_text(*args, _p(buf), C.c_int64(ln), C.byref(nc))
+    return bytes(buf[:ln]).decode(), int(nc.value)
+
+
+def assemble_from_counts(keys, counts, prm: Params):
+    """a-14 driver -> (text, n_contigs, trace[list of record counts per pass], final Records)."""
+    keys = np.ascontiguousarray(keys, np.uint64)
+    counts = np.ascontiguousarray(counts, np.int32)
+    n = len(keys)
+    trace = np.zeros(prm.max_iter + 8, np.int64)
+    ntr = C.c_int64(0); nc = C.c_int64(0)
+    rec = _Records()
+    cap = 4 * (n + 16) * (prm.k + 8) + 1024
+    buf = np.empty(cap, np.uint8)
+    ln = lib().orc_assemble_from_counts(_p(keys), _p(counts), C.c_int64(n), C.byref(prm),
+                                        _p(buf), C.c_int64(cap), C.byref(nc),
+                                        _p(trace), C.c_int64(len(trace)), C.byref(ntr), C.byref(rec))
+    assert ln <= cap
+    m = rec.n
+
+    def arr(ptr, cnt, dt):
+        if cnt == 0:
+            return np.zeros(0, dt)
+        a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(cnt * np.dtype(dt).itemsize,))
+        return a.view(dt).copy()
+    ext_off = arr(rec.ext_off, m + 1, np.int64)
+    out = Records(arr(rec.key, m, np.uint64), arr(rec.marker, m, np.int32), ext_off,
+                  arr(rec.ext, int(ext_off[m]) if m else 0, np.uint64),
+                  arr(rec.left, m, np.int32), arr(rec.right, m, np.int32))
+    lib().orc_free_records(C.byref(rec))
+    return bytes(buf[:ln]).decode(), int(nc.value), [int(x) for x in trace[:ntr.value]], out
+
+
+# ------------------------------------------------------------ synthetic reads
+
+def synth_genome(seed: int, genome_len: int) -> np.ndarray:
+    g = np.empty((genome_len + 31) // 32, np.uint64)
+    lib().orc_synth_genome(C.c_uint64(seed), C.c_int64(genome_len), _p(g))
+    return g
+
+
+def synth_reads(seed: int, genome: np.ndarray, genome_len: int, first_read: int, n_reads: int,
+                read_len: int = 150, err_per_2_32: int = 21474836):
+    """-> (bases uint8[n_reads*read_len] ASCII, read_off int64[n_reads+1])."""
+    bases = np.empty(n_reads * read_len, np.uint8)
+    lib().orc_synth_reads(C.c_uint64(seed), _p(genome), C.c_int64(genome_len), C.c_int64(first_read),
+                          C.c_int64(n_reads), read_len, C.c_uint32(err_per_2_32), _p(bases))
+    return bases, np.arange(n_reads + 1, dtype=np.int64) * read_len

@@ -1,0 +1,736 @@
+/*
+ * reflexiv_oracle.c -- CPU restatement of Reflexiv's fixed-k (k <= 31) assembly
+ * hot path: k-mer extraction -> count/filter -> RC expand -> fork filters ->
+ * reflexible extend-and-merge passes -> contigs.
+ *
+ * TEST INFRASTRUCTURE ONLY (see reflexiv_oracle.h).  Written from the Java of
+ * the reference, cited per function as P/<file>:<lines>, with
+ * P = src/main/java/uni/bielefeld/cmg/reflexiv/pipeline.  The flip/merge
+ * arithmetic is restated at sequence level (unpack -> concatenate -> repack in
+ * the reference's word layout); SURVEY.md C.9 records that for k = 31 this is
+ * equal to the reference's bit code in every stage.
+ *
+ * Parity pin: docs/example.html:303,320-343 (tests/test_oracle_example.py).
+ */
+#include "reflexiv_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+/* ------------------------------------------------------------------ helpers */
+
+static void *xmalloc(size_t n) {
+    void *p = malloc(n ? n : 1);
+    if (!p) { fprintf(stderr, "reflexiv_oracle: out of memory (%zu bytes)\n", n); abort(); }
+    return p;
+}
+
+/* Java Long.numberOfLeadingZeros: 64 for 0 */
+static int nlz64(uint64_t x) { return x ? __builtin_clzll(x) : 64; }
+
+/* "Long.SIZE/2 - (Long.numberOfLeadingZeros(x)/2 + 1)"  P/ReflexivMain.java:2800 */
+static int sentinel_len(uint64_t w) { return 32 - (nlz64(w) / 2 + 1); }
+
+/* nucleotideValue  P/ReflexivMain.java:3062-3074: A0 C1 G2, anything else 3 */
+static inline uint64_t nuc_value(char c) {
+    if (c == 'A') return 0;
+    if (c == 'C') return 1;
+    if (c == 'G') return 2;
+    return 3;
+}
+
+static inline uint64_t low_mask(int bases) {   /* ~((~0L) << 2*bases), bases <= 31 */
+    return ~((~0ULL) << (2 * bases));
+}
+
+void orc_default_params(orc_params *p) {
+    p->k = 31; p->min_cov = 2; p->max_cov = 10000000; p->min_error_cov = 8;
+    p->min_contig = 500; p->min_iter = 15; p->max_iter = 150;
+    p->front_clip = 0; p->end_clip = 0; p->partitions = 8;
+    p->twin = ORC_TWIN_DS; p->coalesce = 0;
+}
+
+/* ---------------------------------------------------------- a-1 fastq filter */
+
+int64_t orc_fastq_group(const char *text, int64_t len,
+                        int64_t *seq_off, int32_t *seq_len, int64_t cap) {
+    /* FastqFilterWithQual.call  P/ReflexivMain.java:3092-3112.  lineMark counts
+     * the lines of the record being assembled; the checks are made in the
+     * reference's order (lineMark==2, ==3, startsWith("@"), ==1). */
+    int lineMark = 0;
+    int64_t n = 0, cur_off = 0; int32_t cur_len = 0;
+    int64_t pos = 0;
+    while (pos < len) {
+        int64_t e = pos;
+        while (e < len && text[e] != '\n') e++;
+        int64_t l = e - pos;
+        if (l > 0 && text[e - 1] == '\r') l--;       /* textFile strips \r\n too */
+        if (lineMark == 2) {
+            lineMark++;
+        } else if (lineMark == 3) {
+            lineMark++;
+            if (n < cap) { seq_off[n] = cur_off; seq_len[n] = cur_len; }
+            n++;
+        } else if (l > 0 && text[pos] == '@') {
+            lineMark = 1;
+        } else if (lineMark == 1) {
+            cur_off = pos; cur_len = (int32_t)l;
+            lineMark++;
+        }
+        pos = e + 1;
+    }
+    return n;
+}
+
+/* -------------------------------------------------------------- a-2 extract */
+
+int64_t orc_extract_canon(const char *bases, const int64_t *read_off, int64_t n_reads,
+                          int k, int front_clip, int end_clip,
+                          uint64_t *out, int64_t cap) {
+    const uint64_t mask = low_mask(k);               /* maxKmerBits :3003 */
+    int64_t n = 0;
+    for (int64_t r = 0; r < n_reads; r++) {
+        const char *read = bases + read_off[r];
+        int64_t len = read_off[r + 1] - read_off[r];
+        if (len - k - end_clip <= 1 || front_clip > len) continue;          /* :3020 */
+        uint64_t fwd = 0, rc = 0;
+        for (int64_t i = front_clip; i < len - end_clip; i++) {             /* :3027 */
+            int64_t j = i - front_clip;
+            uint64_t v = nuc_value(read[i]);
+            fwd = (fwd << 2) | v;                                            /* :3032-3033 */
+            if (j >= k) fwd &= mask;                                         /* :3034-3036 */
+            uint64_t c = v ^ 3;                                              /* :3039 */
+            if (j >= k) { rc >>= 2; c <<= 2 * (k - 1); }                     /* :3041-3043 */
+            else        { c <<= 2 * j; }                                     /* :3045 */
+            rc |= c;                                                         /* :3047 */
+            if (j >= k - 1) {                                                /* :3050 */
+                uint64_t canon = ((int64_t)fwd < (int64_t)rc) ? fwd : rc;    /* :3051-3055 */
+                if (n < cap) out[n] = canon;
+                n++;
+            }
+        }
+    }
+    return n;
+}
+
+/* ---------------------------------------------------------- radix sort u64 */
+
+static void radix_sort_u64(uint64_t *a, int64_t n) {
+    if (n < 2) return;
+    uint64_t *tmp = (uint64_t *)xmalloc((size_t)n * 8);
+    int64_t *hist = (int64_t *)xmalloc(65536 * sizeof(int64_t));
+    uint64_t *src = a, *dst = tmp;
+    for (int pass = 0; pass < 4; pass++) {
+        int sh = 16 * pass;
+        memset(hist, 0, 65536 * sizeof(int64_t));
+        for (int64_t i = 0; i < n; i++) hist[(src[i] >> sh) & 0xFFFF]++;
+        if (hist[(src[0] >> sh) & 0xFFFF] == n) continue;   /* all equal digit */
+        int64_t s = 0;
+        for (int d = 0; d < 65536; d++) { int64_t c = hist[d]; hist[d] = s; s += c; }
+        for (int64_t i = 0; i < n; i++) dst[hist[(src[i] >> sh) & 0xFFFF]++] = src[i];
+        uint64_t *t = src; src = dst; dst = t;
+    }
+    if (src != a) memcpy(a, src, (size_t)n * 8);
+    free(tmp); free(hist);
+}
+
+/* ----------------------------------------------------- a-3/a-4 count, filter */
+
+int64_t orc_count_filter(uint64_t *kmers, int64_t n, int min_cov, int max_cov, int twin,
+                         uint64_t *out_keys, int32_t *out_counts, int64_t cap,
+                         int64_t *n_distinct) {
+    radix_sort_u64(kmers, n);
+    /* the RDD twin filters only when minKmerCoverage > 1  P/ReflexivMain.java:160;
+     * the DS twin always does  P/ReflexivDSMain.java:211-216 */
+    int apply = !(twin == ORC_TWIN_RDD && min_cov <= 1);
+    int64_t m = 0, d = 0, i = 0;
+    while (i < n) {
+        int64_t j = i + 1;
+        while (j < n && kmers[j] == kmers[i]) j++;
+        int64_t c64 = j - i;
+        int32_t c = (int32_t)c64;                      /* i1 + i2 on Integer :2897 */
+        d++;
+        if (!apply || (c >= min_cov && c <= max_cov)) {                     /* :3117 */
+            if (m < cap) { out_keys[m] = kmers[i]; out_counts[m] = c; }
+            m++;
+        }
+        i = j;
+    }
+    if (n_distinct) *n_distinct = d;
+    return m;
+}
+
+/* ------------------------------------------------------------ a-5/a-6 expand */
+
+uint64_t orc_revcomp(uint64_t kmer, int k) {
+    /* KmerReverseComplement.call  P/ReflexivMain.java:2916-2923 */
+    uint64_t rc = 0;
+    for (int i = 0; i < k; i++) {
+        rc <<= 2;
+        rc |= (kmer & 3) ^ 3;
+        kmer >>= 2;
+    }
+    return rc;
+}
+
+void orc_rc_expand_subkmer(const uint64_t *kmers, const int32_t *counts, int64_t n, int k,
+                           uint64_t *key, int32_t *marker, uint64_t *ext,
+                           int32_t *left, int32_t *right) {
+    for (int64_t i = 0; i < n; i++) {
+        uint64_t two[2] = { kmers[i], orc_revcomp(kmers[i], k) };           /* :2925-2926 */
+        for (int t = 0; t < 2; t++) {
+            int64_t o = 2 * i + t;
+            key[o] = two[t] >> 2;                                            /* :2720 */
+            ext[o] = two[t] & 3;                                             /* :2719 */
+            marker[o] = 1; left[o] = counts[i]; right[o] = counts[i];        /* :2724 */
+        }
+    }
+}
+
+/* ------------------------------------------------------------ order contract */
+
+void orc_sort_perm(const uint64_t *key, int64_t n, int64_t *perm) {
+    /* stable LSD radix sort of (key, index); ties keep arrival order (B.0) */
+    int64_t *tmp = (int64_t *)xmalloc((size_t)(n ? n : 1) * sizeof(int64_t));
+    int64_t *hist = (int64_t *)xmalloc(65536 * sizeof(int64_t));
+    for (int64_t i = 0; i < n; i++) perm[i] = i;
+    int64_t *src = perm, *dst = tmp;
+    for (int pass = 0; pass < 4 && n > 1; pass++) {
+        int sh = 16 * pass;
+        memset(hist, 0, 65536 * sizeof(int64_t));
+        for (int64_t i = 0; i < n; i++) hist[(key[src[i]] >> sh) & 0xFFFF]++;
+        if (hist[(key[src[0]] >> sh) & 0xFFFF] == n) continue;
+        int64_t s = 0;
+        for (int d = 0; d < 65536; d++) { int64_t c = hist[d]; hist[d] = s; s += c; }
+        for (int64_t i = 0; i < n; i++) dst[hist[(key[src[i]] >> sh) & 0xFFFF]++] = src[i];
+        int64_t *t = src; src = dst; dst = t;
+    }
+    if (src != perm) memcpy(perm, src, (size_t)n * sizeof(int64_t));
+    free(tmp); free(hist);
+}
+
+void orc_partition_starts(const uint64_t *sorted_key, int64_t n, int P, int64_t *start) {
+    int64_t prev = 0;
+    for (int p = 0; p < P; p++) {
+        /* floor(p*n/P) without overflow for n < 2^62/P */
+        int64_t s = (int64_t)(((__int128)p * (__int128)n) / P);
+        if (s < prev) s = prev;
+        while (s > 0 && s < n && sorted_key[s] == sorted_key[s - 1]) s++;
+        start[p] = s; prev = s;
+    }
+    start[P] = n;
+}
+
+/* --------------------------------------------------------- a-7 forward filter */
+
+int64_t orc_fork_filter_forward(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
+                                const int32_t *left, const int32_t *right, int64_t n,
+                                const int64_t *part_start, int P,
+                                int k, int min_error_cov, int twin,
+                                uint64_t *okey, int32_t *omarker, uint64_t *oext,
+                                int32_t *oleft, int32_t *oright, int64_t *out_part_start) {
+    (void)right;
+    const int32_t sub = k - 1;                              /* param.subKmerSize */
+    int64_t m = 0;
+    for (int p = 0; p < P; p++) {
+        out_part_start[p] = m;
+        int64_t first = m;                                   /* list empty per task */
+        for (int64_t i = part_start[p]; i < part_start[p + 1]; i++) {
+            /* free-end value: RDD -1 (:2478), DS -1-coverage (DS :3436) */
+#define FREE_OF(cov) ((twin == ORC_TWIN_DS && min_error_cov != 0) ? (-1 - (cov)) : -1)
+            if (m == first || key[i] != okey[m - 1]) {                       /* :2475,:2529 */
+                okey[m] = key[i]; omarker[m] = marker[i]; oext[m] = ext[i];
+                oleft[m] = left[i]; oright[m] = FREE_OF(left[i]); m++;
+                continue;
+            }
+            int64_t h = m - 1;                               /* the run's survivor */
+            int32_t cs = left[i], ch = oleft[h];             /* coverages (_3) */
+            if (cs > ch) {                                                   /* :2483 */
+                int err = (min_error_cov != 0) && ch <= min_error_cov && cs >= 2 * ch;  /* :2484 */
+                omarker[h] = marker[i]; oext[h] = ext[i]; oleft[h] = cs;
+                oright[h] = err ? FREE_OF(cs) : sub;
+            } else if (cs == ch) {                                           /* :2497 */
+                if ((int64_t)ext[i] > (int64_t)oext[h]) {                    /* :2498 */
+                    omarker[h] = marker[i]; oext[h] = ext[i]; oleft[h] = cs;
+                }
+                oright[h] = sub;
+            } else {                                                         /* :2512 */
+                int err = (min_error_cov != 0) && cs <= min_error_cov && ch >= 2 * cs;  /* :2513 */
+                oright[h] = err ? FREE_OF(ch) : sub;
+            }
+#undef FREE_OF
+        }
+    }
+    out_part_start[P] = m;
+    return m;
+}
+
+/* ------------------------------------------------------- a-8 reflect records */
+
+void orc_reflect_from_forward(const uint64_t *key, const uint64_t *ext, int64_t n, int k,
+                              uint64_t *okey, int32_t *omarker, uint64_t *oext) {
+    const int sub = k - 1;
+    const int shift = 2 * (sub - 1);                                         /* :2739 */
+    const uint64_t mask = low_mask(sub);                                     /* :2740 */
+    for (int64_t i = 0; i < n; i++) {
+        uint64_t first = (key[i] >> shift) & 3;                              /* :2752-2754 */
+        uint64_t nk = ((key[i] << 2) & mask) | ext[i];                       /* :2757-2758 */
+        okey[i] = nk; omarker[i] = 2; oext[i] = first | 4;                   /* :2755,:2762 */
+    }
+}
+
+/* ------------------------------------------------------- a-9 reflected filter */
+
+int64_t orc_fork_filter_reflected(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
+                                  const int32_t *left, const int32_t *right, int64_t n,
+                                  const int64_t *part_start, int P,
+                                  int k, int min_error_cov, int twin,
+                                  uint64_t *okey, int32_t *omarker, uint64_t *oext,
+                                  int32_t *oleft, int32_t *oright, int64_t *out_part_start) {
+    (void)n;
+    const int32_t sub = k - 1;
+    const int ds_ec = (twin == ORC_TWIN_DS && min_error_cov != 0);
+    int64_t m = 0;
+    for (int p = 0; p < P; p++) {
+        out_part_start[p] = m;
+        int64_t first = m;
+        int32_t last_cov = 0;                                /* HighCoverLastCoverage :2614 */
+        for (int64_t i = part_start[p]; i < part_start[p + 1]; i++) {
+            int32_t cs = left[i];
+            if (m == first || key[i] != okey[m - 1]) {                       /* :2622,:2684 */
+                last_cov = cs;
+                okey[m] = key[i]; omarker[m] = marker[i]; oext[m] = ext[i];
+                oleft[m] = ds_ec ? (-1 - cs) : -1;                            /* :2626 / DS :3556 */
+                oright[m] = right[i]; m++;
+                continue;
+            }
+            int64_t h = m - 1;
+            if (cs > last_cov) {                                             /* :2631 */
+                int err = (min_error_cov != 0) && last_cov <= min_error_cov && cs >= 2 * last_cov;
+                last_cov = cs;
+                omarker[h] = marker[i]; oext[h] = ext[i]; oright[h] = right[i];
+                oleft[h] = err ? (ds_ec ? (-1 - cs) : -1) : sub;              /* :2636,:2643 */
+            } else if (cs == last_cov) {                                     /* :2647 */
+                /* compares (ext >>> 2*(len-1)) of the new record with (ext >>> 2*len)
+                 * of the survivor, lengths from the sentinel  :2648-2653 */
+                int ls = sentinel_len(ext[i]);
+                int lh = sentinel_len(oext[h]);
+                /* Java shift counts are taken mod 64 */
+                uint64_t a = ext[i] >> ((2 * (ls - 1)) & 63);
+                uint64_t b = oext[h] >> ((2 * lh) & 63);
+                if ((int64_t)a > (int64_t)b) {
+                    omarker[h] = marker[i]; oext[h] = ext[i]; oright[h] = right[i];
+                }
+                oleft[h] = sub;                                              /* :2656,:2663 */
+            } else {                                                         /* :2667 */
+                int err = (min_error_cov != 0) && cs <= min_error_cov && last_cov >= 2 * cs;
+                if (err) {
+                    /* RDD :2672 stores -1; DS :3595 keeps the previous left */
+                    if (!ds_ec) oleft[h] = -1;
+                } else {
+                    oleft[h] = sub;                                          /* :2679 */
+                }
+            }
+        }
+    }
+    out_part_start[P] = m;
+    return m;
+}
+
+/* --------------------------------------------- sequence-level record helpers */
+
+static int64_t ext_len_words(const uint64_t *w, int64_t nw) {
+    /* (length-1)*31 + firstBlockLength  P/ReflexivMain.java:820-823 */
+    return (nw - 1) * 31 + sentinel_len(w[0]);
+}
+
+static void unpack_key(uint64_t key, int sub, uint8_t *b) {
+    for (int i = 0; i < sub; i++) b[i] = (uint8_t)((key >> (2 * (sub - 1 - i))) & 3);
+}
+static uint64_t pack_key(const uint8_t *b, int sub) {
+    uint64_t k = 0;
+    for (int i = 0; i < sub; i++) k = (k << 2) | b[i];
+    return k;
+}
+static void unpack_ext(const uint64_t *w, int64_t nw, uint8_t *b) {
+    int f = sentinel_len(w[0]);
+    int64_t o = 0;
+    for (int j = 0; j < f; j++) b[o++] = (uint8_t)((w[0] >> (2 * (f - 1 - j))) & 3);
+    for (int64_t i = 1; i < nw; i++)
+        for (int j = 0; j < 31; j++) b[o++] = (uint8_t)((w[i] >> (2 * (30 - j))) & 3);
+}
+static int64_t ext_words_for(int64_t len) { return (len + 30) / 31; }
+static void pack_ext(const uint8_t *b, int64_t len, uint64_t *w) {
+    int64_t nw = ext_words_for(len);
+    int f = (int)(len - 31 * (nw - 1));
+    uint64_t x = 1;                                   /* the "C marker" sentinel */
+    int64_t o = 0;
+    for (int j = 0; j < f; j++) x = (x << 2) | b[o++];
+    w[0] = x;
+    for (int64_t i = 1; i < nw; i++) {
+        x = 0;
+        for (int j = 0; j < 31; j++) x = (x << 2) | b[o++];
+        w[i] = x;
+    }
+}
+
+/* full sequence of a record: marker 1 = key||ext, marker 2 = ext||key */
+static int64_t record_seq(uint64_t key, int marker, const uint64_t *w, int64_t nw, int sub,
+                          uint8_t *b) {
+    int64_t L = ext_len_words(w, nw);
+    if (marker == 1) { unpack_key(key, sub, b); unpack_ext(w, nw, b + sub); }
+    else             { unpack_ext(w, nw, b); unpack_key(key, sub, b + L); }
+    return L + sub;
+}
+
+/* store sequence b[0..len) in orientation m at output slot */
+typedef struct {
+    uint64_t *key; int32_t *marker; int64_t *ext_off; uint64_t *ext;
+    int32_t *left; int32_t *right; int64_t n;
+} out_set;
+
+static void emit_seq(out_set *o, const uint8_t *b, int64_t len, int sub, int m,
+                     int32_t left, int32_t right) {
+    int64_t i = o->n++;
+    int64_t L = len - sub;
+    uint64_t *w = o->ext + o->ext_off[i];
+    if (m == 1) { o->key[i] = pack_key(b, sub);       pack_ext(b + sub, L, w); }
+    else        { o->key[i] = pack_key(b + L, sub);   pack_ext(b, L, w); }
+    o->marker[i] = m; o->left[i] = left; o->right[i] = right;
+    o->ext_off[i + 1] = o->ext_off[i] + ext_words_for(L);
+}
+
+/* --------------------------------------------------- a-10 random reflection */
+
+void orc_random_reflection(uint64_t *key, int32_t *marker, uint64_t *ext, int64_t n,
+                           const int64_t *part_start, int P, int k) {
+    (void)n;
+    const int sub = k - 1;
+    uint8_t b[96];
+    for (int p = 0; p < P; p++) {
+        int m = 2;                                   /* randomReflexivMarker = 2 :2777 */
+        for (int64_t i = part_start[p]; i < part_start[p + 1]; i++) {
+            if (marker[i] != m) {                    /* singleKmerRandomizer :2792-2876 */
+                int64_t len = record_seq(key[i], marker[i], &ext[i], 1, sub, b);
+                int64_t L = len - sub;
+                if (m == 1) { key[i] = pack_key(b, sub);     pack_ext(b + sub, L, &ext[i]); }
+                else        { key[i] = pack_key(b + L, sub); pack_ext(b, L, &ext[i]); }
+                marker[i] = m;
+            }
+            m = 3 - m;                                                      /* :2880-2884 */
+        }
+    }
+}
+
+/* ------------------------------------------------------ a-11..13 extend pass */
+
+#define ORC_BLOCK (INT32_MIN)
+
+int64_t orc_extend_pass(const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
+                        const uint64_t *ext, const int32_t *left, const int32_t *right,
+                        int64_t n, const int64_t *part_start, int P, int k, int twin,
+                        uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext,
+                        int32_t *oleft, int32_t *oright, int64_t *out_part_start) {
+    const int sub = k - 1;
+    int64_t maxw = 1;
+    for (int64_t i = 0; i < n; i++) { int64_t w = ext_off[i + 1] - ext_off[i]; if (w > maxw) maxw = w; }
+    /* scratch big enough for a merged sequence */
+    uint8_t *bs = (uint8_t *)xmalloc((size_t)(2 * maxw * 31 + 2 * sub + 64));
+    uint8_t *bh = (uint8_t *)xmalloc((size_t)(maxw * 31 + sub + 64));
+    out_set o = { okey, omarker, oext_off, oext, oleft, oright, 0 };
+    oext_off[0] = 0;
+
+#define EXTW(i)   (ext + ext_off[i])
+#define EXTN(i)   (ext_off[(i) + 1] - ext_off[i])
+#define FLIP_EMIT(i) do { /* singleKmerRandomizer  P/ReflexivMain.java:910-1063 */ \
+        int64_t len_ = record_seq(key[i], marker[i], EXTW(i), EXTN(i), sub, bs); \
+        emit_seq(&o, bs, len_, sub, m, left[i], right[i]); m = 3 - m; } while (0)
+
+    for (int p = 0; p < P; p++) {
+        out_part_start[p] = o.n;
+        int m = 2;                                   /* randomReflexivMarker = 2 :770 */
+        int64_t holder = -1;                         /* tmpReflexivKmerExtendList (<= 1 element) */
+        for (int64_t s = part_start[p]; s < part_start[p + 1]; s++) {
+            if (holder < 0) { holder = s; continue; }                        /* :797-799,:813-814 */
+            if (key[s] != key[holder]) {                                     /* :886-893 */
+                FLIP_EMIT(holder); holder = s; continue;
+            }
+            if (marker[s] == marker[holder]) {                               /* :845-854 */
+                FLIP_EMIT(s); continue;
+            }
+            int64_t F = (marker[s] == 1) ? s : holder;       /* forward record   */
+            int64_t R = (marker[s] == 1) ? holder : s;       /* reflected record */
+            int32_t a = left[F], b = right[R];               /* junction-side markers */
+            int64_t lenF = ext_len_words(EXTW(F), EXTN(F));
+            int64_t lenR = ext_len_words(EXTW(R), EXTN(R));
+            int64_t d;
+            if ((a < 0 && b < 0) || (a >= 0 && b >= 0)) {                     /* :825-832 */
+                d = -1;
+            } else if (s == F) {                                             /* :833-840 */
+                if (a >= 0 && a - lenR >= 0) d = a - lenR;
+                else if (b >= 0 && b - lenF >= 0) d = b - lenF;
+                else d = ORC_BLOCK;
+            } else {                                                         /* :868-875 */
+                if (b >= 0 && b - lenF >= 0) d = b - lenF;
+                else if (twin == ORC_TWIN_RDD) {
+                    /* RDD twin tests left but subtracts from right  :872-873 */
+                    int32_t hr = right[F];
+                    if (a >= 0 && hr - lenR >= 0) d = hr - lenR; else d = ORC_BLOCK;
+                } else {
+                    if (a >= 0 && a - lenR >= 0) d = a - lenR; else d = ORC_BLOCK; /* DS :1856-1857 */
+                }
+            }
+            if (d == ORC_BLOCK) { FLIP_EMIT(s); continue; }                   /* :841-843 */
+            /* reflexivExtend: R.ext || key || F.ext   P/ReflexivMain.java:1077-1519 */
+            int64_t lr = record_seq(key[R], 2, EXTW(R), EXTN(R), sub, bs);   /* R.ext||key */
+            unpack_ext(EXTW(F), EXTN(F), bs + lr);
+            int64_t len = lr + lenF;
+            int32_t L, Rt;
+            if (d < 0)             { L = left[R];   Rt = right[F]; }          /* :1214-1218 */
+            else if (left[F] > 0)  { L = (int32_t)d; Rt = right[F]; }         /* :1220-1226 */
+            else                   { L = left[R];   Rt = (int32_t)d; }        /* :1227-1233 */
+            emit_seq(&o, bs, len, sub, m, L, Rt); m = 3 - m;                 /* :1242,:1514 */
+            holder = -1;
+        }
+        if (holder >= 0) FLIP_EMIT(holder);                                   /* :902 */
+    }
+    out_part_start[P] = o.n;
+    free(bs); free(bh);
+    return o.n;
+#undef EXTW
+#undef EXTN
+#undef FLIP_EMIT
+}
+
+void orc_gather(const int64_t *perm, int64_t n,
+                const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
+                const uint64_t *ext, const int32_t *left, const int32_t *right,
+                uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext,
+                int32_t *oleft, int32_t *oright) {
+    oext_off[0] = 0;
+    for (int64_t i = 0; i < n; i++) {
+        int64_t s = perm[i];
+        okey[i] = key[s]; omarker[i] = marker[s]; oleft[i] = left[s]; oright[i] = right[s];
+        int64_t nw = ext_off[s + 1] - ext_off[s];
+        memcpy(oext + oext_off[i], ext + ext_off[s], (size_t)nw * 8);
+        oext_off[i + 1] = oext_off[i] + nw;
+    }
+}
+
+/* --------------------------------------------------------------- a-15 contigs */
+
+int64_t orc_contigs_text(const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
+                         const uint64_t *ext, const int32_t *left, const int32_t *right,
+                         int64_t n, int k, int min_contig, int twin,
+                         char *out, int64_t cap, int64_t *n_contigs) {
+    static const char NUC[4] = { 'A', 'C', 'G', 'T' };
+    const int sub = k - 1;
+    int64_t pos = 0, idx = 0;
+    uint8_t *b = NULL; int64_t bcap = 0;
+#define PUTC(c) do { if (pos < cap) out[pos] = (c); pos++; } while (0)
+    for (int64_t i = 0; i < n; i++) {
+        /* DS skips records with both markers <= -10,000,000  P/ReflexivDSMain.java:749 */
+        if (twin == ORC_TWIN_DS && left[i] <= -10000000 && right[i] <= -10000000) continue;
+        int64_t nw = ext_off[i + 1] - ext_off[i];
+        int64_t len = ext_len_words(ext + ext_off[i], nw) + sub;
+        if (len < min_contig) continue;                                      /* :596,:606 */
+        if (len + 64 > bcap) { free(b); bcap = 2 * len + 64; b = (uint8_t *)xmalloc((size_t)bcap); }
+        record_seq(key[i], marker[i], ext + ext_off[i], nw, sub, b);
+        char hdr[96];
+        int hl;
+        if (twin == ORC_TWIN_DS)                                             /* DS :755,:722 */
+            hl = snprintf(hdr, sizeof hdr, ">Contig-%lld-(%d,%d)-%lld\n", (long long)len,
+                          left[i], right[i], (long long)idx);
+        else                                                                 /* :597,:578 */
+            hl = snprintf(hdr, sizeof hdr, ">Contig-%lld-%lld\n", (long long)len, (long long)idx);
+        for (int j = 0; j < hl; j++) PUTC(hdr[j]);
+        for (int64_t j = 0; j < len; j++) {                                  /* changeLine :616-637 */
+            if (j > 0 && j % 100 == 0) PUTC('\n');
+            PUTC(NUC[b[j]]);
+        }
+        PUTC('\n');                                  /* saveAsTextFile line terminator */
+        idx++;
+    }
+#undef PUTC
+    free(b);
+    if (n_contigs) *n_contigs = idx;
+    return pos;
+}
+
+/* ---------------------------------------------------------------- a-14 driver */
+
+static void rec_alloc(orc_records *r, int64_t n, int64_t words) {
+    r->n = 0;
+    r->key = (uint64_t *)xmalloc((size_t)n * 8);
+    r->marker = (int32_t *)xmalloc((size_t)n * 4);
+    r->ext_off = (int64_t *)xmalloc((size_t)(n + 1) * 8);
+    r->ext = (uint64_t *)xmalloc((size_t)words * 8);
+    r->left = (int32_t *)xmalloc((size_t)n * 4);
+    r->right = (int32_t *)xmalloc((size_t)n * 4);
+    r->ext_off[0] = 0;
+}
+void orc_free_records(orc_records *r) {
+    free(r->key); free(r->marker); free(r->ext_off); free(r->ext); free(r->left); free(r->right);
+    memset(r, 0, sizeof *r);
+}
+
+/* sort + one mapPartitions(extend pass); consumes *cur, returns the new set */
+static void sort_and_extend(orc_records *cur, int P, int k, int twin) {
+    int64_t n = cur->n, words = cur->ext_off[n];
+    int64_t *perm = (int64_t *)xmalloc((size_t)(n ? n : 1) * 8);
+    orc_sort_perm(cur->key, n, perm);                         /* sortByKey  :235,:247,:286 */
+    orc_records srt; rec_alloc(&srt, n ? n : 1, words ? words : 1);
+    orc_gather(perm, n, cur->key, cur->marker, cur->ext_off, cur->ext, cur->left, cur->right,
+               srt.key, srt.marker, srt.ext_off, srt.ext, srt.left, srt.right);
+    srt.n = n;
+    free(perm);
+    int64_t *ps = (int64_t *)xmalloc((size_t)(P + 1) * 8), *ops = (int64_t *)xmalloc((size_t)(P + 1) * 8);
+    orc_partition_starts(srt.key, n, P, ps);
+    orc_records out; rec_alloc(&out, n ? n : 1, words ? words : 1);
+    out.n = orc_extend_pass(srt.key, srt.marker, srt.ext_off, srt.ext, srt.left, srt.right, n,
+                            ps, P, k, twin,
+                            out.key, out.marker, out.ext_off, out.ext, out.left, out.right, ops);
+    free(ps); free(ops);
+    orc_free_records(&srt);
+    orc_free_records(cur);
+    *cur = out;
+}
+
+int64_t orc_assemble_from_counts(const uint64_t *kmers, const int32_t *counts, int64_t n,
+                                 const orc_params *prm,
+                                 char *out, int64_t cap, int64_t *n_contigs,
+                                 int64_t *trace, int64_t trace_cap, int64_t *n_trace,
+                                 orc_records *rec_out) {
+    const int k = prm->k, twin = prm->twin;
+    int P = prm->partitions > 0 ? prm->partitions : 1;
+    int64_t n2 = 2 * n, nt = 0;
+    int64_t a = n2 ? n2 : 1;
+    /* RC expand + forward sub-kmers  :168-176 */
+    uint64_t *key = (uint64_t *)xmalloc((size_t)a * 8), *ext = (uint64_t *)xmalloc((size_t)a * 8);
+    int32_t *marker = (int32_t *)xmalloc((size_t)a * 4), *left = (int32_t *)xmalloc((size_t)a * 4),
+            *right = (int32_t *)xmalloc((size_t)a * 4);
+    uint64_t *key2 = (uint64_t *)xmalloc((size_t)a * 8), *ext2 = (uint64_t *)xmalloc((size_t)a * 8);
+    int32_t *marker2 = (int32_t *)xmalloc((size_t)a * 4), *left2 = (int32_t *)xmalloc((size_t)a * 4),
+            *right2 = (int32_t *)xmalloc((size_t)a * 4);
+    int64_t *perm = (int64_t *)xmalloc((size_t)a * 8);
+    int64_t *ps = (int64_t *)xmalloc((size_t)(P + 1) * 8), *ps2 = (int64_t *)xmalloc((size_t)(P + 1) * 8);
+    orc_rc_expand_subkmer(kmers, counts, n, k, key, marker, ext, left, right);
+    int64_t m = n2;
+
+#define SORT_FIXED() do { \
+        orc_sort_perm(key, m, perm); \
+        for (int64_t i_ = 0; i_ < m; i_++) { int64_t s_ = perm[i_]; key2[i_] = key[s_]; \
+            marker2[i_] = marker[s_]; ext2[i_] = ext[s_]; left2[i_] = left[s_]; right2[i_] = right[s_]; } \
+        orc_partition_starts(key2, m, P, ps); } while (0)
+
+    /* sortByKey + forward fork filter  :179-186 */
+    SORT_FIXED();
+    m = orc_fork_filter_forward(key2, marker2, ext2, left2, right2, m, ps, P, k,
+                                prm->min_error_cov, twin, key, marker, ext, left, right, ps2);
+    /* reflected extraction  :188-189 */
+    orc_reflect_from_forward(key, ext, m, k, key2, marker2, ext2);
+    memcpy(key, key2, (size_t)m * 8); memcpy(ext, ext2, (size_t)m * 8); memcpy(marker, marker2, (size_t)m * 4);
+    /* sortByKey + reflected fork filter  :191-198 */
+    SORT_FIXED();
+    m = orc_fork_filter_reflected(key2, marker2, ext2, left2, right2, m, ps, P, k,
+                                  prm->min_error_cov, twin, key, marker, ext, left, right, ps2);
+    /* random reflection on the filter's output partitions  :204-205 */
+    orc_random_reflection(key, marker, ext, m, ps2, P, k);
+#undef SORT_FIXED
+
+    /* move to the variable-length record set (single word == 1-word array) */
+    orc_records cur; rec_alloc(&cur, m ? m : 1, m ? m : 1);
+    for (int64_t i = 0; i < m; i++) {
+        cur.key[i] = key[i]; cur.marker[i] = marker[i]; cur.left[i] = left[i]; cur.right[i] = right[i];
+        cur.ext[i] = ext[i]; cur.ext_off[i + 1] = i + 1;
+    }
+    cur.n = m;
+    free(key); free(ext); free(marker); free(left); free(right);
+    free(key2); free(ext2); free(marker2); free(left2); free(right2);
+    free(perm); free(ps); free(ps2);
+
+#define TRACE() do { if (trace && nt < trace_cap) trace[nt] = cur.n; nt++; } while (0)
+    /* 1 + 3 single-word passes, then the first-array pass  :211-254 */
+    int iterations = 0;
+    sort_and_extend(&cur, P, k, twin); TRACE();
+    for (int i = 1; i < 4; i++) { iterations++; sort_and_extend(&cur, P, k, twin); TRACE(); }
+    iterations++;
+    sort_and_extend(&cur, P, k, twin); TRACE();
+    /* array loop with the stop rule  :263-296 */
+    int partitionNumber = P;
+    int64_t contigNumber = 0;
+    while (iterations <= prm->max_iter) {
+        iterations++;
+        if (iterations >= prm->min_iter && iterations % 3 == 0) {
+            int64_t current = cur.n;                                          /* count() :270 */
+            if (contigNumber == current) break;
+            contigNumber = current;
+            if (prm->coalesce && partitionNumber >= 16 && current / partitionNumber <= 20) {
+                partitionNumber = partitionNumber / 4 + 1;                    /* :277-281 */
+                P = partitionNumber;
+            }
+        }
+        sort_and_extend(&cur, P, k, twin); TRACE();
+    }
+#undef TRACE
+    if (n_trace) *n_trace = nt;
+    int64_t len = orc_contigs_text(cur.key, cur.marker, cur.ext_off, cur.ext, cur.left, cur.right,
+                                   cur.n, k, prm->min_contig, twin, out, cap, n_contigs);
+    if (rec_out) *rec_out = cur; else orc_free_records(&cur);
+    return len;
+}
+
+/* --------------------------------------------------------- synthetic reads */
+
+uint64_t orc_splitmix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+#define SYNTH_TAG_GENOME 0x47454E4F4D45ULL
+#define SYNTH_TAG_PAIRS  0x5041495253ULL
+#define SYNTH_TAG_ERRORS 0x4552524F5253ULL
+
+void orc_synth_genome(uint64_t seed, int64_t genome_len, uint64_t *packed) {
+    uint64_t sg = orc_splitmix64(seed ^ SYNTH_TAG_GENOME);
+    int64_t nw = (genome_len + 31) / 32;
+    for (int64_t j = 0; j < nw; j++) packed[j] = orc_splitmix64(sg + (uint64_t)j);
+}
+
+static inline unsigned genome_base(const uint64_t *g, int64_t i) {
+    return (unsigned)((g[i >> 5] >> (62 - 2 * (i & 31))) & 3);
+}
+
+void orc_synth_reads(uint64_t seed, const uint64_t *genome, int64_t genome_len,
+                     int64_t first_read, int64_t n_reads, int read_len, uint32_t err_per_2_32,
+                     char *bases) {
+    static const char NUC[4] = { 'A', 'C', 'G', 'T' };
+    uint64_t sp = orc_splitmix64(seed ^ SYNTH_TAG_PAIRS);
+    uint64_t se = orc_splitmix64(seed ^ SYNTH_TAG_ERRORS);
+    for (int64_t t = 0; t < n_reads; t++) {
+        int64_t r = first_read + t;
+        uint64_t pair = (uint64_t)r >> 1;
+        int mate = (int)(r & 1);
+        uint64_t u = orc_splitmix64(sp + pair);
+        int64_t s = (int64_t)(u & 0xFFFF) + (int64_t)((u >> 16) & 0xFFFF)
+                  + (int64_t)((u >> 32) & 0xFFFF) + (int64_t)((u >> 48) & 0xFFFF);
+        int64_t frag = 350 + ((s - 131070) * 35) / 37837;   /* ~N(350,35); truncating division */
+        if (frag < read_len) frag = read_len;
+        if (frag > genome_len) frag = genome_len;
+        uint64_t v = orc_splitmix64(u);
+        int64_t start = (int64_t)((v >> 1) % (uint64_t)(genome_len - frag + 1));
+        int strand = (int)(v & 1);
+        int is_rc = mate ^ strand;
+        int64_t pos = is_rc ? start + frag - read_len : start;
+        char *dst = bases + t * (int64_t)read_len;
+        for (int j = 0; j < read_len; j++) {
+            unsigned b = is_rc ? 3u - genome_base(genome, pos + read_len - 1 - j)
+                               : genome_base(genome, pos + j);
+            uint64_t e = orc_splitmix64(se + (uint64_t)r * (uint64_t)read_len + (uint64_t)j);
+            if ((uint32_t)e < err_per_2_32) b = (b + 1u + (unsigned)((e >> 32) % 3u)) & 3u;
+            dst[j] = NUC[b];
+        }
+    }
+}

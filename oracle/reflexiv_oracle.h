@@ -1,0 +1,177 @@
+/*
+ * reflexiv_oracle.h -- CPU restatement of Reflexiv's fixed-k assembly hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under reflexiv_amd/ may include, link or
+ * call this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg use it, as the checker / the reported CPU baseline.
+ *
+ * Pinning: the reference's tests hold no golden vectors for this path
+ * (src/test/.../ReflexivMainTest.java:36-45 asserts 1 == 1), and no JVM exists
+ * in the build container, so the reference itself cannot run.  The oracle is
+ * pinned by the single known answer the reference documents
+ * (docs/example.html:303,320-343: one 4558-base contig per strand, first 1200
+ * bases printed) -- see tests/test_oracle_example.py.  Everything else is
+ * "parity unpinned by reference tests" and anchored on the Java source cited
+ * per function below.  P = src/main/java/uni/bielefeld/cmg/reflexiv/pipeline.
+ *
+ * All record arrays are flat struct-of-arrays in the reference's own record
+ * layout:
+ *   key    (k-1)-mer, 2 bits/base, first base in the highest used bit pair
+ *   marker 1 = forward  (sequence = key || ext), 2 = reflected (ext || key)
+ *   ext    words [ext_off[i], ext_off[i+1]): word 0 = first f (1..31) bases with
+ *          a 1-bit sentinel at bit 2f, every further word exactly 31 bases
+ *   left,right  bubble-distance markers (< 0: free end)
+ */
+#ifndef REFLEXIV_ORACLE_H
+#define REFLEXIV_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_TWIN_DS  0   /* P/ReflexivDSMain.java arithmetic (normative)   */
+#define ORC_TWIN_RDD 1   /* P/ReflexivMain.java arithmetic (operator twin)  */
+
+typedef struct {
+    int32_t k;                /* kmerSize                 DefaultParam.java:74  */
+    int32_t min_cov;          /* minKmerCoverage          DefaultParam.java:103 */
+    int32_t max_cov;          /* maxKmerCoverage          DefaultParam.java:104 */
+    int32_t min_error_cov;    /* minErrorCoverage         DefaultParam.java:105 */
+    int32_t min_contig;       /* minContig                DefaultParam.java:107 */
+    int32_t min_iter;         /* minimumIteration         DefaultParam.java:115 */
+    int32_t max_iter;         /* maximumIteration         DefaultParam.java:114 */
+    int32_t front_clip;       /* frontClip                DefaultParam.java:119 */
+    int32_t end_clip;         /* endClip                  DefaultParam.java:120 */
+    int32_t partitions;       /* logical partitions P of the order contract    */
+    int32_t twin;             /* ORC_TWIN_DS / ORC_TWIN_RDD                     */
+    int32_t coalesce;         /* apply the partition coalesce rule (:277-281)   */
+} orc_params;
+
+void orc_default_params(orc_params *p);
+
+/* a-1  FastqFilterWithQual  P/ReflexivMain.java:3089-3113.  Walks '\n'-separated
+ * lines of text[0..len) with the reference's 4-line state machine and records the
+ * (offset,length) of the sequence line of every emitted record.  Returns the
+ * number of records (may exceed cap; only the first cap are written). */
+int64_t orc_fastq_group(const char *text, int64_t len,
+                        int64_t *seq_off, int32_t *seq_len, int64_t cap);
+
+/* a-2  ReverseComplementKmerBinaryExtraction.call  P/ReflexivMain.java:3013-3075.
+ * Reads are ASCII, read i = bases[read_off[i] .. read_off[i+1]).  Returns the
+ * number of canonical k-mers (written to out if it fits in cap). */
+int64_t orc_extract_canon(const char *bases, const int64_t *read_off, int64_t n_reads,
+                          int k, int front_clip, int end_clip,
+                          uint64_t *out, int64_t cap);
+
+/* a-3/a-4  reduceByKey(KmerCounting) + KmerCoverageFilter
+ * P/ReflexivMain.java:155,160-163,2895-2899,3115-3119.  Sorts kmers in place,
+ * emits (key,count) with min<=count<=max in ascending key order.  Returns the
+ * number of survivors; *n_distinct (optional) = distinct keys before filter. */
+int64_t orc_count_filter(uint64_t *kmers, int64_t n, int min_cov, int max_cov, int twin,
+                         uint64_t *out_keys, int32_t *out_counts, int64_t cap,
+                         int64_t *n_distinct);
+
+/* a-5/a-6  KmerReverseComplement + ForwardSubKmerExtraction
+ * P/ReflexivMain.java:2910-2930, 2709-2730.  n (kmer,count) -> 2n records
+ * (key = kmer>>>2, marker 1, ext = kmer&3 [no sentinel], left = right = count). */
+void orc_rc_expand_subkmer(const uint64_t *kmers, const int32_t *counts, int64_t n, int k,
+                           uint64_t *key, int32_t *marker, uint64_t *ext,
+                           int32_t *left, int32_t *right);
+
+uint64_t orc_revcomp(uint64_t kmer, int k);
+
+/* Order contract B.0: stable sort by key; writes the permutation (perm[i] =
+ * source index of the record at sorted position i). */
+void orc_sort_perm(const uint64_t *key, int64_t n, int64_t *perm);
+
+/* Order contract B.0: logical partition starts after a sort: start[p] =
+ * floor(p*n/P) moved forward so that equal keys never split; start[P] = n. */
+void orc_partition_starts(const uint64_t *sorted_key, int64_t n, int P, int64_t *start);
+
+/* a-7  FilterForkSubKmer[WithErrorCorrection]  P/ReflexivMain.java:2412-2540,
+ * DS P/ReflexivDSMain.java:3375-3483.  Single-word records sorted by key.
+ * part_start[P+1] in, out_part_start[P+1] out.  Returns survivors. */
+int64_t orc_fork_filter_forward(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
+                                const int32_t *left, const int32_t *right, int64_t n,
+                                const int64_t *part_start, int P,
+                                int k, int min_error_cov, int twin,
+                                uint64_t *okey, int32_t *omarker, uint64_t *oext,
+                                int32_t *oleft, int32_t *oright, int64_t *out_part_start);
+
+/* a-8  ReflectedSubKmerExtractionFromForward  P/ReflexivMain.java:2742-2768 */
+void orc_reflect_from_forward(const uint64_t *key, const uint64_t *ext, int64_t n, int k,
+                              uint64_t *okey, int32_t *omarker, uint64_t *oext);
+
+/* a-9  FilterForkReflectedSubKmer[WithErrorCorrection]  P/ReflexivMain.java:2550-2696,
+ * DS P/ReflexivDSMain.java:3493-3616 */
+int64_t orc_fork_filter_reflected(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
+                                  const int32_t *left, const int32_t *right, int64_t n,
+                                  const int64_t *part_start, int P,
+                                  int k, int min_error_cov, int twin,
+                                  uint64_t *okey, int32_t *omarker, uint64_t *oext,
+                                  int32_t *oleft, int32_t *oright, int64_t *out_part_start);
+
+/* a-10 kmerRandomReflection  P/ReflexivMain.java:2783-2885: record j of a partition
+ * takes orientation 2 if j is even, 1 if odd (in place). */
+void orc_random_reflection(uint64_t *key, int32_t *marker, uint64_t *ext, int64_t n,
+                           const int64_t *part_start, int P, int k);
+
+/* a-11..a-13  ExtendReflexivKmer / ...ToArrayFirstTime / ...ToArrayLoop
+ * P/ReflexivMain.java:2019-2401, 1564-2013, 762-1558 (DS: 3011-3367, 2559-3009,
+ * 1746-2557).  One extend pass over records already sorted by key.  Outputs must
+ * have room for n records and ext_off[n] words.  Returns the output record count;
+ * out_part_start[P+1] receives the per-partition output offsets. */
+int64_t orc_extend_pass(const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
+                        const uint64_t *ext, const int32_t *left, const int32_t *right,
+                        int64_t n, const int64_t *part_start, int P, int k, int twin,
+                        uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext,
+                        int32_t *oleft, int32_t *oright, int64_t *out_part_start);
+
+/* gather records (with variable-length ext) by permutation */
+void orc_gather(const int64_t *perm, int64_t n,
+                const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
+                const uint64_t *ext, const int32_t *left, const int32_t *right,
+                uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext,
+                int32_t *oleft, int32_t *oright);
+
+/* a-15  BinaryReflexivKmerArrayToString + KmerToContig + TagContigID
+ * P/ReflexivMain.java:696-741, 590-637, 573-581 (DS 855-900, 743-795, 717-725).
+ * Writes the text saveAsTextFile would write (every element followed by '\n').
+ * Returns the text length (written only if it fits in cap). */
+int64_t orc_contigs_text(const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
+                         const uint64_t *ext, const int32_t *left, const int32_t *right,
+                         int64_t n, int k, int min_contig, int twin,
+                         char *out, int64_t cap, int64_t *n_contigs);
+
+/* a-14 whole driver (P/ReflexivMain.java:147-310 / P/ReflexivDSMain.java:204-352)
+ * from sorted filtered (kmer,count) to contig text.  trace (optional, cap entries)
+ * receives the record count after every extend pass; *n_trace the passes run.
+ * If rec_out != NULL it is filled with a malloc'd copy of the final records
+ * (free with orc_free_records). */
+typedef struct {
+    int64_t n;
+    uint64_t *key; int32_t *marker; int64_t *ext_off; uint64_t *ext;
+    int32_t *left; int32_t *right;
+} orc_records;
+
+int64_t orc_assemble_from_counts(const uint64_t *kmers, const int32_t *counts, int64_t n,
+                                 const orc_params *prm,
+                                 char *out, int64_t cap, int64_t *n_contigs,
+                                 int64_t *trace, int64_t trace_cap, int64_t *n_trace,
+                                 orc_records *rec_out);
+void orc_free_records(orc_records *r);
+
+/* Synthetic reads, integer-only counter-based generator shared
+ * bit-for-bit with reflexiv_amd/csrc (rfx_synth_*). */
+uint64_t orc_splitmix64(uint64_t x);
+void orc_synth_genome(uint64_t seed, int64_t genome_len, uint64_t *packed /* ceil(len/32) words */);
+/* read r (0..n_reads): ASCII into bases[r*read_len ...] */
+void orc_synth_reads(uint64_t seed, const uint64_t *genome, int64_t genome_len,
+                     int64_t first_read, int64_t n_reads, int read_len, uint32_t err_per_2_32,
+                     char *bases);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

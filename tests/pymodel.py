@@ -1,0 +1,217 @@
+"""Pure-Python, string-level model of the reflexible extend path (small cases only).
+
+An independent second restatement used to cross-check oracle/reflexiv_oracle.c:
+records are (key_str, marker, ext_str, left, right) with plain ACGT strings, so
+none of the 2-bit word packing of the C oracle is shared.  Follows SURVEY.md
+Appendix B (B.0 order contract, B.3-B.6) and the same reference lines
+(P/ReflexivMain.java / P/ReflexivDSMain.java) as the C oracle.
+"""
+from __future__ import annotations
+
+NUC = "ACGT"
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A"}
+BLOCK = object()
+
+
+def decode_kmer(x: int, k: int) -> str:
+    return "".join(NUC[(x >> (2 * (k - 1 - i))) & 3] for i in range(k))
+
+
+def revcomp(s: str) -> str:
+    return "".join(COMP[c] for c in reversed(s))
+
+
+def partition_starts(keys, P):
+    n = len(keys)
+    st, prev = [], 0
+    for p in range(P):
+        s = max((p * n) // P, prev)
+        while 0 < s < n and keys[s] == keys[s - 1]:
+            s += 1
+        st.append(s)
+        prev = s
+    st.append(n)
+    return st
+
+
+def stable_sort(recs):
+    return sorted(recs, key=lambda r: r[0])          # Python's sort is stable
+
+
+def rc_expand(kmers, counts, k):
+    out = []
+    for x, c in zip(kmers, counts):
+        s = decode_kmer(x, k)
+        for t in (s, revcomp(s)):
+            out.append((t[:-1], 1, t[-1], c, c))
+    return out
+
+
+def fork_forward(recs, starts, sub, min_err, ds):
+    free = (lambda cov: -1 - cov) if (ds and min_err) else (lambda cov: -1)
+    out, ostarts = [], []
+    for p in range(len(starts) - 1):
+        ostarts.append(len(out))
+        first = len(out)
+        for key, mk, ext, left, right in recs[starts[p]:starts[p + 1]]:
+            if len(out) == first or out[-1][0] != key:
+                out.append([key, mk, ext, left, free(left)])
+                continue
+            h = out[-1]
+            cs, ch = left, h[3]
+            if cs > ch:
+                err = min_err and ch <= min_err and cs >= 2 * ch
+                out[-1] = [key, mk, ext, cs, free(cs) if err else sub]
+            elif cs == ch:
+                if NUC.index(ext) > NUC.index(h[2]):
+                    out[-1] = [key, mk, ext, cs, sub]
+                else:
+                    h[4] = sub
+            else:
+                err = min_err and cs <= min_err and ch >= 2 * cs
+                h[4] = free(ch) if err else sub
+    ostarts.append(len(out))
+    return [tuple(r) for r in out], ostarts
+
+
+def reflect(recs):
+    return [(key[1:] + ext, 2, key[0], left, right) for key, mk, ext, left, right in recs]
+
+
+def fork_reflected(recs, starts, sub, min_err, ds):
+    ds_ec = ds and bool(min_err)
+    out, ostarts = [], []
+    for p in range(len(starts) - 1):
+        ostarts.append(len(out))
+        first = len(out)
+        last_cov = 0
+        for key, mk, ext, left, right in recs[starts[p]:starts[p + 1]]:
+            cs = left
+            if len(out) == first or out[-1][0] != key:
+                last_cov = cs
+                out.append([key, mk, ext, (-1 - cs) if ds_ec else -1, right])
+                continue
+            h = out[-1]
+            if cs > last_cov:
+                err = min_err and last_cov <= min_err and cs >= 2 * last_cov
+                last_cov = cs
+                out[-1] = [key, mk, ext, ((-1 - cs) if ds_ec else -1) if err else sub, right]
+            elif cs == last_cov:
+                # a tie always goes to the later record (4|base vs 1): ReflexivMain.java:2648-2653
+                out[-1] = [key, mk, ext, sub, right]
+            else:
+                err = min_err and cs <= min_err and last_cov >= 2 * cs
+                if err:
+                    if not ds_ec:
+                        h[3] = -1
+                else:
+                    h[3] = sub
+    ostarts.append(len(out))
+    return [tuple(r) for r in out], ostarts
+
+
+def seq_of(r):
+    return r[0] + r[2] if r[1] == 1 else r[2] + r[0]
+
+
+def oriented(seq, m, sub, left, right):
+    if m == 1:
+        return (seq[:sub], 1, seq[sub:], left, right)
+    return (seq[-sub:], 2, seq[:-sub], left, right)
+
+
+def random_reflection(recs, starts, sub):
+    out = []
+    for p in range(len(starts) - 1):
+        m = 2
+        for r in recs[starts[p]:starts[p + 1]]:
+            out.append(oriented(seq_of(r), m, sub, r[3], r[4]))
+            m = 3 - m
+    return out
+
+
+def extend_pass(recs, starts, sub, rdd=False):
+    out, ostarts = [], []
+    for p in range(len(starts) - 1):
+        ostarts.append(len(out))
+        m = 2
+        holder = None
+
+        def flip(r):
+            nonlocal m
+            out.append(oriented(seq_of(r), m, sub, r[3], r[4]))
+            m = 3 - m
+        for s in recs[starts[p]:starts[p + 1]]:
+            if holder is None:
+                holder = s
+                continue
+            if s[0] != holder[0]:
+                flip(holder)
+                holder = s
+                continue
+            if s[1] == holder[1]:
+                flip(s)
+                continue
+            F, R = (s, holder) if s[1] == 1 else (holder, s)
+            a, b = F[3], R[4]
+            lf, lr = len(F[2]), len(R[2])
+            if (a < 0 and b < 0) or (a >= 0 and b >= 0):
+                d = -1
+            elif s is F:
+                d = a - lr if (a >= 0 and a - lr >= 0) else (b - lf if (b >= 0 and b - lf >= 0) else BLOCK)
+            else:
+                if b >= 0 and b - lf >= 0:
+                    d = b - lf
+                elif rdd:
+                    d = F[4] - lr if (a >= 0 and F[4] - lr >= 0) else BLOCK
+                else:
+                    d = a - lr if (a >= 0 and a - lr >= 0) else BLOCK
+            if d is BLOCK:
+                flip(s)
+                continue
+            seq = R[2] + R[0] + F[2]
+            if d < 0:
+                L, Rt = R[3], F[4]
+            elif F[3] > 0:
+                L, Rt = d, F[4]
+            else:
+                L, Rt = R[3], d
+            out.append(oriented(seq, m, sub, L, Rt))
+            m = 3 - m
+            holder = None
+        if holder is not None:
+            flip(holder)
+    ostarts.append(len(out))
+    return out, ostarts
+
+
+def assemble(kmers, counts, k=31, P=4, min_err=8, min_iter=15, max_iter=150, ds=True, trace=None):
+    sub = k - 1
+    recs = stable_sort(rc_expand(kmers, counts, k))
+    recs, _ = fork_forward(recs, partition_starts([r[0] for r in recs], P), sub, min_err, ds)
+    recs = stable_sort(reflect(recs))
+    recs, st = fork_reflected(recs, partition_starts([r[0] for r in recs], P), sub, min_err, ds)
+    recs = random_reflection(recs, st, sub)
+
+    def one_pass(recs):
+        recs = stable_sort(recs)
+        out, _ = extend_pass(recs, partition_starts([r[0] for r in recs], P), sub, rdd=not ds)
+        if trace is not None:
+            trace.append(len(out))
+        return out
+    it = 0
+    recs = one_pass(recs)
+    for _ in range(3):
+        it += 1
+        recs = one_pass(recs)
+    it += 1
+    recs = one_pass(recs)
+    last = 0
+    while it <= max_iter:
+        it += 1
+        if it >= min_iter and it % 3 == 0:
+            if last == len(recs):
+                break
+            last = len(recs)
+        recs = one_pass(recs)
+    return recs

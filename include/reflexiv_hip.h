@@ -1,0 +1,229 @@
+/*
+ * reflexiv_hip.h -- C ABI of libreflexiv_hip.so, the MI355X (gfx950) implementation of
+ * Reflexiv's k-mer counting + reflexible extend-and-merge hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI seam of its own:
+ * the path sits behind Spark's Java functional interfaces, one inner class per operator,
+ * called once per partition.  Every "operator" entry point below replaces the body of one
+ * of those classes (cited as P/<file>:<lines>, P = src/main/java/uni/bielefeld/cmg/
+ * reflexiv/pipeline) and takes / returns the same records as flat arrays; INTEGRATION.md
+ * shows the JNI stub that binds each of them.  Conventions:
+ *
+ *  - plain pointers and sizes only; the caller owns every buffer (Java: direct
+ *    ByteBuffers or arrays pinned with GetPrimitiveArrayCritical);
+ *  - host entry points (rfx_*) take HOST pointers, stage through HBM and run the HIP
+ *    kernels; device entry points (rfx_dev_*) take DEVICE pointers and run on the
+ *    context's stream, for callers that keep the data resident (the Python/torch
+ *    harness, the C++ driver, the multi-GPU path);
+ *  - return value: RFX_OK or a negative rfx_status; never aborts, never falls back to a
+ *    CPU path.  RFX_E_CAP means an output buffer was too small: *out_n (and *out_words)
+ *    hold the needed size, nothing else was written;
+ *  - re-entrant per context; one context = one device + one HIP stream.
+ *
+ * Record layout = the reference's: key is the (k-1)-mer, 2 bits per
+ * base, first base in the highest used pair; marker 1 = forward (sequence = key||ext),
+ * 2 = reflected (ext||key); ext words [ext_off[i], ext_off[i+1]): word 0 holds the first
+ * f (1..31) bases under a 1-bit sentinel at bit 2f, every further word exactly 31 bases;
+ * left/right are the bubble-distance markers (< 0: free end).
+ */
+#ifndef REFLEXIV_HIP_H
+#define REFLEXIV_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    RFX_OK        =  0,
+    RFX_E_ARG     = -1,   /* bad argument (k out of range, null pointer, ...)              */
+    RFX_E_CAP     = -2,   /* output capacity too small; needed size reported              */
+    RFX_E_HIP     = -3,   /* a HIP runtime call failed; see rfx_last_error()               */
+    RFX_E_NOGPU   = -4,   /* no usable gfx950 device                                       */
+    RFX_E_STATE   = -5,   /* "impossible" record state (the reference prints and goes on)  */
+    RFX_E_LIMIT   = -6    /* size beyond this build's limits (e.g. > 2^32-1 records)       */
+} rfx_status;
+
+#define RFX_TWIN_DS  0    /* arithmetic of P/ReflexivDSMain.java (the wired, fixed twin)   */
+#define RFX_TWIN_RDD 1    /* arithmetic of P/ReflexivMain.java (the RDD-surface twin)      */
+
+typedef struct rfx_ctx rfx_ctx;
+
+/* U/DefaultParam.java:74-120 -- the fields that reach the hot path. */
+typedef struct {
+    int32_t k;               /* kmerSize (<= 31 in this build)                 :74  */
+    int32_t min_cov;         /* minKmerCoverage                                :103 */
+    int32_t max_cov;         /* maxKmerCoverage                                :104 */
+    int32_t min_error_cov;   /* minErrorCoverage (4 * 2)                       :105 */
+    int32_t min_contig;      /* minContig                                      :107 */
+    int32_t min_iter;        /* minimumIteration                               :115 */
+    int32_t max_iter;        /* maximumIteration                               :114 */
+    int32_t front_clip;      /* frontClip                                      :119 */
+    int32_t end_clip;        /* endClip                                        :120 */
+    int32_t partitions;      /* logical partitions P of the order contract */
+    int32_t twin;            /* RFX_TWIN_DS / RFX_TWIN_RDD                      */
+    int32_t coalesce;        /* apply P/ReflexivMain.java:277-281               */
+} rfx_params;
+
+/* Flat record set.  n and the pointers are filled by the caller on input; on output the
+ * callee sets n (and ext_off[n] words of ext).  cap_n / cap_words are the capacities of
+ * the caller's output buffers (ext_off needs cap_n + 1 entries); on RFX_E_CAP nothing is
+ * written except need_n / need_words. */
+typedef struct {
+    int64_t   n;
+    uint64_t *key;
+    int32_t  *marker;
+    int64_t  *ext_off;
+    uint64_t *ext;
+    int32_t  *left;
+    int32_t  *right;
+    int64_t   cap_n;
+    int64_t   cap_words;
+    int64_t   need_n;      /* set by the callee: records / words the output needs */
+    int64_t   need_words;
+} rfx_records;
+
+/* ------------------------------------------------------------------ context */
+
+int  rfx_version(void);
+void rfx_default_params(rfx_params *p);                 /* U/DefaultParam.java defaults   */
+/* device < 0: current device.  Fails with RFX_E_NOGPU when there is no gfx950 GPU.       */
+int  rfx_ctx_create(int device, rfx_ctx **out);
+void rfx_ctx_destroy(rfx_ctx *ctx);
+int  rfx_ctx_sync(rfx_ctx *ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. */
+int  rfx_ctx_set_stream(rfx_ctx *ctx, void *hip_stream);
+void *rfx_ctx_stream(rfx_ctx *ctx);
+const char *rfx_last_error(rfx_ctx *ctx);               /* text of the last RFX_E_HIP      */
+
+/* ------------------------------------------------- operators, host buffers */
+
+/* ReverseComplementKmerBinaryExtraction.call  P/ReflexivMain.java:3013-3075
+ * (DS: P/ReflexivDSMain.java:3961-4024, P/ReflexivDataFrameCounter.java:459-526).
+ * ASCII reads, read i = bases[read_off[i] .. read_off[i+1]); emits the canonical k-mers
+ * in read order, window order. */
+int rfx_extract_canon(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_off,
+                      int64_t n_reads, int k, int front_clip, int end_clip,
+                      uint64_t *out_kmers, int64_t cap, int64_t *out_n);
+
+/* reduceByKey(KmerCounting) + filter(KmerCoverageFilter)
+ * P/ReflexivMain.java:155,160-163,2895-2899,3115-3119 (DS :207-216).
+ * Output ascending by k-mer (the order contract's count-stage order). */
+int rfx_count_filter(rfx_ctx *ctx, const uint64_t *kmers, int64_t n,
+                     int min_cov, int max_cov, int twin,
+                     uint64_t *out_keys, int32_t *out_counts, int64_t cap,
+                     int64_t *out_n, int64_t *out_distinct);
+
+/* KmerReverseComplement.call + ForwardSubKmerExtraction.call
+ * P/ReflexivMain.java:2910-2930, 2709-2730 (DS :3849-3868, :3625-3644).
+ * n (kmer,count) -> 2n single-word records; ext carries no sentinel yet. */
+int rfx_rc_expand_subkmer(rfx_ctx *ctx, const uint64_t *kmers, const int32_t *counts,
+                          int64_t n, int k, rfx_records *out);
+
+/* sortByKey() / sort("k-1")  P/ReflexivMain.java:179,191,211,235,247,286: global stable
+ * sort by key; also returns the logical partition starts part_start[P+1]. */
+int rfx_sort_records(rfx_ctx *ctx, const rfx_records *in, int P,
+                     rfx_records *out, int64_t *part_start);
+
+/* FilterForkSubKmer[WithErrorCorrection].call  P/ReflexivMain.java:2412-2540
+ * (DS :3375-3483).  Input sorted by key with its partition starts. */
+int rfx_fork_filter_forward(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start,
+                            int P, int k, int min_error_cov, int twin,
+                            rfx_records *out, int64_t *out_part_start);
+
+/* ReflectedSubKmerExtractionFromForward.call  P/ReflexivMain.java:2742-2768 (DS :3661-3685) */
+int rfx_reflect_from_forward(rfx_ctx *ctx, const rfx_records *in, int k, rfx_records *out);
+
+/* FilterForkReflectedSubKmer[WithErrorCorrection].call  P/ReflexivMain.java:2550-2696
+ * (DS :3493-3616) */
+int rfx_fork_filter_reflected(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start,
+                              int P, int k, int min_error_cov, int twin,
+                              rfx_records *out, int64_t *out_part_start);
+
+/* kmerRandomReflection.call  P/ReflexivMain.java:2783-2885 (DS :3697-3805) */
+int rfx_random_reflection(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start,
+                          int P, int k, rfx_records *out);
+
+/* ExtendReflexivKmer / ExtendReflexivKmerToArrayFirstTime / ExtendReflexivKmerToArrayLoop
+ * .call  P/ReflexivMain.java:2048-2362, 1594-1974, 792-1519 (DS :3040-3329, :2589-2971,
+ * :1776-2518).  One extend pass over records sorted by key.  stage: 0 single word,
+ * 1 first array pass, 2 array loop -- the three classes share one algorithm and one
+ * word layout; stage 0 additionally checks that every output fits one word. */
+int rfx_extend_pass(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P,
+                    int k, int twin, int stage, rfx_records *out, int64_t *out_part_start);
+
+/* BinaryReflexivKmerArrayToString + KmerToContig + TagContigID
+ * P/ReflexivMain.java:696-741, 590-637, 573-581 (DS :855-900, :743-795, :717-725):
+ * the text saveAsTextFile writes (host-side formatting). */
+int rfx_contigs_text(rfx_ctx *ctx, const rfx_records *in, int k, int min_contig, int twin,
+                     char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs);
+
+/* ------------------------------------------- resident pipeline, device buffers */
+
+/* 2-bit read store: read i occupies words [i*words_per_read, (i+1)*words_per_read), base j
+ * in word j/32 at bits 63-2*(j%32)..62-2*(j%32) (code A0 C1 G2, anything else 3:
+ * P/ReflexivMain.java:3062-3074), read_len[i] bases.  All pointers are device pointers. */
+int rfx_dev_encode_reads(rfx_ctx *ctx, const uint8_t *d_bases, const int64_t *d_read_off,
+                         int64_t n_reads, int words_per_read,
+                         uint64_t *d_words, uint32_t *d_read_len);
+
+/* Number of k-mer instances the extraction emits for uniform reads (host arithmetic). */
+int64_t rfx_kmers_per_read(int read_len, int k, int front_clip, int end_clip);
+
+/* Workspace bytes rfx_dev_count_reads needs for n_kmers instances. */
+int64_t rfx_count_workspace_bytes(int64_t n_kmers);
+
+/* extract + reduceByKey + filter fused, reads of one uniform length already packed in HBM.
+ * d_out_keys/d_out_counts (cap entries) receive the survivors ascending by k-mer.
+ * d_workspace: rfx_count_workspace_bytes(n_reads * kmers_per_read) bytes.
+ * shard_lo/shard_hi select the radix shard [lo, hi) of 2^16 of the k-mer hash space that
+ * this call counts (0, 65536 = everything); used by the multi-GPU path. */
+int rfx_dev_count_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads,
+                        int words_per_read, int read_len, int k, int front_clip, int end_clip,
+                        int min_cov, int max_cov, int twin,
+                        void *d_workspace, int64_t workspace_bytes,
+                        uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap,
+                        int64_t *out_n, int64_t *out_distinct, int64_t *out_instances);
+
+/* Same, from an explicit k-mer array (the reduceByKey input) in HBM. */
+int rfx_dev_count_kmers(rfx_ctx *ctx, const uint64_t *d_kmers, int64_t n,
+                        int min_cov, int max_cov, int twin,
+                        void *d_workspace, int64_t workspace_bytes,
+                        uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap,
+                        int64_t *out_n, int64_t *out_distinct);
+
+/* Multi-GPU exchange support: bucket the canonical k-mers of packed reads by owner
+ * (owner = hash(kmer) * n_owners >> 64, the radix shard of the k-mer space), writing each
+ * owner's k-mers contiguously into d_out with d_owner_off[n_owners+1] element offsets. */
+int rfx_dev_bucket_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads,
+                            int words_per_read, int read_len, int k, int front_clip,
+                            int end_clip, int n_owners, uint64_t *d_out, int64_t cap,
+                            int64_t *d_owner_off, int64_t *h_owner_off);
+
+/* Whole driver  P/ReflexivMain.java:168-310 (DS :221-352) from the filtered, ascending
+ * (kmer,count) list in HBM to the contig text in host memory.  trace (optional) receives
+ * the record count after every extend pass. */
+int rfx_dev_assemble(rfx_ctx *ctx, const uint64_t *d_keys, const int32_t *d_counts, int64_t n,
+                     const rfx_params *prm, char *out, int64_t cap, int64_t *out_len,
+                     int64_t *out_contigs, int64_t *trace, int64_t trace_cap, int64_t *n_trace);
+
+/* Synthetic reads: integer-only counter-based generator, bit-identical to
+ * oracle/reflexiv_oracle.c orc_synth_*.  Writes packed reads straight into HBM. */
+int rfx_dev_synth_genome(rfx_ctx *ctx, uint64_t seed, int64_t genome_len, uint64_t *d_genome);
+int rfx_dev_synth_reads(rfx_ctx *ctx, uint64_t seed, const uint64_t *d_genome, int64_t genome_len,
+                        int64_t first_read, int64_t n_reads, int read_len, uint32_t err_per_2_32,
+                        int words_per_read, uint64_t *d_words);
+
+/* Plain stable radix sort of (key, value) pairs in HBM -- exposed for tests and for the
+ * driver; d_tmp_* are same-sized scratch arrays. key_bits = significant low bits. */
+int rfx_dev_sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n,
+                       int key_bits, uint64_t *d_tmp_keys, uint32_t *d_tmp_vals);
+
+/* Timing of the last rfx_dev_count_* call, per kernel family, from HIP events recorded on
+ * the context's stream (ms).  names: "hist1","part1","hist2","part2","leaf","sort". */
+int rfx_last_count_timing(rfx_ctx *ctx, const char *name, float *ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,86 @@
+"""ctypes binding of libreflexiv_hip.so (include/reflexiv_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no gfx950 GPU is
+present when a context is created, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libreflexiv_hip.so")
+_LIB = None
+
+RFX_OK, RFX_E_ARG, RFX_E_CAP, RFX_E_HIP, RFX_E_NOGPU, RFX_E_STATE, RFX_E_LIMIT = 0, -1, -2, -3, -4, -5, -6
+TWIN_DS, TWIN_RDD = 0, 1
+_STATUS = {0: "RFX_OK", -1: "RFX_E_ARG", -2: "RFX_E_CAP", -3: "RFX_E_HIP", -4: "RFX_E_NOGPU",
+           -5: "RFX_E_STATE", -6: "RFX_E_LIMIT"}
+
+
+class RfxError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__(f"{where}: {_STATUS.get(status, status)}{(' -- ' + detail) if detail else ''}")
+
+
+class Params(C.Structure):
+    """rfx_params (U/DefaultParam.java:74-120)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "k", "min_cov", "max_cov", "min_error_cov", "min_contig", "min_iter", "max_iter",
+        "front_clip", "end_clip", "partitions", "twin", "coalesce")]
+
+
+class CRecords(C.Structure):
+    """rfx_records."""
+    _fields_ = [("n", C.c_int64), ("key", C.c_void_p), ("marker", C.c_void_p), ("ext_off", C.c_void_p),
+                ("ext", C.c_void_p), ("left", C.c_void_p), ("right", C.c_void_p),
+                ("cap_n", C.c_int64), ("cap_words", C.c_int64), ("need_n", C.c_int64), ("need_words", C.c_int64)]
+
+
+# every symbol include/reflexiv_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "rfx_version", "rfx_default_params", "rfx_ctx_create", "rfx_ctx_destroy", "rfx_ctx_sync",
+    "rfx_ctx_set_stream", "rfx_ctx_stream", "rfx_last_error",
+    "rfx_extract_canon", "rfx_count_filter", "rfx_rc_expand_subkmer", "rfx_sort_records",
+    "rfx_fork_filter_forward", "rfx_reflect_from_forward", "rfx_fork_filter_reflected",
+    "rfx_random_reflection", "rfx_extend_pass", "rfx_contigs_text",
+    "rfx_dev_encode_reads", "rfx_kmers_per_read", "rfx_count_workspace_bytes", "rfx_dev_count_reads",
+    "rfx_dev_count_kmers", "rfx_dev_bucket_by_owner", "rfx_dev_assemble", "rfx_dev_synth_genome",
+    "rfx_dev_synth_reads", "rfx_dev_sort_pairs", "rfx_last_count_timing",
+]
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src)
+                 if f.endswith((".hip", ".h")) or f == "Makefile")
+    newest = max(newest, os.path.getmtime(os.path.join(_HERE, "..", "include", "reflexiv_hip.h")))
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
+        subprocess.check_call(["make", "-s", "-j4", "-C", src])
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RfxError(RFX_E_NOGPU, "reflexiv_amd",
+                           f"{LIB_PATH} is missing -- build it with reflexiv_amd._lib.build() "
+                           "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.rfx_version.restype = C.c_int
+        L.rfx_ctx_stream.restype = C.c_void_p
+        L.rfx_last_error.restype = C.c_char_p
+        L.rfx_kmers_per_read.restype = C.c_int64
+        L.rfx_count_workspace_bytes.restype = C.c_int64
+        L.rfx_count_workspace_bytes.argtypes = [C.c_int64]
+        for name in SYMBOLS:
+            fn = getattr(L, name)
+            if name not in ("rfx_ctx_stream", "rfx_last_error", "rfx_kmers_per_read",
+                            "rfx_count_workspace_bytes", "rfx_ctx_destroy", "rfx_default_params"):
+                fn.restype = C.c_int
+        _LIB = L
+    return _LIB

@@ -1,0 +1,304 @@
+"""Host-side mirror of the reference's operator surface for the hot path, over the C ABI.
+
+`Reflexiv` exposes one method per Spark operator class of P/ReflexivMain.java (names kept),
+taking and returning flat numpy arrays in the reference's record layout, plus the resident
+device pipeline (`count_reads_dev`, `assemble_dev`) that keeps everything in HBM.  Every
+method runs the HIP kernels; nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import Params, CRecords, RfxError, TWIN_DS, TWIN_RDD, RFX_OK, RFX_E_CAP  # noqa: F401
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+@dataclass
+class Records:
+    """Flat SoA record set (include/reflexiv_hip.h rfx_records)."""
+    key: np.ndarray
+    marker: np.ndarray
+    ext_off: np.ndarray
+    ext: np.ndarray
+    left: np.ndarray
+    right: np.ndarray
+
+    @property
+    def n(self) -> int:
+        return int(self.key.shape[0])
+
+    def tuple_list(self):
+        return [(int(self.key[i]), int(self.marker[i]),
+                 tuple(int(x) for x in self.ext[self.ext_off[i]:self.ext_off[i + 1]]),
+                 int(self.left[i]), int(self.right[i])) for i in range(self.n)]
+
+    def _c(self) -> CRecords:
+        c = CRecords()
+        c.n = self.n
+        c.key, c.marker, c.ext_off = _p(self.key), _p(self.marker), _p(self.ext_off)
+        c.ext, c.left, c.right = _p(self.ext), _p(self.left), _p(self.right)
+        c.cap_n, c.cap_words = self.n, len(self.ext)
+        return c
+
+    @staticmethod
+    def empty(cap_n: int, cap_words: int) -> "Records":
+        cap_n, cap_words = max(1, cap_n), max(1, cap_words)
+        return Records(np.empty(cap_n, np.uint64), np.empty(cap_n, np.int32), np.empty(cap_n + 1, np.int64),
+                       np.empty(cap_words, np.uint64), np.empty(cap_n, np.int32), np.empty(cap_n, np.int32))
+
+    def _trim(self, c: CRecords) -> "Records":
+        n = int(c.n)
+        w = int(self.ext_off[n]) if n else 0
+        return Records(self.key[:n].copy(), self.marker[:n].copy(), self.ext_off[:n + 1].copy(),
+                       self.ext[:w].copy(), self.left[:n].copy(), self.right[:n].copy())
+
+
+def as_records(r) -> Records:
+    """Accept any object with key/marker/ext_off/ext/left/right arrays (e.g. the oracle's Records)."""
+    return Records(np.ascontiguousarray(r.key, np.uint64), np.ascontiguousarray(r.marker, np.int32),
+                   np.ascontiguousarray(r.ext_off, np.int64), np.ascontiguousarray(r.ext, np.uint64),
+                   np.ascontiguousarray(r.left, np.int32), np.ascontiguousarray(r.right, np.int32))
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    _lib.lib().rfx_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class Reflexiv:
+    """One context = one MI355X + one HIP stream."""
+
+    def __init__(self, device: int = -1):
+        self.L = _lib.lib()
+        ctx = C.c_void_p()
+        st = self.L.rfx_ctx_create(device, C.byref(ctx))
+        if st != RFX_OK:
+            raise RfxError(st, "rfx_ctx_create", "a gfx950 (MI355X) GPU is required; there is no CPU fallback")
+        self.ctx = ctx
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.rfx_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st, where):
+        if st != RFX_OK:
+            raise RfxError(st, where, (self.L.rfx_last_error(self.ctx) or b"").decode())
+
+    def use_stream(self, hip_stream: int):
+        self._check(self.L.rfx_ctx_set_stream(self.ctx, C.c_void_p(hip_stream)), "rfx_ctx_set_stream")
+
+    def sync(self):
+        self._check(self.L.rfx_ctx_sync(self.ctx), "rfx_ctx_sync")
+
+    # ------------------------------------------------ operators on host arrays
+
+    def ReverseComplementKmerBinaryExtraction(self, bases, read_off, k=31, front_clip=0, end_clip=0):
+        """P/ReflexivMain.java:3013-3075 -> canonical k-mers in read/window order."""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        read_off = np.ascontiguousarray(read_off, np.int64)
+        nr = len(read_off) - 1
+        n = C.c_int64(0)
+        st = self.L.rfx_extract_canon(self.ctx, _p(bases), _p(read_off), C.c_int64(nr), k, front_clip, end_clip,
+                                      None, C.c_int64(0), C.byref(n))
+        if st not in (RFX_OK, RFX_E_CAP):
+            self._check(st, "rfx_extract_canon")
+        out = np.empty(max(1, n.value), np.uint64)
+        self._check(self.L.rfx_extract_canon(self.ctx, _p(bases), _p(read_off), C.c_int64(nr), k, front_clip,
+                                             end_clip, _p(out), C.c_int64(n.value), C.byref(n)),
+                    "rfx_extract_canon")
+        return out[:n.value]
+
+    def KmerCounting_and_CoverageFilter(self, kmers, min_cov=2, max_cov=10_000_000, twin=TWIN_DS):
+        """reduceByKey(KmerCounting) + filter(KmerCoverageFilter), P/ReflexivMain.java:155-163."""
+        kmers = np.ascontiguousarray(kmers, np.uint64)
+        n = len(kmers)
+        keys = np.empty(max(1, n), np.uint64)
+        counts = np.empty(max(1, n), np.int32)
+        m, d = C.c_int64(0), C.c_int64(0)
+        self._check(self.L.rfx_count_filter(self.ctx, _p(kmers), C.c_int64(n), min_cov, max_cov, twin, _p(keys),
+                                            _p(counts), C.c_int64(n), C.byref(m), C.byref(d)), "rfx_count_filter")
+        return keys[:m.value].copy(), counts[:m.value].copy(), int(d.value)
+
+    def KmerReverseComplement_and_ForwardSubKmerExtraction(self, keys, counts, k=31) -> Records:
+        keys = np.ascontiguousarray(keys, np.uint64)
+        counts = np.ascontiguousarray(counts, np.int32)
+        n = len(keys)
+        out = Records.empty(2 * n, 2 * n)
+        c = out._c(); c.cap_n = 2 * n; c.cap_words = 2 * n
+        self._check(self.L.rfx_rc_expand_subkmer(self.ctx, _p(keys), _p(counts), C.c_int64(n), k, C.byref(c)),
+                    "rfx_rc_expand_subkmer")
+        return out._trim(c)
+
+    def sortByKey(self, r, P: int):
+        """-> (sorted Records, part_start[P+1])."""
+        r = as_records(r)
+        out = Records.empty(r.n, len(r.ext))
+        ci, co = r._c(), out._c()
+        co.cap_n, co.cap_words = r.n, len(r.ext)
+        ps = np.empty(P + 1, np.int64)
+        self._check(self.L.rfx_sort_records(self.ctx, C.byref(ci), P, C.byref(co), _p(ps)), "rfx_sort_records")
+        return out._trim(co), ps
+
+    def _fork(self, fn, name, r, part_start, k, min_error_cov, twin):
+        r = as_records(r)
+        part_start = np.ascontiguousarray(part_start, np.int64)
+        P = len(part_start) - 1
+        out = Records.empty(r.n, r.n)
+        ci, co = r._c(), out._c()
+        co.cap_n, co.cap_words = r.n, r.n
+        ops = np.empty(P + 1, np.int64)
+        self._check(fn(self.ctx, C.byref(ci), _p(part_start), P, k, min_error_cov, twin, C.byref(co), _p(ops)), name)
+        return out._trim(co), ops
+
+    def FilterForkSubKmer(self, r, part_start, k=31, min_error_cov=8, twin=TWIN_DS):
+        return self._fork(self.L.rfx_fork_filter_forward, "rfx_fork_filter_forward", r, part_start, k,
+                          min_error_cov, twin)
+
+    def FilterForkReflectedSubKmer(self, r, part_start, k=31, min_error_cov=8, twin=TWIN_DS):
+        return self._fork(self.L.rfx_fork_filter_reflected, "rfx_fork_filter_reflected", r, part_start, k,
+                          min_error_cov, twin)
+
+    def ReflectedSubKmerExtractionFromForward(self, r, k=31) -> Records:
+        r = as_records(r)
+        out = Records.empty(r.n, r.n)
+        ci, co = r._c(), out._c()
+        co.cap_n, co.cap_words = r.n, r.n
+        self._check(self.L.rfx_reflect_from_forward(self.ctx, C.byref(ci), k, C.byref(co)),
+                    "rfx_reflect_from_forward")
+        return out._trim(co)
+
+    def kmerRandomReflection(self, r, part_start, k=31) -> Records:
+        r = as_records(r)
+        part_start = np.ascontiguousarray(part_start, np.int64)
+        out = Records.empty(r.n, r.n)
+        ci, co = r._c(), out._c()
+        co.cap_n, co.cap_words = r.n, r.n
+        self._check(self.L.rfx_random_reflection(self.ctx, C.byref(ci), _p(part_start), len(part_start) - 1, k,
+                                                 C.byref(co)), "rfx_random_reflection")
+        return out._trim(co)
+
+    def ExtendReflexivKmer(self, r, part_start, k=31, twin=TWIN_DS, stage=2):
+        """One extend pass (stage 0: ExtendReflexivKmer, 1: ...ToArrayFirstTime, 2: ...ToArrayLoop)."""
+        r = as_records(r)
+        part_start = np.ascontiguousarray(part_start, np.int64)
+        P = len(part_start) - 1
+        out = Records.empty(r.n, len(r.ext))
+        ci, co = r._c(), out._c()
+        co.cap_n, co.cap_words = r.n, len(r.ext)
+        ops = np.empty(P + 1, np.int64)
+        self._check(self.L.rfx_extend_pass(self.ctx, C.byref(ci), _p(part_start), P, k, twin, stage, C.byref(co),
+                                           _p(ops)), "rfx_extend_pass")
+        return out._trim(co), ops
+
+    def KmerToContig(self, r, k=31, min_contig=500, twin=TWIN_DS):
+        r = as_records(r)
+        ci = r._c()
+        ln, nc = C.c_int64(0), C.c_int64(0)
+        st = self.L.rfx_contigs_text(self.ctx, C.byref(ci), k, min_contig, twin, None, C.c_int64(0), C.byref(ln),
+                                     C.byref(nc))
+        if st not in (RFX_OK, RFX_E_CAP):
+            self._check(st, "rfx_contigs_text")
+        buf = np.empty(max(1, ln.value), np.uint8)
+        self._check(self.L.rfx_contigs_text(self.ctx, C.byref(ci), k, min_contig, twin, _p(buf),
+                                            C.c_int64(ln.value), C.byref(ln), C.byref(nc)), "rfx_contigs_text")
+        return bytes(buf[:ln.value]).decode(), int(nc.value)
+
+    # ------------------------------------------------ resident device pipeline
+
+    def encode_reads_dev(self, d_bases: int, d_read_off: int, n_reads: int, words_per_read: int, d_words: int,
+                         d_read_len: int = 0):
+        self._check(self.L.rfx_dev_encode_reads(self.ctx, C.c_void_p(d_bases), C.c_void_p(d_read_off),
+                                                C.c_int64(n_reads), words_per_read, C.c_void_p(d_words),
+                                                C.c_void_p(d_read_len) if d_read_len else None),
+                    "rfx_dev_encode_reads")
+
+    def kmers_per_read(self, read_len, k, front_clip=0, end_clip=0) -> int:
+        return int(self.L.rfx_kmers_per_read(read_len, k, front_clip, end_clip))
+
+    def count_reads_dev(self, d_words: int, n_reads: int, words_per_read: int, read_len: int, k: int,
+                        d_out_keys: int, d_out_counts: int, cap: int, min_cov=2, max_cov=10_000_000,
+                        twin=TWIN_DS, front_clip=0, end_clip=0):
+        """extract + reduceByKey + filter from packed reads in HBM -> (n_survivors, n_distinct, n_instances)."""
+        n, d, inst = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        st = self.L.rfx_dev_count_reads(self.ctx, C.c_void_p(d_words), C.c_int64(n_reads), words_per_read, read_len,
+                                        k, front_clip, end_clip, min_cov, max_cov, twin, None, C.c_int64(0),
+                                        C.c_void_p(d_out_keys), C.c_void_p(d_out_counts), C.c_int64(cap),
+                                        C.byref(n), C.byref(d), C.byref(inst))
+        if st == RFX_E_CAP:
+            raise RfxError(st, "rfx_dev_count_reads", f"needs room for {n.value} survivors, cap is {cap}")
+        self._check(st, "rfx_dev_count_reads")
+        return int(n.value), int(d.value), int(inst.value)
+
+    def count_kmers_dev(self, d_kmers: int, n: int, d_out_keys: int, d_out_counts: int, cap: int, min_cov=2,
+                        max_cov=10_000_000, twin=TWIN_DS):
+        m, d = C.c_int64(0), C.c_int64(0)
+        st = self.L.rfx_dev_count_kmers(self.ctx, C.c_void_p(d_kmers), C.c_int64(n), min_cov, max_cov, twin, None,
+                                        C.c_int64(0), C.c_void_p(d_out_keys), C.c_void_p(d_out_counts),
+                                        C.c_int64(cap), C.byref(m), C.byref(d))
+        if st == RFX_E_CAP:
+            raise RfxError(st, "rfx_dev_count_kmers", f"needs room for {m.value} survivors, cap is {cap}")
+        self._check(st, "rfx_dev_count_kmers")
+        return int(m.value), int(d.value)
+
+    def bucket_by_owner_dev(self, d_words: int, n_reads: int, words_per_read: int, read_len: int, k: int,
+                            n_owners: int, d_out: int, cap: int, d_owner_off: int, front_clip=0, end_clip=0):
+        h = np.empty(n_owners + 1, np.int64)
+        self._check(self.L.rfx_dev_bucket_by_owner(self.ctx, C.c_void_p(d_words), C.c_int64(n_reads), words_per_read,
+                                                   read_len, k, front_clip, end_clip, n_owners, C.c_void_p(d_out),
+                                                   C.c_int64(cap), C.c_void_p(d_owner_off), _p(h)),
+                    "rfx_dev_bucket_by_owner")
+        return h
+
+    def assemble_dev(self, d_keys: int, d_counts: int, n: int, prm: Params):
+        """Driver P/ReflexivMain.java:168-310 from the filtered (kmer,count) list in HBM
+        -> (contig text, n_contigs, trace)."""
+        trace = np.zeros(prm.max_iter + 8, np.int64)
+        ln, nc, ntr = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        cap = 4 * (n + 16) * (prm.k + 8) + 1024
+        buf = np.empty(cap, np.uint8)
+        self._check(self.L.rfx_dev_assemble(self.ctx, C.c_void_p(d_keys), C.c_void_p(d_counts), C.c_int64(n),
+                                            C.byref(prm), _p(buf), C.c_int64(cap), C.byref(ln), C.byref(nc),
+                                            _p(trace), C.c_int64(len(trace)), C.byref(ntr)), "rfx_dev_assemble")
+        return bytes(buf[:ln.value]).decode(), int(nc.value), [int(x) for x in trace[:ntr.value]]
+
+    def synth_genome_dev(self, seed: int, genome_len: int, d_genome: int):
+        self._check(self.L.rfx_dev_synth_genome(self.ctx, C.c_uint64(seed), C.c_int64(genome_len),
+                                                C.c_void_p(d_genome)), "rfx_dev_synth_genome")
+
+    def synth_reads_dev(self, seed: int, d_genome: int, genome_len: int, first_read: int, n_reads: int,
+                        read_len: int, words_per_read: int, d_words: int, err_per_2_32: int = 21474836):
+        self._check(self.L.rfx_dev_synth_reads(self.ctx, C.c_uint64(seed), C.c_void_p(d_genome),
+                                               C.c_int64(genome_len), C.c_int64(first_read), C.c_int64(n_reads),
+                                               read_len, C.c_uint32(err_per_2_32), words_per_read,
+                                               C.c_void_p(d_words)), "rfx_dev_synth_reads")
+
+    def sort_pairs_dev(self, d_keys: int, d_vals: int, n: int, key_bits: int, d_tmp_keys: int, d_tmp_vals: int):
+        self._check(self.L.rfx_dev_sort_pairs(self.ctx, C.c_void_p(d_keys), C.c_void_p(d_vals), C.c_int64(n),
+                                              key_bits, C.c_void_p(d_tmp_keys), C.c_void_p(d_tmp_vals)),
+                    "rfx_dev_sort_pairs")
+
+    def count_timing(self):
+        """Per-kernel-family HIP-event timing of the last count call: {name: (ms, launches)}."""
+        out = {}
+        for name in ("hist1", "part1", "hist2", "part2", "hist3", "part3", "leaf", "sort"):
+            ms, ln = C.c_float(0), C.c_int64(0)
+            if self.L.rfx_last_count_timing(self.ctx, name.encode(), C.byref(ms), C.byref(ln)) == RFX_OK:
+                out[name] = (float(ms.value), int(ln.value))
+        return out

@@ -1,0 +1,461 @@
+// rfx_api.hip -- the extern "C" boundary of libreflexiv_hip.so (include/reflexiv_hip.h) and
+// the driver loop that mirrors ReflexivMain.assembly() (P/ReflexivMain.java:168-310).
+#include "rfx_internal.h"
+#include <algorithm>
+#include <cstdlib>
+
+using namespace rfx;
+
+namespace {
+
+int check_k(int k) { return (k >= 3 && k <= 31) ? RFX_OK : RFX_E_ARG; }
+
+int download_to(rfx_ctx *ctx, const DevRecords &d, rfx_records *out) {
+    if (!out) return RFX_E_ARG;
+    out->need_n = d.n; out->need_words = d.words;
+    if (d.n > out->cap_n || d.words > out->cap_words) return RFX_E_CAP;
+    return dev_records_download(ctx, d, out);
+}
+
+int upload_part_start(rfx_ctx *ctx, const int64_t *h, int P, DevBuf &d) {
+    RFX_HIP(d.alloc((size_t)(P + 1) * 8, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(d.p, h, (size_t)(P + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    return RFX_OK;
+}
+int download_part_start(rfx_ctx *ctx, const DevBuf &d, int P, int64_t *h) {
+    if (!h) return RFX_OK;
+    RFX_HIP(hipMemcpyAsync(h, d.p, (size_t)(P + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    return RFX_OK;
+}
+
+// a-15 on the host (tiny): BinaryReflexivKmerArrayToString + KmerToContig + TagContigID
+int64_t contigs_text_host(const rfx_records *r, int k, int min_contig, int twin, char *out, int64_t cap,
+                          int64_t *n_contigs) {
+    static const char NUC[4] = {'A', 'C', 'G', 'T'};
+    const int sub = k - 1;
+    int64_t pos = 0, idx = 0;
+    std::vector<uint8_t> b;
+    auto putc_ = [&](char c) { if (pos < cap) out[pos] = c; pos++; };
+    for (int64_t i = 0; i < r->n; i++) {
+        // DS drops records whose markers are both <= -10,000,000  P/ReflexivDSMain.java:749
+        if (twin == RFX_TWIN_DS && r->left[i] <= -10000000 && r->right[i] <= -10000000) continue;
+        const uint64_t *w = r->ext + r->ext_off[i];
+        const int64_t nw = r->ext_off[i + 1] - r->ext_off[i];
+        const int nlz = w[0] ? __builtin_clzll(w[0]) : 64;
+        const int f = 32 - (nlz / 2 + 1);                                  // :702
+        const int64_t L = (nw - 1) * 31 + f;
+        const int64_t len = L + sub;
+        if (len < min_contig) continue;                                    // :596, :606
+        b.resize((size_t)len);
+        uint8_t *e = r->marker[i] == 1 ? b.data() + sub : b.data();        // :593-594 / :603-604
+        uint8_t *kb = r->marker[i] == 1 ? b.data() : b.data() + L;
+        for (int j = 0; j < sub; j++) kb[j] = (uint8_t)((r->key[i] >> (2 * (sub - 1 - j))) & 3);   // :704-709
+        int64_t o = 0;
+        for (int j = 0; j < f; j++) e[o++] = (uint8_t)((w[0] >> (2 * (f - 1 - j))) & 3);           // :713-718
+        for (int64_t x = 1; x < nw; x++)
+            for (int j = 0; j < 31; j++) e[o++] = (uint8_t)((w[x] >> (2 * (30 - j))) & 3);         // :720-729
+        char hdr[96];
+        int hl = twin == RFX_TWIN_DS
+                     ? snprintf(hdr, sizeof hdr, ">Contig-%lld-(%d,%d)-%lld\n", (long long)len, r->left[i],
+                                r->right[i], (long long)idx)                // DS :755, :722
+                     : snprintf(hdr, sizeof hdr, ">Contig-%lld-%lld\n", (long long)len, (long long)idx);   // :597, :578
+        for (int j = 0; j < hl; j++) putc_(hdr[j]);
+        for (int64_t j = 0; j < len; j++) {                                 // changeLine :616-637
+            if (j > 0 && j % 100 == 0) putc_('\n');
+            putc_(NUC[b[(size_t)j]]);
+        }
+        putc_('\n');                                                        // saveAsTextFile
+        idx++;
+    }
+    if (n_contigs) *n_contigs = idx;
+    return pos;
+}
+
+struct HostRecords {
+    std::vector<uint64_t> key, ext; std::vector<int32_t> marker, left, right; std::vector<int64_t> ext_off;
+    rfx_records view;
+    void resize(int64_t n, int64_t words) {
+        key.resize((size_t)std::max<int64_t>(n, 1)); marker.resize(key.size()); left.resize(key.size());
+        right.resize(key.size()); ext_off.resize((size_t)n + 1); ext.resize((size_t)std::max<int64_t>(words, 1));
+        view.n = 0; view.key = key.data(); view.marker = marker.data(); view.ext_off = ext_off.data();
+        view.ext = ext.data(); view.left = left.data(); view.right = right.data(); view.cap_n = n;
+        view.cap_words = words;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int rfx_version(void) { return 100; }
+
+void rfx_default_params(rfx_params *p) {
+    p->k = 31; p->min_cov = 2; p->max_cov = 10000000; p->min_error_cov = 8; p->min_contig = 500;
+    p->min_iter = 15; p->max_iter = 150; p->front_clip = 0; p->end_clip = 0; p->partitions = 8;
+    p->twin = RFX_TWIN_DS; p->coalesce = 0;
+}
+
+int rfx_ctx_create(int device, rfx_ctx **out) {
+    if (!out) return RFX_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RFX_E_NOGPU;
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return RFX_E_NOGPU; }
+    if (device >= ndev) return RFX_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return RFX_E_NOGPU;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return RFX_E_NOGPU;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RFX_E_NOGPU;   // the code object is gfx950-only
+    rfx_ctx *ctx = new rfx_ctx();
+    ctx->device = device;
+    ctx->num_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return RFX_E_HIP; }
+    ctx->own_stream = true;
+    // keep freed scratch in the stream-ordered pool instead of returning it to the driver
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+        uint64_t thr = UINT64_MAX;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+    }
+    *out = ctx;
+    return RFX_OK;
+}
+
+void rfx_ctx_destroy(rfx_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int rfx_ctx_sync(rfx_ctx *ctx) {
+    if (!ctx) return RFX_E_ARG;
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    return RFX_OK;
+}
+
+int rfx_ctx_set_stream(rfx_ctx *ctx, void *hip_stream) {
+    if (!ctx) return RFX_E_ARG;
+    if (ctx->own_stream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    ctx->own_stream = false;
+    return RFX_OK;
+}
+
+void *rfx_ctx_stream(rfx_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+const char *rfx_last_error(rfx_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "no context"; }
+
+// ------------------------------------------------------------- host operators
+
+int rfx_extract_canon(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_off, int64_t n_reads, int k,
+                      int front_clip, int end_clip, uint64_t *out_kmers, int64_t cap, int64_t *out_n) {
+    if (!ctx || !read_off || !out_n || n_reads < 0) return RFX_E_ARG;
+    RFX_TRY(check_k(k));
+    if (front_clip < 0 || end_clip < 0) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    *out_n = 0;
+    if (n_reads == 0) return RFX_OK;
+    const int64_t nb = read_off[n_reads] - read_off[0];
+    int64_t maxlen = 0;
+    for (int64_t r = 0; r < n_reads; r++) maxlen = std::max(maxlen, read_off[r + 1] - read_off[r]);
+    const int wpr = (int)std::max<int64_t>(1, (maxlen + 31) / 32);
+    DevBuf d_bases, d_off, d_words, d_nk, d_koff, d_out;
+    RFX_HIP(d_bases.alloc((size_t)nb, ctx->stream));
+    RFX_HIP(d_off.alloc((size_t)(n_reads + 1) * 8, ctx->stream));
+    RFX_HIP(d_words.alloc((size_t)n_reads * wpr * 8, ctx->stream));
+    RFX_HIP(d_nk.alloc((size_t)n_reads * 8, ctx->stream));
+    RFX_HIP(d_koff.alloc((size_t)(n_reads + 1) * 8, ctx->stream));
+    // offsets are rebased to the first read
+    std::vector<int64_t> off((size_t)n_reads + 1);
+    for (int64_t r = 0; r <= n_reads; r++) off[(size_t)r] = read_off[r] - read_off[0];
+    if (nb > 0) RFX_HIP(hipMemcpyAsync(d_bases.p, bases + read_off[0], (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(d_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    RFX_TRY(encode_reads(ctx, d_bases.as<uint8_t>(), d_off.as<int64_t>(), n_reads, wpr, d_words.as<uint64_t>(), nullptr));
+    RFX_TRY(kmer_counts_per_read(ctx, d_off.as<int64_t>(), n_reads, k, front_clip, end_clip, d_nk.as<uint64_t>()));
+    RFX_TRY(exclusive_scan_u64(ctx, d_nk.as<uint64_t>(), d_koff.as<uint64_t>(), n_reads));
+    uint64_t total = 0;
+    RFX_HIP(hipMemcpyAsync(&total, d_koff.as<uint64_t>() + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    *out_n = (int64_t)total;
+    if ((int64_t)total > cap) return RFX_E_CAP;
+    if (total == 0) return RFX_OK;
+    if (!out_kmers) return RFX_E_ARG;
+    RFX_HIP(d_out.alloc((size_t)total * 8, ctx->stream));
+    RFX_TRY(extract_ordered_packed(ctx, d_words.as<uint64_t>(), wpr, d_koff.as<uint64_t>(), n_reads, k, front_clip,
+                                   d_out.as<uint64_t>()));
+    RFX_HIP(hipMemcpyAsync(out_kmers, d_out.p, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    return RFX_OK;
+}
+
+int rfx_count_filter(rfx_ctx *ctx, const uint64_t *kmers, int64_t n, int min_cov, int max_cov, int twin,
+                     uint64_t *out_keys, int32_t *out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct) {
+    if (!ctx || n < 0 || !out_n || (n > 0 && !kmers)) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    *out_n = 0;
+    if (out_distinct) *out_distinct = 0;
+    if (n == 0) return RFX_OK;
+    DevBuf d_in, d_keys, d_counts;
+    RFX_HIP(d_in.alloc((size_t)n * 8, ctx->stream));
+    // at most n survivors; the device path reports the needed size if cap is smaller
+    const int64_t dcap = n;
+    RFX_HIP(d_keys.alloc((size_t)dcap * 8, ctx->stream));
+    RFX_HIP(d_counts.alloc((size_t)dcap * 4, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(d_in.p, kmers, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    int64_t m = 0, dist = 0;
+    RFX_TRY(count_filter(ctx, nullptr, d_in.as<uint64_t>(), n, min_cov, max_cov, twin, nullptr, 0,
+                         d_keys.as<uint64_t>(), d_counts.as<int32_t>(), dcap, &m, &dist));
+    *out_n = m;
+    if (out_distinct) *out_distinct = dist;
+    if (m > cap) return RFX_E_CAP;
+    if (m > 0) {
+        RFX_HIP(hipMemcpyAsync(out_keys, d_keys.p, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(out_counts, d_counts.p, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    return RFX_OK;
+}
+
+int rfx_rc_expand_subkmer(rfx_ctx *ctx, const uint64_t *kmers, const int32_t *counts, int64_t n, int k,
+                          rfx_records *out) {
+    if (!ctx || n < 0 || !out) return RFX_E_ARG;
+    RFX_TRY(check_k(k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    DevBuf dk, dc;
+    RFX_HIP(dk.alloc((size_t)n * 8, ctx->stream));
+    RFX_HIP(dc.alloc((size_t)n * 4, ctx->stream));
+    if (n > 0) {
+        RFX_HIP(hipMemcpyAsync(dk.p, kmers, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(dc.p, counts, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    DevRecords r;
+    RFX_TRY(rc_expand_subkmer(ctx, dk.as<uint64_t>(), dc.as<int32_t>(), n, k, r));
+    return download_to(ctx, r, out);
+}
+
+int rfx_sort_records(rfx_ctx *ctx, const rfx_records *in, int P, rfx_records *out, int64_t *part_start) {
+    if (!ctx || !in || !out || P < 1) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    DevRecords d, s;
+    DevBuf ps;
+    RFX_TRY(dev_records_upload(ctx, in, d));
+    RFX_TRY(sort_records(ctx, d, P, 64, s, ps));
+    RFX_TRY(download_to(ctx, s, out));
+    return download_part_start(ctx, ps, P, part_start);
+}
+
+static int fork_host(rfx_ctx *ctx, bool reflected, const rfx_records *in, const int64_t *part_start, int P, int k,
+                     int min_error_cov, int twin, rfx_records *out, int64_t *out_part_start) {
+    if (!ctx || !in || !out || !part_start || P < 1) return RFX_E_ARG;
+    RFX_TRY(check_k(k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    DevRecords d, o;
+    DevBuf ps, ops;
+    RFX_TRY(dev_records_upload(ctx, in, d));
+    RFX_TRY(upload_part_start(ctx, part_start, P, ps));
+    RFX_TRY(fork_filter(ctx, reflected, d, ps.as<int64_t>(), P, k, min_error_cov, twin, o, ops));
+    RFX_TRY(download_to(ctx, o, out));
+    return download_part_start(ctx, ops, P, out_part_start);
+}
+
+int rfx_fork_filter_forward(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P, int k,
+                            int min_error_cov, int twin, rfx_records *out, int64_t *out_part_start) {
+    return fork_host(ctx, false, in, part_start, P, k, min_error_cov, twin, out, out_part_start);
+}
+
+int rfx_fork_filter_reflected(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P, int k,
+                              int min_error_cov, int twin, rfx_records *out, int64_t *out_part_start) {
+    return fork_host(ctx, true, in, part_start, P, k, min_error_cov, twin, out, out_part_start);
+}
+
+int rfx_reflect_from_forward(rfx_ctx *ctx, const rfx_records *in, int k, rfx_records *out) {
+    if (!ctx || !in || !out) return RFX_E_ARG;
+    RFX_TRY(check_k(k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    DevRecords d, o;
+    RFX_TRY(dev_records_upload(ctx, in, d));
+    RFX_TRY(reflect_from_forward(ctx, d, k, o));
+    return download_to(ctx, o, out);
+}
+
+int rfx_random_reflection(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P, int k,
+                          rfx_records *out) {
+    if (!ctx || !in || !out || !part_start || P < 1) return RFX_E_ARG;
+    RFX_TRY(check_k(k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    DevRecords d, o;
+    DevBuf ps;
+    RFX_TRY(dev_records_upload(ctx, in, d));
+    RFX_TRY(upload_part_start(ctx, part_start, P, ps));
+    RFX_TRY(random_reflection(ctx, d, ps.as<int64_t>(), P, k, o));
+    return download_to(ctx, o, out);
+}
+
+int rfx_extend_pass(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P, int k, int twin,
+                    int stage, rfx_records *out, int64_t *out_part_start) {
+    if (!ctx || !in || !out || !part_start || P < 1 || stage < 0 || stage > 2) return RFX_E_ARG;
+    RFX_TRY(check_k(k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    DevRecords d, o;
+    DevBuf ps, ops;
+    RFX_TRY(dev_records_upload(ctx, in, d));
+    RFX_TRY(upload_part_start(ctx, part_start, P, ps));
+    RFX_TRY(extend_pass(ctx, d, ps.as<int64_t>(), P, k, twin, stage, o, ops));
+    RFX_TRY(download_to(ctx, o, out));
+    return download_part_start(ctx, ops, P, out_part_start);
+}
+
+int rfx_contigs_text(rfx_ctx *ctx, const rfx_records *in, int k, int min_contig, int twin, char *out, int64_t cap,
+                     int64_t *out_len, int64_t *out_contigs) {
+    if (!ctx || !in || !out_len) return RFX_E_ARG;
+    RFX_TRY(check_k(k));
+    int64_t len = contigs_text_host(in, k, min_contig, twin, out, out ? cap : 0, out_contigs);
+    *out_len = len;
+    return len > cap ? RFX_E_CAP : RFX_OK;
+}
+
+// ------------------------------------------------------------ device pipeline
+
+int rfx_dev_encode_reads(rfx_ctx *ctx, const uint8_t *d_bases, const int64_t *d_read_off, int64_t n_reads,
+                         int words_per_read, uint64_t *d_words, uint32_t *d_read_len) {
+    if (!ctx || n_reads < 0 || words_per_read < 1) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    return encode_reads(ctx, d_bases, d_read_off, n_reads, words_per_read, d_words, d_read_len);
+}
+
+int64_t rfx_kmers_per_read(int read_len, int k, int front_clip, int end_clip) {
+    return kmers_per_read(read_len, k, front_clip, end_clip);
+}
+
+int64_t rfx_count_workspace_bytes(int64_t n_kmers) { return count_workspace_bytes(n_kmers); }
+
+int rfx_dev_count_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read, int read_len,
+                        int k, int front_clip, int end_clip, int min_cov, int max_cov, int twin,
+                        void *d_workspace, int64_t workspace_bytes, uint64_t *d_out_keys, int32_t *d_out_counts,
+                        int64_t cap, int64_t *out_n, int64_t *out_distinct, int64_t *out_instances) {
+    if (!ctx || !d_words || n_reads < 0 || words_per_read * 32 < read_len) return RFX_E_ARG;
+    RFX_TRY(check_k(k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    ReadStore rs{d_words, n_reads, words_per_read, read_len, k, front_clip, end_clip};
+    if (out_instances) *out_instances = kmers_per_read(read_len, k, front_clip, end_clip) * n_reads;
+    return count_filter(ctx, &rs, nullptr, 0, min_cov, max_cov, twin, d_workspace, workspace_bytes, d_out_keys,
+                        d_out_counts, cap, out_n, out_distinct);
+}
+
+int rfx_dev_count_kmers(rfx_ctx *ctx, const uint64_t *d_kmers, int64_t n, int min_cov, int max_cov, int twin,
+                        void *d_workspace, int64_t workspace_bytes, uint64_t *d_out_keys, int32_t *d_out_counts,
+                        int64_t cap, int64_t *out_n, int64_t *out_distinct) {
+    if (!ctx || n < 0) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    return count_filter(ctx, nullptr, d_kmers, n, min_cov, max_cov, twin, d_workspace, workspace_bytes, d_out_keys,
+                        d_out_counts, cap, out_n, out_distinct);
+}
+
+int rfx_dev_bucket_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read,
+                            int read_len, int k, int front_clip, int end_clip, int n_owners, uint64_t *d_out,
+                            int64_t cap, int64_t *d_owner_off, int64_t *h_owner_off) {
+    if (!ctx || !d_words || !d_owner_off) return RFX_E_ARG;
+    RFX_TRY(check_k(k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    ReadStore rs{d_words, n_reads, words_per_read, read_len, k, front_clip, end_clip};
+    return bucket_by_owner(ctx, &rs, n_owners, d_out, cap, d_owner_off, h_owner_off);
+}
+
+int rfx_dev_sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int key_bits,
+                       uint64_t *d_tmp_keys, uint32_t *d_tmp_vals) {
+    if (!ctx || n < 0) return RFX_E_ARG;
+    if (n > (int64_t)0xFFFFFFFFLL) return RFX_E_LIMIT;
+    RFX_HIP(hipSetDevice(ctx->device));
+    return sort_pairs(ctx, d_keys, d_vals, n, key_bits, d_tmp_keys, d_tmp_vals);
+}
+
+int rfx_dev_synth_genome(rfx_ctx *ctx, uint64_t seed, int64_t genome_len, uint64_t *d_genome) {
+    if (!ctx || !d_genome) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    return synth_genome(ctx, seed, genome_len, d_genome);
+}
+
+int rfx_dev_synth_reads(rfx_ctx *ctx, uint64_t seed, const uint64_t *d_genome, int64_t genome_len,
+                        int64_t first_read, int64_t n_reads, int read_len, uint32_t err_per_2_32,
+                        int words_per_read, uint64_t *d_words) {
+    if (!ctx || !d_genome || !d_words) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    return synth_reads(ctx, seed, d_genome, genome_len, first_read, n_reads, read_len, err_per_2_32,
+                       words_per_read, d_words);
+}
+
+int rfx_last_count_timing(rfx_ctx *ctx, const char *name, float *ms, int64_t *launches) {
+    if (!ctx || !name) return RFX_E_ARG;
+    auto it = ctx->timing.find(name);
+    if (it == ctx->timing.end()) { if (ms) *ms = 0.f; if (launches) *launches = 0; return RFX_E_ARG; }
+    if (ms) *ms = it->second.ms;
+    if (launches) *launches = it->second.launches;
+    return RFX_OK;
+}
+
+// Driver: P/ReflexivMain.java:168-310 (DS P/ReflexivDSMain.java:221-352)
+int rfx_dev_assemble(rfx_ctx *ctx, const uint64_t *d_keys, const int32_t *d_counts, int64_t n,
+                     const rfx_params *prm, char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs,
+                     int64_t *trace, int64_t trace_cap, int64_t *n_trace) {
+    if (!ctx || !prm || !out_len || n < 0) return RFX_E_ARG;
+    RFX_TRY(check_k(prm->k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    const int k = prm->k, twin = prm->twin;
+    int P = prm->partitions > 0 ? prm->partitions : 1;
+    const int key_bits = 2 * (k - 1);
+    int64_t nt = 0;
+    DevRecords a, b;
+    DevBuf ps, ops;
+    // KmerReverseComplement + ForwardSubKmerExtraction  :168-176
+    RFX_TRY(rc_expand_subkmer(ctx, d_keys, d_counts, n, k, a));
+    // sortByKey + FilterForkSubKmer[WithErrorCorrection]  :179-186
+    RFX_TRY(sort_records(ctx, a, P, key_bits, b, ps));
+    RFX_TRY(fork_filter(ctx, false, b, ps.as<int64_t>(), P, k, prm->min_error_cov, twin, a, ops));
+    // ReflectedSubKmerExtractionFromForward  :188-189
+    RFX_TRY(reflect_from_forward(ctx, a, k, b));
+    // sortByKey + FilterForkReflectedSubKmer[WithErrorCorrection]  :191-198
+    RFX_TRY(sort_records(ctx, b, P, key_bits, a, ps));
+    RFX_TRY(fork_filter(ctx, true, a, ps.as<int64_t>(), P, k, prm->min_error_cov, twin, b, ops));
+    // kmerRandomReflection on the filter's output partitions  :204-205
+    RFX_TRY(random_reflection(ctx, b, ops.as<int64_t>(), P, k, a));
+
+    auto one_pass = [&](int stage) -> int {
+        RFX_TRY(sort_records(ctx, a, P, key_bits, b, ps));                        // sortByKey :211,:235,:247,:286
+        RFX_TRY(extend_pass(ctx, b, ps.as<int64_t>(), P, k, twin, stage, a, ops));
+        if (trace && nt < trace_cap) trace[nt] = a.n;
+        nt++;
+        return RFX_OK;
+    };
+    int iterations = 0;
+    RFX_TRY(one_pass(0));                                                         // :221-222
+    for (int i = 1; i < 4; i++) { iterations++; RFX_TRY(one_pass(0)); }           // :233-241
+    iterations++;
+    RFX_TRY(one_pass(1));                                                         // :247-254
+    int partitionNumber = P;
+    int64_t contigNumber = 0;
+    while (iterations <= prm->max_iter) {                                         // :265-296
+        iterations++;
+        if (iterations >= prm->min_iter && iterations % 3 == 0) {
+            const int64_t current = a.n;                                          // count() :270
+            if (contigNumber == current) break;
+            contigNumber = current;
+            if (prm->coalesce && partitionNumber >= 16 && current / partitionNumber <= 20) {
+                partitionNumber = partitionNumber / 4 + 1;                        // :277-281
+                P = partitionNumber;
+            }
+        }
+        RFX_TRY(one_pass(2));
+    }
+    if (n_trace) *n_trace = nt;
+    HostRecords h;
+    h.resize(a.n, a.words);
+    RFX_TRY(dev_records_download(ctx, a, &h.view));
+    int64_t len = contigs_text_host(&h.view, k, prm->min_contig, twin, out, out ? cap : 0, out_contigs);
+    *out_len = len;
+    return len > cap ? RFX_E_CAP : RFX_OK;
+}
+
+}  // extern "C"

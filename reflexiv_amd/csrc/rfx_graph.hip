@@ -1,0 +1,450 @@
+// rfx_graph.hip -- the record-building operators between the count stage and the extend
+// loop (K4..K9 of SURVEY.md 2.3) plus the record sort that stands in for sortByKey().
+//
+//   KmerReverseComplement + ForwardSubKmerExtraction   P/ReflexivMain.java:2910-2930, 2709-2730
+//   sortByKey()                                        P/ReflexivMain.java:179,191,211,...
+//   FilterForkSubKmer[WithErrorCorrection]             P/ReflexivMain.java:2412-2540 (DS :3375-3483)
+//   ReflectedSubKmerExtractionFromForward              P/ReflexivMain.java:2742-2768
+//   FilterForkReflectedSubKmer[WithErrorCorrection]    P/ReflexivMain.java:2550-2696 (DS :3493-3616)
+//   kmerRandomReflection                               P/ReflexivMain.java:2783-2885
+//
+// Records live in HBM as flat struct-of-arrays in the reference's layout (include/
+// reflexiv_hip.h).  A sort moves (key, index) pairs only; fixed fields are gathered once
+// through the permutation and extension words are copied record by record.  The fork
+// filters are segmented folds over equal-key runs: the thread that owns a run head walks
+// its run (<= 4 records once both strands are present) and writes the survivor at the
+// run's compacted position.
+#include "rfx_internal.h"
+#include "rfx_device.h"
+
+using namespace rfxd;
+
+namespace {
+
+__global__ void k_iota_u32(uint32_t *v, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+__global__ void k_iota_i64(int64_t *v, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+
+// ---- K4 + K5
+__global__ void k_rc_expand(const uint64_t *__restrict__ kmers, const int32_t *__restrict__ counts, int64_t n,
+                            int k, uint64_t *__restrict__ key, int32_t *__restrict__ marker,
+                            int64_t *__restrict__ ext_off, uint64_t *__restrict__ ext,
+                            int32_t *__restrict__ left, int32_t *__restrict__ right) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t x = kmers[i];
+    uint64_t two[2] = {x, revcomp(x, k)};                 // (kmer, rc) adjacent  :2925-2926
+    int32_t c = counts[i];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        int64_t o = 2 * i + t;
+        key[o] = two[t] >> 2;                              // :2720
+        ext[o] = two[t] & 3;                               // :2719 (no sentinel yet)
+        marker[o] = 1; left[o] = c; right[o] = c;          // :2724
+        ext_off[o] = o;
+    }
+    if (i == n - 1) ext_off[2 * n] = 2 * n;
+}
+
+// ---- sort support
+__global__ void k_gather_fixed(const uint32_t *__restrict__ perm, int64_t n, const int32_t *__restrict__ marker,
+                               const int32_t *__restrict__ left, const int32_t *__restrict__ right,
+                               const int64_t *__restrict__ ext_off, int32_t *__restrict__ omarker,
+                               int32_t *__restrict__ oleft, int32_t *__restrict__ oright,
+                               uint32_t *__restrict__ onw) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s = perm[i];
+    omarker[i] = marker[s]; oleft[i] = left[s]; oright[i] = right[s];
+    onw[i] = (uint32_t)(ext_off[s + 1] - ext_off[s]);
+}
+
+constexpr int SHORT_WORDS = 8;
+
+// copy extension words record by record; records longer than SHORT_WORDS are queued
+__global__ void k_gather_ext(const uint32_t *__restrict__ perm, int64_t n, const int64_t *__restrict__ ext_off,
+                             const uint64_t *__restrict__ ext, const uint64_t *__restrict__ oext_off_u,
+                             int64_t *__restrict__ oext_off, uint64_t *__restrict__ oext,
+                             uint32_t *__restrict__ long_list, unsigned long long *__restrict__ long_n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    int64_t o = (int64_t)oext_off_u[i];
+    oext_off[i] = o;
+    if (i == n) return;
+    uint32_t s = perm[i];
+    int64_t b = ext_off[s], nw = ext_off[s + 1] - b;
+    if (nw <= SHORT_WORDS) {
+        for (int64_t w = 0; w < nw; w++) oext[o + w] = ext[b + w];
+    } else {
+        long_list[atomicAdd(long_n, 1ULL)] = (uint32_t)i;
+    }
+}
+
+__global__ void k_gather_ext_long(const uint32_t *__restrict__ perm, const int64_t *__restrict__ ext_off,
+                                  const uint64_t *__restrict__ ext, const int64_t *__restrict__ oext_off,
+                                  uint64_t *__restrict__ oext, const uint32_t *__restrict__ long_list,
+                                  const unsigned long long *__restrict__ long_n) {
+    unsigned long long cnt = *long_n;
+    for (unsigned long long e = blockIdx.x; e < cnt; e += gridDim.x) {
+        uint32_t i = long_list[e];
+        uint32_t s = perm[i];
+        int64_t b = ext_off[s], nw = ext_off[s + 1] - b, o = oext_off[i];
+        for (int64_t w = threadIdx.x; w < nw; w += blockDim.x) oext[o + w] = ext[b + w];
+    }
+}
+
+// Order contract B.0: start[p] = floor(p*n/P) moved forward so equal keys never split.
+__global__ void k_partition_starts(const uint64_t *__restrict__ skey, int64_t n, int P,
+                                   int64_t *__restrict__ start) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > P) return;
+    if (p == P) { start[P] = n; return; }
+    int64_t s = (int64_t)(((uint64_t)p * (uint64_t)n) / (uint64_t)P);   // n < 2^32, p < 2^31
+    while (s > 0 && s < n && skey[s] == skey[s - 1]) s++;
+    start[p] = s;
+}
+
+// ---- run heads
+__global__ void k_head_flags(const uint64_t *__restrict__ key, int64_t n, uint32_t *__restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (i == 0 || key[i] != key[i - 1]) ? 1u : 0u;
+}
+
+// a-7: forward fork filter, one thread per run head
+__global__ void k_fork_forward(const uint64_t *__restrict__ key, const int32_t *__restrict__ marker,
+                               const uint64_t *__restrict__ ext, const int32_t *__restrict__ left, int64_t n,
+                               const uint32_t *__restrict__ flag, const uint64_t *__restrict__ pos,
+                               int sub, int min_err, int ds_ec,
+                               uint64_t *__restrict__ okey, int32_t *__restrict__ omarker,
+                               int64_t *__restrict__ oext_off, uint64_t *__restrict__ oext,
+                               int32_t *__restrict__ oleft, int32_t *__restrict__ oright) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == n) { oext_off[pos[n]] = (int64_t)pos[n]; return; }
+    if (i > n || !flag[i]) return;
+    const uint64_t kk = key[i];
+    int32_t hm = marker[i], hc = left[i];
+    uint64_t he = ext[i];
+    int32_t hr = ds_ec ? (-1 - hc) : -1;                                   // :2478 / DS :3436
+    for (int64_t j = i + 1; j < n && key[j] == kk; j++) {
+        int32_t cs = left[j];
+        if (cs > hc) {                                                     // :2483
+            bool err = min_err != 0 && hc <= min_err && cs >= 2 * hc;      // :2484
+            hm = marker[j]; he = ext[j]; hc = cs;
+            hr = err ? (ds_ec ? (-1 - cs) : -1) : sub;
+        } else if (cs == hc) {                                             // :2497
+            if ((int64_t)ext[j] > (int64_t)he) { hm = marker[j]; he = ext[j]; }
+            hr = sub;
+        } else {                                                           // :2512
+            bool err = min_err != 0 && cs <= min_err && hc >= 2 * cs;      // :2513
+            hr = err ? (ds_ec ? (-1 - hc) : -1) : sub;
+        }
+    }
+    uint64_t o = pos[i];
+    okey[o] = kk; omarker[o] = hm; oext[o] = he; oleft[o] = hc; oright[o] = hr; oext_off[o] = (int64_t)o;
+}
+
+// a-9: reflected fork filter
+__global__ void k_fork_reflected(const uint64_t *__restrict__ key, const int32_t *__restrict__ marker,
+                                 const uint64_t *__restrict__ ext, const int32_t *__restrict__ left,
+                                 const int32_t *__restrict__ right, int64_t n,
+                                 const uint32_t *__restrict__ flag, const uint64_t *__restrict__ pos,
+                                 int sub, int min_err, int ds_ec,
+                                 uint64_t *__restrict__ okey, int32_t *__restrict__ omarker,
+                                 int64_t *__restrict__ oext_off, uint64_t *__restrict__ oext,
+                                 int32_t *__restrict__ oleft, int32_t *__restrict__ oright) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == n) { oext_off[pos[n]] = (int64_t)pos[n]; return; }
+    if (i > n || !flag[i]) return;
+    const uint64_t kk = key[i];
+    int32_t last_cov = left[i];                                            // HighCoverLastCoverage :2623
+    int32_t hm = marker[i], hr = right[i];
+    uint64_t he = ext[i];
+    int32_t hl = ds_ec ? (-1 - last_cov) : -1;                             // :2626 / DS :3556
+    for (int64_t j = i + 1; j < n && key[j] == kk; j++) {
+        int32_t cs = left[j];
+        if (cs > last_cov) {                                               // :2631
+            bool err = min_err != 0 && last_cov <= min_err && cs >= 2 * last_cov;
+            last_cov = cs;
+            hm = marker[j]; he = ext[j]; hr = right[j];
+            hl = err ? (ds_ec ? (-1 - cs) : -1) : sub;
+        } else if (cs == last_cov) {                                       // :2647-2653
+            int ls = sentinel_len(ext[j]), lh = sentinel_len(he);
+            uint64_t a = ext[j] >> ((2 * (ls - 1)) & 63);
+            uint64_t b = he >> ((2 * lh) & 63);
+            if ((int64_t)a > (int64_t)b) { hm = marker[j]; he = ext[j]; hr = right[j]; }
+            hl = sub;
+        } else {                                                           // :2667
+            bool err = min_err != 0 && cs <= min_err && last_cov >= 2 * cs;
+            if (err) { if (!ds_ec) hl = -1; }                              // :2672 / DS :3595 keeps left
+            else hl = sub;
+        }
+    }
+    uint64_t o = pos[i];
+    okey[o] = kk; omarker[o] = hm; oext[o] = he; oleft[o] = hl; oright[o] = hr; oext_off[o] = (int64_t)o;
+}
+
+__global__ void k_map_part_start(const int64_t *__restrict__ ps, int P, const uint64_t *__restrict__ pos,
+                                 int64_t *__restrict__ ops) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p <= P) ops[p] = (int64_t)pos[ps[p]];
+}
+
+// a-8
+__global__ void k_reflect(const uint64_t *__restrict__ key, const uint64_t *__restrict__ ext,
+                          const int32_t *__restrict__ left, const int32_t *__restrict__ right, int64_t n, int sub,
+                          uint64_t *__restrict__ okey, int32_t *__restrict__ omarker,
+                          int64_t *__restrict__ oext_off, uint64_t *__restrict__ oext,
+                          int32_t *__restrict__ oleft, int32_t *__restrict__ oright) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == n) { oext_off[n] = n; return; }
+    if (i > n) return;
+    uint64_t kk = key[i];
+    uint64_t first = (kk >> (2 * (sub - 1))) & 3;                          // :2752-2754
+    okey[i] = ((kk << 2) & low_mask(sub)) | ext[i];                        // :2757-2758
+    oext[i] = first | 4;                                                   // :2755
+    omarker[i] = 2; oleft[i] = left[i]; oright[i] = right[i]; oext_off[i] = i;
+}
+
+// partition of sorted position i: last p with ps[p] <= i
+__device__ __forceinline__ int part_of(const int64_t *__restrict__ ps, int P, int64_t i) {
+    int lo = 0, hi = P;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (ps[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// a-10: single-word flip to the orientation the arrival index asks for
+__global__ void k_random_reflection(const uint64_t *__restrict__ key, const int32_t *__restrict__ marker,
+                                    const uint64_t *__restrict__ ext, const int32_t *__restrict__ left,
+                                    const int32_t *__restrict__ right, int64_t n,
+                                    const int64_t *__restrict__ ps, int P, int sub,
+                                    uint64_t *__restrict__ okey, int32_t *__restrict__ omarker,
+                                    int64_t *__restrict__ oext_off, uint64_t *__restrict__ oext,
+                                    int32_t *__restrict__ oleft, int32_t *__restrict__ oright) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == n) { oext_off[n] = n; return; }
+    if (i > n) return;
+    int p = part_of(ps, P, i);
+    int m = ((i - ps[p]) & 1) ? 1 : 2;                                      // :2777, :2880-2884
+    uint64_t kk = key[i], e = ext[i];
+    int mk = marker[i];
+    if (mk != m) {
+        int L = sentinel_len(e);
+        unsigned __int128 S;
+        uint64_t eb = e & low_mask(L);
+        if (mk == 1) {                      // key||ext  -> keyed at its last k-1 bases
+            S = ((unsigned __int128)kk << (2 * L)) | eb;
+            kk = (uint64_t)(S & (unsigned __int128)low_mask(sub));
+            e = (uint64_t)(S >> (2 * sub)) | (1ULL << (2 * L));
+        } else {                            // ext||key  -> keyed at its first k-1 bases
+            S = ((unsigned __int128)eb << (2 * sub)) | kk;
+            kk = (uint64_t)(S >> (2 * L));
+            e = (uint64_t)(S & (unsigned __int128)low_mask(L)) | (1ULL << (2 * L));
+        }
+    }
+    okey[i] = kk; omarker[i] = m; oext[i] = e; oleft[i] = left[i]; oright[i] = right[i]; oext_off[i] = i;
+}
+
+inline unsigned grid_for(int64_t n, int block = 256) { return (unsigned)ceil_div(n > 0 ? n : 1, block); }
+
+}  // namespace
+
+namespace rfx {
+
+int dev_records_alloc(rfx_ctx *ctx, DevRecords &r, int64_t cap_n, int64_t cap_words) {
+    if (cap_n < 1) cap_n = 1;
+    if (cap_words < 1) cap_words = 1;
+    RFX_HIP(r.key.alloc((size_t)cap_n * 8, ctx->stream));
+    RFX_HIP(r.marker.alloc((size_t)cap_n * 4, ctx->stream));
+    RFX_HIP(r.ext_off.alloc((size_t)(cap_n + 1) * 8, ctx->stream));
+    RFX_HIP(r.ext.alloc((size_t)cap_words * 8, ctx->stream));
+    RFX_HIP(r.left.alloc((size_t)cap_n * 4, ctx->stream));
+    RFX_HIP(r.right.alloc((size_t)cap_n * 4, ctx->stream));
+    r.n = 0; r.words = 0;
+    return RFX_OK;
+}
+
+int dev_records_upload(rfx_ctx *ctx, const rfx_records *h, DevRecords &d) {
+    const int64_t n = h->n;
+    const int64_t words = n > 0 ? h->ext_off[n] : 0;
+    RFX_TRY(dev_records_alloc(ctx, d, n, words));
+    if (n > 0) {
+        RFX_HIP(hipMemcpyAsync(d.key.p, h->key, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(d.marker.p, h->marker, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(d.left.p, h->left, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(d.right.p, h->right, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(d.ext_off.p, h->ext_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (words > 0)
+            RFX_HIP(hipMemcpyAsync(d.ext.p, h->ext, (size_t)words * 8, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        int64_t zero = 0;
+        RFX_HIP(hipMemcpyAsync(d.ext_off.p, &zero, 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    d.n = n; d.words = words;
+    return RFX_OK;
+}
+
+int dev_records_download(rfx_ctx *ctx, const DevRecords &d, rfx_records *h) {
+    h->need_n = d.n; h->need_words = d.words;
+    if (d.n > h->cap_n || d.words > h->cap_words) return RFX_E_CAP;
+    const int64_t n = d.n;
+    h->n = n;
+    if (n > 0) {
+        RFX_HIP(hipMemcpyAsync(h->key, d.key.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(h->marker, d.marker.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(h->left, d.left.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(h->right, d.right.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (d.words > 0)
+            RFX_HIP(hipMemcpyAsync(h->ext, d.ext.p, (size_t)d.words * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    RFX_HIP(hipMemcpyAsync(h->ext_off, d.ext_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    return RFX_OK;
+}
+
+int rc_expand_subkmer(rfx_ctx *ctx, const uint64_t *d_kmers, const int32_t *d_counts, int64_t n, int k,
+                      DevRecords &out) {
+    RFX_TRY(dev_records_alloc(ctx, out, 2 * n, 2 * n));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_rc_expand, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_kmers, d_counts, n, k,
+                           out.key.as<uint64_t>(), out.marker.as<int32_t>(), out.ext_off.as<int64_t>(),
+                           out.ext.as<uint64_t>(), out.left.as<int32_t>(), out.right.as<int32_t>());
+        RFX_HIP(hipGetLastError());
+    } else {
+        RFX_HIP(hipMemsetAsync(out.ext_off.p, 0, 8, ctx->stream));
+    }
+    out.n = 2 * n; out.words = 2 * n;
+    return RFX_OK;
+}
+
+int sort_records(rfx_ctx *ctx, const DevRecords &in, int P, int key_bits, DevRecords &out, DevBuf &part_start) {
+    const int64_t n = in.n;
+    if (n > (int64_t)0xFFFFFFFFLL) return RFX_E_LIMIT;
+    RFX_TRY(dev_records_alloc(ctx, out, n, in.words));
+    RFX_HIP(part_start.alloc((size_t)(P + 1) * 8, ctx->stream));
+    DevBuf perm, tk, tv, nw, wscan, long_list, long_n;
+    RFX_HIP(perm.alloc((size_t)(n ? n : 1) * 4, ctx->stream));
+    RFX_HIP(tk.alloc((size_t)(n ? n : 1) * 8, ctx->stream));
+    RFX_HIP(tv.alloc((size_t)(n ? n : 1) * 4, ctx->stream));
+    RFX_HIP(nw.alloc((size_t)(n ? n : 1) * 4, ctx->stream));
+    RFX_HIP(wscan.alloc((size_t)(n + 1) * 8, ctx->stream));
+    RFX_HIP(long_list.alloc((size_t)(n ? n : 1) * 4, ctx->stream));
+    RFX_HIP(long_n.alloc(8, ctx->stream));
+    RFX_HIP(hipMemsetAsync(long_n.p, 0, 8, ctx->stream));
+    if (n > 0) {
+        RFX_HIP(hipMemcpyAsync(out.key.p, in.key.p, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n)), dim3(256), 0, ctx->stream, perm.as<uint32_t>(), n);
+        RFX_HIP(hipGetLastError());
+        RFX_TRY(sort_pairs(ctx, out.key.as<uint64_t>(), perm.as<uint32_t>(), n, key_bits, tk.as<uint64_t>(),
+                           tv.as<uint32_t>()));
+        hipLaunchKernelGGL(k_gather_fixed, dim3(grid_for(n)), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)perm.as<uint32_t>(), n, (const int32_t *)in.marker.as<int32_t>(),
+                           (const int32_t *)in.left.as<int32_t>(), (const int32_t *)in.right.as<int32_t>(),
+                           (const int64_t *)in.ext_off.as<int64_t>(), out.marker.as<int32_t>(),
+                           out.left.as<int32_t>(), out.right.as<int32_t>(), nw.as<uint32_t>());
+        RFX_HIP(hipGetLastError());
+    }
+    RFX_TRY(exclusive_scan_u32_to_u64(ctx, nw.as<uint32_t>(), wscan.as<uint64_t>(), n));
+    hipLaunchKernelGGL(k_gather_ext, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream,
+                       (const uint32_t *)perm.as<uint32_t>(), n, (const int64_t *)in.ext_off.as<int64_t>(),
+                       (const uint64_t *)in.ext.as<uint64_t>(), (const uint64_t *)wscan.as<uint64_t>(),
+                       out.ext_off.as<int64_t>(), out.ext.as<uint64_t>(), long_list.as<uint32_t>(),
+                       long_n.as<unsigned long long>());
+    RFX_HIP(hipGetLastError());
+    if (in.words > n) {     // some record has more than one word: a long one may exist
+        hipLaunchKernelGGL(k_gather_ext_long, dim3(1024), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)perm.as<uint32_t>(), (const int64_t *)in.ext_off.as<int64_t>(),
+                           (const uint64_t *)in.ext.as<uint64_t>(), (const int64_t *)out.ext_off.as<int64_t>(),
+                           out.ext.as<uint64_t>(), (const uint32_t *)long_list.as<uint32_t>(),
+                           (const unsigned long long *)long_n.as<unsigned long long>());
+        RFX_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_partition_starts, dim3(grid_for(P + 1)), dim3(256), 0, ctx->stream,
+                       (const uint64_t *)out.key.as<uint64_t>(), n, P, part_start.as<int64_t>());
+    RFX_HIP(hipGetLastError());
+    out.n = n; out.words = in.words;
+    return RFX_OK;
+}
+
+int fork_filter(rfx_ctx *ctx, bool reflected, const DevRecords &in, const int64_t *d_part_start, int P, int k,
+                int min_error_cov, int twin, DevRecords &out, DevBuf &out_part_start) {
+    const int64_t n = in.n;
+    if (in.words != n) return RFX_E_ARG;             // single-word records only
+    RFX_TRY(dev_records_alloc(ctx, out, n, n));
+    RFX_HIP(out_part_start.alloc((size_t)(P + 1) * 8, ctx->stream));
+    DevBuf flag, pos;
+    RFX_HIP(flag.alloc((size_t)(n ? n : 1) * 4, ctx->stream));
+    RFX_HIP(pos.alloc((size_t)(n + 1) * 8, ctx->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_head_flags, dim3(grid_for(n)), dim3(256), 0, ctx->stream,
+                           (const uint64_t *)in.key.as<uint64_t>(), n, flag.as<uint32_t>());
+        RFX_HIP(hipGetLastError());
+    }
+    RFX_TRY(exclusive_scan_u32_to_u64(ctx, flag.as<uint32_t>(), pos.as<uint64_t>(), n));
+    const int ds_ec = (twin == RFX_TWIN_DS && min_error_cov != 0) ? 1 : 0;
+    if (!reflected)
+        hipLaunchKernelGGL(k_fork_forward, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream,
+                           (const uint64_t *)in.key.as<uint64_t>(), (const int32_t *)in.marker.as<int32_t>(),
+                           (const uint64_t *)in.ext.as<uint64_t>(), (const int32_t *)in.left.as<int32_t>(), n,
+                           (const uint32_t *)flag.as<uint32_t>(), (const uint64_t *)pos.as<uint64_t>(), k - 1,
+                           min_error_cov, ds_ec, out.key.as<uint64_t>(), out.marker.as<int32_t>(),
+                           out.ext_off.as<int64_t>(), out.ext.as<uint64_t>(), out.left.as<int32_t>(),
+                           out.right.as<int32_t>());
+    else
+        hipLaunchKernelGGL(k_fork_reflected, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream,
+                           (const uint64_t *)in.key.as<uint64_t>(), (const int32_t *)in.marker.as<int32_t>(),
+                           (const uint64_t *)in.ext.as<uint64_t>(), (const int32_t *)in.left.as<int32_t>(),
+                           (const int32_t *)in.right.as<int32_t>(), n, (const uint32_t *)flag.as<uint32_t>(),
+                           (const uint64_t *)pos.as<uint64_t>(), k - 1, min_error_cov, ds_ec,
+                           out.key.as<uint64_t>(), out.marker.as<int32_t>(), out.ext_off.as<int64_t>(),
+                           out.ext.as<uint64_t>(), out.left.as<int32_t>(), out.right.as<int32_t>());
+    RFX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_map_part_start, dim3(grid_for(P + 1)), dim3(256), 0, ctx->stream, d_part_start, P,
+                       (const uint64_t *)pos.as<uint64_t>(), out_part_start.as<int64_t>());
+    RFX_HIP(hipGetLastError());
+    uint64_t m = 0;
+    RFX_HIP(hipMemcpyAsync(&m, pos.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    out.n = (int64_t)m; out.words = (int64_t)m;
+    return RFX_OK;
+}
+
+int reflect_from_forward(rfx_ctx *ctx, const DevRecords &in, int k, DevRecords &out) {
+    const int64_t n = in.n;
+    if (in.words != n) return RFX_E_ARG;
+    RFX_TRY(dev_records_alloc(ctx, out, n, n));
+    hipLaunchKernelGGL(k_reflect, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream,
+                       (const uint64_t *)in.key.as<uint64_t>(), (const uint64_t *)in.ext.as<uint64_t>(),
+                       (const int32_t *)in.left.as<int32_t>(), (const int32_t *)in.right.as<int32_t>(), n, k - 1,
+                       out.key.as<uint64_t>(), out.marker.as<int32_t>(), out.ext_off.as<int64_t>(),
+                       out.ext.as<uint64_t>(), out.left.as<int32_t>(), out.right.as<int32_t>());
+    RFX_HIP(hipGetLastError());
+    out.n = n; out.words = n;
+    return RFX_OK;
+}
+
+int random_reflection(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start, int P, int k,
+                      DevRecords &out) {
+    const int64_t n = in.n;
+    if (in.words != n) return RFX_E_ARG;
+    RFX_TRY(dev_records_alloc(ctx, out, n, n));
+    hipLaunchKernelGGL(k_random_reflection, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream,
+                       (const uint64_t *)in.key.as<uint64_t>(), (const int32_t *)in.marker.as<int32_t>(),
+                       (const uint64_t *)in.ext.as<uint64_t>(), (const int32_t *)in.left.as<int32_t>(),
+                       (const int32_t *)in.right.as<int32_t>(), n, d_part_start, P, k - 1,
+                       out.key.as<uint64_t>(), out.marker.as<int32_t>(), out.ext_off.as<int64_t>(),
+                       out.ext.as<uint64_t>(), out.left.as<int32_t>(), out.right.as<int32_t>());
+    RFX_HIP(hipGetLastError());
+    out.n = n; out.words = n;
+    return RFX_OK;
+}
+
+}  // namespace rfx

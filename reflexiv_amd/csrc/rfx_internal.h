@@ -1,0 +1,150 @@
+// rfx_internal.h -- host-side plumbing shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/reflexiv_hip.h"
+
+struct rfx_timing_slot { float ms = 0.f; int64_t launches = 0; };
+
+struct rfx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+    int num_cu = 256;
+    // per-kernel-family timing of the last count call (HIP events on `stream`)
+    std::map<std::string, rfx_timing_slot> timing;
+    bool timing_enabled = true;
+};
+
+#define RFX_HIP(call)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            char buf_[512];                                                               \
+            snprintf(buf_, sizeof buf_, "%s:%d: %s -> %s", __FILE__, __LINE__, #call,     \
+                     hipGetErrorString(e_));                                              \
+            if (ctx) ctx->last_error = buf_;                                              \
+            return RFX_E_HIP;                                                             \
+        }                                                                                 \
+    } while (0)
+
+#define RFX_TRY(call)                              \
+    do {                                           \
+        int s_ = (call);                           \
+        if (s_ != RFX_OK) return s_;               \
+    } while (0)
+
+// Stream-ordered scratch allocation that frees itself.
+struct DevBuf {
+    void *p = nullptr;
+    hipStream_t s = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    hipError_t alloc(size_t bytes, hipStream_t stream) {
+        release();
+        s = stream;
+        if (bytes == 0) bytes = 16;
+        return hipMallocAsync(&p, bytes, stream);
+    }
+    void release() {
+        if (p) { (void)hipFreeAsync(p, s); p = nullptr; }
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Event pair that accumulates into ctx->timing[name].
+struct ScopedTimer {
+    rfx_ctx *ctx; const char *name; hipEvent_t a = nullptr, b = nullptr; bool on;
+    ScopedTimer(rfx_ctx *c, const char *n) : ctx(c), name(n), on(c && c->timing_enabled) {
+        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, ctx->stream); }
+    }
+    void stop(int64_t launches = 1) {
+        if (!on) return;
+        (void)hipEventRecord(b, ctx->stream);
+        pending().push_back({name, a, b, launches});
+        on = false;
+    }
+    ~ScopedTimer() { stop(); }
+    struct Pending { const char *name; hipEvent_t a, b; int64_t launches; };
+    static std::vector<Pending> &pending() { static thread_local std::vector<Pending> v; return v; }
+    // call after a stream sync
+    static void collect(rfx_ctx *ctx) {
+        for (auto &p : pending()) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+                ctx->timing[p.name].ms += ms;
+                ctx->timing[p.name].launches += p.launches;
+            }
+            (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+        }
+        pending().clear();
+    }
+};
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+namespace rfx {
+
+// ---- rfx_scan.hip
+int exclusive_scan_u64(rfx_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int64_t n);   // out[n] = total (n+1 entries)
+int exclusive_scan_u32_to_u64(rfx_ctx *ctx, const uint32_t *d_in, uint64_t *d_out, int64_t n);
+
+// ---- rfx_sort.hip
+int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int key_bits,
+               uint64_t *d_tmp_keys, uint32_t *d_tmp_vals);   // result in d_keys/d_vals
+
+// ---- rfx_kmer.hip
+struct ReadStore {
+    const uint64_t *words; int64_t n_reads; int words_per_read; int read_len;
+    int k, front_clip, end_clip;
+};
+int64_t kmers_per_read(int read_len, int k, int front_clip, int end_clip);
+int encode_reads(rfx_ctx *ctx, const uint8_t *d_bases, const int64_t *d_read_off, int64_t n_reads,
+                 int words_per_read, uint64_t *d_words, uint32_t *d_read_len);
+int extract_ordered_packed(rfx_ctx *ctx, const uint64_t *d_words, int wpr, const uint64_t *d_kmer_off,
+                           int64_t n_reads, int k, int front_clip, uint64_t *d_out);
+int kmer_counts_per_read(rfx_ctx *ctx, const int64_t *d_read_off, int64_t n_reads, int k,
+                         int front_clip, int end_clip, uint64_t *d_nk);
+int64_t count_workspace_bytes(int64_t n_kmers);
+int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, int64_t n,
+                 int min_cov, int max_cov, int twin, void *ws, int64_t ws_bytes,
+                 uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap,
+                 int64_t *out_n, int64_t *out_distinct);
+int bucket_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, uint64_t *d_out,
+                    int64_t cap, int64_t *d_owner_off, int64_t *h_owner_off);
+int synth_genome(rfx_ctx *ctx, uint64_t seed, int64_t genome_len, uint64_t *d_genome);
+int synth_reads(rfx_ctx *ctx, uint64_t seed, const uint64_t *d_genome, int64_t genome_len,
+                int64_t first_read, int64_t n_reads, int read_len, uint32_t err, int words_per_read,
+                uint64_t *d_words);
+
+// ---- rfx_graph.hip : device record set (reference layout, in HBM)
+struct DevRecords {
+    int64_t n = 0, words = 0;
+    DevBuf key, marker, ext_off, ext, left, right;
+};
+int dev_records_alloc(rfx_ctx *ctx, DevRecords &r, int64_t cap_n, int64_t cap_words);
+int dev_records_upload(rfx_ctx *ctx, const rfx_records *h, DevRecords &d);
+int dev_records_download(rfx_ctx *ctx, const DevRecords &d, rfx_records *h);
+
+int rc_expand_subkmer(rfx_ctx *ctx, const uint64_t *d_kmers, const int32_t *d_counts, int64_t n,
+                      int k, DevRecords &out);
+int sort_records(rfx_ctx *ctx, const DevRecords &in, int P, int key_bits, DevRecords &out,
+                 DevBuf &part_start /* int64[P+1] */);
+int fork_filter(rfx_ctx *ctx, bool reflected, const DevRecords &in, const int64_t *d_part_start,
+                int P, int k, int min_error_cov, int twin, DevRecords &out,
+                DevBuf &out_part_start);
+int reflect_from_forward(rfx_ctx *ctx, const DevRecords &in, int k, DevRecords &out);
+int random_reflection(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start, int P,
+                      int k, DevRecords &out);
+int extend_pass(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start, int P, int k,
+                int twin, int stage, DevRecords &out, DevBuf &out_part_start);
+
+}  // namespace rfx

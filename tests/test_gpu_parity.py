@@ -1,0 +1,388 @@
+"""GPU parity tests: every operator of the hot path, called through the C ABI
+(libreflexiv_hip.so), against the CPU oracle on the same inputs -- bit-exact (integer work).
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rfx():
+    import reflexiv_amd
+    r = reflexiv_amd.Reflexiv()
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture(scope="module")
+def ex(golden_dir):
+    return np.load(os.path.join(golden_dir, "example.npz"))
+
+
+@pytest.fixture(scope="module")
+def planted(golden_dir):
+    return np.load(os.path.join(golden_dir, "planted.npz"))
+
+
+def same_records(a, b):
+    assert a.n == b.n
+    for f in ("key", "marker", "ext_off", "ext", "left", "right"):
+        x, y = getattr(a, f), getattr(b, f)
+        assert np.array_equal(np.asarray(x), np.asarray(y)), f
+
+
+def test_native_library_is_loaded(rfx):
+    """The HIP extension must be the thing that runs (no eager / CPU fallback exists)."""
+    import reflexiv_amd
+    maps = open("/proc/self/maps").read()
+    assert "libreflexiv_hip.so" in maps
+    assert reflexiv_amd.lib().rfx_version() >= 100
+
+
+# ------------------------------------------------------------------ K1 extraction
+
+def test_extract_example(rfx, ex):
+    got = rfx.ReverseComplementKmerBinaryExtraction(ex["bases"], ex["read_off"], 31)
+    want = O.extract_canon(ex["bases"], ex["read_off"], 31)
+    assert len(got) == 161_000 and np.array_equal(got, want)
+    assert np.array_equal(got[:280], ex["k1_first4"])
+
+
+@pytest.mark.parametrize("k,fc,ec", [(31, 0, 0), (31, 3, 5), (21, 0, 0), (15, 2, 0), (5, 0, 1)])
+def test_extract_ragged_and_edge_reads(rfx, k, fc, ec):
+    rng = np.random.default_rng(k * 100 + fc * 10 + ec)
+    lens = np.concatenate([[0, 1, k - 1, k, k + 1, k + 2, k + 3, 64, 65, 96, 97, 200, 31, 32, 33],
+                           rng.integers(0, 300, 200)])
+    off = np.zeros(len(lens) + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    alphabet = np.frombuffer(b"ACGTNacgt", np.uint8)       # N and lower case -> code 3
+    bases = alphabet[rng.integers(0, len(alphabet), off[-1])]
+    got = rfx.ReverseComplementKmerBinaryExtraction(bases, off, k, fc, ec)
+    want = O.extract_canon(bases, off, k, fc, ec)
+    assert np.array_equal(got, want)
+
+
+def test_extract_empty(rfx):
+    got = rfx.ReverseComplementKmerBinaryExtraction(np.zeros(0, np.uint8), np.zeros(1, np.int64), 31)
+    assert len(got) == 0
+    got = rfx.ReverseComplementKmerBinaryExtraction(np.frombuffer(b"ACGT", np.uint8), np.array([0, 4]), 31)
+    assert len(got) == 0
+
+
+# ------------------------------------------------------------ K2/K3 count + filter
+
+@pytest.mark.parametrize("min_cov,twin", [(1, O.TWIN_DS), (2, O.TWIN_DS), (3, O.TWIN_RDD), (1, O.TWIN_RDD)])
+def test_count_filter_example(rfx, ex, min_cov, twin):
+    km = O.extract_canon(ex["bases"], ex["read_off"], 31)
+    keys, counts, nd = rfx.KmerCounting_and_CoverageFilter(km, min_cov, 10_000_000, twin)
+    wk, wc, wd = O.count_filter(km, min_cov, 10_000_000, twin)
+    assert nd == wd == 43_748
+    assert np.array_equal(keys, wk) and np.array_equal(counts, wc)
+
+
+def test_count_filter_max_cov_and_collisions(rfx):
+    """heavy hitters, a max-coverage cut and many duplicates of few keys (hash-table collisions)."""
+    rng = np.random.default_rng(5)
+    few = rng.integers(0, 1 << 62, 50, dtype=np.uint64)
+    km = np.concatenate([np.repeat(few, rng.integers(1, 3000, 50)),
+                         rng.integers(0, 1 << 62, 300_000, dtype=np.uint64),
+                         np.full(70_000, 12345, np.uint64), np.zeros(10, np.uint64)])
+    rng.shuffle(km)
+    for mn, mx in ((1, 10_000_000), (2, 1000), (5, 69_999), (3, 70_000)):
+        keys, counts, nd = rfx.KmerCounting_and_CoverageFilter(km, mn, mx)
+        wk, wc, wd = O.count_filter(km, mn, mx)
+        assert nd == wd and np.array_equal(keys, wk) and np.array_equal(counts, wc)
+
+
+def test_count_filter_empty_and_single(rfx):
+    k, c, d = rfx.KmerCounting_and_CoverageFilter(np.zeros(0, np.uint64), 1)
+    assert len(k) == 0 and d == 0
+    k, c, d = rfx.KmerCounting_and_CoverageFilter(np.array([7, 7, 7], np.uint64), 2)
+    assert list(k) == [7] and list(c) == [3] and d == 1
+
+
+def test_count_filter_multi_level(rfx):
+    """enough instances for two radix levels and low-coverage leaves that need the split fallback."""
+    rng = np.random.default_rng(11)
+    base = rng.integers(0, 1 << 62, 3_000_000, dtype=np.uint64)
+    km = np.concatenate([base, base[:1_500_000], base[:400_000], base[:400_000]])
+    rng.shuffle(km)
+    keys, counts, nd = rfx.KmerCounting_and_CoverageFilter(km, 2)
+    wk, wc, wd = O.count_filter(km, 2)
+    assert nd == wd and np.array_equal(keys, wk) and np.array_equal(counts, wc)
+
+
+# ---------------------------------------------------- K4..K9 and the extend passes
+
+def run_operator_chain(rfx, keys, counts, k, P, min_err, twin, n_pass=8):
+    """GPU and oracle side by side, every operator fed with the ORACLE's previous output
+    so one mismatch does not cascade; returns nothing, asserts record for record."""
+    o = O.rc_expand_subkmer(keys, counts, k)
+    g = rfx.KmerReverseComplement_and_ForwardSubKmerExtraction(keys, counts, k)
+    same_records(g, o)
+    o = O.sort_records(o)
+    ops = O.partition_starts(o.key, P)
+    g, gps = rfx.sortByKey(g, P)
+    same_records(g, o)
+    assert np.array_equal(gps, ops)
+    o2, ops2 = O.fork_filter_forward(o, ops, k, min_err, twin)
+    g2, gps2 = rfx.FilterForkSubKmer(o, ops, k, min_err, twin)
+    same_records(g2, o2)
+    assert np.array_equal(gps2, ops2)
+    o3 = O.reflect_from_forward(o2, k)
+    same_records(rfx.ReflectedSubKmerExtractionFromForward(o2, k), o3)
+    o3 = O.sort_records(o3)
+    ops3 = O.partition_starts(o3.key, P)
+    o4, ops4 = O.fork_filter_reflected(o3, ops3, k, min_err, twin)
+    g4, gps4 = rfx.FilterForkReflectedSubKmer(o3, ops3, k, min_err, twin)
+    same_records(g4, o4)
+    assert np.array_equal(gps4, ops4)
+    o5 = O.random_reflection(o4, ops4, k)
+    same_records(rfx.kmerRandomReflection(o4, ops4, k), o5)
+    cur = o5
+    for i in range(n_pass):
+        cur = O.sort_records(cur)
+        ps = O.partition_starts(cur.key, P)
+        gs, gps = rfx.sortByKey(cur, P)
+        same_records(gs, cur)
+        assert np.array_equal(gps, ps)
+        nxt, nps = O.extend_pass(cur, ps, k, twin)
+        stage = 0 if i < 4 else (1 if i == 4 else 2)
+        g, gps = rfx.ExtendReflexivKmer(cur, ps, k, twin, stage)
+        same_records(g, nxt)
+        assert np.array_equal(gps, nps)
+        cur = nxt
+    return cur
+
+
+@pytest.mark.parametrize("P,twin", [(4, O.TWIN_DS), (1, O.TWIN_RDD), (7, O.TWIN_DS)])
+def test_operator_chain_example(rfx, ex, P, twin):
+    run_operator_chain(rfx, ex["keys_cov3"], ex["counts_cov3"], 31, P, 8, twin, n_pass=10)
+
+
+@pytest.mark.parametrize("k,twin,min_err", [(31, O.TWIN_DS, 8), (31, O.TWIN_RDD, 8), (31, O.TWIN_DS, 0),
+                                            (21, O.TWIN_DS, 8)])
+def test_operator_chain_planted_bubbles(rfx, planted, k, twin, min_err):
+    """SNP bubble + repeat: exercises the left/right >= 0 (bubble distance) branches."""
+    run_operator_chain(rfx, planted[f"k{k}_keys"], planted[f"k{k}_counts"], k, 4, min_err, twin, n_pass=12)
+
+
+def test_late_passes_with_long_extensions(rfx, ex):
+    """few records, many words each: the long-record emit path (one workgroup per record)."""
+    prm = O.default_params(min_cov=3, partitions=4)
+    cur = O.rc_expand_subkmer(ex["keys_cov3"], ex["counts_cov3"], 31)
+    cur = O.sort_records(cur)
+    cur, ps = O.fork_filter_forward(cur, O.partition_starts(cur.key, 4), 31, 8, O.TWIN_DS)
+    cur = O.sort_records(O.reflect_from_forward(cur, 31))
+    cur, ps = O.fork_filter_reflected(cur, O.partition_starts(cur.key, 4), 31, 8, O.TWIN_DS)
+    cur = O.random_reflection(cur, ps, 31)
+    for i in range(26):
+        cur = O.sort_records(cur)
+        ps = O.partition_starts(cur.key, 4)
+        nxt, nps = O.extend_pass(cur, ps, 31, O.TWIN_DS)
+        if i >= 12:
+            g, gps = rfx.ExtendReflexivKmer(cur, ps, 31, O.TWIN_DS, 2)
+            same_records(g, nxt)
+            assert np.array_equal(gps, nps)
+        cur = nxt
+    assert np.diff(cur.ext_off).max() > 20          # really did exercise long records
+    text, nc = rfx.KmerToContig(cur, 31, 500, O.TWIN_RDD)
+    assert (text, nc) == O.contigs_text(cur, 31, 500, O.TWIN_RDD)
+
+
+def test_extend_pass_empty_and_singletons(rfx):
+    empty = O.Records(np.zeros(0, np.uint64), np.zeros(0, np.int32), np.zeros(1, np.int64),
+                      np.zeros(0, np.uint64), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    ps = np.zeros(3, np.int64)
+    g, gps = rfx.ExtendReflexivKmer(empty, ps, 31)
+    assert g.n == 0 and list(gps) == [0, 0, 0]
+    one = O.Records.from_single(np.array([5], np.uint64), np.array([1], np.int32), np.array([6], np.uint64),
+                                np.array([-1], np.int32), np.array([-1], np.int32))
+    ps = np.array([0, 1], np.int64)
+    want, wps = O.extend_pass(one, ps, 31)
+    g, gps = rfx.ExtendReflexivKmer(one, ps, 31, O.TWIN_DS, 0)
+    same_records(g, want)
+
+
+# ----------------------------------------------------------------- whole driver
+
+def dev_assemble(rfx, torch, keys, counts, prm):
+    dk = torch.from_numpy(np.ascontiguousarray(keys).view(np.int64)).cuda()
+    dc = torch.from_numpy(np.ascontiguousarray(counts)).cuda()
+    torch.cuda.synchronize()
+    return rfx.assemble_dev(dk.data_ptr(), dc.data_ptr(), len(keys), prm)
+
+
+@pytest.mark.parametrize("P", [1, 2, 4, 8])
+@pytest.mark.parametrize("tn", ["ds", "rdd"])
+def test_assemble_example_matches_golden(rfx, torch_mod, ex, P, tn):
+    import reflexiv_amd
+    twin = O.TWIN_DS if tn == "ds" else O.TWIN_RDD
+    prm = reflexiv_amd.default_params(min_cov=3, partitions=P, twin=twin)
+    text, nc, trace = dev_assemble(rfx, torch_mod, ex["keys_cov3"], ex["counts_cov3"], prm)
+    assert text == str(ex[f"contigs_{tn}_P{P}"])
+    assert trace == [int(x) for x in ex[f"trace_{tn}_P{P}"]]
+
+
+def test_documented_known_answer_on_gpu(rfx, torch_mod, ex):
+    """docs/example.html:303,320-343 end to end on the GPU: reads -> k-mers -> contigs."""
+    import reflexiv_amd
+    km = rfx.ReverseComplementKmerBinaryExtraction(ex["bases"], ex["read_off"], 31)
+    keys, counts, nd = rfx.KmerCounting_and_CoverageFilter(km, 3)
+    assert len(keys) == 4612
+    prm = reflexiv_amd.default_params(min_cov=3, partitions=4, twin=O.TWIN_RDD)
+    text, nc, trace = dev_assemble(rfx, torch_mod, keys, counts, prm)
+    seqs = ["".join(b.split("\n")[1:]) for b in text.split(">")[1:]]
+    assert sorted(len(s) for s in seqs) == [4558, 4558]
+    hit = [s for s in seqs if s.startswith(str(ex["doc_prefix1200"]))]
+    assert len(hit) == 1
+    assert hashlib.sha256(hit[0].encode()).hexdigest() == \
+        "245baebd8b5b681f639217f31d647d9fcd03adfeef7f6d5ef10edd5cc12ae62c"
+    assert text.split("\n")[0] == str(ex["doc_header"])
+
+
+@pytest.mark.parametrize("tn", ["ds", "rdd"])
+def test_assemble_planted_matches_golden(rfx, torch_mod, planted, tn):
+    import reflexiv_amd
+    twin = O.TWIN_DS if tn == "ds" else O.TWIN_RDD
+    prm = reflexiv_amd.default_params(k=31, min_cov=2, partitions=4, twin=twin, min_contig=100)
+    text, nc, trace = dev_assemble(rfx, torch_mod, planted["k31_keys"], planted["k31_counts"], prm)
+    assert text == str(planted[f"k31_{tn}_contigs"])
+    assert trace == [int(x) for x in planted[f"k31_{tn}_trace"]]
+
+
+# ------------------------------------------------ synthetic reads + fused count path
+
+def packed_to_ascii(words, n_reads, wpr, read_len):
+    w = words.reshape(n_reads, wpr)
+    out = np.empty((n_reads, read_len), np.uint8)
+    nuc = np.frombuffer(b"ACGT", np.uint8)
+    for j in range(read_len):
+        out[:, j] = nuc[((w[:, j // 32] >> np.uint64(62 - 2 * (j % 32))) & np.uint64(3)).astype(np.int64)]
+    return out.reshape(-1)
+
+
+def make_reads_dev(rfx, torch, seed, genome_len, n_reads, read_len, first_read=0):
+    wpr = (read_len + 31) // 32
+    dg = torch.empty((genome_len + 31) // 32, dtype=torch.int64, device="cuda")
+    dw = torch.empty(n_reads * wpr, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    rfx.synth_genome_dev(seed, genome_len, dg.data_ptr())
+    rfx.synth_reads_dev(seed, dg.data_ptr(), genome_len, first_read, n_reads, read_len, wpr, dw.data_ptr())
+    rfx.sync()
+    return dg, dw, wpr
+
+
+def test_synth_generator_matches_oracle(rfx, torch_mod):
+    seed, G, n, L = 99, 50_000, 4000, 150
+    dg, dw, wpr = make_reads_dev(rfx, torch_mod, seed, G, n, L, first_read=10)
+    g = O.synth_genome(seed, G)
+    assert np.array_equal(dg.cpu().numpy().view(np.uint64), g)
+    want, _ = O.synth_reads(seed, g, G, 10, n, L)
+    got = packed_to_ascii(dw.cpu().numpy().view(np.uint64), n, wpr, L)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n_reads,L,k,min_cov", [(3000, 100, 31, 2), (120_000, 150, 31, 3), (50_000, 150, 21, 2)])
+def test_fused_count_from_packed_reads(rfx, torch_mod, n_reads, L, k, min_cov):
+    torch = torch_mod
+    seed, G = 1234, 200_000
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    nk = rfx.kmers_per_read(L, k)
+    N = nk * n_reads
+    dk = torch.empty(N, dtype=torch.int64, device="cuda")
+    dc = torch.empty(N, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, min_cov)
+    assert inst == N
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+    km = O.extract_canon(bases, off, k)
+    assert len(km) == N
+    wk, wc, wd = O.count_filter(km, min_cov)
+    assert nd == wd and m == len(wk)
+    assert np.array_equal(dk[:m].cpu().numpy().view(np.uint64), wk)
+    assert np.array_equal(dc[:m].cpu().numpy(), wc)
+
+
+def test_fused_count_properties_at_scale(rfx, torch_mod):
+    """Size-independent properties on a workload the oracle would take minutes for:
+    counts of all distinct k-mers sum to N; output strictly ascending; raising min_cov
+    yields a subset with identical counts."""
+    torch = torch_mod
+    seed, G, n_reads, L, k = 77, 2_000_000, 2_000_000, 150, 31
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    N = rfx.kmers_per_read(L, k) * n_reads
+    dk = torch.empty(N // 2, dtype=torch.int64, device="cuda")
+    dc = torch.empty(N // 2, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    m1, nd1, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N // 2, 1)
+    assert inst == N and m1 == nd1
+    k1, c1 = dk[:m1].clone(), dc[:m1].clone()
+    assert int(c1.sum(dtype=torch.int64)) == N
+    assert bool((k1[1:] > k1[:-1]).all())
+    m3, nd3, _ = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N // 2, 3)
+    assert nd3 == nd1
+    sel = c1 >= 3
+    assert m3 == int(sel.sum())
+    assert torch.equal(dk[:m3], k1[sel]) and torch.equal(dc[:m3], c1[sel])
+
+
+def test_bucket_by_owner_partitions_kmer_space(rfx, torch_mod):
+    """multi-GPU support kernel: every instance lands in exactly one owner bucket, and an owner's
+    bucket holds exactly the k-mers whose hash falls in its shard."""
+    torch = torch_mod
+    seed, G, n_reads, L, k, owners = 5, 100_000, 20_000, 150, 31, 8
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    N = rfx.kmers_per_read(L, k) * n_reads
+    out = torch.empty(N, dtype=torch.int64, device="cuda")
+    doff = torch.empty(owners + 1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    h = rfx.bucket_by_owner_dev(dw.data_ptr(), n_reads, wpr, L, k, owners, out.data_ptr(), N, doff.data_ptr())
+    assert h[0] == 0 and h[-1] == N and np.all(np.diff(h) > 0)
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+    km = np.sort(O.extract_canon(bases, off, k))
+    got = out.cpu().numpy().view(np.uint64)
+    assert np.array_equal(np.sort(got), km)
+    # per-owner counting of the buckets == global counting restricted to the bucket
+    wk, wc, _ = O.count_filter(km, 2)
+    parts = []
+    for o in range(owners):
+        seg = got[h[o]:h[o + 1]]
+        kk, cc, _ = O.count_filter(seg, 2)
+        parts.append((kk, cc))
+    allk = np.concatenate([p[0] for p in parts]); allc = np.concatenate([p[1] for p in parts])
+    order = np.argsort(allk, kind="stable")
+    assert np.array_equal(allk[order], wk) and np.array_equal(allc[order], wc)
+
+
+def test_sort_pairs_is_stable(rfx, torch_mod):
+    torch = torch_mod
+    rng = np.random.default_rng(3)
+    for n, bits in ((1, 60), (100, 8), (2048, 60), (2049, 60), (300_000, 60), (1_000_000, 20)):
+        keys = rng.integers(0, 1 << min(bits, 12 if n > 2048 else bits), n, dtype=np.uint64)   # many ties
+        vals = np.arange(n, dtype=np.uint32)
+        dk = torch.from_numpy(keys.view(np.int64)).cuda(); dv = torch.from_numpy(vals.view(np.int32)).cuda()
+        tk = torch.empty_like(dk); tv = torch.empty_like(dv)
+        torch.cuda.synchronize()
+        rfx.sort_pairs_dev(dk.data_ptr(), dv.data_ptr(), n, bits, tk.data_ptr(), tv.data_ptr())
+        rfx.sync()
+        order = np.argsort(keys, kind="stable")
+        assert np.array_equal(dk.cpu().numpy().view(np.uint64), keys[order])
+        assert np.array_equal(dv.cpu().numpy().view(np.uint32), vals[order])

@@ -70,6 +70,13 @@ def lib():
             raise RfxError(RFX_E_NOGPU, "reflexiv_amd",
                            f"{LIB_PATH} is missing -- build it with reflexiv_amd._lib.build() "
                            "(there is no CPU fallback)")
+        # One HIP runtime per process: torch ships its own libamdhip64 (soname libamdhip64.so.7).
+        # Loaded first, it also satisfies this library's NEEDED entry, so device pointers and
+        # streams are shared with torch; loaded second, the process would hold two runtimes.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.rfx_version.restype = C.c_int
         L.rfx_ctx_stream.restype = C.c_void_p

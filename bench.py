@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mers/sec of the count stage (extract + count + filter) on synthetic PE150
+reads, k = 31, with the kernel roofline and the CPU baseline beside it.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path's count stage over one batch of synthetic reads that is
+already resident in HBM (2-bit packed): at N = 1 the batch is BASELINE.json configs[1]
+("Synthetic 5 Gbp E.coli-like PE150, k=31, 1xMI355X": 33,333,334 reads of 150 bp from a
+4.64 Mbp genome, 0.5 % substitutions, -cover 30).  At N > 1 every rank holds its own 5 Gbp
+shard of the read set (weak scaling), k-mer space is radix-sharded over the ranks and one
+RCCL all-to-all(v) replaces the Spark shuffle.  After the timed steps the run goes on to
+final contigs once and reports that wall-clock beside the metric.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec)
+
+# algorithmic HBM bytes per k-mer instance, per kernel family (DESIGN.md "Kernels")
+ALGO_BYTES = {"hist1": 0.25, "part1": 8.25, "hist2": 8.0, "part2": 16.0, "hist3": 8.0, "part3": 16.0,
+              "leaf": 8.0}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gbp", type=float, default=5.0, help="Gbp of reads per GPU")
+    ap.add_argument("--genome", type=int, default=4_640_000, help="genome length (bases, multiple of 32)")
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--cover", type=int, default=30, help="-cover (minKmerCoverage) for this depth")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--partitions", type=int, default=8)
+    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-contigs", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, n_sample):
+    """The oracle (CPU restatement of the same operators, one core) on a bounded sample of the
+    same workload: the first n_sample reads."""
+    import numpy as np
+    from oracle import oracle as O
+    import ctypes as C
+    g = O.synth_genome(args.seed, args.genome)
+    bases, off = O.synth_reads(args.seed, g, args.genome, 0, n_sample, args.read_len)
+    nk = (args.read_len - args.k + 1) * n_sample
+    out = np.empty(nk, np.uint64)
+    keys = np.empty(nk, np.uint64); counts = np.empty(nk, np.int32)
+    L = O.lib()
+    t0 = time.perf_counter()
+    n = L.orc_extract_canon(bases.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), C.c_int64(n_sample),
+                            args.k, 0, 0, out.ctypes.data_as(C.c_void_p), C.c_int64(nk))
+    nd = C.c_int64(0)
+    L.orc_count_filter(out.ctypes.data_as(C.c_void_p), C.c_int64(n), args.cover, 10_000_000, 0,
+                       keys.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), C.c_int64(nk),
+                       C.byref(nd))
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_sample} reads of the workload ({n} k-mer instances), extract+count+filter, "
+                      f"{dt:.1f} s on one host core (oracle/reflexiv_oracle.c)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import reflexiv_amd
+    from reflexiv_amd import dist as rd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    rfx = reflexiv_amd.Reflexiv(local)
+    rfx.use_stream(torch.cuda.current_stream().cuda_stream)   # kernels, copies and RCCL share one stream
+    dev = torch.device("cuda", local)
+
+    L, k = args.read_len, args.k
+    wpr = (L + 31) // 32
+    n_reads = int(round(args.gbp * 1e9 / L))
+    n_reads += n_reads & 1                                    # whole pairs
+    nk = rfx.kmers_per_read(L, k)
+    n_inst = nk * n_reads                                     # instances per rank per step
+
+    # synthetic reads straight into HBM, 2-bit packed (data = "synthetic")
+    d_genome = torch.empty((args.genome + 31) // 32, dtype=torch.int64, device=dev)
+    d_words = torch.empty(n_reads * wpr, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    rfx.synth_genome_dev(args.seed, args.genome, d_genome.data_ptr())
+    rfx.synth_reads_dev(args.seed, d_genome.data_ptr(), args.genome, rank * n_reads, n_reads, L, wpr,
+                        d_words.data_ptr())
+    rfx.sync()
+
+    cap = max(1 << 20, n_inst // 8)
+    d_keys = torch.empty(cap, dtype=torch.int64, device=dev)
+    d_counts = torch.empty(cap, dtype=torch.int32, device=dev)
+    reads = dict(words=d_words, n_reads=n_reads, wpr=wpr, read_len=L, k=k)
+    engine = rd.HipEngine(rfx)
+    timing_acc = {}
+
+    def step():
+        if world == 1:
+            m, nd, inst = rfx.count_reads_dev(d_words.data_ptr(), n_reads, wpr, L, k, d_keys.data_ptr(),
+                                              d_counts.data_ptr(), cap, args.cover)
+            return m, nd, inst
+        keys, counts, tot = rd.sharded_count(engine, reads, args.cover, 10_000_000, 0)
+        return int(keys.numel()), tot[1], tot[0]
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m, nd, inst = step()
+        for name, (ms, ln) in rfx.count_timing().items():
+            a = timing_acc.setdefault(name, [0.0, 0])
+            a[0] += ms; a[1] += ln
+    sync_all()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    total_inst = n_inst * world * args.steps
+    value = total_inst / dt
+
+    # roofline of the dominant kernel family: algorithmic bytes per launch / average launch
+    # duration (HIP events recorded inside the library on the stream the kernels run on)
+    roofline = None
+    if timing_acc:
+        dom = max((n for n in timing_acc if n in ALGO_BYTES), key=lambda n: timing_acc[n][0])
+        ms, launches = timing_acc[dom]
+        per_launch_bytes = ALGO_BYTES[dom] * n_inst
+        avg_s = ms / 1e3 / max(1, launches)
+        achieved = per_launch_bytes / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                    "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_s * 1e3,
+                    "per_kernel_ms_per_step": {n: v[0] / args.steps for n, v in sorted(timing_acc.items())}}
+
+    out = {
+        "metric": "k-mers/sec (extract+count+filter; wall-clock to final contigs beside it)",
+        "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"synthetic {args.gbp:g} Gbp per GPU, E.coli-like genome {args.genome} bp, "
+                               f"PE{L}, k={k}, -cover {args.cover}, 0.5% substitutions",
+                   "reads_per_gpu": n_reads, "kmer_instances_per_gpu": n_inst, "distinct_kmers": nd,
+                   "kmers_kept": m if world == 1 else None,
+                   "parallelism": "1 GPU" if world == 1 else f"k-mer space radix-sharded over {world} GPUs, "
+                                                               "RCCL all-to-all(v)"},
+        "roofline": roofline,
+        "stage_hbm_frac": ((16.25 * n_inst + 12 * m) / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS) if world == 1 else None,
+    }
+
+    if rank == 0 and world == 1 and not args.no_contigs:
+        prm = reflexiv_amd.default_params(k=k, min_cov=args.cover, partitions=args.partitions)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        text, nc, trace = rfx.assemble_dev(d_keys.data_ptr(), d_counts.data_ptr(), m, prm)
+        t_asm = time.perf_counter() - t1
+        lens = sorted((int(h.split("-")[1]) for h in text.split("\n") if h.startswith(">")), reverse=True)
+        out["contigs"] = {"wall_ms_from_counts": t_asm * 1e3, "wall_ms_reads_to_contigs": t_asm * 1e3 + dt / args.steps * 1e3,
+                          "extend_passes": len(trace), "n_contigs": nc, "longest": lens[:3],
+                          "total_bases": sum(lens)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, min(args.cpu_sample_reads, n_reads))
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

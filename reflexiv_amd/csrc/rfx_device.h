@@ -20,6 +20,16 @@ __device__ __host__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
+// Bijective, one 64-bit multiply: the product's high half is well mixed, folding it into the
+// low half mixes that too.  Its top OWNER_BITS pick the owning GPU, the bits below feed the
+// local radix levels and the leaf hash table (rfx_kmer.hip).  Result correctness never depends
+// on hash quality (bucket sizes are exact histograms); only load balance does.
+constexpr int OWNER_BITS = 6;
+__device__ __host__ __forceinline__ uint64_t kmer_hash(uint64_t x) {
+    uint64_t h = x * 0x9E3779B97F4A7C15ULL;
+    return h ^ (h >> 32);
+}
+
 // swap the two bits of every base pair
 __device__ __forceinline__ uint64_t pair_swap(uint64_t x) {
     return ((x & 0x5555555555555555ULL) << 1) | ((x >> 1) & 0x5555555555555555ULL);

@@ -20,6 +20,22 @@ struct rfx_ctx {
     // per-kernel-family timing of the last count call (HIP events on `stream`)
     std::map<std::string, rfx_timing_slot> timing;
     bool timing_enabled = true;
+    // grow-only workspace slots for the large, reused buffers (instance arrays of the count
+    // stage): allocated once with hipMalloc, kept until the context dies
+    struct WsSlot { void *p = nullptr; size_t bytes = 0; };
+    WsSlot ws[4];
+    void *ws_get(int slot, size_t bytes) {
+        WsSlot &w = ws[slot];
+        if (w.bytes >= bytes && w.p) return w.p;
+        if (w.p) { (void)hipStreamSynchronize(stream); (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
+        size_t want = bytes + (bytes >> 4) + (1 << 20);
+        if (hipMalloc(&w.p, want) != hipSuccess) { w.p = nullptr; return nullptr; }
+        w.bytes = want;
+        return w.p;
+    }
+    void ws_free() {
+        for (auto &w : ws) { if (w.p) (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
+    }
 };
 
 #define RFX_HIP(call)                                                                     \
@@ -44,6 +60,7 @@ struct rfx_ctx {
 struct DevBuf {
     void *p = nullptr;
     hipStream_t s = nullptr;
+    bool borrowed = false;        // points into a context workspace slot: never freed here
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -55,7 +72,8 @@ struct DevBuf {
         return hipMallocAsync(&p, bytes, stream);
     }
     void release() {
-        if (p) { (void)hipFreeAsync(p, s); p = nullptr; }
+        if (p && !borrowed) (void)hipFreeAsync(p, s);
+        p = nullptr; borrowed = false;
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };

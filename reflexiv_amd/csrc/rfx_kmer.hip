@@ -25,6 +25,7 @@
 #include "rfx_device.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 using namespace rfxd;
 
@@ -84,19 +85,12 @@ __global__ void k_extract_ordered(const uint64_t *__restrict__ words, int wpr,
     for (int64_t p = lane; p < nk; p += 64) out[o + p] = canonical(kmer_at(w, fc + (int)p, k), k);
 }
 
-// -------------------------------------------------------- instance sources
+// ------------------------------------------------------------ hash, levels
 
-struct Src {
-    const uint64_t *kmers;     // explicit instances (reduceByKey input) or nullptr
-    const uint64_t *words;     // packed uniform reads
-    int wpr, nk, fc, k;        // words per read, k-mers per read, front clip
-};
-
-// second, independent hash for the local radix levels (the first one, mix64(key), picks
-// the owning GPU in the multi-GPU path, so its top bits are constant inside a shard)
-__device__ __forceinline__ uint64_t local_hash(uint64_t key) { return mix64(mix64(key) ^ 0x5bd1e9955bd1e995ULL); }
-
-// ----------------------------------------------------------- radix levels
+// Hash bits (kmer_hash in rfx_device.h): the top OWNER_BITS pick the owning GPU in the multi-GPU
+// path (mulhi(h, n_owners)), the next <= 30 bits are the local radix digits, then 12 bits of
+// leaf-table slot and 16 bits for the leaf split fallback.
+__device__ __forceinline__ uint64_t local_hash(uint64_t key) { return kmer_hash(key) << OWNER_BITS; }
 
 constexpr int PT = 512;               // threads per workgroup
 constexpr int PK = 16;                // instances per thread
@@ -107,7 +101,201 @@ struct Level {
     int bits;                 // digit width of this level
     int shift;                // digit = (h >> shift) & (2^bits - 1); child id = h >> shift
     int parent_shift;         // parent id = h >> parent_shift (64 -> id 0)
+    int n_owners;             // > 0: the "digit" is the owning rank, mulhi(kmer_hash, n_owners)
 };
+
+__device__ __forceinline__ unsigned digit_of(uint64_t key, const Level &lv) {
+    if (lv.n_owners > 0) return (unsigned)__umul64hi(kmer_hash(key), (uint64_t)lv.n_owners);
+    return (unsigned)((local_hash(key) >> lv.shift) & ((1u << lv.bits) - 1));
+}
+
+// LDS layout shared by the two scatter kernels: sorted tile + per-digit bookkeeping
+struct ScatterLds {
+    uint64_t *skey;     // PTILE
+    uint64_t *gbase;    // 2^MAX_BITS: reserved global base of each digit's run
+    uint32_t *cnt;      // 2^MAX_BITS: per-digit count, then (aliased) local exclusive offset
+};
+__device__ __forceinline__ ScatterLds scatter_lds(unsigned char *smem) {
+    ScatterLds l;
+    l.skey = reinterpret_cast<uint64_t *>(smem);
+    l.gbase = l.skey + PTILE;
+    l.cnt = reinterpret_cast<uint32_t *>(l.gbase + (1 << MAX_BITS));
+    return l;
+}
+
+// One tile's worth of keys sits in registers with their (rank | digit << 16): turn the
+// per-digit counts into local offsets, reserve the global runs, place the keys digit by digit
+// in LDS and copy the runs out (consecutive lanes -> consecutive addresses of a run).
+// Reservation: PRIVATE -- the workgroup owns exact output ranges (priv[d] = its running cursor in
+// LDS, from the per-workgroup histogram), no atomics at all; otherwise one returning global
+// atomic per digit on cursor[].  Ends with a barrier after which skey / cnt may be reused.
+template <bool PRIVATE>
+__device__ __forceinline__ void scatter_tile(const ScatterLds &l, const Level &lv, uint64_t parent,
+                                             const uint64_t (&key)[PK], const uint32_t (&rank)[PK],
+                                             const bool (&ok)[PK], unsigned long long *__restrict__ cursor,
+                                             uint64_t *priv, uint64_t *__restrict__ out, uint32_t *wsum) {
+    const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
+    uint32_t total;
+    {
+        uint32_t c0 = 0, c1 = 0;
+        const int d0 = 2 * threadIdx.x, d1 = d0 + 1;
+        if (d0 < nb) c0 = l.cnt[d0];
+        if (d1 < nb) c1 = l.cnt[d1];
+        const uint32_t ex = block_exclusive_scan(c0 + c1, wsum, &total);   // barriers inside
+        const uint64_t cbase = lv.n_owners > 0 ? 0 : (parent << lv.bits);
+        if (d0 < nb) {
+            l.cnt[d0] = ex;
+            if (PRIVATE) { l.gbase[d0] = priv[d0]; priv[d0] += c0; }
+            else l.gbase[d0] = c0 ? atomicAdd(&cursor[cbase | (uint64_t)d0], (unsigned long long)c0) : 0;
+        }
+        if (d1 < nb) {
+            l.cnt[d1] = ex + c0;
+            if (PRIVATE) { l.gbase[d1] = priv[d1]; priv[d1] += c1; }
+            else l.gbase[d1] = c1 ? atomicAdd(&cursor[cbase | (uint64_t)d1], (unsigned long long)c1) : 0;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PK; i++)
+        if (ok[i]) l.skey[l.cnt[rank[i] >> 16] + (rank[i] & 0xFFFFu)] = key[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < (int)total; i += PT) {
+        const uint64_t kk = l.skey[i];
+        const unsigned d = digit_of(kk, lv);
+        out[l.gbase[d] + (uint64_t)(i - l.cnt[d])] = kk;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------- level 1 straight from reads
+
+// A thread owns PK consecutive windows of ONE read ("segment"): it loads the <= 3 packed words
+// they span, builds the first k-mer and its reverse complement with shifts and a bit reversal,
+// and rolls both through the remaining windows in registers -- no LDS, no per-base loads.
+struct ReadSrc {
+    const uint64_t *words;
+    int64_t n_reads, n_threads;    // n_threads = n_reads * segs
+    int wpr, nk, fc, k, segs;      // words/read, k-mers/read, front clip, k, segments/read
+};
+
+struct SegPos { int64_t r; int sgm; };
+
+__device__ __forceinline__ void seg_load(const ReadSrc &s, const SegPos &q, uint64_t (&w)[3]) {
+    const uint64_t *g = s.words + q.r * s.wpr;
+    const int wi = (s.fc + q.sgm * PK) >> 5;
+    const int last = s.wpr - 1;
+    w[0] = g[wi < last ? wi : last];
+    w[1] = g[wi + 1 < last ? wi + 1 : last];
+    w[2] = g[wi + 2 < last ? wi + 2 : last];
+}
+
+// -> number of valid windows; key[i] canonical k-mer of window sgm*PK + i
+__device__ __forceinline__ int seg_keys(const ReadSrc &s, int sgm, const uint64_t (&w)[3], uint64_t (&key)[PK]) {
+    const int p0 = sgm * PK;
+    int v = s.nk - p0;
+    v = v > PK ? PK : v;
+    const int sh = 2 * ((s.fc + p0) & 31);
+    // 64 bases starting at the first window's first base
+    const uint64_t hi = sh ? (w[0] << sh) | (w[1] >> (64 - sh)) : w[0];
+    const uint64_t lo = sh ? (w[1] << sh) | (w[2] >> (64 - sh)) : w[1];
+    const int k2 = 2 * s.k;
+    uint64_t fwd = hi >> (64 - k2);
+    uint64_t rc = revcomp(fwd, s.k);
+    uint64_t rest = (hi << k2) | (lo >> (64 - k2));          // bases k, k+1, ... (k2 in [6, 62])
+    const uint64_t mask = low_mask(s.k);
+    const int top = k2 - 2;
+#pragma unroll
+    for (int i = 0; i < PK; i++) {
+        key[i] = fwd < rc ? fwd : rc;                          // P/ReflexivMain.java:3051-3055
+        const uint64_t b = rest >> 62;                          // roll one base  (:3032-3047)
+        rest <<= 2;
+        fwd = ((fwd << 2) | b) & mask;
+        rc = (rc >> 2) | ((b ^ 3) << top);
+    }
+    return v;
+}
+
+// persistent: every workgroup strides over the tiles with one LDS histogram and stores ITS row
+// blockhist[bin * gridDim.x + blockIdx.x]: scanned in that order the table hands every workgroup
+// of the scatter kernel (same grid, same tile assignment) exact, private output ranges.
+__global__ __launch_bounds__(PT) void k_reads_hist(ReadSrc s, Level lv, uint64_t *__restrict__ blockhist) {
+    __shared__ uint32_t h[1 << MAX_BITS];
+    const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
+    for (int i = threadIdx.x; i < nb; i += PT) h[i] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * PT;
+    const int64_t dq = stride / s.segs;
+    const int dr = (int)(stride - dq * s.segs);
+    int64_t g = (int64_t)blockIdx.x * PT + threadIdx.x;
+    SegPos q;
+    q.r = g / s.segs;
+    q.sgm = (int)(g - q.r * s.segs);
+    for (; g < s.n_threads; g += stride) {
+        uint64_t w[3], key[PK];
+        seg_load(s, q, w);
+        const int v = seg_keys(s, q.sgm, w, key);
+#pragma unroll
+        for (int i = 0; i < PK; i++)
+            if (i < v) atomicAdd(&h[digit_of(key[i], lv)], 1u);
+        q.r += dq; q.sgm += dr;
+        if (q.sgm >= s.segs) { q.sgm -= s.segs; q.r++; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += PT) blockhist[(int64_t)i * gridDim.x + blockIdx.x] = h[i];
+}
+
+// bucket offsets of the next level = every bin's first workgroup entry of the scanned table
+__global__ void k_bin_offsets(const uint64_t *__restrict__ scanned, int nb, int64_t grid,
+                              uint64_t *__restrict__ seg_off) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= nb) seg_off[i] = scanned[(int64_t)i * grid];      // entry nb*grid = total
+}
+
+// persistent scatter: private cursors in LDS (no atomics); the next tile's words are in flight
+// while this tile is ranked, placed and copied out
+__global__ __launch_bounds__(PT) void k_reads_scatter(ReadSrc s, Level lv, const uint64_t *__restrict__ scanned,
+                                                      uint64_t *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const ScatterLds l = scatter_lds(smem);
+    uint64_t *priv = reinterpret_cast<uint64_t *>(l.cnt + (1 << MAX_BITS));     // 2^bits running cursors
+    __shared__ uint32_t wsum[PT / 64];
+    const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
+    for (int i = threadIdx.x; i < nb; i += PT) priv[i] = scanned[(int64_t)i * gridDim.x + blockIdx.x];
+    const int64_t stride = (int64_t)gridDim.x * PT;
+    const int64_t dq = stride / s.segs;
+    const int dr = (int)(stride - dq * s.segs);
+    int64_t g = (int64_t)blockIdx.x * PT + threadIdx.x;
+    SegPos q;
+    q.r = g / s.segs;
+    q.sgm = (int)(g - q.r * s.segs);
+    uint64_t w[3] = {0, 0, 0};
+    if (g < s.n_threads) seg_load(s, q, w);
+    const int64_t tiles = (s.n_threads + PT - 1) / PT;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x, g += stride) {
+        for (int i = threadIdx.x; i < nb; i += PT) l.cnt[i] = 0;
+        __syncthreads();
+        uint64_t key[PK];
+        uint32_t rank[PK];
+        bool ok[PK];
+        const int v = g < s.n_threads ? seg_keys(s, q.sgm, w, key) : 0;
+        // advance and prefetch the next tile's words
+        q.r += dq; q.sgm += dr;
+        if (q.sgm >= s.segs) { q.sgm -= s.segs; q.r++; }
+        if (g + stride < s.n_threads) seg_load(s, q, w);
+#pragma unroll
+        for (int i = 0; i < PK; i++) {
+            ok[i] = i < v;
+            if (ok[i]) {
+                const unsigned d = digit_of(key[i], lv);
+                rank[i] = atomicAdd(&l.cnt[d], 1u) | (d << 16);     // rank < 8192 fits 16 bits
+            }
+        }
+        __syncthreads();
+        scatter_tile<true>(l, lv, 0, key, rank, ok, nullptr, priv, out, wsum);
+    }
+}
+
+// ------------------------------------------------- levels >= 2 (and arrays)
 
 // tile -> (segment, first slot, count).  seg_off[nseg+1] element offsets of the parent
 // buckets, tile_start[nseg+1] exclusive scan of tiles per segment.
@@ -133,137 +321,85 @@ __global__ void k_tiles_per_seg(const uint64_t *__restrict__ seg_off, int64_t ns
     if (s < nseg) tiles[s] = (seg_off[s + 1] - seg_off[s] + PTILE - 1) / PTILE;
 }
 
-// Loads this thread's PK instances of the tile (slot = begin + i*PT + tid) into key[].
-template <bool FROM_READS>
-__device__ __forceinline__ void load_tile(const Src &src, int64_t begin, int count, uint64_t (&key)[PK]) {
-    if (FROM_READS) {
-        int64_t slot = begin + threadIdx.x;
-        int64_t r = slot / src.nk;
-        int p = (int)(slot - r * src.nk);
-#pragma unroll
-        for (int i = 0; i < PK; i++) {
-            int idx = i * PT + threadIdx.x;
-            if (idx < count) key[i] = canonical(kmer_at(src.words + r * src.wpr, src.fc + p, src.k), src.k);
-            else key[i] = 0;
-            p += PT;
-            int q = p / src.nk;
-            r += q; p -= q * src.nk;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < PK; i++) {
-            int idx = i * PT + threadIdx.x;
-            key[i] = idx < count ? src.kmers[begin + idx] : 0;
-        }
-    }
-}
-
-template <bool FROM_READS>
-__global__ __launch_bounds__(PT) void k_level_hist(Src src, const uint64_t *__restrict__ seg_off,
+__global__ __launch_bounds__(PT) void k_level_hist(const uint64_t *__restrict__ kmers,
+                                                   const uint64_t *__restrict__ seg_off,
                                                    const uint64_t *__restrict__ tile_start, int64_t nseg,
                                                    Level lv, unsigned long long *__restrict__ hist) {
     __shared__ uint32_t h[1 << MAX_BITS];
+    __shared__ uint64_t s_parent;
     int64_t begin; int count;
     if (!locate_tile(seg_off, tile_start, nseg, blockIdx.x, &begin, &count)) return;
     const int nb = 1 << lv.bits;
     for (int i = threadIdx.x; i < nb; i += PT) h[i] = 0;
     __syncthreads();
     uint64_t key[PK];
-    load_tile<FROM_READS>(src, begin, count, key);
-    uint64_t parent = 0;
 #pragma unroll
     for (int i = 0; i < PK; i++) {
-        int idx = i * PT + threadIdx.x;
-        if (idx < count) {
-            uint64_t hh = local_hash(key[i]);
+        const int idx = i * PT + threadIdx.x;
+        key[i] = idx < count ? kmers[begin + idx] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < PK; i++) {
+        if (i * PT + (int)threadIdx.x < count) {
+            const uint64_t hh = local_hash(key[i]);
             atomicAdd(&h[(hh >> lv.shift) & (nb - 1)], 1u);
-            if (i == 0) parent = lv.parent_shift >= 64 ? 0 : (hh >> lv.parent_shift);
-        }
-    }
-    __shared__ uint64_t s_parent;
-    if (threadIdx.x == 0) s_parent = parent;       // thread 0 always holds a valid instance
-    __syncthreads();
-    for (int i = threadIdx.x; i < nb; i += PT) {
-        uint32_t c = h[i];
-        if (c) atomicAdd(&hist[(s_parent << lv.bits) | (uint64_t)i], (unsigned long long)c);
-    }
-}
-
-// LDS: sorted tile (PTILE keys) + per-digit count / local offset / reserved global base
-template <bool FROM_READS>
-__global__ __launch_bounds__(PT) void k_level_scatter(Src src, const uint64_t *__restrict__ seg_off,
-                                                      const uint64_t *__restrict__ tile_start, int64_t nseg,
-                                                      Level lv, unsigned long long *__restrict__ cursor,
-                                                      uint64_t *__restrict__ out) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    uint64_t *skey = reinterpret_cast<uint64_t *>(smem);                      // PTILE
-    uint64_t *gbase = skey + PTILE;                                           // 2^bits
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(gbase + (1 << MAX_BITS));    // 2^bits
-    uint32_t *loff = cnt;      // aliases cnt: every count is read before the scan's barrier
-    __shared__ uint32_t wsum[PT / 64];
-    __shared__ uint64_t s_parent;
-
-    int64_t begin; int count;
-    if (!locate_tile(seg_off, tile_start, nseg, blockIdx.x, &begin, &count)) return;
-    const int nb = 1 << lv.bits;
-    for (int i = threadIdx.x; i < nb; i += PT) cnt[i] = 0;
-    __syncthreads();
-
-    uint64_t key[PK];
-    uint32_t rank[PK];
-    load_tile<FROM_READS>(src, begin, count, key);
-#pragma unroll
-    for (int i = 0; i < PK; i++) {
-        int idx = i * PT + threadIdx.x;
-        if (idx < count) {
-            uint64_t hh = local_hash(key[i]);
-            unsigned d = (unsigned)((hh >> lv.shift) & (nb - 1));
-            rank[i] = atomicAdd(&cnt[d], 1u) | (d << 16);       // rank < 8192 fits 16 bits
             if (i == 0 && threadIdx.x == 0) s_parent = lv.parent_shift >= 64 ? 0 : (hh >> lv.parent_shift);
         }
     }
     __syncthreads();
-    // local exclusive offsets (nb <= 1024 = 2 per thread at most) and global reservation
-    {
-        uint32_t c0 = 0, c1 = 0;
-        int d0 = 2 * threadIdx.x, d1 = d0 + 1;
-        if (d0 < nb) c0 = cnt[d0];
-        if (d1 < nb) c1 = cnt[d1];
-        uint32_t ex = block_exclusive_scan(c0 + c1, wsum, nullptr);
-        if (d0 < nb) {
-            loff[d0] = ex;
-            gbase[d0] = c0 ? atomicAdd(&cursor[(s_parent << lv.bits) | (uint64_t)d0], (unsigned long long)c0) : 0;
-        }
-        if (d1 < nb) {
-            loff[d1] = ex + c0;
-            gbase[d1] = c1 ? atomicAdd(&cursor[(s_parent << lv.bits) | (uint64_t)d1], (unsigned long long)c1) : 0;
-        }
+    for (int i = threadIdx.x; i < nb; i += PT) {
+        const uint32_t c = h[i];
+        if (c) atomicAdd(&hist[(s_parent << lv.bits) | (uint64_t)i], (unsigned long long)c);
     }
+}
+
+__global__ __launch_bounds__(PT) void k_level_scatter(const uint64_t *__restrict__ kmers,
+                                                      const uint64_t *__restrict__ seg_off,
+                                                      const uint64_t *__restrict__ tile_start, int64_t nseg,
+                                                      Level lv, unsigned long long *__restrict__ cursor,
+                                                      uint64_t *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const ScatterLds l = scatter_lds(smem);
+    __shared__ uint32_t wsum[PT / 64];
+    __shared__ uint64_t s_parent;
+    int64_t begin; int count;
+    if (!locate_tile(seg_off, tile_start, nseg, blockIdx.x, &begin, &count)) return;
+    const int nb = 1 << lv.bits;
+    for (int i = threadIdx.x; i < nb; i += PT) l.cnt[i] = 0;
     __syncthreads();
+    uint64_t key[PK];
+    uint32_t rank[PK];
+    bool ok[PK];
 #pragma unroll
     for (int i = 0; i < PK; i++) {
-        int idx = i * PT + threadIdx.x;
-        if (idx < count) {
-            unsigned d = rank[i] >> 16;
-            skey[loff[d] + (rank[i] & 0xFFFFu)] = key[i];
+        const int idx = i * PT + threadIdx.x;
+        ok[i] = idx < count;
+        key[i] = ok[i] ? kmers[begin + idx] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < PK; i++) {
+        if (ok[i]) {
+            const uint64_t hh = local_hash(key[i]);
+            const unsigned d = (unsigned)((hh >> lv.shift) & (nb - 1));
+            rank[i] = atomicAdd(&l.cnt[d], 1u) | (d << 16);
+            if (i == 0 && threadIdx.x == 0) s_parent = lv.parent_shift >= 64 ? 0 : (hh >> lv.parent_shift);
         }
     }
     __syncthreads();
-    // copy out: consecutive lanes write consecutive elements of a digit's run
-    for (int i = threadIdx.x; i < count; i += PT) {
-        uint64_t kk = skey[i];
-        unsigned d = (unsigned)((local_hash(kk) >> lv.shift) & (nb - 1));
-        out[gbase[d] + (uint64_t)(i - loff[d])] = kk;
-    }
+    scatter_tile<false>(l, lv, s_parent, key, rank, ok, cursor, nullptr, out, wsum);
 }
 
 // ------------------------------------------------------------------- leaves
 
-constexpr int LT = 256;                 // threads per leaf workgroup
+constexpr int LT = 512;                 // threads per leaf workgroup
+constexpr int OBUF = 1024;              // survivors buffered in LDS between flushes
 constexpr int LCAP = 4096;              // hash slots
 constexpr int LFULL = (LCAP * 3) / 4;   // give up on a sub-pass beyond this many distinct keys
 constexpr uint64_t EMPTY = ~0ULL;
 constexpr int LSTACK = 48;
+constexpr int LB = 8;                   // instance loads in flight per lane
+constexpr int LEAF_SLOT_SHIFT = 22;     // bits of local_hash below the <= 30 digit bits
+constexpr int LEAF_SPLIT_SHIFT = 6;
 
 struct CountOut {
     unsigned long long n_out;        // survivors appended (may exceed cap)
@@ -271,6 +407,12 @@ struct CountOut {
     unsigned long long n_failed;     // leaves that ran out of split depth (must stay 0)
 };
 
+// Persistent workgroups walk the leaf buckets; each bucket is streamed through an LDS hash table
+// (k-mer -> count).  Equal k-mers inside a wave are combined first (wave64 ballots over an 8-bit
+// digest, then an exact key compare against the group leader), so a k-mer seen 1000x costs one LDS
+// atomic per wave round instead of 64 serialised ones.  Survivors collect in an LDS buffer and
+// leave with ONE global atomic per flush: a per-leaf atomic on a single hot counter serialises the
+// whole grid (measured: 24 ms of a 25 ms kernel).
 __global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ keys,
                                                    const uint64_t *__restrict__ leaf_off, int64_t nleaf,
                                                    int min_cov, int max_cov, int apply_filter,
@@ -278,10 +420,31 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ 
                                                    unsigned long long cap, CountOut *__restrict__ co) {
     __shared__ unsigned long long tkey[LCAP];
     __shared__ uint32_t tcnt[LCAP];
+    __shared__ unsigned long long obk[OBUF];
+    __shared__ int32_t obc[OBUF];
     __shared__ uint32_t stackS[LSTACK], stacks[LSTACK];
     __shared__ int sp;
-    __shared__ uint32_t n_dist, overflow, n_emit, emit_pos;
+    __shared__ uint32_t n_dist, overflow, n_emit, emit_pos, ob_n;
     __shared__ unsigned long long g_emit;
+    const int lane = threadIdx.x & 63;
+    unsigned long long my_distinct = 0;            // thread 0 only
+    if (threadIdx.x == 0) ob_n = 0;
+
+    // flush the survivor buffer (all threads call)
+    auto flush = [&]() {
+        __syncthreads();
+        const uint32_t cntv = ob_n;
+        if (cntv == 0) return;
+        if (threadIdx.x == 0) g_emit = atomicAdd(&co->n_out, (unsigned long long)cntv);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cntv; i += LT) {
+            const unsigned long long pos = g_emit + i;
+            if (pos < cap) { out_keys[pos] = obk[i]; out_counts[pos] = obc[i]; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) ob_n = 0;
+        __syncthreads();
+    };
 
     for (int64_t leaf = blockIdx.x; leaf < nleaf; leaf += gridDim.x) {
         const uint64_t begin = leaf_off[leaf], end = leaf_off[leaf + 1];
@@ -296,28 +459,58 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ 
             if (threadIdx.x == 0) { sp--; n_dist = 0; overflow = 0; n_emit = 0; emit_pos = 0; }
             for (int i = threadIdx.x; i < LCAP; i += LT) { tkey[i] = EMPTY; tcnt[i] = 0; }
             __syncthreads();
-            for (uint64_t i = begin + threadIdx.x; i < end; i += LT) {
-                const uint64_t key = keys[i];
-                const uint64_t h = local_hash(key);
-                if (S > 1 && ((uint32_t)(h >> 12) & (S - 1)) != s) continue;
-                uint32_t slot = (uint32_t)h & (LCAP - 1);
-                for (int probe = 0; probe < LCAP; probe++) {
-                    unsigned long long prev = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
-                    if (prev == EMPTY) {
-                        if (atomicAdd(&n_dist, 1u) >= (uint32_t)LFULL) overflow = 1;
-                        atomicAdd(&tcnt[slot], 1u);
-                        break;
-                    }
-                    if (prev == key) { atomicAdd(&tcnt[slot], 1u); break; }
-                    slot = (slot + 1) & (LCAP - 1);
-                    if (probe == LCAP - 1) overflow = 1;
+            // whole waves iterate together (ballots need every lane); LB loads in flight per lane
+            for (uint64_t base = begin; base < end; base += (uint64_t)LT * LB) {
+                uint64_t kbuf[LB];
+#pragma unroll
+                for (int j = 0; j < LB; j++) {
+                    const uint64_t i = base + (uint64_t)j * LT + threadIdx.x;
+                    kbuf[j] = i < end ? keys[i] : 0;
                 }
-                if (overflow) break;               // the sub-pass is abandoned anyway
+#pragma unroll
+                for (int j = 0; j < LB; j++) {
+                    bool ok = base + (uint64_t)j * LT + threadIdx.x < end;
+                    const uint64_t key = kbuf[j];
+                    const uint64_t h = local_hash(key);
+                    if (S > 1 && ((uint32_t)(h >> LEAF_SPLIT_SHIFT) & (S - 1)) != s) ok = false;
+                    uint32_t slot = (uint32_t)(h >> LEAF_SLOT_SHIFT) & (LCAP - 1);
+                    // group lanes by the low 8 bits of the slot, then confirm the key
+                    uint64_t peers = __ballot(ok);
+#pragma unroll
+                    for (int b = 0; b < 8; b++) {
+                        uint64_t m = __ballot((slot >> b) & 1u);
+                        peers &= ((slot >> b) & 1u) ? m : ~m;
+                    }
+                    uint32_t mult = 1;
+                    {
+                        const int leader = peers ? __ffsll((unsigned long long)peers) - 1 : lane;
+                        const uint64_t lkey = __shfl(key, leader, 64);
+                        const bool eq = ok && key == lkey;
+                        const uint64_t same = __ballot(eq) & peers;      // lanes equal to their group leader
+                        if (eq) {
+                            if (lane != leader) ok = false;              // the leader inserts for the group
+                            else mult = (uint32_t)__popcll(same);
+                        }
+                    }
+                    if (ok) {
+                        for (int probe = 0; probe < LCAP; probe++) {
+                            unsigned long long prev = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
+                            if (prev == EMPTY) {
+                                if (atomicAdd(&n_dist, 1u) >= (uint32_t)LFULL) overflow = 1;
+                                atomicAdd(&tcnt[slot], mult);
+                                break;
+                            }
+                            if (prev == key) { atomicAdd(&tcnt[slot], mult); break; }
+                            slot = (slot + 1) & (LCAP - 1);
+                            if (probe == LCAP - 1) overflow = 1;
+                        }
+                    }
+                }
             }
             __syncthreads();
             if (overflow) {
                 if (threadIdx.x == 0) {
-                    if (sp + 2 <= LSTACK && S < (1u << 20)) {
+                    if (sp + 2 <= LSTACK && S < (1u << 16)) {
                         stackS[sp] = 2 * S; stacks[sp] = s + S; sp++;
                         stackS[sp] = 2 * S; stacks[sp] = s;     sp++;
                     } else {
@@ -326,7 +519,7 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ 
                 }
                 continue;
             }
-            // emit survivors of this sub-pass
+            // survivors of this sub-pass
             for (int i = threadIdx.x; i < LCAP; i += LT) {
                 if (tkey[i] != EMPTY) {
                     int32_t c = (int32_t)tcnt[i];
@@ -334,87 +527,43 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ 
                 }
             }
             __syncthreads();
-            if (threadIdx.x == 0) {
-                g_emit = n_emit ? atomicAdd(&co->n_out, (unsigned long long)n_emit) : 0;
-                atomicAdd(&co->n_distinct, (unsigned long long)n_dist);
-            }
-            __syncthreads();
-            for (int i = threadIdx.x; i < LCAP; i += LT) {
-                if (tkey[i] != EMPTY) {
-                    int32_t c = (int32_t)tcnt[i];
-                    if (!apply_filter || (c >= min_cov && c <= max_cov)) {
-                        unsigned long long pos = g_emit + atomicAdd(&emit_pos, 1u);
-                        if (pos < cap) { out_keys[pos] = tkey[i]; out_counts[pos] = c; }
+            if (threadIdx.x == 0) my_distinct += n_dist;
+            const uint32_t ne = n_emit;
+            if (ne == 0) continue;
+            if (ob_n + ne > (uint32_t)OBUF) flush();           // uniform: ob_n and n_emit are shared
+            if (ne > (uint32_t)OBUF) {
+                // larger than the buffer (mostly-distinct data with a low cut-off): straight out
+                if (threadIdx.x == 0) g_emit = atomicAdd(&co->n_out, (unsigned long long)ne);
+                __syncthreads();
+                for (int i = threadIdx.x; i < LCAP; i += LT) {
+                    if (tkey[i] != EMPTY) {
+                        int32_t c = (int32_t)tcnt[i];
+                        if (!apply_filter || (c >= min_cov && c <= max_cov)) {
+                            unsigned long long pos = g_emit + atomicAdd(&emit_pos, 1u);
+                            if (pos < cap) { out_keys[pos] = tkey[i]; out_counts[pos] = c; }
+                        }
                     }
                 }
+            } else {
+                const uint32_t ob0 = ob_n;
+                __syncthreads();
+                for (int i = threadIdx.x; i < LCAP; i += LT) {
+                    if (tkey[i] != EMPTY) {
+                        int32_t c = (int32_t)tcnt[i];
+                        if (!apply_filter || (c >= min_cov && c <= max_cov)) {
+                            uint32_t pos = ob0 + atomicAdd(&emit_pos, 1u);
+                            obk[pos] = tkey[i]; obc[pos] = c;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) ob_n = ob0 + ne;
             }
         }
         __syncthreads();
     }
-}
-
-// ------------------------------------------------ owner buckets (multi-GPU)
-
-__global__ __launch_bounds__(PT) void k_owner_hist(Src src, int64_t n, int n_owners,
-                                                   unsigned long long *__restrict__ hist) {
-    __shared__ uint32_t h[64];
-    if (threadIdx.x < 64) h[threadIdx.x] = 0;
-    __syncthreads();
-    int64_t begin = (int64_t)blockIdx.x * PTILE;
-    int count = (int)((n - begin) < PTILE ? (n - begin) : PTILE);
-    uint64_t key[PK];
-    load_tile<true>(src, begin, count, key);
-#pragma unroll
-    for (int i = 0; i < PK; i++) {
-        int idx = i * PT + threadIdx.x;
-        if (idx < count) atomicAdd(&h[(unsigned)__umul64hi(mix64(key[i]), (uint64_t)n_owners)], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < n_owners && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
-}
-
-__global__ __launch_bounds__(PT) void k_owner_scatter(Src src, int64_t n, int n_owners,
-                                                      unsigned long long *__restrict__ cursor,
-                                                      uint64_t *__restrict__ out) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    uint64_t *skey = reinterpret_cast<uint64_t *>(smem);
-    __shared__ uint32_t cnt[64], loff[64];
-    __shared__ uint64_t gbase[64];
-    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
-    __syncthreads();
-    int64_t begin = (int64_t)blockIdx.x * PTILE;
-    int count = (int)((n - begin) < PTILE ? (n - begin) : PTILE);
-    uint64_t key[PK];
-    uint32_t rank[PK];
-    load_tile<true>(src, begin, count, key);
-#pragma unroll
-    for (int i = 0; i < PK; i++) {
-        int idx = i * PT + threadIdx.x;
-        if (idx < count) {
-            unsigned d = (unsigned)__umul64hi(mix64(key[i]), (uint64_t)n_owners);
-            rank[i] = atomicAdd(&cnt[d], 1u) | (d << 16);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int d = 0; d < n_owners; d++) {
-            loff[d] = run; run += cnt[d];
-            gbase[d] = cnt[d] ? atomicAdd(&cursor[d], (unsigned long long)cnt[d]) : 0;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < PK; i++) {
-        int idx = i * PT + threadIdx.x;
-        if (idx < count) { unsigned d = rank[i] >> 16; skey[loff[d] + (rank[i] & 0xFFFFu)] = key[i]; }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < count; i += PT) {
-        uint64_t kk = skey[i];
-        unsigned d = (unsigned)__umul64hi(mix64(kk), (uint64_t)n_owners);
-        out[gbase[d] + (uint64_t)(i - loff[d])] = kk;
-    }
+    flush();
+    if (threadIdx.x == 0 && my_distinct) atomicAdd(&co->n_distinct, my_distinct);
 }
 
 // ------------------------------------------------------------ synthetic reads
@@ -467,6 +616,8 @@ __global__ void k_synth_reads(uint64_t sp, uint64_t se, const uint64_t *__restri
 }
 
 size_t scatter_lds_bytes() { return (size_t)PTILE * 8 + (size_t)(1 << MAX_BITS) * (8 + 4); }
+// + the private running cursors; only the first 2^bits entries are touched
+size_t reads_scatter_lds_bytes(int nb) { return scatter_lds_bytes() + (size_t)nb * 8; }
 
 }  // namespace
 
@@ -509,13 +660,51 @@ int64_t count_workspace_bytes(int64_t n_kmers) { return 2 * n_kmers * 8 + (int64
 
 static void plan_levels(int64_t n, bool from_reads, std::vector<int> &bits) {
     bits.clear();
-    const double target = 8192.0;
+    if (const char *e = getenv("RFX_LEVEL_BITS")) {          // tuning override, e.g. "9,9"
+        for (const char *q = e; *q;) {
+            int v = atoi(q);
+            if (v >= 0 && v <= MAX_BITS) bits.push_back(v);
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+        if (!bits.empty()) return;
+    }
+    double target = 8192.0;
+    if (const char *e = getenv("RFX_LEAF_TARGET")) target = atof(e) > 0 ? atof(e) : target;
     int B = 0;
     if ((double)n > target) B = (int)std::ceil(std::log2((double)n / target));
     if (B > 3 * MAX_BITS) B = 3 * MAX_BITS;
     int L = (B + MAX_BITS - 1) / MAX_BITS;
-    for (int l = 0; l < L; l++) bits.push_back(B / L + (l < B % L ? 1 : 0));
+    for (int l = 0; l < L; l++) bits.push_back(B / L + (l >= L - B % L ? 1 : 0));   // later levels take the extra bit
     if (bits.empty() && from_reads) bits.push_back(0);   // materialise the instances once
+}
+
+static ReadSrc make_read_src(const ReadStore *reads) {
+    ReadSrc s{};
+    s.words = reads->words; s.n_reads = reads->n_reads; s.wpr = reads->words_per_read;
+    s.fc = reads->front_clip; s.k = reads->k;
+    s.nk = (int)kmers_per_read(reads->read_len, reads->k, reads->front_clip, reads->end_clip);
+    s.segs = s.nk > 0 ? (s.nk + PK - 1) / PK : 1;
+    s.n_threads = s.n_reads * s.segs;
+    return s;
+}
+
+static int set_scatter_attrs(rfx_ctx *ctx) {
+    static bool done = false;
+    if (done) return RFX_OK;
+    RFX_HIP(hipFuncSetAttribute((const void *)k_level_scatter, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)scatter_lds_bytes()));
+    RFX_HIP(hipFuncSetAttribute((const void *)k_reads_scatter, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)reads_scatter_lds_bytes(1 << MAX_BITS)));
+    done = true;
+    return RFX_OK;
+}
+
+// grid of the persistent reads kernels: a few workgroups per CU, never more than tiles
+static unsigned reads_grid(rfx_ctx *ctx, const ReadSrc &s, int per_cu) {
+    int64_t tiles = ceil_div(s.n_threads, PT);
+    int64_t g = (int64_t)ctx->num_cu * per_cu;
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, g));
 }
 
 int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, int64_t n,
@@ -524,16 +713,13 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
                  int64_t *out_n, int64_t *out_distinct) {
     (void)ws; (void)ws_bytes;
     ctx->timing.clear();
-    Src src{};
+    ReadSrc rsrc{};
     int k_bits = 64;
     const bool from_reads = reads != nullptr;
     if (from_reads) {
-        src.words = reads->words; src.wpr = reads->words_per_read; src.fc = reads->front_clip; src.k = reads->k;
-        src.nk = (int)kmers_per_read(reads->read_len, reads->k, reads->front_clip, reads->end_clip);
-        n = (int64_t)src.nk * reads->n_reads;
+        rsrc = make_read_src(reads);
+        n = (int64_t)rsrc.nk * reads->n_reads;
         k_bits = 2 * reads->k;
-    } else {
-        src.kmers = d_kmers;
     }
     if (out_n) *out_n = 0;
     if (out_distinct) *out_distinct = 0;
@@ -541,15 +727,7 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
 
     std::vector<int> bits;
     plan_levels(n, from_reads, bits);
-
-    static bool attr_set = false;
-    if (!attr_set) {
-        RFX_HIP(hipFuncSetAttribute((const void *)k_level_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)scatter_lds_bytes()));
-        RFX_HIP(hipFuncSetAttribute((const void *)k_level_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)scatter_lds_bytes()));
-        attr_set = true;
-    }
+    RFX_TRY(set_scatter_attrs(ctx));
 
     DevBuf bufA, bufB, segA, segB, tiles, tile_start, hist, cursor, co_buf;
     uint64_t seg_init[2] = {0, (uint64_t)n};
@@ -565,57 +743,76 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
     for (size_t l = 0; l < bits.size(); l++) {
         Level lv;
         lv.bits = bits[l];
+        lv.n_owners = 0;
         lv.parent_shift = 64 - used_bits;
         used_bits += bits[l];
         lv.shift = 64 - used_bits;
         if (lv.shift >= 64) lv.shift = 63;            // bits == 0 on the first level: digit mask is 0
         const int64_t nchild = nseg << lv.bits;
-        const int64_t max_tiles = ceil_div(n, PTILE) + nseg;
-        RFX_HIP(tiles.alloc((size_t)nseg * 8, ctx->stream));
-        RFX_HIP(tile_start.alloc((size_t)(nseg + 1) * 8, ctx->stream));
-        hipLaunchKernelGGL(k_tiles_per_seg, dim3((unsigned)ceil_div(nseg, 256)), dim3(256), 0, ctx->stream,
-                           (const uint64_t *)seg_cur->as<uint64_t>(), nseg, tiles.as<uint64_t>());
-        RFX_HIP(hipGetLastError());
-        RFX_TRY(exclusive_scan_u64(ctx, tiles.as<uint64_t>(), tile_start.as<uint64_t>(), nseg));
         RFX_HIP(hist.alloc((size_t)nchild * 8, ctx->stream));
         RFX_HIP(hipMemsetAsync(hist.p, 0, (size_t)nchild * 8, ctx->stream));
         RFX_HIP(seg_next->alloc((size_t)(nchild + 1) * 8, ctx->stream));
-        Src s2 = src;
-        if (!cur_from_reads) { s2.kmers = cur_arr; s2.words = nullptr; }
-        {
-            ScopedTimer t(ctx, l == 0 ? "hist1" : l == 1 ? "hist2" : "hist3");
-            if (cur_from_reads)
-                hipLaunchKernelGGL(k_level_hist<true>, dim3((unsigned)max_tiles), dim3(PT), 0, ctx->stream, s2,
-                                   (const uint64_t *)seg_cur->as<uint64_t>(), (const uint64_t *)tile_start.as<uint64_t>(),
-                                   nseg, lv, hist.as<unsigned long long>());
-            else
-                hipLaunchKernelGGL(k_level_hist<false>, dim3((unsigned)max_tiles), dim3(PT), 0, ctx->stream, s2,
-                                   (const uint64_t *)seg_cur->as<uint64_t>(), (const uint64_t *)tile_start.as<uint64_t>(),
-                                   nseg, lv, hist.as<unsigned long long>());
-            RFX_HIP(hipGetLastError());
+        if (!out_buf->p) {
+            // the two big instance buffers live in the context (grow-only), not in the pool
+            void *wsp = ctx->ws_get(out_buf == &bufA ? 0 : 1, (size_t)n * 8);
+            if (!wsp) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
+            out_buf->p = wsp; out_buf->borrowed = true;
         }
-        RFX_TRY(exclusive_scan_u64(ctx, hist.as<uint64_t>(), seg_next->as<uint64_t>(), nchild));
         RFX_HIP(cursor.alloc((size_t)nchild * 8, ctx->stream));
-        RFX_HIP(hipMemcpyAsync(cursor.p, seg_next->p, (size_t)nchild * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        RFX_HIP(out_buf->alloc((size_t)n * 8, ctx->stream));
-        {
-            ScopedTimer t(ctx, l == 0 ? "part1" : l == 1 ? "part2" : "part3");
-            if (cur_from_reads)
-                hipLaunchKernelGGL(k_level_scatter<true>, dim3((unsigned)max_tiles), dim3(PT), scatter_lds_bytes(),
-                                   ctx->stream, s2, (const uint64_t *)seg_cur->as<uint64_t>(),
-                                   (const uint64_t *)tile_start.as<uint64_t>(), nseg, lv,
-                                   cursor.as<unsigned long long>(), out_buf->as<uint64_t>());
-            else
-                hipLaunchKernelGGL(k_level_scatter<false>, dim3((unsigned)max_tiles), dim3(PT), scatter_lds_bytes(),
-                                   ctx->stream, s2, (const uint64_t *)seg_cur->as<uint64_t>(),
-                                   (const uint64_t *)tile_start.as<uint64_t>(), nseg, lv,
-                                   cursor.as<unsigned long long>(), out_buf->as<uint64_t>());
+        const char *hn = l == 0 ? "hist1" : l == 1 ? "hist2" : "hist3";
+        const char *pn = l == 0 ? "part1" : l == 1 ? "part2" : "part3";
+        if (cur_from_reads) {
+            // level 1 straight from the packed reads: per-workgroup histogram rows, one scan,
+            // then a scatter with private cursors (same grid, same tile assignment, no atomics)
+            const int nb = 1 << lv.bits;
+            const unsigned G = reads_grid(ctx, rsrc, nb <= 512 ? 2 : 1);
+            DevBuf bh, scanned;
+            RFX_HIP(bh.alloc((size_t)nb * G * 8, ctx->stream));
+            RFX_HIP(scanned.alloc(((size_t)nb * G + 1) * 8, ctx->stream));
+            {
+                ScopedTimer t(ctx, hn);
+                hipLaunchKernelGGL(k_reads_hist, dim3(G), dim3(PT), 0, ctx->stream, rsrc, lv, bh.as<uint64_t>());
+                RFX_HIP(hipGetLastError());
+            }
+            RFX_TRY(exclusive_scan_u64(ctx, bh.as<uint64_t>(), scanned.as<uint64_t>(), (int64_t)nb * G));
+            hipLaunchKernelGGL(k_bin_offsets, dim3((unsigned)ceil_div(nb + 1, 256)), dim3(256), 0, ctx->stream,
+                               (const uint64_t *)scanned.as<uint64_t>(), nb, (int64_t)G, seg_next->as<uint64_t>());
             RFX_HIP(hipGetLastError());
+            {
+                ScopedTimer t(ctx, pn);
+                hipLaunchKernelGGL(k_reads_scatter, dim3(G), dim3(PT), reads_scatter_lds_bytes(nb), ctx->stream, rsrc,
+                                   lv, (const uint64_t *)scanned.as<uint64_t>(), out_buf->as<uint64_t>());
+                RFX_HIP(hipGetLastError());
+            }
+        } else {
+            const int64_t max_tiles = ceil_div(n, PTILE) + nseg;
+            RFX_HIP(tiles.alloc((size_t)nseg * 8, ctx->stream));
+            RFX_HIP(tile_start.alloc((size_t)(nseg + 1) * 8, ctx->stream));
+            hipLaunchKernelGGL(k_tiles_per_seg, dim3((unsigned)ceil_div(nseg, 256)), dim3(256), 0, ctx->stream,
+                               (const uint64_t *)seg_cur->as<uint64_t>(), nseg, tiles.as<uint64_t>());
+            RFX_HIP(hipGetLastError());
+            RFX_TRY(exclusive_scan_u64(ctx, tiles.as<uint64_t>(), tile_start.as<uint64_t>(), nseg));
+            {
+                ScopedTimer t(ctx, hn);
+                hipLaunchKernelGGL(k_level_hist, dim3((unsigned)max_tiles), dim3(PT), 0, ctx->stream, cur_arr,
+                                   (const uint64_t *)seg_cur->as<uint64_t>(), (const uint64_t *)tile_start.as<uint64_t>(),
+                                   nseg, lv, hist.as<unsigned long long>());
+                RFX_HIP(hipGetLastError());
+            }
+            RFX_TRY(exclusive_scan_u64(ctx, hist.as<uint64_t>(), seg_next->as<uint64_t>(), nchild));
+            RFX_HIP(hipMemcpyAsync(cursor.p, seg_next->p, (size_t)nchild * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            {
+                ScopedTimer t(ctx, pn);
+                hipLaunchKernelGGL(k_level_scatter, dim3((unsigned)max_tiles), dim3(PT), scatter_lds_bytes(),
+                                   ctx->stream, cur_arr, (const uint64_t *)seg_cur->as<uint64_t>(),
+                                   (const uint64_t *)tile_start.as<uint64_t>(), nseg, lv,
+                                   cursor.as<unsigned long long>(), out_buf->as<uint64_t>());
+                RFX_HIP(hipGetLastError());
+            }
         }
         cur_arr = out_buf->as<uint64_t>();
         cur_from_reads = false;
         std::swap(out_buf, in_buf);
-        if (l + 1 < bits.size()) out_buf->release();   // the buffer two levels back is dead
         std::swap(seg_cur, seg_next);
         nseg = nchild;
     }
@@ -625,7 +822,7 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
     const int apply = !(twin == RFX_TWIN_RDD && min_cov <= 1);    // P/ReflexivMain.java:160
     {
         ScopedTimer t(ctx, "leaf");
-        int64_t grid = std::min<int64_t>(nseg, (int64_t)1 << 22);
+        int64_t grid = std::min<int64_t>(nseg, (int64_t)ctx->num_cu * 2);      // persistent, 60 KB LDS each
         hipLaunchKernelGGL(k_leaf_count, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, cur_arr,
                            (const uint64_t *)seg_cur->as<uint64_t>(), nseg, min_cov, max_cov, apply, d_out_keys,
                            d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>());
@@ -657,33 +854,28 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
 int bucket_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, uint64_t *d_out, int64_t cap,
                     int64_t *d_owner_off, int64_t *h_owner_off) {
     if (n_owners < 1 || n_owners > 64) return RFX_E_ARG;
-    Src src{};
-    src.words = reads->words; src.wpr = reads->words_per_read; src.fc = reads->front_clip; src.k = reads->k;
-    src.nk = (int)kmers_per_read(reads->read_len, reads->k, reads->front_clip, reads->end_clip);
-    const int64_t n = (int64_t)src.nk * reads->n_reads;
+    ReadSrc rsrc = make_read_src(reads);
+    const int64_t n = (int64_t)rsrc.nk * reads->n_reads;
     if (n > cap) return RFX_E_CAP;
-    static bool attr_set = false;
-    if (!attr_set) {
-        RFX_HIP(hipFuncSetAttribute((const void *)k_owner_scatter, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    PTILE * 8));
-        attr_set = true;
-    }
-    DevBuf hist, cursor;
-    RFX_HIP(hist.alloc(64 * 8, ctx->stream));
-    RFX_HIP(cursor.alloc(64 * 8, ctx->stream));
-    RFX_HIP(hipMemsetAsync(hist.p, 0, 64 * 8, ctx->stream));
-    const int64_t tiles = ceil_div(n, PTILE);
-    if (tiles > 0) {
-        hipLaunchKernelGGL(k_owner_hist, dim3((unsigned)tiles), dim3(PT), 0, ctx->stream, src, n, n_owners,
-                           hist.as<unsigned long long>());
+    RFX_TRY(set_scatter_attrs(ctx));
+    Level lv{};
+    lv.bits = 6; lv.shift = 0; lv.parent_shift = 64; lv.n_owners = n_owners;
+    const unsigned G = reads_grid(ctx, rsrc, 2);
+    DevBuf bh, scanned;
+    RFX_HIP(bh.alloc((size_t)n_owners * G * 8, ctx->stream));
+    RFX_HIP(scanned.alloc(((size_t)n_owners * G + 1) * 8, ctx->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_reads_hist, dim3(G), dim3(PT), 0, ctx->stream, rsrc, lv, bh.as<uint64_t>());
         RFX_HIP(hipGetLastError());
-    }
-    RFX_TRY(exclusive_scan_u64(ctx, hist.as<uint64_t>(), reinterpret_cast<uint64_t *>(d_owner_off), n_owners));
-    RFX_HIP(hipMemcpyAsync(cursor.p, d_owner_off, (size_t)n_owners * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    if (tiles > 0) {
-        hipLaunchKernelGGL(k_owner_scatter, dim3((unsigned)tiles), dim3(PT), PTILE * 8, ctx->stream, src, n, n_owners,
-                           cursor.as<unsigned long long>(), d_out);
+        RFX_TRY(exclusive_scan_u64(ctx, bh.as<uint64_t>(), scanned.as<uint64_t>(), (int64_t)n_owners * G));
+        hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(256), 0, ctx->stream, (const uint64_t *)scanned.as<uint64_t>(),
+                           n_owners, (int64_t)G, reinterpret_cast<uint64_t *>(d_owner_off));
         RFX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_reads_scatter, dim3(G), dim3(PT), reads_scatter_lds_bytes(n_owners), ctx->stream, rsrc, lv,
+                           (const uint64_t *)scanned.as<uint64_t>(), d_out);
+        RFX_HIP(hipGetLastError());
+    } else {
+        RFX_HIP(hipMemsetAsync(d_owner_off, 0, (size_t)(n_owners + 1) * 8, ctx->stream));
     }
     if (h_owner_off) {
         RFX_HIP(hipMemcpyAsync(h_owner_off, d_owner_off, (size_t)(n_owners + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));

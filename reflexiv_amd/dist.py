@@ -1,0 +1,75 @@
+"""Radix-sharded k-mer counting across the GPUs of one node.
+
+Stands in for the hash shuffle of `reduceByKey` (P/ReflexivMain.java:155;
+`groupBy("value").count()` P/ReflexivDSMain.java:207-209): rank r owns the k-mers whose hash
+falls in shard r of the k-mer space (owner = mulhi(kmer_hash(kmer), world)), so after ONE
+all-to-all(v) every rank holds every instance of its k-mers and counts / filters locally.
+One process per GPU; `torch.distributed` (backend "nccl" = RCCL over xGMI) moves the bytes.
+
+The local compute is an `engine`: `HipEngine` (the product: HIP kernels through the C ABI)
+or, in the CPU test-suite only, a stand-in injected by the test.  This module never
+computes on the CPU itself.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class HipEngine:
+    """Local compute on one MI355X through libreflexiv_hip.so."""
+
+    def __init__(self, rfx):
+        self.rfx = rfx
+
+    def bucket_by_owner(self, reads, n_owners):
+        """reads = dict(words=int64 cuda tensor, n_reads, wpr, read_len, k) ->
+        (kmers int64[N] grouped by owner, owner_off int64[n_owners+1] on the host)."""
+        n = self.rfx.kmers_per_read(reads["read_len"], reads["k"]) * reads["n_reads"]
+        out = torch.empty(max(1, n), dtype=torch.int64, device=reads["words"].device)
+        doff = torch.empty(n_owners + 1, dtype=torch.int64, device=reads["words"].device)
+        torch.cuda.current_stream().synchronize()
+        h = self.rfx.bucket_by_owner_dev(reads["words"].data_ptr(), reads["n_reads"], reads["wpr"],
+                                         reads["read_len"], reads["k"], n_owners, out.data_ptr(), n,
+                                         doff.data_ptr())
+        return out[:n], torch.from_numpy(h.copy())
+
+    def count_kmers(self, kmers, min_cov, max_cov, twin):
+        n = int(kmers.numel())
+        cap = max(1, n)
+        keys = torch.empty(cap, dtype=torch.int64, device=kmers.device)
+        counts = torch.empty(cap, dtype=torch.int32, device=kmers.device)
+        torch.cuda.current_stream().synchronize()
+        m, d = self.rfx.count_kmers_dev(kmers.data_ptr(), n, keys.data_ptr(), counts.data_ptr(), cap,
+                                        min_cov, max_cov, twin)
+        return keys[:m], counts[:m], d
+
+
+def exchange_by_owner(kmers: torch.Tensor, owner_off: torch.Tensor, group=None) -> torch.Tensor:
+    """all-to-all(v): send bucket o of `kmers` to rank o, return the concatenation of what
+    every rank sent to this one (C2 of SURVEY.md 2.4)."""
+    world = dist.get_world_size(group)
+    send_counts = (owner_off[1:] - owner_off[:-1]).to(torch.int64)
+    assert send_counts.numel() == world
+    recv_counts = torch.empty(world, dtype=torch.int64)
+    sc = send_counts.to(kmers.device) if kmers.is_cuda else send_counts
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = rc.cpu()
+    recv = torch.empty(int(recv_counts.sum()), dtype=kmers.dtype, device=kmers.device)
+    dist.all_to_all_single(recv, kmers, output_split_sizes=[int(x) for x in recv_counts],
+                           input_split_sizes=[int(x) for x in send_counts], group=group)
+    return recv
+
+
+def sharded_count(engine, reads, min_cov, max_cov, twin, group=None):
+    """-> (keys, counts) of this rank's shard (ascending), global (instances, distinct, survivors)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    kmers, owner_off = engine.bucket_by_owner(reads, world)
+    recv = exchange_by_owner(kmers, owner_off, group) if world > 1 else kmers
+    keys, counts, distinct = engine.count_kmers(recv, min_cov, max_cov, twin)
+    tot = torch.tensor([int(kmers.numel()), int(distinct), int(keys.numel())], dtype=torch.int64,
+                       device=keys.device)
+    if world > 1:
+        dist.all_reduce(tot, group=group)            # C4-style scalar reduce
+    return keys, counts, [int(x) for x in tot.cpu()]

@@ -1,0 +1,107 @@
+"""world_size-2 gloo rehearsal of the multi-GPU count path (reflexiv_amd/dist.py).
+
+The exchange logic (owner buckets -> all-to-all(v) -> local count -> scalar all-reduce) is
+the product code; the local compute is replaced, in this CPU test only, by an engine built
+on the oracle that buckets with the same owner function as the HIP kernel
+(owner = mulhi(kmer_hash(kmer), world), reflexiv_amd/csrc/rfx_kmer.hip k_owner_*)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle as O
+
+M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def kmer_hash(x):
+    """reflexiv_amd/csrc/rfx_device.h kmer_hash"""
+    with np.errstate(over="ignore"):
+        h = x.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    return h ^ (h >> np.uint64(32))
+
+
+def owner_of(kmers, n):
+    h = kmer_hash(kmers)
+    n = np.uint64(n)
+    lo, hi = h & np.uint64(0xFFFFFFFF), h >> np.uint64(32)
+    return ((hi * n + ((lo * n) >> np.uint64(32))) >> np.uint64(32)).astype(np.int64)
+
+
+class OracleEngine:
+    """CPU stand-in for HipEngine (tests only)."""
+
+    def bucket_by_owner(self, reads, n_owners):
+        km = O.extract_canon(reads["bases"], reads["read_off"], reads["k"])
+        own = owner_of(km, n_owners)
+        order = np.argsort(own, kind="stable")
+        off = np.zeros(n_owners + 1, np.int64)
+        np.cumsum(np.bincount(own, minlength=n_owners), out=off[1:])
+        return torch.from_numpy(km[order].view(np.int64)), torch.from_numpy(off)
+
+    def count_kmers(self, kmers, min_cov, max_cov, twin):
+        k, c, d = O.count_filter(kmers.numpy().view(np.uint64), min_cov, max_cov, twin)
+        return torch.from_numpy(k.view(np.int64)), torch.from_numpy(c), d
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from reflexiv_amd import dist as rd
+        g = O.synth_genome(seed, G)
+        bases, off = O.synth_reads(seed, g, G, rank * per_rank, per_rank, L)    # this rank's read shard
+        reads = dict(bases=bases, read_off=off, k=k)
+        keys, counts, tot = rd.sharded_count(OracleEngine(), reads, min_cov, 10_000_000, O.TWIN_DS)
+        q.put((rank, keys.numpy().view(np.uint64).copy(), counts.numpy().copy(), tot))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_count_equals_global_count(world):
+    seed, G, per_rank, L, k, min_cov = 42, 20_000, 1500, 100, 31, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, G, per_rank, L, k, min_cov, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, per_rank * world, L)
+    km = O.extract_canon(bases, off, k)
+    wk, wc, wd = O.count_filter(km, min_cov)
+    # global scalars agree on every rank
+    for _, _, _, tot in res:
+        assert tot == [len(km), wd, len(wk)]
+    # shards are disjoint, each ascending, owner-consistent, and their union is the global answer
+    allk = np.concatenate([r[1] for r in res]); allc = np.concatenate([r[2] for r in res])
+    for rank, kk, cc, _ in res:
+        assert np.all(kk[1:] > kk[:-1])
+        assert np.all(owner_of(kk, world) == rank)
+    order = np.argsort(allk, kind="stable")
+    assert np.array_equal(allk[order], wk) and np.array_equal(allc[order], wc)
+
+
+def test_owner_function_is_balanced_and_total():
+    rng = np.random.default_rng(1)
+    km = rng.integers(0, 1 << 62, 200_000, dtype=np.uint64)
+    for n in (1, 2, 4, 8):
+        own = owner_of(km, n)
+        assert own.min() >= 0 and own.max() == n - 1
+        cnt = np.bincount(own, minlength=n)
+        assert cnt.min() > 0.9 * len(km) / n

@@ -360,6 +360,9 @@ def test_bucket_by_owner_partitions_kmer_space(rfx, torch_mod):
     km = np.sort(O.extract_canon(bases, off, k))
     got = out.cpu().numpy().view(np.uint64)
     assert np.array_equal(np.sort(got), km)
+    from tests.test_dist_gloo import owner_of
+    for o in range(owners):
+        assert np.all(owner_of(got[h[o]:h[o + 1]], owners) == o)
     # per-owner counting of the buckets == global counting restricted to the bucket
     wk, wc, _ = O.count_filter(km, 2)
     parts = []

@@ -1,0 +1,236 @@
+// ReflexivMain.cpp -- see ReflexivMain.h.  Every call() forwards to one C-ABI entry point.
+#include "ReflexivMain.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace reflexiv {
+
+rfx_records ReflexivSubKmerRDD::view() {
+    rfx_records r{};
+    r.n = size();
+    r.key = key.data(); r.marker = marker.data(); r.ext_off = extOff.data(); r.ext = ext.data();
+    r.left = left.data(); r.right = right.data();
+    r.cap_n = (int64_t)key.size(); r.cap_words = (int64_t)ext.size();
+    return r;
+}
+void ReflexivSubKmerRDD::reserve(int64_t n, int64_t words) {
+    n = std::max<int64_t>(n, 1); words = std::max<int64_t>(words, 1);
+    key.resize(n); marker.resize(n); left.resize(n); right.resize(n); extOff.resize(n + 1); ext.resize(words);
+}
+void ReflexivSubKmerRDD::shrink(const rfx_records &r) {
+    key.resize(r.n); marker.resize(r.n); left.resize(r.n); right.resize(r.n); extOff.resize(r.n + 1);
+    ext.resize(r.n ? extOff[r.n] : 0);
+}
+
+ReflexivMain::ReflexivMain(int device) {
+    int st = rfx_ctx_create(device, &ctx);
+    if (st != RFX_OK) throw RfxException(st, "rfx_ctx_create", "an MI355X (gfx950) is required; there is no CPU path");
+}
+ReflexivMain::~ReflexivMain() { rfx_ctx_destroy(ctx); }
+
+void ReflexivMain::check(int st, const char *where) const {
+    if (st != RFX_OK) throw RfxException(st, where, rfx_last_error(ctx));
+}
+
+// FastqFilterWithQual.call + FastqUnitFilter.call  P/ReflexivMain.java:3080-3113: the 4-line state
+// machine; emits the sequence line of every completed record.
+void ReflexivMain::FastqFilterWithQual::call(const std::string &text, std::vector<uint8_t> &bases,
+                                             std::vector<int64_t> &readOff) const {
+    int lineMark = 0;
+    size_t pos = 0, seqOff = 0, seqLen = 0;
+    bases.clear(); readOff.assign(1, 0);
+    while (pos < text.size()) {
+        size_t e = text.find('\n', pos);
+        if (e == std::string::npos) e = text.size();
+        size_t l = e - pos;
+        if (l > 0 && text[e - 1] == '\r') l--;
+        if (lineMark == 2) lineMark++;                                  // :3093-3096
+        else if (lineMark == 3) {                                       // :3097-3100
+            lineMark++;
+            bases.insert(bases.end(), text.begin() + seqOff, text.begin() + seqOff + seqLen);
+            readOff.push_back((int64_t)bases.size());
+        } else if (l > 0 && text[pos] == '@') lineMark = 1;             // :3101-3104
+        else if (lineMark == 1) { seqOff = pos; seqLen = l; lineMark++; }   // :3105-3108
+        pos = e + 1;
+    }
+}
+
+std::vector<uint64_t> ReflexivMain::ReverseComplementKmerBinaryExtraction::call(
+    const std::vector<uint8_t> &bases, const std::vector<int64_t> &readOff) const {
+    int64_t n = 0;
+    const int64_t nr = (int64_t)readOff.size() - 1;
+    int st = rfx_extract_canon(m.ctx, bases.data(), readOff.data(), nr, m.param.kmerSize, m.param.frontClip,
+                               m.param.endClip, nullptr, 0, &n);
+    if (st != RFX_OK && st != RFX_E_CAP) m.check(st, "rfx_extract_canon");
+    std::vector<uint64_t> out((size_t)std::max<int64_t>(n, 1));
+    m.check(rfx_extract_canon(m.ctx, bases.data(), readOff.data(), nr, m.param.kmerSize, m.param.frontClip,
+                              m.param.endClip, out.data(), n, &n), "rfx_extract_canon");
+    out.resize((size_t)n);
+    return out;
+}
+
+KmerBinaryRDD ReflexivMain::KmerCounting_KmerCoverageFilter::call(const std::vector<uint64_t> &kmers) const {
+    KmerBinaryRDD o;
+    const int64_t n = (int64_t)kmers.size();
+    o.kmer.resize((size_t)std::max<int64_t>(n, 1)); o.count.resize(o.kmer.size());
+    int64_t mm = 0, d = 0;
+    m.check(rfx_count_filter(m.ctx, kmers.data(), n, m.param.minKmerCoverage, m.param.maxKmerCoverage, m.param.twin,
+                             o.kmer.data(), o.count.data(), n, &mm, &d), "rfx_count_filter");
+    o.kmer.resize((size_t)mm); o.count.resize((size_t)mm);
+    return o;
+}
+
+ReflexivSubKmerRDD ReflexivMain::KmerReverseComplement_ForwardSubKmerExtraction::call(const KmerBinaryRDD &in) const {
+    ReflexivSubKmerRDD o;
+    const int64_t n = (int64_t)in.kmer.size();
+    o.reserve(2 * n, 2 * n);
+    rfx_records r = o.view();
+    m.check(rfx_rc_expand_subkmer(m.ctx, in.kmer.data(), in.count.data(), n, m.param.kmerSize, &r), "rfx_rc_expand_subkmer");
+    o.shrink(r);
+    return o;
+}
+
+ReflexivSubKmerRDD ReflexivMain::SortByKey::call(ReflexivSubKmerRDD &in, int P) const {
+    ReflexivSubKmerRDD o;
+    o.reserve(in.size(), (int64_t)in.ext.size());
+    o.partStart.resize((size_t)P + 1);
+    rfx_records ri = in.view(), ro = o.view();
+    m.check(rfx_sort_records(m.ctx, &ri, P, &ro, o.partStart.data()), "rfx_sort_records");
+    o.shrink(ro);
+    return o;
+}
+
+static ReflexivSubKmerRDD fork_call(const ReflexivMain &m, bool reflected, ReflexivSubKmerRDD &in) {
+    ReflexivSubKmerRDD o;
+    const int P = (int)in.partStart.size() - 1;
+    o.reserve(in.size(), in.size());
+    o.partStart.resize(in.partStart.size());
+    rfx_records ri = in.view(), ro = o.view();
+    int st = reflected
+        ? rfx_fork_filter_reflected(m.ctx, &ri, in.partStart.data(), P, m.param.kmerSize, m.param.minErrorCoverage,
+                                    m.param.twin, &ro, o.partStart.data())
+        : rfx_fork_filter_forward(m.ctx, &ri, in.partStart.data(), P, m.param.kmerSize, m.param.minErrorCoverage,
+                                  m.param.twin, &ro, o.partStart.data());
+    m.check(st, reflected ? "rfx_fork_filter_reflected" : "rfx_fork_filter_forward");
+    o.shrink(ro);
+    return o;
+}
+ReflexivSubKmerRDD ReflexivMain::FilterForkSubKmer::call(ReflexivSubKmerRDD &in) const { return fork_call(m, false, in); }
+ReflexivSubKmerRDD ReflexivMain::FilterForkReflectedSubKmer::call(ReflexivSubKmerRDD &in) const { return fork_call(m, true, in); }
+
+ReflexivSubKmerRDD ReflexivMain::ReflectedSubKmerExtractionFromForward::call(ReflexivSubKmerRDD &in) const {
+    ReflexivSubKmerRDD o;
+    o.reserve(in.size(), in.size());
+    rfx_records ri = in.view(), ro = o.view();
+    m.check(rfx_reflect_from_forward(m.ctx, &ri, m.param.kmerSize, &ro), "rfx_reflect_from_forward");
+    o.shrink(ro);
+    o.partStart = in.partStart;
+    return o;
+}
+
+ReflexivSubKmerRDD ReflexivMain::kmerRandomReflection::call(ReflexivSubKmerRDD &in) const {
+    ReflexivSubKmerRDD o;
+    o.reserve(in.size(), in.size());
+    rfx_records ri = in.view(), ro = o.view();
+    m.check(rfx_random_reflection(m.ctx, &ri, in.partStart.data(), (int)in.partStart.size() - 1, m.param.kmerSize, &ro),
+            "rfx_random_reflection");
+    o.shrink(ro);
+    o.partStart = in.partStart;
+    return o;
+}
+
+ReflexivSubKmerRDD ReflexivMain::ExtendReflexivKmer::call(ReflexivSubKmerRDD &in) const {
+    ReflexivSubKmerRDD o;
+    const int P = (int)in.partStart.size() - 1;
+    o.reserve(in.size(), (int64_t)in.ext.size());
+    o.partStart.resize(in.partStart.size());
+    rfx_records ri = in.view(), ro = o.view();
+    m.check(rfx_extend_pass(m.ctx, &ri, in.partStart.data(), P, m.param.kmerSize, m.param.twin, stage, &ro,
+                            o.partStart.data()), "rfx_extend_pass");
+    o.shrink(ro);
+    return o;
+}
+
+std::string ReflexivMain::KmerToContig::call(ReflexivSubKmerRDD &in, int64_t *nContigs) const {
+    rfx_records ri = in.view();
+    int64_t len = 0, nc = 0;
+    int st = rfx_contigs_text(m.ctx, &ri, m.param.kmerSize, m.param.minContig, m.param.twin, nullptr, 0, &len, &nc);
+    if (st != RFX_OK && st != RFX_E_CAP) m.check(st, "rfx_contigs_text");
+    std::string out((size_t)len, '\0');
+    m.check(rfx_contigs_text(m.ctx, &ri, m.param.kmerSize, m.param.minContig, m.param.twin, out.data(), len, &len, &nc),
+            "rfx_contigs_text");
+    if (nContigs) *nContigs = nc;
+    return out;
+}
+
+// P/ReflexivMain.java:168-316
+std::string ReflexivMain::assemblyFromCounts(const KmerBinaryRDD &counts, std::vector<int64_t> *trace) {
+    if (!param.bubble)
+        throw std::runtime_error("-bubble (no fork filtering) is unusable in the reference too (SURVEY.md C.6)");
+    const int P0 = std::max(1, param.logicalPartitions);
+    int P = P0;
+    SortByKey sortByKey{*this};
+    // Step: generate reverse complement k-mers, extract forward sub k-mers  :168-176
+    ReflexivSubKmerRDD rdd = KmerReverseComplement_ForwardSubKmerExtraction{*this}.call(counts);
+    // filter forks  :178-199
+    rdd = sortByKey.call(rdd, P);
+    rdd = FilterForkSubKmer{*this}.call(rdd);
+    rdd = ReflectedSubKmerExtractionFromForward{*this}.call(rdd);
+    rdd = sortByKey.call(rdd, P);
+    rdd = FilterForkReflectedSubKmer{*this}.call(rdd);
+    // Step 6  :204-205
+    rdd = kmerRandomReflection{*this}.call(rdd);
+    auto pass = [&](int stage) {
+        rdd = sortByKey.call(rdd, P);                       // Step 7  :211
+        rdd = ExtendReflexivKmer{*this, stage}.call(rdd);   // Step 8  :221-222
+        if (trace) trace->push_back(rdd.size());
+    };
+    pass(0);
+    int iterations = 0;
+    for (int i = 1; i < 4; i++) { iterations++; pass(0); }  // :233-241
+    iterations++;
+    pass(1);                                                // :247-254
+    int partitionNumber = P;                                // :263
+    int64_t contigNumber = 0;
+    while (iterations <= param.maximumIteration) {          // :265-296
+        iterations++;
+        if (iterations >= param.minimumIteration && iterations % 3 == 0) {
+            int64_t currentContigNumber = rdd.size();       // count()  :270
+            if (contigNumber == currentContigNumber) break;
+            contigNumber = currentContigNumber;
+            (void)partitionNumber;                          // coalesce (:277-281) is outside the order contract
+        }
+        pass(2);
+    }
+    int64_t nc = 0;
+    return KmerToContig{*this}.call(rdd, &nc);              // Step 11  :302-316
+}
+
+std::string ReflexivMain::assembly(const std::string &fastqText, std::vector<int64_t> *trace) {
+    std::vector<uint8_t> bases; std::vector<int64_t> readOff;
+    FastqFilterWithQual{*this}.call(fastqText, bases, readOff);                          // Steps 1-2  :126-134
+    std::vector<uint64_t> kmers = ReverseComplementKmerBinaryExtraction{*this}.call(bases, readOff);   // Step 3  :147-148
+    KmerBinaryRDD counts = KmerCounting_KmerCoverageFilter{*this}.call(kmers);            // Steps 4-5  :154-163
+    return assemblyFromCounts(counts, trace);
+}
+
+// P/ReflexivCounter.java:109-191: k-mer, count text lines
+std::string ReflexivMain::counter(const std::string &fastqText) {
+    static const char NUC[4] = {'A', 'C', 'G', 'T'};
+    std::vector<uint8_t> bases; std::vector<int64_t> readOff;
+    FastqFilterWithQual{*this}.call(fastqText, bases, readOff);
+    std::vector<uint64_t> kmers = ReverseComplementKmerBinaryExtraction{*this}.call(bases, readOff);
+    KmerBinaryRDD counts = KmerCounting_KmerCoverageFilter{*this}.call(kmers);
+    std::string out;
+    const int k = param.kmerSize;
+    for (size_t i = 0; i < counts.kmer.size(); i++) {
+        for (int j = 0; j < k; j++) out.push_back(NUC[(counts.kmer[i] >> (2 * (k - 1 - j))) & 3]);
+        out.push_back(',');
+        out += std::to_string(counts.count[i]);
+        out.push_back('\n');
+    }
+    return out;
+}
+
+}  // namespace reflexiv

@@ -1,0 +1,111 @@
+// ReflexivMain.h -- C++ host mirror of P/ReflexivMain.java (the RDD-surface twin) and
+// P/ReflexivCounter.java over the C ABI of libreflexiv_hip.so.
+//
+// The reference is Java on Spark; no JVM exists in the build or test environment, so the host
+// side above the C ABI is written here in C++ with the reference's class and method names: one
+// nested class per Spark operator, each with a call() that takes the partition's records and
+// returns the operator's output, and a driver assembly() that applies them in the order of
+// P/ReflexivMain.java:147-316.  Errors surface as exceptions (Java: unchecked exceptions ->
+// task failure); there is no CPU path.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/reflexiv_hip.h"
+#include "DefaultParam.h"
+
+namespace reflexiv {
+
+struct RfxException : std::runtime_error {
+    int status;
+    RfxException(int st, const std::string &where, const std::string &detail)
+        : std::runtime_error(where + ": status " + std::to_string(st) + (detail.empty() ? "" : " -- " + detail)),
+          status(st) {}
+};
+
+// JavaPairRDD<Long, Integer> KmerBinaryRDD  (P/ReflexivMain.java:105)
+struct KmerBinaryRDD {
+    std::vector<uint64_t> kmer;
+    std::vector<int32_t> count;
+};
+
+// JavaPairRDD<Long, Tuple4<Integer, Long[], Integer, Integer>> (P/ReflexivMain.java:108-109);
+// a single-word extension is a one-word array.  partStart = logical partition offsets.
+struct ReflexivSubKmerRDD {
+    std::vector<uint64_t> key, ext;
+    std::vector<int32_t> marker, left, right;
+    std::vector<int64_t> extOff, partStart;
+    int64_t size() const { return (int64_t)key.size(); }
+    rfx_records view();
+    void reserve(int64_t n, int64_t words);
+    void shrink(const rfx_records &r);
+};
+
+class ReflexivMain {
+public:
+    explicit ReflexivMain(int device = -1);
+    ~ReflexivMain();
+    void setParam(const DefaultParam &p) { param = p; }          // P/ReflexivMain.java:3126-3128
+
+    // ---- operators (one per inner class; names kept)
+    struct FastqFilterWithQual {            // :3089-3113 (+ FastqUnitFilter :3080-3084)
+        ReflexivMain &m;
+        // text -> concatenated sequence lines + offsets
+        void call(const std::string &text, std::vector<uint8_t> &bases, std::vector<int64_t> &readOff) const;
+    };
+    struct ReverseComplementKmerBinaryExtraction {   // :3002-3075
+        ReflexivMain &m;
+        std::vector<uint64_t> call(const std::vector<uint8_t> &bases, const std::vector<int64_t> &readOff) const;
+    };
+    struct KmerCounting_KmerCoverageFilter {         // reduceByKey(:2895-2899) + filter(:3115-3119)
+        ReflexivMain &m;
+        KmerBinaryRDD call(const std::vector<uint64_t> &kmers) const;
+    };
+    struct KmerReverseComplement_ForwardSubKmerExtraction {   // :2901-2931 + :2703-2731
+        ReflexivMain &m;
+        ReflexivSubKmerRDD call(const KmerBinaryRDD &in) const;
+    };
+    struct SortByKey {                               // sortByKey() :179,191,211,235,247,286
+        ReflexivMain &m;
+        ReflexivSubKmerRDD call(ReflexivSubKmerRDD &in, int P) const;
+    };
+    struct FilterForkSubKmer {                       // :2406-2541 (with or without error correction)
+        ReflexivMain &m;
+        ReflexivSubKmerRDD call(ReflexivSubKmerRDD &in) const;
+    };
+    struct ReflectedSubKmerExtractionFromForward {   // :2734-2769
+        ReflexivMain &m;
+        ReflexivSubKmerRDD call(ReflexivSubKmerRDD &in) const;
+    };
+    struct FilterForkReflectedSubKmer {              // :2543-2697
+        ReflexivMain &m;
+        ReflexivSubKmerRDD call(ReflexivSubKmerRDD &in) const;
+    };
+    struct kmerRandomReflection {                    // :2774-2886
+        ReflexivMain &m;
+        ReflexivSubKmerRDD call(ReflexivSubKmerRDD &in) const;
+    };
+    struct ExtendReflexivKmer {                      // :2019-2401, :1564-2013, :762-1558 by stage
+        ReflexivMain &m; int stage;
+        ReflexivSubKmerRDD call(ReflexivSubKmerRDD &in) const;
+    };
+    struct KmerToContig {                            // :693-758 + :588-638 + :571-582
+        ReflexivMain &m;
+        std::string call(ReflexivSubKmerRDD &in, int64_t *nContigs) const;
+    };
+
+    // ---- drivers
+    // assembly(): P/ReflexivMain.java:95-322 from FASTQ text to the contig text of saveAsTextFile
+    std::string assembly(const std::string &fastqText, std::vector<int64_t> *trace = nullptr);
+    // ReflexivCounter.assembly(): P/ReflexivCounter.java:109-191 -> lines "KMER,count"
+    std::string counter(const std::string &fastqText);
+    std::string assemblyFromCounts(const KmerBinaryRDD &counts, std::vector<int64_t> *trace = nullptr);
+
+    rfx_ctx *ctx = nullptr;
+    DefaultParam param;
+    void check(int st, const char *where) const;
+};
+
+}  // namespace reflexiv

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ 
                                                    const uint64_t *__restrict__ leaf_off, int64_t nleaf,
                                                    int min_cov, int max_cov, int apply_filter,
                                                    uint64_t *__restrict__ out_keys, int32_t *__restrict__ out_counts,
-                                                   unsigned long long cap, CountOut *__restrict__ co) {
+                                                   unsigned long long cap, CountOut *__restrict__ co, int dbg) {
     __shared__ unsigned long long tkey[LCAP];
     __shared__ uint32_t tcnt[LCAP];
     __shared__ unsigned long long obk[OBUF];
@@ -476,12 +476,13 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ 
                     uint32_t slot = (uint32_t)(h >> LEAF_SLOT_SHIFT) & (LCAP - 1);
                     // group lanes by the low 8 bits of the slot, then confirm the key
                     uint64_t peers = __ballot(ok);
+                    uint32_t mult = 1;
+                    if (!(dbg & 1)) {
 #pragma unroll
                     for (int b = 0; b < 8; b++) {
                         uint64_t m = __ballot((slot >> b) & 1u);
                         peers &= ((slot >> b) & 1u) ? m : ~m;
                     }
-                    uint32_t mult = 1;
                     {
                         const int leader = peers ? __ffsll((unsigned long long)peers) - 1 : lane;
                         const uint64_t lkey = __shfl(key, leader, 64);
@@ -492,11 +493,21 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ 
                             else mult = (uint32_t)__popcll(same);
                         }
                     }
+                    }
+                    if (dbg & 2) { if (ok && key == 12345) tcnt[slot] = 1; ok = false; }
                     if (ok) {
                         for (int probe = 0; probe < LCAP; probe++) {
-                            unsigned long long prev = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
+                            unsigned long long prev;
+                            if (dbg & 4) {
+                                prev = tkey[slot];                    // plain read: same-address lanes broadcast
+                                if (prev == EMPTY) prev = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
+                                else if (prev != key) { slot = (slot + 1) & (LCAP - 1); if (probe == LCAP - 1) overflow = 1; continue; }
+                            } else {
+                                prev = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
+                            }
                             if (prev == EMPTY) {
-                                if (atomicAdd(&n_dist, 1u) >= (uint32_t)LFULL) overflow = 1;
+                                if (dbg & 8) { atomicAdd(&n_dist, 1u); }
+                                else if (atomicAdd(&n_dist, 1u) >= (uint32_t)LFULL) overflow = 1;
                                 atomicAdd(&tcnt[slot], mult);
                                 break;
                             }
@@ -507,6 +518,8 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ 
                     }
                 }
             }
+            __syncthreads();
+            if ((dbg & 8) && n_dist > (uint32_t)LFULL) overflow = 1;     // benign race: same value
             __syncthreads();
             if (overflow) {
                 if (threadIdx.x == 0) {
@@ -825,7 +838,8 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
         int64_t grid = std::min<int64_t>(nseg, (int64_t)ctx->num_cu * 2);      // persistent, 60 KB LDS each
         hipLaunchKernelGGL(k_leaf_count, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, cur_arr,
                            (const uint64_t *)seg_cur->as<uint64_t>(), nseg, min_cov, max_cov, apply, d_out_keys,
-                           d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>());
+                           d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>(),
+                           getenv("RFX_LEAF_DBG") ? atoi(getenv("RFX_LEAF_DBG")) : 1);   // 1: no wave pre-grouping (measured slower)
         RFX_HIP(hipGetLastError());
     }
     CountOut co{};

@@ -389,3 +389,50 @@ def test_sort_pairs_is_stable(rfx, torch_mod):
         order = np.argsort(keys, kind="stable")
         assert np.array_equal(dk.cpu().numpy().view(np.uint64), keys[order])
         assert np.array_equal(dv.cpu().numpy().view(np.uint32), vals[order])
+
+
+# ------------------------------------------------ C++ host mirror of the reference driver
+
+def write_fastq(path, bases, read_off, gz=False):
+    import gzip
+    opener = gzip.open if gz else open
+    with opener(path, "wb") as fh:
+        for i in range(len(read_off) - 1):
+            seq = bytes(bases[read_off[i]:read_off[i + 1]])
+            qual = b"@" * len(seq)                       # quality lines starting with '@' on purpose
+            fh.write(b"@r%d/1\n" % i + seq + b"\n+\n" + qual + b"\n")
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_cpp_host_run_matches_documented_example(tmp_path, ex, gz):
+    """`reflexiv_host run -fastq ... -kmer 31 -cover 3` (C++ mirror of ReflexivMain.assembly()
+    calling one C-ABI entry per Spark operator) reproduces the documented contigs."""
+    import subprocess
+    import reflexiv_amd._lib as L
+    host = os.path.join(os.path.dirname(L.LIB_PATH), "reflexiv_host")
+    assert os.path.exists(host), "build with reflexiv_amd.build()"
+    fq = str(tmp_path / ("ex.fq.gz" if gz else "ex.fq"))
+    write_fastq(fq, ex["bases"], ex["read_off"], gz)
+    out = str(tmp_path / "result")
+    subprocess.check_call([host, "run", "-fastq", fq, "-outfile", out, "-kmer", "31", "-cover", "3",
+                           "--logical-partitions", "4", "--twin", "rdd"])
+    text = open(os.path.join(out, "part-00000")).read()
+    assert os.path.exists(os.path.join(out, "_SUCCESS"))
+    assert text == str(ex["contigs_rdd_P4"])
+    assert text.startswith(str(ex["doc_header"]) + "\n")
+
+
+def test_cpp_host_counter(tmp_path, ex):
+    import subprocess
+    import reflexiv_amd._lib as L
+    host = os.path.join(os.path.dirname(L.LIB_PATH), "reflexiv_host")
+    fq = str(tmp_path / "ex.fq")
+    write_fastq(fq, ex["bases"], ex["read_off"])
+    out = str(tmp_path / "cnt")
+    subprocess.check_call([host, "counter", "-fastq", fq, "-outfile", out, "-kmer", "31", "-cover", "3"])
+    lines = open(os.path.join(out, "part-00000")).read().split("\n")[:-1]
+    assert len(lines) == 4612
+    nuc = "ACGT"
+    want = ["".join(nuc[(int(k) >> (2 * (30 - j))) & 3] for j in range(31)) + "," + str(int(c))
+            for k, c in zip(ex["keys_cov3"], ex["counts_cov3"])]
+    assert lines == want

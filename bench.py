@@ -28,6 +28,19 @@ ALGO_BYTES = {"hist1": 0.25, "part1": 8.25, "hist2": 8.0, "part2": 16.0, "hist3"
               "leaf": 8.0}
 
 
+def measured_traffic(kernel, n_inst):
+    """HBM bytes per launch of `kernel` from the committed PMC profile (separate FETCH_SIZE /
+    WRITE_SIZE passes, FETCH doubled per MI355X_MICROARCH.md), if it was taken on this workload."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    try:
+        prof = json.load(open(path))
+        if prof.get("kmer_instances") == n_inst and kernel in prof["kernels"]:
+            return prof["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -40,7 +53,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--partitions", type=int, default=8)
-    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-contigs", action="store_true")
     return ap.parse_args()
@@ -155,7 +168,7 @@ def main():
         avg_s = ms / 1e3 / max(1, launches)
         achieved = per_launch_bytes / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(dom, n_inst),
                     "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_s * 1e3,
                     "per_kernel_ms_per_step": {n: v[0] / args.steps for n, v in sorted(timing_acc.items())}}
 

@@ -436,3 +436,20 @@ def test_cpp_host_counter(tmp_path, ex):
     want = ["".join(nuc[(int(k) >> (2 * (30 - j))) & 3] for j in range(31)) + "," + str(int(c))
             for k, c in zip(ex["keys_cov3"], ex["counts_cov3"])]
     assert lines == want
+
+
+def test_sharded_count_engine_world1(rfx, torch_mod):
+    """The multi-GPU code path (owner buckets -> [all-to-all] -> count of an explicit k-mer
+    array) on one GPU must equal the fused single-GPU path."""
+    torch = torch_mod
+    from reflexiv_amd import dist as rd
+    seed, G, n_reads, L, k = 21, 300_000, 150_000, 150, 31
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    reads = dict(words=dw, n_reads=n_reads, wpr=wpr, read_len=L, k=k)
+    keys, counts, tot = rd.sharded_count(rd.HipEngine(rfx), reads, 3, 10_000_000, 0)
+    N = rfx.kmers_per_read(L, k) * n_reads
+    dk = torch.empty(N, dtype=torch.int64, device="cuda"); dc = torch.empty(N, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, 3)
+    assert tot == [inst, nd, m]
+    assert torch.equal(keys, dk[:m]) and torch.equal(counts, dc[:m])

@@ -407,30 +407,38 @@ struct CountOut {
     unsigned long long n_failed;     // leaves that ran out of split depth (must stay 0)
 };
 
-// Persistent workgroups walk the leaf buckets; each bucket is streamed through an LDS hash table
-// (k-mer -> count).  Equal k-mers inside a wave are combined first (wave64 ballots over an 8-bit
-// digest, then an exact key compare against the group leader), so a k-mer seen 1000x costs one LDS
-// atomic per wave round instead of 64 serialised ones.  Survivors collect in an LDS buffer and
-// leave with ONE global atomic per flush: a per-leaf atomic on a single hot counter serialises the
-// whole grid (measured: 24 ms of a 25 ms kernel).
+// Persistent workgroups each walk a CONTIGUOUS chunk of leaf buckets, i.e. one contiguous
+// stream of instances: the next batch (LB keys per lane) is always in flight while the current
+// one is inserted, across leaf boundaries.  A leaf is streamed through an LDS hash table
+// (k-mer -> count, 64-bit CAS + add); the slots it fills are remembered in a list, so emitting
+// and resetting touch only those.  Survivors collect in an LDS buffer and leave with ONE global
+// atomic per flush (a per-leaf atomic on one hot counter serialises the whole grid).
+// A leaf with more than LFULL distinct keys is re-streamed in 2, 4, ... hash-selected parts.
 __global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ keys,
                                                    const uint64_t *__restrict__ leaf_off, int64_t nleaf,
                                                    int min_cov, int max_cov, int apply_filter,
                                                    uint64_t *__restrict__ out_keys, int32_t *__restrict__ out_counts,
-                                                   unsigned long long cap, CountOut *__restrict__ co, int dbg) {
+                                                   unsigned long long cap, CountOut *__restrict__ co) {
     __shared__ unsigned long long tkey[LCAP];
     __shared__ uint32_t tcnt[LCAP];
+    __shared__ uint16_t occ[LFULL];
     __shared__ unsigned long long obk[OBUF];
     __shared__ int32_t obc[OBUF];
     __shared__ uint32_t stackS[LSTACK], stacks[LSTACK];
     __shared__ int sp;
-    __shared__ uint32_t n_dist, overflow, n_emit, emit_pos, ob_n;
+    __shared__ uint32_t n_dist, overflow, ob_n;
     __shared__ unsigned long long g_emit;
-    const int lane = threadIdx.x & 63;
     unsigned long long my_distinct = 0;            // thread 0 only
-    if (threadIdx.x == 0) ob_n = 0;
 
-    // flush the survivor buffer (all threads call)
+    const int64_t l0 = (int64_t)(((unsigned long long)blockIdx.x * (unsigned long long)nleaf) / gridDim.x);
+    const int64_t l1 = (int64_t)(((unsigned long long)(blockIdx.x + 1) * (unsigned long long)nleaf) / gridDim.x);
+    if (l0 >= l1) return;
+    const uint64_t stream_end = leaf_off[l1];
+
+    for (int i = threadIdx.x; i < LCAP; i += LT) { tkey[i] = EMPTY; tcnt[i] = 0; }
+    if (threadIdx.x == 0) { ob_n = 0; n_dist = 0; overflow = 0; }
+
+    // flush the survivor buffer (every thread calls)
     auto flush = [&]() {
         __syncthreads();
         const uint32_t cntv = ob_n;
@@ -446,134 +454,113 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ 
         __syncthreads();
     };
 
-    for (int64_t leaf = blockIdx.x; leaf < nleaf; leaf += gridDim.x) {
-        const uint64_t begin = leaf_off[leaf], end = leaf_off[leaf + 1];
-        if (begin == end) continue;                // uniform per block
-        if (threadIdx.x == 0) { sp = 1; stackS[0] = 1; stacks[0] = 0; }
-        __syncthreads();
-        while (true) {
-            __syncthreads();
-            if (sp == 0) break;
-            const uint32_t S = stackS[sp - 1], s = stacks[sp - 1];
-            __syncthreads();
-            if (threadIdx.x == 0) { sp--; n_dist = 0; overflow = 0; n_emit = 0; emit_pos = 0; }
-            for (int i = threadIdx.x; i < LCAP; i += LT) { tkey[i] = EMPTY; tcnt[i] = 0; }
-            __syncthreads();
-            // whole waves iterate together (ballots need every lane); LB loads in flight per lane
-            for (uint64_t base = begin; base < end; base += (uint64_t)LT * LB) {
-                uint64_t kbuf[LB];
+    // prefetched batch: kn[j] = keys[pf + j*LT + tid] (0 beyond the chunk's stream)
+    uint64_t kn[LB];
+    uint64_t pf = leaf_off[l0];
+    auto prefetch = [&](uint64_t pos) {
+        pf = pos;
 #pragma unroll
-                for (int j = 0; j < LB; j++) {
-                    const uint64_t i = base + (uint64_t)j * LT + threadIdx.x;
-                    kbuf[j] = i < end ? keys[i] : 0;
-                }
+        for (int j = 0; j < LB; j++) {
+            const uint64_t i = pos + (uint64_t)j * LT + threadIdx.x;
+            kn[j] = i < stream_end ? keys[i] : 0;
+        }
+    };
+    prefetch(pf);
+    uint64_t begin = pf;
+    uint64_t end = leaf_off[l0 + 1];
+    __syncthreads();
+
+    for (int64_t leaf = l0; leaf < l1; leaf++) {
+        // the offset after the next leaf travels while this leaf is processed
+        const uint64_t end_next = leaf + 2 <= l1 ? leaf_off[leaf + 2] : stream_end;
+        if (begin != end) {
+            __syncthreads();                        // every thread has left the previous leaf's loop
+            if (threadIdx.x == 0) { sp = 1; stackS[0] = 1; stacks[0] = 0; }
+            __syncthreads();
+            while (true) {
+                if (sp == 0) break;                 // uniform: sp only changes between barriers
+                const uint32_t S = stackS[sp - 1], s = stacks[sp - 1];
+                __syncthreads();
+                if (threadIdx.x == 0) sp--;
+                for (uint64_t base = begin; base < end; base += (uint64_t)LT * LB) {
+                    uint64_t kc[LB];
+                    if (pf == base) {
 #pragma unroll
-                for (int j = 0; j < LB; j++) {
-                    bool ok = base + (uint64_t)j * LT + threadIdx.x < end;
-                    const uint64_t key = kbuf[j];
-                    const uint64_t h = local_hash(key);
-                    if (S > 1 && ((uint32_t)(h >> LEAF_SPLIT_SHIFT) & (S - 1)) != s) ok = false;
-                    uint32_t slot = (uint32_t)(h >> LEAF_SLOT_SHIFT) & (LCAP - 1);
-                    // group lanes by the low 8 bits of the slot, then confirm the key
-                    uint64_t peers = __ballot(ok);
-                    uint32_t mult = 1;
-                    if (!(dbg & 1)) {
+                        for (int j = 0; j < LB; j++) kc[j] = kn[j];
+                    } else {                        // re-streaming a split leaf: load now
 #pragma unroll
-                    for (int b = 0; b < 8; b++) {
-                        uint64_t m = __ballot((slot >> b) & 1u);
-                        peers &= ((slot >> b) & 1u) ? m : ~m;
-                    }
-                    {
-                        const int leader = peers ? __ffsll((unsigned long long)peers) - 1 : lane;
-                        const uint64_t lkey = __shfl(key, leader, 64);
-                        const bool eq = ok && key == lkey;
-                        const uint64_t same = __ballot(eq) & peers;      // lanes equal to their group leader
-                        if (eq) {
-                            if (lane != leader) ok = false;              // the leader inserts for the group
-                            else mult = (uint32_t)__popcll(same);
+                        for (int j = 0; j < LB; j++) {
+                            const uint64_t i = base + (uint64_t)j * LT + threadIdx.x;
+                            kc[j] = i < end ? keys[i] : 0;
                         }
                     }
-                    }
-                    if (dbg & 2) { if (ok && key == 12345) tcnt[slot] = 1; ok = false; }
-                    if (ok) {
+                    // next batch of this leaf, or the first batch of the next leaf
+                    const uint64_t nxt = base + (uint64_t)LT * LB < end ? base + (uint64_t)LT * LB : end;
+                    if (nxt < stream_end && nxt != pf) prefetch(nxt);
+                    // key-major inserts (issuing the LB CAS of a lane back to back measured slower:
+                    // the LDS pipe, not its latency, is the limit -- profiles/README.md)
+#pragma unroll
+                    for (int j = 0; j < LB; j++) {
+                        if (base + (uint64_t)j * LT + threadIdx.x >= end) continue;
+                        const uint64_t key = kc[j];
+                        const uint64_t h = local_hash(key);
+                        if (S > 1 && ((uint32_t)(h >> LEAF_SPLIT_SHIFT) & (S - 1)) != s) continue;
+                        uint32_t slot = (uint32_t)(h >> LEAF_SLOT_SHIFT) & (LCAP - 1);
                         for (int probe = 0; probe < LCAP; probe++) {
-                            unsigned long long prev;
-                            if (dbg & 4) {
-                                prev = tkey[slot];                    // plain read: same-address lanes broadcast
-                                if (prev == EMPTY) prev = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
-                                else if (prev != key) { slot = (slot + 1) & (LCAP - 1); if (probe == LCAP - 1) overflow = 1; continue; }
-                            } else {
-                                prev = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
-                            }
+                            const unsigned long long prev = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
                             if (prev == EMPTY) {
-                                if (dbg & 8) { atomicAdd(&n_dist, 1u); }
-                                else if (atomicAdd(&n_dist, 1u) >= (uint32_t)LFULL) overflow = 1;
-                                atomicAdd(&tcnt[slot], mult);
+                                const uint32_t pos = atomicAdd(&n_dist, 1u);
+                                if (pos < (uint32_t)LFULL) occ[pos] = (uint16_t)slot; else overflow = 1;
+                                atomicAdd(&tcnt[slot], 1u);
                                 break;
                             }
-                            if (prev == key) { atomicAdd(&tcnt[slot], mult); break; }
+                            if (prev == key) { atomicAdd(&tcnt[slot], 1u); break; }
                             slot = (slot + 1) & (LCAP - 1);
-                            if (probe == LCAP - 1) overflow = 1;
                         }
                     }
                 }
-            }
-            __syncthreads();
-            if ((dbg & 8) && n_dist > (uint32_t)LFULL) overflow = 1;     // benign race: same value
-            __syncthreads();
-            if (overflow) {
-                if (threadIdx.x == 0) {
-                    if (sp + 2 <= LSTACK && S < (1u << 16)) {
-                        stackS[sp] = 2 * S; stacks[sp] = s + S; sp++;
-                        stackS[sp] = 2 * S; stacks[sp] = s;     sp++;
-                    } else {
-                        atomicAdd(&co->n_failed, 1ULL);
-                    }
-                }
-                continue;
-            }
-            // survivors of this sub-pass
-            for (int i = threadIdx.x; i < LCAP; i += LT) {
-                if (tkey[i] != EMPTY) {
-                    int32_t c = (int32_t)tcnt[i];
-                    if (!apply_filter || (c >= min_cov && c <= max_cov)) atomicAdd(&n_emit, 1u);
-                }
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) my_distinct += n_dist;
-            const uint32_t ne = n_emit;
-            if (ne == 0) continue;
-            if (ob_n + ne > (uint32_t)OBUF) flush();           // uniform: ob_n and n_emit are shared
-            if (ne > (uint32_t)OBUF) {
-                // larger than the buffer (mostly-distinct data with a low cut-off): straight out
-                if (threadIdx.x == 0) g_emit = atomicAdd(&co->n_out, (unsigned long long)ne);
                 __syncthreads();
-                for (int i = threadIdx.x; i < LCAP; i += LT) {
-                    if (tkey[i] != EMPTY) {
-                        int32_t c = (int32_t)tcnt[i];
+                const uint32_t nd = n_dist;
+                if (overflow) {
+                    // abandon: wipe the table, re-stream in two hash-selected halves
+                    __syncthreads();
+                    for (int i = threadIdx.x; i < LCAP; i += LT) { tkey[i] = EMPTY; tcnt[i] = 0; }
+                    if (threadIdx.x == 0) {
+                        n_dist = 0; overflow = 0;
+                        if (sp + 2 <= LSTACK && S < (1u << 16)) {
+                            stackS[sp] = 2 * S; stacks[sp] = s + S; sp++;
+                            stackS[sp] = 2 * S; stacks[sp] = s;     sp++;
+                        } else {
+                            atomicAdd(&co->n_failed, 1ULL);
+                        }
+                    }
+                    __syncthreads();
+                    continue;
+                }
+                if (threadIdx.x == 0) my_distinct += nd;
+                // emit + reset the occupied slots, OBUF entries at a time
+                for (uint32_t c0 = 0; c0 < nd; c0 += OBUF) {
+                    const uint32_t chunk = nd - c0 < (uint32_t)OBUF ? nd - c0 : (uint32_t)OBUF;
+                    const uint32_t ob0 = ob_n;
+                    __syncthreads();            // everyone has read ob_n before anyone appends
+                    if (ob0 + chunk > (uint32_t)OBUF) flush();
+                    for (uint32_t i = c0 + threadIdx.x; i < c0 + chunk; i += LT) {
+                        const uint32_t slot = occ[i];
+                        const int32_t c = (int32_t)tcnt[slot];
                         if (!apply_filter || (c >= min_cov && c <= max_cov)) {
-                            unsigned long long pos = g_emit + atomicAdd(&emit_pos, 1u);
-                            if (pos < cap) { out_keys[pos] = tkey[i]; out_counts[pos] = c; }
+                            const uint32_t pos = atomicAdd(&ob_n, 1u);
+                            obk[pos] = tkey[slot]; obc[pos] = c;
                         }
+                        tkey[slot] = EMPTY; tcnt[slot] = 0;
                     }
+                    __syncthreads();
                 }
-            } else {
-                const uint32_t ob0 = ob_n;
+                if (threadIdx.x == 0) n_dist = 0;
                 __syncthreads();
-                for (int i = threadIdx.x; i < LCAP; i += LT) {
-                    if (tkey[i] != EMPTY) {
-                        int32_t c = (int32_t)tcnt[i];
-                        if (!apply_filter || (c >= min_cov && c <= max_cov)) {
-                            uint32_t pos = ob0 + atomicAdd(&emit_pos, 1u);
-                            obk[pos] = tkey[i]; obc[pos] = c;
-                        }
-                    }
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) ob_n = ob0 + ne;
             }
         }
-        __syncthreads();
+        begin = end;
+        end = end_next;
     }
     flush();
     if (threadIdx.x == 0 && my_distinct) atomicAdd(&co->n_distinct, my_distinct);
@@ -838,8 +825,7 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
         int64_t grid = std::min<int64_t>(nseg, (int64_t)ctx->num_cu * 2);      // persistent, 60 KB LDS each
         hipLaunchKernelGGL(k_leaf_count, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, cur_arr,
                            (const uint64_t *)seg_cur->as<uint64_t>(), nseg, min_cov, max_cov, apply, d_out_keys,
-                           d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>(),
-                           getenv("RFX_LEAF_DBG") ? atoi(getenv("RFX_LEAF_DBG")) : 1);   // 1: no wave pre-grouping (measured slower)
+                           d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>());
         RFX_HIP(hipGetLastError());
     }
     CountOut co{};

@@ -453,3 +453,31 @@ def test_sharded_count_engine_world1(rfx, torch_mod):
     m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, 3)
     assert tot == [inst, nd, m]
     assert torch.equal(keys, dk[:m]) and torch.equal(counts, dc[:m])
+
+
+def test_deep_coverage_recovers_exactly_the_genome_kmers(rfx, torch_mod):
+    """At ~200x coverage with a cut-off of 10 the survivors must be exactly the canonical k-mers
+    of the genome (error k-mers never reach 10, genomic ones never fall below it): a
+    size-independent check of the whole count stage with ~1000 leaves per workgroup, which is
+    where barrier races in the persistent kernels show up."""
+    torch = torch_mod
+    seed, G, n_reads, L, k = 5, 1_000_000, 1_400_000, 150, 31
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    N = rfx.kmers_per_read(L, k) * n_reads
+    dk = torch.empty(N // 8, dtype=torch.int64, device="cuda")
+    dc = torch.empty(N // 8, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N // 8, 10)
+    g = O.synth_genome(seed, G)
+    nuc = np.frombuffer(b"ACGT", np.uint8)
+    gb = nuc[((g[np.arange(G) >> 5] >> (np.uint64(62) - np.uint64(2) * (np.arange(G, dtype=np.uint64) & np.uint64(31))))
+              & np.uint64(3)).astype(np.int64)]
+    allk = O.extract_canon(gb, np.array([0, G]), k)
+    want = np.unique(allk)
+    core = np.unique(allk[400:-400])          # the genome's two ends are sampled thinly
+    got = dk[:m].cpu().numpy().view(np.uint64)
+    assert np.all(got[1:] > got[:-1])
+    assert np.isin(got, want).all()           # no error k-mer survives
+    assert np.isin(core, got).all()           # no genomic k-mer is lost
+    assert len(want) - m < 200
+    assert int(dc[:m].min()) >= 10

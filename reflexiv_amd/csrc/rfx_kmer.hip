@@ -109,32 +109,30 @@ __device__ __forceinline__ unsigned digit_of(uint64_t key, const Level &lv) {
     return (unsigned)((local_hash(key) >> lv.shift) & ((1u << lv.bits) - 1));
 }
 
-// LDS layout shared by the two scatter kernels: sorted tile + per-digit bookkeeping
+// LDS layout shared by the scatter kernels: sorted tile + per-digit bookkeeping.  Sized at launch
+// for the actual digit count nb: PTILE*8 + (nb+1)*4 + nb*8 bytes (76 KB at 1024 digits, so two
+// workgroups fit a CU's 160 KB).
 struct ScatterLds {
-    uint64_t *skey;     // PTILE
-    uint64_t *gbase;    // 2^MAX_BITS: reserved global base of each digit's run
-    uint32_t *cnt;      // 2^MAX_BITS: per-digit count, then (aliased) local exclusive offset
+    uint64_t *skey;     // PTILE sorted keys
+    uint64_t *priv;     // nb running private output cursors of this workgroup
+    uint32_t *cnt;      // nb+1: per-digit count, then (in place) local exclusive offset; [nb] = total
 };
-__device__ __forceinline__ ScatterLds scatter_lds(unsigned char *smem) {
+__device__ __forceinline__ ScatterLds scatter_lds(unsigned char *smem, int nb) {
     ScatterLds l;
     l.skey = reinterpret_cast<uint64_t *>(smem);
-    l.gbase = l.skey + PTILE;
-    l.cnt = reinterpret_cast<uint32_t *>(l.gbase + (1 << MAX_BITS));
+    l.priv = l.skey + PTILE;
+    l.cnt = reinterpret_cast<uint32_t *>(l.priv + nb);
     return l;
 }
 
 // One tile's worth of keys sits in registers with their (rank | digit << 16): turn the
-// per-digit counts into local offsets, reserve the global runs, place the keys digit by digit
-// in LDS and copy the runs out (consecutive lanes -> consecutive addresses of a run).
-// Reservation: PRIVATE -- the workgroup owns exact output ranges (priv[d] = its running cursor in
-// LDS, from the per-workgroup histogram), no atomics at all; otherwise one returning global
-// atomic per digit on cursor[].  Ends with a barrier after which skey / cnt may be reused.
-template <bool PRIVATE>
-__device__ __forceinline__ void scatter_tile(const ScatterLds &l, const Level &lv, uint64_t parent,
+// per-digit counts into local offsets, advance the workgroup's private cursors (its exact output
+// ranges come from the per-workgroup histogram rows -- no atomics anywhere), place the keys digit
+// by digit in LDS and copy the runs out (consecutive lanes -> consecutive addresses of a run).
+// Ends with a barrier after which skey / cnt may be reused.
+__device__ __forceinline__ void scatter_tile(const ScatterLds &l, const Level &lv, int nb,
                                              const uint64_t (&key)[PK], const uint32_t (&rank)[PK],
-                                             const bool (&ok)[PK], unsigned long long *__restrict__ cursor,
-                                             uint64_t *priv, uint64_t *__restrict__ out, uint32_t *wsum) {
-    const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
+                                             const bool (&ok)[PK], uint64_t *__restrict__ out, uint32_t *wsum) {
     uint32_t total;
     {
         uint32_t c0 = 0, c1 = 0;
@@ -142,17 +140,9 @@ __device__ __forceinline__ void scatter_tile(const ScatterLds &l, const Level &l
         if (d0 < nb) c0 = l.cnt[d0];
         if (d1 < nb) c1 = l.cnt[d1];
         const uint32_t ex = block_exclusive_scan(c0 + c1, wsum, &total);   // barriers inside
-        const uint64_t cbase = lv.n_owners > 0 ? 0 : (parent << lv.bits);
-        if (d0 < nb) {
-            l.cnt[d0] = ex;
-            if (PRIVATE) { l.gbase[d0] = priv[d0]; priv[d0] += c0; }
-            else l.gbase[d0] = c0 ? atomicAdd(&cursor[cbase | (uint64_t)d0], (unsigned long long)c0) : 0;
-        }
-        if (d1 < nb) {
-            l.cnt[d1] = ex + c0;
-            if (PRIVATE) { l.gbase[d1] = priv[d1]; priv[d1] += c1; }
-            else l.gbase[d1] = c1 ? atomicAdd(&cursor[cbase | (uint64_t)d1], (unsigned long long)c1) : 0;
-        }
+        if (d0 < nb) { l.cnt[d0] = ex; l.priv[d0] += c0; }
+        if (d1 < nb) { l.cnt[d1] = ex + c0; l.priv[d1] += c1; }
+        if (threadIdx.x == 0) l.cnt[nb] = total;
     }
     __syncthreads();
 #pragma unroll
@@ -162,7 +152,9 @@ __device__ __forceinline__ void scatter_tile(const ScatterLds &l, const Level &l
     for (int i = threadIdx.x; i < (int)total; i += PT) {
         const uint64_t kk = l.skey[i];
         const unsigned d = digit_of(kk, lv);
-        out[l.gbase[d] + (uint64_t)(i - l.cnt[d])] = kk;
+        const uint32_t lo = l.cnt[d], hi = l.cnt[d + 1];
+        // the run of digit d starts where the cursor stood before this tile
+        out[l.priv[d] - (uint64_t)(hi - lo) + (uint64_t)(i - lo)] = kk;
     }
     __syncthreads();
 }
@@ -256,11 +248,10 @@ __global__ void k_bin_offsets(const uint64_t *__restrict__ scanned, int nb, int6
 __global__ __launch_bounds__(PT) void k_reads_scatter(ReadSrc s, Level lv, const uint64_t *__restrict__ scanned,
                                                       uint64_t *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const ScatterLds l = scatter_lds(smem);
-    uint64_t *priv = reinterpret_cast<uint64_t *>(l.cnt + (1 << MAX_BITS));     // 2^bits running cursors
     __shared__ uint32_t wsum[PT / 64];
     const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
-    for (int i = threadIdx.x; i < nb; i += PT) priv[i] = scanned[(int64_t)i * gridDim.x + blockIdx.x];
+    const ScatterLds l = scatter_lds(smem, nb);
+    for (int i = threadIdx.x; i < nb; i += PT) l.priv[i] = scanned[(int64_t)i * gridDim.x + blockIdx.x];
     const int64_t stride = (int64_t)gridDim.x * PT;
     const int64_t dq = stride / s.segs;
     const int dr = (int)(stride - dq * s.segs);
@@ -291,102 +282,131 @@ __global__ __launch_bounds__(PT) void k_reads_scatter(ReadSrc s, Level lv, const
             }
         }
         __syncthreads();
-        scatter_tile<true>(l, lv, 0, key, rank, ok, nullptr, priv, out, wsum);
+        scatter_tile(l, lv, nb, key, rank, ok, out, wsum);
     }
 }
 
 // ------------------------------------------------- levels >= 2 (and arrays)
 
-// tile -> (segment, first slot, count).  seg_off[nseg+1] element offsets of the parent
-// buckets, tile_start[nseg+1] exclusive scan of tiles per segment.
-__device__ __forceinline__ bool locate_tile(const uint64_t *__restrict__ seg_off,
-                                            const uint64_t *__restrict__ tile_start, int64_t nseg,
-                                            int64_t tile, int64_t *begin, int *count) {
-    if (tile >= (int64_t)tile_start[nseg]) return false;
-    int64_t lo = 0, hi = nseg;             // last seg with tile_start[seg] <= tile
+// The instances of every parent bucket are cut into "virtual workgroups" of tpb consecutive
+// tiles.  Virtual workgroup (p, g) histograms its tiles into row g of parent p's table region
+// (entry (d, g) at nb*vb_start[p] + d*G_p + g); one exclusive scan over the table in that order
+// yields, for every child bucket (p, d), its start and, inside it, every virtual workgroup's
+// private range.  The scatter kernel then needs no atomics and the output is deterministic.
+struct VbMap {
+    const uint64_t *seg_off;     // nseg+1 element offsets of the parents
+    const uint64_t *vb_start;    // nseg+1 exclusive scan of virtual workgroups per parent
+    int64_t nseg;
+    int tpb;                     // tiles per virtual workgroup
+};
+
+__global__ void k_vb_per_seg(const uint64_t *__restrict__ seg_off, int64_t nseg, int tpb,
+                             uint64_t *__restrict__ nvb) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < nseg) {
+        const uint64_t per = (uint64_t)tpb * PTILE;
+        nvb[s] = (seg_off[s + 1] - seg_off[s] + per - 1) / per;
+    }
+}
+
+struct VbPos { int64_t p, g, G; uint64_t begin, end; };
+
+__device__ __forceinline__ bool locate_vb(const VbMap &m, int64_t vb, VbPos *q) {
+    if (vb >= (int64_t)m.vb_start[m.nseg]) return false;
+    int64_t lo = 0, hi = m.nseg;           // last p with vb_start[p] <= vb
     while (hi - lo > 1) {
         int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)tile_start[mid] <= tile) lo = mid; else hi = mid;
+        if ((int64_t)m.vb_start[mid] <= vb) lo = mid; else hi = mid;
     }
-    int64_t b = (int64_t)seg_off[lo] + (tile - (int64_t)tile_start[lo]) * PTILE;
-    int64_t e = (int64_t)seg_off[lo + 1];
-    *begin = b;
-    *count = (int)((e - b) < PTILE ? (e - b) : PTILE);
+    q->p = lo;
+    q->g = vb - (int64_t)m.vb_start[lo];
+    q->G = (int64_t)m.vb_start[lo + 1] - (int64_t)m.vb_start[lo];
+    const uint64_t per = (uint64_t)m.tpb * PTILE;
+    q->begin = m.seg_off[lo] + (uint64_t)q->g * per;
+    const uint64_t e = m.seg_off[lo + 1];
+    q->end = q->begin + per < e ? q->begin + per : e;
     return true;
 }
 
-__global__ void k_tiles_per_seg(const uint64_t *__restrict__ seg_off, int64_t nseg,
-                                uint64_t *__restrict__ tiles) {
-    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < nseg) tiles[s] = (seg_off[s + 1] - seg_off[s] + PTILE - 1) / PTILE;
+__device__ __forceinline__ void load_striped(const uint64_t *__restrict__ kmers, uint64_t base, uint64_t end,
+                                             uint64_t (&key)[PK]) {
+#pragma unroll
+    for (int i = 0; i < PK; i++) {
+        const uint64_t idx = base + (uint64_t)i * PT + threadIdx.x;
+        key[i] = idx < end ? kmers[idx] : 0;
+    }
 }
 
-__global__ __launch_bounds__(PT) void k_level_hist(const uint64_t *__restrict__ kmers,
-                                                   const uint64_t *__restrict__ seg_off,
-                                                   const uint64_t *__restrict__ tile_start, int64_t nseg,
-                                                   Level lv, unsigned long long *__restrict__ hist) {
+__global__ __launch_bounds__(PT) void k_vb_hist(const uint64_t *__restrict__ kmers, VbMap m, Level lv,
+                                                uint32_t *__restrict__ table) {
     __shared__ uint32_t h[1 << MAX_BITS];
-    __shared__ uint64_t s_parent;
-    int64_t begin; int count;
-    if (!locate_tile(seg_off, tile_start, nseg, blockIdx.x, &begin, &count)) return;
-    const int nb = 1 << lv.bits;
+    VbPos q;
+    if (!locate_vb(m, blockIdx.x, &q)) return;
+    const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
     for (int i = threadIdx.x; i < nb; i += PT) h[i] = 0;
     __syncthreads();
-    uint64_t key[PK];
+    uint64_t kn[PK];
+    load_striped(kmers, q.begin, q.end, kn);
+    for (uint64_t base = q.begin; base < q.end; base += PTILE) {
+        uint64_t key[PK];
 #pragma unroll
-    for (int i = 0; i < PK; i++) {
-        const int idx = i * PT + threadIdx.x;
-        key[i] = idx < count ? kmers[begin + idx] : 0;
-    }
+        for (int i = 0; i < PK; i++) key[i] = kn[i];
+        if (base + PTILE < q.end) load_striped(kmers, base + PTILE, q.end, kn);   // next tile in flight
 #pragma unroll
-    for (int i = 0; i < PK; i++) {
-        if (i * PT + (int)threadIdx.x < count) {
-            const uint64_t hh = local_hash(key[i]);
-            atomicAdd(&h[(hh >> lv.shift) & (nb - 1)], 1u);
-            if (i == 0 && threadIdx.x == 0) s_parent = lv.parent_shift >= 64 ? 0 : (hh >> lv.parent_shift);
-        }
+        for (int i = 0; i < PK; i++)
+            if (base + (uint64_t)i * PT + threadIdx.x < q.end) atomicAdd(&h[digit_of(key[i], lv)], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nb; i += PT) {
-        const uint32_t c = h[i];
-        if (c) atomicAdd(&hist[(s_parent << lv.bits) | (uint64_t)i], (unsigned long long)c);
-    }
+    const int64_t tb = (int64_t)nb * (int64_t)m.vb_start[q.p];
+    for (int i = threadIdx.x; i < nb; i += PT) table[tb + (int64_t)i * q.G + q.g] = h[i];
 }
 
-__global__ __launch_bounds__(PT) void k_level_scatter(const uint64_t *__restrict__ kmers,
-                                                      const uint64_t *__restrict__ seg_off,
-                                                      const uint64_t *__restrict__ tile_start, int64_t nseg,
-                                                      Level lv, unsigned long long *__restrict__ cursor,
-                                                      uint64_t *__restrict__ out) {
+// child bucket (p, d) starts at scanned[nb*vb_start[p] + d*G_p]; entry nchild = total
+__global__ void k_child_offsets(const uint64_t *__restrict__ scanned, VbMap m, int nb, uint64_t total,
+                                uint64_t *__restrict__ child_off) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nchild = m.nseg * nb;
+    if (c > nchild) return;
+    if (c == nchild) { child_off[c] = total; return; }
+    const int64_t p = c / nb;
+    const int d = (int)(c - p * nb);
+    const int64_t G = (int64_t)m.vb_start[p + 1] - (int64_t)m.vb_start[p];
+    // an empty parent has no rows: its children start where the next non-empty region starts
+    child_off[c] = scanned[(int64_t)nb * (int64_t)m.vb_start[p] + (int64_t)d * G];
+}
+
+__global__ __launch_bounds__(PT) void k_vb_scatter(const uint64_t *__restrict__ kmers, VbMap m, Level lv,
+                                                   const uint64_t *__restrict__ scanned,
+                                                   uint64_t *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const ScatterLds l = scatter_lds(smem);
     __shared__ uint32_t wsum[PT / 64];
-    __shared__ uint64_t s_parent;
-    int64_t begin; int count;
-    if (!locate_tile(seg_off, tile_start, nseg, blockIdx.x, &begin, &count)) return;
-    const int nb = 1 << lv.bits;
-    for (int i = threadIdx.x; i < nb; i += PT) l.cnt[i] = 0;
-    __syncthreads();
-    uint64_t key[PK];
-    uint32_t rank[PK];
-    bool ok[PK];
+    VbPos q;
+    if (!locate_vb(m, blockIdx.x, &q)) return;
+    const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
+    const ScatterLds l = scatter_lds(smem, nb);
+    const int64_t tb = (int64_t)nb * (int64_t)m.vb_start[q.p];
+    for (int i = threadIdx.x; i < nb; i += PT) l.priv[i] = scanned[tb + (int64_t)i * q.G + q.g];
+    uint64_t kn[PK];
+    load_striped(kmers, q.begin, q.end, kn);
+    for (uint64_t base = q.begin; base < q.end; base += PTILE) {
+        for (int i = threadIdx.x; i < nb; i += PT) l.cnt[i] = 0;
+        __syncthreads();
+        uint64_t key[PK];
+        uint32_t rank[PK];
+        bool ok[PK];
 #pragma unroll
-    for (int i = 0; i < PK; i++) {
-        const int idx = i * PT + threadIdx.x;
-        ok[i] = idx < count;
-        key[i] = ok[i] ? kmers[begin + idx] : 0;
-    }
+        for (int i = 0; i < PK; i++) { key[i] = kn[i]; ok[i] = base + (uint64_t)i * PT + threadIdx.x < q.end; }
+        if (base + PTILE < q.end) load_striped(kmers, base + PTILE, q.end, kn);   // next tile in flight
 #pragma unroll
-    for (int i = 0; i < PK; i++) {
-        if (ok[i]) {
-            const uint64_t hh = local_hash(key[i]);
-            const unsigned d = (unsigned)((hh >> lv.shift) & (nb - 1));
-            rank[i] = atomicAdd(&l.cnt[d], 1u) | (d << 16);
-            if (i == 0 && threadIdx.x == 0) s_parent = lv.parent_shift >= 64 ? 0 : (hh >> lv.parent_shift);
+        for (int i = 0; i < PK; i++) {
+            if (ok[i]) {
+                const unsigned d = digit_of(key[i], lv);
+                rank[i] = atomicAdd(&l.cnt[d], 1u) | (d << 16);
+            }
         }
+        __syncthreads();
+        scatter_tile(l, lv, nb, key, rank, ok, out, wsum);
     }
-    __syncthreads();
-    scatter_tile<false>(l, lv, s_parent, key, rank, ok, cursor, nullptr, out, wsum);
 }
 
 // ------------------------------------------------------------------- leaves
@@ -483,6 +503,9 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ 
                 __syncthreads();
                 if (threadIdx.x == 0) sp--;
                 for (uint64_t base = begin; base < end; base += (uint64_t)LT * LB) {
+                    // an overflowing pass is abandoned: stop feeding a table that is filling up
+                    // (probe sequences in a full table would cost LCAP CAS per key)
+                    if (*(volatile uint32_t *)&overflow) break;
                     uint64_t kc[LB];
                     if (pf == base) {
 #pragma unroll
@@ -516,6 +539,7 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ 
                             }
                             if (prev == key) { atomicAdd(&tcnt[slot], 1u); break; }
                             slot = (slot + 1) & (LCAP - 1);
+                            if ((probe & 31) == 31 && *(volatile uint32_t *)&overflow) break;
                         }
                     }
                 }
@@ -615,9 +639,7 @@ __global__ void k_synth_reads(uint64_t sp, uint64_t se, const uint64_t *__restri
     words[t] = x;
 }
 
-size_t scatter_lds_bytes() { return (size_t)PTILE * 8 + (size_t)(1 << MAX_BITS) * (8 + 4); }
-// + the private running cursors; only the first 2^bits entries are touched
-size_t reads_scatter_lds_bytes(int nb) { return scatter_lds_bytes() + (size_t)nb * 8; }
+size_t scatter_lds_bytes(int nb) { return (size_t)PTILE * 8 + (size_t)nb * 8 + (size_t)(nb + 1) * 4 + 16; }
 
 }  // namespace
 
@@ -669,7 +691,7 @@ static void plan_levels(int64_t n, bool from_reads, std::vector<int> &bits) {
         }
         if (!bits.empty()) return;
     }
-    double target = 8192.0;
+    double target = 16384.0;
     if (const char *e = getenv("RFX_LEAF_TARGET")) target = atof(e) > 0 ? atof(e) : target;
     int B = 0;
     if ((double)n > target) B = (int)std::ceil(std::log2((double)n / target));
@@ -692,10 +714,10 @@ static ReadSrc make_read_src(const ReadStore *reads) {
 static int set_scatter_attrs(rfx_ctx *ctx) {
     static bool done = false;
     if (done) return RFX_OK;
-    RFX_HIP(hipFuncSetAttribute((const void *)k_level_scatter, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)scatter_lds_bytes()));
+    RFX_HIP(hipFuncSetAttribute((const void *)k_vb_scatter, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)scatter_lds_bytes(1 << MAX_BITS)));
     RFX_HIP(hipFuncSetAttribute((const void *)k_reads_scatter, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)reads_scatter_lds_bytes(1 << MAX_BITS)));
+                                (int)scatter_lds_bytes(1 << MAX_BITS)));
     done = true;
     return RFX_OK;
 }
@@ -729,7 +751,7 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
     plan_levels(n, from_reads, bits);
     RFX_TRY(set_scatter_attrs(ctx));
 
-    DevBuf bufA, bufB, segA, segB, tiles, tile_start, hist, cursor, co_buf;
+    DevBuf bufA, bufB, segA, segB, co_buf;
     uint64_t seg_init[2] = {0, (uint64_t)n};
     RFX_HIP(segA.alloc(2 * 8, ctx->stream));
     RFX_HIP(hipMemcpyAsync(segA.p, seg_init, 16, hipMemcpyHostToDevice, ctx->stream));
@@ -749,8 +771,6 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
         lv.shift = 64 - used_bits;
         if (lv.shift >= 64) lv.shift = 63;            // bits == 0 on the first level: digit mask is 0
         const int64_t nchild = nseg << lv.bits;
-        RFX_HIP(hist.alloc((size_t)nchild * 8, ctx->stream));
-        RFX_HIP(hipMemsetAsync(hist.p, 0, (size_t)nchild * 8, ctx->stream));
         RFX_HIP(seg_next->alloc((size_t)(nchild + 1) * 8, ctx->stream));
         if (!out_buf->p) {
             // the two big instance buffers live in the context (grow-only), not in the pool
@@ -758,7 +778,6 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
             if (!wsp) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
             out_buf->p = wsp; out_buf->borrowed = true;
         }
-        RFX_HIP(cursor.alloc((size_t)nchild * 8, ctx->stream));
         const char *hn = l == 0 ? "hist1" : l == 1 ? "hist2" : "hist3";
         const char *pn = l == 0 ? "part1" : l == 1 ? "part2" : "part3";
         if (cur_from_reads) {
@@ -780,33 +799,42 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
             RFX_HIP(hipGetLastError());
             {
                 ScopedTimer t(ctx, pn);
-                hipLaunchKernelGGL(k_reads_scatter, dim3(G), dim3(PT), reads_scatter_lds_bytes(nb), ctx->stream, rsrc,
+                hipLaunchKernelGGL(k_reads_scatter, dim3(G), dim3(PT), scatter_lds_bytes(nb), ctx->stream, rsrc,
                                    lv, (const uint64_t *)scanned.as<uint64_t>(), out_buf->as<uint64_t>());
                 RFX_HIP(hipGetLastError());
             }
         } else {
-            const int64_t max_tiles = ceil_div(n, PTILE) + nseg;
-            RFX_HIP(tiles.alloc((size_t)nseg * 8, ctx->stream));
-            RFX_HIP(tile_start.alloc((size_t)(nseg + 1) * 8, ctx->stream));
-            hipLaunchKernelGGL(k_tiles_per_seg, dim3((unsigned)ceil_div(nseg, 256)), dim3(256), 0, ctx->stream,
-                               (const uint64_t *)seg_cur->as<uint64_t>(), nseg, tiles.as<uint64_t>());
+            // virtual workgroups of tpb tiles inside every parent; table rows -> scan -> private cursors
+            const int nb = 1 << lv.bits;
+            const int64_t total_tiles = ceil_div(n, PTILE);
+            int tpb = (int)std::min<int64_t>(32, std::max<int64_t>(1, total_tiles / ((int64_t)ctx->num_cu * 8)));
+            if (const char *e = getenv("RFX_TPB")) tpb = std::max(1, atoi(e));
+            const int64_t v_bound = ceil_div(n, (int64_t)tpb * PTILE) + nseg;
+            DevBuf nvb, vb_start, table, scanned;
+            RFX_HIP(nvb.alloc((size_t)nseg * 8, ctx->stream));
+            RFX_HIP(vb_start.alloc((size_t)(nseg + 1) * 8, ctx->stream));
+            RFX_HIP(table.alloc((size_t)nb * v_bound * 4, ctx->stream));
+            RFX_HIP(scanned.alloc(((size_t)nb * v_bound + 1) * 8, ctx->stream));
+            RFX_HIP(hipMemsetAsync(table.p, 0, (size_t)nb * v_bound * 4, ctx->stream));
+            hipLaunchKernelGGL(k_vb_per_seg, dim3((unsigned)ceil_div(nseg, 256)), dim3(256), 0, ctx->stream,
+                               (const uint64_t *)seg_cur->as<uint64_t>(), nseg, tpb, nvb.as<uint64_t>());
             RFX_HIP(hipGetLastError());
-            RFX_TRY(exclusive_scan_u64(ctx, tiles.as<uint64_t>(), tile_start.as<uint64_t>(), nseg));
+            RFX_TRY(exclusive_scan_u64(ctx, nvb.as<uint64_t>(), vb_start.as<uint64_t>(), nseg));
+            VbMap vm{seg_cur->as<uint64_t>(), vb_start.as<uint64_t>(), nseg, tpb};
             {
                 ScopedTimer t(ctx, hn);
-                hipLaunchKernelGGL(k_level_hist, dim3((unsigned)max_tiles), dim3(PT), 0, ctx->stream, cur_arr,
-                                   (const uint64_t *)seg_cur->as<uint64_t>(), (const uint64_t *)tile_start.as<uint64_t>(),
-                                   nseg, lv, hist.as<unsigned long long>());
+                hipLaunchKernelGGL(k_vb_hist, dim3((unsigned)v_bound), dim3(PT), 0, ctx->stream, cur_arr, vm, lv,
+                                   table.as<uint32_t>());
                 RFX_HIP(hipGetLastError());
             }
-            RFX_TRY(exclusive_scan_u64(ctx, hist.as<uint64_t>(), seg_next->as<uint64_t>(), nchild));
-            RFX_HIP(hipMemcpyAsync(cursor.p, seg_next->p, (size_t)nchild * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            RFX_TRY(exclusive_scan_u32_to_u64(ctx, table.as<uint32_t>(), scanned.as<uint64_t>(), (int64_t)nb * v_bound));
+            hipLaunchKernelGGL(k_child_offsets, dim3((unsigned)ceil_div(nchild + 1, 256)), dim3(256), 0, ctx->stream,
+                               (const uint64_t *)scanned.as<uint64_t>(), vm, nb, (uint64_t)n, seg_next->as<uint64_t>());
+            RFX_HIP(hipGetLastError());
             {
                 ScopedTimer t(ctx, pn);
-                hipLaunchKernelGGL(k_level_scatter, dim3((unsigned)max_tiles), dim3(PT), scatter_lds_bytes(),
-                                   ctx->stream, cur_arr, (const uint64_t *)seg_cur->as<uint64_t>(),
-                                   (const uint64_t *)tile_start.as<uint64_t>(), nseg, lv,
-                                   cursor.as<unsigned long long>(), out_buf->as<uint64_t>());
+                hipLaunchKernelGGL(k_vb_scatter, dim3((unsigned)v_bound), dim3(PT), scatter_lds_bytes(nb), ctx->stream,
+                                   cur_arr, vm, lv, (const uint64_t *)scanned.as<uint64_t>(), out_buf->as<uint64_t>());
                 RFX_HIP(hipGetLastError());
             }
         }
@@ -871,7 +899,7 @@ int bucket_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, uint64_t
         hipLaunchKernelGGL(k_bin_offsets, dim3(1), dim3(256), 0, ctx->stream, (const uint64_t *)scanned.as<uint64_t>(),
                            n_owners, (int64_t)G, reinterpret_cast<uint64_t *>(d_owner_off));
         RFX_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_reads_scatter, dim3(G), dim3(PT), reads_scatter_lds_bytes(n_owners), ctx->stream, rsrc, lv,
+        hipLaunchKernelGGL(k_reads_scatter, dim3(G), dim3(PT), scatter_lds_bytes(n_owners), ctx->stream, rsrc, lv,
                            (const uint64_t *)scanned.as<uint64_t>(), d_out);
         RFX_HIP(hipGetLastError());
     } else {

@@ -3,6 +3,7 @@
 #include "rfx_internal.h"
 #include <algorithm>
 #include <cstdlib>
+#include <ctime>
 
 using namespace rfx;
 
@@ -410,22 +411,50 @@ int rfx_dev_assemble(rfx_ctx *ctx, const uint64_t *d_keys, const int32_t *d_coun
     int64_t nt = 0;
     DevRecords a, b;
     DevBuf ps, ops;
+    // two alternating bump arenas hold every temporary and record set of a pass / stage
+    Arena arena[2];
+    {
+        const size_t per = (size_t)(2 * n) * 176 + ((size_t)64 << 20);
+        for (int i = 0; i < 2; i++) {
+            arena[i].base = (char *)ctx->ws_get(2 + i, per);
+            if (!arena[i].base) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
+            arena[i].cap = per;
+        }
+    }
+    struct ArenaGuard { ~ArenaGuard() { tl_arena = nullptr; } } arena_guard;
+    int arena_turn = 0;
+    auto next_arena = [&]() { Arena *ar = &arena[arena_turn++ & 1]; ar->off = 0; tl_arena = ar; };
+    next_arena();
     // KmerReverseComplement + ForwardSubKmerExtraction  :168-176
     RFX_TRY(rc_expand_subkmer(ctx, d_keys, d_counts, n, k, a));
     // sortByKey + FilterForkSubKmer[WithErrorCorrection]  :179-186
+    next_arena();
     RFX_TRY(sort_records(ctx, a, P, key_bits, b, ps));
+    next_arena();
     RFX_TRY(fork_filter(ctx, false, b, ps.as<int64_t>(), P, k, prm->min_error_cov, twin, a, ops));
     // ReflectedSubKmerExtractionFromForward  :188-189
+    next_arena();
     RFX_TRY(reflect_from_forward(ctx, a, k, b));
     // sortByKey + FilterForkReflectedSubKmer[WithErrorCorrection]  :191-198
+    next_arena();
     RFX_TRY(sort_records(ctx, b, P, key_bits, a, ps));
+    next_arena();
     RFX_TRY(fork_filter(ctx, true, a, ps.as<int64_t>(), P, k, prm->min_error_cov, twin, b, ops));
     // kmerRandomReflection on the filter's output partitions  :204-205
+    next_arena();
     RFX_TRY(random_reflection(ctx, b, ops.as<int64_t>(), P, k, a));
 
+    const bool verbose = getenv("RFX_TRACE") != nullptr;
+    auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     auto one_pass = [&](int stage) -> int {
+        const double t0 = verbose ? now_ms() : 0;
+        next_arena();                     // `a` (this pass's input) stays valid in the other arena
         RFX_TRY(sort_records(ctx, a, P, key_bits, b, ps));                        // sortByKey :211,:235,:247,:286
+        if (verbose) (void)hipStreamSynchronize(ctx->stream);
+        const double t1 = verbose ? now_ms() : 0;
         RFX_TRY(extend_pass(ctx, b, ps.as<int64_t>(), P, k, twin, stage, a, ops));
+        if (verbose) fprintf(stderr, "pass %lld: n_in %lld words %lld sort %.3f ms extend %.3f ms -> n %lld\n", (long long)nt,
+                             (long long)b.n, (long long)b.words, t1 - t0, now_ms() - t1, (long long)a.n);
         if (trace && nt < trace_cap) trace[nt] = a.n;
         nt++;
         return RFX_OK;

@@ -56,7 +56,13 @@ struct rfx_ctx {
         if (s_ != RFX_OK) return s_;               \
     } while (0)
 
-// Stream-ordered scratch allocation that frees itself.
+// Bump arena for the temporaries of one pass of the extend loop: two of them alternate, so a
+// pass reads its inputs from the previous pass's arena and nothing is allocated or freed per pass
+// (hipMallocAsync with ever-changing sizes cost ~5 ms per pass, far more than the kernels).
+struct Arena { char *base = nullptr; size_t cap = 0, off = 0; };
+inline thread_local Arena *tl_arena = nullptr;
+
+// Stream-ordered scratch allocation that frees itself (or a slice of the current arena).
 struct DevBuf {
     void *p = nullptr;
     hipStream_t s = nullptr;
@@ -69,6 +75,15 @@ struct DevBuf {
         release();
         s = stream;
         if (bytes == 0) bytes = 16;
+        if (tl_arena) {
+            const size_t need = (bytes + 255) & ~(size_t)255;
+            if (tl_arena->off + need <= tl_arena->cap) {
+                p = tl_arena->base + tl_arena->off;
+                tl_arena->off += need;
+                borrowed = true;
+                return hipSuccess;
+            }
+        }
         return hipMallocAsync(&p, bytes, stream);
     }
     void release() {

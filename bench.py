@@ -126,13 +126,16 @@ def main():
     engine = rd.HipEngine(rfx)
     timing_acc = {}
 
+    shard = {}
+
     def step():
         if world == 1:
             m, nd, inst = rfx.count_reads_dev(d_words.data_ptr(), n_reads, wpr, L, k, d_keys.data_ptr(),
                                               d_counts.data_ptr(), cap, args.cover)
             return m, nd, inst
         keys, counts, tot = rd.sharded_count(engine, reads, args.cover, 10_000_000, 0)
-        return int(keys.numel()), tot[1], tot[0]
+        shard["keys"], shard["counts"] = keys, counts
+        return tot[2], tot[1], tot[0] // world
 
     def sync_all():
         torch.cuda.synchronize()
@@ -180,19 +183,36 @@ def main():
         "config": {"workload": f"synthetic {args.gbp:g} Gbp per GPU, E.coli-like genome {args.genome} bp, "
                                f"PE{L}, k={k}, -cover {args.cover}, 0.5% substitutions",
                    "reads_per_gpu": n_reads, "kmer_instances_per_gpu": n_inst, "distinct_kmers": nd,
-                   "kmers_kept": m if world == 1 else None,
+                   "kmers_kept": m,
                    "parallelism": "1 GPU" if world == 1 else f"k-mer space radix-sharded over {world} GPUs, "
                                                                "RCCL all-to-all(v)"},
         "roofline": roofline,
         "stage_hbm_frac": ((16.25 * n_inst + 12 * m) / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS) if world == 1 else None,
     }
 
-    if rank == 0 and world == 1 and not args.no_contigs:
+    if world > 1 and not args.no_contigs:
+        # the filtered list is small: gather it on rank 0, restore ascending k-mer order there
+        # and run the extend stage on that one GPU
+        torch.cuda.synchronize()
+        t_g = time.perf_counter()
+        gk, gc = rd.gather_survivors(shard["keys"], shard["counts"])
+        if rank == 0:
+            m = int(gk.numel())
+            gk = gk.contiguous(); gc = gc.contiguous()
+            tk = torch.empty_like(gk); tv = torch.empty_like(gc)
+            torch.cuda.synchronize()
+            rfx.sort_pairs_dev(gk.data_ptr(), gc.data_ptr(), m, 2 * k, tk.data_ptr(), tv.data_ptr())
+            rfx.sync()
+            d_keys, d_counts = gk, gc
+        t_gather = time.perf_counter() - t_g
+    if rank == 0 and not args.no_contigs:
         prm = reflexiv_amd.default_params(k=k, min_cov=args.cover, partitions=args.partitions)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         text, nc, trace = rfx.assemble_dev(d_keys.data_ptr(), d_counts.data_ptr(), m, prm)
         t_asm = time.perf_counter() - t1
+        if world > 1:
+            t_asm += t_gather
         lens = sorted((int(h.split("-")[1]) for h in text.split("\n") if h.startswith(">")), reverse=True)
         out["contigs"] = {"wall_ms_from_counts": t_asm * 1e3, "wall_ms_reads_to_contigs": t_asm * 1e3 + dt / args.steps * 1e3,
                           "extend_passes": len(trace), "n_contigs": nc, "longest": lens[:3],

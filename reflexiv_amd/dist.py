@@ -35,14 +35,22 @@ class HipEngine:
         return out[:n], torch.from_numpy(h.copy())
 
     def count_kmers(self, kmers, min_cov, max_cov, twin):
+        from ._lib import RfxError, RFX_E_CAP
         n = int(kmers.numel())
-        cap = max(1, n)
-        keys = torch.empty(cap, dtype=torch.int64, device=kmers.device)
-        counts = torch.empty(cap, dtype=torch.int32, device=kmers.device)
-        torch.cuda.current_stream().synchronize()
-        m, d = self.rfx.count_kmers_dev(kmers.data_ptr(), n, keys.data_ptr(), counts.data_ptr(), cap,
-                                        min_cov, max_cov, twin)
-        return keys[:m], counts[:m], d
+        cap = max(1 << 20, n // 8)              # survivors are few; grow on RFX_E_CAP
+        while True:
+            keys = torch.empty(cap, dtype=torch.int64, device=kmers.device)
+            counts = torch.empty(cap, dtype=torch.int32, device=kmers.device)
+            torch.cuda.current_stream().synchronize()
+            try:
+                m, d = self.rfx.count_kmers_dev(kmers.data_ptr(), n, keys.data_ptr(), counts.data_ptr(), cap,
+                                                min_cov, max_cov, twin)
+                return keys[:m], counts[:m], d
+            except RfxError as e:
+                if e.status != RFX_E_CAP or cap >= n:
+                    raise
+                del keys, counts
+                cap = min(max(1, n), cap * 4)
 
 
 def exchange_by_owner(kmers: torch.Tensor, owner_off: torch.Tensor, group=None) -> torch.Tensor:
@@ -73,3 +81,28 @@ def sharded_count(engine, reads, min_cov, max_cov, twin, group=None):
     if world > 1:
         dist.all_reduce(tot, group=group)            # C4-style scalar reduce
     return keys, counts, [int(x) for x in tot.cpu()]
+
+
+def gather_survivors(keys: torch.Tensor, counts: torch.Tensor, group=None, root: int = 0):
+    """Collect every rank's (kmer, count) shard on `root` (all-gather of padded shards; the
+    filtered list is tiny next to the instances: D' << N).  Shards are hash ranges, so the
+    concatenation is NOT in k-mer order -- the caller sorts it (rfx sort_pairs) before the
+    extend stage, which runs on one GPU this round."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return keys, counts
+    n = torch.tensor([int(keys.numel())], dtype=torch.int64, device=keys.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(x.item()) for x in sizes]
+    m = max(1, max(sizes))
+    pk = torch.zeros(m, dtype=keys.dtype, device=keys.device); pk[:keys.numel()] = keys
+    pc = torch.zeros(m, dtype=counts.dtype, device=counts.device); pc[:counts.numel()] = counts
+    gk = [torch.empty_like(pk) for _ in range(world)]
+    gc = [torch.empty_like(pc) for _ in range(world)]
+    dist.all_gather(gk, pk, group=group)
+    dist.all_gather(gc, pc, group=group)
+    if dist.get_rank(group) != root:
+        return None, None
+    return (torch.cat([gk[r][:sizes[r]] for r in range(world)]),
+            torch.cat([gc[r][:sizes[r]] for r in range(world)]))

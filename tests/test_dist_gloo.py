@@ -61,6 +61,11 @@ def _worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q):
         bases, off = O.synth_reads(seed, g, G, rank * per_rank, per_rank, L)    # this rank's read shard
         reads = dict(bases=bases, read_off=off, k=k)
         keys, counts, tot = rd.sharded_count(OracleEngine(), reads, min_cov, 10_000_000, O.TWIN_DS)
+        allk, allc = rd.gather_survivors(keys, counts)
+        if rank == 0:
+            q.put(("root", allk.numpy().view(np.uint64).copy(), allc.numpy().copy(), None))
+        else:
+            assert allk is None
         q.put((rank, keys.numpy().view(np.uint64).copy(), counts.numpy().copy(), tot))
         dist.barrier()
     finally:
@@ -77,7 +82,9 @@ def test_sharded_count_equals_global_count(world):
              for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    got = [q.get(timeout=120) for _ in range(world + 1)]
+    root = [t for t in got if t[0] == "root"][0]
+    res = sorted([t for t in got if t[0] != "root"], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -95,6 +102,8 @@ def test_sharded_count_equals_global_count(world):
         assert np.all(owner_of(kk, world) == rank)
     order = np.argsort(allk, kind="stable")
     assert np.array_equal(allk[order], wk) and np.array_equal(allc[order], wc)
+    # the root's gathered list is the same multiset, in rank order
+    assert np.array_equal(root[1], allk) and np.array_equal(root[2], allc)
 
 
 def test_owner_function_is_balanced_and_total():

@@ -215,6 +215,54 @@ std::string ReflexivMain::assembly(const std::string &fastqText, std::vector<int
     return assemblyFromCounts(counts, trace);
 }
 
+// KmerBinarizer.call  P/ReflexivDSMain.java:3883-3931: "KMER,count" or "(KMER,count)"; a count of
+// ten or more digits saturates at 1,000,000,000; bases A0 C1 G2, anything else 3.
+KmerBinaryRDD ReflexivMain::KmerBinarizer::call(const std::string &csvText) const {
+    KmerBinaryRDD o;
+    const int k = m.param.kmerSize;
+    size_t pos = 0;
+    while (pos < csvText.size()) {
+        size_t e = csvText.find('\n', pos);
+        if (e == std::string::npos) e = csvText.size();
+        size_t l = e - pos;
+        if (l > 0 && csvText[e - 1] == '\r') l--;
+        std::string line = csvText.substr(pos, l);
+        pos = e + 1;
+        if (line.empty()) continue;
+        size_t comma = line.find(',');
+        if (comma == std::string::npos) throw std::runtime_error("k-mer count row without a comma: " + line);
+        std::string kmer = line.substr(0, comma), cnt = line.substr(comma + 1);
+        if (!kmer.empty() && kmer[0] == '(') kmer = kmer.substr(1);                    // :3892-3894
+        int cover;
+        if (!cnt.empty() && cnt.back() == ')') {                                       // :3896-3901
+            cover = cnt.size() >= 11 ? 1000000000 : std::stoi(cnt.substr(0, cnt.size() - 1));
+        } else {                                                                       // :3902-3908
+            cover = cnt.size() >= 10 ? 1000000000 : std::stoi(cnt);
+        }
+        if ((int)kmer.size() < k) throw std::runtime_error("k-mer shorter than -kmer: " + kmer);
+        uint64_t b = 0;
+        for (int i = 0; i < k; i++) {                                                  // :3912-3919
+            char c = kmer[(size_t)i];
+            b = (b << 2) | (c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : 3u);
+        }
+        o.kmer.push_back(b); o.count.push_back(cover);
+    }
+    return o;
+}
+
+// `run -kmerc`: load -> filter(min <= count <= max) (P/ReflexivDSMain.java:458-478) -> the same driver.
+// The order contract wants the (kmer,count) list ascending, whatever order the files came in.
+std::string ReflexivMain::assemblyFromKmer(const std::string &csvText, std::vector<int64_t> *trace) {
+    KmerBinaryRDD in = KmerBinarizer{*this}.call(csvText);
+    std::vector<size_t> idx;
+    for (size_t i = 0; i < in.kmer.size(); i++)
+        if (in.count[i] >= param.minKmerCoverage && in.count[i] <= param.maxKmerCoverage) idx.push_back(i);
+    std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return in.kmer[a] < in.kmer[b]; });
+    KmerBinaryRDD f;
+    for (size_t i : idx) { f.kmer.push_back(in.kmer[i]); f.count.push_back(in.count[i]); }
+    return assemblyFromCounts(f, trace);
+}
+
 // P/ReflexivCounter.java:109-191: k-mer, count text lines
 std::string ReflexivMain::counter(const std::string &fastqText) {
     static const char NUC[4] = {'A', 'C', 'G', 'T'};

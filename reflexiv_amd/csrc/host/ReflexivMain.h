@@ -102,6 +102,13 @@ public:
     // ReflexivCounter.assembly(): P/ReflexivCounter.java:109-191 -> lines "KMER,count"
     std::string counter(const std::string &fastqText);
     std::string assemblyFromCounts(const KmerBinaryRDD &counts, std::vector<int64_t> *trace = nullptr);
+    // assemblyFromKmer(): P/ReflexivMain.java:327-568 / P/ReflexivDSMain.java:362-712 -- `run -kmerc`:
+    // CSV rows "KMER,count" (also the legacy "(KMER,count)" tuple text) as written by `counter`
+    struct KmerBinarizer {                           // P/ReflexivDSMain.java:3871-3947
+        ReflexivMain &m;
+        KmerBinaryRDD call(const std::string &csvText) const;
+    };
+    std::string assemblyFromKmer(const std::string &csvText, std::vector<int64_t> *trace = nullptr);
 
     rfx_ctx *ctx = nullptr;
     DefaultParam param;

@@ -8,6 +8,9 @@
 #include <iostream>
 #include <sstream>
 #include <sys/stat.h>
+#include <dirent.h>
+#include <cstring>
+#include <algorithm>
 
 #include "ReflexivMain.h"
 
@@ -28,19 +31,41 @@ int main(int argc, char **argv) {
         std::string cmd = argv[1];
         std::vector<std::string> args(argv + 2, argv + argc);
         reflexiv::DefaultParam param = reflexiv::importCommandLine(args);
-        if (param.inputFqPath.empty() || param.outputPath.empty()) throw std::runtime_error("-fastq and -outfile are required");
-        std::string text;
-        std::stringstream ss(param.inputFqPath);
-        for (std::string one; std::getline(ss, one, ',');) { text += slurp(one); if (!text.empty() && text.back() != '\n') text.push_back('\n'); }
+        if (param.outputPath.empty()) throw std::runtime_error("-outfile is required");
+        if (param.inputFqPath.empty() && param.inputKmerPath.empty()) throw std::runtime_error("-fastq or -kmerc is required");
+        auto read_all = [&](const std::string &paths) {
+            std::string text;
+            std::stringstream ss(paths);
+            for (std::string one; std::getline(ss, one, ',');) {
+                struct stat st;
+                if (stat(one.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) {      // a Spark output directory: every part-*
+                    DIR *d = opendir(one.c_str());
+                    std::vector<std::string> parts;
+                    for (dirent *e; d && (e = readdir(d));) if (strncmp(e->d_name, "part-", 5) == 0) parts.push_back(one + "/" + e->d_name);
+                    if (d) closedir(d);
+                    std::sort(parts.begin(), parts.end());
+                    for (auto &f : parts) text += slurp(f);
+                } else {
+                    text += slurp(one);
+                }
+                if (!text.empty() && text.back() != '\n') text.push_back('\n');
+            }
+            return text;
+        };
         reflexiv::ReflexivMain m;
         m.setParam(param);
-        std::string out;
-        if (cmd == "run") out = m.assembly(text);
-        else if (cmd == "counter") out = m.counter(text);
-        else throw std::runtime_error("unknown command " + cmd);
-        mkdir(param.outputPath.c_str(), 0755);
-        std::ofstream(param.outputPath + "/part-00000", std::ios::binary) << out;      // saveAsTextFile
-        std::ofstream(param.outputPath + "/_SUCCESS", std::ios::binary);
+        std::string out, dir = param.outputPath;
+        mkdir(dir.c_str(), 0755);
+        if (cmd == "run") {
+            // M/Main.java:74-78 -> Pipelines.reflexivDSMainPipe(): -kmerc routes to assemblyFromKmer()
+            out = param.inputKmerPath.empty() ? m.assembly(read_all(param.inputFqPath)) : m.assemblyFromKmer(read_all(param.inputKmerPath));
+        } else if (cmd == "counter") {
+            out = m.counter(read_all(param.inputFqPath));
+            dir += "/Count_" + std::to_string(param.kmerSize);               // P/ReflexivDataFrameCounter.java:222-233
+            mkdir(dir.c_str(), 0755);
+        } else throw std::runtime_error("unknown command " + cmd);
+        std::ofstream(dir + (cmd == "counter" ? "/part-00000.csv" : "/part-00000"), std::ios::binary) << out;   // saveAsTextFile / csv
+        std::ofstream(dir + "/_SUCCESS", std::ios::binary);
         return 0;
     } catch (const std::exception &e) {
         std::cerr << "reflexiv_host: " << e.what() << "\n";

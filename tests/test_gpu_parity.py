@@ -422,7 +422,10 @@ def test_cpp_host_run_matches_documented_example(tmp_path, ex, gz):
     assert text.startswith(str(ex["doc_header"]) + "\n")
 
 
-def test_cpp_host_counter(tmp_path, ex):
+def test_cpp_host_counter_then_run_kmerc(tmp_path, ex):
+    """`counter` writes Count_<k>/part-*.csv rows "KMER,count" (P/ReflexivDataFrameCounter.java:222-233);
+    `run -kmerc` parses them (KmerBinarizer, P/ReflexivDSMain.java:3883-3931) and assembles -- the
+    working k-mer-count hand-off of the reference."""
     import subprocess
     import reflexiv_amd._lib as L
     host = os.path.join(os.path.dirname(L.LIB_PATH), "reflexiv_host")
@@ -430,12 +433,22 @@ def test_cpp_host_counter(tmp_path, ex):
     write_fastq(fq, ex["bases"], ex["read_off"])
     out = str(tmp_path / "cnt")
     subprocess.check_call([host, "counter", "-fastq", fq, "-outfile", out, "-kmer", "31", "-cover", "3"])
-    lines = open(os.path.join(out, "part-00000")).read().split("\n")[:-1]
+    cdir = os.path.join(out, "Count_31")
+    lines = open(os.path.join(cdir, "part-00000.csv")).read().split("\n")[:-1]
     assert len(lines) == 4612
     nuc = "ACGT"
     want = ["".join(nuc[(int(k) >> (2 * (30 - j))) & 3] for j in range(31)) + "," + str(int(c))
             for k, c in zip(ex["keys_cov3"], ex["counts_cov3"])]
     assert lines == want
+    # legacy tuple text + shuffled row order must parse to the same assembly
+    rng = np.random.default_rng(0)
+    legacy = ["(" + l.replace(",", ",") + ")" for l in lines]
+    rng.shuffle(legacy)
+    open(os.path.join(cdir, "part-00000.csv"), "w").write("\n".join(legacy) + "\n")
+    res = str(tmp_path / "asm")
+    subprocess.check_call([host, "run", "-kmerc", cdir, "-outfile", res, "-kmer", "31", "-cover", "3",
+                           "--logical-partitions", "4", "--twin", "rdd"])
+    assert open(os.path.join(res, "part-00000")).read() == str(ex["contigs_rdd_P4"])
 
 
 def test_sharded_count_engine_world1(rfx, torch_mod):

@@ -412,7 +412,9 @@ __global__ __launch_bounds__(PT) void k_vb_scatter(const uint64_t *__restrict__ 
 // ------------------------------------------------------------------- leaves
 
 constexpr int LT = 512;                 // threads per leaf workgroup
-constexpr int OBUF = 1024;              // survivors buffered in LDS between flushes
+constexpr int OBUF = 512;               // survivors buffered in LDS between flushes
+constexpr int WSTAGE = 256;             // expanded k-mers a wave stages per round (record leaves)
+constexpr int LSTAGE = WSTAGE * (LT / 64);
 constexpr int LCAP = 4096;              // hash slots
 constexpr int LFULL = (LCAP * 3) / 4;   // give up on a sub-pass beyond this many distinct keys
 constexpr uint64_t EMPTY = ~0ULL;
@@ -425,6 +427,9 @@ struct CountOut {
     unsigned long long n_out;        // survivors appended (may exceed cap)
     unsigned long long n_distinct;   // distinct k-mers seen
     unsigned long long n_failed;     // leaves that ran out of split depth (must stay 0)
+    unsigned long long n_passes;     // table passes run (>= non-empty leaves)
+    unsigned long long n_overflow;   // passes abandoned because the table filled up
+    unsigned long long n_leaves;     // non-empty leaves
 };
 
 // Persistent workgroups each walk a CONTIGUOUS chunk of leaf buckets, i.e. one contiguous
@@ -434,8 +439,46 @@ struct CountOut {
 // and resetting touch only those.  Survivors collect in an LDS buffer and leave with ONE global
 // atomic per flush (a per-leaf atomic on one hot counter serialises the whole grid).
 // A leaf with more than LFULL distinct keys is re-streamed in 2, 4, ... hash-selected parts.
-__global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ keys,
-                                                   const uint64_t *__restrict__ leaf_off, int64_t nleaf,
+// Leaf input element: a k-mer instance (8 B) or a super-k-mer record (16 B, <= 16 instances).
+struct alignas(16) Rec { uint64_t w0, w1; };
+// Rec: w0 = bases 0..31 of the run's base string, w1 = [63..36] bases 32..45, [35..32] windows-1,
+// [31..0] the top 32 bits of the minimiser's local hash (radix digits peel off its top).
+__device__ __forceinline__ int rec_len(const Rec &r) { return (int)((r.w1 >> 32) & 15) + 1; }
+__device__ __forceinline__ uint32_t rec_hdr(const Rec &r) { return (uint32_t)r.w1; }
+
+template <bool RECS> struct LeafElem;
+template <> struct LeafElem<false> {
+    using T = uint64_t;
+    static constexpr int PER_LANE = LB;
+    __device__ static __forceinline__ T none() { return 0; }
+    template <class F> __device__ static __forceinline__ void for_each_kmer(const T &e, int, F &&f) { f(e); }
+};
+template <> struct LeafElem<true> {
+    using T = Rec;
+    static constexpr int PER_LANE = 1;
+    __device__ static __forceinline__ T none() { return Rec{0, 0}; }
+    // canonical k-mers of the record's windows, rolled in registers (same arithmetic as seg_keys)
+    template <class F> __device__ static __forceinline__ void for_each_kmer(const T &e, int k, F &&f) {
+        const int n = rec_len(e);
+        const int k2 = 2 * k;
+        uint64_t fwd = e.w0 >> (64 - k2);
+        uint64_t rc = revcomp(fwd, k);
+        uint64_t rest = (e.w0 << k2) | (e.w1 >> (64 - k2));
+        const uint64_t mask = low_mask(k);
+        const int top = k2 - 2;
+        for (int i = 0; i < n; i++) {
+            f(fwd < rc ? fwd : rc);
+            const uint64_t b = rest >> 62;
+            rest <<= 2;
+            fwd = ((fwd << 2) | b) & mask;
+            rc = (rc >> 2) | ((b ^ 3) << top);
+        }
+    }
+};
+
+template <bool RECS>
+__global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>::T *__restrict__ keys,
+                                                   const uint64_t *__restrict__ leaf_off, int64_t nleaf, int k,
                                                    int min_cov, int max_cov, int apply_filter,
                                                    uint64_t *__restrict__ out_keys, int32_t *__restrict__ out_counts,
                                                    unsigned long long cap, CountOut *__restrict__ co) {
@@ -448,7 +491,9 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ 
     __shared__ int sp;
     __shared__ uint32_t n_dist, overflow, ob_n;
     __shared__ unsigned long long g_emit;
+    __shared__ uint64_t stage[RECS ? LSTAGE : 1];  // records: expanded k-mers, one per lane per round
     unsigned long long my_distinct = 0;            // thread 0 only
+    const int lane_ = threadIdx.x & 63;
 
     const int64_t l0 = (int64_t)(((unsigned long long)blockIdx.x * (unsigned long long)nleaf) / gridDim.x);
     const int64_t l1 = (int64_t)(((unsigned long long)(blockIdx.x + 1) * (unsigned long long)nleaf) / gridDim.x);
@@ -474,15 +519,17 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ 
         __syncthreads();
     };
 
-    // prefetched batch: kn[j] = keys[pf + j*LT + tid] (0 beyond the chunk's stream)
-    uint64_t kn[LB];
+    // prefetched batch: kn[j] = keys[pf + j*LT + tid] (empty beyond the chunk's stream)
+    using Elem = typename LeafElem<RECS>::T;
+    constexpr int NB = LeafElem<RECS>::PER_LANE;      // elements in flight per lane
+    Elem kn[NB];
     uint64_t pf = leaf_off[l0];
     auto prefetch = [&](uint64_t pos) {
         pf = pos;
 #pragma unroll
-        for (int j = 0; j < LB; j++) {
+        for (int j = 0; j < NB; j++) {
             const uint64_t i = pos + (uint64_t)j * LT + threadIdx.x;
-            kn[j] = i < stream_end ? keys[i] : 0;
+            kn[j] = i < stream_end ? keys[i] : LeafElem<RECS>::none();
         }
     };
     prefetch(pf);
@@ -502,49 +549,106 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ 
                 const uint32_t S = stackS[sp - 1], s = stacks[sp - 1];
                 __syncthreads();
                 if (threadIdx.x == 0) sp--;
-                for (uint64_t base = begin; base < end; base += (uint64_t)LT * LB) {
-                    // an overflowing pass is abandoned: stop feeding a table that is filling up
-                    // (probe sequences in a full table would cost LCAP CAS per key)
-                    if (*(volatile uint32_t *)&overflow) break;
-                    uint64_t kc[LB];
-                    if (pf == base) {
-#pragma unroll
-                        for (int j = 0; j < LB; j++) kc[j] = kn[j];
-                    } else {                        // re-streaming a split leaf: load now
-#pragma unroll
-                        for (int j = 0; j < LB; j++) {
-                            const uint64_t i = base + (uint64_t)j * LT + threadIdx.x;
-                            kc[j] = i < end ? keys[i] : 0;
-                        }
-                    }
-                    // next batch of this leaf, or the first batch of the next leaf
-                    const uint64_t nxt = base + (uint64_t)LT * LB < end ? base + (uint64_t)LT * LB : end;
-                    if (nxt < stream_end && nxt != pf) prefetch(nxt);
-                    // key-major inserts (issuing the LB CAS of a lane back to back measured slower:
-                    // the LDS pipe, not its latency, is the limit -- profiles/README.md)
-#pragma unroll
-                    for (int j = 0; j < LB; j++) {
-                        if (base + (uint64_t)j * LT + threadIdx.x >= end) continue;
-                        const uint64_t key = kc[j];
-                        const uint64_t h = local_hash(key);
-                        if (S > 1 && ((uint32_t)(h >> LEAF_SPLIT_SHIFT) & (S - 1)) != s) continue;
-                        uint32_t slot = (uint32_t)(h >> LEAF_SLOT_SHIFT) & (LCAP - 1);
-                        for (int probe = 0; probe < LCAP; probe++) {
-                            const unsigned long long prev = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
-                            if (prev == EMPTY) {
-                                const uint32_t pos = atomicAdd(&n_dist, 1u);
+                auto insert = [&](uint64_t key) {
+                    const uint64_t h = local_hash(key);
+                    if (S > 1 && ((uint32_t)(h >> LEAF_SPLIT_SHIFT) & (S - 1)) != s) return;
+                    uint32_t slot = (uint32_t)(h >> LEAF_SLOT_SHIFT) & (LCAP - 1);
+                    for (int probe = 0; probe < LCAP; probe++) {
+                        const unsigned long long prev = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
+                        // the lanes that just claimed a slot take their places in the occupancy list
+                        // with ONE add on the shared counter (a per-lane add serialises on one address)
+                        const bool fresh = prev == EMPTY;
+                        const uint64_t fm = __ballot(fresh);
+                        if (fm) {
+                            const int leader = __ffsll((unsigned long long)fm) - 1;
+                            uint32_t pos = 0;
+                            if (lane_ == leader) pos = atomicAdd(&n_dist, (uint32_t)__popcll(fm));
+                            pos = __shfl(pos, leader, 64) + (uint32_t)__popcll(fm & ((1ULL << lane_) - 1));
+                            if (fresh) {
                                 if (pos < (uint32_t)LFULL) occ[pos] = (uint16_t)slot; else overflow = 1;
                                 atomicAdd(&tcnt[slot], 1u);
                                 break;
                             }
-                            if (prev == key) { atomicAdd(&tcnt[slot], 1u); break; }
-                            slot = (slot + 1) & (LCAP - 1);
-                            if ((probe & 31) == 31 && *(volatile uint32_t *)&overflow) break;
+                        }
+                        if (prev == key) { atomicAdd(&tcnt[slot], 1u); break; }
+                        slot = (slot + 1) & (LCAP - 1);
+                        if ((probe & 31) == 31 && *(volatile uint32_t *)&overflow) break;
+                    }
+                };
+                for (uint64_t base = begin; base < end; base += (uint64_t)LT * NB) {
+                    // an overflowing pass is abandoned: stop feeding a table that is filling up
+                    // (probe sequences in a full table would cost LCAP CAS per key)
+                    if (*(volatile uint32_t *)&overflow) break;
+                    Elem kc[NB];
+                    if (pf == base) {
+#pragma unroll
+                        for (int j = 0; j < NB; j++) kc[j] = kn[j];
+                    } else {                        // re-streaming a split leaf: load now
+#pragma unroll
+                        for (int j = 0; j < NB; j++) {
+                            const uint64_t i = base + (uint64_t)j * LT + threadIdx.x;
+                            kc[j] = i < end ? keys[i] : LeafElem<RECS>::none();
+                        }
+                    }
+                    // next batch of this leaf, or the first batch of the next leaf
+                    const uint64_t nxt = base + (uint64_t)LT * NB < end ? base + (uint64_t)LT * NB : end;
+                    if (nxt < stream_end && nxt != pf) prefetch(nxt);
+                    if constexpr (RECS) {
+                        // Records hold 1..16 windows each: expand them into LDS so that every lane
+                        // inserts the same number of k-mers (lane-per-record loops ran at ~40 %
+                        // utilisation).  One record per lane per batch.
+                        const bool valid = base + threadIdx.x < end;
+                        const int nwin = valid ? rec_len(kc[0]) : 0;
+                        uint64_t km[PK];
+                        {
+                            const int k2 = 2 * k;
+                            uint64_t fwd = kc[0].w0 >> (64 - k2);
+                            uint64_t rc = revcomp(fwd, k);
+                            uint64_t rest = (kc[0].w0 << k2) | (kc[0].w1 >> (64 - k2));
+                            const uint64_t mask = low_mask(k);
+                            const int top = k2 - 2;
+#pragma unroll
+                            for (int t = 0; t < PK; t++) {
+                                km[t] = fwd < rc ? fwd : rc;
+                                const uint64_t bb = rest >> 62;
+                                rest <<= 2;
+                                fwd = ((fwd << 2) | bb) & mask;
+                                rc = (rc >> 2) | ((bb ^ 3) << top);
+                            }
+                        }
+                        // wave-private staging: a wave scans its 64 lengths with shuffles, writes
+                        // its k-mers to its own LDS window and reads them back one per lane -- no
+                        // workgroup barrier anywhere in the batch (LDS ops of one wave stay in order)
+                        const int lane = threadIdx.x & 63;
+                        uint64_t *wst = stage + (threadIdx.x >> 6) * WSTAGE;
+                        uint32_t x = (uint32_t)nwin;
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const uint32_t y = __shfl_up(x, o, 64);
+                            if (lane >= o) x += y;
+                        }
+                        const uint32_t off = x - (uint32_t)nwin;
+                        const uint32_t total = __shfl(x, 63, 64);
+                        for (uint32_t wb = 0; wb < total; wb += WSTAGE) {
+#pragma unroll
+                            for (int t = 0; t < PK; t++) {
+                                const uint32_t pos = off + t - wb;        // wraps for pos < wb: fails the test
+                                if (t < nwin && pos < (uint32_t)WSTAGE) wst[pos] = km[t];
+                            }
+                            const uint32_t lim = total - wb < (uint32_t)WSTAGE ? total - wb : (uint32_t)WSTAGE;
+                            for (uint32_t j = lane; j < lim; j += 64) insert(wst[j]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NB; j++) {
+                            if (base + (uint64_t)j * LT + threadIdx.x >= end) continue;
+                            insert(kc[j]);
                         }
                     }
                 }
                 __syncthreads();
                 const uint32_t nd = n_dist;
+                if (threadIdx.x == 0) { atomicAdd(&co->n_passes, 1ULL); if (overflow) atomicAdd(&co->n_overflow, 1ULL); }
                 if (overflow) {
                     // abandon: wipe the table, re-stream in two hash-selected halves
                     __syncthreads();
@@ -588,6 +692,175 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const uint64_t *__restrict__ 
     }
     flush();
     if (threadIdx.x == 0 && my_distinct) atomicAdd(&co->n_distinct, my_distinct);
+}
+
+// ------------------------------------------------------- super-k-mer records
+
+// Level 1 from reads, second form: instead of one 8-byte k-mer per window, a thread emits one
+// 16-byte record per RUN of consecutive windows (inside its 16-window segment) that share a
+// minimiser -- the canonical 13-mer with the smallest hash among the window's W = k-12 m-mers.
+// The minimiser is a function of the canonical k-mer (the set of canonical m-mers is the same on
+// both strands), so every instance of a k-mer follows the same bucket path; buckets are radix
+// digits of the minimiser's hash.  ~6 windows per record -> ~2.6 B per instance through the
+// partition levels instead of 8, and the leaf expands records straight into its LDS table, so the
+// 8-byte instance array never exists in HBM.  (KMC / Gerbil-style, re-cut for wave64 + LDS.)
+constexpr int SK_M = 13;
+constexpr int SKT = 1024;             // threads per workgroup of the reads -> records kernels
+
+__device__ __forceinline__ uint64_t mmer_key(uint32_t canon) {
+    uint32_t h = canon * 0x9E3779B1u;
+    h ^= h >> 15;
+    return ((uint64_t)h << 32) | canon;           // ordered by hash, ties by the m-mer itself
+}
+
+// digit of a record at a level that follows `used` radix bits
+__device__ __forceinline__ unsigned rec_digit(uint32_t hdr, int used, int bits) {
+    return bits ? (unsigned)((hdr << used) >> (32 - bits)) : 0u;
+}
+
+// Walks the runs of one segment; calls emit(first_window, n_windows, canon_mmer).
+template <int W, class F>
+__device__ __forceinline__ void seg_runs(const ReadSrc &s, int sgm, const uint64_t (&w)[3], F &&emit,
+                                         uint64_t *hi_out, uint64_t *lo_out) {
+    constexpr int NM = PK + W - 1;                 // m-mers a segment can touch (<= 34)
+    const int p0 = sgm * PK;
+    int v = s.nk - p0;
+    v = v > PK ? PK : v;
+    const int sh = 2 * ((s.fc + p0) & 31);
+    const uint64_t hi = sh ? (w[0] << sh) | (w[1] >> (64 - sh)) : w[0];
+    const uint64_t lo = sh ? (w[1] << sh) | (w[2] >> (64 - sh)) : w[1];
+    *hi_out = hi; *lo_out = lo;
+    constexpr int M2 = 2 * SK_M;
+    const uint32_t mmask = (1u << M2) - 1;
+    uint32_t fm = (uint32_t)(hi >> (64 - M2));
+    uint32_t rm = (uint32_t)revcomp((uint64_t)fm, SK_M);
+    uint64_t rhi = (hi << M2) | (lo >> (64 - M2)), rlo = lo << M2;     // bases M, M+1, ...
+    uint64_t val[NM];
+#pragma unroll
+    for (int j = 0; j < NM; j++) {
+        val[j] = mmer_key(fm < rm ? fm : rm);
+        const uint32_t b = (uint32_t)(rhi >> 62);
+        rhi = (rhi << 2) | (rlo >> 62);
+        rlo <<= 2;
+        fm = ((fm << 2) | b) & mmask;
+        rm = (rm >> 2) | ((b ^ 3u) << (M2 - 2));
+    }
+    // sliding minimum over W m-mers with two blocks: window i = suffix of block 0 from i
+    // joined with the prefix of block 1 up to i-1 (needs W >= PK)
+#pragma unroll
+    for (int j = W - 2; j >= 0; j--) val[j] = val[j] < val[j + 1] ? val[j] : val[j + 1];
+#pragma unroll
+    for (int j = W + 1; j < NM; j++) val[j] = val[j] < val[j - 1] ? val[j] : val[j - 1];
+    uint64_t cur = val[0];
+    int start = 0;
+#pragma unroll
+    for (int i = 1; i < PK; i++) {
+        const uint64_t wi = val[i] < val[W + i - 1] ? val[i] : val[W + i - 1];
+        if (i < v && wi != cur) {
+            emit(start, i - start, (uint32_t)cur);
+            cur = wi; start = i;
+        }
+    }
+    emit(start, v - start, (uint32_t)cur);
+}
+
+__device__ __forceinline__ uint64_t mmer_hash64(uint32_t canon) { return kmer_hash((uint64_t)canon); }
+
+__device__ __forceinline__ unsigned sk_digit(uint32_t canon, const Level &lv) {
+    const uint64_t h = mmer_hash64(canon);
+    if (lv.n_owners > 0) return (unsigned)__umul64hi(h, (uint64_t)lv.n_owners);
+    return rec_digit((uint32_t)((h << OWNER_BITS) >> 32), 0, lv.bits);
+}
+
+template <int W>
+__global__ __launch_bounds__(SKT) void k_sk_hist(ReadSrc s, Level lv, uint64_t *__restrict__ blockhist) {
+    __shared__ uint32_t h[1 << MAX_BITS];
+    const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
+    for (int i = threadIdx.x; i < nb; i += SKT) h[i] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * SKT;
+    const int64_t dq = stride / s.segs;
+    const int dr = (int)(stride - dq * s.segs);
+    int64_t g = (int64_t)blockIdx.x * SKT + threadIdx.x;
+    SegPos q;
+    q.r = g / s.segs;
+    q.sgm = (int)(g - q.r * s.segs);
+    for (; g < s.n_threads; g += stride) {
+        uint64_t w[3], hi, lo;
+        seg_load(s, q, w);
+        seg_runs<W>(s, q.sgm, w, [&](int, int, uint32_t canon) { atomicAdd(&h[sk_digit(canon, lv)], 1u); }, &hi, &lo);
+        q.r += dq; q.sgm += dr;
+        if (q.sgm >= s.segs) { q.sgm -= s.segs; q.r++; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += SKT) blockhist[(int64_t)i * gridDim.x + blockIdx.x] = h[i];
+}
+
+// records go straight to the workgroup's private per-digit ranges (16-byte stores; the L2 of the
+// workgroup's XCD combines the records a stream appends to one line)
+template <int W>
+__global__ __launch_bounds__(SKT) void k_sk_scatter(ReadSrc s, Level lv, const uint64_t *__restrict__ scanned,
+                                                   Rec *__restrict__ out) {
+    __shared__ unsigned long long cur[1 << MAX_BITS];
+    const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
+    for (int i = threadIdx.x; i < nb; i += SKT) cur[i] = scanned[(int64_t)i * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * SKT;
+    const int64_t dq = stride / s.segs;
+    const int dr = (int)(stride - dq * s.segs);
+    int64_t g = (int64_t)blockIdx.x * SKT + threadIdx.x;
+    SegPos q;
+    q.r = g / s.segs;
+    q.sgm = (int)(g - q.r * s.segs);
+    for (; g < s.n_threads; g += stride) {
+        uint64_t w[3], hi = 0, lo = 0;
+        seg_load(s, q, w);
+        // `hi`/`lo` are written before the first emit() runs (seg_runs stores them first)
+        seg_runs<W>(s, q.sgm, w, [&](int i0, int n, uint32_t canon) {
+            const uint64_t h = mmer_hash64(canon);
+            const unsigned d = lv.n_owners > 0 ? (unsigned)__umul64hi(h, (uint64_t)lv.n_owners)
+                                               : rec_digit((uint32_t)((h << OWNER_BITS) >> 32), 0, lv.bits);
+            const int sft = 2 * i0;
+            Rec r;
+            r.w0 = sft ? (hi << sft) | (lo >> (64 - sft)) : hi;
+            r.w1 = ((lo << sft) & 0xFFFFFFF000000000ULL) | ((uint64_t)(n - 1) << 32) |
+                   (uint64_t)(uint32_t)((h << OWNER_BITS) >> 32);
+            out[atomicAdd(&cur[d], 1ULL)] = r;
+        }, &hi, &lo);
+        q.r += dq; q.sgm += dr;
+        if (q.sgm >= s.segs) { q.sgm -= s.segs; q.r++; }
+    }
+}
+
+// levels >= 2 on records: virtual workgroups as for k-mers, digit from the record header
+__global__ __launch_bounds__(PT) void k_rec_hist(const Rec *__restrict__ recs, VbMap m, Level lv, int used,
+                                                 uint32_t *__restrict__ table) {
+    __shared__ uint32_t h[1 << MAX_BITS];
+    VbPos q;
+    if (!locate_vb(m, blockIdx.x, &q)) return;
+    const int nb = 1 << lv.bits;
+    for (int i = threadIdx.x; i < nb; i += PT) h[i] = 0;
+    __syncthreads();
+    for (uint64_t i = q.begin + threadIdx.x; i < q.end; i += PT)
+        atomicAdd(&h[rec_digit(rec_hdr(recs[i]), used, lv.bits)], 1u);
+    __syncthreads();
+    const int64_t tb = (int64_t)nb * (int64_t)m.vb_start[q.p];
+    for (int i = threadIdx.x; i < nb; i += PT) table[tb + (int64_t)i * q.G + q.g] = h[i];
+}
+
+__global__ __launch_bounds__(PT) void k_rec_scatter(const Rec *__restrict__ recs, VbMap m, Level lv, int used,
+                                                    const uint64_t *__restrict__ scanned, Rec *__restrict__ out) {
+    __shared__ unsigned long long cur[1 << MAX_BITS];
+    VbPos q;
+    if (!locate_vb(m, blockIdx.x, &q)) return;
+    const int nb = 1 << lv.bits;
+    const int64_t tb = (int64_t)nb * (int64_t)m.vb_start[q.p];
+    for (int i = threadIdx.x; i < nb; i += PT) cur[i] = scanned[tb + (int64_t)i * q.G + q.g];
+    __syncthreads();
+    for (uint64_t i = q.begin + threadIdx.x; i < q.end; i += PT) {
+        const Rec r = recs[i];
+        out[atomicAdd(&cur[rec_digit(rec_hdr(r), used, lv.bits)], 1ULL)] = r;
+    }
 }
 
 // ------------------------------------------------------------ synthetic reads
@@ -729,11 +1002,209 @@ static unsigned reads_grid(rfx_ctx *ctx, const ReadSrc &s, int per_cu) {
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, g));
 }
 
+// leaf count + filter + ascending sort of the survivors (shared tail of every source kind)
+template <bool RECS>
+static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<RECS>::T *elems, const uint64_t *d_leaf_off,
+                         int64_t nleaf, int k, int min_cov, int max_cov, int twin, int key_bits,
+                         uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n,
+                         int64_t *out_distinct) {
+    DevBuf co_buf;
+    RFX_HIP(co_buf.alloc(sizeof(CountOut), ctx->stream));
+    RFX_HIP(hipMemsetAsync(co_buf.p, 0, sizeof(CountOut), ctx->stream));
+    const int apply = !(twin == RFX_TWIN_RDD && min_cov <= 1);    // P/ReflexivMain.java:160
+    {
+        ScopedTimer t(ctx, "leaf");
+        int64_t grid = std::min<int64_t>(nleaf, (int64_t)ctx->num_cu * 2);      // persistent, ~66 KB LDS each
+        hipLaunchKernelGGL(k_leaf_count<RECS>, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, elems, d_leaf_off, nleaf,
+                           k, min_cov, max_cov, apply, d_out_keys, d_out_counts, (unsigned long long)cap,
+                           co_buf.as<CountOut>());
+        RFX_HIP(hipGetLastError());
+    }
+    CountOut co{};
+    RFX_HIP(hipMemcpyAsync(&co, co_buf.p, sizeof co, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    if (out_n) *out_n = (int64_t)co.n_out;
+    if (out_distinct) *out_distinct = (int64_t)co.n_distinct;
+    if (getenv("RFX_TRACE"))
+        fprintf(stderr, "leaves: %lld buckets, %llu table passes, %llu overflowed\n", (long long)nleaf, co.n_passes, co.n_overflow);
+    if (co.n_failed) { ctx->last_error = "leaf split depth exhausted"; ScopedTimer::collect(ctx); return RFX_E_LIMIT; }
+    if ((int64_t)co.n_out > cap) { ScopedTimer::collect(ctx); return RFX_E_CAP; }
+    if ((int64_t)co.n_out > (int64_t)0xFFFFFFFFLL) { ScopedTimer::collect(ctx); return RFX_E_LIMIT; }
+    // ascending k-mer order (order contract B.0)
+    {
+        DevBuf tk, tv;
+        RFX_HIP(tk.alloc((size_t)co.n_out * 8, ctx->stream));
+        RFX_HIP(tv.alloc((size_t)co.n_out * 4, ctx->stream));
+        ScopedTimer t(ctx, "sort");
+        RFX_TRY(sort_pairs(ctx, d_out_keys, reinterpret_cast<uint32_t *>(d_out_counts), (int64_t)co.n_out, key_bits,
+                           tk.as<uint64_t>(), tv.as<uint32_t>()));
+        t.stop();
+        RFX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    ScopedTimer::collect(ctx);
+    return RFX_OK;
+}
+
+// super-k-mer records are used for k = 28..31 (W = k - 12 in 16..19); RFX_SUPERKMER=0 disables them
+static bool superkmer_enabled(int k) {
+    if (const char *e = getenv("RFX_SUPERKMER")) if (atoi(e) == 0) return false;
+    return k >= SK_M + PK - 1 && k <= 31;
+}
+
+template <class... Args>
+static void launch_sk_hist(int W, dim3 grid, hipStream_t st, Args... args) {
+    switch (W) {
+        case 16: hipLaunchKernelGGL(k_sk_hist<16>, grid, dim3(SKT), 0, st, args...); break;
+        case 17: hipLaunchKernelGGL(k_sk_hist<17>, grid, dim3(SKT), 0, st, args...); break;
+        case 18: hipLaunchKernelGGL(k_sk_hist<18>, grid, dim3(SKT), 0, st, args...); break;
+        default: hipLaunchKernelGGL(k_sk_hist<19>, grid, dim3(SKT), 0, st, args...); break;
+    }
+}
+template <class... Args>
+static void launch_sk_scatter(int W, dim3 grid, hipStream_t st, Args... args) {
+    switch (W) {
+        case 16: hipLaunchKernelGGL(k_sk_scatter<16>, grid, dim3(SKT), 0, st, args...); break;
+        case 17: hipLaunchKernelGGL(k_sk_scatter<17>, grid, dim3(SKT), 0, st, args...); break;
+        case 18: hipLaunchKernelGGL(k_sk_scatter<18>, grid, dim3(SKT), 0, st, args...); break;
+        default: hipLaunchKernelGGL(k_sk_scatter<19>, grid, dim3(SKT), 0, st, args...); break;
+    }
+}
+
+// level 1 of the record path: reads -> records bucketed by `lv` (radix digit or owner).
+// *out_recs (workspace slot `ws_slot`, or the caller's buffer d_dst of cap_dst records) receives
+// the records, d_seg_off[nb+1] their bucket offsets; *n_recs the total.
+static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv, int ws_slot, Rec *d_dst,
+                              int64_t cap_dst, uint64_t *d_seg_off, Rec **out_recs, int64_t *n_recs,
+                              const char *hn, const char *pn) {
+    const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
+    const int W = rsrc.k - SK_M + 1;
+    // few, fat workgroups: the number of concurrently open output lines (workgroups x digits x
+    // 128 B) must stay inside the L2 for the 16-byte record stores to combine
+    int per_cu = 1;
+    if (const char *e = getenv("RFX_SK_PER_CU")) per_cu = std::max(1, atoi(e));
+    const unsigned G = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(rsrc.n_threads, SKT), (int64_t)ctx->num_cu * per_cu));
+    DevBuf bh, scanned;
+    RFX_HIP(bh.alloc((size_t)nb * G * 8, ctx->stream));
+    RFX_HIP(scanned.alloc(((size_t)nb * G + 1) * 8, ctx->stream));
+    {
+        ScopedTimer t(ctx, hn);
+        launch_sk_hist(W, dim3(G), ctx->stream, rsrc, lv, bh.as<uint64_t>());
+        RFX_HIP(hipGetLastError());
+    }
+    RFX_TRY(exclusive_scan_u64(ctx, bh.as<uint64_t>(), scanned.as<uint64_t>(), (int64_t)nb * G));
+    hipLaunchKernelGGL(k_bin_offsets, dim3((unsigned)ceil_div(nb + 1, 256)), dim3(256), 0, ctx->stream,
+                       (const uint64_t *)scanned.as<uint64_t>(), nb, (int64_t)G, d_seg_off);
+    RFX_HIP(hipGetLastError());
+    uint64_t R = 0;
+    RFX_HIP(hipMemcpyAsync(&R, scanned.as<uint64_t>() + (size_t)nb * G, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    *n_recs = (int64_t)R;
+    Rec *dst = d_dst;
+    if (!dst) {
+        dst = (Rec *)ctx->ws_get(ws_slot, (size_t)R * sizeof(Rec));
+        if (!dst) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
+    } else if ((int64_t)R > cap_dst) {
+        return RFX_E_CAP;
+    }
+    {
+        ScopedTimer t(ctx, pn);
+        launch_sk_scatter(W, dim3(G), ctx->stream, rsrc, lv, (const uint64_t *)scanned.as<uint64_t>(), dst);
+        RFX_HIP(hipGetLastError());
+    }
+    *out_recs = dst;
+    return RFX_OK;
+}
+
+// levels [first_level, ...) of the record path on records already bucketed by `used` bits
+// (seg offsets in *seg_cur), then the leaves.
+static int count_records_levels(rfx_ctx *ctx, const Rec *recs, int64_t n_recs, int ws_slot_of_recs,
+                                const std::vector<int> &bits, size_t first_level, int used, DevBuf *seg_cur,
+                                DevBuf *seg_next, int64_t nseg, int k, int min_cov, int max_cov, int twin,
+                                uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n,
+                                int64_t *out_distinct) {
+    const Rec *cur = recs;
+    int slot = ws_slot_of_recs;          // the next level writes into the other slot
+    for (size_t l = first_level; l < bits.size(); l++) {
+        Level lv{};
+        lv.bits = bits[l];
+        const int nb = 1 << lv.bits;
+        const int64_t nchild = nseg << lv.bits;
+        const int64_t total_tiles = ceil_div(std::max<int64_t>(n_recs, 1), PTILE);
+        int tpb = (int)std::min<int64_t>(32, std::max<int64_t>(1, total_tiles / ((int64_t)ctx->num_cu * 8)));
+        const int64_t v_bound = ceil_div(std::max<int64_t>(n_recs, 1), (int64_t)tpb * PTILE) + nseg;
+        DevBuf nvb, vb_start, table, scanned;
+        RFX_HIP(nvb.alloc((size_t)nseg * 8, ctx->stream));
+        RFX_HIP(vb_start.alloc((size_t)(nseg + 1) * 8, ctx->stream));
+        RFX_HIP(table.alloc((size_t)nb * v_bound * 4, ctx->stream));
+        RFX_HIP(scanned.alloc(((size_t)nb * v_bound + 1) * 8, ctx->stream));
+        RFX_HIP(seg_next->alloc((size_t)(nchild + 1) * 8, ctx->stream));
+        RFX_HIP(hipMemsetAsync(table.p, 0, (size_t)nb * v_bound * 4, ctx->stream));
+        hipLaunchKernelGGL(k_vb_per_seg, dim3((unsigned)ceil_div(nseg, 256)), dim3(256), 0, ctx->stream,
+                           (const uint64_t *)seg_cur->as<uint64_t>(), nseg, tpb, nvb.as<uint64_t>());
+        RFX_HIP(hipGetLastError());
+        RFX_TRY(exclusive_scan_u64(ctx, nvb.as<uint64_t>(), vb_start.as<uint64_t>(), nseg));
+        VbMap vm{seg_cur->as<uint64_t>(), vb_start.as<uint64_t>(), nseg, tpb};
+        const char *hn = l == 0 ? "hist1" : l == 1 ? "hist2" : "hist3";
+        const char *pn = l == 0 ? "part1" : l == 1 ? "part2" : "part3";
+        {
+            ScopedTimer t(ctx, hn);
+            hipLaunchKernelGGL(k_rec_hist, dim3((unsigned)v_bound), dim3(PT), 0, ctx->stream, cur, vm, lv, used,
+                               table.as<uint32_t>());
+            RFX_HIP(hipGetLastError());
+        }
+        RFX_TRY(exclusive_scan_u32_to_u64(ctx, table.as<uint32_t>(), scanned.as<uint64_t>(), (int64_t)nb * v_bound));
+        hipLaunchKernelGGL(k_child_offsets, dim3((unsigned)ceil_div(nchild + 1, 256)), dim3(256), 0, ctx->stream,
+                           (const uint64_t *)scanned.as<uint64_t>(), vm, nb, (uint64_t)n_recs, seg_next->as<uint64_t>());
+        RFX_HIP(hipGetLastError());
+        slot = slot == 0 ? 1 : 0;
+        Rec *dst = (Rec *)ctx->ws_get(slot, (size_t)std::max<int64_t>(n_recs, 1) * sizeof(Rec));
+        if (!dst) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
+        {
+            ScopedTimer t(ctx, pn);
+            hipLaunchKernelGGL(k_rec_scatter, dim3((unsigned)v_bound), dim3(PT), 0, ctx->stream, cur, vm, lv, used,
+                               (const uint64_t *)scanned.as<uint64_t>(), dst);
+            RFX_HIP(hipGetLastError());
+        }
+        cur = dst;
+        used += lv.bits;
+        std::swap(seg_cur, seg_next);
+        nseg = nchild;
+    }
+    return finish_leaves<true>(ctx, cur, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, k, min_cov, max_cov, twin,
+                               2 * k, d_out_keys, d_out_counts, cap, out_n, out_distinct);
+}
+
+// reads -> records -> count (the default for k = 28..31)
+static int count_reads_superkmer(rfx_ctx *ctx, const ReadStore *reads, int min_cov, int max_cov, int twin,
+                                 uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n,
+                                 int64_t *out_distinct) {
+    ctx->timing.clear();
+    ReadSrc rsrc = make_read_src(reads);
+    const int64_t n = (int64_t)rsrc.nk * reads->n_reads;
+    if (out_n) *out_n = 0;
+    if (out_distinct) *out_distinct = 0;
+    if (n <= 0) return RFX_OK;
+    std::vector<int> bits;
+    plan_levels(n, true, bits);
+    Level lv{};
+    lv.bits = bits[0];
+    DevBuf segA, segB;
+    RFX_HIP(segA.alloc(((size_t)(1 << lv.bits) + 1) * 8, ctx->stream));
+    Rec *recs = nullptr;
+    int64_t R = 0;
+    RFX_TRY(records_from_reads(ctx, rsrc, lv, 0, nullptr, 0, segA.as<uint64_t>(), &recs, &R, "hist1", "part1"));
+    return count_records_levels(ctx, recs, R, 0, bits, 1, lv.bits, &segA, &segB, (int64_t)1 << lv.bits, reads->k,
+                                min_cov, max_cov, twin, d_out_keys, d_out_counts, cap, out_n, out_distinct);
+}
+
 int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, int64_t n,
                  int min_cov, int max_cov, int twin, void *ws, int64_t ws_bytes,
                  uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap,
                  int64_t *out_n, int64_t *out_distinct) {
     (void)ws; (void)ws_bytes;
+    if (reads && superkmer_enabled(reads->k))
+        return count_reads_superkmer(ctx, reads, min_cov, max_cov, twin, d_out_keys, d_out_counts, cap, out_n,
+                                     out_distinct);
     ctx->timing.clear();
     ReadSrc rsrc{};
     int k_bits = 64;
@@ -845,38 +1316,9 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
         nseg = nchild;
     }
 
-    RFX_HIP(co_buf.alloc(sizeof(CountOut), ctx->stream));
-    RFX_HIP(hipMemsetAsync(co_buf.p, 0, sizeof(CountOut), ctx->stream));
-    const int apply = !(twin == RFX_TWIN_RDD && min_cov <= 1);    // P/ReflexivMain.java:160
-    {
-        ScopedTimer t(ctx, "leaf");
-        int64_t grid = std::min<int64_t>(nseg, (int64_t)ctx->num_cu * 2);      // persistent, 60 KB LDS each
-        hipLaunchKernelGGL(k_leaf_count, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, cur_arr,
-                           (const uint64_t *)seg_cur->as<uint64_t>(), nseg, min_cov, max_cov, apply, d_out_keys,
-                           d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>());
-        RFX_HIP(hipGetLastError());
-    }
-    CountOut co{};
-    RFX_HIP(hipMemcpyAsync(&co, co_buf.p, sizeof co, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
-    if (out_n) *out_n = (int64_t)co.n_out;
-    if (out_distinct) *out_distinct = (int64_t)co.n_distinct;
-    if (co.n_failed) { ctx->last_error = "leaf split depth exhausted"; ScopedTimer::collect(ctx); return RFX_E_LIMIT; }
-    if ((int64_t)co.n_out > cap) { ScopedTimer::collect(ctx); return RFX_E_CAP; }
-    if ((int64_t)co.n_out > (int64_t)0xFFFFFFFFLL) { ScopedTimer::collect(ctx); return RFX_E_LIMIT; }
-    // ascending k-mer order (order contract B.0)
-    {
-        DevBuf tk, tv;
-        RFX_HIP(tk.alloc((size_t)co.n_out * 8, ctx->stream));
-        RFX_HIP(tv.alloc((size_t)co.n_out * 4, ctx->stream));
-        ScopedTimer t(ctx, "sort");
-        RFX_TRY(sort_pairs(ctx, d_out_keys, reinterpret_cast<uint32_t *>(d_out_counts), (int64_t)co.n_out,
-                           from_reads ? k_bits : 64, tk.as<uint64_t>(), tv.as<uint32_t>()));
-        t.stop();
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
-    }
-    ScopedTimer::collect(ctx);
-    return RFX_OK;
+    return finish_leaves<false>(ctx, cur_arr, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, from_reads ? reads->k : 31,
+                                min_cov, max_cov, twin, from_reads ? k_bits : 64, d_out_keys, d_out_counts, cap, out_n,
+                                out_distinct);
 }
 
 int bucket_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, uint64_t *d_out, int64_t cap,

@@ -953,7 +953,7 @@ int extract_ordered_packed(rfx_ctx *ctx, const uint64_t *d_words, int wpr, const
 
 int64_t count_workspace_bytes(int64_t n_kmers) { return 2 * n_kmers * 8 + (int64_t)(64 << 20); }
 
-static void plan_levels(int64_t n, bool from_reads, std::vector<int> &bits) {
+static void plan_levels(int64_t n, bool from_reads, std::vector<int> &bits, double target = 16384.0) {
     bits.clear();
     if (const char *e = getenv("RFX_LEVEL_BITS")) {          // tuning override, e.g. "9,9"
         for (const char *q = e; *q;) {
@@ -964,7 +964,6 @@ static void plan_levels(int64_t n, bool from_reads, std::vector<int> &bits) {
         }
         if (!bits.empty()) return;
     }
-    double target = 16384.0;
     if (const char *e = getenv("RFX_LEAF_TARGET")) target = atof(e) > 0 ? atof(e) : target;
     int B = 0;
     if ((double)n > target) B = (int)std::ceil(std::log2((double)n / target));
@@ -1185,7 +1184,7 @@ static int count_reads_superkmer(rfx_ctx *ctx, const ReadStore *reads, int min_c
     if (out_distinct) *out_distinct = 0;
     if (n <= 0) return RFX_OK;
     std::vector<int> bits;
-    plan_levels(n, true, bits);
+    plan_levels(n, true, bits, 8192.0);            // measured best for the record leaf (tools/ab_count.py)
     Level lv{};
     lv.bits = bits[0];
     DevBuf segA, segB;

@@ -200,6 +200,18 @@ int rfx_dev_bucket_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_rea
                             int end_clip, int n_owners, uint64_t *d_out, int64_t cap,
                             int64_t *d_owner_off, int64_t *h_owner_off);
 
+/* The same two steps on super-k-mer RECORDS (16 bytes per run of <= 16 consecutive windows that
+ * share a minimiser; ~2.6 B per instance instead of 8), for k = 28..31.  Bucketing: call with
+ * d_out = NULL / cap_records = 0 to learn *out_n_records (returns RFX_E_CAP), then with a buffer.
+ * Counting: n_instances_hint (k-mer instances the records hold, 0 = unknown) sizes the radix plan. */
+int rfx_dev_bucket_records_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read,
+                                    int read_len, int k, int front_clip, int end_clip, int n_owners,
+                                    void *d_out_records, int64_t cap_records, int64_t *d_owner_off,
+                                    int64_t *h_owner_off, int64_t *out_n_records);
+int rfx_dev_count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_t n_instances_hint,
+                          int k, int min_cov, int max_cov, int twin, uint64_t *d_out_keys,
+                          int32_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct);
+
 /* Whole driver  P/ReflexivMain.java:168-310 (DS :221-352) from the filtered, ascending
  * (kmer,count) list in HBM to the contig text in host memory.  trace (optional) receives
  * the record count after every extend pass. */

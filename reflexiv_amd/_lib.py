@@ -47,7 +47,8 @@ SYMBOLS = [
     "rfx_fork_filter_forward", "rfx_reflect_from_forward", "rfx_fork_filter_reflected",
     "rfx_random_reflection", "rfx_extend_pass", "rfx_contigs_text",
     "rfx_dev_encode_reads", "rfx_kmers_per_read", "rfx_count_workspace_bytes", "rfx_dev_count_reads",
-    "rfx_dev_count_kmers", "rfx_dev_bucket_by_owner", "rfx_dev_assemble", "rfx_dev_synth_genome",
+    "rfx_dev_count_kmers", "rfx_dev_bucket_by_owner", "rfx_dev_bucket_records_by_owner",
+    "rfx_dev_count_records", "rfx_dev_assemble", "rfx_dev_synth_genome",
     "rfx_dev_synth_reads", "rfx_dev_sort_pairs", "rfx_last_count_timing",
 ]
 

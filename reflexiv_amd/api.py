@@ -266,6 +266,34 @@ class Reflexiv:
                     "rfx_dev_bucket_by_owner")
         return h
 
+    def bucket_records_by_owner_dev(self, d_words: int, n_reads: int, words_per_read: int, read_len: int, k: int,
+                                    n_owners: int, d_out: int, cap_records: int, d_owner_off: int,
+                                    front_clip=0, end_clip=0):
+        """Super-k-mer records (16 B each) grouped by owning rank.  d_out = 0: only returns how many
+        records there are.  -> (n_records, owner_off[n_owners+1] or None)"""
+        h = np.empty(n_owners + 1, np.int64)
+        nrec = C.c_int64(0)
+        st = self.L.rfx_dev_bucket_records_by_owner(self.ctx, C.c_void_p(d_words), C.c_int64(n_reads), words_per_read,
+                                                    read_len, k, front_clip, end_clip, n_owners,
+                                                    C.c_void_p(d_out) if d_out else None, C.c_int64(cap_records),
+                                                    C.c_void_p(d_owner_off), _p(h), C.byref(nrec))
+        if st == RFX_E_CAP:
+            return int(nrec.value), None
+        self._check(st, "rfx_dev_bucket_records_by_owner")
+        return int(nrec.value), h
+
+    def count_records_dev(self, d_records: int, n_records: int, n_instances_hint: int, k: int, d_out_keys: int,
+                          d_out_counts: int, cap: int, min_cov=2, max_cov=10_000_000, twin=TWIN_DS):
+        m, d = C.c_int64(0), C.c_int64(0)
+        st = self.L.rfx_dev_count_records(self.ctx, C.c_void_p(d_records), C.c_int64(n_records),
+                                          C.c_int64(n_instances_hint), k, min_cov, max_cov, twin,
+                                          C.c_void_p(d_out_keys), C.c_void_p(d_out_counts), C.c_int64(cap),
+                                          C.byref(m), C.byref(d))
+        if st == RFX_E_CAP:
+            raise RfxError(st, "rfx_dev_count_records", f"needs room for {m.value} survivors, cap is {cap}")
+        self._check(st, "rfx_dev_count_records")
+        return int(m.value), int(d.value)
+
     def assemble_dev(self, d_keys: int, d_counts: int, n: int, prm: Params):
         """Driver P/ReflexivMain.java:168-310 from the filtered (kmer,count) list in HBM
         -> (contig text, n_contigs, trace)."""

@@ -366,6 +366,28 @@ int rfx_dev_bucket_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_rea
     return bucket_by_owner(ctx, &rs, n_owners, d_out, cap, d_owner_off, h_owner_off);
 }
 
+int rfx_dev_bucket_records_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read,
+                                    int read_len, int k, int front_clip, int end_clip, int n_owners,
+                                    void *d_out_records, int64_t cap_records, int64_t *d_owner_off,
+                                    int64_t *h_owner_off, int64_t *out_n_records) {
+    if (!ctx || !d_words || !d_owner_off) return RFX_E_ARG;
+    RFX_TRY(check_k(k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    ReadStore rs{d_words, n_reads, words_per_read, read_len, k, front_clip, end_clip};
+    return bucket_records_by_owner(ctx, &rs, n_owners, d_out_records, cap_records, d_owner_off, h_owner_off,
+                                   out_n_records);
+}
+
+int rfx_dev_count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_t n_instances_hint, int k,
+                          int min_cov, int max_cov, int twin, uint64_t *d_out_keys, int32_t *d_out_counts,
+                          int64_t cap, int64_t *out_n, int64_t *out_distinct) {
+    if (!ctx || n_records < 0) return RFX_E_ARG;
+    RFX_TRY(check_k(k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    return count_records(ctx, d_records, n_records, n_instances_hint, k, min_cov, max_cov, twin, d_out_keys,
+                         d_out_counts, cap, out_n, out_distinct);
+}
+
 int rfx_dev_sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int key_bits,
                        uint64_t *d_tmp_keys, uint32_t *d_tmp_vals) {
     if (!ctx || n < 0) return RFX_E_ARG;

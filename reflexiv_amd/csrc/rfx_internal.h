@@ -153,6 +153,11 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
                  int64_t *out_n, int64_t *out_distinct);
 int bucket_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, uint64_t *d_out,
                     int64_t cap, int64_t *d_owner_off, int64_t *h_owner_off);
+int bucket_records_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, void *d_out, int64_t cap_records,
+                            int64_t *d_owner_off, int64_t *h_owner_off, int64_t *out_n_records);
+int count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_t n_instances_hint, int k,
+                  int min_cov, int max_cov, int twin, uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap,
+                  int64_t *out_n, int64_t *out_distinct);
 int synth_genome(rfx_ctx *ctx, uint64_t seed, int64_t genome_len, uint64_t *d_genome);
 int synth_reads(rfx_ctx *ctx, uint64_t seed, const uint64_t *d_genome, int64_t genome_len,
                 int64_t first_read, int64_t n_reads, int read_len, uint32_t err, int words_per_read,

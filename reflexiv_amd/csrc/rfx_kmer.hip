@@ -1072,8 +1072,8 @@ static void launch_sk_scatter(int W, dim3 grid, hipStream_t st, Args... args) {
 // level 1 of the record path: reads -> records bucketed by `lv` (radix digit or owner).
 // *out_recs (workspace slot `ws_slot`, or the caller's buffer d_dst of cap_dst records) receives
 // the records, d_seg_off[nb+1] their bucket offsets; *n_recs the total.
-static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv, int ws_slot, Rec *d_dst,
-                              int64_t cap_dst, uint64_t *d_seg_off, Rec **out_recs, int64_t *n_recs,
+static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv, bool use_ws, int ws_slot,
+                              Rec *d_dst, int64_t cap_dst, uint64_t *d_seg_off, Rec **out_recs, int64_t *n_recs,
                               const char *hn, const char *pn) {
     const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
     const int W = rsrc.k - SK_M + 1;
@@ -1099,11 +1099,11 @@ static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv
     RFX_HIP(hipStreamSynchronize(ctx->stream));
     *n_recs = (int64_t)R;
     Rec *dst = d_dst;
-    if (!dst) {
+    if (use_ws) {
         dst = (Rec *)ctx->ws_get(ws_slot, (size_t)R * sizeof(Rec));
         if (!dst) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
-    } else if ((int64_t)R > cap_dst) {
-        return RFX_E_CAP;
+    } else if (!dst || (int64_t)R > cap_dst) {
+        return RFX_E_CAP;                      // caller's buffer missing or too small: *n_recs holds the need
     }
     {
         ScopedTimer t(ctx, pn);
@@ -1191,7 +1191,7 @@ static int count_reads_superkmer(rfx_ctx *ctx, const ReadStore *reads, int min_c
     RFX_HIP(segA.alloc(((size_t)(1 << lv.bits) + 1) * 8, ctx->stream));
     Rec *recs = nullptr;
     int64_t R = 0;
-    RFX_TRY(records_from_reads(ctx, rsrc, lv, 0, nullptr, 0, segA.as<uint64_t>(), &recs, &R, "hist1", "part1"));
+    RFX_TRY(records_from_reads(ctx, rsrc, lv, true, 0, nullptr, 0, segA.as<uint64_t>(), &recs, &R, "hist1", "part1"));
     return count_records_levels(ctx, recs, R, 0, bits, 1, lv.bits, &segA, &segB, (int64_t)1 << lv.bits, reads->k,
                                 min_cov, max_cov, twin, d_out_keys, d_out_counts, cap, out_n, out_distinct);
 }
@@ -1351,6 +1351,56 @@ int bucket_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, uint64_t
         RFX_HIP(hipStreamSynchronize(ctx->stream));
     }
     return RFX_OK;
+}
+
+// multi-GPU, record form: bucket this rank's reads by the OWNER of each run's minimiser
+// (owner = mulhi(hash(minimiser), n_owners)) -- the exchange then ships ~2.6 B per instance
+int bucket_records_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, void *d_out, int64_t cap_records,
+                            int64_t *d_owner_off, int64_t *h_owner_off, int64_t *out_n_records) {
+    if (n_owners < 1 || n_owners > 64 || !superkmer_enabled(reads->k)) return RFX_E_ARG;
+    ReadSrc rsrc = make_read_src(reads);
+    if (out_n_records) *out_n_records = 0;
+    if (rsrc.nk <= 0 || reads->n_reads <= 0) {
+        RFX_HIP(hipMemsetAsync(d_owner_off, 0, (size_t)(n_owners + 1) * 8, ctx->stream));
+        if (h_owner_off) memset(h_owner_off, 0, (size_t)(n_owners + 1) * 8);
+        return RFX_OK;
+    }
+    Level lv{};
+    lv.n_owners = n_owners;
+    Rec *recs = nullptr;
+    int64_t R = 0;
+    int st = records_from_reads(ctx, rsrc, lv, false, 0, (Rec *)d_out, cap_records,
+                                reinterpret_cast<uint64_t *>(d_owner_off), &recs, &R, "hist1", "part1");
+    if (out_n_records) *out_n_records = R;
+    if (st != RFX_OK) return st;
+    if (h_owner_off) {
+        RFX_HIP(hipMemcpyAsync(h_owner_off, d_owner_off, (size_t)(n_owners + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return RFX_OK;
+}
+
+// count + filter of records that arrived from the exchange (any order): all radix levels run
+// on the record headers, then the record leaves
+int count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_t n_instances_hint, int k,
+                  int min_cov, int max_cov, int twin, uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap,
+                  int64_t *out_n, int64_t *out_distinct) {
+    if (!superkmer_enabled(k)) return RFX_E_ARG;
+    ctx->timing.clear();
+    if (out_n) *out_n = 0;
+    if (out_distinct) *out_distinct = 0;
+    if (n_records <= 0) return RFX_OK;
+    const int64_t n_inst = n_instances_hint > 0 ? n_instances_hint : n_records * 6;
+    std::vector<int> bits;
+    plan_levels(n_inst, false, bits, 8192.0);
+    DevBuf segA, segB;
+    uint64_t seg_init[2] = {0, (uint64_t)n_records};
+    RFX_HIP(segA.alloc(2 * 8, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(segA.p, seg_init, 16, hipMemcpyHostToDevice, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    // slot -1: the caller's buffer; the first level writes workspace slot 0
+    return count_records_levels(ctx, (const Rec *)d_records, n_records, 1, bits, 0, 0, &segA, &segB, 1, k, min_cov,
+                                max_cov, twin, d_out_keys, d_out_counts, cap, out_n, out_distinct);
 }
 
 int synth_genome(rfx_ctx *ctx, uint64_t seed, int64_t genome_len, uint64_t *d_genome) {

@@ -494,3 +494,80 @@ def test_deep_coverage_recovers_exactly_the_genome_kmers(rfx, torch_mod):
     assert np.isin(core, got).all()           # no genomic k-mer is lost
     assert len(want) - m < 200
     assert int(dc[:m].min()) >= 10
+
+
+def test_bucket_records_by_owner_then_count(rfx, torch_mod):
+    """multi-GPU record path on one GPU: super-k-mer records bucketed by owner; counting every
+    owner's bucket on its own gives disjoint shards whose union is the oracle's global count."""
+    torch = torch_mod
+    seed, G, n_reads, L, k, owners = 8, 150_000, 40_000, 150, 31, 4
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    doff = torch.empty(owners + 1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    args = (dw.data_ptr(), n_reads, wpr, L, k, owners)
+    nrec, h = rfx.bucket_records_by_owner_dev(*args, 0, 0, doff.data_ptr())
+    assert h is None and nrec > 0
+    recs = torch.empty(2 * nrec, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    nrec2, h = rfx.bucket_records_by_owner_dev(*args, recs.data_ptr(), nrec, doff.data_ptr())
+    N = rfx.kmers_per_read(L, k) * n_reads
+    assert nrec2 == nrec and h[0] == 0 and h[-1] == nrec and N / nrec > 3      # several windows per record
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+    wk, wc, wd = O.count_filter(O.extract_canon(bases, off, k), 2)
+    allk, allc, nd_sum = [], [], 0
+    for o in range(owners):
+        seg = recs[2 * h[o]: 2 * h[o + 1]].contiguous()
+        n_o = int(h[o + 1] - h[o])
+        dk = torch.empty(N, dtype=torch.int64, device="cuda"); dc = torch.empty(N, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        m, d = rfx.count_records_dev(seg.data_ptr(), n_o, 0, k, dk.data_ptr(), dc.data_ptr(), N, 2)
+        kk = dk[:m].cpu().numpy().view(np.uint64)
+        assert np.all(kk[1:] > kk[:-1])
+        allk.append(kk); allc.append(dc[:m].cpu().numpy()); nd_sum += d
+    allk = np.concatenate(allk); allc = np.concatenate(allc)
+    assert nd_sum == wd and len(np.unique(allk)) == len(allk)
+    order = np.argsort(allk, kind="stable")
+    assert np.array_equal(allk[order], wk) and np.array_equal(allc[order], wc)
+
+
+@pytest.mark.parametrize("k", [28, 29, 30, 27, 21])
+def test_fused_count_other_k(rfx, torch_mod, k):
+    """k = 28..31 take the super-k-mer record path (W = k-12 = 16..19), smaller k the k-mer path."""
+    torch = torch_mod
+    seed, G, n_reads, L = 31 + k, 100_000, 30_000, 150
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    N = rfx.kmers_per_read(L, k) * n_reads
+    dk = torch.empty(N, dtype=torch.int64, device="cuda"); dc = torch.empty(N, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, 2)
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+    wk, wc, wd = O.count_filter(O.extract_canon(bases, off, k), 2)
+    assert (m, nd) == (len(wk), wd)
+    assert np.array_equal(dk[:m].cpu().numpy().view(np.uint64), wk) and np.array_equal(dc[:m].cpu().numpy(), wc)
+
+
+def test_fused_count_with_clips_and_short_reads(rfx, torch_mod):
+    """front/end clips shift the window origin inside the packed words; reads shorter than k+2 emit nothing."""
+    torch = torch_mod
+    for L, k, fc, ec in ((100, 31, 3, 5), (64, 31, 0, 0), (40, 31, 2, 1), (33, 31, 0, 0), (32, 31, 0, 0), (150, 29, 7, 0)):
+        seed, G, n_reads = 1000 + L, 50_000, 5_000
+        wpr = (L + 31) // 32
+        dg = torch.empty((G + 31) // 32, dtype=torch.int64, device="cuda")
+        dw = torch.empty(n_reads * wpr, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        rfx.synth_genome_dev(seed, G, dg.data_ptr())
+        rfx.synth_reads_dev(seed, dg.data_ptr(), G, 0, n_reads, L, wpr, dw.data_ptr())
+        rfx.sync()
+        N = max(1, rfx.kmers_per_read(L, k, fc, ec) * n_reads)
+        dk = torch.empty(N, dtype=torch.int64, device="cuda"); dc = torch.empty(N, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, 1,
+                                          front_clip=fc, end_clip=ec)
+        g = O.synth_genome(seed, G)
+        bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+        km = O.extract_canon(bases, off, k, fc, ec)
+        wk, wc, wd = O.count_filter(km, 1)
+        assert inst == len(km) and (m, nd) == (len(wk), wd), (L, k, fc, ec)
+        assert np.array_equal(dk[:m].cpu().numpy().view(np.uint64), wk) and np.array_equal(dc[:m].cpu().numpy(), wc)

@@ -1079,7 +1079,7 @@ static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv
     const int W = rsrc.k - SK_M + 1;
     // few, fat workgroups: the number of concurrently open output lines (workgroups x digits x
     // 128 B) must stay inside the L2 for the 16-byte record stores to combine
-    int per_cu = 1;
+    int per_cu = 2;
     if (const char *e = getenv("RFX_SK_PER_CU")) per_cu = std::max(1, atoi(e));
     const unsigned G = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(rsrc.n_threads, SKT), (int64_t)ctx->num_cu * per_cu));
     DevBuf bh, scanned;

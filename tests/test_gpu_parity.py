@@ -571,3 +571,25 @@ def test_fused_count_with_clips_and_short_reads(rfx, torch_mod):
         wk, wc, wd = O.count_filter(km, 1)
         assert inst == len(km) and (m, nd) == (len(wk), wd), (L, k, fc, ec)
         assert np.array_equal(dk[:m].cpu().numpy().view(np.uint64), wk) and np.array_equal(dc[:m].cpu().numpy(), wc)
+
+
+def test_assemble_long_contigs_whole_grid_emit(rfx, torch_mod):
+    """640 kbp genome at 40x: contigs of several hundred kbp (> 8192 extension words), which take
+    the whole-grid emission path of the late extend passes; the contig text must equal the oracle's."""
+    import reflexiv_amd
+    torch = torch_mod
+    seed, G, n_reads, L, k = 3, 640_000, 170_000, 150, 31
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    N = rfx.kmers_per_read(L, k) * n_reads
+    dk = torch.empty(N // 4, dtype=torch.int64, device="cuda"); dc = torch.empty(N // 4, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N // 4, 3)
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+    wk, wc, wd = O.count_filter(O.extract_canon(bases, off, k), 3)
+    assert (m, nd) == (len(wk), wd)
+    for P, twin in ((8, O.TWIN_DS), (3, O.TWIN_RDD)):
+        text, nc, trace = rfx.assemble_dev(dk.data_ptr(), dc.data_ptr(), m, reflexiv_amd.default_params(min_cov=3, partitions=P, twin=twin))
+        otext, onc, otrace, _ = O.assemble_from_counts(wk, wc, O.default_params(min_cov=3, partitions=P, twin=twin))
+        assert trace == otrace and nc == onc and text == otext
+        assert max(int(h.split("-")[1]) for h in text.split("\n") if h.startswith(">")) > 31 * 8192

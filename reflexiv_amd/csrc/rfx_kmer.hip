@@ -416,7 +416,9 @@ constexpr int OBUF = 512;               // survivors buffered in LDS between flu
 constexpr int WSTAGE = 256;             // expanded k-mers a wave stages per round (record leaves)
 constexpr int LSTAGE = WSTAGE * (LT / 64);
 constexpr int LCAP = 4096;              // hash slots
-constexpr int LFULL = (LCAP * 3) / 4;   // give up on a sub-pass beyond this many distinct keys
+constexpr int LCAP_BITS = 12;
+static_assert(LCAP == 1 << LCAP_BITS, "slot bits");
+constexpr int LPROBE = 48;              // a probe sequence this long means the table is too full: split the leaf
 constexpr uint64_t EMPTY = ~0ULL;
 constexpr int LSTACK = 48;
 constexpr int LB = 8;                   // instance loads in flight per lane
@@ -438,7 +440,7 @@ struct CountOut {
 // (k-mer -> count, 64-bit CAS + add); the slots it fills are remembered in a list, so emitting
 // and resetting touch only those.  Survivors collect in an LDS buffer and leave with ONE global
 // atomic per flush (a per-leaf atomic on one hot counter serialises the whole grid).
-// A leaf with more than LFULL distinct keys is re-streamed in 2, 4, ... hash-selected parts.
+// A leaf whose table fills up (a probe sequence > LPROBE) is re-streamed in 2, 4, ... hash-selected parts.
 // Leaf input element: a k-mer instance (8 B) or a super-k-mer record (16 B, <= 16 instances).
 struct alignas(16) Rec { uint64_t w0, w1; };
 // Rec: w0 = bases 0..31 of the run's base string, w1 = [63..36] bases 32..45, [35..32] windows-1,
@@ -455,7 +457,7 @@ template <> struct LeafElem<false> {
 };
 template <> struct LeafElem<true> {
     using T = Rec;
-    static constexpr int PER_LANE = 1;
+    static constexpr int PER_LANE = 3;       // 64-record steps a wave holds in registers per leaf
     __device__ static __forceinline__ T none() { return Rec{0, 0}; }
     // canonical k-mers of the record's windows, rolled in registers (same arithmetic as seg_keys)
     template <class F> __device__ static __forceinline__ void for_each_kmer(const T &e, int k, F &&f) {
@@ -476,24 +478,37 @@ template <> struct LeafElem<true> {
     }
 };
 
+// inclusive +scan over the 64 lanes of a wave on the DPP path (no LDS round trips)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);    // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);    // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);    // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);    // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1,3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2,3
+    return x;
+}
+
 template <bool RECS>
 __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>::T *__restrict__ keys,
                                                    const uint64_t *__restrict__ leaf_off, int64_t nleaf, int k,
                                                    int min_cov, int max_cov, int apply_filter,
                                                    uint64_t *__restrict__ out_keys, int32_t *__restrict__ out_counts,
-                                                   unsigned long long cap, CountOut *__restrict__ co) {
-    __shared__ unsigned long long tkey[LCAP];
-    __shared__ uint32_t tcnt[LCAP];
-    __shared__ uint16_t occ[LFULL];
+                                                   unsigned long long cap, CountOut *__restrict__ co, int dbg) {
+    __shared__ __attribute__((aligned(16))) unsigned long long tkey[LCAP];
+    __shared__ __attribute__((aligned(16))) uint32_t tcnt[LCAP];
     __shared__ unsigned long long obk[OBUF];
     __shared__ int32_t obc[OBUF];
     __shared__ uint32_t stackS[LSTACK], stacks[LSTACK];
     __shared__ int sp;
-    __shared__ uint32_t n_dist, overflow, ob_n;
+    __shared__ uint32_t overflow, ob_n, ob_lim;
     __shared__ unsigned long long g_emit;
-    __shared__ uint64_t stage[RECS ? LSTAGE : 1];  // records: expanded k-mers, one per lane per round
-    unsigned long long my_distinct = 0;            // thread 0 only
+    __shared__ __attribute__((aligned(16))) uint64_t stage[RECS ? LSTAGE : 2];  // records: per-wave expansion area
+    uint32_t my_distinct = 0;                                                // every thread
+    unsigned long long my_passes = 0, my_overflows = 0;                      // thread 0 only
     const int lane_ = threadIdx.x & 63;
+    const int wave_ = threadIdx.x >> 6;
+    constexpr int NW = LT / 64;
 
     const int64_t l0 = (int64_t)(((unsigned long long)blockIdx.x * (unsigned long long)nleaf) / gridDim.x);
     const int64_t l1 = (int64_t)(((unsigned long long)(blockIdx.x + 1) * (unsigned long long)nleaf) / gridDim.x);
@@ -501,30 +516,32 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
     const uint64_t stream_end = leaf_off[l1];
 
     for (int i = threadIdx.x; i < LCAP; i += LT) { tkey[i] = EMPTY; tcnt[i] = 0; }
-    if (threadIdx.x == 0) { ob_n = 0; n_dist = 0; overflow = 0; }
+    if (threadIdx.x == 0) { ob_n = 0; ob_lim = 0xffffffffu; overflow = 0; sp = 0; }
 
     // flush the survivor buffer (every thread calls)
     auto flush = [&]() {
         __syncthreads();
-        const uint32_t cntv = ob_n;
-        if (cntv == 0) return;
-        if (threadIdx.x == 0) g_emit = atomicAdd(&co->n_out, (unsigned long long)cntv);
+        const uint32_t cntv = ob_n < ob_lim ? ob_n : ob_lim;
+        if (ob_n == 0) return;
+        if (threadIdx.x == 0 && cntv) g_emit = atomicAdd(&co->n_out, (unsigned long long)cntv);
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < cntv; i += LT) {
             const unsigned long long pos = g_emit + i;
             if (pos < cap) { out_keys[pos] = obk[i]; out_counts[pos] = obc[i]; }
         }
         __syncthreads();
-        if (threadIdx.x == 0) ob_n = 0;
+        if (threadIdx.x == 0) { ob_n = 0; ob_lim = 0xffffffffu; }
         __syncthreads();
     };
 
-    // prefetched batch: kn[j] = keys[pf + j*LT + tid] (empty beyond the chunk's stream)
+    // prefetched elements.  k-mers: kn[j] = keys[pf + j*LT + tid] (empty beyond the chunk's stream);
+    // records: kn[i] = record 64*i + lane of this wave's share of the leaf about to be processed
     using Elem = typename LeafElem<RECS>::T;
     constexpr int NB = LeafElem<RECS>::PER_LANE;      // elements in flight per lane
+    constexpr int RPF = NB;
     Elem kn[NB];
     uint64_t pf = leaf_off[l0];
-    auto prefetch = [&](uint64_t pos) {
+    auto prefetch = [&](uint64_t pos) __attribute__((always_inline)) {
         pf = pos;
 #pragma unroll
         for (int j = 0; j < NB; j++) {
@@ -532,166 +549,273 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
             kn[j] = i < stream_end ? keys[i] : LeafElem<RECS>::none();
         }
     };
-    prefetch(pf);
+    if constexpr (RECS) {
+        const uint64_t b0 = leaf_off[l0], n0 = leaf_off[l0 + 1] - b0;
+        const uint64_t ws = b0 + n0 * wave_ / NW, we = b0 + n0 * (wave_ + 1) / NW;
+#pragma unroll
+        for (int i = 0; i < RPF; i++) {
+            const uint64_t r = ws + 64u * i + lane_;
+            kn[i] = r < we ? keys[r] : Rec{0, 0};
+        }
+    } else {
+        prefetch(pf);
+    }
     uint64_t begin = pf;
     uint64_t end = leaf_off[l0 + 1];
     __syncthreads();
 
+    // one table pass over the leaf [begin, end): inserts the keys selected by (S, s); no barriers
+    auto run_pass = [&](uint32_t S, uint32_t s, bool first, uint64_t end_next) __attribute__((always_inline)) {
+        // Two keys per lane probe in lock-step so that two LDS compare-and-swaps are in flight.  A key
+        // is done when its slot held EMPTY (claimed) or the key itself; either way its count goes up.
+        // There is no occupancy counter: a probe sequence longer than LPROBE flags the pass as
+        // overflowing (the table is too full to be worth probing) and the leaf is split.
+        auto insert2 = [&](uint64_t keyA, bool a, uint64_t keyB, bool b) __attribute__((always_inline)) {
+            const uint32_t gA = ((uint32_t)keyA ^ __builtin_rotateleft32((uint32_t)(keyA >> 32), 13)) * 0x9E3779B1u;
+            const uint32_t gB = ((uint32_t)keyB ^ __builtin_rotateleft32((uint32_t)(keyB >> 32), 13)) * 0x9E3779B1u;
+            uint32_t slotA = gA >> (32 - LCAP_BITS), slotB = gB >> (32 - LCAP_BITS);
+            if (S > 1) {
+                a = a && (((gA >> 4) & 0xffffu) & (S - 1)) == s;
+                b = b && (((gB >> 4) & 0xffffu) & (S - 1)) == s;
+            }
+            for (int probe = 0; a || b; probe++) {
+                unsigned long long pA = 0, pB = 0;
+                if (a) pA = atomicCAS(&tkey[slotA], EMPTY, (unsigned long long)keyA);
+                if (b) pB = atomicCAS(&tkey[slotB], EMPTY, (unsigned long long)keyB);
+                if (a) {
+                    if (pA == EMPTY || pA == keyA) { atomicAdd(&tcnt[slotA], 1u); a = false; }
+                    else slotA = (slotA + 1) & (LCAP - 1);
+                }
+                if (b) {
+                    if (pB == EMPTY || pB == keyB) { atomicAdd(&tcnt[slotB], 1u); b = false; }
+                    else slotB = (slotB + 1) & (LCAP - 1);
+                }
+                if (probe >= LPROBE) { overflow = 1; break; }
+                if ((probe & 15) == 15 && *(volatile uint32_t *)&overflow) break;
+            }
+        };
+        if constexpr (RECS) {
+            // Records: every wave takes an equal contiguous share of the leaf and walks it 64 records
+            // at a time.  The first RPF steps of a leaf's first pass come from registers (loaded
+            // while the previous leaf was processed); anything else is loaded on the spot.
+            const uint64_t n = end - begin;
+            const uint64_t ws = begin + n * wave_ / NW, we = begin + n * (wave_ + 1) / NW;
+            Rec cur[RPF];
+            if (first) {
+#pragma unroll
+                for (int i = 0; i < RPF; i++) cur[i] = kn[i];
+                // this wave's share of the next leaf travels while this leaf is processed
+                const uint64_t nn = end_next - end;
+                const uint64_t ns = end + nn * wave_ / NW, ne = end + nn * (wave_ + 1) / NW;
+#pragma unroll
+                for (int i = 0; i < RPF; i++) {
+                    const uint64_t r = ns + 64u * i + lane_;
+                    kn[i] = r < ne ? keys[r] : Rec{0, 0};
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < RPF; i++) {
+                    const uint64_t r = ws + 64u * i + lane_;
+                    cur[i] = r < we ? keys[r] : Rec{0, 0};
+                }
+            }
+            uint32_t *wbits = (uint32_t *)(stage + wave_ * WSTAGE);   // 32 words of head bits
+            uint32_t *wcum = wbits + 32;                              // exclusive popcount per word
+            Rec *wrec = (Rec *)(wbits + 64);                          // the wave's 64 records
+            const int k2 = 2 * k;
+            // Records hold 1..16 windows each.  The wave lays its 64 records out in LDS, marks where
+            // each record's windows start in the wave's output sequence (one bit per output position)
+            // and then every lane extracts k-mers by position: lane j finds its record by a prefix
+            // popcount of the head bits.  Balanced lanes; no workgroup barrier (LDS ops of one wave
+            // stay in order).
+            auto kmer_at_pos = [&](uint32_t j) __attribute__((always_inline)) -> uint64_t {
+                const uint32_t wd = wbits[j >> 5];
+                const uint32_t r = wcum[j >> 5] + (uint32_t)__popc(wd & (0xffffffffu >> (31 - (j & 31)))) - 1u;
+                const Rec rr = wrec[r];
+                const uint32_t sh = 2u * (j - (uint32_t)rr.w1);                  // 2 * window index, <= 30
+                const uint64_t fwd = ((rr.w0 << sh) | ((rr.w1 >> 1) >> (63 - sh))) >> (64 - k2);
+                const uint64_t rc = revcomp(fwd, k);
+                return fwd < rc ? fwd : rc;
+            };
+            auto step = [&](const Rec rcur, const bool valid) __attribute__((always_inline)) {
+                if (dbg & 1) {       // ablation: stream only
+                    if (rcur.w0 == 0x123456789ULL) overflow = 1;
+                    return;
+                }
+                const uint32_t nwin = valid ? (uint32_t)rec_len(rcur) : 0u;
+                const uint32_t x = wave_incl_scan(nwin);
+                const uint32_t off = x - nwin;
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+                if (lane_ < 32) wbits[lane_] = 0;
+                __builtin_amdgcn_wave_barrier();
+                if (nwin) atomicOr(&wbits[off >> 5], 1u << (off & 31));
+                wrec[lane_] = Rec{rcur.w0, (rcur.w1 & ~0xffffffffULL) | off};       // hdr is spent: carry `off`
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const uint32_t c = (uint32_t)__popc(wbits[lane_ & 31]);
+                    const uint32_t y = wave_incl_scan(c);          // lanes 0..31 hold the prefix over the 32 words
+                    if (lane_ < 32) wcum[lane_] = y - c;
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t wb = 0; wb < total; wb += 128) {
+                    const uint32_t j0 = wb + lane_, j1 = j0 + 64;
+                    const bool v0 = j0 < total, v1 = j1 < total;
+                    const uint64_t c0 = kmer_at_pos(v0 ? j0 : 0), c1 = kmer_at_pos(v1 ? j1 : 0);
+                    if (dbg & 2) {       // ablation: expand, no table
+                        if ((v0 && c0 == 0x123456789ULL) || (v1 && c1 == 0x123456789ULL)) overflow = 1;
+                        continue;
+                    }
+                    insert2(c0, v0, c1, v1);
+                }
+                __builtin_amdgcn_wave_barrier();
+            };
+#pragma unroll
+            for (int i = 0; i < RPF; i++) {
+                const uint64_t r0 = ws + 64u * i;
+                // an overflowing pass is abandoned: stop feeding a table that is filling up
+                if (r0 < we && !*(volatile uint32_t *)&overflow) step(cur[i], r0 + lane_ < we);
+            }
+            for (uint64_t r0 = ws + 64u * RPF; r0 < we; r0 += 64) {
+                if (*(volatile uint32_t *)&overflow) break;
+                const bool valid = r0 + lane_ < we;
+                step(valid ? keys[r0 + lane_] : Rec{0, 0}, valid);
+            }
+        } else {
+            for (uint64_t base = begin; base < end; base += (uint64_t)LT * NB) {
+                // an overflowing pass is abandoned: stop feeding a table that is filling up
+                if (*(volatile uint32_t *)&overflow) break;
+                Elem kc[NB];
+                if (pf == base) {
+#pragma unroll
+                    for (int j = 0; j < NB; j++) kc[j] = kn[j];
+                } else {                        // re-streaming a split leaf: load now
+#pragma unroll
+                    for (int j = 0; j < NB; j++) {
+                        const uint64_t i = base + (uint64_t)j * LT + threadIdx.x;
+                        kc[j] = i < end ? keys[i] : LeafElem<RECS>::none();
+                    }
+                }
+                // next batch of this leaf, or the first batch of the next leaf
+                const uint64_t nxt = base + (uint64_t)LT * NB < end ? base + (uint64_t)LT * NB : end;
+                if (nxt < stream_end && nxt != pf) prefetch(nxt);
+                if (dbg & 1) {       // ablation: stream only
+                    if (kc[0] == 0x123456789ULL) overflow = 1;
+                    continue;
+                }
+                static_assert(RECS || NB % 2 == 0, "pairs");
+#pragma unroll
+                for (int j = 0; j + 1 < NB; j += 2)
+                    insert2(kc[j], base + (uint64_t)j * LT + threadIdx.x < end, kc[j + 1],
+                            base + (uint64_t)(j + 1) * LT + threadIdx.x < end);
+            }
+        }
+    };
+
+    // Survivors of the pass that just ended -> LDS buffer, by a sweep over the whole table that
+    // also resets it.  Thread t owns the 16-byte count chunks t and t + LT (4 slots each) and the
+    // key chunks under them.  Call after a barrier; ends with a barrier.  A wave reserves room for
+    // its survivors with one LDS add; when the buffer is full the wave writes straight to the
+    // output instead (one global add per wave), so no barrier depends on how many keys survive.
+    auto emit_pass = [&]() __attribute__((always_inline)) {
+        static_assert(LCAP == 8 * LT, "two 4-slot chunks per thread");
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t c4 = threadIdx.x + h * LT;                    // chunk of 4 slots
+            const uint4 cv = *(const uint4 *)&tcnt[4 * c4];
+            const uint32_t cs[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t slot = 4 * c4 + q;
+                const int32_t c = (int32_t)cs[q];
+                my_distinct += c != 0;
+                const bool keep = c != 0 && (!apply_filter || (c >= min_cov && c <= max_cov));
+                const uint64_t km = __ballot(keep);
+                if (km) {
+                    const uint32_t cntw = (uint32_t)__popcll(km);
+                    const int leader = __ffsll((unsigned long long)km) - 1;
+                    const uint32_t r = (uint32_t)__popcll(km & ((1ULL << lane_) - 1));
+                    uint32_t base = 0;
+                    if (lane_ == leader) base = atomicAdd(&ob_n, cntw);
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                    if (base + cntw <= (uint32_t)OBUF) {
+                        if (keep) { obk[base + r] = tkey[slot]; obc[base + r] = c; }
+                    } else {
+                        uint32_t glo = 0, ghi = 0;
+                        if (lane_ == leader) {
+                            atomicMin(&ob_lim, base);       // buffer entries at and after `base` are holes
+                            const unsigned long long g = atomicAdd(&co->n_out, (unsigned long long)cntw);
+                            glo = (uint32_t)g; ghi = (uint32_t)(g >> 32);
+                        }
+                        glo = (uint32_t)__builtin_amdgcn_readlane((int)glo, leader);
+                        ghi = (uint32_t)__builtin_amdgcn_readlane((int)ghi, leader);
+                        const unsigned long long pos = (((unsigned long long)ghi << 32) | glo) + r;
+                        if (keep && pos < cap) { out_keys[pos] = tkey[slot]; out_counts[pos] = c; }
+                    }
+                }
+            }
+            *(uint4 *)&tcnt[4 * c4] = make_uint4(0, 0, 0, 0);
+            *(ulonglong2 *)&tkey[4 * c4] = make_ulonglong2(EMPTY, EMPTY);
+            *(ulonglong2 *)&tkey[4 * c4 + 2] = make_ulonglong2(EMPTY, EMPTY);
+        }
+        __syncthreads();
+        const uint32_t raw = ob_n, lim = ob_lim;      // stable until the next emit_pass
+        if (raw >= (uint32_t)OBUF / 2 || lim != 0xffffffffu) flush();
+    };
+
     for (int64_t leaf = l0; leaf < l1; leaf++) {
         // the offset after the next leaf travels while this leaf is processed
         const uint64_t end_next = leaf + 2 <= l1 ? leaf_off[leaf + 2] : stream_end;
-        if (begin != end) {
-            __syncthreads();                        // every thread has left the previous leaf's loop
-            if (threadIdx.x == 0) { sp = 1; stackS[0] = 1; stacks[0] = 0; }
+        // Passes of this leaf.  Normally one: (S, s) = (1, 0), two barriers.  A leaf whose table
+        // fills up is re-streamed in 2, 4, ... hash-selected parts off a small stack (rare; the
+        // stack is empty between leaves).
+        uint32_t S = 1, s = 0;
+        bool first = true;
+        while (true) {
+            run_pass(S, s, first, end_next);        // (an empty leaf still hands the prefetch chain on)
+            first = false;
+            if (begin == end) break;
             __syncthreads();
-            while (true) {
-                if (sp == 0) break;                 // uniform: sp only changes between barriers
-                const uint32_t S = stackS[sp - 1], s = stacks[sp - 1];
-                __syncthreads();
-                if (threadIdx.x == 0) sp--;
-                auto insert = [&](uint64_t key) {
-                    const uint64_t h = local_hash(key);
-                    if (S > 1 && ((uint32_t)(h >> LEAF_SPLIT_SHIFT) & (S - 1)) != s) return;
-                    uint32_t slot = (uint32_t)(h >> LEAF_SLOT_SHIFT) & (LCAP - 1);
-                    for (int probe = 0; probe < LCAP; probe++) {
-                        const unsigned long long prev = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
-                        // the lanes that just claimed a slot take their places in the occupancy list
-                        // with ONE add on the shared counter (a per-lane add serialises on one address)
-                        const bool fresh = prev == EMPTY;
-                        const uint64_t fm = __ballot(fresh);
-                        if (fm) {
-                            const int leader = __ffsll((unsigned long long)fm) - 1;
-                            uint32_t pos = 0;
-                            if (lane_ == leader) pos = atomicAdd(&n_dist, (uint32_t)__popcll(fm));
-                            pos = __shfl(pos, leader, 64) + (uint32_t)__popcll(fm & ((1ULL << lane_) - 1));
-                            if (fresh) {
-                                if (pos < (uint32_t)LFULL) occ[pos] = (uint16_t)slot; else overflow = 1;
-                                atomicAdd(&tcnt[slot], 1u);
-                                break;
-                            }
-                        }
-                        if (prev == key) { atomicAdd(&tcnt[slot], 1u); break; }
-                        slot = (slot + 1) & (LCAP - 1);
-                        if ((probe & 31) == 31 && *(volatile uint32_t *)&overflow) break;
-                    }
-                };
-                for (uint64_t base = begin; base < end; base += (uint64_t)LT * NB) {
-                    // an overflowing pass is abandoned: stop feeding a table that is filling up
-                    // (probe sequences in a full table would cost LCAP CAS per key)
-                    if (*(volatile uint32_t *)&overflow) break;
-                    Elem kc[NB];
-                    if (pf == base) {
-#pragma unroll
-                        for (int j = 0; j < NB; j++) kc[j] = kn[j];
-                    } else {                        // re-streaming a split leaf: load now
-#pragma unroll
-                        for (int j = 0; j < NB; j++) {
-                            const uint64_t i = base + (uint64_t)j * LT + threadIdx.x;
-                            kc[j] = i < end ? keys[i] : LeafElem<RECS>::none();
-                        }
-                    }
-                    // next batch of this leaf, or the first batch of the next leaf
-                    const uint64_t nxt = base + (uint64_t)LT * NB < end ? base + (uint64_t)LT * NB : end;
-                    if (nxt < stream_end && nxt != pf) prefetch(nxt);
-                    if constexpr (RECS) {
-                        // Records hold 1..16 windows each: expand them into LDS so that every lane
-                        // inserts the same number of k-mers (lane-per-record loops ran at ~40 %
-                        // utilisation).  One record per lane per batch.
-                        const bool valid = base + threadIdx.x < end;
-                        const int nwin = valid ? rec_len(kc[0]) : 0;
-                        uint64_t km[PK];
-                        {
-                            const int k2 = 2 * k;
-                            uint64_t fwd = kc[0].w0 >> (64 - k2);
-                            uint64_t rc = revcomp(fwd, k);
-                            uint64_t rest = (kc[0].w0 << k2) | (kc[0].w1 >> (64 - k2));
-                            const uint64_t mask = low_mask(k);
-                            const int top = k2 - 2;
-#pragma unroll
-                            for (int t = 0; t < PK; t++) {
-                                km[t] = fwd < rc ? fwd : rc;
-                                const uint64_t bb = rest >> 62;
-                                rest <<= 2;
-                                fwd = ((fwd << 2) | bb) & mask;
-                                rc = (rc >> 2) | ((bb ^ 3) << top);
-                            }
-                        }
-                        // wave-private staging: a wave scans its 64 lengths with shuffles, writes
-                        // its k-mers to its own LDS window and reads them back one per lane -- no
-                        // workgroup barrier anywhere in the batch (LDS ops of one wave stay in order)
-                        const int lane = threadIdx.x & 63;
-                        uint64_t *wst = stage + (threadIdx.x >> 6) * WSTAGE;
-                        uint32_t x = (uint32_t)nwin;
-#pragma unroll
-                        for (int o = 1; o < 64; o <<= 1) {
-                            const uint32_t y = __shfl_up(x, o, 64);
-                            if (lane >= o) x += y;
-                        }
-                        const uint32_t off = x - (uint32_t)nwin;
-                        const uint32_t total = __shfl(x, 63, 64);
-                        for (uint32_t wb = 0; wb < total; wb += WSTAGE) {
-#pragma unroll
-                            for (int t = 0; t < PK; t++) {
-                                const uint32_t pos = off + t - wb;        // wraps for pos < wb: fails the test
-                                if (t < nwin && pos < (uint32_t)WSTAGE) wst[pos] = km[t];
-                            }
-                            const uint32_t lim = total - wb < (uint32_t)WSTAGE ? total - wb : (uint32_t)WSTAGE;
-                            for (uint32_t j = lane; j < lim; j += 64) insert(wst[j]);
-                        }
+            const bool ov = overflow != 0;
+            if (threadIdx.x == 0) my_passes++;
+            if (!ov) {
+                emit_pass();
+                if (S == 1) break;
+            } else {
+                // wipe the abandoned table, push the two halves of (S, s)
+                for (int i = threadIdx.x; i < LCAP; i += LT) { tkey[i] = EMPTY; tcnt[i] = 0; }
+                __syncthreads();                    // everyone has read `overflow`
+                if (threadIdx.x == 0) {
+                    my_overflows++;
+                    overflow = 0;
+                    if (sp + 2 <= LSTACK && S < (1u << 16)) {
+                        stackS[sp] = 2 * S; stacks[sp] = s + S; sp++;
+                        stackS[sp] = 2 * S; stacks[sp] = s;     sp++;
                     } else {
-#pragma unroll
-                        for (int j = 0; j < NB; j++) {
-                            if (base + (uint64_t)j * LT + threadIdx.x >= end) continue;
-                            insert(kc[j]);
-                        }
+                        atomicAdd(&co->n_failed, 1ULL);
                     }
                 }
-                __syncthreads();
-                const uint32_t nd = n_dist;
-                if (threadIdx.x == 0) { atomicAdd(&co->n_passes, 1ULL); if (overflow) atomicAdd(&co->n_overflow, 1ULL); }
-                if (overflow) {
-                    // abandon: wipe the table, re-stream in two hash-selected halves
-                    __syncthreads();
-                    for (int i = threadIdx.x; i < LCAP; i += LT) { tkey[i] = EMPTY; tcnt[i] = 0; }
-                    if (threadIdx.x == 0) {
-                        n_dist = 0; overflow = 0;
-                        if (sp + 2 <= LSTACK && S < (1u << 16)) {
-                            stackS[sp] = 2 * S; stacks[sp] = s + S; sp++;
-                            stackS[sp] = 2 * S; stacks[sp] = s;     sp++;
-                        } else {
-                            atomicAdd(&co->n_failed, 1ULL);
-                        }
-                    }
-                    __syncthreads();
-                    continue;
-                }
-                if (threadIdx.x == 0) my_distinct += nd;
-                // emit + reset the occupied slots, OBUF entries at a time
-                for (uint32_t c0 = 0; c0 < nd; c0 += OBUF) {
-                    const uint32_t chunk = nd - c0 < (uint32_t)OBUF ? nd - c0 : (uint32_t)OBUF;
-                    const uint32_t ob0 = ob_n;
-                    __syncthreads();            // everyone has read ob_n before anyone appends
-                    if (ob0 + chunk > (uint32_t)OBUF) flush();
-                    for (uint32_t i = c0 + threadIdx.x; i < c0 + chunk; i += LT) {
-                        const uint32_t slot = occ[i];
-                        const int32_t c = (int32_t)tcnt[slot];
-                        if (!apply_filter || (c >= min_cov && c <= max_cov)) {
-                            const uint32_t pos = atomicAdd(&ob_n, 1u);
-                            obk[pos] = tkey[slot]; obc[pos] = c;
-                        }
-                        tkey[slot] = EMPTY; tcnt[slot] = 0;
-                    }
-                    __syncthreads();
-                }
-                if (threadIdx.x == 0) n_dist = 0;
                 __syncthreads();
             }
+            if (sp == 0) break;                     // uniform: sp only changes between barriers
+            S = stackS[sp - 1]; s = stacks[sp - 1];
+            __syncthreads();
+            if (threadIdx.x == 0) sp--;
         }
         begin = end;
         end = end_next;
     }
     flush();
-    if (threadIdx.x == 0 && my_distinct) atomicAdd(&co->n_distinct, my_distinct);
+    {
+        // distinct keys: wave sums, one global add per wave
+        uint32_t d = my_distinct;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        if (lane_ == 0 && d) atomicAdd(&co->n_distinct, (unsigned long long)d);
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&co->n_passes, my_passes);
+        if (my_overflows) atomicAdd(&co->n_overflow, my_overflows);
+    }
 }
 
 // ------------------------------------------------------- super-k-mer records
@@ -707,10 +831,12 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
 constexpr int SK_M = 13;
 constexpr int SKT = 1024;             // threads per workgroup of the reads -> records kernels
 
-__device__ __forceinline__ uint64_t mmer_key(uint32_t canon) {
+// order of the m-mers: a bijection of the canonical 26-bit m-mer onto 32 bits (odd multiplier,
+// xor-shift), so two different m-mers never tie and a plain 32-bit minimum picks the minimiser;
+// the value itself (not the m-mer) names the bucket
+__device__ __forceinline__ uint32_t mmer_key(uint32_t canon) {
     uint32_t h = canon * 0x9E3779B1u;
-    h ^= h >> 15;
-    return ((uint64_t)h << 32) | canon;           // ordered by hash, ties by the m-mer itself
+    return h ^ (h >> 15);
 }
 
 // digit of a record at a level that follows `used` radix bits
@@ -718,7 +844,7 @@ __device__ __forceinline__ unsigned rec_digit(uint32_t hdr, int used, int bits) 
     return bits ? (unsigned)((hdr << used) >> (32 - bits)) : 0u;
 }
 
-// Walks the runs of one segment; calls emit(first_window, n_windows, canon_mmer).
+// Walks the runs of one segment; calls emit(first_window, n_windows, minimiser_key).
 template <int W, class F>
 __device__ __forceinline__ void seg_runs(const ReadSrc &s, int sgm, const uint64_t (&w)[3], F &&emit,
                                          uint64_t *hi_out, uint64_t *lo_out) {
@@ -734,14 +860,13 @@ __device__ __forceinline__ void seg_runs(const ReadSrc &s, int sgm, const uint64
     const uint32_t mmask = (1u << M2) - 1;
     uint32_t fm = (uint32_t)(hi >> (64 - M2));
     uint32_t rm = (uint32_t)revcomp((uint64_t)fm, SK_M);
-    uint64_t rhi = (hi << M2) | (lo >> (64 - M2)), rlo = lo << M2;     // bases M, M+1, ...
-    uint64_t val[NM];
+    uint32_t val[NM];
 #pragma unroll
     for (int j = 0; j < NM; j++) {
         val[j] = mmer_key(fm < rm ? fm : rm);
-        const uint32_t b = (uint32_t)(rhi >> 62);
-        rhi = (rhi << 2) | (rlo >> 62);
-        rlo <<= 2;
+        // base M + j of the 64-base stream (hi, lo): compile-time position
+        const int pos = SK_M + j;
+        const uint32_t b = pos < 32 ? (uint32_t)(hi >> (62 - 2 * pos)) & 3u : (uint32_t)(lo >> (62 - 2 * (pos - 32))) & 3u;
         fm = ((fm << 2) | b) & mmask;
         rm = (rm >> 2) | ((b ^ 3u) << (M2 - 2));
     }
@@ -751,17 +876,17 @@ __device__ __forceinline__ void seg_runs(const ReadSrc &s, int sgm, const uint64
     for (int j = W - 2; j >= 0; j--) val[j] = val[j] < val[j + 1] ? val[j] : val[j + 1];
 #pragma unroll
     for (int j = W + 1; j < NM; j++) val[j] = val[j] < val[j - 1] ? val[j] : val[j - 1];
-    uint64_t cur = val[0];
+    uint32_t cur = val[0];
     int start = 0;
 #pragma unroll
     for (int i = 1; i < PK; i++) {
-        const uint64_t wi = val[i] < val[W + i - 1] ? val[i] : val[W + i - 1];
+        const uint32_t wi = val[i] < val[W + i - 1] ? val[i] : val[W + i - 1];
         if (i < v && wi != cur) {
-            emit(start, i - start, (uint32_t)cur);
+            emit(start, i - start, cur);
             cur = wi; start = i;
         }
     }
-    emit(start, v - start, (uint32_t)cur);
+    emit(start, v - start, cur);
 }
 
 __device__ __forceinline__ uint64_t mmer_hash64(uint32_t canon) { return kmer_hash((uint64_t)canon); }
@@ -1013,10 +1138,10 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<RECS>::T *elems, 
     const int apply = !(twin == RFX_TWIN_RDD && min_cov <= 1);    // P/ReflexivMain.java:160
     {
         ScopedTimer t(ctx, "leaf");
-        int64_t grid = std::min<int64_t>(nleaf, (int64_t)ctx->num_cu * 2);      // persistent, ~66 KB LDS each
-        hipLaunchKernelGGL(k_leaf_count<RECS>, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, elems, d_leaf_off, nleaf,
-                           k, min_cov, max_cov, apply, d_out_keys, d_out_counts, (unsigned long long)cap,
-                           co_buf.as<CountOut>());
+        int64_t grid = std::min<int64_t>(nleaf, (int64_t)ctx->num_cu * 2);      // persistent, <= 78 KB LDS each
+        hipLaunchKernelGGL(k_leaf_count<RECS>, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, elems, d_leaf_off, nleaf, k,
+                           min_cov, max_cov, apply, d_out_keys, d_out_counts, (unsigned long long)cap,
+                           co_buf.as<CountOut>(), getenv("RFX_LEAF_DBG") ? atoi(getenv("RFX_LEAF_DBG")) : 0);
         RFX_HIP(hipGetLastError());
     }
     CountOut co{};

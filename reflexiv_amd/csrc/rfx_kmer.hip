@@ -830,6 +830,12 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
 // 8-byte instance array never exists in HBM.  (KMC / Gerbil-style, re-cut for wave64 + LDS.)
 constexpr int SK_M = 13;
 constexpr int SKT = 1024;             // threads per workgroup of the reads -> records kernels
+#ifndef SK_HIST_RUNLOOP
+#define SK_HIST_RUNLOOP false
+#endif
+#ifndef SK_SCATTER_RUNLOOP
+#define SK_SCATTER_RUNLOOP true
+#endif
 
 // order of the m-mers: a bijection of the canonical 26-bit m-mer onto 32 bits (odd multiplier,
 // xor-shift), so two different m-mers never tie and a plain 32-bit minimum picks the minimiser;
@@ -845,7 +851,7 @@ __device__ __forceinline__ unsigned rec_digit(uint32_t hdr, int used, int bits) 
 }
 
 // Walks the runs of one segment; calls emit(first_window, n_windows, minimiser_key).
-template <int W, class F>
+template <int W, bool RUNLOOP, class F>
 __device__ __forceinline__ void seg_runs(const ReadSrc &s, int sgm, const uint64_t (&w)[3], F &&emit,
                                          uint64_t *hi_out, uint64_t *lo_out) {
     constexpr int NM = PK + W - 1;                 // m-mers a segment can touch (<= 34)
@@ -876,17 +882,41 @@ __device__ __forceinline__ void seg_runs(const ReadSrc &s, int sgm, const uint64
     for (int j = W - 2; j >= 0; j--) val[j] = val[j] < val[j + 1] ? val[j] : val[j + 1];
 #pragma unroll
     for (int j = W + 1; j < NM; j++) val[j] = val[j] < val[j - 1] ? val[j] : val[j - 1];
-    uint32_t cur = val[0];
-    int start = 0;
+    if constexpr (!RUNLOOP) {
+        // cheap emit(): call it where the run ends (16 divergent call sites)
+        uint32_t cur = val[0];
+        int start = 0;
 #pragma unroll
-    for (int i = 1; i < PK; i++) {
-        const uint32_t wi = val[i] < val[W + i - 1] ? val[i] : val[W + i - 1];
-        if (i < v && wi != cur) {
-            emit(start, i - start, cur);
-            cur = wi; start = i;
+        for (int i = 1; i < PK; i++) {
+            const uint32_t wi = val[i] < val[W + i - 1] ? val[i] : val[W + i - 1];
+            if (i < v && wi != cur) {
+                emit(start, i - start, cur);
+                cur = wi; start = i;
+            }
         }
+        emit(start, v - start, cur);
+        return;
     }
-    emit(start, v - start, cur);
+    // per-window minimiser, then a bit per window that starts a run.  The runs are walked in a
+    // loop of their own so that emit() -- the expensive part -- runs once per run of the busiest
+    // lane (~6 times) instead of once per window position (16 divergent call sites).
+    uint32_t wm[PK];
+    wm[0] = val[0];
+#pragma unroll
+    for (int i = 1; i < PK; i++) wm[i] = val[i] < val[W + i - 1] ? val[i] : val[W + i - 1];
+    uint32_t starts = 1u;
+#pragma unroll
+    for (int i = 1; i < PK; i++) starts |= (uint32_t)(i < v && wm[i] != wm[i - 1]) << i;
+    while (starts) {
+        const int i0 = __ffs((int)starts) - 1;
+        starts &= starts - 1;
+        const int i1 = starts ? __ffs((int)starts) - 1 : v;
+        // wm[i0] by a compare-select chain (a register array cannot be indexed at run time)
+        uint32_t key = wm[0];
+#pragma unroll
+        for (int j = 1; j < PK; j++) key = i0 == j ? wm[j] : key;
+        emit(i0, i1 - i0, key);
+    }
 }
 
 __device__ __forceinline__ uint64_t mmer_hash64(uint32_t canon) { return kmer_hash((uint64_t)canon); }
@@ -913,7 +943,7 @@ __global__ __launch_bounds__(SKT) void k_sk_hist(ReadSrc s, Level lv, uint64_t *
     for (; g < s.n_threads; g += stride) {
         uint64_t w[3], hi, lo;
         seg_load(s, q, w);
-        seg_runs<W>(s, q.sgm, w, [&](int, int, uint32_t canon) { atomicAdd(&h[sk_digit(canon, lv)], 1u); }, &hi, &lo);
+        seg_runs<W, SK_HIST_RUNLOOP>(s, q.sgm, w, [&](int, int, uint32_t canon) { atomicAdd(&h[sk_digit(canon, lv)], 1u); }, &hi, &lo);
         q.r += dq; q.sgm += dr;
         if (q.sgm >= s.segs) { q.sgm -= s.segs; q.r++; }
     }
@@ -921,40 +951,71 @@ __global__ __launch_bounds__(SKT) void k_sk_hist(ReadSrc s, Level lv, uint64_t *
     for (int i = threadIdx.x; i < nb; i += SKT) blockhist[(int64_t)i * gridDim.x + blockIdx.x] = h[i];
 }
 
-// records go straight to the workgroup's private per-digit ranges (16-byte stores; the L2 of the
-// workgroup's XCD combines the records a stream appends to one line)
+// Records leave through write-combining rings (see k_rec_scatter_wc): every private per-digit
+// stream has SKB record slots in LDS indexed by the record's final position, and only whole
+// aligned 64-byte lines are stored; a digit that overruns its ring in one round stores directly.
+constexpr int SKB = 8, SKA = 4;
 template <int W>
-__global__ __launch_bounds__(SKT) void k_sk_scatter(ReadSrc s, Level lv, const uint64_t *__restrict__ scanned,
+__global__ __launch_bounds__(SKT, 8) void k_sk_scatter(ReadSrc s, Level lv, const uint64_t *__restrict__ scanned,
                                                    Rec *__restrict__ out) {
-    __shared__ unsigned long long cur[1 << MAX_BITS];
+    extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
     const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
-    for (int i = threadIdx.x; i < nb; i += SKT) cur[i] = scanned[(int64_t)i * gridDim.x + blockIdx.x];
+    Rec *buf = (Rec *)sk_smem;
+    unsigned long long *tail = (unsigned long long *)(buf + (size_t)nb * SKB);
+    unsigned long long *head = tail + nb;
+    for (int i = threadIdx.x; i < nb; i += SKT) tail[i] = head[i] = scanned[(int64_t)i * gridDim.x + blockIdx.x];
     __syncthreads();
+    auto drain = [&](bool final) __attribute__((always_inline)) {
+        for (int d = threadIdx.x / SKB; d < nb; d += SKT / SKB) {
+            const int j = threadIdx.x % SKB;
+            const unsigned long long h = head[d], t = tail[d];
+            unsigned long long e, nh;
+            if (t - h > (unsigned long long)SKB) { e = h + SKB; nh = t; }     // the excess went out directly
+            else {
+                e = final ? t : (t & ~(unsigned long long)(SKA - 1));
+                if (e < h) e = h;
+                nh = e;
+            }
+            const unsigned long long g = h + j;
+            if (g < e) out[g] = buf[(size_t)d * SKB + (g & (SKB - 1))];
+            if (j == 0) head[d] = nh;
+        }
+    };
     const int64_t stride = (int64_t)gridDim.x * SKT;
     const int64_t dq = stride / s.segs;
     const int dr = (int)(stride - dq * s.segs);
-    int64_t g = (int64_t)blockIdx.x * SKT + threadIdx.x;
+    const int64_t g0 = (int64_t)blockIdx.x * SKT;
+    int64_t g = g0 + threadIdx.x;
     SegPos q;
     q.r = g / s.segs;
     q.sgm = (int)(g - q.r * s.segs);
-    for (; g < s.n_threads; g += stride) {
-        uint64_t w[3], hi = 0, lo = 0;
-        seg_load(s, q, w);
-        // `hi`/`lo` are written before the first emit() runs (seg_runs stores them first)
-        seg_runs<W>(s, q.sgm, w, [&](int i0, int n, uint32_t canon) {
-            const uint64_t h = mmer_hash64(canon);
-            const unsigned d = lv.n_owners > 0 ? (unsigned)__umul64hi(h, (uint64_t)lv.n_owners)
-                                               : rec_digit((uint32_t)((h << OWNER_BITS) >> 32), 0, lv.bits);
-            const int sft = 2 * i0;
-            Rec r;
-            r.w0 = sft ? (hi << sft) | (lo >> (64 - sft)) : hi;
-            r.w1 = ((lo << sft) & 0xFFFFFFF000000000ULL) | ((uint64_t)(n - 1) << 32) |
-                   (uint64_t)(uint32_t)((h << OWNER_BITS) >> 32);
-            out[atomicAdd(&cur[d], 1ULL)] = r;
-        }, &hi, &lo);
-        q.r += dq; q.sgm += dr;
-        if (q.sgm >= s.segs) { q.sgm -= s.segs; q.r++; }
+    // every thread of the workgroup runs the same number of rounds (the barriers are uniform)
+    for (int64_t gb = g0; gb < s.n_threads; gb += stride, g += stride) {
+        if (g < s.n_threads) {
+            uint64_t w[3], hi = 0, lo = 0;
+            seg_load(s, q, w);
+            // `hi`/`lo` are written before the first emit() runs (seg_runs stores them first)
+            seg_runs<W, SK_SCATTER_RUNLOOP>(s, q.sgm, w, [&](int i0, int n, uint32_t canon) {
+                const uint64_t h = mmer_hash64(canon);
+                const unsigned d = lv.n_owners > 0 ? (unsigned)__umul64hi(h, (uint64_t)lv.n_owners)
+                                                   : rec_digit((uint32_t)((h << OWNER_BITS) >> 32), 0, lv.bits);
+                const int sft = 2 * i0;
+                Rec r;
+                r.w0 = sft ? (hi << sft) | (lo >> (64 - sft)) : hi;
+                r.w1 = ((lo << sft) & 0xFFFFFFF000000000ULL) | ((uint64_t)(n - 1) << 32) |
+                       (uint64_t)(uint32_t)((h << OWNER_BITS) >> 32);
+                const unsigned long long pos = atomicAdd(&tail[d], 1ULL);
+                if (pos - head[d] < (unsigned long long)SKB) buf[(size_t)d * SKB + (pos & (SKB - 1))] = r;
+                else out[pos] = r;
+            }, &hi, &lo);
+            q.r += dq; q.sgm += dr;
+            if (q.sgm >= s.segs) { q.sgm -= s.segs; q.r++; }
+        }
+        __syncthreads();
+        drain(false);
+        __syncthreads();
     }
+    drain(true);
 }
 
 // levels >= 2 on records: virtual workgroups as for k-mers, digit from the record header
@@ -986,6 +1047,70 @@ __global__ __launch_bounds__(PT) void k_rec_scatter(const Rec *__restrict__ recs
         const Rec r = recs[i];
         out[atomicAdd(&cur[rec_digit(rec_hdr(r), used, lv.bits)], 1ULL)] = r;
     }
+}
+
+// Write-combining scatter.  A 16-byte store per record into 512+ private streams runs the memory
+// system at a third of its rate (tools/scatter_bench.hip: 10.1 ms for 10.7 GB read + scattered
+// 16-B writes, 3.7 ms when every stream is written in aligned 128-byte bursts).  So each stream
+// gets a ring of B record slots in LDS, indexed by the record's final position in the output, and
+// only whole aligned lines of B/2 records leave the ring (partial lines stay for the next round;
+// a bin that receives more than the ring holds in one round writes the excess directly).
+constexpr int WCT = 1024;             // threads per workgroup (one workgroup per CU: the rings fill the LDS)
+constexpr int WC_PER = 2;             // records per thread per round
+
+template <int B>
+__global__ __launch_bounds__(WCT) void k_rec_scatter_wc(const Rec *__restrict__ recs, VbMap m, Level lv, int used,
+                                                        const uint64_t *__restrict__ scanned, Rec *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wc_smem[];
+    constexpr int A = B / 2;          // records per aligned output line (128 B for B = 16)
+    VbPos q;
+    if (!locate_vb(m, blockIdx.x, &q)) return;
+    const int nb = 1 << lv.bits;
+    Rec *buf = (Rec *)wc_smem;
+    unsigned long long *tail = (unsigned long long *)(buf + (size_t)nb * B);
+    unsigned long long *head = tail + nb;
+    const int64_t tb = (int64_t)nb * (int64_t)m.vb_start[q.p];
+    for (int i = threadIdx.x; i < nb; i += WCT) tail[i] = head[i] = scanned[tb + (int64_t)i * q.G + q.g];
+    __syncthreads();
+    // B adjacent lanes drain one bin: everything up to the last aligned boundary (all of it at the end)
+    auto drain = [&](bool final) __attribute__((always_inline)) {
+        for (int d = threadIdx.x / B; d < nb; d += WCT / B) {
+            const int j = threadIdx.x % B;
+            const unsigned long long h = head[d], t = tail[d];
+            unsigned long long e, nh;
+            if (t - h > (unsigned long long)B) { e = h + B; nh = t; }         // the excess went out directly
+            else {
+                e = final ? t : (t & ~(unsigned long long)(A - 1));
+                if (e < h) e = h;
+                nh = e;
+            }
+            const unsigned long long g = h + j;
+            if (g < e) out[g] = buf[(size_t)d * B + (g & (B - 1))];
+            if (j == 0) head[d] = nh;
+        }
+    };
+    for (uint64_t base = q.begin; base < q.end; base += (uint64_t)WCT * WC_PER) {
+        Rec r[WC_PER];
+#pragma unroll
+        for (int i = 0; i < WC_PER; i++) {
+            const uint64_t idx = base + (uint64_t)i * WCT + threadIdx.x;
+            if (idx < q.end) r[i] = recs[idx];
+        }
+#pragma unroll
+        for (int i = 0; i < WC_PER; i++) {
+            const uint64_t idx = base + (uint64_t)i * WCT + threadIdx.x;
+            if (idx < q.end) {
+                const unsigned d = rec_digit(rec_hdr(r[i]), used, lv.bits);
+                const unsigned long long g = atomicAdd(&tail[d], 1ULL);
+                if (g - head[d] < (unsigned long long)B) buf[(size_t)d * B + (g & (B - 1))] = r[i];
+                else out[g] = r[i];
+            }
+        }
+        __syncthreads();
+        drain(false);
+        __syncthreads();
+    }
+    drain(true);
 }
 
 // ------------------------------------------------------------ synthetic reads
@@ -1184,13 +1309,20 @@ static void launch_sk_hist(int W, dim3 grid, hipStream_t st, Args... args) {
         default: hipLaunchKernelGGL(k_sk_hist<19>, grid, dim3(SKT), 0, st, args...); break;
     }
 }
+template <int W, class... Args>
+static hipError_t launch_sk_scatter_w(dim3 grid, size_t lds, hipStream_t st, Args... args) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_sk_scatter<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_sk_scatter<W>, grid, dim3(SKT), lds, st, args...);
+    return hipGetLastError();
+}
 template <class... Args>
-static void launch_sk_scatter(int W, dim3 grid, hipStream_t st, Args... args) {
+static hipError_t launch_sk_scatter(int W, dim3 grid, size_t lds, hipStream_t st, Args... args) {
     switch (W) {
-        case 16: hipLaunchKernelGGL(k_sk_scatter<16>, grid, dim3(SKT), 0, st, args...); break;
-        case 17: hipLaunchKernelGGL(k_sk_scatter<17>, grid, dim3(SKT), 0, st, args...); break;
-        case 18: hipLaunchKernelGGL(k_sk_scatter<18>, grid, dim3(SKT), 0, st, args...); break;
-        default: hipLaunchKernelGGL(k_sk_scatter<19>, grid, dim3(SKT), 0, st, args...); break;
+        case 16: return launch_sk_scatter_w<16>(grid, lds, st, args...);
+        case 17: return launch_sk_scatter_w<17>(grid, lds, st, args...);
+        case 18: return launch_sk_scatter_w<18>(grid, lds, st, args...);
+        default: return launch_sk_scatter_w<19>(grid, lds, st, args...);
     }
 }
 
@@ -1202,9 +1334,8 @@ static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv
                               const char *hn, const char *pn) {
     const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
     const int W = rsrc.k - SK_M + 1;
-    // few, fat workgroups: the number of concurrently open output lines (workgroups x digits x
-    // 128 B) must stay inside the L2 for the 16-byte record stores to combine
-    int per_cu = 2;
+    const size_t sk_lds = (size_t)nb * (SKB * sizeof(Rec) + 16);
+    int per_cu = sk_lds <= 80 * 1024 ? 2 : 1;          // as many workgroups as the rings leave room for
     if (const char *e = getenv("RFX_SK_PER_CU")) per_cu = std::max(1, atoi(e));
     const unsigned G = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(rsrc.n_threads, SKT), (int64_t)ctx->num_cu * per_cu));
     DevBuf bh, scanned;
@@ -1232,8 +1363,8 @@ static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv
     }
     {
         ScopedTimer t(ctx, pn);
-        launch_sk_scatter(W, dim3(G), ctx->stream, rsrc, lv, (const uint64_t *)scanned.as<uint64_t>(), dst);
-        RFX_HIP(hipGetLastError());
+        RFX_HIP(launch_sk_scatter(W, dim3(G), sk_lds, ctx->stream, rsrc, lv,
+                                  (const uint64_t *)scanned.as<uint64_t>(), dst));
     }
     *out_recs = dst;
     return RFX_OK;
@@ -1285,8 +1416,21 @@ static int count_records_levels(rfx_ctx *ctx, const Rec *recs, int64_t n_recs, i
         if (!dst) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
         {
             ScopedTimer t(ctx, pn);
-            hipLaunchKernelGGL(k_rec_scatter, dim3((unsigned)v_bound), dim3(PT), 0, ctx->stream, cur, vm, lv, used,
-                               (const uint64_t *)scanned.as<uint64_t>(), dst);
+            const bool wc = !(getenv("RFX_WC") && atoi(getenv("RFX_WC")) == 0) && lv.bits >= 4;
+            if (wc && lv.bits <= 9) {
+                const size_t lds = (size_t)nb * (16 * sizeof(Rec) + 16);
+                RFX_HIP(hipFuncSetAttribute((const void *)k_rec_scatter_wc<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_rec_scatter_wc<16>, dim3((unsigned)v_bound), dim3(WCT), lds, ctx->stream, cur, vm, lv,
+                                   used, (const uint64_t *)scanned.as<uint64_t>(), dst);
+            } else if (wc) {
+                const size_t lds = (size_t)nb * (8 * sizeof(Rec) + 16);
+                RFX_HIP(hipFuncSetAttribute((const void *)k_rec_scatter_wc<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_rec_scatter_wc<8>, dim3((unsigned)v_bound), dim3(WCT), lds, ctx->stream, cur, vm, lv,
+                                   used, (const uint64_t *)scanned.as<uint64_t>(), dst);
+            } else {
+                hipLaunchKernelGGL(k_rec_scatter, dim3((unsigned)v_bound), dim3(PT), 0, ctx->stream, cur, vm, lv, used,
+                                   (const uint64_t *)scanned.as<uint64_t>(), dst);
+            }
             RFX_HIP(hipGetLastError());
         }
         cur = dst;

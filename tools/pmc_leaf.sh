@@ -1,6 +1,8 @@
+# SQ counters of the leaf kernel (rocprofv3 --pmc passes; run on the GPU box): bash tools/pmc_leaf.sh [tag]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+T=${1:-pmc}
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ATOMIC_RETURN SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_RD"; do
   tag=$(echo $set | cut -d' ' -f1)
-  timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$tag -- python3 $R/tools/prof_count.py --gbp 5 --steps 1 > $R/gpurun_out/pmc_$tag.log 2>&1 || exit 1
+  timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/${T}_$tag -- python3 $R/tools/prof_count.py --gbp 5 --steps 1 > $R/gpurun_out/${T}_$tag.log 2>&1 || exit 1
 done

@@ -578,21 +578,24 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
                 a = a && (((gA >> 4) & 0xffffu) & (S - 1)) == s;
                 b = b && (((gB >> 4) & 0xffffu) & (S - 1)) == s;
             }
-            for (int probe = 0; a || b; probe++) {
-                unsigned long long pA = 0, pB = 0;
-                if (a) pA = atomicCAS(&tkey[slotA], EMPTY, (unsigned long long)keyA);
-                if (b) pB = atomicCAS(&tkey[slotB], EMPTY, (unsigned long long)keyB);
-                if (a) {
-                    if (pA == EMPTY || pA == keyA) { atomicAdd(&tcnt[slotA], 1u); a = false; }
-                    else slotA = (slotA + 1) & (LCAP - 1);
+            // first probe of both keys (nine in ten end here: the key is already in the table)
+            unsigned long long pA = EMPTY, pB = EMPTY;
+            if (a) pA = atomicCAS(&tkey[slotA], EMPTY, (unsigned long long)keyA);
+            if (b) pB = atomicCAS(&tkey[slotB], EMPTY, (unsigned long long)keyB);
+            const bool dA = pA == EMPTY || pA == keyA, dB = pB == EMPTY || pB == keyB;
+            if (a && dA) atomicAdd(&tcnt[slotA], 1u);
+            if (b && dB) atomicAdd(&tcnt[slotB], 1u);
+            // the rest walk their probe sequences one key at a time
+            auto walk = [&](uint64_t key, uint32_t slot) __attribute__((always_inline)) {
+                for (int probe = 1;; probe++) {
+                    slot = (slot + 1) & (LCAP - 1);
+                    const unsigned long long p = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
+                    if (p == EMPTY || p == key) { atomicAdd(&tcnt[slot], 1u); break; }
+                    if (probe >= LPROBE) { overflow = 1; break; }
                 }
-                if (b) {
-                    if (pB == EMPTY || pB == keyB) { atomicAdd(&tcnt[slotB], 1u); b = false; }
-                    else slotB = (slotB + 1) & (LCAP - 1);
-                }
-                if (probe >= LPROBE) { overflow = 1; break; }
-                if ((probe & 15) == 15 && *(volatile uint32_t *)&overflow) break;
-            }
+            };
+            if (!dA) walk(keyA, slotA);
+            if (!dB) walk(keyB, slotB);
         };
         if constexpr (RECS) {
             // Records: every wave takes an equal contiguous share of the leaf and walks it 64 records
@@ -673,17 +676,17 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
             for (int i = 0; i < RPF; i++) {
                 const uint64_t r0 = ws + 64u * i;
                 // an overflowing pass is abandoned: stop feeding a table that is filling up
-                if (r0 < we && !*(volatile uint32_t *)&overflow) step(cur[i], r0 + lane_ < we);
+                if (r0 < we && !__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) step(cur[i], r0 + lane_ < we);
             }
             for (uint64_t r0 = ws + 64u * RPF; r0 < we; r0 += 64) {
-                if (*(volatile uint32_t *)&overflow) break;
+                if (__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
                 const bool valid = r0 + lane_ < we;
                 step(valid ? keys[r0 + lane_] : Rec{0, 0}, valid);
             }
         } else {
             for (uint64_t base = begin; base < end; base += (uint64_t)LT * NB) {
                 // an overflowing pass is abandoned: stop feeding a table that is filling up
-                if (*(volatile uint32_t *)&overflow) break;
+                if (__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
                 Elem kc[NB];
                 if (pf == base) {
 #pragma unroll

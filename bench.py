@@ -25,7 +25,7 @@ HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s s
 
 # algorithmic HBM bytes per k-mer instance, per kernel family (DESIGN.md "Kernels")
 ALGO_BYTES = {"hist1": 0.25, "part1": 8.25, "hist2": 8.0, "part2": 16.0, "hist3": 8.0, "part3": 16.0,
-              "leaf": 8.0}
+              "leaf": 8.0, "extract_w": 0.25 + 16.0, "count_w": 16.0}      # k = 63: W = 2 words per instance
 
 
 def measured_traffic(kernel, n_inst):
@@ -107,8 +107,14 @@ def main():
     wpr = (L + 31) // 32
     n_reads = int(round(args.gbp * 1e9 / L))
     n_reads += n_reads & 1                                    # whole pairs
-    nk = rfx.kmers_per_read(L, k)
+    wide = k > 31                                             # the counter's multi-word k-mers
+    W = k // 32 + 1 if wide else 1
+    nk = rfx.kmers_per_read_w(L, k) if wide else rfx.kmers_per_read(L, k)
     n_inst = nk * n_reads                                     # instances per rank per step
+    if wide:
+        assert world == 1, "k > 31 is a single-GPU path this round"
+        args.no_contigs = True                                # the assembler's k > 31 twin is SURVEY.md 8f-3
+        args.no_cpu_baseline = True
 
     # synthetic reads straight into HBM, 2-bit packed (data = "synthetic")
     d_genome = torch.empty((args.genome + 31) // 32, dtype=torch.int64, device=dev)
@@ -120,8 +126,8 @@ def main():
     rfx.sync()
 
     cap = max(1 << 20, n_inst // 8)
-    d_keys = torch.empty(cap, dtype=torch.int64, device=dev)
-    d_counts = torch.empty(cap, dtype=torch.int32, device=dev)
+    d_keys = torch.empty(cap * W, dtype=torch.int64, device=dev)
+    d_counts = torch.empty(cap, dtype=torch.int64 if wide else torch.int32, device=dev)
     reads = dict(words=d_words, n_reads=n_reads, wpr=wpr, read_len=L, k=k)
     engine = rd.HipEngine(rfx)
     timing_acc = {}
@@ -129,6 +135,9 @@ def main():
     shard = {}
 
     def step():
+        if wide:
+            return rfx.count_reads_w_dev(d_words.data_ptr(), n_reads, wpr, L, k, d_keys.data_ptr(), d_counts.data_ptr(),
+                                         cap, args.cover)
         if world == 1:
             m, nd, inst = rfx.count_reads_dev(d_words.data_ptr(), n_reads, wpr, L, k, d_keys.data_ptr(),
                                               d_counts.data_ptr(), cap, args.cover)
@@ -187,7 +196,7 @@ def main():
                    "parallelism": "1 GPU" if world == 1 else f"k-mer space radix-sharded over {world} GPUs, "
                                                                "RCCL all-to-all(v)"},
         "roofline": roofline,
-        "stage_hbm_frac": ((16.25 * n_inst + 12 * m) / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS) if world == 1 else None,
+        "stage_hbm_frac": (((0.25 + 16 * W) * n_inst + (8 * W + 4) * m) / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS) if world == 1 else None,
     }
 
     if world > 1 and not args.no_contigs:

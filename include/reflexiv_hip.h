@@ -114,6 +114,25 @@ int rfx_count_filter(rfx_ctx *ctx, const uint64_t *kmers, int64_t n,
                      uint64_t *out_keys, int32_t *out_counts, int64_t cap,
                      int64_t *out_n, int64_t *out_distinct);
 
+/* ---- k > 31: the counter's multi-word k-mers ----
+ * W = k/32+1 words per k-mer, words 0..W-2 hold 32 bases each, the last word the k%32 remaining
+ * bases right-aligned (P/ReflexivDataFrameCounter64.java:429-437); k > 32, k % 32 != 0, W <= 8.
+ * Arrays hold W consecutive words per k-mer, as the reference's Row(long[]) does. */
+
+/* ReverseComplementKmerBinaryExtractionFromDataset64.call
+ * P/ReflexivDataFrameCounter64.java:401-650 (canonical by compareLongArrayBlocks :652-687:
+ * base-wise fwd < rc, ties -> fwd).  Skip rule :410.  cap/out_n count k-mers, not words. */
+int rfx_extract_canon_w(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_off,
+                        int64_t n_reads, int k, int front_clip, int end_clip,
+                        uint64_t *out_kmers, int64_t cap, int64_t *out_n);
+
+/* groupBy("kmerBlocks").count() + filter(count >= min if min > 1) + filter(count <= max if
+ * max < 10000000)  P/ReflexivDataFrameCounter64.java:191-205.  Output ascending by base string. */
+int rfx_count_filter_w(rfx_ctx *ctx, const uint64_t *kmers, int64_t n, int k,
+                       int min_cov, int max_cov,
+                       uint64_t *out_keys, int64_t *out_counts, int64_t cap,
+                       int64_t *out_n, int64_t *out_distinct);
+
 /* KmerReverseComplement.call + ForwardSubKmerExtraction.call
  * P/ReflexivMain.java:2910-2930, 2709-2730 (DS :3849-3868, :3625-3644).
  * n (kmer,count) -> 2n single-word records; ext carries no sentinel yet. */
@@ -184,6 +203,14 @@ int rfx_dev_count_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads,
                         void *d_workspace, int64_t workspace_bytes,
                         uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap,
                         int64_t *out_n, int64_t *out_distinct, int64_t *out_instances);
+
+/* k > 31 twin of rfx_dev_count_reads (all device pointers; d_out_keys: cap*W words). */
+int64_t rfx_kmers_per_read_w(int read_len, int k, int front_clip, int end_clip);
+int rfx_dev_count_reads_w(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads,
+                          int words_per_read, int read_len, int k, int front_clip, int end_clip,
+                          int min_cov, int max_cov,
+                          uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap,
+                          int64_t *out_n, int64_t *out_distinct, int64_t *out_instances);
 
 /* Same, from an explicit k-mer array (the reduceByKey input) in HBM. */
 int rfx_dev_count_kmers(rfx_ctx *ctx, const uint64_t *d_kmers, int64_t n,

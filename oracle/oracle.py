@@ -50,6 +50,8 @@ def lib():
         L.orc_fastq_group.restype = C.c_int64
         L.orc_extract_canon.restype = C.c_int64
         L.orc_count_filter.restype = C.c_int64
+        L.orc_extract_canon_w.restype = C.c_int64
+        L.orc_count_filter_w.restype = C.c_int64
         L.orc_revcomp.restype = C.c_uint64
         L.orc_revcomp.argtypes = [C.c_uint64, C.c_int]
         L.orc_fork_filter_forward.restype = C.c_int64
@@ -155,6 +157,44 @@ def count_filter(kmers: np.ndarray, min_cov=2, max_cov=10_000_000, twin=TWIN_DS)
     m = lib().orc_count_filter(_p(work), C.c_int64(n), min_cov, max_cov, twin,
                                _p(keys), _p(counts), C.c_int64(n), C.byref(nd))
     return keys[:m].copy(), counts[:m].copy(), int(nd.value)
+
+
+def words_w(k: int) -> int:
+    return k // 32 + 1
+
+
+def extract_canon_w(bases: np.ndarray, read_off: np.ndarray, k=63, front_clip=0, end_clip=0) -> np.ndarray:
+    """k > 31 (ReflexivDataFrameCounter64): -> uint64[n, W], W = k//32+1, last word right-aligned."""
+    bases = np.ascontiguousarray(bases, np.uint8)
+    read_off = np.ascontiguousarray(read_off, np.int64)
+    nr = len(read_off) - 1
+    W = words_w(k)
+    n = lib().orc_extract_canon_w(_p(bases), _p(read_off), C.c_int64(nr), k, front_clip, end_clip, None, C.c_int64(0))
+    if n < 0:
+        raise ValueError("k must be > 32 and not a multiple of 32")
+    out = np.empty((n, W), np.uint64)
+    lib().orc_extract_canon_w(_p(bases), _p(read_off), C.c_int64(nr), k, front_clip, end_clip, _p(out), C.c_int64(n))
+    return out
+
+
+def count_filter_w(kmers: np.ndarray, k=63, min_cov=2, max_cov=10_000_000):
+    """-> (keys uint64[m, W] ascending, counts int64[m], n_distinct); kmers is not modified."""
+    W = words_w(k)
+    work = np.array(kmers, dtype=np.uint64, copy=True).reshape(-1, W)
+    n = len(work)
+    keys = np.empty((n, W), np.uint64)
+    counts = np.empty(n, np.int64)
+    nd = C.c_int64(0)
+    m = lib().orc_count_filter_w(_p(work), C.c_int64(n), k, min_cov, max_cov, _p(keys), _p(counts), C.c_int64(n),
+                                 C.byref(nd))
+    return keys[:m].copy(), counts[:m].copy(), int(nd.value)
+
+
+def kmer_text_w(kmer: np.ndarray, k: int) -> str:
+    kmer = np.ascontiguousarray(kmer, np.uint64)
+    buf = C.create_string_buffer(k)
+    lib().orc_kmer_text_w(_p(kmer), k, buf)
+    return buf.raw.decode()
 
 
 def revcomp(kmer: int, k: int) -> int:

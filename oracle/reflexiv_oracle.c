@@ -113,6 +113,124 @@ int64_t orc_extract_canon(const char *bases, const int64_t *read_off, int64_t n_
     return n;
 }
 
+/* ------------------------------------------------------- a-2w extract, k > 31 */
+
+int orc_words_w(int k) { return k / 32 + 1; }
+
+/* compareLongArrayBlocks :652-687: base by base from the left; equal -> true (forward) */
+static int fwd_not_after_rc(const uint64_t *f, const uint64_t *r, int W, int res) {
+    for (int i = 0; i < W; i++) {
+        const int nb = i < W - 1 ? 32 : res;
+        for (int j = 0; j < nb; j++) {
+            const unsigned a = (unsigned)(f[i] >> (2 * (nb - 1 - j))) & 3u;
+            const unsigned b = (unsigned)(r[i] >> (2 * (nb - 1 - j))) & 3u;
+            if (a < b) return 1;
+            if (a > b) return 0;
+        }
+    }
+    return 1;
+}
+
+int64_t orc_extract_canon_w(const char *bases, const int64_t *read_off, int64_t n_reads,
+                            int k, int front_clip, int end_clip, uint64_t *out, int64_t cap) {
+    const int W = k / 32 + 1, res = k % 32;             /* kmerBinarySlots, kmerSizeResidue */
+    if (k <= 32 || res == 0 || W > 8) return -1;
+    const uint64_t mask = ~((~0ULL) << (2 * res));      /* maxKmerBits :391 */
+    int64_t n = 0;
+    for (int64_t r = 0; r < n_reads; r++) {
+        const char *read = bases + read_off[r];
+        const int64_t len = read_off[r + 1] - read_off[r];
+        if (len - k - end_clip + 1 <= 0 || front_clip > len) continue;       /* :410 */
+        uint64_t acc = 0, racc = 0, f[8] = {0}, rc[8] = {0};
+        for (int64_t i = front_clip; i < len - end_clip; i++) {              /* :419 */
+            const int64_t j = i - front_clip;
+            const uint64_t v = nuc_value(read[i]);
+            if (j <= k - 1) {                                                /* :425-441 */
+                acc = (acc << 2) | v;
+                if ((j + 1) % 32 == 0) { f[(j + 1) / 32 - 1] = acc; acc = 0; }
+                if (j == k - 1) { acc &= mask; f[(j + 1) / 32] = acc; acc = 0; }
+            } else {                                                         /* :442-460 */
+                uint64_t t1 = f[W - 1] >> (2 * (res - 1)), t2;
+                f[W - 1] = ((f[W - 1] << 2) | v) & mask;
+                for (int q = W - 2; q >= 0; q--) {
+                    t2 = f[q] >> 62;
+                    f[q] = (f[q] << 2) | t1;
+                    t1 = t2;
+                }
+            }
+            uint64_t c = v ^ 3;                                              /* :463 */
+            if (j <= k - 1) {                                                /* :465-491 */
+                if (j < res - 1) { racc |= c << (2 * j); }
+                else if (j == res - 1) { racc |= c << (2 * j); rc[W - 1] = racc; racc = 0; }
+                else if ((j - res + 1) % 32 == 0) {
+                    racc |= c << (2 * ((j - res) % 32));
+                    rc[W - (j - res + 1) / 32 - 1] = racc; racc = 0;
+                } else { racc |= c << (2 * ((j - res) % 32)); }
+            } else {                                                         /* :492-512 */
+                uint64_t t1 = rc[0] << 62, t2;
+                rc[0] = (rc[0] >> 2) | (c << 62);
+                for (int q = 1; q < W - 1; q++) {
+                    t2 = rc[q] << 62;
+                    rc[q] = (rc[q] >> 2) | t1;
+                    t1 = t2;
+                }
+                rc[W - 1] >>= 2;
+                rc[W - 1] |= t1 >> (2 * (31 - res + 1));
+            }
+            if (j >= k - 1) {                                                /* :524, :609-627 */
+                const uint64_t *src = fwd_not_after_rc(f, rc, W, res) ? f : rc;
+                if (n < cap) for (int q = 0; q < W; q++) out[n * W + q] = src[q];
+                n++;
+            }
+        }
+    }
+    return n;
+}
+
+static int g_cmp_w = 1;
+static int cmp_words(const void *a, const void *b) {
+    const uint64_t *x = (const uint64_t *)a, *y = (const uint64_t *)b;
+    for (int i = 0; i < g_cmp_w; i++) {
+        if (x[i] < y[i]) return -1;
+        if (x[i] > y[i]) return 1;
+    }
+    return 0;
+}
+
+int64_t orc_count_filter_w(uint64_t *kmers, int64_t n, int k, int min_cov, int max_cov,
+                           uint64_t *out_keys, int64_t *out_counts, int64_t cap, int64_t *n_distinct) {
+    const int W = k / 32 + 1;
+    g_cmp_w = W;
+    qsort(kmers, (size_t)n, (size_t)W * 8, cmp_words);
+    int64_t m = 0, d = 0;
+    for (int64_t i = 0; i < n;) {
+        int64_t j = i + 1;
+        while (j < n && cmp_words(kmers + i * W, kmers + j * W) == 0) j++;
+        const int64_t c = j - i;
+        d++;
+        int keep = 1;
+        if (min_cov > 1 && c < min_cov) keep = 0;                            /* :197-200 */
+        if (max_cov < 10000000 && c > max_cov) keep = 0;                     /* :202-205 */
+        if (keep) {
+            if (m < cap) {
+                for (int q = 0; q < W; q++) out_keys[m * W + q] = kmers[i * W + q];
+                out_counts[m] = c;
+            }
+            m++;
+        }
+        i = j;
+    }
+    if (n_distinct) *n_distinct = d;
+    return m;
+}
+
+void orc_kmer_text_w(const uint64_t *kmer, int k, char *out) {
+    static const char nt[4] = {'A', 'C', 'G', 'T'};
+    const int res = k % 32;
+    for (int i = 0; i < (k / 32) * 32; i++) out[i] = nt[(kmer[i / 32] >> (2 * (31 - i % 32))) & 3];      /* :346-352 */
+    for (int i = (k / 32) * 32; i < k; i++) out[i] = nt[(kmer[i / 32] >> (2 * (res - 1 - i % 32))) & 3];  /* :354-360 */
+}
+
 /* ---------------------------------------------------------- radix sort u64 */
 
 static void radix_sort_u64(uint64_t *a, int64_t n) {

@@ -162,6 +162,20 @@ int64_t orc_assemble_from_counts(const uint64_t *kmers, const int32_t *counts, i
                                  orc_records *rec_out);
 void orc_free_records(orc_records *r);
 
+/* ---- a-2w: k > 31 (the counter's multi-word k-mers), P/ReflexivDataFrameCounter64.java
+ * W = k/32+1 words per k-mer: words 0..W-2 hold 32 bases each (all 64 bits), the last word the
+ * k%32 remaining bases right-aligned (:429-437).  k % 32 != 0, k > 32.  AoS: k-mer i = out[i*W ..]. */
+int orc_words_w(int k);                                   /* k/32+1 (U/DefaultParam.java:81) */
+/* ReverseComplementKmerBinaryExtractionFromDataset64.call :401-650, compareLongArrayBlocks :652-687 */
+int64_t orc_extract_canon_w(const char *bases, const int64_t *read_off, int64_t n_reads,
+                            int k, int front_clip, int end_clip, uint64_t *out, int64_t cap);
+/* groupBy("kmerBlocks").count() + the two filters (:197-209).  Output ascending by base string
+ * (the order contract's count-stage order).  kmers (n*W words) is sorted in place. */
+int64_t orc_count_filter_w(uint64_t *kmers, int64_t n, int k, int min_cov, int max_cov,
+                           uint64_t *out_keys, int64_t *out_counts, int64_t cap, int64_t *n_distinct);
+/* DSBinaryKmerToString.call :340-369: the k characters of one k-mer (no terminator). */
+void orc_kmer_text_w(const uint64_t *kmer, int k, char *out);
+
 /* Synthetic reads, integer-only counter-based generator shared
  * bit-for-bit with reflexiv_amd/csrc (rfx_synth_*). */
 uint64_t orc_splitmix64(uint64_t x);

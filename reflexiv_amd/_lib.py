@@ -50,6 +50,7 @@ SYMBOLS = [
     "rfx_dev_count_kmers", "rfx_dev_bucket_by_owner", "rfx_dev_bucket_records_by_owner",
     "rfx_dev_count_records", "rfx_dev_assemble", "rfx_dev_synth_genome",
     "rfx_dev_synth_reads", "rfx_dev_sort_pairs", "rfx_last_count_timing",
+    "rfx_extract_canon_w", "rfx_count_filter_w", "rfx_kmers_per_read_w", "rfx_dev_count_reads_w",
 ]
 
 
@@ -87,6 +88,9 @@ def lib():
         L.rfx_count_workspace_bytes.argtypes = [C.c_int64]
         for name in SYMBOLS:
             fn = getattr(L, name)
+            if name == "rfx_kmers_per_read_w":
+                fn.restype = C.c_int64
+                continue
             if name not in ("rfx_ctx_stream", "rfx_last_error", "rfx_kmers_per_read",
                             "rfx_count_workspace_bytes", "rfx_ctx_destroy", "rfx_default_params"):
                 fn.restype = C.c_int

@@ -136,6 +136,53 @@ class Reflexiv:
                                             _p(counts), C.c_int64(n), C.byref(m), C.byref(d)), "rfx_count_filter")
         return keys[:m.value].copy(), counts[:m.value].copy(), int(d.value)
 
+    # k > 31: the counter's W = k//32+1 word k-mers (P/ReflexivDataFrameCounter64.java)
+    def ReverseComplementKmerBinaryExtractionFromDataset64(self, bases, read_off, k=63, front_clip=0, end_clip=0):
+        """:401-650 -> canonical k-mers uint64[n, W] in read/window order."""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        read_off = np.ascontiguousarray(read_off, np.int64)
+        nr = len(read_off) - 1
+        W = k // 32 + 1
+        n = C.c_int64(0)
+        st = self.L.rfx_extract_canon_w(self.ctx, _p(bases), _p(read_off), C.c_int64(nr), k, front_clip, end_clip,
+                                        None, C.c_int64(0), C.byref(n))
+        if st not in (RFX_OK, RFX_E_CAP):
+            self._check(st, "rfx_extract_canon_w")
+        out = np.empty((max(1, n.value), W), np.uint64)
+        self._check(self.L.rfx_extract_canon_w(self.ctx, _p(bases), _p(read_off), C.c_int64(nr), k, front_clip,
+                                               end_clip, _p(out), C.c_int64(n.value), C.byref(n)),
+                    "rfx_extract_canon_w")
+        return out[:n.value]
+
+    def groupBy_count_filter_w(self, kmers, k=63, min_cov=2, max_cov=10_000_000):
+        """groupBy("kmerBlocks").count() + the two filters, :191-205 -> (keys[m, W], counts int64[m], n_distinct)."""
+        W = k // 32 + 1
+        kmers = np.ascontiguousarray(kmers, np.uint64).reshape(-1, W)
+        n = len(kmers)
+        keys = np.empty((max(1, n), W), np.uint64)
+        counts = np.empty(max(1, n), np.int64)
+        m, d = C.c_int64(0), C.c_int64(0)
+        self._check(self.L.rfx_count_filter_w(self.ctx, _p(kmers), C.c_int64(n), k, min_cov, max_cov, _p(keys),
+                                              _p(counts), C.c_int64(n), C.byref(m), C.byref(d)), "rfx_count_filter_w")
+        return keys[:m.value].copy(), counts[:m.value].copy(), int(d.value)
+
+    def kmers_per_read_w(self, read_len, k, front_clip=0, end_clip=0) -> int:
+        return int(self.L.rfx_kmers_per_read_w(read_len, k, front_clip, end_clip))
+
+    def count_reads_w_dev(self, d_words: int, n_reads: int, words_per_read: int, read_len: int, k: int,
+                          d_out_keys: int, d_out_counts: int, cap: int, min_cov=2, max_cov=10_000_000,
+                          front_clip=0, end_clip=0):
+        """k > 31 twin of count_reads_dev -> (n_survivors, n_distinct, n_instances); keys cap*W words, counts int64."""
+        n, d, inst = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        st = self.L.rfx_dev_count_reads_w(self.ctx, C.c_void_p(d_words), C.c_int64(n_reads), words_per_read, read_len,
+                                          k, front_clip, end_clip, min_cov, max_cov, C.c_void_p(d_out_keys),
+                                          C.c_void_p(d_out_counts), C.c_int64(cap), C.byref(n), C.byref(d),
+                                          C.byref(inst))
+        if st == RFX_E_CAP:
+            raise RfxError(st, "rfx_dev_count_reads_w", f"needs room for {n.value} survivors, cap is {cap}")
+        self._check(st, "rfx_dev_count_reads_w")
+        return int(n.value), int(d.value), int(inst.value)
+
     def KmerReverseComplement_and_ForwardSubKmerExtraction(self, keys, counts, k=31) -> Records:
         keys = np.ascontiguousarray(keys, np.uint64)
         counts = np.ascontiguousarray(counts, np.int32)
@@ -325,7 +372,7 @@ class Reflexiv:
     def count_timing(self):
         """Per-kernel-family HIP-event timing of the last count call: {name: (ms, launches)}."""
         out = {}
-        for name in ("hist1", "part1", "hist2", "part2", "hist3", "part3", "leaf", "sort"):
+        for name in ("hist1", "part1", "hist2", "part2", "hist3", "part3", "leaf", "sort", "extract_w", "count_w"):
             ms, ln = C.c_float(0), C.c_int64(0)
             if self.L.rfx_last_count_timing(self.ctx, name.encode(), C.byref(ms), C.byref(ln)) == RFX_OK:
                 out[name] = (float(ms.value), int(ln.value))

@@ -81,6 +81,42 @@ KmerBinaryRDD ReflexivMain::KmerCounting_KmerCoverageFilter::call(const std::vec
     return o;
 }
 
+std::vector<uint64_t> ReflexivMain::ReverseComplementKmerBinaryExtractionFromDataset64::call(
+    const std::vector<uint8_t> &bases, const std::vector<int64_t> &readOff) const {
+    int64_t n = 0;
+    const int64_t nr = (int64_t)readOff.size() - 1;
+    const int W = m.param.kmerSize / 32 + 1;                     // kmerBinarySlots, U/DefaultParam.java:81
+    int st = rfx_extract_canon_w(m.ctx, bases.data(), readOff.data(), nr, m.param.kmerSize, m.param.frontClip,
+                                 m.param.endClip, nullptr, 0, &n);
+    if (st != RFX_OK && st != RFX_E_CAP) m.check(st, "rfx_extract_canon_w");
+    std::vector<uint64_t> out((size_t)std::max<int64_t>(n, 1) * W);
+    m.check(rfx_extract_canon_w(m.ctx, bases.data(), readOff.data(), nr, m.param.kmerSize, m.param.frontClip,
+                                m.param.endClip, out.data(), n, &n), "rfx_extract_canon_w");
+    out.resize((size_t)n * W);
+    return out;
+}
+
+void ReflexivMain::KmerBlocksCount::call(const std::vector<uint64_t> &kmers, std::vector<uint64_t> &keys,
+                                         std::vector<int64_t> &counts) const {
+    const int W = m.param.kmerSize / 32 + 1;
+    const int64_t n = (int64_t)kmers.size() / W;
+    keys.resize((size_t)std::max<int64_t>(n, 1) * W); counts.resize((size_t)std::max<int64_t>(n, 1));
+    int64_t mm = 0, d = 0;
+    m.check(rfx_count_filter_w(m.ctx, kmers.data(), n, m.param.kmerSize, m.param.minKmerCoverage, m.param.maxKmerCoverage,
+                               keys.data(), counts.data(), n, &mm, &d), "rfx_count_filter_w");
+    keys.resize((size_t)mm * W); counts.resize((size_t)mm);
+}
+
+std::string ReflexivMain::DSBinaryKmerToString::call(const uint64_t *b) const {
+    static const char NUC[4] = {'A', 'C', 'G', 'T'};
+    const int k = m.param.kmerSize, res = k % 32;                // kmerSizeResidue
+    std::string sb;
+    sb.reserve((size_t)k);
+    for (int i = 0; i < (k / 32) * 32; i++) sb.push_back(NUC[(b[i / 32] >> (2 * (31 - i % 32))) & 3]);       // :346-352
+    for (int i = (k / 32) * 32; i < k; i++) sb.push_back(NUC[(b[i / 32] >> (2 * (res - 1 - i % 32))) & 3]);  // :354-360
+    return sb;
+}
+
 ReflexivSubKmerRDD ReflexivMain::KmerReverseComplement_ForwardSubKmerExtraction::call(const KmerBinaryRDD &in) const {
     ReflexivSubKmerRDD o;
     const int64_t n = (int64_t)in.kmer.size();
@@ -268,6 +304,21 @@ std::string ReflexivMain::counter(const std::string &fastqText) {
     static const char NUC[4] = {'A', 'C', 'G', 'T'};
     std::vector<uint8_t> bases; std::vector<int64_t> readOff;
     FastqFilterWithQual{*this}.call(fastqText, bases, readOff);
+    if (param.kmerSize > 31) {                       // P/ReflexivDataFrameCounter64.java:133-232
+        const int W = param.kmerSize / 32 + 1;
+        std::vector<uint64_t> kmers = ReverseComplementKmerBinaryExtractionFromDataset64{*this}.call(bases, readOff);
+        std::vector<uint64_t> keys; std::vector<int64_t> cnt;
+        KmerBlocksCount{*this}.call(kmers, keys, cnt);
+        std::string out;
+        DSBinaryKmerToString toString{*this};
+        for (size_t i = 0; i < cnt.size(); i++) {
+            out += toString.call(keys.data() + i * W);
+            out.push_back(',');
+            out += std::to_string(cnt[i]);
+            out.push_back('\n');
+        }
+        return out;
+    }
     std::vector<uint64_t> kmers = ReverseComplementKmerBinaryExtraction{*this}.call(bases, readOff);
     KmerBinaryRDD counts = KmerCounting_KmerCoverageFilter{*this}.call(kmers);
     std::string out;

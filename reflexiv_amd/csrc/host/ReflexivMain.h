@@ -63,6 +63,20 @@ public:
         ReflexivMain &m;
         KmerBinaryRDD call(const std::vector<uint64_t> &kmers) const;
     };
+    // ---- k > 31: P/ReflexivDataFrameCounter64.java (W = kmerBinarySlots words per k-mer)
+    struct ReverseComplementKmerBinaryExtractionFromDataset64 {   // :390-687
+        ReflexivMain &m;
+        std::vector<uint64_t> call(const std::vector<uint8_t> &bases, const std::vector<int64_t> &readOff) const;
+    };
+    struct KmerBlocksCount {                         // groupBy("kmerBlocks").count() + filters :191-205
+        ReflexivMain &m;
+        // kmers: W words per k-mer; -> rows (W words, count) ascending
+        void call(const std::vector<uint64_t> &kmers, std::vector<uint64_t> &keys, std::vector<int64_t> &counts) const;
+    };
+    struct DSBinaryKmerToString {                    // :335-384
+        ReflexivMain &m;
+        std::string call(const uint64_t *kmerBlocks) const;
+    };
     struct KmerReverseComplement_ForwardSubKmerExtraction {   // :2901-2931 + :2703-2731
         ReflexivMain &m;
         ReflexivSubKmerRDD call(const KmerBinaryRDD &in) const;

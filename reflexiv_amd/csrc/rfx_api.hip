@@ -193,6 +193,117 @@ int rfx_extract_canon(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_of
     return RFX_OK;
 }
 
+int rfx_extract_canon_w(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_off, int64_t n_reads, int k,
+                        int front_clip, int end_clip, uint64_t *out_kmers, int64_t cap, int64_t *out_n) {
+    if (!ctx || !read_off || !out_n || n_reads < 0) return RFX_E_ARG;
+    RFX_TRY(check_k_w(k));
+    if (front_clip < 0 || end_clip < 0) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    *out_n = 0;
+    if (n_reads == 0) return RFX_OK;
+    const int W = k / 32 + 1;
+    const int64_t nb = read_off[n_reads] - read_off[0];
+    int64_t maxlen = 0;
+    for (int64_t r = 0; r < n_reads; r++) maxlen = std::max(maxlen, read_off[r + 1] - read_off[r]);
+    const int wpr = (int)std::max<int64_t>(1, (maxlen + 31) / 32);
+    DevBuf d_bases, d_off, d_words, d_nk, d_koff, d_soa, d_out;
+    RFX_HIP(d_bases.alloc((size_t)nb, ctx->stream));
+    RFX_HIP(d_off.alloc((size_t)(n_reads + 1) * 8, ctx->stream));
+    RFX_HIP(d_words.alloc((size_t)n_reads * wpr * 8, ctx->stream));
+    RFX_HIP(d_nk.alloc((size_t)n_reads * 8, ctx->stream));
+    RFX_HIP(d_koff.alloc((size_t)(n_reads + 1) * 8, ctx->stream));
+    std::vector<int64_t> off((size_t)n_reads + 1);
+    for (int64_t r = 0; r <= n_reads; r++) off[(size_t)r] = read_off[r] - read_off[0];
+    if (nb > 0) RFX_HIP(hipMemcpyAsync(d_bases.p, bases + read_off[0], (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(d_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    RFX_TRY(encode_reads(ctx, d_bases.as<uint8_t>(), d_off.as<int64_t>(), n_reads, wpr, d_words.as<uint64_t>(), nullptr));
+    RFX_TRY(kmer_counts_per_read_w(ctx, d_off.as<int64_t>(), n_reads, k, front_clip, end_clip, d_nk.as<uint64_t>()));
+    RFX_TRY(exclusive_scan_u64(ctx, d_nk.as<uint64_t>(), d_koff.as<uint64_t>(), n_reads));
+    uint64_t total = 0;
+    RFX_HIP(hipMemcpyAsync(&total, d_koff.as<uint64_t>() + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    *out_n = (int64_t)total;
+    if ((int64_t)total > cap) return RFX_E_CAP;
+    if (total == 0) return RFX_OK;
+    if (!out_kmers) return RFX_E_ARG;
+    RFX_HIP(d_soa.alloc((size_t)total * W * 8, ctx->stream));
+    RFX_HIP(d_out.alloc((size_t)total * W * 8, ctx->stream));
+    RFX_TRY(extract_w(ctx, d_words.as<uint64_t>(), wpr, d_koff.as<uint64_t>(), 0, n_reads, k, front_clip,
+                      d_soa.as<uint64_t>(), (int64_t)total));
+    RFX_TRY(soa_to_aos(ctx, d_soa.as<uint64_t>(), (int64_t)total, W, d_out.as<uint64_t>()));
+    RFX_HIP(hipMemcpyAsync(out_kmers, d_out.p, (size_t)total * W * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    return RFX_OK;
+}
+
+int rfx_count_filter_w(rfx_ctx *ctx, const uint64_t *kmers, int64_t n, int k, int min_cov, int max_cov,
+                       uint64_t *out_keys, int64_t *out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct) {
+    if (!ctx || n < 0 || !out_n || (n > 0 && !kmers)) return RFX_E_ARG;
+    RFX_TRY(check_k_w(k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    *out_n = 0;
+    if (out_distinct) *out_distinct = 0;
+    if (n == 0) return RFX_OK;
+    const int W = k / 32 + 1;
+    DevBuf d_in, d_soa, d_keys, d_counts;
+    RFX_HIP(d_in.alloc((size_t)n * W * 8, ctx->stream));
+    RFX_HIP(d_soa.alloc((size_t)n * W * 8, ctx->stream));
+    RFX_HIP(d_keys.alloc((size_t)n * W * 8, ctx->stream));
+    RFX_HIP(d_counts.alloc((size_t)n * 8, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(d_in.p, kmers, (size_t)n * W * 8, hipMemcpyHostToDevice, ctx->stream));
+    RFX_TRY(aos_to_soa(ctx, d_in.as<uint64_t>(), n, W, d_soa.as<uint64_t>()));
+    int64_t m = 0, dist = 0;
+    RFX_TRY(count_filter_w(ctx, d_soa.as<uint64_t>(), n, k, min_cov, max_cov, d_keys.as<uint64_t>(), d_counts.as<int64_t>(),
+                           n, &m, &dist));
+    *out_n = m;
+    if (out_distinct) *out_distinct = dist;
+    if (m > cap) return RFX_E_CAP;
+    if (m > 0) {
+        if (!out_keys || !out_counts) return RFX_E_ARG;
+        RFX_HIP(hipMemcpyAsync(out_keys, d_keys.p, (size_t)m * W * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(out_counts, d_counts.p, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    return RFX_OK;
+}
+
+int64_t rfx_kmers_per_read_w(int read_len, int k, int front_clip, int end_clip) {
+    return kmers_per_read_w(read_len, k, front_clip, end_clip);
+}
+
+int rfx_dev_count_reads_w(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read, int read_len,
+                          int k, int front_clip, int end_clip, int min_cov, int max_cov, uint64_t *d_out_keys,
+                          int64_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct,
+                          int64_t *out_instances) {
+    if (!ctx || !out_n || n_reads < 0 || (n_reads > 0 && !d_words)) return RFX_E_ARG;
+    RFX_TRY(check_k_w(k));
+    if (front_clip < 0 || end_clip < 0 || words_per_read * 32 < read_len) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    *out_n = 0;
+    if (out_distinct) *out_distinct = 0;
+    const int W = k / 32 + 1;
+    ctx->timing.clear();
+    const int64_t nk = kmers_per_read_w(read_len, k, front_clip, end_clip);
+    const int64_t N = nk * n_reads;
+    if (out_instances) *out_instances = N;
+    if (N == 0) return RFX_OK;
+    DevBuf d_soa;
+    RFX_HIP(d_soa.alloc((size_t)N * W * 8, ctx->stream));
+    {
+        ScopedTimer t(ctx, "extract_w");
+        RFX_TRY(extract_w(ctx, d_words, words_per_read, nullptr, nk, n_reads, k, front_clip, d_soa.as<uint64_t>(), N));
+    }
+    int st;
+    {
+        ScopedTimer t(ctx, "count_w");
+        st = count_filter_w(ctx, d_soa.as<uint64_t>(), N, k, min_cov, max_cov, d_out_keys, d_out_counts, cap, out_n,
+                            out_distinct);
+    }
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    ScopedTimer::collect(ctx);
+    return st;
+}
+
 int rfx_count_filter(rfx_ctx *ctx, const uint64_t *kmers, int64_t n, int min_cov, int max_cov, int twin,
                      uint64_t *out_keys, int32_t *out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct) {
     if (!ctx || n < 0 || !out_n || (n > 0 && !kmers)) return RFX_E_ARG;

@@ -163,6 +163,18 @@ int synth_reads(rfx_ctx *ctx, uint64_t seed, const uint64_t *d_genome, int64_t g
                 int64_t first_read, int64_t n_reads, int read_len, uint32_t err, int words_per_read,
                 uint64_t *d_words);
 
+// ---- rfx_wide.hip : k > 31, W = k/32+1 words per k-mer (the counter's layout)
+int check_k_w(int k);
+int64_t kmers_per_read_w(int read_len, int k, int fc, int ec);
+int kmer_counts_per_read_w(rfx_ctx *ctx, const int64_t *d_read_off, int64_t n_reads, int k, int fc, int ec,
+                           uint64_t *d_nk);
+int extract_w(rfx_ctx *ctx, const uint64_t *d_words, int wpr, const uint64_t *d_kmer_off, int64_t nk_uniform,
+              int64_t n_reads, int k, int fc, uint64_t *d_soa, int64_t N);
+int aos_to_soa(rfx_ctx *ctx, const uint64_t *d_aos, int64_t n, int W, uint64_t *d_soa);
+int soa_to_aos(rfx_ctx *ctx, const uint64_t *d_soa, int64_t n, int W, uint64_t *d_aos);
+int count_filter_w(rfx_ctx *ctx, uint64_t *d_soa, int64_t N, int k, int min_cov, int max_cov, uint64_t *d_out_keys,
+                   int64_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct);
+
 // ---- rfx_graph.hip : device record set (reference layout, in HBM)
 struct DevRecords {
     int64_t n = 0, words = 0;

@@ -118,9 +118,29 @@ def planted():
     np.savez_compressed(os.path.join(HERE, "planted.npz"), **out)
 
 
+def wide():
+    """k > 31 (the counter's multi-word k-mers) on the example reads."""
+    ex = np.load(os.path.join(HERE, "example.npz"))
+    bases, off = ex["bases"], ex["read_off"]
+    out = {}
+    for k in (63, 47):
+        km = O.extract_canon_w(bases, off, k)
+        keys, counts, nd = O.count_filter_w(km, k, 3, 10_000_000)
+        out[f"k{k}_first4"] = O.extract_canon_w(bases[:off[4]], off[:5], k)
+        out[f"k{k}_n_instances"] = np.array(len(km)); out[f"k{k}_n_distinct"] = np.array(nd)
+        out[f"k{k}_keys_cov3"] = keys; out[f"k{k}_counts_cov3"] = counts
+        out[f"k{k}_text_first"] = np.array(O.kmer_text_w(keys[0], k))
+        print(f"wide k={k}: instances {len(km)} distinct {nd} kept {len(keys)}")
+    np.savez_compressed(os.path.join(HERE, "wide.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--wide-only" in sys.argv:
+        wide()
+        sys.exit(0)
     example()
     planted()
+    wide()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             p = os.path.join(HERE, f)

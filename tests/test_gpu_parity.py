@@ -593,3 +593,123 @@ def test_assemble_long_contigs_whole_grid_emit(rfx, torch_mod):
         otext, onc, otrace, _ = O.assemble_from_counts(wk, wc, O.default_params(min_cov=3, partitions=P, twin=twin))
         assert trace == otrace and nc == onc and text == otext
         assert max(int(h.split("-")[1]) for h in text.split("\n") if h.startswith(">")) > 31 * 8192
+
+
+# ------------------------------------------------------------------ k > 31
+
+def _ragged_reads(seed, n, lo, hi):
+    rng = np.random.default_rng(seed)
+    reads = ["".join(rng.choice(list("ACGTN"), size=int(rng.integers(lo, hi)), p=[.24, .24, .24, .24, .04]))
+             for _ in range(n)]
+    bases = np.frombuffer("".join(reads).encode(), np.uint8)
+    off = np.cumsum([0] + [len(r) for r in reads]).astype(np.int64)
+    return bases, off
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [33, 47, 63, 65, 95, 127])
+@pytest.mark.parametrize("clips", [(0, 0), (3, 5)])
+def test_wide_extraction_matches_oracle(rfx, k, clips):
+    """ReverseComplementKmerBinaryExtractionFromDataset64 on ragged reads with N, reads shorter than k, clips."""
+    bases, off = _ragged_reads(k, 300, 10, 260)
+    fc, ec = clips
+    want = O.extract_canon_w(bases, off, k, fc, ec)
+    got = rfx.ReverseComplementKmerBinaryExtractionFromDataset64(bases, off, k, fc, ec)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [33, 63, 95])
+def test_wide_count_filter_matches_oracle(rfx, k):
+    bases, off = _ragged_reads(100 + k, 400, 100, 200)
+    # repeat the reads so that counts > 1 occur, in a different order
+    bases2 = np.concatenate([bases, bases[:off[200]], bases])
+    off2 = np.concatenate([off, off[-1] + off[1:201], off[-1] + off[200] + off[1:]])
+    km = O.extract_canon_w(bases2, off2, k)
+    for min_cov, max_cov in ((1, 10_000_000), (2, 10_000_000), (3, 10_000_000), (1, 2)):
+        wk, wc, wd = O.count_filter_w(km, k, min_cov, max_cov)
+        gk, gc, gd = rfx.groupBy_count_filter_w(km, k, min_cov, max_cov)
+        assert gd == wd and np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    # empty input
+    gk, gc, gd = rfx.groupBy_count_filter_w(np.empty((0, k // 32 + 1), np.uint64), k, 1)
+    assert len(gk) == 0 and gd == 0
+
+
+@pytest.mark.gpu
+def test_wide_golden_example(rfx, ex, golden_dir):
+    gw = np.load(os.path.join(golden_dir, "wide.npz"))
+    bases, off = ex["bases"], ex["read_off"]
+    for k in (63, 47):
+        km = rfx.ReverseComplementKmerBinaryExtractionFromDataset64(bases, off, k)
+        assert len(km) == int(gw[f"k{k}_n_instances"])
+        assert np.array_equal(km[:len(gw[f"k{k}_first4"])], gw[f"k{k}_first4"])
+        keys, counts, nd = rfx.groupBy_count_filter_w(km, k, 3)
+        assert nd == int(gw[f"k{k}_n_distinct"])
+        assert np.array_equal(keys, gw[f"k{k}_keys_cov3"]) and np.array_equal(counts, gw[f"k{k}_counts_cov3"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_reads,L,k,min_cov", [(4000, 150, 63, 2), (20_000, 150, 63, 3), (5000, 100, 47, 1)])
+def test_wide_fused_count_from_packed_reads(rfx, torch_mod, n_reads, L, k, min_cov):
+    torch = torch_mod
+    seed, G = 31 + k, 30_000
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    W = k // 32 + 1
+    N = rfx.kmers_per_read_w(L, k) * n_reads
+    assert N == (L - k + 1) * n_reads
+    dk = torch.empty(N * W, dtype=torch.int64, device="cuda")
+    dc = torch.empty(N, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    m, nd, inst = rfx.count_reads_w_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, min_cov)
+    assert inst == N
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+    km = O.extract_canon_w(bases, off, k)
+    wk, wc, wd = O.count_filter_w(km, k, min_cov)
+    assert nd == wd and m == len(wk)
+    assert np.array_equal(dk[:m * W].cpu().numpy().view(np.uint64).reshape(m, W), wk)
+    assert np.array_equal(dc[:m].cpu().numpy(), wc)
+
+
+@pytest.mark.gpu
+def test_wide_count_properties_at_scale(rfx, torch_mod):
+    """k = 63 on 1 M reads (8.8e7 instances): counts sum to N, keys strictly ascending word-wise,
+    raising min_cov yields the subset with identical counts."""
+    torch = torch_mod
+    seed, G, n_reads, L, k = 63, 1_000_000, 1_000_000, 150, 63
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    N = rfx.kmers_per_read_w(L, k) * n_reads
+    cap = N // 2
+    dk = torch.empty(cap * 2, dtype=torch.int64, device="cuda")
+    dc = torch.empty(cap, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    m1, nd1, inst = rfx.count_reads_w_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), cap, 1)
+    assert inst == N and m1 == nd1
+    k1 = dk[:2 * m1].clone().view(m1, 2); c1 = dc[:m1].clone()
+    assert int(c1.sum()) == N
+    # unsigned word-wise order: compare through a bias flip of the sign bit
+    bias = torch.tensor(-(1 << 63), dtype=torch.int64, device="cuda")
+    a = k1 ^ bias
+    asc = (a[1:, 0] > a[:-1, 0]) | ((a[1:, 0] == a[:-1, 0]) & (a[1:, 1] > a[:-1, 1]))
+    assert bool(asc.all())
+    m3, nd3, _ = rfx.count_reads_w_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), cap, 3)
+    sel = c1 >= 3
+    assert nd3 == nd1 and m3 == int(sel.sum())
+    assert torch.equal(dk[:2 * m3].view(m3, 2), k1[sel]) and torch.equal(dc[:m3], c1[sel])
+
+
+@pytest.mark.gpu
+def test_cpp_host_counter_k63(tmp_path, ex, golden_dir):
+    """`counter -kmer 63`: the C++ mirror of ReflexivDataFrameCounter64.assembly() (extraction,
+    groupBy/count/filter, DSBinaryKmerToString) writes the rows the oracle predicts."""
+    import subprocess
+    import reflexiv_amd._lib as L
+    host = os.path.join(os.path.dirname(L.LIB_PATH), "reflexiv_host")
+    gw = np.load(os.path.join(golden_dir, "wide.npz"))
+    fq = str(tmp_path / "ex.fq")
+    write_fastq(fq, ex["bases"], ex["read_off"])
+    out = str(tmp_path / "cnt")
+    subprocess.check_call([host, "counter", "-fastq", fq, "-outfile", out, "-kmer", "63", "-cover", "3"])
+    lines = open(os.path.join(out, "Count_63", "part-00000.csv")).read().split("\n")[:-1]
+    want = [O.kmer_text_w(k, 63) + "," + str(int(c)) for k, c in zip(gw["k63_keys_cov3"], gw["k63_counts_cov3"])]
+    assert lines == want

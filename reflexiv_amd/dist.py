@@ -138,3 +138,229 @@ def gather_survivors(keys: torch.Tensor, counts: torch.Tensor, group=None, root:
         return None, None
     return (torch.cat([gk[r][:sizes[r]] for r in range(world)]),
             torch.cat([gc[r][:sizes[r]] for r in range(world)]))
+
+
+# ----------------------------------------------------------------------------------------------
+# Range-sharded extend stage: every sort of the reference's loop
+# (sortByKey, P/ReflexivMain.java:179,191,211,235,247,286) becomes
+#   local stable sort -> exact splitters at the LOGICAL partition boundaries (order contract B.0:
+#   floor(p*n/P) moved forward past equal keys) by a bitwise distributed selection (one small
+#   all-reduce per key bit) -> ONE all-to-all(v) of whole records -> local stable sort.
+# Rank r owns the logical partitions [r*P/W, (r+1)*P/W): equal keys never straddle ranks, every
+# per-partition operator (fork filters, random reflection, extend pass) runs locally with its own
+# partition starts, and the result does not depend on the number of ranks.  Records travel as the
+# flat arrays of the reference layout; ties keep (source rank, local position) order, which is the
+# global arrival order because ranks hold consecutive partitions.
+#
+# The local operators come from an `ops` object: `HipOps` (the C ABI operators of
+# libreflexiv_hip.so) or, in the CPU test-suite only, a stand-in injected by the test.
+
+import numpy as np
+
+
+class HipOps:
+    """The per-operator C ABI (include/reflexiv_hip.h) behind the names the sharded driver uses."""
+
+    def __init__(self, rfx):
+        self.rfx = rfx
+
+    def make(self, key, marker, ext_off, ext, left, right):
+        from .api import Records
+        return Records(np.ascontiguousarray(key, np.uint64), np.ascontiguousarray(marker, np.int32),
+                       np.ascontiguousarray(ext_off, np.int64), np.ascontiguousarray(ext, np.uint64),
+                       np.ascontiguousarray(left, np.int32), np.ascontiguousarray(right, np.int32))
+
+    def sort_pairs(self, keys, counts):
+        import torch as _t
+        dk = _t.from_numpy(keys.view(np.int64)).cuda(); dc = _t.from_numpy(counts.astype(np.int32)).cuda()
+        tk, tc = _t.empty_like(dk), _t.empty_like(dc)
+        _t.cuda.synchronize()
+        self.rfx.sort_pairs_dev(dk.data_ptr(), dc.data_ptr(), int(dk.numel()), 64, tk.data_ptr(), tc.data_ptr())
+        self.rfx.sync()
+        return dk.cpu().numpy().view(np.uint64), dc.cpu().numpy()
+
+    def rc_expand(self, keys, counts, k):
+        return self.rfx.KmerReverseComplement_and_ForwardSubKmerExtraction(keys, counts, k)
+
+    def sort(self, r):
+        return self.rfx.sortByKey(r, 1)[0]
+
+    def fork_forward(self, r, ps, k, min_err, twin):
+        return self.rfx.FilterForkSubKmer(r, ps, k, min_err, twin)
+
+    def reflect(self, r, k):
+        return self.rfx.ReflectedSubKmerExtractionFromForward(r, k)
+
+    def fork_reflected(self, r, ps, k, min_err, twin):
+        return self.rfx.FilterForkReflectedSubKmer(r, ps, k, min_err, twin)
+
+    def random_reflection(self, r, ps, k):
+        return self.rfx.kmerRandomReflection(r, ps, k)
+
+    def extend_pass(self, r, ps, k, twin, stage):
+        return self.rfx.ExtendReflexivKmer(r, ps, k, twin, stage)
+
+    def contigs_text(self, r, k, min_contig, twin):
+        return self.rfx.KmerToContig(r, k, min_contig, twin)
+
+
+def _coll_device():
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def _allreduce_i64(a: np.ndarray, group=None) -> np.ndarray:
+    t = torch.from_numpy(np.ascontiguousarray(a, np.int64)).to(_coll_device())
+    dist.all_reduce(t, group=group)
+    return t.cpu().numpy()
+
+
+def _alltoall_var(chunks, dtype, group=None):
+    """chunks[d] = 1-D numpy array for rank d -> list of what every rank sent here (in rank order)."""
+    world = dist.get_world_size(group)
+    dev = _coll_device()
+    sc = torch.tensor([len(c) for c in chunks], dtype=torch.int64, device=dev)
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc, group=group)
+    rcl = [int(x) for x in rc.cpu()]
+    send = np.concatenate(chunks) if world else np.empty(0, dtype)
+    st = torch.from_numpy(np.ascontiguousarray(send).view(np.int64 if send.dtype.itemsize == 8 else np.int32)).to(dev)
+    rt = torch.empty(sum(rcl), dtype=st.dtype, device=dev)
+    dist.all_to_all_single(rt, st, output_split_sizes=rcl, input_split_sizes=[len(c) for c in chunks], group=group)
+    out = rt.cpu().numpy().view(dtype)
+    cuts = np.cumsum([0] + rcl)
+    return [out[cuts[i]:cuts[i + 1]] for i in range(world)]
+
+
+def splitters(sorted_keys: np.ndarray, P: int, key_bits: int, group=None):
+    """Boundary of every logical partition p = 1..P-1 over the GLOBAL sorted order of all ranks' keys:
+    (v[p-1], incl[p-1]) -- partition p starts at the first key >= v (incl) or > v (the run of v began
+    before floor(p*n/P) and is not split).  Exact; key_bits + 2 all-reduces of P-1 integers."""
+    n_glob = int(_allreduce_i64(np.array([len(sorted_keys)]), group)[0])
+    q = np.array([(p * n_glob) // P for p in range(1, P)], np.int64)
+    v = np.zeros(P - 1, np.uint64)
+    if n_glob == 0 or P == 1:
+        return v, np.ones(P - 1, bool), n_glob
+    for bit in range(key_bits - 1, -1, -1):
+        t = v | np.uint64(1 << bit)
+        c = _allreduce_i64(np.searchsorted(sorted_keys, t, side="left"), group)
+        v = np.where(c <= q, t, v)           # largest v with count(keys < v) <= q  ==  key at global rank q
+    c_lt = _allreduce_i64(np.searchsorted(sorted_keys, v, side="left"), group)
+    return v, c_lt == q, n_glob
+
+
+def _local_bounds(sorted_keys, v, incl):
+    """index in the local sorted keys where each partition p = 1..P-1 starts"""
+    lo = np.searchsorted(sorted_keys, v, side="left")
+    hi = np.searchsorted(sorted_keys, v, side="right")
+    return np.where(incl, lo, hi).astype(np.int64)
+
+
+def sort_exchange(ops, r, P: int, key_bits: int, group=None):
+    """Global stable sort by key of the ranks' record sets (in rank-major arrival order) ->
+    (this rank's logical partitions, sorted; their local partition starts [P/W + 1])."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    assert P % world == 0, "the logical partition count must be a multiple of the number of ranks"
+    per = P // world
+    r = ops.sort(r)
+    if world == 1:
+        if P == 1:
+            return r, np.array([0, r.n], np.int64)
+        v, incl, _ = _splitters_local(r.key, P)
+        return r, np.concatenate([[0], _local_bounds(r.key, v, incl), [r.n]]).astype(np.int64)
+    v, incl, _ = splitters(r.key, P, key_bits, group)
+    b = np.concatenate([[0], _local_bounds(r.key, v, incl), [r.n]]).astype(np.int64)     # partition p = [b[p], b[p+1])
+    rcut = b[::per]                                                                        # rank d = [rcut[d], rcut[d+1])
+    wcut = r.ext_off[rcut]
+    lens = (r.ext_off[1:] - r.ext_off[:-1]).astype(np.int64)
+    parts = {}
+    for name, arr, cut, dt in (("key", r.key, rcut, np.uint64), ("marker", r.marker, rcut, np.int32),
+                               ("len", lens, rcut, np.int64), ("ext", r.ext, wcut, np.uint64),
+                               ("left", r.left, rcut, np.int32), ("right", r.right, rcut, np.int32)):
+        got = _alltoall_var([arr[cut[d]:cut[d + 1]] for d in range(world)], dt, group)
+        parts[name] = np.concatenate(got) if got else np.empty(0, dt)
+    ext_off = np.concatenate([[0], np.cumsum(parts["len"])]).astype(np.int64)
+    merged = ops.sort(ops.make(parts["key"], parts["marker"], ext_off, parts["ext"], parts["left"], parts["right"]))
+    p0 = rank * per
+    lb = _local_bounds(merged.key, v, incl)                                                # all P-1 boundaries, local indices
+    full = np.concatenate([[0], lb, [merged.n]]).astype(np.int64)
+    ps = full[p0:p0 + per + 1].copy()
+    ps[0], ps[-1] = 0, merged.n
+    return merged, ps
+
+
+def _splitters_local(sorted_keys, P):
+    n = len(sorted_keys)
+    q = np.array([(p * n) // P for p in range(1, P)], np.int64)
+    if n == 0:
+        return np.zeros(P - 1, np.uint64), np.ones(P - 1, bool), 0
+    v = sorted_keys[q]
+    return v, np.searchsorted(sorted_keys, v, side="left") == q, n
+
+
+def sharded_assemble(ops, keys: np.ndarray, counts: np.ndarray, prm, group=None, root: int = 0, trace=None):
+    """Extend stage on range-sharded records.  keys/counts: this rank's shard of the filtered
+    (k-mer, count) list in any order (e.g. the hash shard sharded_count() leaves).  Returns
+    (contig text, n_contigs) on `root`, (None, None) elsewhere; identical to the single-GPU driver
+    for the same prm.partitions (P/ReflexivMain.java:168-316)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    k, twin, P = prm.k, prm.twin, max(1, prm.partitions)
+    keys = np.ascontiguousarray(keys, np.uint64); counts = np.ascontiguousarray(counts, np.int32)
+    # the count stage's order contract: ascending canonical k-mer -> range-shard the survivors first
+    if world > 1:
+        keys, counts = ops.sort_pairs(keys, counts)
+        v, incl, _ = splitters(keys, world, 2 * k, group)
+        cut = np.concatenate([[0], _local_bounds(keys, v, incl), [len(keys)]]).astype(np.int64)
+        gk = _alltoall_var([keys[cut[d]:cut[d + 1]] for d in range(world)], np.uint64, group)
+        gc = _alltoall_var([counts[cut[d]:cut[d + 1]] for d in range(world)], np.int32, group)
+        keys, counts = ops.sort_pairs(np.concatenate(gk), np.concatenate(gc))
+    else:
+        keys, counts = ops.sort_pairs(keys, counts)
+    kb = 2 * (k - 1)
+    r = ops.rc_expand(keys, counts, k)
+    r, ps = sort_exchange(ops, r, P, kb, group)
+    r, ps = ops.fork_forward(r, ps, k, prm.min_error_cov, twin)
+    r = ops.reflect(r, k)
+    r, ps = sort_exchange(ops, r, P, kb, group)
+    r, ps = ops.fork_reflected(r, ps, k, prm.min_error_cov, twin)
+    r = ops.random_reflection(r, ps, k)
+
+    def count(rr):
+        return int(_allreduce_i64(np.array([rr.n]), group)[0]) if world > 1 else rr.n
+
+    def one_pass(rr, stage):
+        rr, pst = sort_exchange(ops, rr, P, kb, group)
+        rr, _ = ops.extend_pass(rr, pst, k, twin, stage)
+        if trace is not None:
+            trace.append(count(rr))
+        return rr
+    r = one_pass(r, 0)
+    it = 0
+    for _ in range(3):
+        it += 1
+        r = one_pass(r, 0)
+    it += 1
+    r = one_pass(r, 1)
+    last = 0
+    while it <= prm.max_iter:
+        it += 1
+        if it >= prm.min_iter and it % 3 == 0:
+            c = count(r)
+            if c == last:
+                break
+            last = c
+        r = one_pass(r, 2)
+    # the surviving records are few: contig ids follow the global record order, so the text is made on root
+    if world > 1:
+        lens = (r.ext_off[1:] - r.ext_off[:-1]).astype(np.int64)
+        fields = {}
+        for name, arr, dt in (("key", r.key, np.uint64), ("marker", r.marker, np.int32), ("len", lens, np.int64),
+                              ("ext", r.ext, np.uint64), ("left", r.left, np.int32), ("right", r.right, np.int32)):
+            got = _alltoall_var([arr if d == root else arr[:0] for d in range(world)], dt, group)
+            fields[name] = np.concatenate(got)
+        if rank != root:
+            return None, None
+        off = np.concatenate([[0], np.cumsum(fields["len"])]).astype(np.int64)
+        r = ops.make(fields["key"], fields["marker"], off, fields["ext"], fields["left"], fields["right"])
+    return ops.contigs_text(r, k, prm.min_contig, twin)

@@ -114,3 +114,105 @@ def test_owner_function_is_balanced_and_total():
         assert own.min() >= 0 and own.max() == n - 1
         cnt = np.bincount(own, minlength=n)
         assert cnt.min() > 0.9 * len(km) / n
+
+
+# ------------------------------------------------------------------ range-sharded extend stage
+
+class OracleOps:
+    """CPU stand-in for reflexiv_amd.dist.HipOps (tests only): the oracle's operators."""
+
+    def make(self, key, marker, ext_off, ext, left, right):
+        return O.Records(np.ascontiguousarray(key, np.uint64), np.ascontiguousarray(marker, np.int32),
+                         np.ascontiguousarray(ext_off, np.int64), np.ascontiguousarray(ext, np.uint64),
+                         np.ascontiguousarray(left, np.int32), np.ascontiguousarray(right, np.int32))
+
+    def sort_pairs(self, keys, counts):
+        o = np.argsort(keys, kind="stable")
+        return keys[o], counts[o]
+
+    def rc_expand(self, keys, counts, k):
+        return O.rc_expand_subkmer(keys, counts, k)
+
+    def sort(self, r):
+        return O.sort_records(r)
+
+    def fork_forward(self, r, ps, k, min_err, twin):
+        return O.fork_filter_forward(r, ps, k, min_err, twin)
+
+    def reflect(self, r, k):
+        return O.reflect_from_forward(r, k)
+
+    def fork_reflected(self, r, ps, k, min_err, twin):
+        return O.fork_filter_reflected(r, ps, k, min_err, twin)
+
+    def random_reflection(self, r, ps, k):
+        return O.random_reflection(r, ps, k)
+
+    def extend_pass(self, r, ps, k, twin, stage):
+        return O.extend_pass(r, ps, k, twin)
+
+    def contigs_text(self, r, k, min_contig, twin):
+        return O.contigs_text(r, k, min_contig, twin)
+
+
+def _asm_worker(rank, world, port, keys, counts, prm_kw, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from reflexiv_amd import dist as rd
+        mine = owner_of(keys, world) == rank                     # the hash shard the count stage leaves on this rank
+        prm = O.default_params(**prm_kw)
+        trace = []
+        text, nc = rd.sharded_assemble(OracleOps(), keys[mine], counts[mine], prm, trace=trace)
+        if rank == 0:
+            q.put((text, nc, trace))
+        else:
+            assert text is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_sharded_assemble(world, keys, counts, prm_kw):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_asm_worker, args=(r, world, port, keys, counts, prm_kw, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("world,P,twin", [(2, 4, "ds"), (2, 4, "rdd"), (4, 4, "ds"), (2, 8, "ds")])
+def test_sharded_extend_reproduces_the_example(golden_dir, world, P, twin):
+    """Range-sharded extend stage on 2 / 4 ranks == the single-process driver for the same logical
+    partition count (documented example: two contigs of 4558 bp at P = 4)."""
+    ex = np.load(os.path.join(golden_dir, "example.npz"))
+    tw = O.TWIN_DS if twin == "ds" else O.TWIN_RDD
+    text, nc, trace = _run_sharded_assemble(world, ex["keys_cov3"], ex["counts_cov3"],
+                                            dict(min_cov=3, partitions=P, twin=tw))
+    assert text == str(ex[f"contigs_{twin}_P{P}"])
+    assert trace == [int(x) for x in ex[f"trace_{twin}_P{P}"]]
+
+
+def test_sharded_extend_with_bubbles_and_repeat(golden_dir):
+    """planted fixture (SNP bubble + repeat: fork-marked records, left/right >= 0 branches)."""
+    pl = np.load(os.path.join(golden_dir, "planted.npz"))
+    text, nc, trace = _run_sharded_assemble(2, pl["k31_keys"], pl["k31_counts"],
+                                            dict(k=31, min_cov=2, partitions=4, twin=O.TWIN_DS, min_contig=100))
+    assert text == str(pl["k31_ds_contigs"])
+    assert trace == [int(x) for x in pl["k31_ds_trace"]]
+
+
+def test_sharded_extend_world1_without_process_group(golden_dir):
+    from reflexiv_amd import dist as rd
+    ex = np.load(os.path.join(golden_dir, "example.npz"))
+    prm = O.default_params(min_cov=3, partitions=4, twin=O.TWIN_DS)
+    rng = np.random.default_rng(3)
+    o = rng.permutation(len(ex["keys_cov3"]))                   # any input order
+    text, nc = rd.sharded_assemble(OracleOps(), ex["keys_cov3"][o], ex["counts_cov3"][o], prm)
+    assert text == str(ex["contigs_ds_P4"])

@@ -713,3 +713,23 @@ def test_cpp_host_counter_k63(tmp_path, ex, golden_dir):
     lines = open(os.path.join(out, "Count_63", "part-00000.csv")).read().split("\n")[:-1]
     want = [O.kmer_text_w(k, 63) + "," + str(int(c)) for k, c in zip(gw["k63_keys_cov3"], gw["k63_counts_cov3"])]
     assert lines == want
+
+
+@pytest.mark.gpu
+def test_sharded_extend_hip_ops_world1(rfx, ex, planted):
+    """reflexiv_amd.dist.sharded_assemble with the C ABI operators (HipOps) on one GPU: the same
+    driver the multi-GPU path runs per rank, checked against the golden contigs."""
+    from reflexiv_amd import dist as rd
+    import reflexiv_amd
+    ops = rd.HipOps(rfx)
+    rng = np.random.default_rng(9)
+    o = rng.permutation(len(ex["keys_cov3"]))
+    for P, twin, tn in ((4, O.TWIN_DS, "ds"), (8, O.TWIN_RDD, "rdd")):
+        prm = reflexiv_amd.default_params(min_cov=3, partitions=P, twin=twin)
+        trace = []
+        text, nc = rd.sharded_assemble(ops, ex["keys_cov3"][o], ex["counts_cov3"][o], prm, trace=trace)
+        assert text == str(ex[f"contigs_{tn}_P{P}"])
+        assert trace == [int(x) for x in ex[f"trace_{tn}_P{P}"]]
+    prm = reflexiv_amd.default_params(k=31, min_cov=2, partitions=4, twin=O.TWIN_DS, min_contig=100)
+    text, nc = rd.sharded_assemble(ops, planted["k31_keys"], planted["k31_counts"], prm)
+    assert text == str(planted["k31_ds_contigs"])

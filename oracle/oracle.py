@@ -48,6 +48,7 @@ def lib():
         _LIB = C.CDLL(build())
         L = _LIB
         L.orc_fastq_group.restype = C.c_int64
+        L.orc_fastq_only_seq.restype = C.c_int64
         L.orc_extract_canon.restype = C.c_int64
         L.orc_count_filter.restype = C.c_int64
         L.orc_extract_canon_w.restype = C.c_int64
@@ -114,6 +115,16 @@ def fastq_group(text: bytes):
     off = np.empty(n, np.int64)
     ln = np.empty(n, np.int32)
     lib().orc_fastq_group(_p(buf), C.c_int64(len(text)), _p(off), _p(ln), C.c_int64(n))
+    return off, ln
+
+
+def fastq_only_seq(text: bytes):
+    """DSFastqFilterOnlySeq (P/ReflexivDataFrameCounter.java:238-290) -> (seq_off, seq_len)."""
+    buf = np.frombuffer(text, dtype=np.uint8)
+    n = lib().orc_fastq_only_seq(_p(buf), C.c_int64(len(text)), None, None, C.c_int64(0))
+    off = np.empty(n, np.int64)
+    ln = np.empty(n, np.int32)
+    lib().orc_fastq_only_seq(_p(buf), C.c_int64(len(text)), _p(off), _p(ln), C.c_int64(n))
     return off, ln
 
 

@@ -82,6 +82,27 @@ int64_t orc_fastq_group(const char *text, int64_t len,
     return n;
 }
 
+static int check_seq(char a) { return a == 'A' || a == 'T' || a == 'C' || a == 'G' || a == 'N'; }   /* :268-289 */
+
+int64_t orc_fastq_only_seq(const char *text, int64_t len,
+                           int64_t *seq_off, int32_t *seq_len, int64_t cap) {
+    int64_t n = 0, pos = 0;
+    while (pos < len) {
+        int64_t e = pos;
+        while (e < len && text[e] != '\n') e++;
+        int64_t l = e - pos;
+        if (l > 0 && text[e - 1] == '\r') l--;
+        const char *s = text + pos;
+        if (l > 20 && s[0] != '@' && s[0] != '+' &&                              /* :245-250 */
+            check_seq(s[0]) && check_seq(s[4]) && check_seq(s[9]) && check_seq(s[14]) && check_seq(s[19])) {
+            if (n < cap) { seq_off[n] = pos; seq_len[n] = (int32_t)l; }
+            n++;
+        }
+        pos = e + 1;
+    }
+    return n;
+}
+
 /* -------------------------------------------------------------- a-2 extract */
 
 int64_t orc_extract_canon(const char *bases, const int64_t *read_off, int64_t n_reads,

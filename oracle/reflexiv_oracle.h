@@ -57,6 +57,13 @@ void orc_default_params(orc_params *p);
 int64_t orc_fastq_group(const char *text, int64_t len,
                         int64_t *seq_off, int32_t *seq_len, int64_t cap);
 
+/* DSFastqFilterOnlySeq.call  P/ReflexivDataFrameCounter.java:238-290 (the counter's line filter,
+ * same in ReflexivDataFrameCounter64.java:236-288): keeps every line longer than 20 characters
+ * that starts with neither '@' nor '+' and has one of A T C G N at positions 0, 4, 9, 14, 19
+ * (so a quality line that happens to pass is kept too).  Same output convention as above. */
+int64_t orc_fastq_only_seq(const char *text, int64_t len,
+                           int64_t *seq_off, int32_t *seq_len, int64_t cap);
+
 /* a-2  ReverseComplementKmerBinaryExtraction.call  P/ReflexivMain.java:3013-3075.
  * Reads are ASCII, read i = bases[read_off[i] .. read_off[i+1]).  Returns the
  * number of canonical k-mers (written to out if it fits in cap). */

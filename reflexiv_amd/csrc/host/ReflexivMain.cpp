@@ -56,6 +56,26 @@ void ReflexivMain::FastqFilterWithQual::call(const std::string &text, std::vecto
     }
 }
 
+void ReflexivMain::DSFastqFilterOnlySeq::call(const std::string &text, std::vector<uint8_t> &bases,
+                                              std::vector<int64_t> &readOff) const {
+    auto checkSeq = [](char a) { return a == 'A' || a == 'T' || a == 'C' || a == 'G' || a == 'N'; };   // :268-289
+    size_t pos = 0;
+    bases.clear(); readOff.assign(1, 0);
+    while (pos < text.size()) {
+        size_t e = text.find('\n', pos);
+        if (e == std::string::npos) e = text.size();
+        size_t l = e - pos;
+        if (l > 0 && text[e - 1] == '\r') l--;
+        const char *s = text.data() + pos;
+        if (l > 20 && s[0] != '@' && s[0] != '+' && checkSeq(s[0]) && checkSeq(s[4]) && checkSeq(s[9]) &&
+            checkSeq(s[14]) && checkSeq(s[19])) {                      // :245-262
+            bases.insert(bases.end(), text.begin() + pos, text.begin() + pos + l);
+            readOff.push_back((int64_t)bases.size());
+        }
+        pos = e + 1;
+    }
+}
+
 std::vector<uint64_t> ReflexivMain::ReverseComplementKmerBinaryExtraction::call(
     const std::vector<uint8_t> &bases, const std::vector<int64_t> &readOff) const {
     int64_t n = 0;
@@ -303,7 +323,7 @@ std::string ReflexivMain::assemblyFromKmer(const std::string &csvText, std::vect
 std::string ReflexivMain::counter(const std::string &fastqText) {
     static const char NUC[4] = {'A', 'C', 'G', 'T'};
     std::vector<uint8_t> bases; std::vector<int64_t> readOff;
-    FastqFilterWithQual{*this}.call(fastqText, bases, readOff);
+    DSFastqFilterOnlySeq{*this}.call(fastqText, bases, readOff);      // P/ReflexivDataFrameCounter.java:170-173
     if (param.kmerSize > 31) {                       // P/ReflexivDataFrameCounter64.java:133-232
         const int W = param.kmerSize / 32 + 1;
         std::vector<uint64_t> kmers = ReverseComplementKmerBinaryExtractionFromDataset64{*this}.call(bases, readOff);

@@ -55,6 +55,10 @@ public:
         // text -> concatenated sequence lines + offsets
         void call(const std::string &text, std::vector<uint8_t> &bases, std::vector<int64_t> &readOff) const;
     };
+    struct DSFastqFilterOnlySeq {           // P/ReflexivDataFrameCounter.java:238-290 (the counter's line filter)
+        ReflexivMain &m;
+        void call(const std::string &text, std::vector<uint8_t> &bases, std::vector<int64_t> &readOff) const;
+    };
     struct ReverseComplementKmerBinaryExtraction {   // :3002-3075
         ReflexivMain &m;
         std::vector<uint64_t> call(const std::vector<uint8_t> &bases, const std::vector<int64_t> &readOff) const;

@@ -733,3 +733,38 @@ def test_sharded_extend_hip_ops_world1(rfx, ex, planted):
     prm = reflexiv_amd.default_params(k=31, min_cov=2, partitions=4, twin=O.TWIN_DS, min_contig=100)
     text, nc = rd.sharded_assemble(ops, planted["k31_keys"], planted["k31_counts"], prm)
     assert text == str(planted["k31_ds_contigs"])
+
+
+@pytest.mark.gpu
+def test_cpp_host_counter_uses_the_counters_line_filter(tmp_path):
+    """`counter` reads lines through DSFastqFilterOnlySeq (P/ReflexivDataFrameCounter.java:238-290), not
+    through the assembler's 4-line grouping: a quality line that looks like sequence is counted, reads of
+    <= 20 bases and lower-case reads are not."""
+    import subprocess
+    import reflexiv_amd._lib as L
+    host = os.path.join(os.path.dirname(L.LIB_PATH), "reflexiv_host")
+    rng = np.random.default_rng(4)
+    recs = []
+    for i in range(200):
+        seq = "".join(rng.choice(list("ACGT"), size=int(rng.integers(15, 80))))
+        qual = "".join(rng.choice(list("ACGTNI5"), size=len(seq)))        # some quality lines pass the filter
+        if i % 17 == 0:
+            seq = seq.lower()
+        recs.append(f"@r{i}\n{seq}\n+\n{qual}\n")
+    text = "".join(recs).encode()
+    fq = tmp_path / "odd.fq"
+    fq.write_bytes(text)
+    out = str(tmp_path / "cnt")
+    k = 21
+    subprocess.check_call([host, "counter", "-fastq", str(fq), "-outfile", out, "-kmer", str(k), "-cover", "1"])
+    lines = open(os.path.join(out, f"Count_{k}", "part-00000.csv")).read().split("\n")[:-1]
+    off, ln = O.fastq_only_seq(text)
+    tb = np.frombuffer(text, np.uint8)
+    bases = np.concatenate([tb[o:o + l] for o, l in zip(off, ln)])
+    roff = np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
+    assert len(off) > 200 * 0.5 and len(off) != len(O.fastq_group(text)[0])      # the two filters differ here
+    keys, counts, _ = O.count_filter(O.extract_canon(bases, roff, k), 1)
+    nuc = "ACGT"
+    want = ["".join(nuc[(int(x) >> (2 * (k - 1 - j))) & 3] for j in range(k)) + "," + str(int(c))
+            for x, c in zip(keys, counts)]
+    assert lines == want

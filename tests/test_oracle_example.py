@@ -199,3 +199,26 @@ def test_synth_generator_is_deterministic_and_strand_balanced():
     clean, _ = O.synth_reads(7, g, 4096, 0, 200, 150, err_per_2_32=0)
     diff = (a != clean).mean()
     assert 0.001 < diff < 0.012                           # ~0.5 % substitutions
+
+
+def test_counter_line_filter_only_seq():
+    """DSFastqFilterOnlySeq (P/ReflexivDataFrameCounter.java:238-290): a line survives iff it is longer
+    than 20, starts with neither '@' nor '+', and shows A/T/C/G/N at positions 0, 4, 9, 14, 19 --
+    a quality line that passes is kept, a lower-case or short read is dropped."""
+    lines = [b"@r1", b"ACGTACGTACGTACGTACGTACGT", b"+", b"IIIIIIIIIIIIIIIIIIIIIIII",       # plain record
+             b"@r2", b"ACGTACGTACGTACGTACGT", b"+", b"IIIIIIIIIIIIIIIIIIII",               # 20 bases: too short
+             b"@r3", b"acgtacgtacgtacgtacgtacgt", b"+", b"AIIIAIIIICIIIIGIIIITIIII",       # lower case dropped; quality passes!
+             b"@r4", b"NCGTNCGTANGTACNTACGNACGTAC", b"+r4", b"@IIIIIIIIIIIIIIIIIIIIIIIII",  # N allowed; '@' quality dropped
+             b"ACGTACGTACGTACGTACGXACGT"]                                                   # X at position 19
+    text = b"\n".join(lines) + b"\n"
+    off, ln = O.fastq_only_seq(text)
+    got = [text[o:o + l] for o, l in zip(off, ln)]
+    assert got == [lines[1], lines[11], lines[13]]
+    # on the example reads both filters agree (2300 reads)
+    import gzip
+    for f in ("/root/reference/example/paired_dat1.fq.gz",):
+        if os.path.exists(f):
+            t = gzip.open(f, "rb").read()
+            o1, l1 = O.fastq_only_seq(t)
+            o2, l2 = O.fastq_group(t)
+            assert np.array_equal(o1, o2) and np.array_equal(l1, l2)

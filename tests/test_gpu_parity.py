@@ -768,3 +768,39 @@ def test_cpp_host_counter_uses_the_counters_line_filter(tmp_path):
     want = ["".join(nuc[(int(x) >> (2 * (k - 1 - j))) & 3] for j in range(k)) + "," + str(int(c))
             for x, c in zip(keys, counts)]
     assert lines == want
+
+
+def _count_ascii_reads_dev(rfx, torch, reads, L, k, min_cov):
+    """uniform-length ASCII reads -> rfx_dev_encode_reads -> fused device count (the ingest path)."""
+    n = len(reads)
+    bases = np.frombuffer("".join(reads).encode(), np.uint8)
+    off = (np.arange(n + 1, dtype=np.int64) * L)
+    wpr = (L + 31) // 32
+    db = torch.from_numpy(bases.copy()).cuda(); do = torch.from_numpy(off).cuda()
+    dw = torch.empty(n * wpr, dtype=torch.int64, device="cuda")
+    N = rfx.kmers_per_read(L, k) * n
+    dk = torch.empty(max(N, 1), dtype=torch.int64, device="cuda"); dc = torch.empty(max(N, 1), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    rfx.encode_reads_dev(db.data_ptr(), do.data_ptr(), n, wpr, dw.data_ptr())
+    m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, min_cov)
+    return bases, off, dk[:m].cpu().numpy().view(np.uint64), dc[:m].cpu().numpy(), nd, inst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [31, 21])
+def test_count_survives_extreme_skew(rfx, torch_mod, k):
+    """Low-complexity input: every read poly-A / a dinucleotide repeat / one repeated read -- one
+    minimiser bucket and one leaf receive (almost) everything, one k-mer occurs millions of times.
+    Bucket sizes are exact, so only balance may suffer; the counts must still be the oracle's."""
+    L = 150
+    rng = np.random.default_rng(k)
+    one = "".join(rng.choice(list("ACGT"), size=L))
+    reads = ["A" * L] * 12000 + ["AC" * (L // 2)] * 6000 + [one] * 5000 + ["T" * L] * 3000 + \
+            ["".join(rng.choice(list("ACGT"), size=L)) for _ in range(2000)] + ["N" * L] * 10
+    rng.shuffle(reads)
+    bases, off, gk, gc, nd, inst = _count_ascii_reads_dev(rfx, torch_mod, reads, L, k, 2)
+    km = O.extract_canon(bases, off, k)
+    assert inst == len(km)
+    wk, wc, wd = O.count_filter(km, 2)
+    assert nd == wd and np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    assert int(gc.max()) >= 15000 * (L - k + 1)                      # poly-A and poly-T (and N) are one canonical k-mer

@@ -491,7 +491,9 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
 
 template <bool RECS>
 __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>::T *__restrict__ keys,
-                                                   const uint64_t *__restrict__ leaf_off, int64_t nleaf, int k,
+                                                   const uint64_t *__restrict__ leaf_off, int64_t nleaf,
+                                                   const uint64_t *__restrict__ sl_begin, const uint64_t *__restrict__ sl_end,
+                                                   uint64_t heavy, uint64_t n_elems, int k,
                                                    int min_cov, int max_cov, int apply_filter,
                                                    uint64_t *__restrict__ out_keys, int32_t *__restrict__ out_counts,
                                                    unsigned long long cap, CountOut *__restrict__ co, int dbg) {
@@ -513,7 +515,16 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
     const int64_t l0 = (int64_t)(((unsigned long long)blockIdx.x * (unsigned long long)nleaf) / gridDim.x);
     const int64_t l1 = (int64_t)(((unsigned long long)(blockIdx.x + 1) * (unsigned long long)nleaf) / gridDim.x);
     if (l0 >= l1) return;
-    const uint64_t stream_end = leaf_off[l1];
+    const uint64_t stream_end = n_elems;
+    // Leaf l = elements [b, e).  Normal run: consecutive ranges of leaf_off, with HEAVY leaves (more
+    // than `heavy` elements: low-complexity sequence piles millions of instances of a few k-mers on one
+    // bucket) treated as empty -- they are cut into slices and counted by the whole grid in a second
+    // launch of this kernel that takes its ranges from (sl_begin, sl_end) instead.
+    auto range = [&](int64_t l, uint64_t &b, uint64_t &e) __attribute__((always_inline)) {
+        if (sl_begin) { b = sl_begin[l]; e = sl_end[l]; return; }
+        b = leaf_off[l]; e = leaf_off[l + 1];
+        if (heavy && e - b > heavy) e = b;
+    };
 
     for (int i = threadIdx.x; i < LCAP; i += LT) { tkey[i] = EMPTY; tcnt[i] = 0; }
     if (threadIdx.x == 0) { ob_n = 0; ob_lim = 0xffffffffu; overflow = 0; sp = 0; }
@@ -540,7 +551,9 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
     constexpr int NB = LeafElem<RECS>::PER_LANE;      // elements in flight per lane
     constexpr int RPF = NB;
     Elem kn[NB];
-    uint64_t pf = leaf_off[l0];
+    uint64_t begin, end;
+    range(l0, begin, end);
+    uint64_t pf = begin;
     auto prefetch = [&](uint64_t pos) __attribute__((always_inline)) {
         pf = pos;
 #pragma unroll
@@ -550,7 +563,7 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
         }
     };
     if constexpr (RECS) {
-        const uint64_t b0 = leaf_off[l0], n0 = leaf_off[l0 + 1] - b0;
+        const uint64_t b0 = begin, n0 = end - begin;
         const uint64_t ws = b0 + n0 * wave_ / NW, we = b0 + n0 * (wave_ + 1) / NW;
 #pragma unroll
         for (int i = 0; i < RPF; i++) {
@@ -560,12 +573,10 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
     } else {
         prefetch(pf);
     }
-    uint64_t begin = pf;
-    uint64_t end = leaf_off[l0 + 1];
     __syncthreads();
 
     // one table pass over the leaf [begin, end): inserts the keys selected by (S, s); no barriers
-    auto run_pass = [&](uint32_t S, uint32_t s, bool first, uint64_t end_next) __attribute__((always_inline)) {
+    auto run_pass = [&](uint32_t S, uint32_t s, bool first, uint64_t begin_next, uint64_t end_next) __attribute__((always_inline)) {
         // Two keys per lane probe in lock-step so that two LDS compare-and-swaps are in flight.  A key
         // is done when its slot held EMPTY (claimed) or the key itself; either way its count goes up.
         // There is no occupancy counter: a probe sequence longer than LPROBE flags the pass as
@@ -608,8 +619,8 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
 #pragma unroll
                 for (int i = 0; i < RPF; i++) cur[i] = kn[i];
                 // this wave's share of the next leaf travels while this leaf is processed
-                const uint64_t nn = end_next - end;
-                const uint64_t ns = end + nn * wave_ / NW, ne = end + nn * (wave_ + 1) / NW;
+                const uint64_t nn = end_next - begin_next;
+                const uint64_t ns = begin_next + nn * wave_ / NW, ne = begin_next + nn * (wave_ + 1) / NW;
 #pragma unroll
                 for (int i = 0; i < RPF; i++) {
                     const uint64_t r = ns + 64u * i + lane_;
@@ -699,7 +710,7 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
                     }
                 }
                 // next batch of this leaf, or the first batch of the next leaf
-                const uint64_t nxt = base + (uint64_t)LT * NB < end ? base + (uint64_t)LT * NB : end;
+                const uint64_t nxt = base + (uint64_t)LT * NB < end ? base + (uint64_t)LT * NB : begin_next;
                 if (nxt < stream_end && nxt != pf) prefetch(nxt);
                 if (dbg & 1) {       // ablation: stream only
                     if (kc[0] == 0x123456789ULL) overflow = 1;
@@ -767,14 +778,15 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
 
     for (int64_t leaf = l0; leaf < l1; leaf++) {
         // the offset after the next leaf travels while this leaf is processed
-        const uint64_t end_next = leaf + 2 <= l1 ? leaf_off[leaf + 2] : stream_end;
+        uint64_t begin_next = stream_end, end_next = stream_end;
+        if (leaf + 1 < l1) range(leaf + 1, begin_next, end_next);
         // Passes of this leaf.  Normally one: (S, s) = (1, 0), two barriers.  A leaf whose table
         // fills up is re-streamed in 2, 4, ... hash-selected parts off a small stack (rare; the
         // stack is empty between leaves).
         uint32_t S = 1, s = 0;
         bool first = true;
         while (true) {
-            run_pass(S, s, first, end_next);        // (an empty leaf still hands the prefetch chain on)
+            run_pass(S, s, first, begin_next, end_next);        // (an empty leaf still hands the prefetch chain on)
             first = false;
             if (begin == end) break;
             __syncthreads();
@@ -804,7 +816,7 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
             __syncthreads();
             if (threadIdx.x == 0) sp--;
         }
-        begin = end;
+        begin = begin_next;
         end = end_next;
     }
     flush();
@@ -819,6 +831,46 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
         atomicAdd(&co->n_passes, my_passes);
         if (my_overflows) atomicAdd(&co->n_overflow, my_overflows);
     }
+}
+
+// ---- heavy leaves: slices for the second launch, and the merge of the slices' partial counts
+
+__global__ void k_heavy_count(const uint64_t *__restrict__ off, int64_t nleaf, uint64_t heavy, uint64_t slice,
+                              uint64_t *__restrict__ nsl) {
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nleaf) return;
+    const uint64_t n = off[l + 1] - off[l];
+    nsl[l] = n > heavy ? (n + slice - 1) / slice : 0;
+}
+
+__global__ void k_heavy_fill(const uint64_t *__restrict__ off, int64_t nleaf, const uint64_t *__restrict__ pos,
+                             uint64_t *__restrict__ sb, uint64_t *__restrict__ se) {
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nleaf) return;
+    const uint64_t c = pos[l + 1] - pos[l];
+    if (!c) return;
+    const uint64_t b = off[l], n = off[l + 1] - b;
+    for (uint64_t j = 0; j < c; j++) {            // equal slices
+        sb[pos[l] + j] = b + n * j / c;                 // n < 2^40, j < 2^24: no overflow
+        se[pos[l] + j] = b + n * (j + 1) / c;
+    }
+}
+
+// partial (key, count) pairs of the slices, sorted by key: sum every run, filter, append
+__global__ void k_reduce_partials(const uint64_t *__restrict__ pk, const uint32_t *__restrict__ pc, int64_t np,
+                                  int min_cov, int max_cov, int apply_filter, uint64_t *__restrict__ out_keys,
+                                  int32_t *__restrict__ out_counts, unsigned long long cap, CountOut *__restrict__ co) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    const uint64_t key = pk[i];
+    if (i > 0 && pk[i - 1] == key) return;
+    uint32_t sum = 0;                              // Integer sums wrap in the reference too (:2895-2899)
+    for (int64_t j = i; j < np && pk[j] == key; j++) sum += pc[j];
+    atomicAdd(&co->n_distinct, 1ULL);
+    const int32_t c = (int32_t)sum;
+    if (apply_filter && !(c >= min_cov && c <= max_cov)) return;
+    const unsigned long long o = atomicAdd(&co->n_out, 1ULL);
+    if (o < cap) { out_keys[o] = key; out_counts[o] = c; }
 }
 
 // ------------------------------------------------------- super-k-mer records
@@ -1256,21 +1308,83 @@ static unsigned reads_grid(rfx_ctx *ctx, const ReadSrc &s, int per_cu) {
 
 // leaf count + filter + ascending sort of the survivors (shared tail of every source kind)
 template <bool RECS>
-static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<RECS>::T *elems, const uint64_t *d_leaf_off,
-                         int64_t nleaf, int k, int min_cov, int max_cov, int twin, int key_bits,
+static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<RECS>::T *elems, int64_t elem_count,
+                         const uint64_t *d_leaf_off, int64_t nleaf, int k, int min_cov, int max_cov, int twin, int key_bits,
                          uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n,
                          int64_t *out_distinct) {
     DevBuf co_buf;
     RFX_HIP(co_buf.alloc(sizeof(CountOut), ctx->stream));
     RFX_HIP(hipMemsetAsync(co_buf.p, 0, sizeof(CountOut), ctx->stream));
     const int apply = !(twin == RFX_TWIN_RDD && min_cov <= 1);    // P/ReflexivMain.java:160
+    // heavy leaves (low-complexity sequence: millions of instances of a few k-mers in one bucket) are
+    // left out of the first launch, cut into slices and counted by the whole grid in a second one
+    uint64_t heavy = RECS ? 16384 : 131072, slice = RECS ? 2048 : 16384, pcap_min = 1 << 20;
+    if (const char *e = getenv("RFX_HEAVY")) {          // test knob: "heavy,slice,pcap" in elements
+        unsigned long long a = 0, b = 0, c = 0;
+        if (sscanf(e, "%llu,%llu,%llu", &a, &b, &c) == 3 && a && b && c) { heavy = a; slice = b; pcap_min = c; }
+    }
+    const int dbg = getenv("RFX_LEAF_DBG") ? atoi(getenv("RFX_LEAF_DBG")) : 0;
+    DevBuf nsl, spos;
+    RFX_HIP(nsl.alloc((size_t)nleaf * 8, ctx->stream));
+    RFX_HIP(spos.alloc((size_t)(nleaf + 1) * 8, ctx->stream));
+    hipLaunchKernelGGL(k_heavy_count, dim3((unsigned)ceil_div(nleaf, 256)), dim3(256), 0, ctx->stream, d_leaf_off, nleaf,
+                       heavy, slice, nsl.as<uint64_t>());
+    RFX_HIP(hipGetLastError());
+    RFX_TRY(exclusive_scan_u64(ctx, nsl.as<uint64_t>(), spos.as<uint64_t>(), nleaf));
+    uint64_t n_slices = 0;
+    RFX_HIP(hipMemcpyAsync(&n_slices, spos.as<uint64_t>() + nleaf, 8, hipMemcpyDeviceToHost, ctx->stream));
     {
         ScopedTimer t(ctx, "leaf");
         int64_t grid = std::min<int64_t>(nleaf, (int64_t)ctx->num_cu * 2);      // persistent, <= 78 KB LDS each
-        hipLaunchKernelGGL(k_leaf_count<RECS>, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, elems, d_leaf_off, nleaf, k,
-                           min_cov, max_cov, apply, d_out_keys, d_out_counts, (unsigned long long)cap,
-                           co_buf.as<CountOut>(), getenv("RFX_LEAF_DBG") ? atoi(getenv("RFX_LEAF_DBG")) : 0);
+        hipLaunchKernelGGL(k_leaf_count<RECS>, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, elems, d_leaf_off, nleaf,
+                           (const uint64_t *)nullptr, (const uint64_t *)nullptr, heavy, (uint64_t)elem_count, k, min_cov,
+                           max_cov, apply, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>(), dbg);
         RFX_HIP(hipGetLastError());
+    }
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_slices > 0) {
+        DevBuf sb, se, co2, pk, pc, tk, tv;
+        RFX_HIP(sb.alloc((size_t)n_slices * 8, ctx->stream));
+        RFX_HIP(se.alloc((size_t)n_slices * 8, ctx->stream));
+        RFX_HIP(co2.alloc(sizeof(CountOut), ctx->stream));
+        hipLaunchKernelGGL(k_heavy_fill, dim3((unsigned)ceil_div(nleaf, 256)), dim3(256), 0, ctx->stream, d_leaf_off, nleaf,
+                           (const uint64_t *)spos.as<uint64_t>(), sb.as<uint64_t>(), se.as<uint64_t>());
+        RFX_HIP(hipGetLastError());
+        // partial counts: every distinct key of every slice; grow on demand
+        uint64_t pcap = std::max<uint64_t>(pcap_min, n_slices * 64);
+        CountOut c2{};
+        for (;;) {
+            RFX_HIP(pk.alloc((size_t)pcap * 8, ctx->stream));
+            RFX_HIP(pc.alloc((size_t)pcap * 4, ctx->stream));
+            RFX_HIP(hipMemsetAsync(co2.p, 0, sizeof(CountOut), ctx->stream));
+            {
+                ScopedTimer t(ctx, "leaf");
+                int64_t grid = std::min<int64_t>((int64_t)n_slices, (int64_t)ctx->num_cu * 2);
+                hipLaunchKernelGGL(k_leaf_count<RECS>, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, elems, d_leaf_off,
+                                   (int64_t)n_slices, (const uint64_t *)sb.as<uint64_t>(), (const uint64_t *)se.as<uint64_t>(),
+                                   (uint64_t)0, (uint64_t)elem_count, k, min_cov, max_cov, 0, pk.as<uint64_t>(),
+                                   pc.as<int32_t>(), (unsigned long long)pcap, co2.as<CountOut>(), dbg);
+                RFX_HIP(hipGetLastError());
+            }
+            RFX_HIP(hipMemcpyAsync(&c2, co2.p, sizeof c2, hipMemcpyDeviceToHost, ctx->stream));
+            RFX_HIP(hipStreamSynchronize(ctx->stream));
+            if (c2.n_failed) { ctx->last_error = "leaf split depth exhausted"; ScopedTimer::collect(ctx); return RFX_E_LIMIT; }
+            if (c2.n_out <= pcap) break;
+            pcap = c2.n_out;
+        }
+        if (c2.n_out >= (1ULL << 32)) { ctx->last_error = "too many partial counts"; ScopedTimer::collect(ctx); return RFX_E_LIMIT; }
+        RFX_HIP(tk.alloc((size_t)c2.n_out * 8, ctx->stream));
+        RFX_HIP(tv.alloc((size_t)c2.n_out * 4, ctx->stream));
+        ScopedTimer t(ctx, "leaf");
+        RFX_TRY(sort_pairs(ctx, pk.as<uint64_t>(), pc.as<uint32_t>(), (int64_t)c2.n_out, key_bits, tk.as<uint64_t>(),
+                           tv.as<uint32_t>()));
+        hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)ceil_div((int64_t)c2.n_out, 256)), dim3(256), 0, ctx->stream,
+                           (const uint64_t *)pk.as<uint64_t>(), (const uint32_t *)pc.as<uint32_t>(), (int64_t)c2.n_out,
+                           min_cov, max_cov, apply, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>());
+        RFX_HIP(hipGetLastError());
+        t.stop();
+        if (getenv("RFX_TRACE"))
+            fprintf(stderr, "heavy leaves: %llu slices, %llu partial counts\n", (unsigned long long)n_slices, c2.n_out);
     }
     CountOut co{};
     RFX_HIP(hipMemcpyAsync(&co, co_buf.p, sizeof co, hipMemcpyDeviceToHost, ctx->stream));
@@ -1441,7 +1555,7 @@ static int count_records_levels(rfx_ctx *ctx, const Rec *recs, int64_t n_recs, i
         std::swap(seg_cur, seg_next);
         nseg = nchild;
     }
-    return finish_leaves<true>(ctx, cur, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, k, min_cov, max_cov, twin,
+    return finish_leaves<true>(ctx, cur, n_recs, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, k, min_cov, max_cov, twin,
                                2 * k, d_out_keys, d_out_counts, cap, out_n, out_distinct);
 }
 
@@ -1587,7 +1701,7 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
         nseg = nchild;
     }
 
-    return finish_leaves<false>(ctx, cur_arr, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, from_reads ? reads->k : 31,
+    return finish_leaves<false>(ctx, cur_arr, n, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, from_reads ? reads->k : 31,
                                 min_cov, max_cov, twin, from_reads ? k_bits : 64, d_out_keys, d_out_counts, cap, out_n,
                                 out_distinct);
 }

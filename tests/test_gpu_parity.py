@@ -804,3 +804,25 @@ def test_count_survives_extreme_skew(rfx, torch_mod, k):
     wk, wc, wd = O.count_filter(km, 2)
     assert nd == wd and np.array_equal(gk, wk) and np.array_equal(gc, wc)
     assert int(gc.max()) >= 15000 * (L - k + 1)                      # poly-A and poly-T (and N) are one canonical k-mer
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [31, 21])
+def test_heavy_leaf_slices_merge_exactly(rfx, torch_mod, k, monkeypatch):
+    """Force every leaf through the heavy-leaf path (slices counted by the whole grid, partial counts
+    sorted and merged, partial buffer grown once) and compare with the oracle."""
+    torch = torch_mod
+    monkeypatch.setenv("RFX_HEAVY", "40,16,64" if k == 31 else "300,128,64")
+    seed, G, n_reads, L = 5 + k, 20_000, 30_000, 150
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    N = rfx.kmers_per_read(L, k) * n_reads
+    dk = torch.empty(N, dtype=torch.int64, device="cuda"); dc = torch.empty(N, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+    km = O.extract_canon(bases, off, k)
+    for min_cov in (1, 3):
+        m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, min_cov)
+        wk, wc, wd = O.count_filter(km, min_cov)
+        assert inst == len(km) and nd == wd and m == len(wk)
+        assert np.array_equal(dk[:m].cpu().numpy().view(np.uint64), wk) and np.array_equal(dc[:m].cpu().numpy(), wc)

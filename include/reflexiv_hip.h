@@ -212,6 +212,14 @@ int rfx_dev_count_reads_w(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads
                           uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap,
                           int64_t *out_n, int64_t *out_distinct, int64_t *out_instances);
 
+/* The same for reads of different lengths (real FASTQ): d_read_len[i] bases in read i, as
+ * rfx_dev_encode_reads writes them; max_read_len <= 32 * words_per_read bounds them. */
+int rfx_dev_count_reads_ragged(rfx_ctx *ctx, const uint64_t *d_words, const uint32_t *d_read_len,
+                               int64_t n_reads, int words_per_read, int max_read_len, int k,
+                               int front_clip, int end_clip, int min_cov, int max_cov, int twin,
+                               uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap,
+                               int64_t *out_n, int64_t *out_distinct, int64_t *out_instances);
+
 /* Same, from an explicit k-mer array (the reduceByKey input) in HBM. */
 int rfx_dev_count_kmers(rfx_ctx *ctx, const uint64_t *d_kmers, int64_t n,
                         int min_cov, int max_cov, int twin,
@@ -245,6 +253,15 @@ int rfx_dev_count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records
 int rfx_dev_assemble(rfx_ctx *ctx, const uint64_t *d_keys, const int32_t *d_counts, int64_t n,
                      const rfx_params *prm, char *out, int64_t cap, int64_t *out_len,
                      int64_t *out_contigs, int64_t *trace, int64_t trace_cap, int64_t *n_trace);
+
+/* The whole resident path from ASCII reads in host memory (any lengths) to the contig text:
+ * upload, 2-bit encode, extract + count + filter (prm->min_cov .. max_cov), the driver above --
+ * nothing but the reads goes up and nothing but the text comes back.  k <= 31.
+ * out_kept (optional) = number of k-mers that passed the coverage filter. */
+int rfx_assemble_reads(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_off, int64_t n_reads,
+                       const rfx_params *prm, char *out, int64_t cap, int64_t *out_len,
+                       int64_t *out_contigs, int64_t *trace, int64_t trace_cap, int64_t *n_trace,
+                       int64_t *out_kept);
 
 /* Synthetic reads: integer-only counter-based generator, bit-identical to
  * oracle/reflexiv_oracle.c orc_synth_*.  Writes packed reads straight into HBM. */

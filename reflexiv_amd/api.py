@@ -293,6 +293,20 @@ class Reflexiv:
         self._check(st, "rfx_dev_count_reads")
         return int(n.value), int(d.value), int(inst.value)
 
+    def count_reads_ragged_dev(self, d_words: int, d_read_len: int, n_reads: int, words_per_read: int, max_read_len: int,
+                               k: int, d_out_keys: int, d_out_counts: int, cap: int, min_cov=2, max_cov=10_000_000,
+                               twin=TWIN_DS, front_clip=0, end_clip=0):
+        """count_reads_dev for reads of different lengths (d_read_len: uint32 per read, as encode_reads_dev writes)."""
+        n, d, inst = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        st = self.L.rfx_dev_count_reads_ragged(self.ctx, C.c_void_p(d_words), C.c_void_p(d_read_len), C.c_int64(n_reads),
+                                               words_per_read, max_read_len, k, front_clip, end_clip, min_cov, max_cov,
+                                               twin, C.c_void_p(d_out_keys), C.c_void_p(d_out_counts), C.c_int64(cap),
+                                               C.byref(n), C.byref(d), C.byref(inst))
+        if st == RFX_E_CAP:
+            raise RfxError(st, "rfx_dev_count_reads_ragged", f"needs room for {n.value} survivors, cap is {cap}")
+        self._check(st, "rfx_dev_count_reads_ragged")
+        return int(n.value), int(d.value), int(inst.value)
+
     def count_kmers_dev(self, d_kmers: int, n: int, d_out_keys: int, d_out_counts: int, cap: int, min_cov=2,
                         max_cov=10_000_000, twin=TWIN_DS):
         m, d = C.c_int64(0), C.c_int64(0)

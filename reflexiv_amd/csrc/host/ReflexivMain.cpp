@@ -271,6 +271,34 @@ std::string ReflexivMain::assembly(const std::string &fastqText, std::vector<int
     return assemblyFromCounts(counts, trace);
 }
 
+std::string ReflexivMain::assemblyResident(const std::string &fastqText, std::vector<int64_t> *trace) {
+    if (!param.bubble)
+        throw std::runtime_error("-bubble (no fork filtering) is unusable in the reference too (SURVEY.md C.6)");
+    std::vector<uint8_t> bases; std::vector<int64_t> readOff;
+    FastqFilterWithQual{*this}.call(fastqText, bases, readOff);
+    rfx_params prm;
+    rfx_default_params(&prm);
+    prm.k = param.kmerSize; prm.min_cov = param.minKmerCoverage; prm.max_cov = param.maxKmerCoverage;
+    prm.min_error_cov = param.minErrorCoverage; prm.min_contig = param.minContig;
+    prm.min_iter = param.minimumIteration; prm.max_iter = param.maximumIteration;
+    prm.front_clip = param.frontClip; prm.end_clip = param.endClip;
+    prm.partitions = std::max(1, param.logicalPartitions); prm.twin = param.twin;
+    const int64_t nr = (int64_t)readOff.size() - 1;
+    std::vector<int64_t> tr((size_t)param.maximumIteration + 8);
+    int64_t len = 0, nc = 0, nt = 0, kept = 0;
+    std::string out((size_t)1 << 20, '\0');
+    for (;;) {
+        int st = rfx_assemble_reads(ctx, bases.data(), readOff.data(), nr, &prm, out.data(), (int64_t)out.size(), &len, &nc,
+                                    tr.data(), (int64_t)tr.size(), &nt, &kept);
+        if (st == RFX_E_CAP && len > (int64_t)out.size()) { out.assign((size_t)len, '\0'); continue; }
+        check(st, "rfx_assemble_reads");
+        break;
+    }
+    out.resize((size_t)len);
+    if (trace) trace->assign(tr.begin(), tr.begin() + nt);
+    return out;
+}
+
 // KmerBinarizer.call  P/ReflexivDSMain.java:3883-3931: "KMER,count" or "(KMER,count)"; a count of
 // ten or more digits saturates at 1,000,000,000; bases A0 C1 G2, anything else 3.
 KmerBinaryRDD ReflexivMain::KmerBinarizer::call(const std::string &csvText) const {

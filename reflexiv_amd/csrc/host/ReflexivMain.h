@@ -117,6 +117,8 @@ public:
     // ---- drivers
     // assembly(): P/ReflexivMain.java:95-322 from FASTQ text to the contig text of saveAsTextFile
     std::string assembly(const std::string &fastqText, std::vector<int64_t> *trace = nullptr);
+    // the same result through ONE call (rfx_assemble_reads): reads go up, contig text comes back
+    std::string assemblyResident(const std::string &fastqText, std::vector<int64_t> *trace = nullptr);
     // ReflexivCounter.assembly(): P/ReflexivCounter.java:109-191 -> lines "KMER,count"
     std::string counter(const std::string &fastqText);
     std::string assemblyFromCounts(const KmerBinaryRDD &counts, std::vector<int64_t> *trace = nullptr);

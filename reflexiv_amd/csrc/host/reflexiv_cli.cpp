@@ -58,7 +58,9 @@ int main(int argc, char **argv) {
         mkdir(dir.c_str(), 0755);
         if (cmd == "run") {
             // M/Main.java:74-78 -> Pipelines.reflexivDSMainPipe(): -kmerc routes to assemblyFromKmer()
-            out = param.inputKmerPath.empty() ? m.assembly(read_all(param.inputFqPath)) : m.assemblyFromKmer(read_all(param.inputKmerPath));
+            out = !param.inputKmerPath.empty() ? m.assemblyFromKmer(read_all(param.inputKmerPath))
+                  : param.resident          ? m.assemblyResident(read_all(param.inputFqPath))
+                                            : m.assembly(read_all(param.inputFqPath));
         } else if (cmd == "counter") {
             out = m.counter(read_all(param.inputFqPath));
             dir += "/Count_" + std::to_string(param.kmerSize);               // P/ReflexivDataFrameCounter.java:222-233

@@ -37,8 +37,13 @@ int64_t contigs_text_host(const rfx_records *r, int k, int min_contig, int twin,
     static const char NUC[4] = {'A', 'C', 'G', 'T'};
     const int sub = k - 1;
     int64_t pos = 0, idx = 0;
-    std::vector<uint8_t> b;
+    std::vector<char> b;
     auto putc_ = [&](char c) { if (pos < cap) out[pos] = c; pos++; };
+    auto puts_ = [&](const char *p, int64_t n) {                           // bulk copy when it fits, else count / clip
+        if (pos + n <= cap) memcpy(out + pos, p, (size_t)n);
+        else for (int64_t j = 0; j < n; j++) if (pos + j < cap) out[pos + j] = p[j];
+        pos += n;
+    };
     for (int64_t i = 0; i < r->n; i++) {
         // DS drops records whose markers are both <= -10,000,000  P/ReflexivDSMain.java:749
         if (twin == RFX_TWIN_DS && r->left[i] <= -10000000 && r->right[i] <= -10000000) continue;
@@ -50,22 +55,26 @@ int64_t contigs_text_host(const rfx_records *r, int k, int min_contig, int twin,
         const int64_t len = L + sub;
         if (len < min_contig) continue;                                    // :596, :606
         b.resize((size_t)len);
-        uint8_t *e = r->marker[i] == 1 ? b.data() + sub : b.data();        // :593-594 / :603-604
-        uint8_t *kb = r->marker[i] == 1 ? b.data() : b.data() + L;
-        for (int j = 0; j < sub; j++) kb[j] = (uint8_t)((r->key[i] >> (2 * (sub - 1 - j))) & 3);   // :704-709
+        char *e = r->marker[i] == 1 ? b.data() + sub : b.data();           // :593-594 / :603-604
+        char *kb = r->marker[i] == 1 ? b.data() : b.data() + L;
+        for (int j = 0; j < sub; j++) kb[j] = NUC[(r->key[i] >> (2 * (sub - 1 - j))) & 3];         // :704-709
         int64_t o = 0;
-        for (int j = 0; j < f; j++) e[o++] = (uint8_t)((w[0] >> (2 * (f - 1 - j))) & 3);           // :713-718
-        for (int64_t x = 1; x < nw; x++)
-            for (int j = 0; j < 31; j++) e[o++] = (uint8_t)((w[x] >> (2 * (30 - j))) & 3);         // :720-729
+        for (int j = 0; j < f; j++) e[o++] = NUC[(w[0] >> (2 * (f - 1 - j))) & 3];                 // :713-718
+        for (int64_t x = 1; x < nw; x++) {                                                         // :720-729
+            const uint64_t v = w[x];
+            char *q = e + o;
+            for (int j = 0; j < 31; j++) q[j] = NUC[(v >> (2 * (30 - j))) & 3];
+            o += 31;
+        }
         char hdr[96];
         int hl = twin == RFX_TWIN_DS
                      ? snprintf(hdr, sizeof hdr, ">Contig-%lld-(%d,%d)-%lld\n", (long long)len, r->left[i],
                                 r->right[i], (long long)idx)                // DS :755, :722
                      : snprintf(hdr, sizeof hdr, ">Contig-%lld-%lld\n", (long long)len, (long long)idx);   // :597, :578
-        for (int j = 0; j < hl; j++) putc_(hdr[j]);
-        for (int64_t j = 0; j < len; j++) {                                 // changeLine :616-637
-            if (j > 0 && j % 100 == 0) putc_('\n');
-            putc_(NUC[b[(size_t)j]]);
+        puts_(hdr, hl);
+        for (int64_t j = 0; j < len; j += 100) {                            // changeLine :616-637
+            if (j > 0) putc_('\n');
+            puts_(b.data() + j, std::min<int64_t>(100, len - j));
         }
         putc_('\n');                                                        // saveAsTextFile
         idx++;
@@ -458,6 +467,21 @@ int rfx_dev_count_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, 
                         d_out_counts, cap, out_n, out_distinct);
 }
 
+int rfx_dev_count_reads_ragged(rfx_ctx *ctx, const uint64_t *d_words, const uint32_t *d_read_len, int64_t n_reads,
+                               int words_per_read, int max_read_len, int k, int front_clip, int end_clip, int min_cov,
+                               int max_cov, int twin, uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap,
+                               int64_t *out_n, int64_t *out_distinct, int64_t *out_instances) {
+    if (!ctx || !d_words || !d_read_len || n_reads < 0 || words_per_read * 32 < max_read_len) return RFX_E_ARG;
+    RFX_TRY(check_k(k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    ReadStore rs{d_words, n_reads, words_per_read, max_read_len, k, front_clip, end_clip};
+    rs.read_len_arr = d_read_len;
+    RFX_TRY(ragged_instances(ctx, d_read_len, n_reads, k, front_clip, end_clip, &rs.n_instances));
+    if (out_instances) *out_instances = rs.n_instances;
+    return count_filter(ctx, &rs, nullptr, 0, min_cov, max_cov, twin, nullptr, 0, d_out_keys, d_out_counts, cap, out_n,
+                        out_distinct);
+}
+
 int rfx_dev_count_kmers(rfx_ctx *ctx, const uint64_t *d_kmers, int64_t n, int min_cov, int max_cov, int twin,
                         void *d_workspace, int64_t workspace_bytes, uint64_t *d_out_keys, int32_t *d_out_counts,
                         int64_t cap, int64_t *out_n, int64_t *out_distinct) {
@@ -554,6 +578,8 @@ int rfx_dev_assemble(rfx_ctx *ctx, const uint64_t *d_keys, const int32_t *d_coun
             arena[i].cap = per;
         }
     }
+    timespec ts_enter; clock_gettime(CLOCK_MONOTONIC, &ts_enter);
+    const double t_enter = ts_enter.tv_sec * 1e3 + ts_enter.tv_nsec * 1e-6;
     struct ArenaGuard { ~ArenaGuard() { tl_arena = nullptr; } } arena_guard;
     int arena_turn = 0;
     auto next_arena = [&]() { Arena *ar = &arena[arena_turn++ & 1]; ar->off = 0; tl_arena = ar; };
@@ -579,6 +605,8 @@ int rfx_dev_assemble(rfx_ctx *ctx, const uint64_t *d_keys, const int32_t *d_coun
 
     const bool verbose = getenv("RFX_TRACE") != nullptr;
     auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double t_loop0 = verbose ? ((void)hipStreamSynchronize(ctx->stream), now_ms()) : 0;
+    if (verbose) fprintf(stderr, "assemble: stages before the loop %.3f ms\n", t_loop0 - t_enter);
     auto one_pass = [&](int stage) -> int {
         const double t0 = verbose ? now_ms() : 0;
         next_arena();                     // `a` (this pass's input) stays valid in the other arena
@@ -613,12 +641,58 @@ int rfx_dev_assemble(rfx_ctx *ctx, const uint64_t *d_keys, const int32_t *d_coun
         RFX_TRY(one_pass(2));
     }
     if (n_trace) *n_trace = nt;
+    const double t_loop1 = verbose ? now_ms() : 0;
     HostRecords h;
     h.resize(a.n, a.words);
     RFX_TRY(dev_records_download(ctx, a, &h.view));
+    const double t_dl = verbose ? now_ms() : 0;
     int64_t len = contigs_text_host(&h.view, k, prm->min_contig, twin, out, out ? cap : 0, out_contigs);
+    if (verbose) fprintf(stderr, "assemble: loop %.3f ms, download %.3f ms, text %.3f ms\n", t_loop1 - t_loop0, t_dl - t_loop1,
+                         now_ms() - t_dl);
     *out_len = len;
     return len > cap ? RFX_E_CAP : RFX_OK;
+}
+
+int rfx_assemble_reads(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_off, int64_t n_reads,
+                       const rfx_params *prm, char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs,
+                       int64_t *trace, int64_t trace_cap, int64_t *n_trace, int64_t *out_kept) {
+    if (!ctx || !read_off || !prm || !out_len || n_reads < 0) return RFX_E_ARG;
+    RFX_TRY(check_k(prm->k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    const int64_t nb = n_reads ? read_off[n_reads] - read_off[0] : 0;
+    int64_t maxlen = 1;
+    for (int64_t r = 0; r < n_reads; r++) maxlen = std::max(maxlen, read_off[r + 1] - read_off[r]);
+    const int wpr = (int)((maxlen + 31) / 32);
+    DevBuf d_bases, d_off, d_words, d_len, d_keys, d_counts;
+    RFX_HIP(d_bases.alloc((size_t)std::max<int64_t>(nb, 1), ctx->stream));
+    RFX_HIP(d_off.alloc((size_t)(n_reads + 1) * 8, ctx->stream));
+    RFX_HIP(d_words.alloc((size_t)std::max<int64_t>(n_reads, 1) * wpr * 8, ctx->stream));
+    RFX_HIP(d_len.alloc((size_t)std::max<int64_t>(n_reads, 1) * 4, ctx->stream));
+    std::vector<int64_t> off((size_t)n_reads + 1, 0);
+    for (int64_t r = 0; r <= n_reads && n_reads > 0; r++) off[(size_t)r] = read_off[r] - read_off[0];
+    if (nb > 0) RFX_HIP(hipMemcpyAsync(d_bases.p, bases + read_off[0], (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(d_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    RFX_TRY(encode_reads(ctx, d_bases.as<uint8_t>(), d_off.as<int64_t>(), n_reads, wpr, d_words.as<uint64_t>(),
+                         d_len.as<uint32_t>()));
+    ReadStore rs{d_words.as<uint64_t>(), n_reads, wpr, (int)maxlen, prm->k, prm->front_clip, prm->end_clip};
+    rs.read_len_arr = d_len.as<uint32_t>();
+    RFX_TRY(ragged_instances(ctx, rs.read_len_arr, n_reads, prm->k, prm->front_clip, prm->end_clip, &rs.n_instances));
+    d_bases.release(); d_off.release();
+    int64_t m = 0, dist = 0;
+    int64_t kcap = std::max<int64_t>(1 << 20, rs.n_instances / 8);
+    for (;;) {                                      // survivors are few; grow on RFX_E_CAP
+        RFX_HIP(d_keys.alloc((size_t)kcap * 8, ctx->stream));
+        RFX_HIP(d_counts.alloc((size_t)kcap * 4, ctx->stream));
+        const int st = count_filter(ctx, &rs, nullptr, 0, prm->min_cov, prm->max_cov, prm->twin, nullptr, 0,
+                                    d_keys.as<uint64_t>(), d_counts.as<int32_t>(), kcap, &m, &dist);
+        if (st == RFX_E_CAP && m > kcap) { kcap = m; continue; }
+        RFX_TRY(st);
+        break;
+    }
+    if (out_kept) *out_kept = m;
+    d_words.release(); d_len.release();
+    return rfx_dev_assemble(ctx, d_keys.as<uint64_t>(), d_counts.as<int32_t>(), m, prm, out, cap, out_len, out_contigs, trace,
+                            trace_cap, n_trace);
 }
 
 }  // extern "C"

@@ -138,7 +138,13 @@ int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int 
 struct ReadStore {
     const uint64_t *words; int64_t n_reads; int words_per_read; int read_len;
     int k, front_clip, end_clip;
+    // ragged reads: per-read lengths in HBM (read_len is then the maximum) and the exact number of
+    // k-mer instances (-1: uniform reads, kmers_per_read(read_len) each)
+    const uint32_t *read_len_arr = nullptr;
+    int64_t n_instances = -1;
 };
+int ragged_instances(rfx_ctx *ctx, const uint32_t *d_read_len, int64_t n_reads, int k, int front_clip,
+                         int end_clip, int64_t *out_total);
 int64_t kmers_per_read(int read_len, int k, int front_clip, int end_clip);
 int encode_reads(rfx_ctx *ctx, const uint8_t *d_bases, const int64_t *d_read_off, int64_t n_reads,
                  int words_per_read, uint64_t *d_words, uint32_t *d_read_len);

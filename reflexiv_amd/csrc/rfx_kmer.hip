@@ -72,6 +72,12 @@ __global__ void k_nk_per_read(const int64_t *__restrict__ read_off, int64_t n_re
     if (r < n_reads) nk[r] = (uint64_t)nk_of(read_off[r + 1] - read_off[r], k, fc, ec);
 }
 
+__global__ void k_nk_from_len(const uint32_t *__restrict__ len, int64_t n_reads, int k, int fc, int ec,
+                              uint64_t *__restrict__ nk) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_reads) nk[r] = (uint64_t)nk_of((int64_t)len[r], k, fc, ec);
+}
+
 // K1 in the reference's emission order: one wave per read, lanes over window positions.
 __global__ void k_extract_ordered(const uint64_t *__restrict__ words, int wpr,
                                   const uint64_t *__restrict__ kmer_off, int64_t n_reads, int k,
@@ -167,8 +173,15 @@ __device__ __forceinline__ void scatter_tile(const ScatterLds &l, const Level &l
 struct ReadSrc {
     const uint64_t *words;
     int64_t n_reads, n_threads;    // n_threads = n_reads * segs
-    int wpr, nk, fc, k, segs;      // words/read, k-mers/read, front clip, k, segments/read
+    int wpr, nk, fc, k, segs;      // words/read, k-mers/read (of the longest read), front clip, k, segments/read
+    const uint32_t *len_arr;       // ragged reads: per-read length (nullptr: every read emits nk k-mers)
+    int ec;                        // end clip (for the per-read count)
 };
+
+// k-mers read r emits
+__device__ __forceinline__ int read_nk(const ReadSrc &s, int64_t r) {
+    return s.len_arr ? (int)nk_of((int64_t)s.len_arr[r], s.k, s.fc, s.ec) : s.nk;
+}
 
 struct SegPos { int64_t r; int sgm; };
 
@@ -182,9 +195,9 @@ __device__ __forceinline__ void seg_load(const ReadSrc &s, const SegPos &q, uint
 }
 
 // -> number of valid windows; key[i] canonical k-mer of window sgm*PK + i
-__device__ __forceinline__ int seg_keys(const ReadSrc &s, int sgm, const uint64_t (&w)[3], uint64_t (&key)[PK]) {
+__device__ __forceinline__ int seg_keys(const ReadSrc &s, int nk_r, int sgm, const uint64_t (&w)[3], uint64_t (&key)[PK]) {
     const int p0 = sgm * PK;
-    int v = s.nk - p0;
+    int v = nk_r - p0;
     v = v > PK ? PK : v;
     const int sh = 2 * ((s.fc + p0) & 31);
     // 64 bases starting at the first window's first base
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(PT) void k_reads_hist(ReadSrc s, Level lv, uint64_t
     for (; g < s.n_threads; g += stride) {
         uint64_t w[3], key[PK];
         seg_load(s, q, w);
-        const int v = seg_keys(s, q.sgm, w, key);
+        const int v = seg_keys(s, read_nk(s, q.r), q.sgm, w, key);
 #pragma unroll
         for (int i = 0; i < PK; i++)
             if (i < v) atomicAdd(&h[digit_of(key[i], lv)], 1u);
@@ -268,7 +281,7 @@ __global__ __launch_bounds__(PT) void k_reads_scatter(ReadSrc s, Level lv, const
         uint64_t key[PK];
         uint32_t rank[PK];
         bool ok[PK];
-        const int v = g < s.n_threads ? seg_keys(s, q.sgm, w, key) : 0;
+        const int v = g < s.n_threads ? seg_keys(s, read_nk(s, q.r), q.sgm, w, key) : 0;
         // advance and prefetch the next tile's words
         q.r += dq; q.sgm += dr;
         if (q.sgm >= s.segs) { q.sgm -= s.segs; q.r++; }
@@ -907,12 +920,13 @@ __device__ __forceinline__ unsigned rec_digit(uint32_t hdr, int used, int bits) 
 
 // Walks the runs of one segment; calls emit(first_window, n_windows, minimiser_key).
 template <int W, bool RUNLOOP, class F>
-__device__ __forceinline__ void seg_runs(const ReadSrc &s, int sgm, const uint64_t (&w)[3], F &&emit,
+__device__ __forceinline__ void seg_runs(const ReadSrc &s, int nk_r, int sgm, const uint64_t (&w)[3], F &&emit,
                                          uint64_t *hi_out, uint64_t *lo_out) {
     constexpr int NM = PK + W - 1;                 // m-mers a segment can touch (<= 34)
     const int p0 = sgm * PK;
-    int v = s.nk - p0;
+    int v = nk_r - p0;
     v = v > PK ? PK : v;
+    if (v <= 0) return;                            // a short read of a ragged set: no window in this segment
     const int sh = 2 * ((s.fc + p0) & 31);
     const uint64_t hi = sh ? (w[0] << sh) | (w[1] >> (64 - sh)) : w[0];
     const uint64_t lo = sh ? (w[1] << sh) | (w[2] >> (64 - sh)) : w[1];
@@ -998,7 +1012,7 @@ __global__ __launch_bounds__(SKT) void k_sk_hist(ReadSrc s, Level lv, uint64_t *
     for (; g < s.n_threads; g += stride) {
         uint64_t w[3], hi, lo;
         seg_load(s, q, w);
-        seg_runs<W, SK_HIST_RUNLOOP>(s, q.sgm, w, [&](int, int, uint32_t canon) { atomicAdd(&h[sk_digit(canon, lv)], 1u); }, &hi, &lo);
+        seg_runs<W, SK_HIST_RUNLOOP>(s, read_nk(s, q.r), q.sgm, w, [&](int, int, uint32_t canon) { atomicAdd(&h[sk_digit(canon, lv)], 1u); }, &hi, &lo);
         q.r += dq; q.sgm += dr;
         if (q.sgm >= s.segs) { q.sgm -= s.segs; q.r++; }
     }
@@ -1050,7 +1064,7 @@ __global__ __launch_bounds__(SKT, 8) void k_sk_scatter(ReadSrc s, Level lv, cons
             uint64_t w[3], hi = 0, lo = 0;
             seg_load(s, q, w);
             // `hi`/`lo` are written before the first emit() runs (seg_runs stores them first)
-            seg_runs<W, SK_SCATTER_RUNLOOP>(s, q.sgm, w, [&](int i0, int n, uint32_t canon) {
+            seg_runs<W, SK_SCATTER_RUNLOOP>(s, read_nk(s, q.r), q.sgm, w, [&](int i0, int n, uint32_t canon) {
                 const uint64_t h = mmer_hash64(canon);
                 const unsigned d = lv.n_owners > 0 ? (unsigned)__umul64hi(h, (uint64_t)lv.n_owners)
                                                    : rec_digit((uint32_t)((h << OWNER_BITS) >> 32), 0, lv.bits);
@@ -1256,6 +1270,24 @@ int extract_ordered_packed(rfx_ctx *ctx, const uint64_t *d_words, int wpr, const
     return RFX_OK;
 }
 
+int ragged_instances(rfx_ctx *ctx, const uint32_t *d_read_len, int64_t n_reads, int k, int front_clip,
+                         int end_clip, int64_t *out_total) {
+    *out_total = 0;
+    if (n_reads <= 0) return RFX_OK;
+    DevBuf nk, off;
+    RFX_HIP(nk.alloc((size_t)n_reads * 8, ctx->stream));
+    RFX_HIP(off.alloc((size_t)(n_reads + 1) * 8, ctx->stream));
+    hipLaunchKernelGGL(k_nk_from_len, dim3((unsigned)ceil_div(n_reads, 256)), dim3(256), 0, ctx->stream, d_read_len, n_reads,
+                       k, front_clip, end_clip, nk.as<uint64_t>());
+    RFX_HIP(hipGetLastError());
+    RFX_TRY(exclusive_scan_u64(ctx, nk.as<uint64_t>(), off.as<uint64_t>(), n_reads));
+    uint64_t t = 0;
+    RFX_HIP(hipMemcpyAsync(&t, off.as<uint64_t>() + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    *out_total = (int64_t)t;
+    return RFX_OK;
+}
+
 int64_t count_workspace_bytes(int64_t n_kmers) { return 2 * n_kmers * 8 + (int64_t)(64 << 20); }
 
 static void plan_levels(int64_t n, bool from_reads, std::vector<int> &bits, double target = 16384.0) {
@@ -1285,8 +1317,15 @@ static ReadSrc make_read_src(const ReadStore *reads) {
     s.nk = (int)kmers_per_read(reads->read_len, reads->k, reads->front_clip, reads->end_clip);
     s.segs = s.nk > 0 ? (s.nk + PK - 1) / PK : 1;
     s.n_threads = s.n_reads * s.segs;
+    s.len_arr = reads->read_len_arr; s.ec = reads->end_clip;
     return s;
 }
+
+// k-mer instances of a read set
+static int64_t instances_of(const ReadStore *reads, const ReadSrc &s) {
+    return reads->n_instances >= 0 ? reads->n_instances : (int64_t)s.nk * reads->n_reads;
+}
+
 
 static int set_scatter_attrs(rfx_ctx *ctx) {
     static bool done = false;
@@ -1565,7 +1604,7 @@ static int count_reads_superkmer(rfx_ctx *ctx, const ReadStore *reads, int min_c
                                  int64_t *out_distinct) {
     ctx->timing.clear();
     ReadSrc rsrc = make_read_src(reads);
-    const int64_t n = (int64_t)rsrc.nk * reads->n_reads;
+    const int64_t n = instances_of(reads, rsrc);
     if (out_n) *out_n = 0;
     if (out_distinct) *out_distinct = 0;
     if (n <= 0) return RFX_OK;
@@ -1596,7 +1635,7 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
     const bool from_reads = reads != nullptr;
     if (from_reads) {
         rsrc = make_read_src(reads);
-        n = (int64_t)rsrc.nk * reads->n_reads;
+        n = instances_of(reads, rsrc);
         k_bits = 2 * reads->k;
     }
     if (out_n) *out_n = 0;
@@ -1710,7 +1749,7 @@ int bucket_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, uint64_t
                     int64_t *d_owner_off, int64_t *h_owner_off) {
     if (n_owners < 1 || n_owners > 64) return RFX_E_ARG;
     ReadSrc rsrc = make_read_src(reads);
-    const int64_t n = (int64_t)rsrc.nk * reads->n_reads;
+    const int64_t n = instances_of(reads, rsrc);
     if (n > cap) return RFX_E_CAP;
     RFX_TRY(set_scatter_attrs(ctx));
     Level lv{};

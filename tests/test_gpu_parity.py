@@ -826,3 +826,63 @@ def test_heavy_leaf_slices_merge_exactly(rfx, torch_mod, k, monkeypatch):
         wk, wc, wd = O.count_filter(km, min_cov)
         assert inst == len(km) and nd == wd and m == len(wk)
         assert np.array_equal(dk[:m].cpu().numpy().view(np.uint64), wk) and np.array_equal(dc[:m].cpu().numpy(), wc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,clips", [(31, (0, 0)), (31, (2, 3)), (28, (0, 0)), (21, (0, 0)), (21, (1, 4))])
+def test_ragged_reads_device_count(rfx, torch_mod, k, clips):
+    """Reads of different lengths (trimmed FASTQ) through rfx_dev_encode_reads + rfx_dev_count_reads_ragged:
+    reads shorter than k, exactly k + 1, and up to 251 bases, with N; record path (k = 28..31) and k-mer path."""
+    torch = torch_mod
+    rng = np.random.default_rng(100 + k)
+    genome = "".join(rng.choice(list("ACGT"), size=5000))
+    reads = []
+    for _ in range(6000):
+        L = int(rng.choice([10, k, k + 1, k + 2, 60, 100, 150, 151, 200, 251]))
+        p = int(rng.integers(0, len(genome) - L))
+        s = list(genome[p:p + L])
+        if rng.random() < 0.05:
+            s[int(rng.integers(0, L))] = "N"
+        reads.append("".join(s))
+    bases = np.frombuffer("".join(reads).encode(), np.uint8)
+    off = np.cumsum([0] + [len(r) for r in reads]).astype(np.int64)
+    fc, ec = clips
+    maxlen = max(len(r) for r in reads)
+    wpr = (maxlen + 31) // 32
+    n = len(reads)
+    db = torch.from_numpy(bases.copy()).cuda(); do = torch.from_numpy(off).cuda()
+    dw = torch.empty(n * wpr, dtype=torch.int64, device="cuda")
+    dl = torch.empty(n, dtype=torch.int32, device="cuda")
+    km = O.extract_canon(bases, off, k, fc, ec)
+    dk = torch.empty(len(km) + 1, dtype=torch.int64, device="cuda"); dc = torch.empty(len(km) + 1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    rfx.encode_reads_dev(db.data_ptr(), do.data_ptr(), n, wpr, dw.data_ptr(), dl.data_ptr())
+    for min_cov in (1, 2):
+        m, nd, inst = rfx.count_reads_ragged_dev(dw.data_ptr(), dl.data_ptr(), n, wpr, maxlen, k, dk.data_ptr(),
+                                                 dc.data_ptr(), len(km) + 1, min_cov, front_clip=fc, end_clip=ec)
+        wk, wc, wd = O.count_filter(km, min_cov)
+        assert inst == len(km) and nd == wd and m == len(wk)
+        assert np.array_equal(dk[:m].cpu().numpy().view(np.uint64), wk) and np.array_equal(dc[:m].cpu().numpy(), wc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("twin", ["rdd", "ds"])
+def test_cpp_host_resident_run(tmp_path, ex, planted, twin):
+    """`reflexiv_host run --resident`: ONE C-ABI call (rfx_assemble_reads: upload, 2-bit encode, ragged
+    count, device-resident extend loop) gives the same contigs as the operator-by-operator driver."""
+    import subprocess
+    import reflexiv_amd._lib as L
+    host = os.path.join(os.path.dirname(L.LIB_PATH), "reflexiv_host")
+    fq = str(tmp_path / "ex.fq.gz")
+    write_fastq(fq, ex["bases"], ex["read_off"], True)
+    out = str(tmp_path / "result")
+    subprocess.check_call([host, "run", "--resident", "-fastq", fq, "-outfile", out, "-kmer", "31", "-cover", "3",
+                           "--logical-partitions", "4", "--twin", twin])
+    assert open(os.path.join(out, "part-00000")).read() == str(ex[f"contigs_{twin}_P4"])
+    # planted bubbles / repeat, 100-base reads, min contig 100
+    fq2 = str(tmp_path / "pl.fq")
+    write_fastq(fq2, planted["bases"], planted["read_off"], False)
+    out2 = str(tmp_path / "result2")
+    subprocess.check_call([host, "run", "--resident", "-fastq", fq2, "-outfile", out2, "-kmer", "31", "-cover", "2",
+                           "-mincontig", "100", "--logical-partitions", "4", "--twin", twin])
+    assert open(os.path.join(out2, "part-00000")).read() == str(planted[f"k31_{twin}_contigs"])

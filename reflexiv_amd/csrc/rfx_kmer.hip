@@ -996,8 +996,16 @@ __device__ __forceinline__ unsigned sk_digit(uint32_t canon, const Level &lv) {
     return rec_digit((uint32_t)((h << OWNER_BITS) >> 32), 0, lv.bits);
 }
 
-template <int W>
-__global__ __launch_bounds__(SKT) void k_sk_hist(ReadSrc s, Level lv, uint64_t *__restrict__ blockhist) {
+// Run descriptors: what the scatter needs to know about a segment without redoing the minimiser
+// arithmetic (two thirds of both kernels' instructions).  desc[g] = run-start bits of segment g |
+// runs << 16, desc[(1 + r) * n_threads + g] = header word (32 hash bits) of its r-th run, r < SKD.
+// Word-major, so the lanes of a wave store / load consecutive words; a segment with more than SKD
+// runs (0.02 %) makes its wave recompute.
+constexpr int SKD = 8;
+
+template <int W, bool DESC>
+__global__ __launch_bounds__(SKT) void k_sk_hist(ReadSrc s, Level lv, uint64_t *__restrict__ blockhist,
+                                                 uint32_t *__restrict__ desc) {
     __shared__ uint32_t h[1 << MAX_BITS];
     const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
     for (int i = threadIdx.x; i < nb; i += SKT) h[i] = 0;
@@ -1012,7 +1020,20 @@ __global__ __launch_bounds__(SKT) void k_sk_hist(ReadSrc s, Level lv, uint64_t *
     for (; g < s.n_threads; g += stride) {
         uint64_t w[3], hi, lo;
         seg_load(s, q, w);
-        seg_runs<W, SK_HIST_RUNLOOP>(s, read_nk(s, q.r), q.sgm, w, [&](int, int, uint32_t canon) { atomicAdd(&h[sk_digit(canon, lv)], 1u); }, &hi, &lo);
+        if constexpr (DESC) {
+            uint32_t mask = 0, nr = 0;
+            // run loop: the r-th run of every lane is handled in the same iteration, so the header
+            // stores of a wave go to consecutive words
+            seg_runs<W, true>(s, read_nk(s, q.r), q.sgm, w, [&](int i0, int, uint32_t canon) {
+                const uint32_t hdr = (uint32_t)((mmer_hash64(canon) << OWNER_BITS) >> 32);
+                atomicAdd(&h[rec_digit(hdr, 0, lv.bits)], 1u);
+                if (nr < (uint32_t)SKD) desc[(int64_t)(1 + nr) * s.n_threads + g] = hdr;
+                mask |= 1u << i0; nr++;
+            }, &hi, &lo);
+            desc[g] = mask | (nr << 16);
+        } else {
+            seg_runs<W, SK_HIST_RUNLOOP>(s, read_nk(s, q.r), q.sgm, w, [&](int, int, uint32_t canon) { atomicAdd(&h[sk_digit(canon, lv)], 1u); }, &hi, &lo);
+        }
         q.r += dq; q.sgm += dr;
         if (q.sgm >= s.segs) { q.sgm -= s.segs; q.r++; }
     }
@@ -1024,14 +1045,16 @@ __global__ __launch_bounds__(SKT) void k_sk_hist(ReadSrc s, Level lv, uint64_t *
 // stream has SKB record slots in LDS indexed by the record's final position, and only whole
 // aligned 64-byte lines are stored; a digit that overruns its ring in one round stores directly.
 constexpr int SKB = 8, SKA = 4;
-template <int W>
+template <int W, bool DESC>
 __global__ __launch_bounds__(SKT, 8) void k_sk_scatter(ReadSrc s, Level lv, const uint64_t *__restrict__ scanned,
-                                                   Rec *__restrict__ out) {
+                                                   Rec *__restrict__ out, const uint32_t *__restrict__ desc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
     const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
-    Rec *buf = (Rec *)sk_smem;
-    unsigned long long *tail = (unsigned long long *)(buf + (size_t)nb * SKB);
-    unsigned long long *head = tail + nb;
+    // (the rings are addressed through these expressions, not through pointer variables: a pointer
+    // captured by the lambdas below decays to a generic one and the LDS atomics with it)
+#define buf ((Rec *)sk_smem)
+#define tail ((unsigned long long *)(sk_smem + (size_t)nb * SKB * sizeof(Rec)))
+#define head (tail + nb)
     for (int i = threadIdx.x; i < nb; i += SKT) tail[i] = head[i] = scanned[(int64_t)i * gridDim.x + blockIdx.x];
     __syncthreads();
     auto drain = [&](bool final) __attribute__((always_inline)) {
@@ -1063,20 +1086,57 @@ __global__ __launch_bounds__(SKT, 8) void k_sk_scatter(ReadSrc s, Level lv, cons
         if (g < s.n_threads) {
             uint64_t w[3], hi = 0, lo = 0;
             seg_load(s, q, w);
-            // `hi`/`lo` are written before the first emit() runs (seg_runs stores them first)
-            seg_runs<W, SK_SCATTER_RUNLOOP>(s, read_nk(s, q.r), q.sgm, w, [&](int i0, int n, uint32_t canon) {
-                const uint64_t h = mmer_hash64(canon);
-                const unsigned d = lv.n_owners > 0 ? (unsigned)__umul64hi(h, (uint64_t)lv.n_owners)
-                                                   : rec_digit((uint32_t)((h << OWNER_BITS) >> 32), 0, lv.bits);
+            // one record: windows [i0, i0 + n) of the segment, header word hdr, digit d
+            auto put = [&](int i0, int n, uint32_t hdr, unsigned d) __attribute__((always_inline)) {
                 const int sft = 2 * i0;
                 Rec r;
                 r.w0 = sft ? (hi << sft) | (lo >> (64 - sft)) : hi;
-                r.w1 = ((lo << sft) & 0xFFFFFFF000000000ULL) | ((uint64_t)(n - 1) << 32) |
-                       (uint64_t)(uint32_t)((h << OWNER_BITS) >> 32);
+                r.w1 = ((lo << sft) & 0xFFFFFFF000000000ULL) | ((uint64_t)(n - 1) << 32) | (uint64_t)hdr;
                 const unsigned long long pos = atomicAdd(&tail[d], 1ULL);
                 if (pos - head[d] < (unsigned long long)SKB) buf[(size_t)d * SKB + (pos & (SKB - 1))] = r;
                 else out[pos] = r;
-            }, &hi, &lo);
+            };
+            // `hi`/`lo` are written before the first emit() runs (seg_runs stores them first)
+            auto recompute = [&]() __attribute__((always_inline)) {
+                seg_runs<W, SK_SCATTER_RUNLOOP>(s, read_nk(s, q.r), q.sgm, w, [&](int i0, int n, uint32_t canon) {
+                    const uint64_t h = mmer_hash64(canon);
+                    const unsigned d = lv.n_owners > 0 ? (unsigned)__umul64hi(h, (uint64_t)lv.n_owners)
+                                                       : rec_digit((uint32_t)((h << OWNER_BITS) >> 32), 0, lv.bits);
+                    put(i0, n, (uint32_t)((h << OWNER_BITS) >> 32), d);
+                }, &hi, &lo);
+            };
+            if constexpr (DESC) {
+                const uint32_t m = desc[g];
+                const uint32_t nr = m >> 16;
+                if (nr > (uint32_t)SKD) {
+                    recompute();
+                } else if (nr) {
+                    // the 64 bases from the segment's first window on (as seg_runs forms them)
+                    const int p0 = q.sgm * PK;
+                    int v = read_nk(s, q.r) - p0;
+                    v = v > PK ? PK : v;
+                    const int sh = 2 * ((s.fc + p0) & 31);
+                    hi = sh ? (w[0] << sh) | (w[1] >> (64 - sh)) : w[0];
+                    lo = sh ? (w[1] << sh) | (w[2] >> (64 - sh)) : w[1];
+                    // all header words of the segment at once: SKD independent loads in flight instead of
+                    // one exposed memory latency per run
+                    uint32_t hd[SKD];
+#pragma unroll
+                    for (int r = 0; r < SKD; r++) hd[r] = (uint32_t)r < nr ? desc[(int64_t)(1 + r) * s.n_threads + g] : 0u;
+                    uint32_t starts = m & 0xffffu;
+#pragma unroll
+                    for (int r = 0; r < SKD; r++) {
+                        if (starts) {
+                            const int i0 = __ffs((int)starts) - 1;
+                            starts &= starts - 1;
+                            const int i1 = starts ? __ffs((int)starts) - 1 : v;
+                            put(i0, i1 - i0, hd[r], rec_digit(hd[r], 0, lv.bits));
+                        }
+                    }
+                }
+            } else {
+                recompute();
+            }
             q.r += dq; q.sgm += dr;
             if (q.sgm >= s.segs) { q.sgm -= s.segs; q.r++; }
         }
@@ -1086,6 +1146,9 @@ __global__ __launch_bounds__(SKT, 8) void k_sk_scatter(ReadSrc s, Level lv, cons
     }
     drain(true);
 }
+#undef buf
+#undef tail
+#undef head
 
 // levels >= 2 on records: virtual workgroups as for k-mers, digit from the record header
 __global__ __launch_bounds__(PT) void k_rec_hist(const Rec *__restrict__ recs, VbMap m, Level lv, int used,
@@ -1456,29 +1519,30 @@ static bool superkmer_enabled(int k) {
     return k >= SK_M + PK - 1 && k <= 31;
 }
 
-template <class... Args>
+template <bool DESC, class... Args>
 static void launch_sk_hist(int W, dim3 grid, hipStream_t st, Args... args) {
     switch (W) {
-        case 16: hipLaunchKernelGGL(k_sk_hist<16>, grid, dim3(SKT), 0, st, args...); break;
-        case 17: hipLaunchKernelGGL(k_sk_hist<17>, grid, dim3(SKT), 0, st, args...); break;
-        case 18: hipLaunchKernelGGL(k_sk_hist<18>, grid, dim3(SKT), 0, st, args...); break;
-        default: hipLaunchKernelGGL(k_sk_hist<19>, grid, dim3(SKT), 0, st, args...); break;
+        case 16: hipLaunchKernelGGL((k_sk_hist<16, DESC>), grid, dim3(SKT), 0, st, args...); break;
+        case 17: hipLaunchKernelGGL((k_sk_hist<17, DESC>), grid, dim3(SKT), 0, st, args...); break;
+        case 18: hipLaunchKernelGGL((k_sk_hist<18, DESC>), grid, dim3(SKT), 0, st, args...); break;
+        default: hipLaunchKernelGGL((k_sk_hist<19, DESC>), grid, dim3(SKT), 0, st, args...); break;
     }
 }
-template <int W, class... Args>
+
+template <int W, bool DESC, class... Args>
 static hipError_t launch_sk_scatter_w(dim3 grid, size_t lds, hipStream_t st, Args... args) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_sk_scatter<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)k_sk_scatter<W, DESC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_sk_scatter<W>, grid, dim3(SKT), lds, st, args...);
+    hipLaunchKernelGGL((k_sk_scatter<W, DESC>), grid, dim3(SKT), lds, st, args...);
     return hipGetLastError();
 }
-template <class... Args>
+template <bool DESC, class... Args>
 static hipError_t launch_sk_scatter(int W, dim3 grid, size_t lds, hipStream_t st, Args... args) {
     switch (W) {
-        case 16: return launch_sk_scatter_w<16>(grid, lds, st, args...);
-        case 17: return launch_sk_scatter_w<17>(grid, lds, st, args...);
-        case 18: return launch_sk_scatter_w<18>(grid, lds, st, args...);
-        default: return launch_sk_scatter_w<19>(grid, lds, st, args...);
+        case 16: return launch_sk_scatter_w<16, DESC>(grid, lds, st, args...);
+        case 17: return launch_sk_scatter_w<17, DESC>(grid, lds, st, args...);
+        case 18: return launch_sk_scatter_w<18, DESC>(grid, lds, st, args...);
+        default: return launch_sk_scatter_w<19, DESC>(grid, lds, st, args...);
     }
 }
 
@@ -1497,9 +1561,14 @@ static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv
     DevBuf bh, scanned;
     RFX_HIP(bh.alloc((size_t)nb * G * 8, ctx->stream));
     RFX_HIP(scanned.alloc(((size_t)nb * G + 1) * 8, ctx->stream));
+    // run descriptors (hist -> scatter) live in the workspace slot the records do not use yet
+    uint32_t *desc = nullptr;
+    const bool want_desc = use_ws && lv.n_owners == 0 && !(getenv("RFX_SK_DESC") && atoi(getenv("RFX_SK_DESC")) == 0);
+    if (want_desc) desc = (uint32_t *)ctx->ws_get(ws_slot == 0 ? 1 : 0, (size_t)(1 + SKD) * 4 * (size_t)rsrc.n_threads);
     {
         ScopedTimer t(ctx, hn);
-        launch_sk_hist(W, dim3(G), ctx->stream, rsrc, lv, bh.as<uint64_t>());
+        if (desc) launch_sk_hist<true>(W, dim3(G), ctx->stream, rsrc, lv, bh.as<uint64_t>(), desc);
+        else launch_sk_hist<false>(W, dim3(G), ctx->stream, rsrc, lv, bh.as<uint64_t>(), (uint32_t *)nullptr);
         RFX_HIP(hipGetLastError());
     }
     RFX_TRY(exclusive_scan_u64(ctx, bh.as<uint64_t>(), scanned.as<uint64_t>(), (int64_t)nb * G));
@@ -1519,8 +1588,10 @@ static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv
     }
     {
         ScopedTimer t(ctx, pn);
-        RFX_HIP(launch_sk_scatter(W, dim3(G), sk_lds, ctx->stream, rsrc, lv,
-                                  (const uint64_t *)scanned.as<uint64_t>(), dst));
+        if (desc) RFX_HIP(launch_sk_scatter<true>(W, dim3(G), sk_lds, ctx->stream, rsrc, lv,
+                                                  (const uint64_t *)scanned.as<uint64_t>(), dst, (const uint32_t *)desc));
+        else RFX_HIP(launch_sk_scatter<false>(W, dim3(G), sk_lds, ctx->stream, rsrc, lv,
+                                              (const uint64_t *)scanned.as<uint64_t>(), dst, (const uint32_t *)nullptr));
     }
     *out_recs = dst;
     return RFX_OK;

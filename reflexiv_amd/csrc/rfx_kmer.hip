@@ -904,6 +904,9 @@ constexpr int SKT = 1024;             // threads per workgroup of the reads -> r
 #ifndef SK_SCATTER_RUNLOOP
 #define SK_SCATTER_RUNLOOP true
 #endif
+#ifndef SK_DESC_RUNLOOP
+#define SK_DESC_RUNLOOP true
+#endif
 
 // order of the m-mers: a bijection of the canonical 26-bit m-mer onto 32 bits (odd multiplier,
 // xor-shift), so two different m-mers never tie and a plain 32-bit minimum picks the minimiser;
@@ -1024,7 +1027,7 @@ __global__ __launch_bounds__(SKT) void k_sk_hist(ReadSrc s, Level lv, uint64_t *
             uint32_t mask = 0, nr = 0;
             // run loop: the r-th run of every lane is handled in the same iteration, so the header
             // stores of a wave go to consecutive words
-            seg_runs<W, true>(s, read_nk(s, q.r), q.sgm, w, [&](int i0, int, uint32_t canon) {
+            seg_runs<W, SK_DESC_RUNLOOP>(s, read_nk(s, q.r), q.sgm, w, [&](int i0, int, uint32_t canon) {
                 const uint32_t hdr = (uint32_t)((mmer_hash64(canon) << OWNER_BITS) >> 32);
                 atomicAdd(&h[rec_digit(hdr, 0, lv.bits)], 1u);
                 if (nr < (uint32_t)SKD) desc[(int64_t)(1 + nr) * s.n_threads + g] = hdr;

@@ -1191,7 +1191,7 @@ __global__ __launch_bounds__(PT) void k_rec_scatter(const Rec *__restrict__ recs
 // only whole aligned lines of B/2 records leave the ring (partial lines stay for the next round;
 // a bin that receives more than the ring holds in one round writes the excess directly).
 constexpr int WCT = 1024;             // threads per workgroup (one workgroup per CU: the rings fill the LDS)
-constexpr int WC_PER = 2;             // records per thread per round
+constexpr int WC_PER = 4;             // records per thread per round
 
 template <int B>
 __global__ __launch_bounds__(WCT) void k_rec_scatter_wc(const Rec *__restrict__ recs, VbMap m, Level lv, int used,

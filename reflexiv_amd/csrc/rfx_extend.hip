@@ -227,10 +227,14 @@ __global__ void k_emit_long(const Desc *__restrict__ desc, const uint64_t *__res
     for (unsigned long long e = 0; e < hcnt; e++) emit_record(huge_list[e], gtid, (int64_t)gridDim.x * blockDim.x);
 }
 
+// output partition starts + the pass summary the host reads back in ONE copy:
+// summary = {records out, words out, status}
 __global__ void k_out_part_start(const int64_t *__restrict__ ps, int P, const uint64_t *__restrict__ oidx,
-                                 int64_t *__restrict__ ops) {
+                                 int64_t *__restrict__ ops, const uint64_t *__restrict__ owoff, int64_t n,
+                                 const int *__restrict__ status, uint64_t *__restrict__ summary) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p <= P) ops[p] = (int64_t)oidx[ps[p]];
+    if (p == 0) { summary[0] = oidx[n]; summary[1] = owoff[n]; summary[2] = (uint64_t)(unsigned)status[0]; }
 }
 
 inline unsigned grid_for(int64_t n, int block = 256) { return (unsigned)ceil_div(n > 0 ? n : 1, block); }
@@ -295,15 +299,16 @@ int extend_pass(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start,
                            (const unsigned long long *)long_n.as<unsigned long long>());
         RFX_HIP(hipGetLastError());
     }
+    DevBuf summary;
+    RFX_HIP(summary.alloc(24, ctx->stream));
     hipLaunchKernelGGL(k_out_part_start, dim3(grid_for(P + 1)), dim3(256), 0, ctx->stream, d_part_start, P,
-                       (const uint64_t *)oidx.as<uint64_t>(), out_part_start.as<int64_t>());
+                       (const uint64_t *)oidx.as<uint64_t>(), out_part_start.as<int64_t>(),
+                       (const uint64_t *)owoff.as<uint64_t>(), n, (const int *)status.as<int>(), summary.as<uint64_t>());
     RFX_HIP(hipGetLastError());
-    uint64_t tot[2] = {0, 0};
-    int st = 0;
-    RFX_HIP(hipMemcpyAsync(&tot[0], oidx.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipMemcpyAsync(&tot[1], owoff.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipMemcpyAsync(&st, status.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    uint64_t tot[3] = {0, 0, 0};
+    RFX_HIP(hipMemcpyAsync(tot, summary.p, 24, hipMemcpyDeviceToHost, ctx->stream));
     RFX_HIP(hipStreamSynchronize(ctx->stream));
+    const int st = (int)tot[2];
     out.n = (int64_t)tot[0]; out.words = (int64_t)tot[1];
     if (st) { ctx->last_error = "extend pass: single-word stage produced an extension > 31 bases"; return RFX_E_STATE; }
     return RFX_OK;

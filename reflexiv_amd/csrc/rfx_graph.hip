@@ -66,11 +66,14 @@ __global__ void k_gather_fixed(const uint32_t *__restrict__ perm, int64_t n, con
 
 constexpr int SHORT_WORDS = 8;
 
-// copy extension words record by record; records longer than SHORT_WORDS are queued
+// copy extension words record by record; records longer than SHORT_WORDS are queued as chunks of
+// LONG_CHUNK words -- (record, chunk) items -- so that a 2.6 Mbp contig (84 K words) is copied by
+// forty workgroups at once instead of one (84 us per sort in the late passes)
+constexpr int LONG_CHUNK = 2048;
 __global__ void k_gather_ext(const uint32_t *__restrict__ perm, int64_t n, const int64_t *__restrict__ ext_off,
                              const uint64_t *__restrict__ ext, const uint64_t *__restrict__ oext_off_u,
                              int64_t *__restrict__ oext_off, uint64_t *__restrict__ oext,
-                             uint32_t *__restrict__ long_list, unsigned long long *__restrict__ long_n) {
+                             uint64_t *__restrict__ long_list, unsigned long long *__restrict__ long_n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n) return;
     int64_t o = (int64_t)oext_off_u[i];
@@ -81,20 +84,25 @@ __global__ void k_gather_ext(const uint32_t *__restrict__ perm, int64_t n, const
     if (nw <= SHORT_WORDS) {
         for (int64_t w = 0; w < nw; w++) oext[o + w] = ext[b + w];
     } else {
-        long_list[atomicAdd(long_n, 1ULL)] = (uint32_t)i;
+        const unsigned long long nc = (unsigned long long)((nw + LONG_CHUNK - 1) / LONG_CHUNK);
+        const unsigned long long at = atomicAdd(long_n, nc);
+        for (unsigned long long c = 0; c < nc; c++) long_list[at + c] = ((uint64_t)c << 32) | (uint64_t)i;
     }
 }
 
 __global__ void k_gather_ext_long(const uint32_t *__restrict__ perm, const int64_t *__restrict__ ext_off,
                                   const uint64_t *__restrict__ ext, const int64_t *__restrict__ oext_off,
-                                  uint64_t *__restrict__ oext, const uint32_t *__restrict__ long_list,
+                                  uint64_t *__restrict__ oext, const uint64_t *__restrict__ long_list,
                                   const unsigned long long *__restrict__ long_n) {
     unsigned long long cnt = *long_n;
     for (unsigned long long e = blockIdx.x; e < cnt; e += gridDim.x) {
-        uint32_t i = long_list[e];
-        uint32_t s = perm[i];
-        int64_t b = ext_off[s], nw = ext_off[s + 1] - b, o = oext_off[i];
-        for (int64_t w = threadIdx.x; w < nw; w += blockDim.x) oext[o + w] = ext[b + w];
+        const uint64_t item = long_list[e];
+        const uint32_t i = (uint32_t)item;
+        const int64_t c0 = (int64_t)(item >> 32) * LONG_CHUNK;
+        const uint32_t s = perm[i];
+        const int64_t b = ext_off[s], nw = ext_off[s + 1] - b, o = oext_off[i];
+        const int64_t c1 = c0 + LONG_CHUNK < nw ? c0 + LONG_CHUNK : nw;
+        for (int64_t w = c0 + threadIdx.x; w < c1; w += blockDim.x) oext[o + w] = ext[b + w];
     }
 }
 
@@ -336,7 +344,8 @@ int sort_records(rfx_ctx *ctx, const DevRecords &in, int P, int key_bits, DevRec
     RFX_HIP(tv.alloc((size_t)(n ? n : 1) * 4, ctx->stream));
     RFX_HIP(nw.alloc((size_t)(n ? n : 1) * 4, ctx->stream));
     RFX_HIP(wscan.alloc((size_t)(n + 1) * 8, ctx->stream));
-    RFX_HIP(long_list.alloc((size_t)(n ? n : 1) * 4, ctx->stream));
+    // chunk items: at most one per record plus one per LONG_CHUNK words
+    RFX_HIP(long_list.alloc((size_t)((n ? n : 1) + in.words / LONG_CHUNK + 1) * 8, ctx->stream));
     RFX_HIP(long_n.alloc(8, ctx->stream));
     RFX_HIP(hipMemsetAsync(long_n.p, 0, 8, ctx->stream));
     if (n > 0) {
@@ -356,14 +365,14 @@ int sort_records(rfx_ctx *ctx, const DevRecords &in, int P, int key_bits, DevRec
     hipLaunchKernelGGL(k_gather_ext, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream,
                        (const uint32_t *)perm.as<uint32_t>(), n, (const int64_t *)in.ext_off.as<int64_t>(),
                        (const uint64_t *)in.ext.as<uint64_t>(), (const uint64_t *)wscan.as<uint64_t>(),
-                       out.ext_off.as<int64_t>(), out.ext.as<uint64_t>(), long_list.as<uint32_t>(),
+                       out.ext_off.as<int64_t>(), out.ext.as<uint64_t>(), long_list.as<uint64_t>(),
                        long_n.as<unsigned long long>());
     RFX_HIP(hipGetLastError());
     if (in.words > n) {     // some record has more than one word: a long one may exist
         hipLaunchKernelGGL(k_gather_ext_long, dim3(1024), dim3(256), 0, ctx->stream,
                            (const uint32_t *)perm.as<uint32_t>(), (const int64_t *)in.ext_off.as<int64_t>(),
                            (const uint64_t *)in.ext.as<uint64_t>(), (const int64_t *)out.ext_off.as<int64_t>(),
-                           out.ext.as<uint64_t>(), (const uint32_t *)long_list.as<uint32_t>(),
+                           out.ext.as<uint64_t>(), (const uint64_t *)long_list.as<uint64_t>(),
                            (const unsigned long long *)long_n.as<unsigned long long>());
         RFX_HIP(hipGetLastError());
     }

@@ -35,6 +35,20 @@ struct rfx_ctx {
     }
     void ws_free() {
         for (auto &w : ws) { if (w.p) (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
+        if (pinned) (void)hipHostFree(pinned);
+        pinned = nullptr; pinned_bytes = 0;
+    }
+    // grow-only pinned host staging for result downloads (a pageable copy of a few MB costs
+    // milliseconds the first time the runtime stages it)
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+    void *pinned_get(size_t bytes) {
+        if (pinned && pinned_bytes >= bytes) return pinned;
+        if (pinned) { (void)hipStreamSynchronize(stream); (void)hipHostFree(pinned); pinned = nullptr; pinned_bytes = 0; }
+        size_t want = bytes + (bytes >> 2) + (1 << 20);
+        if (hipHostMalloc(&pinned, want, hipHostMallocDefault) != hipSuccess) { pinned = nullptr; return nullptr; }
+        pinned_bytes = want;
+        return pinned;
     }
 };
 

@@ -37,7 +37,8 @@ __global__ __launch_bounds__(ST) void k_hist(const uint64_t *__restrict__ keys, 
 __global__ __launch_bounds__(ST) void k_scatter(const uint64_t *__restrict__ keys,
                                                 const uint32_t *__restrict__ vals, int64_t n, int shift,
                                                 const uint64_t *__restrict__ offs, int64_t ntiles,
-                                                uint64_t *__restrict__ okeys, uint32_t *__restrict__ ovals) {
+                                                uint64_t *__restrict__ okeys, uint32_t *__restrict__ ovals,
+                                                const uint32_t *__restrict__ table) {
     __shared__ volatile uint32_t wcnt[SW][256];
     __shared__ uint64_t wbase[SW][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -74,7 +75,22 @@ __global__ __launch_bounds__(ST) void k_scatter(const uint64_t *__restrict__ key
     __syncthreads();
     {
         const int d = threadIdx.x;                 // ST == 256 digits
-        uint64_t run = offs[(int64_t)d * ntiles + blockIdx.x];
+        uint64_t run;
+        if (offs) {
+            run = offs[(int64_t)d * ntiles + blockIdx.x];
+        } else {
+            // few tiles: every workgroup scans the [digit][tile] histogram table itself -- two launches
+            // per digit pass instead of five (the launch chain is what a 30 K-record sort costs)
+            uint32_t before = 0, tot = 0;
+#pragma unroll 8
+            for (int64_t t = 0; t < ntiles; t++) {
+                const uint32_t c = table[(int64_t)d * ntiles + t];
+                tot += c;
+                if (t < blockIdx.x) before += c;
+            }
+            __shared__ uint32_t wsum_inline[SW];
+            run = (uint64_t)rfxd::block_exclusive_scan(tot, wsum_inline, nullptr) + before;
+        }
 #pragma unroll
         for (int w = 0; w < SW; w++) { wbase[w][d] = run; run += wcnt[w][d]; }
     }
@@ -171,14 +187,16 @@ int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int 
     RFX_HIP(offs.alloc((size_t)(ntiles * 256 + 1) * 8, ctx->stream));
     uint64_t *sk = d_keys, *dk = d_tmp_keys;
     uint32_t *sv = d_vals, *dv = d_tmp_vals;
+    const bool inline_scan = ntiles <= 64;           // <= 128 K pairs
     for (int p = 0; p < passes; p++) {
         const int shift = 8 * p;
         hipLaunchKernelGGL(k_hist, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, n, shift,
                            table.as<uint32_t>(), ntiles);
         RFX_HIP(hipGetLastError());
-        RFX_TRY(exclusive_scan_u32_to_u64(ctx, table.as<uint32_t>(), offs.as<uint64_t>(), ntiles * 256));
+        if (!inline_scan) RFX_TRY(exclusive_scan_u32_to_u64(ctx, table.as<uint32_t>(), offs.as<uint64_t>(), ntiles * 256));
         hipLaunchKernelGGL(k_scatter, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, sv, n, shift,
-                           (const uint64_t *)offs.as<uint64_t>(), ntiles, dk, dv);
+                           inline_scan ? (const uint64_t *)nullptr : (const uint64_t *)offs.as<uint64_t>(), ntiles, dk, dv,
+                           (const uint32_t *)table.as<uint32_t>());
         RFX_HIP(hipGetLastError());
         uint64_t *tk = sk; sk = dk; dk = tk;
         uint32_t *tv = sv; sv = dv; dv = tv;

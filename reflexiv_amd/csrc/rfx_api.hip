@@ -272,10 +272,15 @@ int rfx_count_filter_w(rfx_ctx *ctx, const uint64_t *kmers, int64_t n, int k, in
     RFX_HIP(d_keys.alloc((size_t)n * W * 8, ctx->stream));
     RFX_HIP(d_counts.alloc((size_t)n * 8, ctx->stream));
     RFX_HIP(hipMemcpyAsync(d_in.p, kmers, (size_t)n * W * 8, hipMemcpyHostToDevice, ctx->stream));
-    RFX_TRY(aos_to_soa(ctx, d_in.as<uint64_t>(), n, W, d_soa.as<uint64_t>()));
     int64_t m = 0, dist = 0;
-    RFX_TRY(count_filter_w(ctx, d_soa.as<uint64_t>(), n, k, min_cov, max_cov, d_keys.as<uint64_t>(), d_counts.as<int64_t>(),
-                           n, &m, &dist));
+    if (wide_fast_path(k)) {
+        RFX_TRY(count_filter_w2(ctx, d_in.as<uint64_t>(), n, k, min_cov, max_cov, d_keys.as<uint64_t>(), d_counts.as<int64_t>(),
+                                n, &m, &dist));
+    } else {
+        RFX_TRY(aos_to_soa(ctx, d_in.as<uint64_t>(), n, W, d_soa.as<uint64_t>()));
+        RFX_TRY(count_filter_w(ctx, d_soa.as<uint64_t>(), n, k, min_cov, max_cov, d_keys.as<uint64_t>(), d_counts.as<int64_t>(),
+                               n, &m, &dist));
+    }
     *out_n = m;
     if (out_distinct) *out_distinct = dist;
     if (m > cap) return RFX_E_CAP;
@@ -310,12 +315,17 @@ int rfx_dev_count_reads_w(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads
     if (N == 0) return RFX_OK;
     DevBuf d_soa;
     RFX_HIP(d_soa.alloc((size_t)N * W * 8, ctx->stream));
+    const bool fast = wide_fast_path(k);
     {
         ScopedTimer t(ctx, "extract_w");
-        RFX_TRY(extract_w(ctx, d_words, words_per_read, nullptr, nk, n_reads, k, front_clip, d_soa.as<uint64_t>(), N));
+        RFX_TRY(extract_w(ctx, d_words, words_per_read, nullptr, nk, n_reads, k, front_clip, d_soa.as<uint64_t>(), N,
+                          fast ? 1 : 0));
     }
     int st;
-    {
+    if (fast) {
+        st = count_filter_w2(ctx, d_soa.as<uint64_t>(), N, k, min_cov, max_cov, d_out_keys, d_out_counts, cap, out_n,
+                             out_distinct);
+    } else {
         ScopedTimer t(ctx, "count_w");
         st = count_filter_w(ctx, d_soa.as<uint64_t>(), N, k, min_cov, max_cov, d_out_keys, d_out_counts, cap, out_n,
                             out_distinct);

@@ -846,6 +846,158 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
     }
 }
 
+// ---- leaves of the k > 32 path: two-word keys.  No 128-bit LDS atomic exists, so a slot is
+// claimed through its count word: 0 = empty, WLOCK = being written, otherwise the count.  The
+// claimer writes both key words and then publishes count 1; a lane that meets WLOCK simply tries the
+// same slot again on its next trip round the loop (the claimer's branch has run by then -- divergent
+// branches of a wave execute one after the other -- or runs in another wave), a lane that meets a
+// count compares the (now immutable) key words.  Same structure otherwise: persistent workgroups over
+// contiguous leaf chunks, two barriers per leaf, table sweep, split on overflow.
+constexpr int WCAP_BITS = 12;
+constexpr int WCAP = 1 << WCAP_BITS;
+constexpr int WLT = 1024;               // threads per workgroup (one workgroup per CU: the table is 80 KB)
+constexpr uint32_t WLOCK = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(WLT) void k_leaf_count_wide(const Rec *__restrict__ elems, const uint64_t *__restrict__ leaf_off,
+                                                        int64_t nleaf, int min_cov, int max_cov,
+                                                        uint64_t *__restrict__ out_keys, int64_t *__restrict__ out_counts,
+                                                        unsigned long long cap, CountOut *__restrict__ co) {
+    __shared__ unsigned long long thi[WCAP], tlo[WCAP];
+    __shared__ uint32_t tcnt[WCAP];
+    __shared__ unsigned long long obh[OBUF], obl[OBUF];
+    __shared__ uint32_t obc[OBUF];
+    __shared__ uint32_t stackS[LSTACK], stacks[LSTACK];
+    __shared__ int sp;
+    __shared__ uint32_t overflow, ob_n, ob_lim;
+    __shared__ unsigned long long g_emit;
+    uint32_t my_distinct = 0;
+    unsigned long long my_passes = 0, my_overflows = 0;
+    const int lane_ = threadIdx.x & 63;
+    const int64_t l0 = (int64_t)(((unsigned long long)blockIdx.x * (unsigned long long)nleaf) / gridDim.x);
+    const int64_t l1 = (int64_t)(((unsigned long long)(blockIdx.x + 1) * (unsigned long long)nleaf) / gridDim.x);
+    if (l0 >= l1) return;
+    for (int i = threadIdx.x; i < WCAP; i += WLT) tcnt[i] = 0;
+    if (threadIdx.x == 0) { ob_n = 0; ob_lim = 0xffffffffu; overflow = 0; sp = 0; }
+    __syncthreads();
+
+    auto flush = [&]() {
+        __syncthreads();
+        const uint32_t cntv = ob_n < ob_lim ? ob_n : ob_lim;
+        if (ob_n == 0) return;
+        if (threadIdx.x == 0 && cntv) g_emit = atomicAdd(&co->n_out, (unsigned long long)cntv);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cntv; i += WLT) {
+            const unsigned long long pos = g_emit + i;
+            if (pos < cap) { out_keys[2 * pos] = obh[i]; out_keys[2 * pos + 1] = obl[i]; out_counts[pos] = (int64_t)obc[i]; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { ob_n = 0; ob_lim = 0xffffffffu; }
+        __syncthreads();
+    };
+
+    for (int64_t leaf = l0; leaf < l1; leaf++) {
+        const uint64_t begin = leaf_off[leaf], end = leaf_off[leaf + 1];
+        uint32_t S = 1, s = 0;
+        while (begin != end) {
+            // one pass: the keys selected by (S, s) go into the table
+            for (uint64_t i = begin + threadIdx.x; i < end; i += WLT) {
+                if (__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                const Rec e = elems[i];
+                const uint32_t g = ((uint32_t)e.w0 ^ __builtin_rotateleft32((uint32_t)(e.w0 >> 32), 13) ^
+                                    ((uint32_t)e.w1 * 0x85EBCA6Bu) ^ (uint32_t)(e.w1 >> 32)) * 0x9E3779B1u;
+                if (S > 1 && (((g >> 4) & 0xffffu) & (S - 1)) != s) continue;
+                uint32_t slot = g >> (32 - WCAP_BITS);
+                for (int probe = 0;;) {
+                    const uint32_t c = atomicCAS(&tcnt[slot], 0u, WLOCK);
+                    if (c == 0u) {                                  // claimed: write the key, publish count 1
+                        thi[slot] = e.w0; tlo[slot] = e.w1;
+                        __threadfence_block();
+                        atomicExch(&tcnt[slot], 1u);
+                        break;
+                    }
+                    if (c == WLOCK) continue;                       // being written: look again
+                    if (thi[slot] == e.w0 && tlo[slot] == e.w1) { atomicAdd(&tcnt[slot], 1u); break; }
+                    slot = (slot + 1) & (WCAP - 1);
+                    if (++probe >= LPROBE) { overflow = 1; break; }
+                }
+            }
+            __syncthreads();
+            const bool ov = overflow != 0;
+            if (threadIdx.x == 0) my_passes++;
+            if (!ov) {
+                // sweep: survivors -> LDS buffer (one add per wave), slots reset
+                for (int base = 0; base < WCAP; base += WLT) {
+                    const int slot = base + threadIdx.x;
+                    const uint32_t c = tcnt[slot];
+                    my_distinct += c != 0;
+                    bool keep = c != 0;                              // counter64 filters :197-205
+                    if (min_cov > 1 && c < (uint32_t)min_cov) keep = false;
+                    if (max_cov < 10000000 && c > (uint32_t)max_cov) keep = false;
+                    const uint64_t km = __ballot(keep);
+                    if (km) {
+                        const uint32_t cntw = (uint32_t)__popcll(km);
+                        const int leader = __ffsll((unsigned long long)km) - 1;
+                        const uint32_t r = (uint32_t)__popcll(km & ((1ULL << lane_) - 1));
+                        uint32_t b0 = 0;
+                        if (lane_ == leader) b0 = atomicAdd(&ob_n, cntw);
+                        b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, leader);
+                        if (b0 + cntw <= (uint32_t)OBUF) {
+                            if (keep) { obh[b0 + r] = thi[slot]; obl[b0 + r] = tlo[slot]; obc[b0 + r] = c; }
+                        } else {
+                            uint32_t glo = 0, ghi = 0;
+                            if (lane_ == leader) {
+                                atomicMin(&ob_lim, b0);
+                                const unsigned long long gg = atomicAdd(&co->n_out, (unsigned long long)cntw);
+                                glo = (uint32_t)gg; ghi = (uint32_t)(gg >> 32);
+                            }
+                            glo = (uint32_t)__builtin_amdgcn_readlane((int)glo, leader);
+                            ghi = (uint32_t)__builtin_amdgcn_readlane((int)ghi, leader);
+                            const unsigned long long pos = (((unsigned long long)ghi << 32) | glo) + r;
+                            if (keep && pos < cap) {
+                                out_keys[2 * pos] = thi[slot]; out_keys[2 * pos + 1] = tlo[slot]; out_counts[pos] = (int64_t)c;
+                            }
+                        }
+                    }
+                    tcnt[slot] = 0;
+                }
+                __syncthreads();
+                const uint32_t raw = ob_n, lim = ob_lim;
+                if (raw >= (uint32_t)OBUF / 2 || lim != 0xffffffffu) flush();
+                if (S == 1) break;
+            } else {
+                for (int i = threadIdx.x; i < WCAP; i += WLT) tcnt[i] = 0;
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    my_overflows++;
+                    overflow = 0;
+                    if (sp + 2 <= LSTACK && S < (1u << 16)) {
+                        stackS[sp] = 2 * S; stacks[sp] = s + S; sp++;
+                        stackS[sp] = 2 * S; stacks[sp] = s;     sp++;
+                    } else {
+                        atomicAdd(&co->n_failed, 1ULL);
+                    }
+                }
+                __syncthreads();
+            }
+            if (sp == 0) break;
+            S = stackS[sp - 1]; s = stacks[sp - 1];
+            __syncthreads();
+            if (threadIdx.x == 0) sp--;
+        }
+    }
+    flush();
+    {
+        uint32_t d = my_distinct;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        if (lane_ == 0 && d) atomicAdd(&co->n_distinct, (unsigned long long)d);
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&co->n_passes, my_passes);
+        if (my_overflows) atomicAdd(&co->n_overflow, my_overflows);
+    }
+}
+
 // ---- heavy leaves: slices for the second launch, and the merge of the slices' partial counts
 
 __global__ void k_heavy_count(const uint64_t *__restrict__ off, int64_t nleaf, uint64_t heavy, uint64_t slice,
@@ -1153,7 +1305,21 @@ __global__ __launch_bounds__(SKT, 8) void k_sk_scatter(ReadSrc s, Level lv, cons
 #undef tail
 #undef head
 
+// 16-byte elements of the k > 32 path (two-word canonical k-mers, rfx_wide.hip) go through the same
+// level kernels; their digits come from a hash of both words
+__device__ __forceinline__ uint64_t wide_hash(uint64_t hi, uint64_t lo) {
+    uint64_t x = hi ^ (lo * 0x9E3779B97F4A7C15ULL);
+    x *= 0xD6E8FEB86659FD93ULL;
+    return x ^ (x >> 32);
+}
+template <bool WIDE>
+__device__ __forceinline__ unsigned level_digit(const Rec &r, int used, int bits) {
+    if constexpr (WIDE) return bits ? (unsigned)((wide_hash(r.w0, r.w1) << used) >> (64 - bits)) : 0u;
+    else return rec_digit(rec_hdr(r), used, bits);
+}
+
 // levels >= 2 on records: virtual workgroups as for k-mers, digit from the record header
+template <bool WIDE>
 __global__ __launch_bounds__(PT) void k_rec_hist(const Rec *__restrict__ recs, VbMap m, Level lv, int used,
                                                  uint32_t *__restrict__ table) {
     __shared__ uint32_t h[1 << MAX_BITS];
@@ -1163,12 +1329,13 @@ __global__ __launch_bounds__(PT) void k_rec_hist(const Rec *__restrict__ recs, V
     for (int i = threadIdx.x; i < nb; i += PT) h[i] = 0;
     __syncthreads();
     for (uint64_t i = q.begin + threadIdx.x; i < q.end; i += PT)
-        atomicAdd(&h[rec_digit(rec_hdr(recs[i]), used, lv.bits)], 1u);
+        atomicAdd(&h[level_digit<WIDE>(recs[i], used, lv.bits)], 1u);
     __syncthreads();
     const int64_t tb = (int64_t)nb * (int64_t)m.vb_start[q.p];
     for (int i = threadIdx.x; i < nb; i += PT) table[tb + (int64_t)i * q.G + q.g] = h[i];
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(PT) void k_rec_scatter(const Rec *__restrict__ recs, VbMap m, Level lv, int used,
                                                     const uint64_t *__restrict__ scanned, Rec *__restrict__ out) {
     __shared__ unsigned long long cur[1 << MAX_BITS];
@@ -1180,7 +1347,7 @@ __global__ __launch_bounds__(PT) void k_rec_scatter(const Rec *__restrict__ recs
     __syncthreads();
     for (uint64_t i = q.begin + threadIdx.x; i < q.end; i += PT) {
         const Rec r = recs[i];
-        out[atomicAdd(&cur[rec_digit(rec_hdr(r), used, lv.bits)], 1ULL)] = r;
+        out[atomicAdd(&cur[level_digit<WIDE>(r, used, lv.bits)], 1ULL)] = r;
     }
 }
 
@@ -1193,7 +1360,7 @@ __global__ __launch_bounds__(PT) void k_rec_scatter(const Rec *__restrict__ recs
 constexpr int WCT = 1024;             // threads per workgroup (one workgroup per CU: the rings fill the LDS)
 constexpr int WC_PER = 4;             // records per thread per round
 
-template <int B>
+template <int B, bool WIDE>
 __global__ __launch_bounds__(WCT) void k_rec_scatter_wc(const Rec *__restrict__ recs, VbMap m, Level lv, int used,
                                                         const uint64_t *__restrict__ scanned, Rec *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wc_smem[];
@@ -1235,7 +1402,7 @@ __global__ __launch_bounds__(WCT) void k_rec_scatter_wc(const Rec *__restrict__ 
         for (int i = 0; i < WC_PER; i++) {
             const uint64_t idx = base + (uint64_t)i * WCT + threadIdx.x;
             if (idx < q.end) {
-                const unsigned d = rec_digit(rec_hdr(r[i]), used, lv.bits);
+                const unsigned d = level_digit<WIDE>(r[i], used, lv.bits);
                 const unsigned long long g = atomicAdd(&tail[d], 1ULL);
                 if (g - head[d] < (unsigned long long)B) buf[(size_t)d * B + (g & (B - 1))] = r[i];
                 else out[g] = r[i];
@@ -1602,11 +1769,13 @@ static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv
 
 // levels [first_level, ...) of the record path on records already bucketed by `used` bits
 // (seg offsets in *seg_cur), then the leaves.
-static int count_records_levels(rfx_ctx *ctx, const Rec *recs, int64_t n_recs, int ws_slot_of_recs,
-                                const std::vector<int> &bits, size_t first_level, int used, DevBuf *seg_cur,
-                                DevBuf *seg_next, int64_t nseg, int k, int min_cov, int max_cov, int twin,
-                                uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n,
-                                int64_t *out_distinct) {
+// the partition levels of a record array: -> the fully partitioned array and its leaf offsets
+template <bool WIDE>
+static int partition_record_levels(rfx_ctx *ctx, const Rec *recs, int64_t n_recs, int ws_slot_of_recs,
+                                   const std::vector<int> &bits, size_t first_level, int used, DevBuf **seg_cur_io,
+                                   DevBuf **seg_next_io, int64_t *nseg_io, const Rec **cur_out) {
+    DevBuf *seg_cur = *seg_cur_io, *seg_next = *seg_next_io;
+    int64_t nseg = *nseg_io;
     const Rec *cur = recs;
     int slot = ws_slot_of_recs;          // the next level writes into the other slot
     for (size_t l = first_level; l < bits.size(); l++) {
@@ -1633,7 +1802,7 @@ static int count_records_levels(rfx_ctx *ctx, const Rec *recs, int64_t n_recs, i
         const char *pn = l == 0 ? "part1" : l == 1 ? "part2" : "part3";
         {
             ScopedTimer t(ctx, hn);
-            hipLaunchKernelGGL(k_rec_hist, dim3((unsigned)v_bound), dim3(PT), 0, ctx->stream, cur, vm, lv, used,
+            hipLaunchKernelGGL(k_rec_hist<WIDE>, dim3((unsigned)v_bound), dim3(PT), 0, ctx->stream, cur, vm, lv, used,
                                table.as<uint32_t>());
             RFX_HIP(hipGetLastError());
         }
@@ -1649,16 +1818,16 @@ static int count_records_levels(rfx_ctx *ctx, const Rec *recs, int64_t n_recs, i
             const bool wc = !(getenv("RFX_WC") && atoi(getenv("RFX_WC")) == 0) && lv.bits >= 4;
             if (wc && lv.bits <= 9) {
                 const size_t lds = (size_t)nb * (16 * sizeof(Rec) + 16);
-                RFX_HIP(hipFuncSetAttribute((const void *)k_rec_scatter_wc<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(k_rec_scatter_wc<16>, dim3((unsigned)v_bound), dim3(WCT), lds, ctx->stream, cur, vm, lv,
+                RFX_HIP(hipFuncSetAttribute((const void *)k_rec_scatter_wc<16, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_rec_scatter_wc<16, WIDE>), dim3((unsigned)v_bound), dim3(WCT), lds, ctx->stream, cur, vm, lv,
                                    used, (const uint64_t *)scanned.as<uint64_t>(), dst);
             } else if (wc) {
                 const size_t lds = (size_t)nb * (8 * sizeof(Rec) + 16);
-                RFX_HIP(hipFuncSetAttribute((const void *)k_rec_scatter_wc<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(k_rec_scatter_wc<8>, dim3((unsigned)v_bound), dim3(WCT), lds, ctx->stream, cur, vm, lv,
+                RFX_HIP(hipFuncSetAttribute((const void *)k_rec_scatter_wc<8, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_rec_scatter_wc<8, WIDE>), dim3((unsigned)v_bound), dim3(WCT), lds, ctx->stream, cur, vm, lv,
                                    used, (const uint64_t *)scanned.as<uint64_t>(), dst);
             } else {
-                hipLaunchKernelGGL(k_rec_scatter, dim3((unsigned)v_bound), dim3(PT), 0, ctx->stream, cur, vm, lv, used,
+                hipLaunchKernelGGL(k_rec_scatter<WIDE>, dim3((unsigned)v_bound), dim3(PT), 0, ctx->stream, cur, vm, lv, used,
                                    (const uint64_t *)scanned.as<uint64_t>(), dst);
             }
             RFX_HIP(hipGetLastError());
@@ -1668,6 +1837,18 @@ static int count_records_levels(rfx_ctx *ctx, const Rec *recs, int64_t n_recs, i
         std::swap(seg_cur, seg_next);
         nseg = nchild;
     }
+    *seg_cur_io = seg_cur; *seg_next_io = seg_next; *nseg_io = nseg; *cur_out = cur;
+    return RFX_OK;
+}
+
+static int count_records_levels(rfx_ctx *ctx, const Rec *recs, int64_t n_recs, int ws_slot_of_recs,
+                                const std::vector<int> &bits, size_t first_level, int used, DevBuf *seg_cur,
+                                DevBuf *seg_next, int64_t nseg, int k, int min_cov, int max_cov, int twin,
+                                uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n,
+                                int64_t *out_distinct) {
+    const Rec *cur = nullptr;
+    RFX_TRY(partition_record_levels<false>(ctx, recs, n_recs, ws_slot_of_recs, bits, first_level, used, &seg_cur, &seg_next,
+                                           &nseg, &cur));
     return finish_leaves<true>(ctx, cur, n_recs, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, k, min_cov, max_cov, twin,
                                2 * k, d_out_keys, d_out_counts, cap, out_n, out_distinct);
 }
@@ -1900,6 +2081,48 @@ int count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_
     // slot -1: the caller's buffer; the first level writes workspace slot 0
     return count_records_levels(ctx, (const Rec *)d_records, n_records, 1, bits, 0, 0, &segA, &segB, 1, k, min_cov,
                                 max_cov, twin, d_out_keys, d_out_counts, cap, out_n, out_distinct);
+}
+
+// k = 33..63: n two-word canonical k-mers (16-byte elements {word0, word1}) -> distinct keys with
+// counts, unordered.  Same bucket structure as the k <= 31 record path: hash digits, exact
+// histograms, write-combining scatters, LDS-table leaves.
+int count_wide2(rfx_ctx *ctx, const void *d_elems, int64_t n, int min_cov, int max_cov, uint64_t *d_out_keys,
+                int64_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct) {
+    if (out_n) *out_n = 0;
+    if (out_distinct) *out_distinct = 0;
+    if (n <= 0) return RFX_OK;
+    std::vector<int> bits;
+    plan_levels(n, false, bits, 8192.0);             // a 4096-slot table per leaf; overflowing leaves split
+    if (bits.empty()) bits.push_back(0);
+    DevBuf segA, segB, co_buf;
+    uint64_t seg_init[2] = {0, (uint64_t)n};
+    RFX_HIP(segA.alloc(2 * 8, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(segA.p, seg_init, 16, hipMemcpyHostToDevice, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    DevBuf *seg_cur = &segA, *seg_next = &segB;
+    int64_t nseg = 1;
+    const Rec *cur = nullptr;
+    RFX_TRY(partition_record_levels<true>(ctx, (const Rec *)d_elems, n, 1, bits, 0, 0, &seg_cur, &seg_next, &nseg, &cur));
+    RFX_HIP(co_buf.alloc(sizeof(CountOut), ctx->stream));
+    RFX_HIP(hipMemsetAsync(co_buf.p, 0, sizeof(CountOut), ctx->stream));
+    {
+        ScopedTimer t(ctx, "leaf");
+        const int64_t grid = std::min<int64_t>(nseg, (int64_t)ctx->num_cu);
+        hipLaunchKernelGGL(k_leaf_count_wide, dim3((unsigned)grid), dim3(WLT), 0, ctx->stream, cur,
+                           (const uint64_t *)seg_cur->as<uint64_t>(), nseg, min_cov, max_cov, d_out_keys, d_out_counts,
+                           (unsigned long long)cap, co_buf.as<CountOut>());
+        RFX_HIP(hipGetLastError());
+    }
+    CountOut co{};
+    RFX_HIP(hipMemcpyAsync(&co, co_buf.p, sizeof co, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    if (getenv("RFX_TRACE"))
+        fprintf(stderr, "wide leaves: %lld buckets, %llu table passes, %llu overflowed\n", (long long)nseg, co.n_passes, co.n_overflow);
+    if (out_n) *out_n = (int64_t)co.n_out;
+    if (out_distinct) *out_distinct = (int64_t)co.n_distinct;
+    if (co.n_failed) { ctx->last_error = "leaf split depth exhausted"; return RFX_E_LIMIT; }
+    if ((int64_t)co.n_out > cap) return RFX_E_CAP;
+    return RFX_OK;
 }
 
 int synth_genome(rfx_ctx *ctx, uint64_t seed, int64_t genome_len, uint64_t *d_genome) {

@@ -41,7 +41,8 @@ __global__ void k_nk_per_read_w(const int64_t *__restrict__ read_off, int64_t n_
 // One wave per read, lanes over window positions; reference emission order (read, window).
 // kmer_off == nullptr: uniform reads, read r emits nk_uniform windows at r * nk_uniform.
 __global__ void k_extract_w(const uint64_t *__restrict__ words, int wpr, const uint64_t *__restrict__ kmer_off,
-                            int64_t nk_uniform, int64_t n_reads, int k, int fc, uint64_t *__restrict__ out, int64_t N) {
+                            int64_t nk_uniform, int64_t n_reads, int k, int fc, uint64_t *__restrict__ out, int64_t N,
+                            int aos) {
     const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (r >= n_reads) return;
     const int lane = lane_id();
@@ -63,7 +64,29 @@ __global__ void k_extract_w(const uint64_t *__restrict__ words, int wpr, const u
         for (int j = 0; j < W; j++) {
             if (f[j] != rc[j]) { use_f = f[j] < rc[j]; break; }
         }
-        for (int j = 0; j < W; j++) out[(int64_t)j * N + (int64_t)o + p] = use_f ? f[j] : rc[j];
+        for (int j = 0; j < W; j++) out[aos ? ((int64_t)o + p) * W + j : (int64_t)j * N + (int64_t)o + p] = use_f ? f[j] : rc[j];
+    }
+}
+
+// uniform reads: one thread per window, consecutive threads on consecutive windows (and consecutive
+// output elements); the wave-per-read form above left a third of the lanes idle on 88-window reads
+__global__ void k_extract_w_flat(const uint64_t *__restrict__ words, int wpr, int64_t nk, int64_t N, int k, int fc,
+                                 uint64_t *__restrict__ out, int aos) {
+    const int W = k / 32 + 1, res = k % 32;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / nk;
+        const int b = fc + (int)(i - r * nk);
+        const uint64_t *w = words + r * wpr;
+        uint64_t f[MAXW], rc[MAXW];
+        for (int j = 0; j < W - 1; j++) f[j] = chunk_at(w, b + 32 * j, 32);
+        f[W - 1] = chunk_at(w, b + 32 * (W - 1), res);
+        for (int j = 0; j < W - 1; j++) rc[j] = revcomp(chunk_at(w, b + k - 32 * (j + 1), 32), 32);
+        rc[W - 1] = revcomp(chunk_at(w, b, res), res);
+        bool use_f = true;
+        for (int j = 0; j < W; j++) {
+            if (f[j] != rc[j]) { use_f = f[j] < rc[j]; break; }
+        }
+        for (int j = 0; j < W; j++) out[aos ? i * W + j : (int64_t)j * N + i] = use_f ? f[j] : rc[j];
     }
 }
 
@@ -128,6 +151,17 @@ __global__ void k_emit_w(const uint64_t *__restrict__ sw, int64_t n, int W, cons
     out_counts[o] = (int64_t)(start[d + 1] - start[d]);
 }
 
+// final ordering of the fast path's survivors: (hi, lo, count) through the sorted permutation
+__global__ void k_permute_w2(const uint64_t *__restrict__ aos, const int64_t *__restrict__ cnt,
+                             const uint32_t *__restrict__ idx, int64_t m, uint64_t *__restrict__ oaos,
+                             int64_t *__restrict__ ocnt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t s = idx[i];
+    oaos[2 * i] = aos[2 * (int64_t)s]; oaos[2 * i + 1] = aos[2 * (int64_t)s + 1];
+    ocnt[i] = cnt[s];
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)std::max<int64_t>(1, ceil_div(n, 256)); }
 
 }  // namespace
@@ -149,10 +183,17 @@ int kmer_counts_per_read_w(rfx_ctx *ctx, const int64_t *d_read_off, int64_t n_re
 
 // packed reads -> canonical W-word k-mers, SoA [w*N + i]
 int extract_w(rfx_ctx *ctx, const uint64_t *d_words, int wpr, const uint64_t *d_kmer_off, int64_t nk_uniform,
-              int64_t n_reads, int k, int fc, uint64_t *d_soa, int64_t N) {
+              int64_t n_reads, int k, int fc, uint64_t *d_soa, int64_t N, int aos) {
     if (n_reads <= 0 || N <= 0) return RFX_OK;
+    if (!d_kmer_off) {
+        const int64_t blocks = std::min<int64_t>(ceil_div(N, 256), (int64_t)ctx->num_cu * 32);
+        hipLaunchKernelGGL(k_extract_w_flat, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_words, wpr, nk_uniform, N, k,
+                           fc, d_soa, aos);
+        RFX_HIP(hipGetLastError());
+        return RFX_OK;
+    }
     hipLaunchKernelGGL(k_extract_w, dim3(grid_for(n_reads * 64)), dim3(256), 0, ctx->stream, d_words, wpr, d_kmer_off,
-                       nk_uniform, n_reads, k, fc, d_soa, N);
+                       nk_uniform, n_reads, k, fc, d_soa, N, aos);
     RFX_HIP(hipGetLastError());
     return RFX_OK;
 }
@@ -171,6 +212,56 @@ int soa_to_aos(rfx_ctx *ctx, const uint64_t *d_soa, int64_t n, int W, uint64_t *
     return RFX_OK;
 }
 
+bool wide_fast_path(int k) {
+    return k / 32 + 1 == 2 && !(getenv("RFX_WIDE_SORT") && atoi(getenv("RFX_WIDE_SORT")) == 1);
+}
+
+// k = 33..63: the bucketed path (hash digits, write-combining scatters, LDS-table leaves with two-word
+// keys: rfx_kmer.hip count_wide2) on N elements {word0, word1}; the survivors are then put in
+// ascending order.
+int count_filter_w2(rfx_ctx *ctx, const uint64_t *d_elems, int64_t N, int k, int min_cov, int max_cov,
+                    uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct) {
+    *out_n = 0;
+    if (out_distinct) *out_distinct = 0;
+    if (N <= 0) return RFX_OK;
+    if (N >= (1LL << 32)) { ctx->last_error = "k > 31 count: at most 2^32-1 instances per call"; return RFX_E_ARG; }
+    const int res = k % 32;
+    int64_t m = 0;
+    const int st = count_wide2(ctx, d_elems, N, min_cov, max_cov, d_out_keys, d_out_counts, cap, &m, out_distinct);
+    *out_n = m;
+    if (st != RFX_OK) return st;
+    if (m <= 1) return RFX_OK;
+    if (m >= (1LL << 32)) { ctx->last_error = "k > 31 count: too many survivors to order"; return RFX_E_LIMIT; }
+    ScopedTimer t(ctx, "sort");
+    DevBuf soa, idx, idx2, keys, keys2, oaos, ocnt;
+    RFX_HIP(soa.alloc((size_t)m * 16, ctx->stream));
+    RFX_HIP(idx.alloc((size_t)m * 4, ctx->stream));
+    RFX_HIP(idx2.alloc((size_t)m * 4, ctx->stream));
+    RFX_HIP(keys.alloc((size_t)m * 8, ctx->stream));
+    RFX_HIP(keys2.alloc((size_t)m * 8, ctx->stream));
+    RFX_TRY(aos_to_soa(ctx, d_out_keys, m, 2, soa.as<uint64_t>()));
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(m)), dim3(256), 0, ctx->stream, idx.as<uint32_t>(), m);
+    RFX_HIP(hipGetLastError());
+    for (int w = 1; w >= 0; w--) {
+        hipLaunchKernelGGL(k_gather_u64, dim3(grid_for(m)), dim3(256), 0, ctx->stream, soa.as<uint64_t>() + (int64_t)w * m,
+                           (const uint32_t *)idx.as<uint32_t>(), m, keys.as<uint64_t>());
+        RFX_HIP(hipGetLastError());
+        RFX_TRY(sort_pairs(ctx, keys.as<uint64_t>(), idx.as<uint32_t>(), m, w == 1 ? 2 * res : 64, keys2.as<uint64_t>(),
+                           idx2.as<uint32_t>()));
+    }
+    RFX_HIP(oaos.alloc((size_t)m * 16, ctx->stream));
+    RFX_HIP(ocnt.alloc((size_t)m * 8, ctx->stream));
+    hipLaunchKernelGGL(k_permute_w2, dim3(grid_for(m)), dim3(256), 0, ctx->stream, (const uint64_t *)d_out_keys,
+                       (const int64_t *)d_out_counts, (const uint32_t *)idx.as<uint32_t>(), m, oaos.as<uint64_t>(),
+                       ocnt.as<int64_t>());
+    RFX_HIP(hipGetLastError());
+    RFX_HIP(hipMemcpyAsync(d_out_keys, oaos.p, (size_t)m * 16, hipMemcpyDeviceToDevice, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(d_out_counts, ocnt.p, (size_t)m * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    t.stop();
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    return RFX_OK;
+}
+
 // groupBy + count + filter on N W-word k-mers (SoA, destroyed).  d_out_keys: cap*W words (AoS,
 // ascending by base string), d_out_counts: cap int64.
 int count_filter_w(rfx_ctx *ctx, uint64_t *d_soa, int64_t N, int k, int min_cov, int max_cov, uint64_t *d_out_keys,
@@ -180,6 +271,13 @@ int count_filter_w(rfx_ctx *ctx, uint64_t *d_soa, int64_t N, int k, int min_cov,
     if (N <= 0) return RFX_OK;
     if (N >= (1LL << 32)) { ctx->last_error = "k > 31 count: at most 2^32-1 instances per call"; return RFX_E_ARG; }
     const int W = k / 32 + 1, res = k % 32;
+    if (wide_fast_path(k)) {
+        DevBuf elems;
+        RFX_HIP(elems.alloc((size_t)N * 16, ctx->stream));
+        RFX_TRY(soa_to_aos(ctx, d_soa, N, 2, elems.as<uint64_t>()));
+        return count_filter_w2(ctx, elems.as<uint64_t>(), N, k, min_cov, max_cov, d_out_keys, d_out_counts, cap, out_n,
+                               out_distinct);
+    }
     DevBuf idx, idx2, keys, keys2, sorted, head, pos;
     RFX_HIP(idx.alloc((size_t)N * 4, ctx->stream));
     RFX_HIP(idx2.alloc((size_t)N * 4, ctx->stream));

@@ -313,6 +313,17 @@ int rfx_dev_count_reads_w(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads
     const int64_t N = nk * n_reads;
     if (out_instances) *out_instances = N;
     if (N == 0) return RFX_OK;
+    if (wide_fast_path(k) && !getenv("RFX_WIDE_MATERIALIZE")) {
+        // level 1 straight from the packed reads: the 16-byte elements are never written unpartitioned
+        int64_t m = 0;
+        int st = count_wide2_reads(ctx, d_words, n_reads, words_per_read, nk, k, front_clip, min_cov, max_cov, d_out_keys,
+                                   d_out_counts, cap, &m, out_distinct);
+        *out_n = m;
+        if (st == RFX_OK) st = order_wide2(ctx, d_out_keys, d_out_counts, m, k);
+        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        ScopedTimer::collect(ctx);
+        return st;
+    }
     DevBuf d_soa;
     RFX_HIP(d_soa.alloc((size_t)N * W * 8, ctx->stream));
     const bool fast = wide_fast_path(k);

@@ -180,6 +180,9 @@ int count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_
                   int64_t *out_n, int64_t *out_distinct);
 int count_wide2(rfx_ctx *ctx, const void *d_elems, int64_t n, int min_cov, int max_cov, uint64_t *d_out_keys,
                 int64_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct);
+int count_wide2_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,
+                      int min_cov, int max_cov, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n,
+                      int64_t *out_distinct);
 int synth_genome(rfx_ctx *ctx, uint64_t seed, int64_t genome_len, uint64_t *d_genome);
 int synth_reads(rfx_ctx *ctx, uint64_t seed, const uint64_t *d_genome, int64_t genome_len,
                 int64_t first_read, int64_t n_reads, int read_len, uint32_t err, int words_per_read,
@@ -193,6 +196,7 @@ int kmer_counts_per_read_w(rfx_ctx *ctx, const int64_t *d_read_off, int64_t n_re
 int extract_w(rfx_ctx *ctx, const uint64_t *d_words, int wpr, const uint64_t *d_kmer_off, int64_t nk_uniform,
               int64_t n_reads, int k, int fc, uint64_t *d_soa, int64_t N, int aos = 0);
 bool wide_fast_path(int k);
+int order_wide2(rfx_ctx *ctx, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t m, int k);
 int count_filter_w2(rfx_ctx *ctx, const uint64_t *d_elems, int64_t N, int k, int min_cov, int max_cov,
                     uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct);
 int aos_to_soa(rfx_ctx *ctx, const uint64_t *d_aos, int64_t n, int W, uint64_t *d_soa);

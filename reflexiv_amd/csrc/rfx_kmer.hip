@@ -1415,6 +1415,113 @@ __global__ __launch_bounds__(WCT) void k_rec_scatter_wc(const Rec *__restrict__ 
     drain(true);
 }
 
+// ---- level 1 of the k = 33..63 path straight from the packed reads (uniform length): a thread owns
+// 16 consecutive windows of one read and rolls the two-word k-mer and its reverse complement through
+// them; the histogram kernel counts digits, the scatter kernel feeds write-combining rings (drained
+// every W2_STEPS windows).  The 16-byte elements are never written unpartitioned.
+struct WideSrc { const uint64_t *words; int64_t n_reads, nk, segs, total; int wpr, k, fc; };
+constexpr int W2SEG = 16, W2_STEPS = 4, W2T = 1024, W2B = 16, W2A = 4;
+
+struct W2State { uint64_t f0, f1, r0, r1, nxt; int v, j; };
+
+__device__ __forceinline__ void w2_init(const WideSrc &s, int64_t g, W2State &st) {
+    st.v = 0; st.j = 0;
+    if (g >= s.total) return;
+    const int64_t r = g / s.segs;
+    const int p0 = (int)(g - r * s.segs) * W2SEG;
+    int v = (int)(s.nk - p0);
+    v = v > W2SEG ? W2SEG : v;
+    const int res = s.k - 32;
+    const uint64_t *w = s.words + r * s.wpr;
+    const int b = s.fc + p0;
+    st.f0 = kmer_at(w, b, 32); st.f1 = kmer_at(w, b + 32, res);
+    st.r0 = revcomp(kmer_at(w, b + s.k - 32, 32), 32); st.r1 = revcomp(kmer_at(w, b, res), res);
+    st.nxt = v > 1 ? kmer_at(w, b + s.k, v - 1) : 0;
+    st.v = v;
+}
+// canonical element of the current window, then roll one base on
+__device__ __forceinline__ Rec w2_step(W2State &st, int res, uint64_t mres) {
+    const bool use_f = st.f0 != st.r0 ? st.f0 < st.r0 : st.f1 <= st.r1;          // ties -> forward
+    const Rec e{use_f ? st.f0 : st.r0, use_f ? st.f1 : st.r1};
+    if (st.j + 1 < st.v) {
+        const uint64_t nb = (st.nxt >> (2 * (st.v - 2 - st.j))) & 3;
+        const uint64_t cf = st.f1 >> (2 * (res - 1));
+        st.f1 = ((st.f1 << 2) | nb) & mres;
+        st.f0 = (st.f0 << 2) | cf;
+        const uint64_t cr = st.r0 & 3;
+        st.r0 = (st.r0 >> 2) | ((nb ^ 3) << 62);
+        st.r1 = (st.r1 >> 2) | (cr << (2 * (res - 1)));
+    }
+    st.j++;
+    return e;
+}
+
+__global__ __launch_bounds__(W2T) void k_w2_hist(WideSrc s, Level lv, uint64_t *__restrict__ blockhist) {
+    __shared__ uint32_t h[1 << MAX_BITS];
+    const int nb = 1 << lv.bits;
+    for (int i = threadIdx.x; i < nb; i += W2T) h[i] = 0;
+    __syncthreads();
+    const int res = s.k - 32;
+    const uint64_t mres = low_mask(res);
+    for (int64_t g = (int64_t)blockIdx.x * W2T + threadIdx.x; g < s.total; g += (int64_t)gridDim.x * W2T) {
+        W2State st;
+        w2_init(s, g, st);
+        while (st.j < st.v) atomicAdd(&h[level_digit<true>(w2_step(st, res, mres), 0, lv.bits)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += W2T) blockhist[(int64_t)i * gridDim.x + blockIdx.x] = h[i];
+}
+
+__global__ __launch_bounds__(W2T) void k_w2_scatter(WideSrc s, Level lv, const uint64_t *__restrict__ scanned,
+                                                    Rec *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char w2_smem[];
+    const int nb = 1 << lv.bits;
+#define buf ((Rec *)w2_smem)
+#define tail ((unsigned long long *)(w2_smem + (size_t)nb * W2B * sizeof(Rec)))
+#define head (tail + nb)
+    for (int i = threadIdx.x; i < nb; i += W2T) tail[i] = head[i] = scanned[(int64_t)i * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const int res = s.k - 32;
+    const uint64_t mres = low_mask(res);
+    const int64_t stride = (int64_t)gridDim.x * W2T;
+    for (int64_t gb = (int64_t)blockIdx.x * W2T; gb < s.total; gb += stride) {
+        W2State st;
+        w2_init(s, gb + threadIdx.x, st);
+        for (int blk = 0; blk < W2SEG / W2_STEPS; blk++) {
+#pragma unroll
+            for (int q = 0; q < W2_STEPS; q++) {
+                if (st.j < st.v) {
+                    const Rec e = w2_step(st, res, mres);
+                    const unsigned d = level_digit<true>(e, 0, lv.bits);
+                    const unsigned long long pos = atomicAdd(&tail[d], 1ULL);
+                    if (pos - head[d] < (unsigned long long)W2B) buf[(size_t)d * W2B + (pos & (W2B - 1))] = e;
+                    else out[pos] = e;
+                }
+            }
+            __syncthreads();
+            const bool final = gb + stride >= s.total && blk == W2SEG / W2_STEPS - 1;
+            for (int d = threadIdx.x / W2B; d < nb; d += W2T / W2B) {
+                const int j = threadIdx.x % W2B;
+                const unsigned long long h = head[d], t = tail[d];
+                unsigned long long e, nh;
+                if (t - h > (unsigned long long)W2B) { e = h + W2B; nh = t; }
+                else {
+                    e = final ? t : (t & ~(unsigned long long)(W2A - 1));
+                    if (e < h) e = h;
+                    nh = e;
+                }
+                const unsigned long long g = h + j;
+                if (g < e) out[g] = buf[(size_t)d * W2B + (g & (W2B - 1))];
+                if (j == 0) head[d] = nh;
+            }
+            __syncthreads();
+        }
+    }
+#undef buf
+#undef tail
+#undef head
+}
+
 // ------------------------------------------------------------ synthetic reads
 
 constexpr uint64_t TAG_GENOME = 0x47454E4F4D45ULL, TAG_PAIRS = 0x5041495253ULL, TAG_ERRORS = 0x4552524F5253ULL;
@@ -2083,34 +2190,16 @@ int count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_
                                 max_cov, twin, d_out_keys, d_out_counts, cap, out_n, out_distinct);
 }
 
-// k = 33..63: n two-word canonical k-mers (16-byte elements {word0, word1}) -> distinct keys with
-// counts, unordered.  Same bucket structure as the k <= 31 record path: hash digits, exact
-// histograms, write-combining scatters, LDS-table leaves.
-int count_wide2(rfx_ctx *ctx, const void *d_elems, int64_t n, int min_cov, int max_cov, uint64_t *d_out_keys,
-                int64_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct) {
-    if (out_n) *out_n = 0;
-    if (out_distinct) *out_distinct = 0;
-    if (n <= 0) return RFX_OK;
-    std::vector<int> bits;
-    plan_levels(n, false, bits, 8192.0);             // a 4096-slot table per leaf; overflowing leaves split
-    if (bits.empty()) bits.push_back(0);
-    DevBuf segA, segB, co_buf;
-    uint64_t seg_init[2] = {0, (uint64_t)n};
-    RFX_HIP(segA.alloc(2 * 8, ctx->stream));
-    RFX_HIP(hipMemcpyAsync(segA.p, seg_init, 16, hipMemcpyHostToDevice, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
-    DevBuf *seg_cur = &segA, *seg_next = &segB;
-    int64_t nseg = 1;
-    const Rec *cur = nullptr;
-    RFX_TRY(partition_record_levels<true>(ctx, (const Rec *)d_elems, n, 1, bits, 0, 0, &seg_cur, &seg_next, &nseg, &cur));
+static int finish_wide2(rfx_ctx *ctx, const Rec *cur, const uint64_t *d_leaf_off, int64_t nseg, int min_cov, int max_cov,
+                        uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct) {
+    DevBuf co_buf;
     RFX_HIP(co_buf.alloc(sizeof(CountOut), ctx->stream));
     RFX_HIP(hipMemsetAsync(co_buf.p, 0, sizeof(CountOut), ctx->stream));
     {
         ScopedTimer t(ctx, "leaf");
         const int64_t grid = std::min<int64_t>(nseg, (int64_t)ctx->num_cu);
-        hipLaunchKernelGGL(k_leaf_count_wide, dim3((unsigned)grid), dim3(WLT), 0, ctx->stream, cur,
-                           (const uint64_t *)seg_cur->as<uint64_t>(), nseg, min_cov, max_cov, d_out_keys, d_out_counts,
-                           (unsigned long long)cap, co_buf.as<CountOut>());
+        hipLaunchKernelGGL(k_leaf_count_wide, dim3((unsigned)grid), dim3(WLT), 0, ctx->stream, cur, d_leaf_off, nseg, min_cov,
+                           max_cov, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>());
         RFX_HIP(hipGetLastError());
     }
     CountOut co{};
@@ -2123,6 +2212,83 @@ int count_wide2(rfx_ctx *ctx, const void *d_elems, int64_t n, int min_cov, int m
     if (co.n_failed) { ctx->last_error = "leaf split depth exhausted"; return RFX_E_LIMIT; }
     if ((int64_t)co.n_out > cap) return RFX_E_CAP;
     return RFX_OK;
+}
+
+// k = 33..63: n two-word canonical k-mers (16-byte elements {word0, word1}) -> distinct keys with
+// counts, unordered.  Same bucket structure as the k <= 31 record path: hash digits, exact
+// histograms, write-combining scatters, LDS-table leaves.
+int count_wide2(rfx_ctx *ctx, const void *d_elems, int64_t n, int min_cov, int max_cov, uint64_t *d_out_keys,
+                int64_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct) {
+    if (out_n) *out_n = 0;
+    if (out_distinct) *out_distinct = 0;
+    if (n <= 0) return RFX_OK;
+    std::vector<int> bits;
+    plan_levels(n, false, bits, 8192.0);             // a 4096-slot table per leaf; overflowing leaves split
+    if (bits.empty()) bits.push_back(0);
+    DevBuf segA, segB;
+    uint64_t seg_init[2] = {0, (uint64_t)n};
+    RFX_HIP(segA.alloc(2 * 8, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(segA.p, seg_init, 16, hipMemcpyHostToDevice, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    DevBuf *seg_cur = &segA, *seg_next = &segB;
+    int64_t nseg = 1;
+    const Rec *cur = nullptr;
+    RFX_TRY(partition_record_levels<true>(ctx, (const Rec *)d_elems, n, 1, bits, 0, 0, &seg_cur, &seg_next, &nseg, &cur));
+    return finish_wide2(ctx, cur, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, min_cov, max_cov, d_out_keys, d_out_counts,
+                        cap, out_n, out_distinct);
+}
+
+// k = 33..63 from packed uniform reads: level 1 straight from the reads, then count_wide2's levels/leaves
+int count_wide2_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,
+                      int min_cov, int max_cov, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n,
+                      int64_t *out_distinct) {
+    if (out_n) *out_n = 0;
+    if (out_distinct) *out_distinct = 0;
+    const int64_t n = nk * n_reads;
+    if (n <= 0) return RFX_OK;
+    std::vector<int> bits;
+    plan_levels(n, true, bits, 8192.0);
+    if (bits[0] > 9) {                               // the level-1 rings hold 512 bins: move the excess down
+        const int extra = bits[0] - 9;
+        bits[0] = 9;
+        if (bits.size() == 1) bits.push_back(extra); else bits[1] += extra;
+        if (bits[1] > MAX_BITS) { bits.push_back(bits[1] - MAX_BITS); bits[1] = MAX_BITS; }
+    }
+    Level lv{};
+    lv.bits = bits[0];
+    const int nb = 1 << lv.bits;
+    WideSrc ws{d_words, n_reads, nk, ceil_div(nk, W2SEG), 0, wpr, k, fc};
+    ws.total = n_reads * ws.segs;
+    const unsigned G = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(ws.total, W2T), (int64_t)ctx->num_cu));
+    DevBuf bh, scanned, segA, segB, co_buf;
+    RFX_HIP(bh.alloc((size_t)nb * G * 8, ctx->stream));
+    RFX_HIP(scanned.alloc(((size_t)nb * G + 1) * 8, ctx->stream));
+    RFX_HIP(segA.alloc(((size_t)nb + 1) * 8, ctx->stream));
+    {
+        ScopedTimer t(ctx, "hist1");
+        hipLaunchKernelGGL(k_w2_hist, dim3(G), dim3(W2T), 0, ctx->stream, ws, lv, bh.as<uint64_t>());
+        RFX_HIP(hipGetLastError());
+    }
+    RFX_TRY(exclusive_scan_u64(ctx, bh.as<uint64_t>(), scanned.as<uint64_t>(), (int64_t)nb * G));
+    hipLaunchKernelGGL(k_bin_offsets, dim3((unsigned)ceil_div(nb + 1, 256)), dim3(256), 0, ctx->stream,
+                       (const uint64_t *)scanned.as<uint64_t>(), nb, (int64_t)G, segA.as<uint64_t>());
+    RFX_HIP(hipGetLastError());
+    Rec *dst = (Rec *)ctx->ws_get(0, (size_t)n * sizeof(Rec));
+    if (!dst) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
+    {
+        ScopedTimer t(ctx, "part1");
+        const size_t lds = (size_t)nb * (W2B * sizeof(Rec) + 16);
+        RFX_HIP(hipFuncSetAttribute((const void *)k_w2_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_w2_scatter, dim3(G), dim3(W2T), lds, ctx->stream, ws, lv, (const uint64_t *)scanned.as<uint64_t>(),
+                           dst);
+        RFX_HIP(hipGetLastError());
+    }
+    DevBuf *seg_cur = &segA, *seg_next = &segB;
+    int64_t nseg = nb;
+    const Rec *cur = nullptr;
+    RFX_TRY(partition_record_levels<true>(ctx, dst, n, 0, bits, 1, lv.bits, &seg_cur, &seg_next, &nseg, &cur));
+    return finish_wide2(ctx, cur, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, min_cov, max_cov, d_out_keys, d_out_counts,
+                        cap, out_n, out_distinct);
 }
 
 int synth_genome(rfx_ctx *ctx, uint64_t seed, int64_t genome_len, uint64_t *d_genome) {

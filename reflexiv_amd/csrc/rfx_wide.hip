@@ -90,6 +90,44 @@ __global__ void k_extract_w_flat(const uint64_t *__restrict__ words, int wpr, in
     }
 }
 
+// k = 33..63, uniform reads: a thread owns 16 consecutive windows of one read and ROLLS the two-word
+// k-mer and its reverse complement through them (one base in, one out on both strands: a dozen
+// operations per window instead of four funnel-shifted chunks and two full reverse complements).
+constexpr int WSEG = 16;
+__global__ __launch_bounds__(256) void k_extract_w2_roll(const uint64_t *__restrict__ words, int wpr, int64_t nk, int64_t n_reads,
+                                                         int k, int fc, uint64_t *__restrict__ out /* AoS */) {
+    const int res = k - 32;                          // bases in the second word, 1..31
+    const int64_t segs = (nk + WSEG - 1) / WSEG;
+    const int64_t total = n_reads * segs;
+    const uint64_t mres = low_mask(res);
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = g / segs;
+        const int p0 = (int)(g - r * segs) * WSEG;
+        int v = (int)(nk - p0);
+        v = v > WSEG ? WSEG : v;
+        const uint64_t *w = words + r * wpr;
+        const int b = fc + p0;
+        uint64_t f0 = chunk_at(w, b, 32), f1 = chunk_at(w, b + 32, res);
+        uint64_t r0 = revcomp(chunk_at(w, b + k - 32, 32), 32), r1 = revcomp(chunk_at(w, b, res), res);
+        const uint64_t nxt = v > 1 ? chunk_at(w, b + k, v - 1) : 0;      // the v-1 bases that enter, right-aligned
+        uint64_t *o = out + 2 * (r * nk + p0);
+        for (int j = 0; j < v; j++) {
+            const bool use_f = f0 != r0 ? f0 < r0 : f1 <= r1;            // ties -> forward
+            o[2 * j] = use_f ? f0 : r0;
+            o[2 * j + 1] = use_f ? f1 : r1;
+            if (j + 1 < v) {
+                const uint64_t nb = (nxt >> (2 * (v - 2 - j))) & 3;
+                const uint64_t cf = f1 >> (2 * (res - 1));
+                f1 = ((f1 << 2) | nb) & mres;
+                f0 = (f0 << 2) | cf;
+                const uint64_t cr = r0 & 3;
+                r0 = (r0 >> 2) | ((nb ^ 3) << 62);
+                r1 = (r1 >> 2) | (cr << (2 * (res - 1)));
+            }
+        }
+    }
+}
+
 __global__ void k_iota(uint32_t *__restrict__ idx, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) idx[i] = (uint32_t)i;
@@ -185,6 +223,14 @@ int kmer_counts_per_read_w(rfx_ctx *ctx, const int64_t *d_read_off, int64_t n_re
 int extract_w(rfx_ctx *ctx, const uint64_t *d_words, int wpr, const uint64_t *d_kmer_off, int64_t nk_uniform,
               int64_t n_reads, int k, int fc, uint64_t *d_soa, int64_t N, int aos) {
     if (n_reads <= 0 || N <= 0) return RFX_OK;
+    if (!d_kmer_off && aos && k / 32 + 1 == 2 && !getenv("RFX_WIDE_NOROLL")) {
+        const int64_t total = n_reads * ceil_div(nk_uniform, WSEG);
+        const int64_t blocks = std::min<int64_t>(ceil_div(total, 256), (int64_t)ctx->num_cu * 32);
+        hipLaunchKernelGGL(k_extract_w2_roll, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_words, wpr, nk_uniform,
+                           n_reads, k, fc, d_soa);
+        RFX_HIP(hipGetLastError());
+        return RFX_OK;
+    }
     if (!d_kmer_off) {
         const int64_t blocks = std::min<int64_t>(ceil_div(N, 256), (int64_t)ctx->num_cu * 32);
         hipLaunchKernelGGL(k_extract_w_flat, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_words, wpr, nk_uniform, N, k,
@@ -225,13 +271,18 @@ int count_filter_w2(rfx_ctx *ctx, const uint64_t *d_elems, int64_t N, int k, int
     if (out_distinct) *out_distinct = 0;
     if (N <= 0) return RFX_OK;
     if (N >= (1LL << 32)) { ctx->last_error = "k > 31 count: at most 2^32-1 instances per call"; return RFX_E_ARG; }
-    const int res = k % 32;
     int64_t m = 0;
     const int st = count_wide2(ctx, d_elems, N, min_cov, max_cov, d_out_keys, d_out_counts, cap, &m, out_distinct);
     *out_n = m;
     if (st != RFX_OK) return st;
+    return order_wide2(ctx, d_out_keys, d_out_counts, m, k);
+}
+
+// survivors of the fast path (unordered, AoS) -> ascending by (word0, word1)
+int order_wide2(rfx_ctx *ctx, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t m, int k) {
     if (m <= 1) return RFX_OK;
     if (m >= (1LL << 32)) { ctx->last_error = "k > 31 count: too many survivors to order"; return RFX_E_LIMIT; }
+    const int res = k % 32;
     ScopedTimer t(ctx, "sort");
     DevBuf soa, idx, idx2, keys, keys2, oaos, ocnt;
     RFX_HIP(soa.alloc((size_t)m * 16, ctx->stream));

@@ -886,3 +886,32 @@ def test_cpp_host_resident_run(tmp_path, ex, planted, twin):
     subprocess.check_call([host, "run", "--resident", "-fastq", fq2, "-outfile", out2, "-kmer", "31", "-cover", "2",
                            "-mincontig", "100", "--logical-partitions", "4", "--twin", twin])
     assert open(os.path.join(out2, "part-00000")).read() == str(planted[f"k31_{twin}_contigs"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [63, 33])
+def test_wide_count_survives_extreme_skew(rfx, torch_mod, k):
+    """k > 31 fast path under low-complexity input (poly-A, dinucleotide repeats, duplicated reads)."""
+    torch = torch_mod
+    L = 150
+    rng = np.random.default_rng(k)
+    one = "".join(rng.choice(list("ACGT"), size=L))
+    reads = ["A" * L] * 6000 + ["AC" * (L // 2)] * 3000 + [one] * 3000 + ["T" * L] * 1500 + \
+            ["".join(rng.choice(list("ACGT"), size=L)) for _ in range(1500)]
+    rng.shuffle(reads)
+    n = len(reads)
+    bases = np.frombuffer("".join(reads).encode(), np.uint8)
+    off = np.arange(n + 1, dtype=np.int64) * L
+    wpr = (L + 31) // 32
+    db = torch.from_numpy(bases.copy()).cuda(); do = torch.from_numpy(off).cuda()
+    dw = torch.empty(n * wpr, dtype=torch.int64, device="cuda")
+    N = rfx.kmers_per_read_w(L, k) * n
+    dk = torch.empty(2 * N, dtype=torch.int64, device="cuda"); dc = torch.empty(N, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    rfx.encode_reads_dev(db.data_ptr(), do.data_ptr(), n, wpr, dw.data_ptr())
+    m, nd, inst = rfx.count_reads_w_dev(dw.data_ptr(), n, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, 2)
+    km = O.extract_canon_w(bases, off, k)
+    wk, wc, wd = O.count_filter_w(km, k, 2)
+    assert inst == len(km) and nd == wd and m == len(wk)
+    assert np.array_equal(dk[:2 * m].cpu().numpy().view(np.uint64).reshape(m, 2), wk)
+    assert np.array_equal(dc[:m].cpu().numpy(), wc)

@@ -29,8 +29,7 @@ using namespace rfxd;
 namespace {
 
 constexpr int32_t BLOCKED = INT32_MIN;
-constexpr int EMIT_SHORT = 8;           // words a single thread emits before queueing the record
-constexpr int EMIT_HUGE = 8192;         // words beyond which the whole grid shares one record
+constexpr int EMIT_SHORT = 2;           // words the record's own thread emits; longer ones go word-parallel
 
 struct Desc {          // one emission
     uint32_t a, b;     // flip: a = source; merge: a = reflected source R, b = forward source F
@@ -157,9 +156,7 @@ __global__ void k_emit(const Desc *__restrict__ desc, const uint32_t *__restrict
                        const int64_t *__restrict__ ext_off, const uint64_t *__restrict__ ext,
                        const uint32_t *__restrict__ len,
                        uint64_t *__restrict__ okey, int32_t *__restrict__ omarker, int64_t *__restrict__ oext_off,
-                       uint64_t *__restrict__ oext, int32_t *__restrict__ oleft, int32_t *__restrict__ oright,
-                       uint32_t *__restrict__ long_list, uint32_t *__restrict__ huge_list,
-                       unsigned long long *__restrict__ long_n) {
+                       uint64_t *__restrict__ oext, int32_t *__restrict__ oleft, int32_t *__restrict__ oright) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == n) { oext_off[oidx[n]] = (int64_t)owoff[n]; return; }
     if (i > n || !flag[i]) return;
@@ -184,8 +181,7 @@ __global__ void k_emit(const Desc *__restrict__ desc, const uint32_t *__restrict
     else for (int t = 0; t < sub; t++) kk = (kk << 2) | out_base(s, sub, kshift + t);
     okey[j] = kk;
     const int64_t nw = (L + 30) / 31;
-    if (nw > EMIT_HUGE) { huge_list[atomicAdd(long_n + 1, 1ULL)] = (uint32_t)i; return; }   // whole grid per record
-    if (nw > EMIT_SHORT) { long_list[atomicAdd(long_n, 1ULL)] = (uint32_t)i; return; }       // one workgroup per record
+    if (nw > EMIT_SHORT) return;                     // k_emit_words: one thread per output word
     if (d.type == 1 && s.a.marker == m) {            // same orientation: the words are unchanged
         for (int64_t w = 0; w < nw; w++) oext[wo + w] = s.a.w[w];
         return;
@@ -193,38 +189,36 @@ __global__ void k_emit(const Desc *__restrict__ desc, const uint32_t *__restrict
     emit_words(s, sub, m == 1 ? sub : 0, L, 0, nw, 1, oext + wo);
 }
 
-__global__ void k_emit_long(const Desc *__restrict__ desc, const uint64_t *__restrict__ oidx,
-                            const uint64_t *__restrict__ owoff, const int64_t *__restrict__ ps, int P, int sub,
-                            const uint64_t *__restrict__ key, const int32_t *__restrict__ marker,
-                            const int64_t *__restrict__ ext_off, const uint64_t *__restrict__ ext,
-                            const uint32_t *__restrict__ len, uint64_t *__restrict__ oext,
-                            const uint32_t *__restrict__ long_list, const uint32_t *__restrict__ huge_list,
-                            const unsigned long long *__restrict__ long_n) {
-    // words [first, first+step, ...) of emission i
-    auto emit_record = [&](int64_t i, int64_t first, int64_t step) {
-        const Desc d = desc[i];
-        const int64_t j = (int64_t)oidx[i];
-        const int p = part_of(ps, P, i);
-        const int m = ((j - (int64_t)oidx[ps[p]]) & 1) ? 1 : 2;
-        OutSeq s;
-        s.type = (int)d.type;
-        s.a = load_src(d.a, key, marker, ext_off, ext, len);
-        s.lenSa = s.a.len + sub;
-        if (d.type == 2) s.b = load_src(d.b, key, marker, ext_off, ext, len); else s.b = s.a;
-        const int64_t L = d.len, nw = (L + 30) / 31, wo = (int64_t)owoff[i];
-        if (d.type == 1 && s.a.marker == m) {
-            for (int64_t w = first; w < nw; w += step) oext[wo + w] = s.a.w[w];
-        } else {
-            emit_words(s, sub, m == 1 ? sub : 0, L, first, nw, step, oext + wo);
-        }
-    };
-    // medium records: one workgroup each
-    const unsigned long long cnt = long_n[0];
-    for (unsigned long long e = blockIdx.x; e < cnt; e += gridDim.x) emit_record(long_list[e], threadIdx.x, blockDim.x);
-    // huge records (a 2.6 Mbp contig is 84 K words): every workgroup takes a slice of each
-    const unsigned long long hcnt = long_n[1];
-    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (unsigned long long e = 0; e < hcnt; e++) emit_record(huge_list[e], gtid, (int64_t)gridDim.x * blockDim.x);
+// Extensions longer than EMIT_SHORT words, one thread per OUTPUT WORD: thread t finds the emission
+// that owns word t of the output array by a binary search in the word-offset scan (zero-length
+// entries share their successor's offset, so the last entry with offset <= t is the owner) and
+// writes that one word.  A 2.6 Mbp contig (84 K words) is 84 K threads; no per-record queues.
+__global__ void k_emit_words(const Desc *__restrict__ desc, const uint64_t *__restrict__ oidx,
+                             const uint64_t *__restrict__ owoff, int64_t n, const int64_t *__restrict__ ps, int P, int sub,
+                             const uint64_t *__restrict__ key, const int32_t *__restrict__ marker,
+                             const int64_t *__restrict__ ext_off, const uint64_t *__restrict__ ext,
+                             const uint32_t *__restrict__ len, uint64_t *__restrict__ oext) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)owoff[n]) return;
+    int64_t lo = 0, hi = n;                          // owoff[lo] <= t < owoff[hi]
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)owoff[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int64_t i = lo;
+    const Desc d = desc[i];
+    const int64_t L = d.len, nw = (L + 30) / 31, wo = (int64_t)owoff[i], w = t - wo;
+    if (nw <= EMIT_SHORT) return;                    // k_emit wrote it
+    const int64_t j = (int64_t)oidx[i];
+    const int p = part_of(ps, P, i);
+    const int m = ((j - (int64_t)oidx[ps[p]]) & 1) ? 1 : 2;
+    OutSeq s;
+    s.type = (int)d.type;
+    s.a = load_src(d.a, key, marker, ext_off, ext, len);
+    s.lenSa = s.a.len + sub;
+    if (d.type == 2) s.b = load_src(d.b, key, marker, ext_off, ext, len); else s.b = s.a;
+    if (d.type == 1 && s.a.marker == m) oext[wo + w] = s.a.w[w];
+    else emit_words(s, sub, m == 1 ? sub : 0, L, w, w + 1, 1, oext + wo);
 }
 
 // output partition starts + the pass summary the host reads back in ONE copy:
@@ -250,7 +244,7 @@ int extend_pass(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start,
     if (n > (int64_t)0xFFFFFFFFLL) return RFX_E_LIMIT;
     RFX_TRY(dev_records_alloc(ctx, out, n, in.words));
     RFX_HIP(out_part_start.alloc((size_t)(P + 1) * 8, ctx->stream));
-    DevBuf len, desc, flag, onw, oidx, owoff, long_list, huge_list, long_n, status;
+    DevBuf len, desc, flag, onw, oidx, owoff, status;
     const int64_t a = n ? n : 1;
     RFX_HIP(len.alloc((size_t)a * 4, ctx->stream));
     RFX_HIP(desc.alloc((size_t)a * sizeof(Desc), ctx->stream));
@@ -258,11 +252,7 @@ int extend_pass(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start,
     RFX_HIP(onw.alloc((size_t)a * 4, ctx->stream));
     RFX_HIP(oidx.alloc((size_t)(n + 1) * 8, ctx->stream));
     RFX_HIP(owoff.alloc((size_t)(n + 1) * 8, ctx->stream));
-    RFX_HIP(long_list.alloc((size_t)a * 4, ctx->stream));
-    RFX_HIP(huge_list.alloc((size_t)(in.words / EMIT_HUGE + 1) * 4, ctx->stream));
-    RFX_HIP(long_n.alloc(16, ctx->stream));
     RFX_HIP(status.alloc(4, ctx->stream));
-    RFX_HIP(hipMemsetAsync(long_n.p, 0, 16, ctx->stream));
     RFX_HIP(hipMemsetAsync(status.p, 0, 4, ctx->stream));
     if (n > 0) {
         hipLaunchKernelGGL(k_ext_len, dim3(grid_for(n)), dim3(256), 0, ctx->stream,
@@ -285,18 +275,14 @@ int extend_pass(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start,
                        (const int64_t *)in.ext_off.as<int64_t>(), (const uint64_t *)in.ext.as<uint64_t>(),
                        (const uint32_t *)len.as<uint32_t>(), out.key.as<uint64_t>(), out.marker.as<int32_t>(),
                        out.ext_off.as<int64_t>(), out.ext.as<uint64_t>(), out.left.as<int32_t>(),
-                       out.right.as<int32_t>(), long_list.as<uint32_t>(), huge_list.as<uint32_t>(),
-                       long_n.as<unsigned long long>());
+                       out.right.as<int32_t>());
     RFX_HIP(hipGetLastError());
-    if (in.words > n) {
-        hipLaunchKernelGGL(k_emit_long, dim3(1024), dim3(256), 0, ctx->stream, (const Desc *)desc.as<Desc>(),
-                           (const uint64_t *)oidx.as<uint64_t>(), (const uint64_t *)owoff.as<uint64_t>(),
-                           d_part_start, P, sub, (const uint64_t *)in.key.as<uint64_t>(),
-                           (const int32_t *)in.marker.as<int32_t>(), (const int64_t *)in.ext_off.as<int64_t>(),
-                           (const uint64_t *)in.ext.as<uint64_t>(), (const uint32_t *)len.as<uint32_t>(),
-                           out.ext.as<uint64_t>(), (const uint32_t *)long_list.as<uint32_t>(),
-                           (const uint32_t *)huge_list.as<uint32_t>(),
-                           (const unsigned long long *)long_n.as<unsigned long long>());
+    if (in.words > n) {          // some record has more than one word (output words <= input words)
+        hipLaunchKernelGGL(k_emit_words, dim3(grid_for(in.words)), dim3(256), 0, ctx->stream, (const Desc *)desc.as<Desc>(),
+                           (const uint64_t *)oidx.as<uint64_t>(), (const uint64_t *)owoff.as<uint64_t>(), n, d_part_start, P,
+                           sub, (const uint64_t *)in.key.as<uint64_t>(), (const int32_t *)in.marker.as<int32_t>(),
+                           (const int64_t *)in.ext_off.as<int64_t>(), (const uint64_t *)in.ext.as<uint64_t>(),
+                           (const uint32_t *)len.as<uint32_t>(), out.ext.as<uint64_t>());
         RFX_HIP(hipGetLastError());
     }
     DevBuf summary;

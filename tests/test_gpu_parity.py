@@ -915,3 +915,37 @@ def test_wide_count_survives_extreme_skew(rfx, torch_mod, k):
     assert inst == len(km) and nd == wd and m == len(wk)
     assert np.array_equal(dk[:2 * m].cpu().numpy().view(np.uint64).reshape(m, 2), wk)
     assert np.array_equal(dc[:m].cpu().numpy(), wc)
+
+
+@pytest.mark.gpu
+def test_fused_count_fuzz(rfx, torch_mod):
+    """Seeded sweep over read length, k, clips, coverage cut-off, genome size and read count (different
+    level plans, ring sizes, descriptor strides, leaf loads): the fused device count equals the oracle."""
+    torch = torch_mod
+    rng = np.random.default_rng(20261004)
+    for case in range(14):
+        k = int(rng.choice([31, 31, 30, 29, 28, 27, 21, 15]))
+        L = int(rng.choice([k + 1, 64, 100, 150, 151, 250]))
+        L = max(L, k + 2)
+        G = int(rng.choice([3_000, 40_000, 400_000]))
+        G = max(G, L + 1)
+        n_reads = int(rng.choice([700, 9_000, 60_000, 200_000]))
+        fc, ec = (0, 0) if rng.random() < 0.6 else (int(rng.integers(0, 4)), int(rng.integers(0, 4)))
+        min_cov = int(rng.choice([1, 2, 3, 5]))
+        seed = 1000 + case
+        dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+        N = rfx.kmers_per_read(L, k, fc, ec) * n_reads
+        if N <= 0:
+            continue
+        dk = torch.empty(N, dtype=torch.int64, device="cuda"); dc = torch.empty(N, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, min_cov,
+                                          front_clip=fc, end_clip=ec)
+        g = O.synth_genome(seed, G)
+        bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+        km = O.extract_canon(bases, off, k, fc, ec)
+        wk, wc, wd = O.count_filter(km, min_cov)
+        tag = f"case {case}: k={k} L={L} G={G} reads={n_reads} clips=({fc},{ec}) cov={min_cov}"
+        assert inst == len(km) and nd == wd and m == len(wk), tag
+        assert np.array_equal(dk[:m].cpu().numpy().view(np.uint64), wk), tag
+        assert np.array_equal(dc[:m].cpu().numpy(), wc), tag

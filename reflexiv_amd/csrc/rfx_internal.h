@@ -37,9 +37,18 @@ struct rfx_ctx {
         for (auto &w : ws) { if (w.p) (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
         if (pinned) (void)hipHostFree(pinned);
         pinned = nullptr; pinned_bytes = 0;
+        for (auto e : ev_pool) (void)hipEventDestroy(e);
+        ev_pool.clear(); ev_next = 0;
     }
     // grow-only pinned host staging for result downloads (a pageable copy of a few MB costs
     // milliseconds the first time the runtime stages it)
+    // events of the kernel timers: created once, handed out round-robin until the next collect()
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_next = 0;
+    hipEvent_t ev_get() {
+        if (ev_next == ev_pool.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; ev_pool.push_back(e); }
+        return ev_pool[ev_next++];
+    }
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
     void *pinned_get(size_t bytes) {
@@ -110,8 +119,9 @@ struct DevBuf {
 // Event pair that accumulates into ctx->timing[name].
 struct ScopedTimer {
     rfx_ctx *ctx; const char *name; hipEvent_t a = nullptr, b = nullptr; bool on;
-    ScopedTimer(rfx_ctx *c, const char *n) : ctx(c), name(n), on(c && c->timing_enabled) {
-        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, ctx->stream); }
+    ScopedTimer(rfx_ctx *c, const char *n) : ctx(c), name(n), on(c && c->timing_enabled && !getenv("RFX_NO_TIMING")) {
+        if (on) { a = ctx->ev_get(); b = ctx->ev_get(); on = a && b; }
+        if (on) (void)hipEventRecord(a, ctx->stream);
     }
     void stop(int64_t launches = 1) {
         if (!on) return;
@@ -130,9 +140,9 @@ struct ScopedTimer {
                 ctx->timing[p.name].ms += ms;
                 ctx->timing[p.name].launches += p.launches;
             }
-            (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
         }
         pending().clear();
+        ctx->ev_next = 0;                  // the pool's events are free again
     }
 };
 

@@ -1076,7 +1076,7 @@ __device__ __forceinline__ unsigned rec_digit(uint32_t hdr, int used, int bits) 
 // Walks the runs of one segment; calls emit(first_window, n_windows, minimiser_key).
 template <int W, bool RUNLOOP, class F>
 __device__ __forceinline__ void seg_runs(const ReadSrc &s, int nk_r, int sgm, const uint64_t (&w)[3], F &&emit,
-                                         uint64_t *hi_out, uint64_t *lo_out) {
+                                         uint64_t *hi_out, uint64_t *lo_out, uint32_t *wm_lds = nullptr) {
     constexpr int NM = PK + W - 1;                 // m-mers a segment can touch (<= 34)
     const int p0 = sgm * PK;
     int v = nk_r - p0;
@@ -1131,14 +1131,24 @@ __device__ __forceinline__ void seg_runs(const ReadSrc &s, int nk_r, int sgm, co
     uint32_t starts = 1u;
 #pragma unroll
     for (int i = 1; i < PK; i++) starts |= (uint32_t)(i < v && wm[i] != wm[i - 1]) << i;
+    if (wm_lds) {
+#pragma unroll
+        for (int i = 0; i < PK; i++) wm_lds[i * SKT + threadIdx.x] = wm[i];
+    }
     while (starts) {
         const int i0 = __ffs((int)starts) - 1;
         starts &= starts - 1;
         const int i1 = starts ? __ffs((int)starts) - 1 : v;
-        // wm[i0] by a compare-select chain (a register array cannot be indexed at run time)
-        uint32_t key = wm[0];
+        // wm[i0]: a register array cannot be indexed at run time -- through the thread's own LDS column
+        // when the caller has one (16 conflict-free stores, one load per run), else a compare-select chain
+        uint32_t key;
+        if (wm_lds) {
+            key = wm_lds[i0 * SKT + threadIdx.x];
+        } else {
+            key = wm[0];
 #pragma unroll
-        for (int j = 1; j < PK; j++) key = i0 == j ? wm[j] : key;
+            for (int j = 1; j < PK; j++) key = i0 == j ? wm[j] : key;
+        }
         emit(i0, i1 - i0, key);
     }
 }
@@ -1162,6 +1172,7 @@ template <int W, bool DESC>
 __global__ __launch_bounds__(SKT) void k_sk_hist(ReadSrc s, Level lv, uint64_t *__restrict__ blockhist,
                                                  uint32_t *__restrict__ desc) {
     __shared__ uint32_t h[1 << MAX_BITS];
+    __shared__ uint32_t wmcol[DESC && SK_DESC_RUNLOOP ? PK * SKT : 1];      // per-window minimisers, one column per thread
     const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
     for (int i = threadIdx.x; i < nb; i += SKT) h[i] = 0;
     __syncthreads();
@@ -1184,7 +1195,7 @@ __global__ __launch_bounds__(SKT) void k_sk_hist(ReadSrc s, Level lv, uint64_t *
                 atomicAdd(&h[rec_digit(hdr, 0, lv.bits)], 1u);
                 if (nr < (uint32_t)SKD) desc[(int64_t)(1 + nr) * s.n_threads + g] = hdr;
                 mask |= 1u << i0; nr++;
-            }, &hi, &lo);
+            }, &hi, &lo, SK_DESC_RUNLOOP ? wmcol : nullptr);
             desc[g] = mask | (nr << 16);
         } else {
             seg_runs<W, SK_HIST_RUNLOOP>(s, read_nk(s, q.r), q.sgm, w, [&](int, int, uint32_t canon) { atomicAdd(&h[sk_digit(canon, lv)], 1u); }, &hi, &lo);

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(PT) void k_vb_scatter(const uint64_t *__restrict__ 
 
 constexpr int LT = 512;                 // threads per leaf workgroup
 constexpr int OBUF = 512;               // survivors buffered in LDS between flushes
-constexpr int WSTAGE = 256;             // expanded k-mers a wave stages per round (record leaves)
+constexpr int WSTAGE = 256;             // u64 words of a wave's private expansion area (record leaves)
 constexpr int LSTAGE = WSTAGE * (LT / 64);
 constexpr int LCAP = 4096;              // hash slots
 constexpr int LCAP_BITS = 12;
@@ -435,8 +435,6 @@ constexpr int LPROBE = 48;              // a probe sequence this long means the 
 constexpr uint64_t EMPTY = ~0ULL;
 constexpr int LSTACK = 48;
 constexpr int LB = 8;                   // instance loads in flight per lane
-constexpr int LEAF_SLOT_SHIFT = 22;     // bits of local_hash below the <= 30 digit bits
-constexpr int LEAF_SPLIT_SHIFT = 6;
 
 struct CountOut {
     unsigned long long n_out;        // survivors appended (may exceed cap)
@@ -448,12 +446,12 @@ struct CountOut {
 };
 
 // Persistent workgroups each walk a CONTIGUOUS chunk of leaf buckets, i.e. one contiguous
-// stream of instances: the next batch (LB keys per lane) is always in flight while the current
-// one is inserted, across leaf boundaries.  A leaf is streamed through an LDS hash table
-// (k-mer -> count, 64-bit CAS + add); the slots it fills are remembered in a list, so emitting
-// and resetting touch only those.  Survivors collect in an LDS buffer and leave with ONE global
-// atomic per flush (a per-leaf atomic on one hot counter serialises the whole grid).
-// A leaf whose table fills up (a probe sequence > LPROBE) is re-streamed in 2, 4, ... hash-selected parts.
+// stream of elements: the next leaf's data is always in flight while the current one is inserted.
+// A leaf is streamed through an LDS hash table (k-mer -> count, 64-bit CAS + add); after ONE
+// barrier the workgroup sweeps the whole table (filter, reset); survivors collect in an LDS buffer
+// and leave with ONE global atomic per flush (a per-leaf atomic on one hot counter serialises the
+// whole grid).  A leaf whose table fills up (a probe sequence > LPROBE) is re-streamed in 2, 4, ...
+// hash-selected parts; a HEAVY leaf is cut into slices for a second launch (finish_leaves).
 // Leaf input element: a k-mer instance (8 B) or a super-k-mer record (16 B, <= 16 instances).
 struct alignas(16) Rec { uint64_t w0, w1; };
 // Rec: w0 = bases 0..31 of the run's base string, w1 = [63..36] bases 32..45, [35..32] windows-1,

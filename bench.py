@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-contigs", action="store_true")
+    ap.add_argument("--exchange-chunks", type=int, default=4,
+                    help="N > 1: read chunks whose all-to-all overlaps the bucketing of the next chunk (1 = no overlap)")
     return ap.parse_args()
 
 
@@ -142,7 +144,7 @@ def main():
             m, nd, inst = rfx.count_reads_dev(d_words.data_ptr(), n_reads, wpr, L, k, d_keys.data_ptr(),
                                               d_counts.data_ptr(), cap, args.cover)
             return m, nd, inst
-        keys, counts, tot = rd.sharded_count(engine, reads, args.cover, 10_000_000, 0)
+        keys, counts, tot = rd.sharded_count(engine, reads, args.cover, 10_000_000, 0, chunks=args.exchange_chunks)
         shard["keys"], shard["counts"] = keys, counts
         return tot[2], tot[1], tot[0] // world
 

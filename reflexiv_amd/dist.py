@@ -56,6 +56,19 @@ class HipEngine:
                                          doff.data_ptr())
         return out[:n], torch.from_numpy(h.copy())
 
+    def split_reads(self, reads, chunks):
+        """the packed read set as `chunks` contiguous slices (views, nothing is copied)"""
+        n, wpr = reads["n_reads"], reads["wpr"]
+        cuts = [n * c // chunks for c in range(chunks + 1)]
+        out = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if b > a:
+                sub = dict(reads)
+                sub["words"] = reads["words"][a * wpr:b * wpr]
+                sub["n_reads"] = b - a
+                out.append(sub)
+        return out
+
     def count_kmers(self, kmers, min_cov, max_cov, twin):
         from ._lib import RfxError, RFX_E_CAP
         n = int(kmers.numel()) // self.width
@@ -99,15 +112,50 @@ def exchange_by_owner(kmers: torch.Tensor, owner_off: torch.Tensor, group=None, 
     return recv
 
 
-def sharded_count(engine, reads, min_cov, max_cov, twin, group=None):
-    """-> (keys, counts) of this rank's shard (ascending), global (instances, distinct, survivors)."""
+def exchange_by_owner_async(kmers: torch.Tensor, owner_off: torch.Tensor, group=None, width: int = 1):
+    """exchange_by_owner, but the data all-to-all(v) is only LAUNCHED: -> (recv buffer, work handle).
+    The caller keeps bucketing the next chunk of reads while the bytes move (xGMI is the slowest
+    stage of the multi-GPU step), and waits on the handle before it reads `recv`."""
+    world = dist.get_world_size(group)
+    send_counts = (owner_off[1:] - owner_off[:-1]).to(torch.int64) * width
+    sc = send_counts.to(kmers.device) if kmers.is_cuda else send_counts
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = rc.cpu()
+    recv = torch.empty(int(recv_counts.sum()), dtype=kmers.dtype, device=kmers.device)
+    work = dist.all_to_all_single(recv, kmers, output_split_sizes=[int(x) for x in recv_counts],
+                                  input_split_sizes=[int(x) for x in send_counts], group=group, async_op=True)
+    return recv, work
+
+
+def sharded_count(engine, reads, min_cov, max_cov, twin, group=None, chunks: int = 1):
+    """-> (keys, counts) of this rank's shard (ascending), global (instances, distinct, survivors).
+    chunks > 1 (and an engine that can split its reads): the reads are bucketed chunk by chunk and
+    chunk c travels while chunk c+1 is bucketed; counting starts when everything has arrived."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    kmers, owner_off = engine.bucket_by_owner(reads, world)
-    width = getattr(engine, "width", 1)
-    recv = exchange_by_owner(kmers, owner_off, group, width) if world > 1 else kmers
+    width = None
+    if world > 1 and chunks > 1 and hasattr(engine, "split_reads"):
+        parts, sent, n_inst_total, pending = [], 0, 0, []
+        for sub in engine.split_reads(reads, chunks):
+            km, off = engine.bucket_by_owner(sub, world)
+            width = getattr(engine, "width", 1)
+            sent += int(km.numel())
+            n_inst_total += int(getattr(engine, "n_instances", 0) or 0)
+            recv_c, work = exchange_by_owner_async(km, off, group, width)
+            pending.append((recv_c, work, km))             # km stays alive until its send has completed
+        for recv_c, work, _ in pending:
+            work.wait()
+            parts.append(recv_c)
+        recv = torch.cat(parts) if len(parts) > 1 else parts[0]
+        del pending, parts
+        kmers_numel, n_inst = sent, (n_inst_total if width == 2 else None)
+    else:
+        kmers, owner_off = engine.bucket_by_owner(reads, world)
+        width = getattr(engine, "width", 1)
+        recv = exchange_by_owner(kmers, owner_off, group, width) if world > 1 else kmers
+        kmers_numel, n_inst = int(kmers.numel()), getattr(engine, "n_instances", None)
     keys, counts, distinct = engine.count_kmers(recv, min_cov, max_cov, twin)
-    n_inst = getattr(engine, "n_instances", None)
-    tot = torch.tensor([int(kmers.numel()) if n_inst is None or width == 1 else int(n_inst), int(distinct),
+    tot = torch.tensor([kmers_numel if n_inst is None or width == 1 else int(n_inst), int(distinct),
                         int(keys.numel())], dtype=torch.int64,
                        device=keys.device)
     if world > 1:

@@ -47,12 +47,22 @@ class OracleEngine:
         k, c, d = O.count_filter(kmers.numpy().view(np.uint64), min_cov, max_cov, twin)
         return torch.from_numpy(k.view(np.int64)), torch.from_numpy(c), d
 
+    def split_reads(self, reads, chunks):
+        off = reads["read_off"]
+        n = len(off) - 1
+        cuts = [n * c // chunks for c in range(chunks + 1)]
+        out = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if b > a:
+                out.append(dict(bases=reads["bases"][off[a]:off[b]], read_off=off[a:b + 1] - off[a], k=reads["k"]))
+        return out
+
 
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q):
+def _worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q, chunks=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -60,7 +70,7 @@ def _worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q):
         g = O.synth_genome(seed, G)
         bases, off = O.synth_reads(seed, g, G, rank * per_rank, per_rank, L)    # this rank's read shard
         reads = dict(bases=bases, read_off=off, k=k)
-        keys, counts, tot = rd.sharded_count(OracleEngine(), reads, min_cov, 10_000_000, O.TWIN_DS)
+        keys, counts, tot = rd.sharded_count(OracleEngine(), reads, min_cov, 10_000_000, O.TWIN_DS, chunks=chunks)
         allk, allc = rd.gather_survivors(keys, counts)
         if rank == 0:
             q.put(("root", allk.numpy().view(np.uint64).copy(), allc.numpy().copy(), None))
@@ -72,13 +82,13 @@ def _worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_count_equals_global_count(world):
+@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 1), (2, 4), (3, 3)])
+def test_sharded_count_equals_global_count(world, chunks):
     seed, G, per_rank, L, k, min_cov = 42, 20_000, 1500, 100, 31, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, G, per_rank, L, k, min_cov, q))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, G, per_rank, L, k, min_cov, q, chunks))
              for r in range(world)]
     for p in procs:
         p.start()

@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-contigs", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the multi-GPU code path (owner buckets, RCCL all-to-all, gather) even with one rank")
     ap.add_argument("--exchange-chunks", type=int, default=4,
                     help="N > 1: read chunks whose all-to-all overlaps the bucketing of the next chunk (1 = no overlap)")
     return ap.parse_args()
@@ -99,8 +101,11 @@ def main():
     assert world == args.gpus or world == 1, (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    multi = world > 1 or args.force_dist
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     rfx = reflexiv_amd.Reflexiv(local)
     rfx.use_stream(torch.cuda.current_stream().cuda_stream)   # kernels, copies and RCCL share one stream
     dev = torch.device("cuda", local)
@@ -132,6 +137,7 @@ def main():
     d_counts = torch.empty(cap, dtype=torch.int64 if wide else torch.int32, device=dev)
     reads = dict(words=d_words, n_reads=n_reads, wpr=wpr, read_len=L, k=k)
     engine = rd.HipEngine(rfx)
+    engine.force_exchange = args.force_dist
     timing_acc = {}
 
     shard = {}
@@ -140,17 +146,20 @@ def main():
         if wide:
             return rfx.count_reads_w_dev(d_words.data_ptr(), n_reads, wpr, L, k, d_keys.data_ptr(), d_counts.data_ptr(),
                                          cap, args.cover)
-        if world == 1:
+        if not multi:
             m, nd, inst = rfx.count_reads_dev(d_words.data_ptr(), n_reads, wpr, L, k, d_keys.data_ptr(),
                                               d_counts.data_ptr(), cap, args.cover)
             return m, nd, inst
-        keys, counts, tot = rd.sharded_count(engine, reads, args.cover, 10_000_000, 0, chunks=args.exchange_chunks)
+        # enough chunks that no per-peer message needs the staged rounds of dist._alltoallv (512 MiB cap)
+        est = 2.7 * n_inst / world / rd.A2A_LIMIT_BYTES
+        chunks = max(args.exchange_chunks, int(est) + 1)
+        keys, counts, tot = rd.sharded_count(engine, reads, args.cover, 10_000_000, 0, chunks=chunks)
         shard["keys"], shard["counts"] = keys, counts
         return tot[2], tot[1], tot[0] // world
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -166,7 +175,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     total_inst = n_inst * world * args.steps
@@ -195,13 +204,13 @@ def main():
                                f"PE{L}, k={k}, -cover {args.cover}, 0.5% substitutions",
                    "reads_per_gpu": n_reads, "kmer_instances_per_gpu": n_inst, "distinct_kmers": nd,
                    "kmers_kept": m,
-                   "parallelism": "1 GPU" if world == 1 else f"k-mer space radix-sharded over {world} GPUs, "
+                   "parallelism": "1 GPU" if not multi else f"k-mer space radix-sharded over {world} GPUs, "
                                                                "RCCL all-to-all(v)"},
         "roofline": roofline,
-        "stage_hbm_frac": (((0.25 + 16 * W) * n_inst + (8 * W + 4) * m) / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS) if world == 1 else None,
+        "stage_hbm_frac": (((0.25 + 16 * W) * n_inst + (8 * W + 4) * m) / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS) if not multi else None,
     }
 
-    if world > 1 and not args.no_contigs:
+    if multi and not args.no_contigs:
         # the filtered list is small: gather it on rank 0, restore ascending k-mer order there
         # and run the extend stage on that one GPU
         torch.cuda.synchronize()
@@ -222,17 +231,17 @@ def main():
         t1 = time.perf_counter()
         text, nc, trace = rfx.assemble_dev(d_keys.data_ptr(), d_counts.data_ptr(), m, prm)
         t_asm = time.perf_counter() - t1
-        if world > 1:
+        if multi:
             t_asm += t_gather
         lens = sorted((int(h.split("-")[1]) for h in text.split("\n") if h.startswith(">")), reverse=True)
         out["contigs"] = {"wall_ms_from_counts": t_asm * 1e3, "wall_ms_reads_to_contigs": t_asm * 1e3 + dt / args.steps * 1e3,
                           "extend_passes": len(trace), "n_contigs": nc, "longest": lens[:3],
                           "total_bases": sum(lens)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, min(args.cpu_sample_reads, n_reads))
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -94,38 +94,68 @@ class HipEngine:
                 cap = cap * 4
 
 
+# RCCL 2.26 (the one in this torch build) returns corrupt data from all_to_all_single when a per-peer
+# message exceeds 1 GiB (tools/dbg_dist.py on a one-rank group: intact at exactly 2^27 int64, the
+# second half wrong just above).  No single call below ever moves more than A2A_LIMIT_BYTES per
+# peer: larger buckets go in rounds through staging buffers.
+A2A_LIMIT_BYTES = 1 << 29      # per peer per call (512 MiB)
+
+
+def _alltoallv(send: torch.Tensor, send_counts, group=None, async_op: bool = False, limit: int = None):
+    """all-to-all(v) of `send` (bucket d = send_counts[d] elements, buckets back to back) ->
+    (recv, [work handles]); recv holds source 0's bucket, then source 1's, ...  Per-peer messages are
+    capped at `limit` elements per call (default: A2A_LIMIT_BYTES)."""
+    limit = limit or max(1, A2A_LIMIT_BYTES // send.element_size())
+    world = dist.get_world_size(group)
+    send_counts = [int(x) for x in send_counts]
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = [int(x) for x in rc.cpu()]
+    mx = torch.tensor([max(send_counts + recv_counts + [0])], dtype=torch.int64, device=send.device)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    rounds = max(1, -(-int(mx.item()) // limit))
+    recv = torch.empty(sum(recv_counts), dtype=send.dtype, device=send.device)
+    if rounds == 1:
+        w = dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group,
+                                   async_op=async_op)
+        return recv, ([w] if async_op else [])
+    soff = [0]
+    for c in send_counts:
+        soff.append(soff[-1] + c)
+    roff = [0]
+    for c in recv_counts:
+        roff.append(roff[-1] + c)
+    for j in range(rounds):
+        ins = [max(0, min(limit, send_counts[d] - j * limit)) for d in range(world)]
+        outs = [max(0, min(limit, recv_counts[d] - j * limit)) for d in range(world)]
+        stage_in = torch.cat([send[soff[d] + j * limit: soff[d] + j * limit + ins[d]] for d in range(world)])
+        stage_out = torch.empty(sum(outs), dtype=send.dtype, device=send.device)
+        dist.all_to_all_single(stage_out, stage_in, output_split_sizes=outs, input_split_sizes=ins, group=group)
+        o = 0
+        for d in range(world):
+            recv[roff[d] + j * limit: roff[d] + j * limit + outs[d]] = stage_out[o:o + outs[d]]
+            o += outs[d]
+    return recv, []
+
+
 def exchange_by_owner(kmers: torch.Tensor, owner_off: torch.Tensor, group=None, width: int = 1) -> torch.Tensor:
     """all-to-all(v): send bucket o of `kmers` to rank o, return the concatenation of what
     every rank sent to this one (C2 of SURVEY.md 2.4).  `width` int64 words per unit (2 for
     super-k-mer records); owner_off counts units."""
-    world = dist.get_world_size(group)
     send_counts = (owner_off[1:] - owner_off[:-1]).to(torch.int64) * width
-    assert send_counts.numel() == world
-    recv_counts = torch.empty(world, dtype=torch.int64)
-    sc = send_counts.to(kmers.device) if kmers.is_cuda else send_counts
-    rc = torch.empty_like(sc)
-    dist.all_to_all_single(rc, sc, group=group)
-    recv_counts = rc.cpu()
-    recv = torch.empty(int(recv_counts.sum()), dtype=kmers.dtype, device=kmers.device)
-    dist.all_to_all_single(recv, kmers, output_split_sizes=[int(x) for x in recv_counts],
-                           input_split_sizes=[int(x) for x in send_counts], group=group)
+    assert send_counts.numel() == dist.get_world_size(group)
+    recv, _ = _alltoallv(kmers, send_counts.tolist(), group)
     return recv
 
 
 def exchange_by_owner_async(kmers: torch.Tensor, owner_off: torch.Tensor, group=None, width: int = 1):
-    """exchange_by_owner, but the data all-to-all(v) is only LAUNCHED: -> (recv buffer, work handle).
-    The caller keeps bucketing the next chunk of reads while the bytes move (xGMI is the slowest
-    stage of the multi-GPU step), and waits on the handle before it reads `recv`."""
-    world = dist.get_world_size(group)
+    """exchange_by_owner, but the data all-to-all(v) is only LAUNCHED when it fits one call: ->
+    (recv buffer, work handles).  The caller keeps bucketing the next chunk of reads while the bytes
+    move (xGMI is the slowest stage of the multi-GPU step), and waits on the handles before it
+    reads `recv`."""
     send_counts = (owner_off[1:] - owner_off[:-1]).to(torch.int64) * width
-    sc = send_counts.to(kmers.device) if kmers.is_cuda else send_counts
-    rc = torch.empty_like(sc)
-    dist.all_to_all_single(rc, sc, group=group)
-    recv_counts = rc.cpu()
-    recv = torch.empty(int(recv_counts.sum()), dtype=kmers.dtype, device=kmers.device)
-    work = dist.all_to_all_single(recv, kmers, output_split_sizes=[int(x) for x in recv_counts],
-                                  input_split_sizes=[int(x) for x in send_counts], group=group, async_op=True)
-    return recv, work
+    return _alltoallv(kmers, send_counts.tolist(), group, async_op=True)
 
 
 def sharded_count(engine, reads, min_cov, max_cov, twin, group=None, chunks: int = 1):
@@ -134,17 +164,19 @@ def sharded_count(engine, reads, min_cov, max_cov, twin, group=None, chunks: int
     chunk c travels while chunk c+1 is bucketed; counting starts when everything has arrived."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     width = None
-    if world > 1 and chunks > 1 and hasattr(engine, "split_reads"):
+    exchange = world > 1 or (dist.is_initialized() and bool(getattr(engine, "force_exchange", False)))   # (tests: 1-rank RCCL)
+    if exchange and chunks > 1 and hasattr(engine, "split_reads"):
         parts, sent, n_inst_total, pending = [], 0, 0, []
         for sub in engine.split_reads(reads, chunks):
             km, off = engine.bucket_by_owner(sub, world)
             width = getattr(engine, "width", 1)
             sent += int(km.numel())
             n_inst_total += int(getattr(engine, "n_instances", 0) or 0)
-            recv_c, work = exchange_by_owner_async(km, off, group, width)
-            pending.append((recv_c, work, km))             # km stays alive until its send has completed
-        for recv_c, work, _ in pending:
-            work.wait()
+            recv_c, works = exchange_by_owner_async(km, off, group, width)
+            pending.append((recv_c, works, km))            # km stays alive until its send has completed
+        for recv_c, works, _ in pending:
+            for w in works:
+                w.wait()
             parts.append(recv_c)
         recv = torch.cat(parts) if len(parts) > 1 else parts[0]
         del pending, parts
@@ -152,7 +184,7 @@ def sharded_count(engine, reads, min_cov, max_cov, twin, group=None, chunks: int
     else:
         kmers, owner_off = engine.bucket_by_owner(reads, world)
         width = getattr(engine, "width", 1)
-        recv = exchange_by_owner(kmers, owner_off, group, width) if world > 1 else kmers
+        recv = exchange_by_owner(kmers, owner_off, group, width) if exchange else kmers
         kmers_numel, n_inst = int(kmers.numel()), getattr(engine, "n_instances", None)
     keys, counts, distinct = engine.count_kmers(recv, min_cov, max_cov, twin)
     tot = torch.tensor([kmers_numel if n_inst is None or width == 1 else int(n_inst), int(distinct),
@@ -266,14 +298,15 @@ def _alltoall_var(chunks, dtype, group=None):
     """chunks[d] = 1-D numpy array for rank d -> list of what every rank sent here (in rank order)."""
     world = dist.get_world_size(group)
     dev = _coll_device()
-    sc = torch.tensor([len(c) for c in chunks], dtype=torch.int64, device=dev)
+    counts = [len(c) for c in chunks]
+    send = np.ascontiguousarray(np.concatenate(chunks) if world else np.empty(0, dtype))
+    st = torch.from_numpy(send.view(np.int64 if send.dtype.itemsize == 8 else np.int32)).to(dev)
+    # the receive counts come back inside _alltoallv; recover the cuts from a second tiny exchange
+    sc = torch.tensor(counts, dtype=torch.int64, device=dev)
     rc = torch.empty_like(sc)
     dist.all_to_all_single(rc, sc, group=group)
     rcl = [int(x) for x in rc.cpu()]
-    send = np.concatenate(chunks) if world else np.empty(0, dtype)
-    st = torch.from_numpy(np.ascontiguousarray(send).view(np.int64 if send.dtype.itemsize == 8 else np.int32)).to(dev)
-    rt = torch.empty(sum(rcl), dtype=st.dtype, device=dev)
-    dist.all_to_all_single(rt, st, output_split_sizes=rcl, input_split_sizes=[len(c) for c in chunks], group=group)
+    rt, _ = _alltoallv(st, counts, group)
     out = rt.cpu().numpy().view(dtype)
     cuts = np.cumsum([0] + rcl)
     return [out[cuts[i]:cuts[i + 1]] for i in range(world)]

@@ -62,11 +62,13 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q, chunks=1):
+def _worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q, chunks=1, limit_bytes=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from reflexiv_amd import dist as rd
+        if limit_bytes:
+            rd.A2A_LIMIT_BYTES = limit_bytes          # force the message-size rounds
         g = O.synth_genome(seed, G)
         bases, off = O.synth_reads(seed, g, G, rank * per_rank, per_rank, L)    # this rank's read shard
         reads = dict(bases=bases, read_off=off, k=k)
@@ -82,13 +84,14 @@ def _worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q, chunks=1):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 1), (2, 4), (3, 3)])
-def test_sharded_count_equals_global_count(world, chunks):
+@pytest.mark.parametrize("world,chunks,limit_bytes", [(2, 1, None), (3, 1, None), (2, 4, None), (3, 3, None),
+                                                      (2, 1, 40_000), (3, 2, 24_000)])
+def test_sharded_count_equals_global_count(world, chunks, limit_bytes):
     seed, G, per_rank, L, k, min_cov = 42, 20_000, 1500, 100, 31, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, G, per_rank, L, k, min_cov, q, chunks))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, G, per_rank, L, k, min_cov, q, chunks, limit_bytes))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -165,11 +168,13 @@ class OracleOps:
         return O.contigs_text(r, k, min_contig, twin)
 
 
-def _asm_worker(rank, world, port, keys, counts, prm_kw, q):
+def _asm_worker(rank, world, port, keys, counts, prm_kw, q, limit_bytes=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from reflexiv_amd import dist as rd
+        if limit_bytes:
+            rd.A2A_LIMIT_BYTES = limit_bytes
         mine = owner_of(keys, world) == rank                     # the hash shard the count stage leaves on this rank
         prm = O.default_params(**prm_kw)
         trace = []
@@ -183,11 +188,11 @@ def _asm_worker(rank, world, port, keys, counts, prm_kw, q):
         dist.destroy_process_group()
 
 
-def _run_sharded_assemble(world, keys, counts, prm_kw):
+def _run_sharded_assemble(world, keys, counts, prm_kw, limit_bytes=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_asm_worker, args=(r, world, port, keys, counts, prm_kw, q)) for r in range(world)]
+    procs = [ctx.Process(target=_asm_worker, args=(r, world, port, keys, counts, prm_kw, q, limit_bytes)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=300)
@@ -213,7 +218,8 @@ def test_sharded_extend_with_bubbles_and_repeat(golden_dir):
     """planted fixture (SNP bubble + repeat: fork-marked records, left/right >= 0 branches)."""
     pl = np.load(os.path.join(golden_dir, "planted.npz"))
     text, nc, trace = _run_sharded_assemble(2, pl["k31_keys"], pl["k31_counts"],
-                                            dict(k=31, min_cov=2, partitions=4, twin=O.TWIN_DS, min_contig=100))
+                                            dict(k=31, min_cov=2, partitions=4, twin=O.TWIN_DS, min_contig=100),
+                                            limit_bytes=4096)          # record exchanges in several rounds
     assert text == str(pl["k31_ds_contigs"])
     assert trace == [int(x) for x in pl["k31_ds_trace"]]
 

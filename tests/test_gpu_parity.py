@@ -949,3 +949,50 @@ def test_fused_count_fuzz(rfx, torch_mod):
         assert inst == len(km) and nd == wd and m == len(wk), tag
         assert np.array_equal(dk[:m].cpu().numpy().view(np.uint64), wk), tag
         assert np.array_equal(dc[:m].cpu().numpy(), wc), tag
+
+
+@pytest.mark.gpu
+def test_sharded_count_through_rccl_one_rank(rfx, torch_mod):
+    """The multi-GPU count path on real RCCL with a one-rank process group: device tensors through
+    all_to_all_single (blocking and async/chunked), exactly the calls `bench.py --gpus N` makes."""
+    torch = torch_mod
+    import torch.distributed as dist
+    from reflexiv_amd import dist as rd
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        seed, G, n_reads, L, k = 23, 200_000, 100_000, 150, 31
+        dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+        rfx.use_stream(torch.cuda.current_stream().cuda_stream)
+        reads = dict(words=dw, n_reads=n_reads, wpr=wpr, read_len=L, k=k)
+        N = rfx.kmers_per_read(L, k) * n_reads
+        dk = torch.empty(N, dtype=torch.int64, device="cuda"); dc = torch.empty(N, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, 3)
+        for chunks in (1, 4):
+            eng = rd.HipEngine(rfx)
+            eng.force_exchange = True
+            keys, counts, tot = rd.sharded_count(eng, reads, 3, 10_000_000, 0, chunks=chunks)
+            assert tot == [N, nd, m]
+            # one owner: the shard is everything, but in hash-leaf order -> compare as sorted sets
+            o = torch.argsort(keys)
+            assert torch.equal(keys[o], dk[:m]) and torch.equal(counts[o], dc[:m])
+            gk, gc = rd.gather_survivors(keys, counts)
+            assert gk is keys or torch.equal(gk, keys)
+        # RCCL 2.26 corrupts per-peer messages above 1 GiB; dist._alltoallv caps them (rounds of 512 MiB)
+        gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+        n = (1 << 27) + 4099                                      # just over 1 GiB of int64
+        x = torch.randint(-2**62, 2**62, (n,), dtype=torch.int64, device="cuda", generator=gen)
+        r, _ = rd._alltoallv(x, [n])
+        assert torch.equal(r, x)
+        r, works = rd._alltoallv(x, [n], async_op=True)
+        for w in works:
+            w.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(r, x)
+    finally:
+        if created:
+            dist.destroy_process_group()

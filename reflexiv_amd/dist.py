@@ -42,10 +42,19 @@ class HipEngine:
             doff = torch.empty(n_owners + 1, dtype=torch.int64, device=reads["words"].device)
             torch.cuda.current_stream().synchronize()
             args = (reads["words"].data_ptr(), reads["n_reads"], reads["wpr"], reads["read_len"], reads["k"], n_owners)
-            nrec, _ = self.rfx.bucket_records_by_owner_dev(*args, 0, 0, doff.data_ptr())
-            out = torch.empty(2 * max(1, nrec), dtype=torch.int64, device=reads["words"].device)
+            # capacity from the records-per-read ratio of the previous call (one histogram pass instead of
+            # two); the call reports the need if the guess is short
+            ratio = self._records_per_read(reads)
+            cap = int(ratio * reads["n_reads"]) + 4096
+            out = torch.empty(2 * max(1, cap), dtype=torch.int64, device=reads["words"].device)
             torch.cuda.current_stream().synchronize()
-            nrec, h = self.rfx.bucket_records_by_owner_dev(*args, out.data_ptr(), nrec, doff.data_ptr())
+            nrec, h = self.rfx.bucket_records_by_owner_dev(*args, out.data_ptr() if cap else 0, cap, doff.data_ptr())
+            if h is None or nrec > cap:
+                out = torch.empty(2 * max(1, nrec), dtype=torch.int64, device=reads["words"].device)
+                torch.cuda.current_stream().synchronize()
+                nrec, h = self.rfx.bucket_records_by_owner_dev(*args, out.data_ptr(), nrec, doff.data_ptr())
+            if nrec > cap:                             # only ever grows: buffer sizes stay the same from step to step
+                self._rec_per_read = 1.03 * nrec / max(1, reads["n_reads"])
             return out[:2 * nrec], torch.from_numpy(h.copy())
         self.width = 1
         out = torch.empty(max(1, n), dtype=torch.int64, device=reads["words"].device)
@@ -55,6 +64,20 @@ class HipEngine:
                                          reads["read_len"], reads["k"], n_owners, out.data_ptr(), n,
                                          doff.data_ptr())
         return out[:n], torch.from_numpy(h.copy())
+
+    def estimate_units(self, reads):
+        """records (k-mers) this rank's reads produce, from the ratio seen in the previous call; 0 = unknown"""
+        if self._use_records(reads["k"]):
+            return int(self._records_per_read(reads) * reads["n_reads"])
+        return self.rfx.kmers_per_read(reads["read_len"], reads["k"]) * reads["n_reads"]
+
+    def _records_per_read(self, reads):
+        """capacity planning: super-k-mer records a read yields -- one per ~6.2 windows on real-looking
+        sequence; start at one per 5 and grow only if a call reports more (identical buffer sizes in
+        every step keep torch's caching allocator from re-allocating)"""
+        if getattr(self, "_rec_per_read", None) is None:
+            self._rec_per_read = self.rfx.kmers_per_read(reads["read_len"], reads["k"]) / 5.0 + 1.0
+        return self._rec_per_read
 
     def split_reads(self, reads, chunks):
         """the packed read set as `chunks` contiguous slices (views, nothing is copied)"""
@@ -101,7 +124,7 @@ class HipEngine:
 A2A_LIMIT_BYTES = 1 << 29      # per peer per call (512 MiB)
 
 
-def _alltoallv(send: torch.Tensor, send_counts, group=None, async_op: bool = False, limit: int = None):
+def _alltoallv(send: torch.Tensor, send_counts, group=None, async_op: bool = False, limit: int = None, out=None):
     """all-to-all(v) of `send` (bucket d = send_counts[d] elements, buckets back to back) ->
     (recv, [work handles]); recv holds source 0's bucket, then source 1's, ...  Per-peer messages are
     capped at `limit` elements per call (default: A2A_LIMIT_BYTES)."""
@@ -115,7 +138,9 @@ def _alltoallv(send: torch.Tensor, send_counts, group=None, async_op: bool = Fal
     mx = torch.tensor([max(send_counts + recv_counts + [0])], dtype=torch.int64, device=send.device)
     dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
     rounds = max(1, -(-int(mx.item()) // limit))
-    recv = torch.empty(sum(recv_counts), dtype=send.dtype, device=send.device)
+    need = sum(recv_counts)
+    # `out` (optional): a caller-owned buffer whose head receives the data when it is large enough
+    recv = out[:need] if out is not None and out.numel() >= need else torch.empty(need, dtype=send.dtype, device=send.device)
     if rounds == 1:
         w = dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group,
                                    async_op=async_op)
@@ -149,13 +174,13 @@ def exchange_by_owner(kmers: torch.Tensor, owner_off: torch.Tensor, group=None, 
     return recv
 
 
-def exchange_by_owner_async(kmers: torch.Tensor, owner_off: torch.Tensor, group=None, width: int = 1):
+def exchange_by_owner_async(kmers: torch.Tensor, owner_off: torch.Tensor, group=None, width: int = 1, out=None):
     """exchange_by_owner, but the data all-to-all(v) is only LAUNCHED when it fits one call: ->
     (recv buffer, work handles).  The caller keeps bucketing the next chunk of reads while the bytes
     move (xGMI is the slowest stage of the multi-GPU step), and waits on the handles before it
     reads `recv`."""
     send_counts = (owner_off[1:] - owner_off[:-1]).to(torch.int64) * width
-    return _alltoallv(kmers, send_counts.tolist(), group, async_op=True)
+    return _alltoallv(kmers, send_counts.tolist(), group, async_op=True, out=out)
 
 
 def sharded_count(engine, reads, min_cov, max_cov, twin, group=None, chunks: int = 1):
@@ -167,18 +192,29 @@ def sharded_count(engine, reads, min_cov, max_cov, twin, group=None, chunks: int
     exchange = world > 1 or (dist.is_initialized() and bool(getattr(engine, "force_exchange", False)))   # (tests: 1-rank RCCL)
     if exchange and chunks > 1 and hasattr(engine, "split_reads"):
         parts, sent, n_inst_total, pending = [], 0, 0, []
-        for sub in engine.split_reads(reads, chunks):
+        subs = engine.split_reads(reads, chunks)
+        # one receive buffer for all chunks when the engine can estimate the volume (by symmetry a
+        # rank receives about as much as it produces); a chunk that does not fit is joined by a copy
+        est = engine.estimate_units(reads) if hasattr(engine, "estimate_units") else 0
+        big, pos = None, 0
+        for sub in subs:
             km, off = engine.bucket_by_owner(sub, world)
             width = getattr(engine, "width", 1)
+            if big is None and est:
+                big = torch.empty(int(est * width * 1.1) + 4096, dtype=km.dtype, device=km.device)
             sent += int(km.numel())
             n_inst_total += int(getattr(engine, "n_instances", 0) or 0)
-            recv_c, works = exchange_by_owner_async(km, off, group, width)
-            pending.append((recv_c, works, km))            # km stays alive until its send has completed
-        for recv_c, works, _ in pending:
+            recv_c, works = exchange_by_owner_async(km, off, group, width, out=None if big is None else big[pos:])
+            if big is not None and recv_c.numel() and recv_c.data_ptr() == big[pos:].data_ptr():
+                pos += recv_c.numel()
+            elif recv_c.numel():
+                parts.append(recv_c)
+            pending.append((works, km))                    # km stays alive until its send has completed
+        for works, _ in pending:
             for w in works:
                 w.wait()
-            parts.append(recv_c)
-        recv = torch.cat(parts) if len(parts) > 1 else parts[0]
+        head = [big[:pos]] if big is not None and pos else []
+        recv = (head + parts)[0] if len(head + parts) == 1 else torch.cat(head + parts) if head + parts else km[:0]
         del pending, parts
         kmers_numel, n_inst = sent, (n_inst_total if width == 2 else None)
     else:

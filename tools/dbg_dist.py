@@ -1,23 +1,34 @@
-"""One-rank RCCL rehearsal: (1) raw all_to_all_single corrupts per-peer messages above 1 GiB (RCCL 2.26 in this
-torch build); (2) reflexiv_amd.dist._alltoallv (512 MiB rounds) returns them intact."""
-import os, sys, torch
+"""Timing rehearsal of dist.sharded_count (chunked) on a one-rank RCCL group."""
+import os, sys, time, torch
 import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import reflexiv_amd
 from reflexiv_amd import dist as rd
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29588")
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-g = torch.Generator(device="cuda"); g.manual_seed(1)
-src = torch.randint(-2**62, 2**62, ((1 << 28) + 12345,), dtype=torch.int64, device="cuda", generator=g)
-for n in (1 << 27, (1 << 27) + 8, (1 << 28) + 12345):
-    x = src[:n]
-    r = torch.full_like(x, 7)
-    dist.all_to_all_single(r, x, output_split_sizes=[n], input_split_sizes=[n])
-    torch.cuda.synchronize()
-    r2, _ = rd._alltoallv(x, [n])
-    r3, works = rd._alltoallv(x, [n], async_op=True)
-    for w in works:
-        w.wait()
-    torch.cuda.synchronize()
-    print("n=%d (%.3f GiB): raw intact %s | capped intact %s | capped async intact %s" %
-          (n, n * 8 / 2**30, bool(torch.equal(r, x)), bool(torch.equal(r2, x)), bool(torch.equal(r3, x))), flush=True)
+rfx = reflexiv_amd.Reflexiv(0)
+L,k,wpr,G=150,31,5,4_640_000
+n_reads=int(5e9/L)//2*2
+dg=torch.empty((G+31)//32,dtype=torch.int64,device="cuda"); dw=torch.empty(n_reads*wpr,dtype=torch.int64,device="cuda")
+torch.cuda.synchronize()
+rfx.synth_genome_dev(1,G,dg.data_ptr()); rfx.synth_reads_dev(1,dg.data_ptr(),G,0,n_reads,L,wpr,dw.data_ptr()); rfx.sync()
+rfx.use_stream(torch.cuda.current_stream().cuda_stream)
+reads=dict(words=dw,n_reads=n_reads,wpr=wpr,read_len=L,k=k)
+eng=rd.HipEngine(rfx); eng.force_exchange=True
+for it in range(3):
+    torch.cuda.synchronize(); t0=time.perf_counter()
+    subs=eng.split_reads(reads,21)
+    tb=te=0
+    for sub in subs:
+        torch.cuda.synchronize(); a=time.perf_counter()
+        km,off=eng.bucket_by_owner(sub,1)
+        torch.cuda.synchronize(); b=time.perf_counter()
+        r,w=rd.exchange_by_owner_async(km,off,None,2)
+        for x in w: x.wait()
+        torch.cuda.synchronize(); c=time.perf_counter()
+        tb+=b-a; te+=c-b
+    t1=time.perf_counter()
+    keys,counts,tot=rd.sharded_count(eng,reads,30,10_000_000,0,chunks=21)
+    torch.cuda.synchronize(); t2=time.perf_counter()
+    print("iter",it,"bucket %.1f ms exchange %.1f ms loop %.1f ms | sharded_count %.1f ms"%(tb*1e3,te*1e3,(t1-t0)*1e3,(t2-t1)*1e3), tot, flush=True)
 dist.destroy_process_group()

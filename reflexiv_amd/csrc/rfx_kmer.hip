@@ -1188,13 +1188,23 @@ __global__ __launch_bounds__(SKT) void k_sk_hist(ReadSrc s, Level lv, uint64_t *
             uint32_t mask = 0, nr = 0;
             // run loop: the r-th run of every lane is handled in the same iteration, so the header
             // stores of a wave go to consecutive words
+            uint32_t own[2] = {0, 0};                    // owner mode: the runs' owners, 8 bits each
             seg_runs<W, SK_DESC_RUNLOOP>(s, read_nk(s, q.r), q.sgm, w, [&](int i0, int, uint32_t canon) {
-                const uint32_t hdr = (uint32_t)((mmer_hash64(canon) << OWNER_BITS) >> 32);
-                atomicAdd(&h[rec_digit(hdr, 0, lv.bits)], 1u);
-                if (nr < (uint32_t)SKD) desc[(int64_t)(1 + nr) * s.n_threads + g] = hdr;
+                const uint64_t h64 = mmer_hash64(canon);
+                const uint32_t hdr = (uint32_t)((h64 << OWNER_BITS) >> 32);
+                const unsigned d = lv.n_owners > 0 ? (unsigned)__umul64hi(h64, (uint64_t)lv.n_owners) : rec_digit(hdr, 0, lv.bits);
+                atomicAdd(&h[d], 1u);
+                if (nr < (uint32_t)SKD) {
+                    desc[(int64_t)(1 + nr) * s.n_threads + g] = hdr;
+                    if (nr < 4) own[0] |= d << (8 * nr); else own[1] |= d << (8 * (nr - 4));
+                }
                 mask |= 1u << i0; nr++;
             }, &hi, &lo, SK_DESC_RUNLOOP ? wmcol : nullptr);
             desc[g] = mask | (nr << 16);
+            if (lv.n_owners > 0) {
+                desc[(int64_t)(1 + SKD) * s.n_threads + g] = own[0];
+                desc[(int64_t)(2 + SKD) * s.n_threads + g] = own[1];
+            }
         } else {
             seg_runs<W, SK_HIST_RUNLOOP>(s, read_nk(s, q.r), q.sgm, w, [&](int, int, uint32_t canon) { atomicAdd(&h[sk_digit(canon, lv)], 1u); }, &hi, &lo);
         }
@@ -1287,6 +1297,11 @@ __global__ __launch_bounds__(SKT, 8) void k_sk_scatter(ReadSrc s, Level lv, cons
                     uint32_t hd[SKD];
 #pragma unroll
                     for (int r = 0; r < SKD; r++) hd[r] = (uint32_t)r < nr ? desc[(int64_t)(1 + r) * s.n_threads + g] : 0u;
+                    uint32_t own[2] = {0, 0};
+                    if (lv.n_owners > 0) {
+                        own[0] = desc[(int64_t)(1 + SKD) * s.n_threads + g];
+                        own[1] = desc[(int64_t)(2 + SKD) * s.n_threads + g];
+                    }
                     uint32_t starts = m & 0xffffu;
 #pragma unroll
                     for (int r = 0; r < SKD; r++) {
@@ -1294,7 +1309,7 @@ __global__ __launch_bounds__(SKT, 8) void k_sk_scatter(ReadSrc s, Level lv, cons
                             const int i0 = __ffs((int)starts) - 1;
                             starts &= starts - 1;
                             const int i1 = starts ? __ffs((int)starts) - 1 : v;
-                            put(i0, i1 - i0, hd[r], rec_digit(hd[r], 0, lv.bits));
+                            put(i0, i1 - i0, hd[r], lv.n_owners > 0 ? (own[r >> 2] >> (8 * (r & 3))) & 255u : rec_digit(hd[r], 0, lv.bits));
                         }
                     }
                 }
@@ -1849,8 +1864,9 @@ static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv
     RFX_HIP(scanned.alloc(((size_t)nb * G + 1) * 8, ctx->stream));
     // run descriptors (hist -> scatter) live in the workspace slot the records do not use yet
     uint32_t *desc = nullptr;
-    const bool want_desc = use_ws && lv.n_owners == 0 && !(getenv("RFX_SK_DESC") && atoi(getenv("RFX_SK_DESC")) == 0);
-    if (want_desc) desc = (uint32_t *)ctx->ws_get(ws_slot == 0 ? 1 : 0, (size_t)(1 + SKD) * 4 * (size_t)rsrc.n_threads);
+    const bool want_desc = lv.n_owners <= 64 && !(getenv("RFX_SK_DESC") && atoi(getenv("RFX_SK_DESC")) == 0);
+    // (records into the caller's buffer: both slots are free; owner mode adds two words of owners)
+    if (want_desc) desc = (uint32_t *)ctx->ws_get(use_ws && ws_slot == 1 ? 0 : 1, (size_t)(3 + SKD) * 4 * (size_t)rsrc.n_threads);
     {
         ScopedTimer t(ctx, hn);
         if (desc) launch_sk_hist<true>(W, dim3(G), ctx->stream, rsrc, lv, bh.as<uint64_t>(), desc);

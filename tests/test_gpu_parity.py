@@ -996,3 +996,40 @@ def test_sharded_count_through_rccl_one_rank(rfx, torch_mod):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_degenerate_inputs(rfx, torch_mod):
+    """Empty and minimal inputs through every device entry point: no reads, reads shorter than k, one
+    window, one read -- nothing to count is an answer, not an error."""
+    torch = torch_mod
+    one = torch.zeros(8, dtype=torch.int64, device="cuda")
+    dk = torch.empty(64, dtype=torch.int64, device="cuda"); dc = torch.empty(64, dtype=torch.int32, device="cuda")
+    dc64 = torch.empty(64, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    # no reads
+    assert rfx.count_reads_dev(one.data_ptr(), 0, 1, 20, 31, dk.data_ptr(), dc.data_ptr(), 64, 1) == (0, 0, 0)
+    assert rfx.count_reads_w_dev(one.data_ptr(), 0, 3, 80, 63, dk.data_ptr(), dc64.data_ptr(), 32, 1) == (0, 0, 0)
+    # reads shorter than k (the reference skips them: len - k - endClip <= 1)
+    assert rfx.count_reads_dev(one.data_ptr(), 2, 1, 31, 31, dk.data_ptr(), dc.data_ptr(), 64, 1) == (0, 0, 0)
+    # one read, a few windows: poly-A
+    for L, k in ((40, 31), (33, 31), (35, 21)):
+        wpr = (L + 31) // 32
+        w = torch.zeros(wpr, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        m, nd, inst = rfx.count_reads_dev(w.data_ptr(), 1, wpr, L, k, dk.data_ptr(), dc.data_ptr(), 64, 1)
+        want = O.extract_canon(np.frombuffer(b"A" * L, np.uint8), np.array([0, L], np.int64), k)
+        assert inst == len(want) and (m, nd) == (1, 1) and int(dc[0]) == len(want) and int(dk[0]) == int(want[0])
+    # k > 31, one read of exactly k + 2 bases
+    L, k = 65, 63
+    wpr = (L + 31) // 32
+    w = torch.zeros(wpr, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    m, nd, inst = rfx.count_reads_w_dev(w.data_ptr(), 1, wpr, L, k, dk.data_ptr(), dc64.data_ptr(), 32, 1)
+    assert (m, nd, inst) == (1, 1, 3) and int(dc64[0]) == 3
+    # host operators on empty inputs
+    e8 = np.empty(0, np.uint8); off0 = np.zeros(1, np.int64)
+    assert len(rfx.ReverseComplementKmerBinaryExtraction(e8, off0, 31)) == 0
+    k_, c_, d_ = rfx.KmerCounting_and_CoverageFilter(np.empty(0, np.uint64), 1)
+    assert len(k_) == 0 and d_ == 0
+    assert len(rfx.ReverseComplementKmerBinaryExtractionFromDataset64(e8, off0, 63)) == 0

@@ -174,6 +174,22 @@ __global__ void k_emit(const Desc *__restrict__ desc, const uint32_t *__restrict
     const int64_t L = d.len;
     const int64_t wo = (int64_t)owoff[i];
     omarker[j] = m; oleft[j] = d.left; oright[j] = d.right; oext_off[j] = wo;
+    if (L <= 31) {
+        // Single-word output (every record of the first passes): S_out has at most (k-1) + 31 <= 61
+        // bases, so it is assembled as one 128-bit value with shifts and cut into key and extension --
+        // the same bases the per-base walk below produces (seq_of / oriented in the oracle), ~40
+        // instructions instead of ~60 base lookups.
+        typedef unsigned __int128 u128;
+        const u128 ea = (u128)(s.a.w[0] & low_mask((int)s.a.len));
+        u128 S = s.a.marker == 1 ? (((u128)s.a.key << (2 * (int)s.a.len)) | ea) : ((ea << (2 * sub)) | (u128)s.a.key);
+        if (d.type == 2) S = (S << (2 * (int)s.b.len)) | (u128)(s.b.w[0] & low_mask((int)s.b.len));
+        uint64_t kk, eb;
+        if (m == 1) { kk = (uint64_t)(S >> (2 * (int)L)); eb = (uint64_t)S & low_mask((int)L); }
+        else { eb = (uint64_t)(S >> (2 * sub)); kk = (uint64_t)S & low_mask(sub); }
+        okey[j] = kk;
+        oext[wo] = (1ULL << (2 * (int)L)) | eb;
+        return;
+    }
     // key: first (m == 1) or last (m == 2) k-1 bases of S_out
     const int64_t kshift = m == 1 ? 0 : L;
     uint64_t kk = 0;

@@ -1047,6 +1047,7 @@ __global__ void k_reduce_partials(const uint64_t *__restrict__ pk, const uint32_
 // partition levels instead of 8, and the leaf expands records straight into its LDS table, so the
 // 8-byte instance array never exists in HBM.  (KMC / Gerbil-style, re-cut for wave64 + LDS.)
 constexpr int SK_M = 13;
+constexpr int SK_MIN_W = 9;           // record path for k = 21..31 (W = k - 12 m-mers per window)
 constexpr int SKT = 1024;             // threads per workgroup of the reads -> records kernels
 #ifndef SK_HIST_RUNLOOP
 #define SK_HIST_RUNLOOP false
@@ -1098,34 +1099,45 @@ __device__ __forceinline__ void seg_runs(const ReadSrc &s, int nk_r, int sgm, co
         fm = ((fm << 2) | b) & mmask;
         rm = (rm >> 2) | ((b ^ 3u) << (M2 - 2));
     }
-    // sliding minimum over W m-mers with two blocks: window i = suffix of block 0 from i
-    // joined with the prefix of block 1 up to i-1 (needs W >= PK)
+    // per-window minimiser = sliding minimum over W m-mers (van Herk: suffix minima and prefix minima
+    // inside blocks of W m-mers; a window spans at most two blocks)
+    uint32_t wm[PK];
+    if constexpr (W >= PK - 1) {
+        // two blocks cover the segment: suffixes of [0, W) and prefixes of [W, NM), in place
 #pragma unroll
-    for (int j = W - 2; j >= 0; j--) val[j] = val[j] < val[j + 1] ? val[j] : val[j + 1];
+        for (int j = W - 2; j >= 0; j--) val[j] = val[j] < val[j + 1] ? val[j] : val[j + 1];
 #pragma unroll
-    for (int j = W + 1; j < NM; j++) val[j] = val[j] < val[j - 1] ? val[j] : val[j - 1];
+        for (int j = W + 1; j < NM; j++) val[j] = val[j] < val[j - 1] ? val[j] : val[j - 1];
+        wm[0] = val[0];
+#pragma unroll
+        for (int i = 1; i < PK; i++) wm[i] = val[i] < val[W + i - 1] ? val[i] : val[W + i - 1];
+    } else {
+        uint32_t sfx[NM], pfx[NM];
+#pragma unroll
+        for (int j = NM - 1; j >= 0; j--)
+            sfx[j] = (j % W == W - 1 || j == NM - 1) ? val[j] : (val[j] < sfx[j + 1] ? val[j] : sfx[j + 1]);
+#pragma unroll
+        for (int j = 0; j < NM; j++) pfx[j] = (j % W == 0) ? val[j] : (val[j] < pfx[j - 1] ? val[j] : pfx[j - 1]);
+#pragma unroll
+        for (int i = 0; i < PK; i++) wm[i] = sfx[i] < pfx[i + W - 1] ? sfx[i] : pfx[i + W - 1];
+    }
     if constexpr (!RUNLOOP) {
         // cheap emit(): call it where the run ends (16 divergent call sites)
-        uint32_t cur = val[0];
+        uint32_t cur = wm[0];
         int start = 0;
 #pragma unroll
         for (int i = 1; i < PK; i++) {
-            const uint32_t wi = val[i] < val[W + i - 1] ? val[i] : val[W + i - 1];
-            if (i < v && wi != cur) {
+            if (i < v && wm[i] != cur) {
                 emit(start, i - start, cur);
-                cur = wi; start = i;
+                cur = wm[i]; start = i;
             }
         }
         emit(start, v - start, cur);
         return;
     }
-    // per-window minimiser, then a bit per window that starts a run.  The runs are walked in a
-    // loop of their own so that emit() -- the expensive part -- runs once per run of the busiest
-    // lane (~6 times) instead of once per window position (16 divergent call sites).
-    uint32_t wm[PK];
-    wm[0] = val[0];
-#pragma unroll
-    for (int i = 1; i < PK; i++) wm[i] = val[i] < val[W + i - 1] ? val[i] : val[W + i - 1];
+    // a bit per window that starts a run.  The runs are walked in a loop of their own so that emit()
+    // -- the expensive part -- runs once per run of the busiest lane (~6 times) instead of once per
+    // window position (16 divergent call sites).
     uint32_t starts = 1u;
 #pragma unroll
     for (int i = 1; i < PK; i++) starts |= (uint32_t)(i < v && wm[i] != wm[i - 1]) << i;
@@ -1817,15 +1829,16 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<RECS>::T *elems, 
 // super-k-mer records are used for k = 28..31 (W = k - 12 in 16..19); RFX_SUPERKMER=0 disables them
 static bool superkmer_enabled(int k) {
     if (const char *e = getenv("RFX_SUPERKMER")) if (atoi(e) == 0) return false;
-    return k >= SK_M + PK - 1 && k <= 31;
+    return k >= SK_M + SK_MIN_W - 1 && k <= 31;
 }
 
+#define RFX_SK_W_CASES(X) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18)
 template <bool DESC, class... Args>
 static void launch_sk_hist(int W, dim3 grid, hipStream_t st, Args... args) {
     switch (W) {
-        case 16: hipLaunchKernelGGL((k_sk_hist<16, DESC>), grid, dim3(SKT), 0, st, args...); break;
-        case 17: hipLaunchKernelGGL((k_sk_hist<17, DESC>), grid, dim3(SKT), 0, st, args...); break;
-        case 18: hipLaunchKernelGGL((k_sk_hist<18, DESC>), grid, dim3(SKT), 0, st, args...); break;
+#define X(w) case w: hipLaunchKernelGGL((k_sk_hist<w, DESC>), grid, dim3(SKT), 0, st, args...); break;
+        RFX_SK_W_CASES(X)
+#undef X
         default: hipLaunchKernelGGL((k_sk_hist<19, DESC>), grid, dim3(SKT), 0, st, args...); break;
     }
 }
@@ -1840,9 +1853,9 @@ static hipError_t launch_sk_scatter_w(dim3 grid, size_t lds, hipStream_t st, Arg
 template <bool DESC, class... Args>
 static hipError_t launch_sk_scatter(int W, dim3 grid, size_t lds, hipStream_t st, Args... args) {
     switch (W) {
-        case 16: return launch_sk_scatter_w<16, DESC>(grid, lds, st, args...);
-        case 17: return launch_sk_scatter_w<17, DESC>(grid, lds, st, args...);
-        case 18: return launch_sk_scatter_w<18, DESC>(grid, lds, st, args...);
+#define X(w) case w: return launch_sk_scatter_w<w, DESC>(grid, lds, st, args...);
+        RFX_SK_W_CASES(X)
+#undef X
         default: return launch_sk_scatter_w<19, DESC>(grid, lds, st, args...);
     }
 }

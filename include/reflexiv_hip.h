@@ -236,7 +236,7 @@ int rfx_dev_bucket_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_rea
                             int64_t *d_owner_off, int64_t *h_owner_off);
 
 /* The same two steps on super-k-mer RECORDS (16 bytes per run of <= 16 consecutive windows that
- * share a minimiser; ~2.6 B per instance instead of 8), for k = 28..31.  Bucketing: call with
+ * share a minimiser; ~2.6 B per instance instead of 8), for k = 21..31.  Bucketing: call with
  * d_out = NULL / cap_records = 0 to learn *out_n_records (returns RFX_E_CAP), then with a buffer.
  * Counting: n_instances_hint (k-mer instances the records hold, 0 = unknown) sizes the radix plan. */
 int rfx_dev_bucket_records_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read,

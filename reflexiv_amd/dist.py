@@ -19,7 +19,7 @@ import torch.distributed as dist
 class HipEngine:
     """Local compute on one MI355X through libreflexiv_hip.so.
 
-    For k = 28..31 the unit that crosses the exchange is the 16-byte super-k-mer record (two int64
+    For k = 21..31 the unit that crosses the exchange is the 16-byte super-k-mer record (two int64
     per record, ~2.6 B per k-mer instance); otherwise the 8-byte canonical k-mer."""
 
     def __init__(self, rfx, records: bool = True):
@@ -29,7 +29,7 @@ class HipEngine:
         self.width = 1            # int64 words per exchanged unit
 
     def _use_records(self, k):
-        return self.records and 28 <= k <= 31
+        return self.records and 21 <= k <= 31
 
     def bucket_by_owner(self, reads, n_owners):
         """reads = dict(words=int64 cuda tensor, n_reads, wpr, read_len, k) ->

@@ -119,7 +119,6 @@ def main():
     nk = rfx.kmers_per_read_w(L, k) if wide else rfx.kmers_per_read(L, k)
     n_inst = nk * n_reads                                     # instances per rank per step
     if wide:
-        assert world == 1, "k > 31 is a single-GPU path this round"
         args.no_contigs = True                                # the assembler's k > 31 twin is SURVEY.md 8f-3
         args.no_cpu_baseline = True
 
@@ -143,7 +142,7 @@ def main():
     shard = {}
 
     def step():
-        if wide:
+        if wide and not multi:
             return rfx.count_reads_w_dev(d_words.data_ptr(), n_reads, wpr, L, k, d_keys.data_ptr(), d_counts.data_ptr(),
                                          cap, args.cover)
         if not multi:
@@ -151,7 +150,8 @@ def main():
                                               d_counts.data_ptr(), cap, args.cover)
             return m, nd, inst
         # enough chunks that no per-peer message needs the staged rounds of dist._alltoallv (512 MiB cap)
-        est = 2.7 * n_inst / world / rd.A2A_LIMIT_BYTES
+        # (k <= 31: ~2.7 B of super-k-mer record per instance; k > 31: one 16-byte element per instance)
+        est = (16.0 if wide else 2.7) * n_inst / world / rd.A2A_LIMIT_BYTES
         chunks = max(args.exchange_chunks, int(est) + 1)
         keys, counts, tot = rd.sharded_count(engine, reads, args.cover, 10_000_000, 0, chunks=chunks)
         shard["keys"], shard["counts"] = keys, counts

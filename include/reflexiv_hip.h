@@ -220,6 +220,19 @@ int rfx_dev_count_reads_ragged(rfx_ctx *ctx, const uint64_t *d_words, const uint
                                uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap,
                                int64_t *out_n, int64_t *out_distinct, int64_t *out_instances);
 
+/* Multi-GPU exchange support for k = 33..63: the canonical two-word k-mers of packed reads (16-byte
+ * elements {word0, word1}) written contiguously per owner (owner = mulhi(hash(k-mer), n_owners)),
+ * d_owner_off[n_owners+1] element offsets; and the count of such elements after the exchange
+ * (any order) -> ascending (2 words per key, int64 counts), as rfx_dev_count_reads_w returns them. */
+int rfx_dev_bucket_wide_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads,
+                                 int words_per_read, int read_len, int k, int front_clip, int end_clip,
+                                 int n_owners, void *d_out_elems, int64_t cap_elems,
+                                 int64_t *d_owner_off, int64_t *h_owner_off);
+int rfx_dev_count_wide_elems(rfx_ctx *ctx, const void *d_elems, int64_t n_elems, int k,
+                             int min_cov, int max_cov,
+                             uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap,
+                             int64_t *out_n, int64_t *out_distinct);
+
 /* Same, from an explicit k-mer array (the reduceByKey input) in HBM. */
 int rfx_dev_count_kmers(rfx_ctx *ctx, const uint64_t *d_kmers, int64_t n,
                         int min_cov, int max_cov, int twin,

@@ -307,6 +307,27 @@ class Reflexiv:
         self._check(st, "rfx_dev_count_reads_ragged")
         return int(n.value), int(d.value), int(inst.value)
 
+    def bucket_wide_by_owner_dev(self, d_words: int, n_reads: int, words_per_read: int, read_len: int, k: int,
+                                 n_owners: int, d_out: int, cap_elems: int, d_owner_off: int, front_clip=0, end_clip=0):
+        """k = 33..63: two-word k-mers (16 B each) grouped by owning rank -> owner_off[n_owners+1] (host)."""
+        h = np.empty(n_owners + 1, np.int64)
+        self._check(self.L.rfx_dev_bucket_wide_by_owner(self.ctx, C.c_void_p(d_words), C.c_int64(n_reads), words_per_read,
+                                                        read_len, k, front_clip, end_clip, n_owners, C.c_void_p(d_out),
+                                                        C.c_int64(cap_elems), C.c_void_p(d_owner_off), _p(h)),
+                    "rfx_dev_bucket_wide_by_owner")
+        return h
+
+    def count_wide_elems_dev(self, d_elems: int, n_elems: int, k: int, d_out_keys: int, d_out_counts: int, cap: int,
+                             min_cov=2, max_cov=10_000_000):
+        m, d = C.c_int64(0), C.c_int64(0)
+        st = self.L.rfx_dev_count_wide_elems(self.ctx, C.c_void_p(d_elems), C.c_int64(n_elems), k, min_cov, max_cov,
+                                             C.c_void_p(d_out_keys), C.c_void_p(d_out_counts), C.c_int64(cap),
+                                             C.byref(m), C.byref(d))
+        if st == RFX_E_CAP:
+            raise RfxError(st, "rfx_dev_count_wide_elems", f"needs room for {m.value} survivors, cap is {cap}")
+        self._check(st, "rfx_dev_count_wide_elems")
+        return int(m.value), int(d.value)
+
     def count_kmers_dev(self, d_kmers: int, n: int, d_out_keys: int, d_out_counts: int, cap: int, min_cov=2,
                         max_cov=10_000_000, twin=TWIN_DS):
         m, d = C.c_int64(0), C.c_int64(0)

@@ -515,6 +515,33 @@ int rfx_dev_count_reads_ragged(rfx_ctx *ctx, const uint64_t *d_words, const uint
                         out_distinct);
 }
 
+int rfx_dev_bucket_wide_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read, int read_len,
+                                 int k, int front_clip, int end_clip, int n_owners, void *d_out_elems, int64_t cap_elems,
+                                 int64_t *d_owner_off, int64_t *h_owner_off) {
+    if (!ctx || !d_words || !d_owner_off || n_reads < 0 || words_per_read * 32 < read_len) return RFX_E_ARG;
+    RFX_TRY(check_k_w(k));
+    if (!wide_fast_path(k) || front_clip < 0 || end_clip < 0) return RFX_E_ARG;      // two-word k-mers only
+    RFX_HIP(hipSetDevice(ctx->device));
+    const int64_t nk = kmers_per_read_w(read_len, k, front_clip, end_clip);
+    return bucket_wide_by_owner(ctx, d_words, n_reads, words_per_read, nk, k, front_clip, n_owners, d_out_elems, cap_elems,
+                                d_owner_off, h_owner_off);
+}
+
+int rfx_dev_count_wide_elems(rfx_ctx *ctx, const void *d_elems, int64_t n_elems, int k, int min_cov, int max_cov,
+                             uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n,
+                             int64_t *out_distinct) {
+    if (!ctx || !out_n || n_elems < 0 || (n_elems > 0 && !d_elems)) return RFX_E_ARG;
+    RFX_TRY(check_k_w(k));
+    if (!wide_fast_path(k)) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    ctx->timing.clear();
+    const int st = count_filter_w2(ctx, (const uint64_t *)d_elems, n_elems, k, min_cov, max_cov, d_out_keys, d_out_counts,
+                                   cap, out_n, out_distinct);
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    ScopedTimer::collect(ctx);
+    return st;
+}
+
 int rfx_dev_count_kmers(rfx_ctx *ctx, const uint64_t *d_kmers, int64_t n, int min_cov, int max_cov, int twin,
                         void *d_workspace, int64_t workspace_bytes, uint64_t *d_out_keys, int32_t *d_out_counts,
                         int64_t cap, int64_t *out_n, int64_t *out_distinct) {

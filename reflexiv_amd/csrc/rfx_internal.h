@@ -193,6 +193,8 @@ int count_wide2(rfx_ctx *ctx, const void *d_elems, int64_t n, int min_cov, int m
 int count_wide2_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,
                       int min_cov, int max_cov, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n,
                       int64_t *out_distinct);
+int bucket_wide_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,
+                         int n_owners, void *d_out, int64_t cap_elems, int64_t *d_owner_off, int64_t *h_owner_off);
 int synth_genome(rfx_ctx *ctx, uint64_t seed, int64_t genome_len, uint64_t *d_genome);
 int synth_reads(rfx_ctx *ctx, uint64_t seed, const uint64_t *d_genome, int64_t genome_len,
                 int64_t first_read, int64_t n_reads, int read_len, uint32_t err, int words_per_read,

@@ -1348,10 +1348,16 @@ __device__ __forceinline__ uint64_t wide_hash(uint64_t hi, uint64_t lo) {
     x *= 0xD6E8FEB86659FD93ULL;
     return x ^ (x >> 32);
 }
+// (the top OWNER_BITS of the hash pick the owning GPU -- mulhi(hash, n_owners) -- and are skipped by the
+// local digits, as on the k <= 31 path)
 template <bool WIDE>
 __device__ __forceinline__ unsigned level_digit(const Rec &r, int used, int bits) {
-    if constexpr (WIDE) return bits ? (unsigned)((wide_hash(r.w0, r.w1) << used) >> (64 - bits)) : 0u;
+    if constexpr (WIDE) return bits ? (unsigned)(((wide_hash(r.w0, r.w1) << OWNER_BITS) << used) >> (64 - bits)) : 0u;
     else return rec_digit(rec_hdr(r), used, bits);
+}
+__device__ __forceinline__ unsigned wide_level1_digit(const Rec &r, const Level &lv) {
+    if (lv.n_owners > 0) return (unsigned)__umul64hi(wide_hash(r.w0, r.w1), (uint64_t)lv.n_owners);
+    return level_digit<true>(r, 0, lv.bits);
 }
 
 // levels >= 2 on records: virtual workgroups as for k-mers, digit from the record header
@@ -1494,7 +1500,7 @@ __device__ __forceinline__ Rec w2_step(W2State &st, int res, uint64_t mres) {
 
 __global__ __launch_bounds__(W2T) void k_w2_hist(WideSrc s, Level lv, uint64_t *__restrict__ blockhist) {
     __shared__ uint32_t h[1 << MAX_BITS];
-    const int nb = 1 << lv.bits;
+    const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
     for (int i = threadIdx.x; i < nb; i += W2T) h[i] = 0;
     __syncthreads();
     const int res = s.k - 32;
@@ -1502,7 +1508,7 @@ __global__ __launch_bounds__(W2T) void k_w2_hist(WideSrc s, Level lv, uint64_t *
     for (int64_t g = (int64_t)blockIdx.x * W2T + threadIdx.x; g < s.total; g += (int64_t)gridDim.x * W2T) {
         W2State st;
         w2_init(s, g, st);
-        while (st.j < st.v) atomicAdd(&h[level_digit<true>(w2_step(st, res, mres), 0, lv.bits)], 1u);
+        while (st.j < st.v) atomicAdd(&h[wide_level1_digit(w2_step(st, res, mres), lv)], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nb; i += W2T) blockhist[(int64_t)i * gridDim.x + blockIdx.x] = h[i];
@@ -1511,7 +1517,7 @@ __global__ __launch_bounds__(W2T) void k_w2_hist(WideSrc s, Level lv, uint64_t *
 __global__ __launch_bounds__(W2T) void k_w2_scatter(WideSrc s, Level lv, const uint64_t *__restrict__ scanned,
                                                     Rec *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char w2_smem[];
-    const int nb = 1 << lv.bits;
+    const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
 #define buf ((Rec *)w2_smem)
 #define tail ((unsigned long long *)(w2_smem + (size_t)nb * W2B * sizeof(Rec)))
 #define head (tail + nb)
@@ -1528,7 +1534,7 @@ __global__ __launch_bounds__(W2T) void k_w2_scatter(WideSrc s, Level lv, const u
             for (int q = 0; q < W2_STEPS; q++) {
                 if (st.j < st.v) {
                     const Rec e = w2_step(st, res, mres);
-                    const unsigned d = level_digit<true>(e, 0, lv.bits);
+                    const unsigned d = wide_level1_digit(e, lv);
                     const unsigned long long pos = atomicAdd(&tail[d], 1ULL);
                     if (pos - head[d] < (unsigned long long)W2B) buf[(size_t)d * W2B + (pos & (W2B - 1))] = e;
                     else out[pos] = e;
@@ -2276,6 +2282,60 @@ int count_wide2(rfx_ctx *ctx, const void *d_elems, int64_t n, int min_cov, int m
                         cap, out_n, out_distinct);
 }
 
+// level 1 of the k = 33..63 path: packed uniform reads -> two-word elements grouped by `lv`
+// (radix digit or owner) in d_dst, group offsets in d_seg_off[nb + 1]
+static int wide_level1(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,
+                       const Level &lv, Rec *d_dst, uint64_t *d_seg_off) {
+    const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
+    WideSrc ws{d_words, n_reads, nk, ceil_div(nk, W2SEG), 0, wpr, k, fc};
+    ws.total = n_reads * ws.segs;
+    const unsigned G = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(ws.total, W2T), (int64_t)ctx->num_cu));
+    DevBuf bh, scanned;
+    RFX_HIP(bh.alloc((size_t)nb * G * 8, ctx->stream));
+    RFX_HIP(scanned.alloc(((size_t)nb * G + 1) * 8, ctx->stream));
+    {
+        ScopedTimer t(ctx, "hist1");
+        hipLaunchKernelGGL(k_w2_hist, dim3(G), dim3(W2T), 0, ctx->stream, ws, lv, bh.as<uint64_t>());
+        RFX_HIP(hipGetLastError());
+    }
+    RFX_TRY(exclusive_scan_u64(ctx, bh.as<uint64_t>(), scanned.as<uint64_t>(), (int64_t)nb * G));
+    hipLaunchKernelGGL(k_bin_offsets, dim3((unsigned)ceil_div(nb + 1, 256)), dim3(256), 0, ctx->stream,
+                       (const uint64_t *)scanned.as<uint64_t>(), nb, (int64_t)G, d_seg_off);
+    RFX_HIP(hipGetLastError());
+    {
+        ScopedTimer t(ctx, "part1");
+        const size_t lds = (size_t)nb * (W2B * sizeof(Rec) + 16);
+        RFX_HIP(hipFuncSetAttribute((const void *)k_w2_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_w2_scatter, dim3(G), dim3(W2T), lds, ctx->stream, ws, lv, (const uint64_t *)scanned.as<uint64_t>(),
+                           d_dst);
+        RFX_HIP(hipGetLastError());
+    }
+    return RFX_OK;
+}
+
+// multi-GPU support: the two-word k-mers of packed uniform reads, grouped by owning rank
+int bucket_wide_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,
+                         int n_owners, void *d_out, int64_t cap_elems, int64_t *d_owner_off, int64_t *h_owner_off) {
+    if (n_owners < 1 || n_owners > 64) return RFX_E_ARG;
+    const int64_t n = nk * n_reads;
+    if (n > cap_elems) return RFX_E_CAP;
+    if (n <= 0) {
+        RFX_HIP(hipMemsetAsync(d_owner_off, 0, (size_t)(n_owners + 1) * 8, ctx->stream));
+        if (h_owner_off) memset(h_owner_off, 0, (size_t)(n_owners + 1) * 8);
+        return RFX_OK;
+    }
+    ctx->timing.clear();
+    Level lv{};
+    lv.n_owners = n_owners;
+    RFX_TRY(wide_level1(ctx, d_words, n_reads, wpr, nk, k, fc, lv, (Rec *)d_out, reinterpret_cast<uint64_t *>(d_owner_off)));
+    if (h_owner_off) {
+        RFX_HIP(hipMemcpyAsync(h_owner_off, d_owner_off, (size_t)(n_owners + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    ScopedTimer::collect(ctx);
+    return RFX_OK;
+}
+
 // k = 33..63 from packed uniform reads: level 1 straight from the reads, then count_wide2's levels/leaves
 int count_wide2_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,
                       int min_cov, int max_cov, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n,
@@ -2295,32 +2355,11 @@ int count_wide2_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, in
     Level lv{};
     lv.bits = bits[0];
     const int nb = 1 << lv.bits;
-    WideSrc ws{d_words, n_reads, nk, ceil_div(nk, W2SEG), 0, wpr, k, fc};
-    ws.total = n_reads * ws.segs;
-    const unsigned G = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(ws.total, W2T), (int64_t)ctx->num_cu));
-    DevBuf bh, scanned, segA, segB, co_buf;
-    RFX_HIP(bh.alloc((size_t)nb * G * 8, ctx->stream));
-    RFX_HIP(scanned.alloc(((size_t)nb * G + 1) * 8, ctx->stream));
+    DevBuf segA, segB;
     RFX_HIP(segA.alloc(((size_t)nb + 1) * 8, ctx->stream));
-    {
-        ScopedTimer t(ctx, "hist1");
-        hipLaunchKernelGGL(k_w2_hist, dim3(G), dim3(W2T), 0, ctx->stream, ws, lv, bh.as<uint64_t>());
-        RFX_HIP(hipGetLastError());
-    }
-    RFX_TRY(exclusive_scan_u64(ctx, bh.as<uint64_t>(), scanned.as<uint64_t>(), (int64_t)nb * G));
-    hipLaunchKernelGGL(k_bin_offsets, dim3((unsigned)ceil_div(nb + 1, 256)), dim3(256), 0, ctx->stream,
-                       (const uint64_t *)scanned.as<uint64_t>(), nb, (int64_t)G, segA.as<uint64_t>());
-    RFX_HIP(hipGetLastError());
     Rec *dst = (Rec *)ctx->ws_get(0, (size_t)n * sizeof(Rec));
     if (!dst) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
-    {
-        ScopedTimer t(ctx, "part1");
-        const size_t lds = (size_t)nb * (W2B * sizeof(Rec) + 16);
-        RFX_HIP(hipFuncSetAttribute((const void *)k_w2_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_w2_scatter, dim3(G), dim3(W2T), lds, ctx->stream, ws, lv, (const uint64_t *)scanned.as<uint64_t>(),
-                           dst);
-        RFX_HIP(hipGetLastError());
-    }
+    RFX_TRY(wide_level1(ctx, d_words, n_reads, wpr, nk, k, fc, lv, dst, segA.as<uint64_t>()));
     DevBuf *seg_cur = &segA, *seg_next = &segB;
     int64_t nseg = nb;
     const Rec *cur = nullptr;

@@ -35,6 +35,15 @@ class HipEngine:
         """reads = dict(words=int64 cuda tensor, n_reads, wpr, read_len, k) ->
         (kmers int64[N] grouped by owner, owner_off int64[n_owners+1] on the host)."""
         self.k = reads["k"]
+        if reads["k"] > 31:                             # two-word k-mers (k = 33..63): 16-byte elements
+            n = self.rfx.kmers_per_read_w(reads["read_len"], reads["k"]) * reads["n_reads"]
+            self.n_instances, self.width = n, 2
+            out = torch.empty(2 * max(1, n), dtype=torch.int64, device=reads["words"].device)
+            doff = torch.empty(n_owners + 1, dtype=torch.int64, device=reads["words"].device)
+            torch.cuda.current_stream().synchronize()
+            h = self.rfx.bucket_wide_by_owner_dev(reads["words"].data_ptr(), reads["n_reads"], reads["wpr"],
+                                                  reads["read_len"], reads["k"], n_owners, out.data_ptr(), n, doff.data_ptr())
+            return out[:2 * n], torch.from_numpy(h.copy())
         n = self.rfx.kmers_per_read(reads["read_len"], reads["k"]) * reads["n_reads"]
         self.n_instances = n
         if self._use_records(reads["k"]):
@@ -67,6 +76,8 @@ class HipEngine:
 
     def estimate_units(self, reads):
         """records (k-mers) this rank's reads produce, from the ratio seen in the previous call; 0 = unknown"""
+        if reads["k"] > 31:
+            return self.rfx.kmers_per_read_w(reads["read_len"], reads["k"]) * reads["n_reads"]
         if self._use_records(reads["k"]):
             return int(self._records_per_read(reads) * reads["n_reads"])
         return self.rfx.kmers_per_read(reads["read_len"], reads["k"]) * reads["n_reads"]
@@ -94,6 +105,22 @@ class HipEngine:
 
     def count_kmers(self, kmers, min_cov, max_cov, twin):
         from ._lib import RfxError, RFX_E_CAP
+        if self.k is not None and self.k > 31:          # -> keys int64[2m] (two words per k-mer), counts int64[m]
+            n = int(kmers.numel()) // 2
+            cap = max(1 << 20, n // 8)
+            while True:
+                keys = torch.empty(2 * cap, dtype=torch.int64, device=kmers.device)
+                counts = torch.empty(cap, dtype=torch.int64, device=kmers.device)
+                torch.cuda.current_stream().synchronize()
+                try:
+                    m, d = self.rfx.count_wide_elems_dev(kmers.data_ptr(), n, self.k, keys.data_ptr(), counts.data_ptr(), cap,
+                                                         min_cov, max_cov)
+                    return keys[:2 * m], counts[:m], d
+                except RfxError as e:
+                    if e.status != RFX_E_CAP or cap >= 2 * n:
+                        raise
+                    del keys, counts
+                    cap = cap * 4
         n = int(kmers.numel()) // self.width
         recs = self.width == 2
         n_inst = n * 6 if recs else n
@@ -224,7 +251,7 @@ def sharded_count(engine, reads, min_cov, max_cov, twin, group=None, chunks: int
         kmers_numel, n_inst = int(kmers.numel()), getattr(engine, "n_instances", None)
     keys, counts, distinct = engine.count_kmers(recv, min_cov, max_cov, twin)
     tot = torch.tensor([kmers_numel if n_inst is None or width == 1 else int(n_inst), int(distinct),
-                        int(keys.numel())], dtype=torch.int64,
+                        int(counts.numel())], dtype=torch.int64,
                        device=keys.device)
     if world > 1:
         dist.all_reduce(tot, group=group)            # C4-style scalar reduce

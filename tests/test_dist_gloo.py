@@ -32,6 +32,42 @@ def owner_of(kmers, n):
     return ((hi * n + ((lo * n) >> np.uint64(32))) >> np.uint64(32)).astype(np.int64)
 
 
+def wide_hash(hi, lo):
+    """reflexiv_amd/csrc/rfx_kmer.hip wide_hash (two-word k-mers, k = 33..63)"""
+    with np.errstate(over="ignore"):
+        x = hi.astype(np.uint64) ^ (lo.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+        x = x * np.uint64(0xD6E8FEB86659FD93)
+    return x ^ (x >> np.uint64(32))
+
+
+def mulhi_owner(h, n):
+    n = np.uint64(n)
+    lo, hi = h & np.uint64(0xFFFFFFFF), h >> np.uint64(32)
+    return ((hi * n + ((lo * n) >> np.uint64(32))) >> np.uint64(32)).astype(np.int64)
+
+
+class OracleWideEngine:
+    """CPU stand-in for HipEngine on the k > 31 path (tests only): 16-byte elements {word0, word1}."""
+    width = 2
+
+    def bucket_by_owner(self, reads, n_owners):
+        self.k = reads["k"]
+        km = O.extract_canon_w(reads["bases"], reads["read_off"], reads["k"])        # [n, 2]
+        self.n_instances = len(km)
+        own = mulhi_owner(wide_hash(km[:, 0], km[:, 1]), n_owners)
+        order = np.argsort(own, kind="stable")
+        off = np.zeros(n_owners + 1, np.int64)
+        np.cumsum(np.bincount(own, minlength=n_owners), out=off[1:])
+        return torch.from_numpy(np.ascontiguousarray(km[order]).reshape(-1).view(np.int64)), torch.from_numpy(off)
+
+    def count_kmers(self, kmers, min_cov, max_cov, twin):
+        k2, c, d = O.count_filter_w(kmers.numpy().view(np.uint64).reshape(-1, 2), self.k, min_cov, max_cov)
+        return torch.from_numpy(k2.reshape(-1).view(np.int64)), torch.from_numpy(c), d
+
+    def split_reads(self, reads, chunks):
+        return OracleEngine.split_reads(self, reads, chunks)
+
+
 class OracleEngine:
     """CPU stand-in for HipEngine (tests only)."""
 
@@ -232,3 +268,45 @@ def test_sharded_extend_world1_without_process_group(golden_dir):
     o = rng.permutation(len(ex["keys_cov3"]))                   # any input order
     text, nc = rd.sharded_assemble(OracleOps(), ex["keys_cov3"][o], ex["counts_cov3"][o], prm)
     assert text == str(ex["contigs_ds_P4"])
+
+
+def _wide_worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q, chunks):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from reflexiv_amd import dist as rd
+        g = O.synth_genome(seed, G)
+        bases, off = O.synth_reads(seed, g, G, rank * per_rank, per_rank, L)
+        reads = dict(bases=bases, read_off=off, k=k)
+        keys, counts, tot = rd.sharded_count(OracleWideEngine(), reads, min_cov, 10_000_000, 0, chunks=chunks)
+        q.put((rank, keys.numpy().view(np.uint64).reshape(-1, 2).copy(), counts.numpy().copy(), tot))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 2)])
+def test_sharded_wide_count_equals_global_count(world, chunks):
+    """k = 63 (two-word k-mers): owner = mulhi(wide_hash, world); 16-byte elements cross the exchange."""
+    seed, G, per_rank, L, k, min_cov = 7, 15_000, 900, 120, 63, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wide_worker, args=(r, world, port, seed, G, per_rank, L, k, min_cov, q, chunks))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, per_rank * world, L)
+    km = O.extract_canon_w(bases, off, k)
+    wk, wc, wd = O.count_filter_w(km, k, min_cov)
+    for rank, kk, cc, tot in res:
+        assert tot == [len(km), wd, len(wk)]
+        assert np.all(mulhi_owner(wide_hash(kk[:, 0], kk[:, 1]), world) == rank)
+    allk = np.concatenate([r[1] for r in res]); allc = np.concatenate([r[2] for r in res])
+    order = np.lexsort((allk[:, 1], allk[:, 0]))
+    assert np.array_equal(allk[order], wk) and np.array_equal(allc[order], wc)

@@ -1033,3 +1033,58 @@ def test_degenerate_inputs(rfx, torch_mod):
     k_, c_, d_ = rfx.KmerCounting_and_CoverageFilter(np.empty(0, np.uint64), 1)
     assert len(k_) == 0 and d_ == 0
     assert len(rfx.ReverseComplementKmerBinaryExtractionFromDataset64(e8, off0, 63)) == 0
+
+
+@pytest.mark.gpu
+def test_wide_owner_buckets_and_sharded_count(rfx, torch_mod):
+    """k = 63 multi-GPU support: every two-word k-mer lands in the bucket of its owner
+    (mulhi(wide_hash, n_owners)), the per-owner counts are the global count restricted to the owner, and
+    the sharded driver on a one-rank RCCL group equals the fused device count."""
+    torch = torch_mod
+    import torch.distributed as dist
+    from reflexiv_amd import dist as rd
+    from tests.test_dist_gloo import wide_hash, mulhi_owner
+    seed, G, n_reads, L, k, owners = 17, 60_000, 30_000, 150, 63, 4
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    N = rfx.kmers_per_read_w(L, k) * n_reads
+    out = torch.empty(2 * N, dtype=torch.int64, device="cuda")
+    doff = torch.empty(owners + 1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    h = rfx.bucket_wide_by_owner_dev(dw.data_ptr(), n_reads, wpr, L, k, owners, out.data_ptr(), N, doff.data_ptr())
+    assert h[0] == 0 and h[-1] == N and np.all(np.diff(h) > 0)
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+    km = O.extract_canon_w(bases, off, k)
+    got = out.cpu().numpy().view(np.uint64).reshape(N, 2)
+    assert np.array_equal(got[np.lexsort((got[:, 1], got[:, 0]))], km[np.lexsort((km[:, 1], km[:, 0]))])
+    wk, wc, wd = O.count_filter_w(km, k, 2)
+    own_w = mulhi_owner(wide_hash(wk[:, 0], wk[:, 1]), owners)
+    tot_d = 0
+    for o in range(owners):
+        part = got[h[o]:h[o + 1]]
+        assert np.all(mulhi_owner(wide_hash(part[:, 0], part[:, 1]), owners) == o)
+        n_o = int(h[o + 1] - h[o])
+        dk = torch.empty(2 * n_o, dtype=torch.int64, device="cuda"); dc = torch.empty(n_o, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        m, d = rfx.count_wide_elems_dev(out[2 * int(h[o]):].data_ptr(), n_o, k, dk.data_ptr(), dc.data_ptr(), n_o, 2)
+        tot_d += d
+        assert np.array_equal(dk[:2 * m].cpu().numpy().view(np.uint64).reshape(m, 2), wk[own_w == o])
+        assert np.array_equal(dc[:m].cpu().numpy(), wc[own_w == o])
+    assert tot_d == wd
+    # the sharded driver through RCCL with one rank
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rfx.use_stream(torch.cuda.current_stream().cuda_stream)
+        eng = rd.HipEngine(rfx)
+        eng.force_exchange = True
+        reads = dict(words=dw, n_reads=n_reads, wpr=wpr, read_len=L, k=k)
+        keys, counts, tot = rd.sharded_count(eng, reads, 2, 10_000_000, 0, chunks=3)
+        assert tot == [N, wd, len(wk)]
+        assert np.array_equal(keys.cpu().numpy().view(np.uint64).reshape(-1, 2), wk) and np.array_equal(counts.cpu().numpy(), wc)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -60,6 +60,9 @@ def parse():
                     help="run the multi-GPU code path (owner buckets, RCCL all-to-all, gather) even with one rank")
     ap.add_argument("--exchange-chunks", type=int, default=4,
                     help="N > 1: read chunks whose all-to-all overlaps the bucketing of the next chunk (1 = no overlap)")
+    ap.add_argument("--exchange", choices=["pairs", "records"], default="pairs",
+                    help="N > 1, k <= 31: what crosses the all-to-all -- (k-mer, local count) pairs after a local combine "
+                         "(reduceByKey's map-side combine; fewest bytes at high coverage) or super-k-mer records")
     return ap.parse_args()
 
 
@@ -135,7 +138,7 @@ def main():
     d_keys = torch.empty(cap * W, dtype=torch.int64, device=dev)
     d_counts = torch.empty(cap, dtype=torch.int64 if wide else torch.int32, device=dev)
     reads = dict(words=d_words, n_reads=n_reads, wpr=wpr, read_len=L, k=k)
-    engine = rd.HipEngine(rfx)
+    engine = rd.HipEngine(rfx, combine=args.exchange == "pairs" and not wide)
     engine.force_exchange = args.force_dist
     timing_acc = {}
 
@@ -151,6 +154,7 @@ def main():
             return m, nd, inst
         # enough chunks that no per-peer message needs the staged rounds of dist._alltoallv (512 MiB cap)
         # (k <= 31: ~2.7 B of super-k-mer record per instance; k > 31: one 16-byte element per instance)
+        # (pairs: at most 16 B per distinct k-mer of a chunk -- bounded here by the record figure)
         est = (16.0 if wide else 2.7) * n_inst / world / rd.A2A_LIMIT_BYTES
         chunks = max(args.exchange_chunks, int(est) + 1)
         keys, counts, tot = rd.sharded_count(engine, reads, args.cover, 10_000_000, 0, chunks=chunks)
@@ -168,8 +172,10 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        engine.timing.clear()
         m, nd, inst = step()
-        for name, (ms, ln) in rfx.count_timing().items():
+        # N = 1: the one fused call; N > 1: every library call of the step (the engine adds them up)
+        for name, (ms, ln) in (engine.timing if multi else {n: list(v) for n, v in rfx.count_timing().items()}).items():
             a = timing_acc.setdefault(name, [0.0, 0])
             a[0] += ms; a[1] += ln
     sync_all()
@@ -188,7 +194,9 @@ def main():
         dom = max((n for n in timing_acc if n in ALGO_BYTES), key=lambda n: timing_acc[n][0])
         ms, launches = timing_acc[dom]
         per_launch_bytes = ALGO_BYTES[dom] * n_inst
-        avg_s = ms / 1e3 / max(1, launches)
+        # N > 1: a step runs the family several times over parts of the batch (chunks, then the merge):
+        # price the step's total time of the family against the batch's algorithmic bytes
+        avg_s = ms / 1e3 / (args.steps if multi else max(1, launches))
         achieved = per_launch_bytes / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(dom, n_inst),

@@ -260,6 +260,28 @@ int rfx_dev_count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records
                           int k, int min_cov, int max_cov, int twin, uint64_t *d_out_keys,
                           int32_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct);
 
+/* The same exchange AFTER a local combine -- the map-side combine of `reduceByKey`
+ * (P/ReflexivMain.java:155; Spark sums per key inside every map task before the shuffle): a rank
+ * counts its own reads first and ships (k-mer, partial count) PAIRS, 16 bytes {k-mer, count}, one per
+ * distinct k-mer of the rank instead of one unit per instance (k <= 31).
+ *   rfx_dev_combine_reads         reads -> every distinct canonical k-mer with its local count, no filter,
+ *                                 grouped by owner = mulhi(kmer_hash(k-mer), n_owners) (bucket o =
+ *                                 d_out_pairs[owner_off[o] .. owner_off[o+1]), *out_n pairs in all).  Both
+ *                                 d_scratch_pairs and d_out_pairs hold cap_pairs pairs; RFX_E_CAP with
+ *                                 *out_n = the capacity needed when that is short
+ *   rfx_dev_bucket_pairs_by_owner the grouping step alone (pairs with count 0 are dropped)
+ *   rfx_dev_merge_pairs           the owner's half: sum the partial counts per k-mer, then
+ *                                 KmerCoverageFilter (P/ReflexivMain.java:3115-3119), ascending order */
+int rfx_dev_combine_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read, int read_len,
+                          int k, int front_clip, int end_clip, int n_owners, void *d_scratch_pairs, void *d_out_pairs,
+                          int64_t cap_pairs, int64_t *d_owner_off, int64_t *h_owner_off, int64_t *out_n,
+                          int64_t *out_instances);
+int rfx_dev_bucket_pairs_by_owner(rfx_ctx *ctx, const void *d_pairs, int64_t n_pairs, int n_owners, void *d_out_pairs,
+                                  int64_t *d_owner_off, int64_t *h_owner_off);
+int rfx_dev_merge_pairs(rfx_ctx *ctx, const void *d_pairs, int64_t n_pairs, int k, int min_cov, int max_cov, int twin,
+                        uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n,
+                        int64_t *out_distinct);
+
 /* Whole driver  P/ReflexivMain.java:168-310 (DS :221-352) from the filtered, ascending
  * (kmer,count) list in HBM to the contig text in host memory.  trace (optional) receives
  * the record count after every extend pass. */

@@ -376,6 +376,44 @@ class Reflexiv:
         self._check(st, "rfx_dev_count_records")
         return int(m.value), int(d.value)
 
+    # ---- the exchange after a local combine (reduceByKey's map-side combine, P/ReflexivMain.java:155)
+    def combine_reads_dev(self, d_words: int, n_reads: int, wpr: int, read_len: int, k: int, n_owners: int,
+                          d_scratch_pairs: int, d_out_pairs: int, cap_pairs: int, d_owner_off: int,
+                          front_clip=0, end_clip=0):
+        """reads -> every distinct canonical k-mer with its local count as 16-byte {k-mer, count} pairs grouped
+        by owner (no filter) -> (n_pairs, owner_off host int64[n_owners+1], instances); RfxError(RFX_E_CAP)
+        carries the capacity needed in `.need`."""
+        m, inst = C.c_int64(0), C.c_int64(0)
+        h = np.zeros(n_owners + 1, np.int64)
+        st = self.L.rfx_dev_combine_reads(self.ctx, C.c_void_p(d_words), C.c_int64(n_reads), wpr, read_len, k,
+                                          front_clip, end_clip, n_owners, C.c_void_p(d_scratch_pairs),
+                                          C.c_void_p(d_out_pairs), C.c_int64(cap_pairs), C.c_void_p(d_owner_off), _p(h),
+                                          C.byref(m), C.byref(inst))
+        if st == RFX_E_CAP:
+            e = RfxError(st, "rfx_dev_combine_reads", f"needs room for {m.value} pairs, cap is {cap_pairs}")
+            e.need = int(m.value)
+            raise e
+        self._check(st, "rfx_dev_combine_reads")
+        return int(m.value), h, int(inst.value)
+
+    def bucket_pairs_by_owner_dev(self, d_pairs: int, n_pairs: int, n_owners: int, d_out_pairs: int, d_owner_off: int):
+        h = np.zeros(n_owners + 1, np.int64)
+        self._check(self.L.rfx_dev_bucket_pairs_by_owner(self.ctx, C.c_void_p(d_pairs), C.c_int64(n_pairs), n_owners,
+                                                         C.c_void_p(d_out_pairs), C.c_void_p(d_owner_off), _p(h)),
+                    "rfx_dev_bucket_pairs_by_owner")
+        return h
+
+    def merge_pairs_dev(self, d_pairs: int, n_pairs: int, k: int, d_out_keys: int, d_out_counts: int, cap: int,
+                        min_cov=2, max_cov=10_000_000, twin=TWIN_DS):
+        m, d = C.c_int64(0), C.c_int64(0)
+        st = self.L.rfx_dev_merge_pairs(self.ctx, C.c_void_p(d_pairs), C.c_int64(n_pairs), k, min_cov, max_cov, twin,
+                                        C.c_void_p(d_out_keys), C.c_void_p(d_out_counts), C.c_int64(cap),
+                                        C.byref(m), C.byref(d))
+        if st == RFX_E_CAP:
+            raise RfxError(st, "rfx_dev_merge_pairs", f"needs room for {m.value} survivors, cap is {cap}")
+        self._check(st, "rfx_dev_merge_pairs")
+        return int(m.value), int(d.value)
+
     def assemble_dev(self, d_keys: int, d_counts: int, n: int, prm: Params):
         """Driver P/ReflexivMain.java:168-310 from the filtered (kmer,count) list in HBM
         -> (contig text, n_contigs, trace)."""
@@ -407,7 +445,8 @@ class Reflexiv:
     def count_timing(self):
         """Per-kernel-family HIP-event timing of the last count call: {name: (ms, launches)}."""
         out = {}
-        for name in ("hist1", "part1", "hist2", "part2", "hist3", "part3", "leaf", "sort", "extract_w", "count_w"):
+        for name in ("hist1", "part1", "hist2", "part2", "hist3", "part3", "leaf", "sort", "extract_w", "count_w",
+                     "pair_hist", "pair_part"):
             ms, ln = C.c_float(0), C.c_int64(0)
             if self.L.rfx_last_count_timing(self.ctx, name.encode(), C.byref(ms), C.byref(ln)) == RFX_OK:
                 out[name] = (float(ms.value), int(ln.value))

@@ -569,8 +569,11 @@ int rfx_dev_bucket_records_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64
     RFX_TRY(check_k(k));
     RFX_HIP(hipSetDevice(ctx->device));
     ReadStore rs{d_words, n_reads, words_per_read, read_len, k, front_clip, end_clip};
-    return bucket_records_by_owner(ctx, &rs, n_owners, d_out_records, cap_records, d_owner_off, h_owner_off,
-                                   out_n_records);
+    ctx->timing.clear();
+    const int st = bucket_records_by_owner(ctx, &rs, n_owners, d_out_records, cap_records, d_owner_off, h_owner_off,
+                                           out_n_records);
+    if (h_owner_off) ScopedTimer::collect(ctx);        // (the call has synchronised)
+    return st;
 }
 
 int rfx_dev_count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_t n_instances_hint, int k,
@@ -581,6 +584,47 @@ int rfx_dev_count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records
     RFX_HIP(hipSetDevice(ctx->device));
     return count_records(ctx, d_records, n_records, n_instances_hint, k, min_cov, max_cov, twin, d_out_keys,
                          d_out_counts, cap, out_n, out_distinct);
+}
+
+int rfx_dev_combine_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read, int read_len,
+                          int k, int front_clip, int end_clip, int n_owners, void *d_scratch_pairs, void *d_out_pairs,
+                          int64_t cap_pairs, int64_t *d_owner_off, int64_t *h_owner_off, int64_t *out_n,
+                          int64_t *out_instances) {
+    if (!ctx || !d_words || !d_owner_off || n_reads < 0 || words_per_read * 32 < read_len || cap_pairs < 0) return RFX_E_ARG;
+    if (n_owners < 1 || n_owners > 64) return RFX_E_ARG;
+    RFX_TRY(check_k(k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    ReadStore rs{d_words, n_reads, words_per_read, read_len, k, front_clip, end_clip};
+    if (out_instances) *out_instances = kmers_per_read(read_len, k, front_clip, end_clip) * n_reads;
+    // local count: every distinct k-mer as a {k-mer, count} pair, block-allocated in the scratch buffer
+    // (holes have count 0); then one pass groups the pairs by owner and drops the holes
+    int64_t extent = 0;
+    int st = count_filter(ctx, &rs, nullptr, 0, 1, 0x7fffffff, RFX_TWIN_DS, nullptr, 0, (uint64_t *)d_scratch_pairs, nullptr,
+                          cap_pairs, &extent, nullptr, true);
+    if (out_n) *out_n = extent;
+    if (st != RFX_OK) return st;
+    int64_t h_local[65];
+    st = bucket_pairs_by_owner(ctx, d_scratch_pairs, extent, n_owners, d_out_pairs, d_owner_off, h_owner_off ? h_owner_off : h_local);
+    if (st != RFX_OK) return st;
+    if (out_n) *out_n = (h_owner_off ? h_owner_off : h_local)[n_owners];
+    return RFX_OK;
+}
+
+int rfx_dev_bucket_pairs_by_owner(rfx_ctx *ctx, const void *d_pairs, int64_t n_pairs, int n_owners, void *d_out_pairs,
+                                  int64_t *d_owner_off, int64_t *h_owner_off) {
+    if (!ctx || !d_owner_off || n_pairs < 0 || (n_pairs > 0 && (!d_pairs || !d_out_pairs))) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    ctx->timing.clear();
+    return bucket_pairs_by_owner(ctx, d_pairs, n_pairs, n_owners, d_out_pairs, d_owner_off, h_owner_off);
+}
+
+int rfx_dev_merge_pairs(rfx_ctx *ctx, const void *d_pairs, int64_t n_pairs, int k, int min_cov, int max_cov, int twin,
+                        uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n,
+                        int64_t *out_distinct) {
+    if (!ctx || n_pairs < 0) return RFX_E_ARG;
+    RFX_TRY(check_k(k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    return merge_pairs(ctx, d_pairs, n_pairs, k, min_cov, max_cov, twin, d_out_keys, d_out_counts, cap, out_n, out_distinct);
 }
 
 int rfx_dev_sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int key_bits,

@@ -180,7 +180,11 @@ int64_t count_workspace_bytes(int64_t n_kmers);
 int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, int64_t n,
                  int min_cov, int max_cov, int twin, void *ws, int64_t ws_bytes,
                  uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap,
-                 int64_t *out_n, int64_t *out_distinct);
+                 int64_t *out_n, int64_t *out_distinct, bool pair_out = false);
+int bucket_pairs_by_owner(rfx_ctx *ctx, const void *d_pairs, int64_t n, int n_owners, void *d_out,
+                          int64_t *d_owner_off, int64_t *h_owner_off);
+int merge_pairs(rfx_ctx *ctx, const void *d_pairs, int64_t n, int k, int min_cov, int max_cov, int twin,
+                uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct);
 int bucket_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, uint64_t *d_out,
                     int64_t cap, int64_t *d_owner_off, int64_t *h_owner_off);
 int bucket_records_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, void *d_out, int64_t cap_records,

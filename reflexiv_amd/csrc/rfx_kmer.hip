@@ -435,6 +435,8 @@ constexpr int LPROBE = 48;              // a probe sequence this long means the 
 constexpr uint64_t EMPTY = ~0ULL;
 constexpr int LSTACK = 48;
 constexpr int LB = 8;                   // instance loads in flight per lane
+constexpr int PBLOCK = 16384;           // pair_out: pairs per output block a workgroup reserves at a time
+constexpr unsigned long long NOBLK = ~0ULL;
 
 struct CountOut {
     unsigned long long n_out;        // survivors appended (may exceed cap)
@@ -459,17 +461,30 @@ struct alignas(16) Rec { uint64_t w0, w1; };
 __device__ __forceinline__ int rec_len(const Rec &r) { return (int)((r.w1 >> 32) & 15) + 1; }
 __device__ __forceinline__ uint32_t rec_hdr(const Rec &r) { return (uint32_t)r.w1; }
 
-template <bool RECS> struct LeafElem;
-template <> struct LeafElem<false> {
+// ELEM 0: a k-mer instance (8 B); 1: a super-k-mer record (16 B); 2: a (k-mer, partial count) pair
+// (16 B {key, count}: what crosses the multi-GPU exchange after the local combine)
+template <int ELEM> struct LeafElem;
+template <> struct LeafElem<0> {
     using T = uint64_t;
     static constexpr int PER_LANE = LB;
     __device__ static __forceinline__ T none() { return 0; }
+    __device__ static __forceinline__ uint64_t key(const T &e) { return e; }
+    __device__ static __forceinline__ uint32_t weight(const T &) { return 1u; }
     template <class F> __device__ static __forceinline__ void for_each_kmer(const T &e, int, F &&f) { f(e); }
 };
-template <> struct LeafElem<true> {
+template <> struct LeafElem<2> {
+    using T = Rec;
+    static constexpr int PER_LANE = LB / 2;
+    __device__ static __forceinline__ T none() { return Rec{0, 0}; }
+    __device__ static __forceinline__ uint64_t key(const T &e) { return e.w0; }
+    __device__ static __forceinline__ uint32_t weight(const T &e) { return (uint32_t)e.w1; }
+};
+template <> struct LeafElem<1> {
     using T = Rec;
     static constexpr int PER_LANE = 3;       // 64-record steps a wave holds in registers per leaf
     __device__ static __forceinline__ T none() { return Rec{0, 0}; }
+    __device__ static __forceinline__ uint64_t key(const T &e) { return e.w0; }
+    __device__ static __forceinline__ uint32_t weight(const T &) { return 1u; }
     // canonical k-mers of the record's windows, rolled in registers (same arithmetic as seg_keys)
     template <class F> __device__ static __forceinline__ void for_each_kmer(const T &e, int k, F &&f) {
         const int n = rec_len(e);
@@ -500,14 +515,16 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
     return x;
 }
 
-template <bool RECS>
-__global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>::T *__restrict__ keys,
+template <int ELEM>
+__global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<ELEM>::T *__restrict__ keys,
                                                    const uint64_t *__restrict__ leaf_off, int64_t nleaf,
                                                    const uint64_t *__restrict__ sl_begin, const uint64_t *__restrict__ sl_end,
                                                    uint64_t heavy, uint64_t n_elems, int k,
                                                    int min_cov, int max_cov, int apply_filter,
                                                    uint64_t *__restrict__ out_keys, int32_t *__restrict__ out_counts,
-                                                   unsigned long long cap, CountOut *__restrict__ co, int dbg) {
+                                                   unsigned long long cap, CountOut *__restrict__ co, int dbg,
+                                                   int pair_out) {
+    constexpr bool RECS = ELEM == 1;
     __shared__ __attribute__((aligned(16))) unsigned long long tkey[LCAP];
     __shared__ __attribute__((aligned(16))) uint32_t tcnt[LCAP];
     __shared__ unsigned long long obk[OBUF];
@@ -516,6 +533,10 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
     __shared__ int sp;
     __shared__ uint32_t overflow, ob_n, ob_lim;
     __shared__ unsigned long long g_emit;
+    // pair_out: survivors go straight to blocks of PBLOCK pairs this workgroup takes from the global
+    // cursor (one global atomic per 16384 pairs; a per-wave atomic on that one counter costs 30 ns a piece)
+    __shared__ unsigned long long blk_base, blk_next;
+    __shared__ uint32_t blk_pos, have_next, need_grab;
     __shared__ __attribute__((aligned(16))) uint64_t stage[RECS ? LSTAGE : 2];  // records: per-wave expansion area
     uint32_t my_distinct = 0;                                                // every thread
     unsigned long long my_passes = 0, my_overflows = 0;                      // thread 0 only
@@ -538,7 +559,10 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
     };
 
     for (int i = threadIdx.x; i < LCAP; i += LT) { tkey[i] = EMPTY; tcnt[i] = 0; }
-    if (threadIdx.x == 0) { ob_n = 0; ob_lim = 0xffffffffu; overflow = 0; sp = 0; }
+    if (threadIdx.x == 0) {
+        ob_n = 0; ob_lim = 0xffffffffu; overflow = 0; sp = 0;
+        blk_base = NOBLK; blk_next = NOBLK; blk_pos = PBLOCK; have_next = 0; need_grab = 1;
+    }
 
     // flush the survivor buffer (every thread calls)
     auto flush = [&]() {
@@ -549,7 +573,10 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < cntv; i += LT) {
             const unsigned long long pos = g_emit + i;
-            if (pos < cap) { out_keys[pos] = obk[i]; out_counts[pos] = obc[i]; }
+            if (pos < cap) {
+                if (pair_out) ((Rec *)out_keys)[pos] = Rec{obk[i], (uint64_t)(uint32_t)obc[i]};
+                else { out_keys[pos] = obk[i]; out_counts[pos] = obc[i]; }
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) { ob_n = 0; ob_lim = 0xffffffffu; }
@@ -558,8 +585,8 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
 
     // prefetched elements.  k-mers: kn[j] = keys[pf + j*LT + tid] (empty beyond the chunk's stream);
     // records: kn[i] = record 64*i + lane of this wave's share of the leaf about to be processed
-    using Elem = typename LeafElem<RECS>::T;
-    constexpr int NB = LeafElem<RECS>::PER_LANE;      // elements in flight per lane
+    using Elem = typename LeafElem<ELEM>::T;
+    constexpr int NB = LeafElem<ELEM>::PER_LANE;      // elements in flight per lane
     constexpr int RPF = NB;
     Elem kn[NB];
     uint64_t begin, end;
@@ -570,7 +597,7 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
 #pragma unroll
         for (int j = 0; j < NB; j++) {
             const uint64_t i = pos + (uint64_t)j * LT + threadIdx.x;
-            kn[j] = i < stream_end ? keys[i] : LeafElem<RECS>::none();
+            kn[j] = i < stream_end ? keys[i] : LeafElem<ELEM>::none();
         }
     };
     if constexpr (RECS) {
@@ -592,7 +619,7 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
         // is done when its slot held EMPTY (claimed) or the key itself; either way its count goes up.
         // There is no occupancy counter: a probe sequence longer than LPROBE flags the pass as
         // overflowing (the table is too full to be worth probing) and the leaf is split.
-        auto insert2 = [&](uint64_t keyA, bool a, uint64_t keyB, bool b) __attribute__((always_inline)) {
+        auto insert2 = [&](uint64_t keyA, bool a, uint64_t keyB, bool b, uint32_t wA, uint32_t wB) __attribute__((always_inline)) {
             const uint32_t gA = ((uint32_t)keyA ^ __builtin_rotateleft32((uint32_t)(keyA >> 32), 13)) * 0x9E3779B1u;
             const uint32_t gB = ((uint32_t)keyB ^ __builtin_rotateleft32((uint32_t)(keyB >> 32), 13)) * 0x9E3779B1u;
             uint32_t slotA = gA >> (32 - LCAP_BITS), slotB = gB >> (32 - LCAP_BITS);
@@ -605,19 +632,19 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
             if (a) pA = atomicCAS(&tkey[slotA], EMPTY, (unsigned long long)keyA);
             if (b) pB = atomicCAS(&tkey[slotB], EMPTY, (unsigned long long)keyB);
             const bool dA = pA == EMPTY || pA == keyA, dB = pB == EMPTY || pB == keyB;
-            if (a && dA) atomicAdd(&tcnt[slotA], 1u);
-            if (b && dB) atomicAdd(&tcnt[slotB], 1u);
+            if (a && dA) atomicAdd(&tcnt[slotA], wA);
+            if (b && dB) atomicAdd(&tcnt[slotB], wB);
             // the rest walk their probe sequences one key at a time
-            auto walk = [&](uint64_t key, uint32_t slot) __attribute__((always_inline)) {
+            auto walk = [&](uint64_t key, uint32_t slot, uint32_t w) __attribute__((always_inline)) {
                 for (int probe = 1;; probe++) {
                     slot = (slot + 1) & (LCAP - 1);
                     const unsigned long long p = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
-                    if (p == EMPTY || p == key) { atomicAdd(&tcnt[slot], 1u); break; }
+                    if (p == EMPTY || p == key) { atomicAdd(&tcnt[slot], w); break; }
                     if (probe >= LPROBE) { overflow = 1; break; }
                 }
             };
-            if (!dA) walk(keyA, slotA);
-            if (!dB) walk(keyB, slotB);
+            if (!dA) walk(keyA, slotA, wA);
+            if (!dB) walk(keyB, slotB, wB);
         };
         if constexpr (RECS) {
             // Records: every wave takes an equal contiguous share of the leaf and walks it 64 records
@@ -690,7 +717,7 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
                         if ((v0 && c0 == 0x123456789ULL) || (v1 && c1 == 0x123456789ULL)) overflow = 1;
                         continue;
                     }
-                    insert2(c0, v0, c1, v1);
+                    insert2(c0, v0, c1, v1, 1u, 1u);
                 }
                 __builtin_amdgcn_wave_barrier();
             };
@@ -717,21 +744,22 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
 #pragma unroll
                     for (int j = 0; j < NB; j++) {
                         const uint64_t i = base + (uint64_t)j * LT + threadIdx.x;
-                        kc[j] = i < end ? keys[i] : LeafElem<RECS>::none();
+                        kc[j] = i < end ? keys[i] : LeafElem<ELEM>::none();
                     }
                 }
                 // next batch of this leaf, or the first batch of the next leaf
                 const uint64_t nxt = base + (uint64_t)LT * NB < end ? base + (uint64_t)LT * NB : begin_next;
                 if (nxt < stream_end && nxt != pf) prefetch(nxt);
                 if (dbg & 1) {       // ablation: stream only
-                    if (kc[0] == 0x123456789ULL) overflow = 1;
+                    if (LeafElem<ELEM>::key(kc[0]) == 0x123456789ULL) overflow = 1;
                     continue;
                 }
                 static_assert(RECS || NB % 2 == 0, "pairs");
 #pragma unroll
                 for (int j = 0; j + 1 < NB; j += 2)
-                    insert2(kc[j], base + (uint64_t)j * LT + threadIdx.x < end, kc[j + 1],
-                            base + (uint64_t)(j + 1) * LT + threadIdx.x < end);
+                    insert2(LeafElem<ELEM>::key(kc[j]), base + (uint64_t)j * LT + threadIdx.x < end,
+                            LeafElem<ELEM>::key(kc[j + 1]), base + (uint64_t)(j + 1) * LT + threadIdx.x < end,
+                            LeafElem<ELEM>::weight(kc[j]), LeafElem<ELEM>::weight(kc[j + 1]));
             }
         }
     };
@@ -760,6 +788,15 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
                     const int leader = __ffsll((unsigned long long)km) - 1;
                     const uint32_t r = (uint32_t)__popcll(km & ((1ULL << lane_) - 1));
                     uint32_t base = 0;
+                    if (pair_out) {
+                        // room for a whole table is guaranteed (see the leaf loop): positions past the end
+                        // of the current block continue in the next one
+                        if (lane_ == leader) base = atomicAdd(&blk_pos, cntw);
+                        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader) + r;
+                        const unsigned long long pos = base < (uint32_t)PBLOCK ? blk_base + base : blk_next + (base - PBLOCK);
+                        if (keep && pos < cap) ((Rec *)out_keys)[pos] = Rec{tkey[slot], (uint64_t)(uint32_t)c};
+                        continue;
+                    }
                     if (lane_ == leader) base = atomicAdd(&ob_n, cntw);
                     base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
                     if (base + cntw <= (uint32_t)OBUF) {
@@ -774,7 +811,10 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
                         glo = (uint32_t)__builtin_amdgcn_readlane((int)glo, leader);
                         ghi = (uint32_t)__builtin_amdgcn_readlane((int)ghi, leader);
                         const unsigned long long pos = (((unsigned long long)ghi << 32) | glo) + r;
-                        if (keep && pos < cap) { out_keys[pos] = tkey[slot]; out_counts[pos] = c; }
+                        if (keep && pos < cap) {
+                            if (pair_out) ((Rec *)out_keys)[pos] = Rec{tkey[slot], (uint64_t)(uint32_t)c};
+                            else { out_keys[pos] = tkey[slot]; out_counts[pos] = c; }
+                        }
                     }
                 }
             }
@@ -804,7 +844,21 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
             const bool ov = overflow != 0;
             if (threadIdx.x == 0) my_passes++;
             if (!ov) {
+                // (need_grab, not blk_pos: waves already in emit_pass move blk_pos while slower ones still
+                // decide here -- the decision must be the same in every wave or the barriers go out of step)
+                if (pair_out && need_grab) {
+                    __syncthreads();
+                    if (threadIdx.x == 0) {
+                        blk_next = atomicAdd(&co->n_out, (unsigned long long)PBLOCK);
+                        have_next = 1; need_grab = 0;
+                    }
+                    __syncthreads();
+                }
                 emit_pass();
+                if (pair_out && threadIdx.x == 0) {         // (all emission done; next read: after a later barrier)
+                    if (blk_pos >= (uint32_t)PBLOCK) { blk_base = blk_next; blk_pos -= PBLOCK; have_next = 0; }
+                    need_grab = blk_pos + (uint32_t)LCAP > (uint32_t)PBLOCK && !have_next;
+                }
                 if (S == 1) break;
             } else {
                 // wipe the abandoned table, push the two halves of (S, s)
@@ -831,6 +885,15 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<RECS>
         end = end_next;
     }
     flush();
+    if (pair_out) {
+        // the unused tail of this workgroup's last block(s) reads as holes (count 0)
+        if (blk_base != NOBLK)
+            for (uint32_t i = blk_pos + threadIdx.x; i < (uint32_t)PBLOCK; i += LT)
+                if (blk_base + i < cap) ((Rec *)out_keys)[blk_base + i] = Rec{0, 0};
+        if (have_next)
+            for (uint32_t i = threadIdx.x; i < (uint32_t)PBLOCK; i += LT)
+                if (blk_next + i < cap) ((Rec *)out_keys)[blk_next + i] = Rec{0, 0};
+    }
     {
         // distinct keys: wave sums, one global add per wave
         uint32_t d = my_distinct;
@@ -1022,7 +1085,8 @@ __global__ void k_heavy_fill(const uint64_t *__restrict__ off, int64_t nleaf, co
 // partial (key, count) pairs of the slices, sorted by key: sum every run, filter, append
 __global__ void k_reduce_partials(const uint64_t *__restrict__ pk, const uint32_t *__restrict__ pc, int64_t np,
                                   int min_cov, int max_cov, int apply_filter, uint64_t *__restrict__ out_keys,
-                                  int32_t *__restrict__ out_counts, unsigned long long cap, CountOut *__restrict__ co) {
+                                  int32_t *__restrict__ out_counts, unsigned long long cap, CountOut *__restrict__ co,
+                                  int pair_out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= np) return;
     const uint64_t key = pk[i];
@@ -1033,7 +1097,10 @@ __global__ void k_reduce_partials(const uint64_t *__restrict__ pk, const uint32_
     const int32_t c = (int32_t)sum;
     if (apply_filter && !(c >= min_cov && c <= max_cov)) return;
     const unsigned long long o = atomicAdd(&co->n_out, 1ULL);
-    if (o < cap) { out_keys[o] = key; out_counts[o] = c; }
+    if (o < cap) {
+        if (pair_out) ((Rec *)out_keys)[o] = Rec{key, (uint64_t)(uint32_t)c};
+        else { out_keys[o] = key; out_counts[o] = c; }
+    }
 }
 
 // ------------------------------------------------------- super-k-mer records
@@ -1350,46 +1417,61 @@ __device__ __forceinline__ uint64_t wide_hash(uint64_t hi, uint64_t lo) {
 }
 // (the top OWNER_BITS of the hash pick the owning GPU -- mulhi(hash, n_owners) -- and are skipped by the
 // local digits, as on the k <= 31 path)
-template <bool WIDE>
-__device__ __forceinline__ unsigned level_digit(const Rec &r, int used, int bits) {
-    if constexpr (WIDE) return bits ? (unsigned)(((wide_hash(r.w0, r.w1) << OWNER_BITS) << used) >> (64 - bits)) : 0u;
-    else return rec_digit(rec_hdr(r), used, bits);
+// MODE 0: super-k-mer records (digit from the header), 1: two-word k-mers (hash of both words),
+// 2: (k-mer, partial count) pairs (kmer_hash of the key; with lv.n_owners > 0 the digit is the owner)
+template <int MODE>
+__device__ __forceinline__ unsigned level_digit(const Rec &r, int used, const Level &lv) {
+    const int bits = lv.bits;
+    if constexpr (MODE == 1) return bits ? (unsigned)(((wide_hash(r.w0, r.w1) << OWNER_BITS) << used) >> (64 - bits)) : 0u;
+    else if constexpr (MODE == 2) {
+        if (lv.n_owners > 0) return (unsigned)__umul64hi(kmer_hash(r.w0), (uint64_t)lv.n_owners);
+        return bits ? (unsigned)((local_hash(r.w0) << used) >> (64 - bits)) : 0u;
+    } else return rec_digit(rec_hdr(r), used, bits);
+}
+template <int MODE>
+__device__ __forceinline__ int level_bins(const Level &lv) {
+    if constexpr (MODE == 2) return lv.n_owners > 0 ? lv.n_owners : 1 << lv.bits;
+    else return 1 << lv.bits;
 }
 __device__ __forceinline__ unsigned wide_level1_digit(const Rec &r, const Level &lv) {
     if (lv.n_owners > 0) return (unsigned)__umul64hi(wide_hash(r.w0, r.w1), (uint64_t)lv.n_owners);
-    return level_digit<true>(r, 0, lv.bits);
+    return level_digit<1>(r, 0, lv);
 }
 
 // levels >= 2 on records: virtual workgroups as for k-mers, digit from the record header
-template <bool WIDE>
+template <int MODE>
 __global__ __launch_bounds__(PT) void k_rec_hist(const Rec *__restrict__ recs, VbMap m, Level lv, int used,
                                                  uint32_t *__restrict__ table) {
     __shared__ uint32_t h[1 << MAX_BITS];
     VbPos q;
     if (!locate_vb(m, blockIdx.x, &q)) return;
-    const int nb = 1 << lv.bits;
+    const int nb = level_bins<MODE>(lv);
     for (int i = threadIdx.x; i < nb; i += PT) h[i] = 0;
     __syncthreads();
-    for (uint64_t i = q.begin + threadIdx.x; i < q.end; i += PT)
-        atomicAdd(&h[level_digit<WIDE>(recs[i], used, lv.bits)], 1u);
+    for (uint64_t i = q.begin + threadIdx.x; i < q.end; i += PT) {
+        const Rec r = recs[i];
+        if (MODE == 2 && r.w1 == 0) continue;                 // a hole of the combine output (count 0)
+        atomicAdd(&h[level_digit<MODE>(r, used, lv)], 1u);
+    }
     __syncthreads();
     const int64_t tb = (int64_t)nb * (int64_t)m.vb_start[q.p];
     for (int i = threadIdx.x; i < nb; i += PT) table[tb + (int64_t)i * q.G + q.g] = h[i];
 }
 
-template <bool WIDE>
+template <int MODE>
 __global__ __launch_bounds__(PT) void k_rec_scatter(const Rec *__restrict__ recs, VbMap m, Level lv, int used,
                                                     const uint64_t *__restrict__ scanned, Rec *__restrict__ out) {
     __shared__ unsigned long long cur[1 << MAX_BITS];
     VbPos q;
     if (!locate_vb(m, blockIdx.x, &q)) return;
-    const int nb = 1 << lv.bits;
+    const int nb = level_bins<MODE>(lv);
     const int64_t tb = (int64_t)nb * (int64_t)m.vb_start[q.p];
     for (int i = threadIdx.x; i < nb; i += PT) cur[i] = scanned[tb + (int64_t)i * q.G + q.g];
     __syncthreads();
     for (uint64_t i = q.begin + threadIdx.x; i < q.end; i += PT) {
         const Rec r = recs[i];
-        out[atomicAdd(&cur[level_digit<WIDE>(r, used, lv.bits)], 1ULL)] = r;
+        if (MODE == 2 && r.w1 == 0) continue;
+        out[atomicAdd(&cur[level_digit<MODE>(r, used, lv)], 1ULL)] = r;
     }
 }
 
@@ -1402,14 +1484,14 @@ __global__ __launch_bounds__(PT) void k_rec_scatter(const Rec *__restrict__ recs
 constexpr int WCT = 1024;             // threads per workgroup (one workgroup per CU: the rings fill the LDS)
 constexpr int WC_PER = 4;             // records per thread per round
 
-template <int B, bool WIDE>
+template <int B, int MODE>
 __global__ __launch_bounds__(WCT) void k_rec_scatter_wc(const Rec *__restrict__ recs, VbMap m, Level lv, int used,
                                                         const uint64_t *__restrict__ scanned, Rec *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wc_smem[];
     constexpr int A = B / 2;          // records per aligned output line (128 B for B = 16)
     VbPos q;
     if (!locate_vb(m, blockIdx.x, &q)) return;
-    const int nb = 1 << lv.bits;
+    const int nb = level_bins<MODE>(lv);
     Rec *buf = (Rec *)wc_smem;
     unsigned long long *tail = (unsigned long long *)(buf + (size_t)nb * B);
     unsigned long long *head = tail + nb;
@@ -1443,8 +1525,8 @@ __global__ __launch_bounds__(WCT) void k_rec_scatter_wc(const Rec *__restrict__ 
 #pragma unroll
         for (int i = 0; i < WC_PER; i++) {
             const uint64_t idx = base + (uint64_t)i * WCT + threadIdx.x;
-            if (idx < q.end) {
-                const unsigned d = level_digit<WIDE>(r[i], used, lv.bits);
+            if (idx < q.end && !(MODE == 2 && r[i].w1 == 0)) {
+                const unsigned d = level_digit<MODE>(r[i], used, lv);
                 const unsigned long long g = atomicAdd(&tail[d], 1ULL);
                 if (g - head[d] < (unsigned long long)B) buf[(size_t)d * B + (g & (B - 1))] = r[i];
                 else out[g] = r[i];
@@ -1728,15 +1810,18 @@ static unsigned reads_grid(rfx_ctx *ctx, const ReadSrc &s, int per_cu) {
 }
 
 // leaf count + filter + ascending sort of the survivors (shared tail of every source kind)
-template <bool RECS>
-static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<RECS>::T *elems, int64_t elem_count,
+// pair_out: the survivors leave as 16-byte {k-mer, count} pairs in d_out_keys, in no particular order
+// (the local combine of the multi-GPU count: every distinct k-mer, no filter, no sort)
+template <int ELEM>
+static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, int64_t elem_count,
                          const uint64_t *d_leaf_off, int64_t nleaf, int k, int min_cov, int max_cov, int twin, int key_bits,
                          uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n,
-                         int64_t *out_distinct) {
+                         int64_t *out_distinct, bool pair_out = false) {
+    constexpr bool RECS = ELEM == 1;
     DevBuf co_buf;
     RFX_HIP(co_buf.alloc(sizeof(CountOut), ctx->stream));
     RFX_HIP(hipMemsetAsync(co_buf.p, 0, sizeof(CountOut), ctx->stream));
-    const int apply = !(twin == RFX_TWIN_RDD && min_cov <= 1);    // P/ReflexivMain.java:160
+    const int apply = !pair_out && !(twin == RFX_TWIN_RDD && min_cov <= 1);    // P/ReflexivMain.java:160
     // heavy leaves (low-complexity sequence: millions of instances of a few k-mers in one bucket) are
     // left out of the first launch, cut into slices and counted by the whole grid in a second one
     uint64_t heavy = RECS ? 16384 : 131072, slice = RECS ? 2048 : 16384, pcap_min = 1 << 20;
@@ -1757,9 +1842,10 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<RECS>::T *elems, 
     {
         ScopedTimer t(ctx, "leaf");
         int64_t grid = std::min<int64_t>(nleaf, (int64_t)ctx->num_cu * 2);      // persistent, <= 78 KB LDS each
-        hipLaunchKernelGGL(k_leaf_count<RECS>, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, elems, d_leaf_off, nleaf,
+        hipLaunchKernelGGL(k_leaf_count<ELEM>, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, elems, d_leaf_off, nleaf,
                            (const uint64_t *)nullptr, (const uint64_t *)nullptr, heavy, (uint64_t)elem_count, k, min_cov,
-                           max_cov, apply, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>(), dbg);
+                           max_cov, apply, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>(), dbg,
+                           (int)pair_out);
         RFX_HIP(hipGetLastError());
     }
     RFX_HIP(hipStreamSynchronize(ctx->stream));
@@ -1781,10 +1867,10 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<RECS>::T *elems, 
             {
                 ScopedTimer t(ctx, "leaf");
                 int64_t grid = std::min<int64_t>((int64_t)n_slices, (int64_t)ctx->num_cu * 2);
-                hipLaunchKernelGGL(k_leaf_count<RECS>, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, elems, d_leaf_off,
+                hipLaunchKernelGGL(k_leaf_count<ELEM>, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, elems, d_leaf_off,
                                    (int64_t)n_slices, (const uint64_t *)sb.as<uint64_t>(), (const uint64_t *)se.as<uint64_t>(),
                                    (uint64_t)0, (uint64_t)elem_count, k, min_cov, max_cov, 0, pk.as<uint64_t>(),
-                                   pc.as<int32_t>(), (unsigned long long)pcap, co2.as<CountOut>(), dbg);
+                                   pc.as<int32_t>(), (unsigned long long)pcap, co2.as<CountOut>(), dbg, 0);
                 RFX_HIP(hipGetLastError());
             }
             RFX_HIP(hipMemcpyAsync(&c2, co2.p, sizeof c2, hipMemcpyDeviceToHost, ctx->stream));
@@ -1801,7 +1887,8 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<RECS>::T *elems, 
                            tv.as<uint32_t>()));
         hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)ceil_div((int64_t)c2.n_out, 256)), dim3(256), 0, ctx->stream,
                            (const uint64_t *)pk.as<uint64_t>(), (const uint32_t *)pc.as<uint32_t>(), (int64_t)c2.n_out,
-                           min_cov, max_cov, apply, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>());
+                           min_cov, max_cov, apply, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>(),
+                           (int)pair_out);
         RFX_HIP(hipGetLastError());
         t.stop();
         if (getenv("RFX_TRACE"))
@@ -1818,7 +1905,7 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<RECS>::T *elems, 
     if ((int64_t)co.n_out > cap) { ScopedTimer::collect(ctx); return RFX_E_CAP; }
     if ((int64_t)co.n_out > (int64_t)0xFFFFFFFFLL) { ScopedTimer::collect(ctx); return RFX_E_LIMIT; }
     // ascending k-mer order (order contract B.0)
-    {
+    if (!pair_out) {
         DevBuf tk, tv;
         RFX_HIP(tk.alloc((size_t)co.n_out * 8, ctx->stream));
         RFX_HIP(tv.alloc((size_t)co.n_out * 4, ctx->stream));
@@ -1921,7 +2008,7 @@ static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv
 // levels [first_level, ...) of the record path on records already bucketed by `used` bits
 // (seg offsets in *seg_cur), then the leaves.
 // the partition levels of a record array: -> the fully partitioned array and its leaf offsets
-template <bool WIDE>
+template <int MODE>
 static int partition_record_levels(rfx_ctx *ctx, const Rec *recs, int64_t n_recs, int ws_slot_of_recs,
                                    const std::vector<int> &bits, size_t first_level, int used, DevBuf **seg_cur_io,
                                    DevBuf **seg_next_io, int64_t *nseg_io, const Rec **cur_out) {
@@ -1953,7 +2040,7 @@ static int partition_record_levels(rfx_ctx *ctx, const Rec *recs, int64_t n_recs
         const char *pn = l == 0 ? "part1" : l == 1 ? "part2" : "part3";
         {
             ScopedTimer t(ctx, hn);
-            hipLaunchKernelGGL(k_rec_hist<WIDE>, dim3((unsigned)v_bound), dim3(PT), 0, ctx->stream, cur, vm, lv, used,
+            hipLaunchKernelGGL(k_rec_hist<MODE>, dim3((unsigned)v_bound), dim3(PT), 0, ctx->stream, cur, vm, lv, used,
                                table.as<uint32_t>());
             RFX_HIP(hipGetLastError());
         }
@@ -1969,16 +2056,16 @@ static int partition_record_levels(rfx_ctx *ctx, const Rec *recs, int64_t n_recs
             const bool wc = !(getenv("RFX_WC") && atoi(getenv("RFX_WC")) == 0) && lv.bits >= 4;
             if (wc && lv.bits <= 9) {
                 const size_t lds = (size_t)nb * (16 * sizeof(Rec) + 16);
-                RFX_HIP(hipFuncSetAttribute((const void *)k_rec_scatter_wc<16, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL((k_rec_scatter_wc<16, WIDE>), dim3((unsigned)v_bound), dim3(WCT), lds, ctx->stream, cur, vm, lv,
+                RFX_HIP(hipFuncSetAttribute((const void *)k_rec_scatter_wc<16, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_rec_scatter_wc<16, MODE>), dim3((unsigned)v_bound), dim3(WCT), lds, ctx->stream, cur, vm, lv,
                                    used, (const uint64_t *)scanned.as<uint64_t>(), dst);
             } else if (wc) {
                 const size_t lds = (size_t)nb * (8 * sizeof(Rec) + 16);
-                RFX_HIP(hipFuncSetAttribute((const void *)k_rec_scatter_wc<8, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL((k_rec_scatter_wc<8, WIDE>), dim3((unsigned)v_bound), dim3(WCT), lds, ctx->stream, cur, vm, lv,
+                RFX_HIP(hipFuncSetAttribute((const void *)k_rec_scatter_wc<8, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_rec_scatter_wc<8, MODE>), dim3((unsigned)v_bound), dim3(WCT), lds, ctx->stream, cur, vm, lv,
                                    used, (const uint64_t *)scanned.as<uint64_t>(), dst);
             } else {
-                hipLaunchKernelGGL(k_rec_scatter<WIDE>, dim3((unsigned)v_bound), dim3(PT), 0, ctx->stream, cur, vm, lv, used,
+                hipLaunchKernelGGL(k_rec_scatter<MODE>, dim3((unsigned)v_bound), dim3(PT), 0, ctx->stream, cur, vm, lv, used,
                                    (const uint64_t *)scanned.as<uint64_t>(), dst);
             }
             RFX_HIP(hipGetLastError());
@@ -1996,18 +2083,18 @@ static int count_records_levels(rfx_ctx *ctx, const Rec *recs, int64_t n_recs, i
                                 const std::vector<int> &bits, size_t first_level, int used, DevBuf *seg_cur,
                                 DevBuf *seg_next, int64_t nseg, int k, int min_cov, int max_cov, int twin,
                                 uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n,
-                                int64_t *out_distinct) {
+                                int64_t *out_distinct, bool pair_out = false) {
     const Rec *cur = nullptr;
-    RFX_TRY(partition_record_levels<false>(ctx, recs, n_recs, ws_slot_of_recs, bits, first_level, used, &seg_cur, &seg_next,
+    RFX_TRY(partition_record_levels<0>(ctx, recs, n_recs, ws_slot_of_recs, bits, first_level, used, &seg_cur, &seg_next,
                                            &nseg, &cur));
-    return finish_leaves<true>(ctx, cur, n_recs, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, k, min_cov, max_cov, twin,
-                               2 * k, d_out_keys, d_out_counts, cap, out_n, out_distinct);
+    return finish_leaves<1>(ctx, cur, n_recs, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, k, min_cov, max_cov, twin,
+                            2 * k, d_out_keys, d_out_counts, cap, out_n, out_distinct, pair_out);
 }
 
 // reads -> records -> count (the default for k = 28..31)
 static int count_reads_superkmer(rfx_ctx *ctx, const ReadStore *reads, int min_cov, int max_cov, int twin,
                                  uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n,
-                                 int64_t *out_distinct) {
+                                 int64_t *out_distinct, bool pair_out) {
     ctx->timing.clear();
     ReadSrc rsrc = make_read_src(reads);
     const int64_t n = instances_of(reads, rsrc);
@@ -2024,17 +2111,17 @@ static int count_reads_superkmer(rfx_ctx *ctx, const ReadStore *reads, int min_c
     int64_t R = 0;
     RFX_TRY(records_from_reads(ctx, rsrc, lv, true, 0, nullptr, 0, segA.as<uint64_t>(), &recs, &R, "hist1", "part1"));
     return count_records_levels(ctx, recs, R, 0, bits, 1, lv.bits, &segA, &segB, (int64_t)1 << lv.bits, reads->k,
-                                min_cov, max_cov, twin, d_out_keys, d_out_counts, cap, out_n, out_distinct);
+                                min_cov, max_cov, twin, d_out_keys, d_out_counts, cap, out_n, out_distinct, pair_out);
 }
 
 int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, int64_t n,
                  int min_cov, int max_cov, int twin, void *ws, int64_t ws_bytes,
                  uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap,
-                 int64_t *out_n, int64_t *out_distinct) {
+                 int64_t *out_n, int64_t *out_distinct, bool pair_out) {
     (void)ws; (void)ws_bytes;
     if (reads && superkmer_enabled(reads->k))
         return count_reads_superkmer(ctx, reads, min_cov, max_cov, twin, d_out_keys, d_out_counts, cap, out_n,
-                                     out_distinct);
+                                     out_distinct, pair_out);
     ctx->timing.clear();
     ReadSrc rsrc{};
     int k_bits = 64;
@@ -2146,9 +2233,9 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
         nseg = nchild;
     }
 
-    return finish_leaves<false>(ctx, cur_arr, n, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, from_reads ? reads->k : 31,
-                                min_cov, max_cov, twin, from_reads ? k_bits : 64, d_out_keys, d_out_counts, cap, out_n,
-                                out_distinct);
+    return finish_leaves<0>(ctx, cur_arr, n, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, from_reads ? reads->k : 31,
+                            min_cov, max_cov, twin, from_reads ? k_bits : 64, d_out_keys, d_out_counts, cap, out_n,
+                            out_distinct, pair_out);
 }
 
 int bucket_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, uint64_t *d_out, int64_t cap,
@@ -2234,6 +2321,95 @@ int count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_
                                 max_cov, twin, d_out_keys, d_out_counts, cap, out_n, out_distinct);
 }
 
+// ---- multi-GPU, combine form (the map-side combine of reduceByKey, P/ReflexivMain.java:155): every rank
+// counts its own reads first (count_filter with pair_out: all distinct k-mers as 16-byte {k-mer, count}
+// pairs), the PAIRS are bucketed by owner = mulhi(kmer_hash(k-mer), n_owners) and cross the exchange,
+// and the owner sums what arrives.  At high coverage this ships ~1.4 B per instance instead of ~2.6.
+int bucket_pairs_by_owner(rfx_ctx *ctx, const void *d_pairs, int64_t n, int n_owners, void *d_out,
+                          int64_t *d_owner_off, int64_t *h_owner_off) {
+    if (n_owners < 1 || n_owners > 64 || n < 0) return RFX_E_ARG;
+    if (n == 0) {
+        RFX_HIP(hipMemsetAsync(d_owner_off, 0, (size_t)(n_owners + 1) * 8, ctx->stream));
+        if (h_owner_off) memset(h_owner_off, 0, (size_t)(n_owners + 1) * 8);
+        return RFX_OK;
+    }
+    Level lv{};
+    lv.n_owners = n_owners;
+    const int nb = n_owners;
+    DevBuf seg, nvb, vb_start, table, scanned;
+    uint64_t seg_init[2] = {0, (uint64_t)n};
+    RFX_HIP(seg.alloc(16, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(seg.p, seg_init, 16, hipMemcpyHostToDevice, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t total_tiles = ceil_div(n, PTILE);
+    const int tpb = (int)std::min<int64_t>(32, std::max<int64_t>(1, total_tiles / ((int64_t)ctx->num_cu * 8)));
+    const int64_t v_bound = ceil_div(n, (int64_t)tpb * PTILE) + 1;
+    RFX_HIP(nvb.alloc(8, ctx->stream));
+    RFX_HIP(vb_start.alloc(16, ctx->stream));
+    RFX_HIP(table.alloc((size_t)nb * v_bound * 4, ctx->stream));
+    RFX_HIP(scanned.alloc(((size_t)nb * v_bound + 1) * 8, ctx->stream));
+    RFX_HIP(hipMemsetAsync(table.p, 0, (size_t)nb * v_bound * 4, ctx->stream));
+    hipLaunchKernelGGL(k_vb_per_seg, dim3(1), dim3(256), 0, ctx->stream, (const uint64_t *)seg.as<uint64_t>(), (int64_t)1, tpb,
+                       nvb.as<uint64_t>());
+    RFX_HIP(hipGetLastError());
+    RFX_TRY(exclusive_scan_u64(ctx, nvb.as<uint64_t>(), vb_start.as<uint64_t>(), 1));
+    VbMap vm{seg.as<uint64_t>(), vb_start.as<uint64_t>(), 1, tpb};
+    const Rec *src = (const Rec *)d_pairs;
+    {
+        ScopedTimer t(ctx, "pair_hist");
+        hipLaunchKernelGGL(k_rec_hist<2>, dim3((unsigned)v_bound), dim3(PT), 0, ctx->stream, src, vm, lv, 0, table.as<uint32_t>());
+        RFX_HIP(hipGetLastError());
+    }
+    RFX_TRY(exclusive_scan_u32_to_u64(ctx, table.as<uint32_t>(), scanned.as<uint64_t>(), (int64_t)nb * v_bound));
+    hipLaunchKernelGGL(k_child_offsets, dim3((unsigned)ceil_div(nb + 1, 256)), dim3(256), 0, ctx->stream,
+                       (const uint64_t *)scanned.as<uint64_t>(), vm, nb, (uint64_t)n, reinterpret_cast<uint64_t *>(d_owner_off));
+    RFX_HIP(hipGetLastError());
+    // holes (count 0) are not counted: the end of the last bucket is the histogram's total, not n
+    RFX_HIP(hipMemcpyAsync(d_owner_off + n_owners, scanned.as<uint64_t>() + (size_t)nb * v_bound, 8, hipMemcpyDeviceToDevice,
+                           ctx->stream));
+    {
+        ScopedTimer t(ctx, "pair_part");
+        if (nb >= 16) {
+            const size_t lds = (size_t)nb * (16 * sizeof(Rec) + 16);
+            RFX_HIP(hipFuncSetAttribute((const void *)k_rec_scatter_wc<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_rec_scatter_wc<16, 2>), dim3((unsigned)v_bound), dim3(WCT), lds, ctx->stream, src, vm, lv, 0,
+                               (const uint64_t *)scanned.as<uint64_t>(), (Rec *)d_out);
+        } else {
+            hipLaunchKernelGGL(k_rec_scatter<2>, dim3((unsigned)v_bound), dim3(PT), 0, ctx->stream, src, vm, lv, 0,
+                               (const uint64_t *)scanned.as<uint64_t>(), (Rec *)d_out);
+        }
+        RFX_HIP(hipGetLastError());
+    }
+    if (h_owner_off) {
+        RFX_HIP(hipMemcpyAsync(h_owner_off, d_owner_off, (size_t)(n_owners + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        ScopedTimer::collect(ctx);
+    }
+    return RFX_OK;
+}
+
+// the owner's half: sum the partial counts of every k-mer that arrived, filter, ascending order
+int merge_pairs(rfx_ctx *ctx, const void *d_pairs, int64_t n, int k, int min_cov, int max_cov, int twin,
+                uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct) {
+    ctx->timing.clear();
+    if (out_n) *out_n = 0;
+    if (out_distinct) *out_distinct = 0;
+    if (n <= 0) return RFX_OK;
+    std::vector<int> bits;
+    plan_levels(n, false, bits, 2048.0);           // pairs are mostly distinct keys: ~half-full tables
+    DevBuf segA, segB;
+    uint64_t seg_init[2] = {0, (uint64_t)n};
+    RFX_HIP(segA.alloc(2 * 8, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(segA.p, seg_init, 16, hipMemcpyHostToDevice, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    DevBuf *seg_cur = &segA, *seg_next = &segB;
+    int64_t nseg = 1;
+    const Rec *cur = nullptr;
+    RFX_TRY(partition_record_levels<2>(ctx, (const Rec *)d_pairs, n, 1, bits, 0, 0, &seg_cur, &seg_next, &nseg, &cur));
+    return finish_leaves<2>(ctx, cur, n, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, k, min_cov, max_cov, twin, 2 * k,
+                            d_out_keys, d_out_counts, cap, out_n, out_distinct);
+}
+
 static int finish_wide2(rfx_ctx *ctx, const Rec *cur, const uint64_t *d_leaf_off, int64_t nseg, int min_cov, int max_cov,
                         uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct) {
     DevBuf co_buf;
@@ -2277,7 +2453,7 @@ int count_wide2(rfx_ctx *ctx, const void *d_elems, int64_t n, int min_cov, int m
     DevBuf *seg_cur = &segA, *seg_next = &segB;
     int64_t nseg = 1;
     const Rec *cur = nullptr;
-    RFX_TRY(partition_record_levels<true>(ctx, (const Rec *)d_elems, n, 1, bits, 0, 0, &seg_cur, &seg_next, &nseg, &cur));
+    RFX_TRY(partition_record_levels<1>(ctx, (const Rec *)d_elems, n, 1, bits, 0, 0, &seg_cur, &seg_next, &nseg, &cur));
     return finish_wide2(ctx, cur, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, min_cov, max_cov, d_out_keys, d_out_counts,
                         cap, out_n, out_distinct);
 }
@@ -2363,7 +2539,7 @@ int count_wide2_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, in
     DevBuf *seg_cur = &segA, *seg_next = &segB;
     int64_t nseg = nb;
     const Rec *cur = nullptr;
-    RFX_TRY(partition_record_levels<true>(ctx, dst, n, 0, bits, 1, lv.bits, &seg_cur, &seg_next, &nseg, &cur));
+    RFX_TRY(partition_record_levels<1>(ctx, dst, n, 0, bits, 1, lv.bits, &seg_cur, &seg_next, &nseg, &cur));
     return finish_wide2(ctx, cur, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, min_cov, max_cov, d_out_keys, d_out_counts,
                         cap, out_n, out_distinct);
 }

@@ -22,11 +22,68 @@ class HipEngine:
     For k = 21..31 the unit that crosses the exchange is the 16-byte super-k-mer record (two int64
     per record, ~2.6 B per k-mer instance); otherwise the 8-byte canonical k-mer."""
 
-    def __init__(self, rfx, records: bool = True):
+    def __init__(self, rfx, records: bool = True, combine: bool = False):
         self.rfx = rfx
         self.records = records
+        self.combine = combine    # k <= 31: count locally first, ship (k-mer, partial count) pairs
         self.k = None
         self.width = 1            # int64 words per exchanged unit
+        self.timing = {}          # kernel family -> [ms, launches] over every library call since the last reset
+
+    def _acc_timing(self):
+        for name, (ms, ln) in self.rfx.count_timing().items():
+            a = self.timing.setdefault(name, [0.0, 0])
+            a[0] += ms; a[1] += ln
+
+    # ---- combine form (reduceByKey's map-side combine, P/ReflexivMain.java:155): the unit that crosses the
+    # exchange is a 16-byte {k-mer, local count} pair, one per DISTINCT k-mer of the rank's reads -- at high
+    # coverage several times fewer bytes than one unit per instance (5 Gbp of a 4.6 Mbp genome: 1.4 B per
+    # instance against 2.6 for records), and the local count runs while the previous chunk's pairs travel.
+    def _combine_by_owner(self, reads, n_owners):
+        from ._lib import RfxError, RFX_E_CAP
+        dev = reads["words"].device
+        nk = self.rfx.kmers_per_read(reads["read_len"], reads["k"])
+        n = nk * reads["n_reads"]
+        self.n_instances, self.width = n, 2
+        if getattr(self, "_pairs_per_read", None) is None:
+            self._pairs_per_read = nk / 4.0 + 1.0
+        cap = int(self._pairs_per_read * reads["n_reads"]) + (1 << 20)
+        doff = torch.empty(n_owners + 1, dtype=torch.int64, device=dev)
+        while True:
+            scratch = torch.empty(2 * cap, dtype=torch.int64, device=dev)
+            out = torch.empty(2 * cap, dtype=torch.int64, device=dev)      # (same sizes every step: no allocator churn)
+            torch.cuda.current_stream().synchronize()
+            try:
+                m, h, _ = self.rfx.combine_reads_dev(reads["words"].data_ptr(), reads["n_reads"], reads["wpr"],
+                                                     reads["read_len"], reads["k"], n_owners, scratch.data_ptr(),
+                                                     out.data_ptr(), cap, doff.data_ptr())
+                self._acc_timing()
+                return out[:2 * m], torch.from_numpy(h.copy())
+            except RfxError as e:
+                if e.status != RFX_E_CAP:
+                    raise
+                del scratch, out
+                cap = int(1.05 * getattr(e, "need", 2 * cap)) + (1 << 20)
+                self._pairs_per_read = cap / max(1, reads["n_reads"])       # only ever grows
+
+    def _merge_pairs(self, pairs, min_cov, max_cov, twin):
+        from ._lib import RfxError, RFX_E_CAP
+        n = int(pairs.numel()) // 2
+        cap = max(1 << 20, n // 8)
+        while True:
+            keys = torch.empty(cap, dtype=torch.int64, device=pairs.device)
+            counts = torch.empty(cap, dtype=torch.int32, device=pairs.device)
+            torch.cuda.current_stream().synchronize()
+            try:
+                m, d = self.rfx.merge_pairs_dev(pairs.data_ptr(), n, self.k, keys.data_ptr(), counts.data_ptr(), cap,
+                                                min_cov, max_cov, twin)
+                self._acc_timing()
+                return keys[:m], counts[:m], d
+            except RfxError as e:
+                if e.status != RFX_E_CAP or cap >= n:
+                    raise
+                del keys, counts
+                cap = min(n, cap * 4)
 
     def _use_records(self, k):
         return self.records and 21 <= k <= 31
@@ -44,6 +101,8 @@ class HipEngine:
             h = self.rfx.bucket_wide_by_owner_dev(reads["words"].data_ptr(), reads["n_reads"], reads["wpr"],
                                                   reads["read_len"], reads["k"], n_owners, out.data_ptr(), n, doff.data_ptr())
             return out[:2 * n], torch.from_numpy(h.copy())
+        if self.combine:
+            return self._combine_by_owner(reads, n_owners)
         n = self.rfx.kmers_per_read(reads["read_len"], reads["k"]) * reads["n_reads"]
         self.n_instances = n
         if self._use_records(reads["k"]):
@@ -62,6 +121,7 @@ class HipEngine:
                 out = torch.empty(2 * max(1, nrec), dtype=torch.int64, device=reads["words"].device)
                 torch.cuda.current_stream().synchronize()
                 nrec, h = self.rfx.bucket_records_by_owner_dev(*args, out.data_ptr(), nrec, doff.data_ptr())
+            self._acc_timing()
             if nrec > cap:                             # only ever grows: buffer sizes stay the same from step to step
                 self._rec_per_read = 1.03 * nrec / max(1, reads["n_reads"])
             return out[:2 * nrec], torch.from_numpy(h.copy())
@@ -78,6 +138,9 @@ class HipEngine:
         """records (k-mers) this rank's reads produce, from the ratio seen in the previous call; 0 = unknown"""
         if reads["k"] > 31:
             return self.rfx.kmers_per_read_w(reads["read_len"], reads["k"]) * reads["n_reads"]
+        if self.combine:
+            nk = self.rfx.kmers_per_read(reads["read_len"], reads["k"])
+            return int((getattr(self, "_pairs_per_read", None) or nk / 4.0 + 1.0) * reads["n_reads"])
         if self._use_records(reads["k"]):
             return int(self._records_per_read(reads) * reads["n_reads"])
         return self.rfx.kmers_per_read(reads["read_len"], reads["k"]) * reads["n_reads"]
@@ -115,12 +178,15 @@ class HipEngine:
                 try:
                     m, d = self.rfx.count_wide_elems_dev(kmers.data_ptr(), n, self.k, keys.data_ptr(), counts.data_ptr(), cap,
                                                          min_cov, max_cov)
+                    self._acc_timing()
                     return keys[:2 * m], counts[:m], d
                 except RfxError as e:
                     if e.status != RFX_E_CAP or cap >= 2 * n:
                         raise
                     del keys, counts
                     cap = cap * 4
+        if self.combine:
+            return self._merge_pairs(kmers, min_cov, max_cov, twin)
         n = int(kmers.numel()) // self.width
         recs = self.width == 2
         n_inst = n * 6 if recs else n
@@ -136,6 +202,7 @@ class HipEngine:
                 else:
                     m, d = self.rfx.count_kmers_dev(kmers.data_ptr(), n, keys.data_ptr(), counts.data_ptr(), cap,
                                                     min_cov, max_cov, twin)
+                self._acc_timing()
                 return keys[:m], counts[:m], d
             except RfxError as e:
                 if e.status != RFX_E_CAP or cap >= 16 * n_inst:

@@ -94,11 +94,35 @@ class OracleEngine:
         return out
 
 
+class OracleCombineEngine(OracleEngine):
+    """CPU stand-in for HipEngine(combine=True) (tests only): local count first, 16-byte {k-mer, count}
+    pairs cross the exchange, the owner sums the partial counts."""
+    width = 2
+
+    def bucket_by_owner(self, reads, n_owners):
+        km = O.extract_canon(reads["bases"], reads["read_off"], reads["k"])
+        self.n_instances = len(km)
+        k, c, _ = O.count_filter(km, 1)
+        own = owner_of(k, n_owners)
+        order = np.argsort(own, kind="stable")
+        off = np.zeros(n_owners + 1, np.int64)
+        np.cumsum(np.bincount(own, minlength=n_owners), out=off[1:])
+        pairs = np.stack([k[order], c[order].astype(np.uint64)], axis=1).reshape(-1)
+        return torch.from_numpy(pairs.view(np.int64)), torch.from_numpy(off)
+
+    def count_kmers(self, pairs, min_cov, max_cov, twin):
+        p = pairs.numpy().view(np.uint64).reshape(-1, 2)
+        keys, inv = np.unique(p[:, 0], return_inverse=True)
+        sums = np.bincount(inv, weights=p[:, 1].astype(np.float64), minlength=len(keys)).astype(np.int64)
+        keep = np.ones(len(keys), bool) if (twin == O.TWIN_RDD and min_cov <= 1) else (sums >= min_cov) & (sums <= max_cov)
+        return torch.from_numpy(keys[keep].view(np.int64)), torch.from_numpy(sums[keep].astype(np.int32)), len(keys)
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q, chunks=1, limit_bytes=None):
+def _worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q, chunks=1, limit_bytes=None, combine=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -108,7 +132,8 @@ def _worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q, chunks=1, li
         g = O.synth_genome(seed, G)
         bases, off = O.synth_reads(seed, g, G, rank * per_rank, per_rank, L)    # this rank's read shard
         reads = dict(bases=bases, read_off=off, k=k)
-        keys, counts, tot = rd.sharded_count(OracleEngine(), reads, min_cov, 10_000_000, O.TWIN_DS, chunks=chunks)
+        engine = OracleCombineEngine() if combine else OracleEngine()
+        keys, counts, tot = rd.sharded_count(engine, reads, min_cov, 10_000_000, O.TWIN_DS, chunks=chunks)
         allk, allc = rd.gather_survivors(keys, counts)
         if rank == 0:
             q.put(("root", allk.numpy().view(np.uint64).copy(), allc.numpy().copy(), None))
@@ -120,14 +145,15 @@ def _worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q, chunks=1, li
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,chunks,limit_bytes", [(2, 1, None), (3, 1, None), (2, 4, None), (3, 3, None),
-                                                      (2, 1, 40_000), (3, 2, 24_000)])
-def test_sharded_count_equals_global_count(world, chunks, limit_bytes):
+@pytest.mark.parametrize("world,chunks,limit_bytes,combine", [(2, 1, None, False), (3, 1, None, False), (2, 4, None, False),
+                                                              (3, 3, None, False), (2, 1, 40_000, False), (3, 2, 24_000, False),
+                                                              (2, 1, None, True), (3, 3, None, True), (2, 2, 24_000, True)])
+def test_sharded_count_equals_global_count(world, chunks, limit_bytes, combine):
     seed, G, per_rank, L, k, min_cov = 42, 20_000, 1500, 100, 31, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, G, per_rank, L, k, min_cov, q, chunks, limit_bytes))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, G, per_rank, L, k, min_cov, q, chunks, limit_bytes, combine))
              for r in range(world)]
     for p in procs:
         p.start()

@@ -972,8 +972,8 @@ def test_sharded_count_through_rccl_one_rank(rfx, torch_mod):
         dk = torch.empty(N, dtype=torch.int64, device="cuda"); dc = torch.empty(N, dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, 3)
-        for chunks in (1, 4):
-            eng = rd.HipEngine(rfx)
+        for chunks, combine in ((1, False), (4, False), (1, True), (3, True)):
+            eng = rd.HipEngine(rfx, combine=combine)
             eng.force_exchange = True
             keys, counts, tot = rd.sharded_count(eng, reads, 3, 10_000_000, 0, chunks=chunks)
             assert tot == [N, nd, m]
@@ -1088,3 +1088,63 @@ def test_wide_owner_buckets_and_sharded_count(rfx, torch_mod):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,owners", [(31, 3), (31, 16), (25, 8), (17, 2)])
+def test_combine_bucket_merge_pairs(rfx, torch_mod, k, owners):
+    """The exchange after a local combine (reduceByKey's map-side combine): two halves of a read set are
+    combined separately into (k-mer, count) pairs, the pairs are bucketed by owner, and every owner's merge of
+    both halves' buckets equals the global count / filter restricted to that owner."""
+    torch = torch_mod
+    from tests.test_dist_gloo import owner_of
+    seed, G, n_reads, L, min_cov = 31, 40_000, 24_000, 150, 3
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+    km = O.extract_canon(bases, off, k)
+    halves, bucketed = [], []
+    for a, b in ((0, n_reads // 3), (n_reads // 3, n_reads)):
+        nk = rfx.kmers_per_read(L, k) * (b - a)
+        cap = nk + (9 << 20)
+        scratch = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+        out = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+        doff = torch.empty(owners + 1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        # a short buffer reports the need
+        with pytest.raises(Exception) as ei:
+            rfx.combine_reads_dev(dw[a * wpr:].data_ptr(), b - a, wpr, L, k, owners, scratch.data_ptr(), out.data_ptr(), 16,
+                                  doff.data_ptr())
+        assert 16 < ei.value.need <= cap
+        m, h, inst = rfx.combine_reads_dev(dw[a * wpr:].data_ptr(), b - a, wpr, L, k, owners, scratch.data_ptr(),
+                                           out.data_ptr(), cap, doff.data_ptr())
+        assert inst == nk
+        wk, wc, wd = O.count_filter(km[a * (L - k + 1): b * (L - k + 1)], 1)
+        assert m == wd and h[0] == 0 and h[-1] == m and np.array_equal(doff.cpu().numpy(), h)
+        bp = out[:2 * m].cpu().numpy().view(np.uint64).reshape(m, 2)
+        for o in range(owners):
+            assert np.all(owner_of(bp[h[o]:h[o + 1], 0], owners) == o)
+        order = np.argsort(bp[:, 0], kind="stable")
+        assert np.array_equal(bp[order, 0], wk) and np.array_equal(bp[order, 1], wc.astype(np.uint64))
+        # the grouping step alone, on pairs with holes (count 0) in between
+        holes = torch.zeros(4 * m + 2, dtype=torch.int64, device="cuda")
+        holes[2:2 + 4 * m].view(-1, 4)[:, :2] = out[:2 * m].view(-1, 2)
+        out2 = torch.empty(2 * m, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        h2 = rfx.bucket_pairs_by_owner_dev(holes.data_ptr(), 2 * m + 1, owners, out2.data_ptr(), doff.data_ptr())
+        assert np.array_equal(h2, h)
+        bp2 = out2.cpu().numpy().view(np.uint64).reshape(m, 2)
+        assert np.array_equal(bp2[np.argsort(bp2[:, 0], kind="stable")], bp[order])
+        bucketed.append((out, h))
+    gk, gc, gd = O.count_filter(km, min_cov)
+    own = owner_of(gk, owners)
+    own_all = owner_of(np.unique(km), owners)
+    for o in range(owners):
+        recv = torch.cat([out[2 * int(h[o]):2 * int(h[o + 1])] for out, h in bucketed])
+        n = int(recv.numel()) // 2
+        dk = torch.empty(max(1, n), dtype=torch.int64, device="cuda"); dc = torch.empty(max(1, n), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        m, d = rfx.merge_pairs_dev(recv.data_ptr(), n, k, dk.data_ptr(), dc.data_ptr(), max(1, n), min_cov)
+        assert d == int(np.sum(own_all == o))
+        assert np.array_equal(dk[:m].cpu().numpy().view(np.uint64), gk[own == o])
+        assert np.array_equal(dc[:m].cpu().numpy(), gc[own == o])

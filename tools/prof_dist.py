@@ -38,6 +38,17 @@ def timed(obj, name, acc):
     setattr(obj, name, g)
 
 
+_xa = rd.exchange_by_owner_async
+xacc = {}
+def _timed_exchange(*x, **kw):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    r = _xa(*x, **kw)
+    xacc["launch"] = xacc.get("launch", 0.0) + (time.perf_counter() - t) * 1e3
+    torch.cuda.synchronize()
+    xacc["exchange"] = xacc.get("exchange", 0.0) + (time.perf_counter() - t) * 1e3
+    return r
+rd.exchange_by_owner_async = _timed_exchange
+
 for combine in (False, True):
     eng = rd.HipEngine(rfx, combine=combine); eng.force_exchange = True
     acc = {}
@@ -45,12 +56,12 @@ for combine in (False, True):
     for name in ("combine_reads_dev", "bucket_pairs_by_owner_dev", "merge_pairs_dev", "bucket_records_by_owner_dev", "count_records_dev"):
         timed(rfx, name, acc)
     for step in range(a.steps):
-        acc.clear()
+        acc.clear(); xacc.clear()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         keys, counts, tot = rd.sharded_count(eng, reads, a.cover, 10_000_000, 0, chunks=a.chunks)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
         print(f"{'pairs  ' if combine else 'records'} step {step}: {dt:7.1f} ms  tot={tot}  " +
-              "  ".join(f"{k}={v:.1f}" for k, v in sorted(acc.items())), flush=True)
+              "  ".join(f"{k}={v:.1f}" for k, v in sorted(list(acc.items()) + list(xacc.items()))), flush=True)
     del eng, keys, counts
     torch.cuda.empty_cache()
 dist.destroy_process_group()

@@ -176,6 +176,7 @@ struct ReadSrc {
     int wpr, nk, fc, k, segs;      // words/read, k-mers/read (of the longest read), front clip, k, segments/read
     const uint32_t *len_arr;       // ragged reads: per-read length (nullptr: every read emits nk k-mers)
     int ec;                        // end clip (for the per-read count)
+    int wfl;                       // k = 33..63 records: bases of the k-mer on either side of the central window (else 0)
 };
 
 // k-mers read r emits
@@ -459,6 +460,13 @@ struct alignas(16) Rec { uint64_t w0, w1; };
 // Rec: w0 = bases 0..31 of the run's base string, w1 = [63..36] bases 32..45, [35..32] windows-1,
 // [31..0] the top 32 bits of the minimiser's local hash (radix digits peel off its top).
 __device__ __forceinline__ int rec_len(const Rec &r) { return (int)((r.w1 >> 32) & 15) + 1; }
+// WRec: the super-k-mer record of the k = 33..63 path.  b0..b2 = bases 0..95 of the run's base string (the
+// run's first k-mer starts at base 0; k + windows - 1 <= 78 bases are used), hd = [35..32] windows-1,
+// [31..0] the top 32 bits of the minimiser's local hash.  The minimiser is taken over the CENTRAL 31
+// (k odd) or 30 (k even) bases of the k-mer, which the reverse complement maps onto themselves, so it
+// is a function of the canonical k-mer as on the k <= 31 path -- and the front end is the k = 31 / 30 one.
+struct alignas(32) WRec { uint64_t b0, b1, b2, hd; };
+__device__ __forceinline__ int rec_len(const WRec &r) { return (int)((r.hd >> 32) & 15) + 1; }
 __device__ __forceinline__ uint32_t rec_hdr(const Rec &r) { return (uint32_t)r.w1; }
 
 // ELEM 0: a k-mer instance (8 B); 1: a super-k-mer record (16 B); 2: a (k-mer, partial count) pair
@@ -919,10 +927,34 @@ constexpr int WCAP = 1 << WCAP_BITS;
 constexpr int WLT = 1024;               // threads per workgroup (one workgroup per CU: the table is 80 KB)
 constexpr uint32_t WLOCK = 0xFFFFFFFFu;
 
-__global__ __launch_bounds__(WLT) void k_leaf_count_wide(const Rec *__restrict__ elems, const uint64_t *__restrict__ leaf_off,
-                                                        int64_t nleaf, int min_cov, int max_cov,
+// canonical two-word k-mer (counter layout: word0 = bases 0..31, word1 = the last t = k - 32 bases,
+// right-aligned) of window j of a record's base string -- compareLongArrayBlocks' order
+// (P/ReflexivDataFrameCounter64.java:652-687): smaller (word0, word1) wins, ties keep the forward strand
+__device__ __forceinline__ void wrec_kmer(const WRec &r, uint32_t j, int t, uint64_t *k0, uint64_t *k1) {
+    const uint32_t sh = 2u * j;                                  // <= 30
+    const uint64_t f0 = sh ? (r.b0 << sh) | (r.b1 >> (64 - sh)) : r.b0;
+    const uint64_t x1 = sh ? (r.b1 << sh) | (r.b2 >> (64 - sh)) : r.b1;
+    const int t2 = 2 * t;                                        // 2..62
+    const uint64_t f1 = x1 >> (64 - t2);
+    const uint64_t last32 = (f0 << t2) | f1;                     // the k-mer's last 32 bases
+    const uint64_t r0 = revcomp(last32, 32);
+    const uint64_t r1 = revcomp(f0, 32) & ((1ULL << t2) - 1);    // reverse complement of its first t bases
+    const bool fwd = f0 < r0 || (f0 == r0 && f1 <= r1);
+    *k0 = fwd ? f0 : r0;
+    *k1 = fwd ? f1 : r1;
+}
+
+constexpr int WWS = 64 * 4 + 32;        // u64 words of a wave's expansion area: 64 records + head bits + prefix counts
+
+// RECS: the leaf's elements are super-k-mer records (WRec) expanded here, k-mer by k-mer, balanced over the
+// lanes as in k_leaf_count<1>; else two-word k-mers (Rec = {word0, word1}).
+template <bool RECS>
+__global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_t<RECS, WRec, Rec> *__restrict__ elems,
+                                                        const uint64_t *__restrict__ leaf_off,
+                                                        int64_t nleaf, int k, int min_cov, int max_cov,
                                                         uint64_t *__restrict__ out_keys, int64_t *__restrict__ out_counts,
-                                                        unsigned long long cap, CountOut *__restrict__ co) {
+                                                        unsigned long long cap, CountOut *__restrict__ co, uint32_t presplit) {
+    __shared__ __attribute__((aligned(32))) uint64_t wstage[RECS ? WWS * (WLT / 64) : 4];
     __shared__ unsigned long long thi[WCAP], tlo[WCAP];
     __shared__ uint32_t tcnt[WCAP];
     __shared__ unsigned long long obh[OBUF], obl[OBUF];
@@ -959,27 +991,154 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const Rec *__restrict__
     for (int64_t leaf = l0; leaf < l1; leaf++) {
         const uint64_t begin = leaf_off[leaf], end = leaf_off[leaf + 1];
         uint32_t S = 1, s = 0;
+        if constexpr (RECS) {
+            // a leaf with many records will not fit one table: start it in 2, 4, ... hash-selected parts
+            // instead of finding that out from an abandoned pass (presplit = records one table takes)
+            if (presplit) {
+                while ((end - begin) > (uint64_t)presplit * S && S < 16) S *= 2;
+                if (S > 1) {
+                    __syncthreads();
+                    if (threadIdx.x == 0) for (uint32_t q = S - 1; q >= 1; q--) { stackS[sp] = S; stacks[sp] = q; sp++; }
+                    __syncthreads();
+                }
+            }
+        }
         while (begin != end) {
             // one pass: the keys selected by (S, s) go into the table
-            for (uint64_t i = begin + threadIdx.x; i < end; i += WLT) {
-                if (__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-                const Rec e = elems[i];
-                const uint32_t g = ((uint32_t)e.w0 ^ __builtin_rotateleft32((uint32_t)(e.w0 >> 32), 13) ^
-                                    ((uint32_t)e.w1 * 0x85EBCA6Bu) ^ (uint32_t)(e.w1 >> 32)) * 0x9E3779B1u;
-                if (S > 1 && (((g >> 4) & 0xffffu) & (S - 1)) != s) continue;
+            auto insert = [&](const uint64_t w0, const uint64_t w1) __attribute__((always_inline)) {
+                const uint32_t g = ((uint32_t)w0 ^ __builtin_rotateleft32((uint32_t)(w0 >> 32), 13) ^
+                                    ((uint32_t)w1 * 0x85EBCA6Bu) ^ (uint32_t)(w1 >> 32)) * 0x9E3779B1u;
+                if (S > 1 && (((g >> 4) & 0xffffu) & (S - 1)) != s) return;
                 uint32_t slot = g >> (32 - WCAP_BITS);
                 for (int probe = 0;;) {
                     const uint32_t c = atomicCAS(&tcnt[slot], 0u, WLOCK);
                     if (c == 0u) {                                  // claimed: write the key, publish count 1
-                        thi[slot] = e.w0; tlo[slot] = e.w1;
+                        thi[slot] = w0; tlo[slot] = w1;
                         __threadfence_block();
                         atomicExch(&tcnt[slot], 1u);
                         break;
                     }
                     if (c == WLOCK) continue;                       // being written: look again
-                    if (thi[slot] == e.w0 && tlo[slot] == e.w1) { atomicAdd(&tcnt[slot], 1u); break; }
+                    if (thi[slot] == w0 && tlo[slot] == w1) { atomicAdd(&tcnt[slot], 1u); break; }
                     slot = (slot + 1) & (WCAP - 1);
                     if (++probe >= LPROBE) { overflow = 1; break; }
+                }
+            };
+            // two keys: the first probes of both are issued before either is followed up
+            auto insert2 = [&](const uint64_t a0, const uint64_t a1, bool va, const uint64_t b0, const uint64_t b1, bool vb)
+                               __attribute__((always_inline)) {
+                auto slot_hash = [](uint64_t w0, uint64_t w1) __attribute__((always_inline)) {
+                    return ((uint32_t)w0 ^ __builtin_rotateleft32((uint32_t)(w0 >> 32), 13) ^
+                            ((uint32_t)w1 * 0x85EBCA6Bu) ^ (uint32_t)(w1 >> 32)) * 0x9E3779B1u;
+                };
+                const uint32_t ga = slot_hash(a0, a1), gb = slot_hash(b0, b1);
+                if (S > 1) {
+                    va = va && (((ga >> 4) & 0xffffu) & (S - 1)) == s;
+                    vb = vb && (((gb >> 4) & 0xffffu) & (S - 1)) == s;
+                }
+                uint32_t sa = ga >> (32 - WCAP_BITS), sb = gb >> (32 - WCAP_BITS);
+                uint32_t ca = 1u, cb = 1u;
+                if (va) ca = atomicCAS(&tcnt[sa], 0u, WLOCK);
+                if (vb) cb = atomicCAS(&tcnt[sb], 0u, WLOCK);
+                // follow one key up from the result of its first probe (c: what the CAS returned at `slot`)
+                // The loop runs until the whole wave is done (ballot): a lane that leaves a loop early waits at
+                // the exit for the others, and code on an exit path -- a `break` after the publish -- runs only
+                // then, so a lane spinning on a lock its neighbour holds would spin for ever.  Here the publish
+                // sits inside an iteration every lane completes.
+                auto follow = [&](const uint64_t w0, const uint64_t w1, uint32_t slot, uint32_t c, bool active) __attribute__((always_inline)) {
+                    int probe = 0;
+                    bool done = !active;
+                    while (__ballot(!done)) {
+                        if (!done) {
+                            if (c == 0u) {                              // claimed: write the key, publish count 1
+                                thi[slot] = w0; tlo[slot] = w1;
+                                __threadfence_block();
+                                atomicExch(&tcnt[slot], 1u);
+                                done = true;
+                            } else if (c != WLOCK) {
+                                if (thi[slot] == w0 && tlo[slot] == w1) { atomicAdd(&tcnt[slot], 1u); done = true; }
+                                else {
+                                    slot = (slot + 1) & (WCAP - 1);
+                                    if (++probe >= LPROBE) { overflow = 1; done = true; }
+                                }
+                            }
+                            if (!done) c = atomicCAS(&tcnt[slot], 0u, WLOCK);   // next slot, or the same one while it is being written
+                        }
+                    }
+                };
+                // A slot claimed by a first probe is published BEFORE anyone waits for anything: a lane that waited
+                // in follow(a) for a slot its neighbour claimed for key b would wait for ever (the neighbour cannot
+                // reach its own follow(b) before the wave's follow(a) has ended).
+                if (va && ca == 0u) { thi[sa] = a0; tlo[sa] = a1; }
+                if (vb && cb == 0u) { thi[sb] = b0; tlo[sb] = b1; }
+                __threadfence_block();
+                if (va && ca == 0u) atomicExch(&tcnt[sa], 1u);
+                if (vb && cb == 0u) atomicExch(&tcnt[sb], 1u);
+                // nine in ten first probes meet the key itself: compare both keys' slots in one go
+                const bool ha = va && ca != 0u && ca != WLOCK, hb = vb && cb != 0u && cb != WLOCK;
+                const uint64_t ta0 = ha ? thi[sa] : 0, ta1 = ha ? tlo[sa] : 0;
+                const uint64_t tb0 = hb ? thi[sb] : 0, tb1 = hb ? tlo[sb] : 0;
+                const bool ma = ha && ta0 == a0 && ta1 == a1, mb = hb && tb0 == b0 && tb1 == b1;
+                if (ma) atomicAdd(&tcnt[sa], 1u);
+                if (mb) atomicAdd(&tcnt[sb], 1u);
+                follow(a0, a1, sa, ca, va && ca != 0u && !ma);
+                follow(b0, b1, sb, cb, vb && cb != 0u && !mb);
+            };
+            if constexpr (RECS) {
+                // every wave takes an equal contiguous share of the leaf, 64 records at a time: the records go
+                // to the wave's LDS area, a bit per output position marks where each record's windows start,
+                // and lane j extracts the k-mer at position j (its record by a prefix popcount of those bits)
+                constexpr int NWV = WLT / 64;
+                const int wave_ = threadIdx.x >> 6;
+                const uint64_t n = end - begin;
+                const uint64_t ws = begin + n * wave_ / NWV, we = begin + n * (wave_ + 1) / NWV;
+                WRec *wrec = (WRec *)(wstage + (size_t)wave_ * WWS);
+                uint32_t *wbits = (uint32_t *)(wrec + 64);
+                uint32_t *wcum = wbits + 32;
+                const int t = k - 32;
+                WRec nxt = ws + lane_ < we ? elems[ws + lane_] : WRec{0, 0, 0, 0};
+                for (uint64_t r0 = ws; r0 < we; r0 += 64) {
+                    if (__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                    const bool valid = r0 + lane_ < we;
+                    WRec rc = nxt;
+                    nxt = r0 + 64 + lane_ < we ? elems[r0 + 64 + lane_] : WRec{0, 0, 0, 0};   // travels during the expansion
+                    const uint32_t nwin = valid ? (uint32_t)rec_len(rc) : 0u;
+                    const uint32_t x = wave_incl_scan(nwin);
+                    const uint32_t off = x - nwin;
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+                    if (lane_ < 32) wbits[lane_] = 0;
+                    __builtin_amdgcn_wave_barrier();
+                    if (nwin) atomicOr(&wbits[off >> 5], 1u << (off & 31));
+                    rc.hd = (rc.hd & ~0xffffffffULL) | off;          // the header is spent: carry `off`
+                    wrec[lane_] = rc;
+                    __builtin_amdgcn_wave_barrier();
+                    {
+                        const uint32_t c = (uint32_t)__popc(wbits[lane_ & 31]);
+                        const uint32_t y = wave_incl_scan(c);
+                        if (lane_ < 32) wcum[lane_] = y - c;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    auto kmer_at_pos = [&](uint32_t j, uint64_t *k0, uint64_t *k1) __attribute__((always_inline)) {
+                        const uint32_t wd = wbits[j >> 5];
+                        const uint32_t ri = wcum[j >> 5] + (uint32_t)__popc(wd & (0xffffffffu >> (31 - (j & 31)))) - 1u;
+                        const WRec rr = wrec[ri];
+                        wrec_kmer(rr, j - (uint32_t)rr.hd, t, k0, k1);
+                    };
+                    // (one k-mer per lane and round: pairing them, as the k <= 31 leaf does, measured 3 ms slower here)
+                    for (uint32_t wb = 0; wb < total; wb += 64) {
+                        const uint32_t ja = wb + lane_;
+                        const bool va = ja < total;
+                        uint64_t a0, a1;
+                        kmer_at_pos(va ? ja : 0, &a0, &a1);
+                        insert2(a0, a1, va, 0, 0, false);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else {
+                for (uint64_t i = begin + threadIdx.x; i < end; i += WLT) {
+                    if (__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                    const Rec e = elems[i];
+                    insert(e.w0, e.w1);
                 }
             }
             __syncthreads();
@@ -1298,15 +1457,18 @@ __global__ __launch_bounds__(SKT) void k_sk_hist(ReadSrc s, Level lv, uint64_t *
 // stream has SKB record slots in LDS indexed by the record's final position, and only whole
 // aligned 64-byte lines are stored; a digit that overruns its ring in one round stores directly.
 constexpr int SKB = 8, SKA = 4;
-template <int W, bool DESC>
-__global__ __launch_bounds__(SKT, 8) void k_sk_scatter(ReadSrc s, Level lv, const uint64_t *__restrict__ scanned,
-                                                   Rec *__restrict__ out, const uint32_t *__restrict__ desc) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
+// WIDE: the 32-byte records of the k = 33..63 path (s.k = the central window, s.wfl = the flank)
+template <int W, bool DESC, bool WIDE = false>
+__global__ __launch_bounds__(SKT, WIDE ? 4 : 8) void k_sk_scatter(ReadSrc s, Level lv, const uint64_t *__restrict__ scanned,
+                                                              std::conditional_t<WIDE, WRec, Rec> *__restrict__ out,
+                                                              const uint32_t *__restrict__ desc) {
+    using RT = std::conditional_t<WIDE, WRec, Rec>;
+    extern __shared__ __attribute__((aligned(32))) unsigned char sk_smem[];
     const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
     // (the rings are addressed through these expressions, not through pointer variables: a pointer
     // captured by the lambdas below decays to a generic one and the LDS atomics with it)
-#define buf ((Rec *)sk_smem)
-#define tail ((unsigned long long *)(sk_smem + (size_t)nb * SKB * sizeof(Rec)))
+#define buf ((RT *)sk_smem)
+#define tail ((unsigned long long *)(sk_smem + (size_t)nb * SKB * sizeof(RT)))
 #define head (tail + nb)
     for (int i = threadIdx.x; i < nb; i += SKT) tail[i] = head[i] = scanned[(int64_t)i * gridDim.x + blockIdx.x];
     __syncthreads();
@@ -1341,10 +1503,24 @@ __global__ __launch_bounds__(SKT, 8) void k_sk_scatter(ReadSrc s, Level lv, cons
             seg_load(s, q, w);
             // one record: windows [i0, i0 + n) of the segment, header word hdr, digit d
             auto put = [&](int i0, int n, uint32_t hdr, unsigned d) __attribute__((always_inline)) {
-                const int sft = 2 * i0;
-                Rec r;
-                r.w0 = sft ? (hi << sft) | (lo >> (64 - sft)) : hi;
-                r.w1 = ((lo << sft) & 0xFFFFFFF000000000ULL) | ((uint64_t)(n - 1) << 32) | (uint64_t)hdr;
+                RT r;
+                if constexpr (WIDE) {
+                    // 96 bases from the first base of the run's first k-mer: the central window starts
+                    // s.wfl bases further on (words past the read's end are never used: k + n - 1 bases are)
+                    const uint64_t *gw = s.words + q.r * s.wpr;
+                    const int p = s.fc - s.wfl + q.sgm * PK + i0;
+                    const int wi = p >> 5, sft = 2 * (p & 31), last = s.wpr - 1;
+                    const uint64_t a0 = gw[wi < last ? wi : last], a1 = gw[wi + 1 < last ? wi + 1 : last];
+                    const uint64_t a2 = gw[wi + 2 < last ? wi + 2 : last], a3 = gw[wi + 3 < last ? wi + 3 : last];
+                    r.b0 = sft ? (a0 << sft) | (a1 >> (64 - sft)) : a0;
+                    r.b1 = sft ? (a1 << sft) | (a2 >> (64 - sft)) : a1;
+                    r.b2 = sft ? (a2 << sft) | (a3 >> (64 - sft)) : a2;
+                    r.hd = ((uint64_t)(n - 1) << 32) | (uint64_t)hdr;
+                } else {
+                    const int sft = 2 * i0;
+                    r.w0 = sft ? (hi << sft) | (lo >> (64 - sft)) : hi;
+                    r.w1 = ((lo << sft) & 0xFFFFFFF000000000ULL) | ((uint64_t)(n - 1) << 32) | (uint64_t)hdr;
+                }
                 const unsigned long long pos = atomicAdd(&tail[d], 1ULL);
                 if (pos - head[d] < (unsigned long long)SKB) buf[(size_t)d * SKB + (pos & (SKB - 1))] = r;
                 else out[pos] = r;
@@ -1419,10 +1595,13 @@ __device__ __forceinline__ uint64_t wide_hash(uint64_t hi, uint64_t lo) {
 // local digits, as on the k <= 31 path)
 // MODE 0: super-k-mer records (digit from the header), 1: two-word k-mers (hash of both words),
 // 2: (k-mer, partial count) pairs (kmer_hash of the key; with lv.n_owners > 0 the digit is the owner)
-template <int MODE>
-__device__ __forceinline__ unsigned level_digit(const Rec &r, int used, const Level &lv) {
+template <int MODE> struct LevelElem { using T = Rec; };
+template <> struct LevelElem<3> { using T = WRec; };          // MODE 3: super-k-mer records of the k = 33..63 path
+template <int MODE, class E>
+__device__ __forceinline__ unsigned level_digit(const E &r, int used, const Level &lv) {
     const int bits = lv.bits;
-    if constexpr (MODE == 1) return bits ? (unsigned)(((wide_hash(r.w0, r.w1) << OWNER_BITS) << used) >> (64 - bits)) : 0u;
+    if constexpr (MODE == 3) return rec_digit((uint32_t)r.hd, used, bits);
+    else if constexpr (MODE == 1) return bits ? (unsigned)(((wide_hash(r.w0, r.w1) << OWNER_BITS) << used) >> (64 - bits)) : 0u;
     else if constexpr (MODE == 2) {
         if (lv.n_owners > 0) return (unsigned)__umul64hi(kmer_hash(r.w0), (uint64_t)lv.n_owners);
         return bits ? (unsigned)((local_hash(r.w0) << used) >> (64 - bits)) : 0u;
@@ -1440,7 +1619,7 @@ __device__ __forceinline__ unsigned wide_level1_digit(const Rec &r, const Level 
 
 // levels >= 2 on records: virtual workgroups as for k-mers, digit from the record header
 template <int MODE>
-__global__ __launch_bounds__(PT) void k_rec_hist(const Rec *__restrict__ recs, VbMap m, Level lv, int used,
+__global__ __launch_bounds__(PT) void k_rec_hist(const typename LevelElem<MODE>::T *__restrict__ recs, VbMap m, Level lv, int used,
                                                  uint32_t *__restrict__ table) {
     __shared__ uint32_t h[1 << MAX_BITS];
     VbPos q;
@@ -1449,8 +1628,8 @@ __global__ __launch_bounds__(PT) void k_rec_hist(const Rec *__restrict__ recs, V
     for (int i = threadIdx.x; i < nb; i += PT) h[i] = 0;
     __syncthreads();
     for (uint64_t i = q.begin + threadIdx.x; i < q.end; i += PT) {
-        const Rec r = recs[i];
-        if (MODE == 2 && r.w1 == 0) continue;                 // a hole of the combine output (count 0)
+        const typename LevelElem<MODE>::T r = recs[i];
+        if constexpr (MODE == 2) { if (r.w1 == 0) continue; }   // a hole of the combine output (count 0)
         atomicAdd(&h[level_digit<MODE>(r, used, lv)], 1u);
     }
     __syncthreads();
@@ -1459,8 +1638,9 @@ __global__ __launch_bounds__(PT) void k_rec_hist(const Rec *__restrict__ recs, V
 }
 
 template <int MODE>
-__global__ __launch_bounds__(PT) void k_rec_scatter(const Rec *__restrict__ recs, VbMap m, Level lv, int used,
-                                                    const uint64_t *__restrict__ scanned, Rec *__restrict__ out) {
+__global__ __launch_bounds__(PT) void k_rec_scatter(const typename LevelElem<MODE>::T *__restrict__ recs, VbMap m, Level lv, int used,
+                                                    const uint64_t *__restrict__ scanned,
+                                                    typename LevelElem<MODE>::T *__restrict__ out) {
     __shared__ unsigned long long cur[1 << MAX_BITS];
     VbPos q;
     if (!locate_vb(m, blockIdx.x, &q)) return;
@@ -1469,8 +1649,8 @@ __global__ __launch_bounds__(PT) void k_rec_scatter(const Rec *__restrict__ recs
     for (int i = threadIdx.x; i < nb; i += PT) cur[i] = scanned[tb + (int64_t)i * q.G + q.g];
     __syncthreads();
     for (uint64_t i = q.begin + threadIdx.x; i < q.end; i += PT) {
-        const Rec r = recs[i];
-        if (MODE == 2 && r.w1 == 0) continue;
+        const typename LevelElem<MODE>::T r = recs[i];
+        if constexpr (MODE == 2) { if (r.w1 == 0) continue; }
         out[atomicAdd(&cur[level_digit<MODE>(r, used, lv)], 1ULL)] = r;
     }
 }
@@ -1485,9 +1665,11 @@ constexpr int WCT = 1024;             // threads per workgroup (one workgroup pe
 constexpr int WC_PER = 4;             // records per thread per round
 
 template <int B, int MODE>
-__global__ __launch_bounds__(WCT) void k_rec_scatter_wc(const Rec *__restrict__ recs, VbMap m, Level lv, int used,
-                                                        const uint64_t *__restrict__ scanned, Rec *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char wc_smem[];
+__global__ __launch_bounds__(WCT) void k_rec_scatter_wc(const typename LevelElem<MODE>::T *__restrict__ recs, VbMap m, Level lv,
+                                                        int used, const uint64_t *__restrict__ scanned,
+                                                        typename LevelElem<MODE>::T *__restrict__ out) {
+    using Rec = typename LevelElem<MODE>::T;          // (16-byte elements, or the 32-byte records of MODE 3)
+    extern __shared__ __attribute__((aligned(32))) unsigned char wc_smem[];
     constexpr int A = B / 2;          // records per aligned output line (128 B for B = 16)
     VbPos q;
     if (!locate_vb(m, blockIdx.x, &q)) return;
@@ -1525,7 +1707,9 @@ __global__ __launch_bounds__(WCT) void k_rec_scatter_wc(const Rec *__restrict__ 
 #pragma unroll
         for (int i = 0; i < WC_PER; i++) {
             const uint64_t idx = base + (uint64_t)i * WCT + threadIdx.x;
-            if (idx < q.end && !(MODE == 2 && r[i].w1 == 0)) {
+            bool live = idx < q.end;
+            if constexpr (MODE == 2) live = live && r[i].w1 != 0;
+            if (live) {
                 const unsigned d = level_digit<MODE>(r[i], used, lv);
                 const unsigned long long g = atomicAdd(&tail[d], 1ULL);
                 if (g - head[d] < (unsigned long long)B) buf[(size_t)d * B + (g & (B - 1))] = r[i];
@@ -1936,29 +2120,37 @@ static void launch_sk_hist(int W, dim3 grid, hipStream_t st, Args... args) {
     }
 }
 
-template <int W, bool DESC, class... Args>
+template <int W, bool DESC, bool WIDE, class... Args>
 static hipError_t launch_sk_scatter_w(dim3 grid, size_t lds, hipStream_t st, Args... args) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_sk_scatter<W, DESC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)k_sk_scatter<W, DESC, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_sk_scatter<W, DESC>), grid, dim3(SKT), lds, st, args...);
+    hipLaunchKernelGGL((k_sk_scatter<W, DESC, WIDE>), grid, dim3(SKT), lds, st, args...);
     return hipGetLastError();
 }
-template <bool DESC, class... Args>
+template <bool DESC, bool WIDE, class... Args>
 static hipError_t launch_sk_scatter(int W, dim3 grid, size_t lds, hipStream_t st, Args... args) {
-    switch (W) {
-#define X(w) case w: return launch_sk_scatter_w<w, DESC>(grid, lds, st, args...);
-        RFX_SK_W_CASES(X)
+    if constexpr (WIDE) {                  // the central window is 30 or 31 bases: W = 18 or 19
+        if (W == 18) return launch_sk_scatter_w<18, DESC, true>(grid, lds, st, args...);
+        return launch_sk_scatter_w<19, DESC, true>(grid, lds, st, args...);
+    } else {
+        switch (W) {
+#define X(w) case w: return launch_sk_scatter_w<w, DESC, false>(grid, lds, st, args...);
+            RFX_SK_W_CASES(X)
 #undef X
-        default: return launch_sk_scatter_w<19, DESC>(grid, lds, st, args...);
+            default: return launch_sk_scatter_w<19, DESC, false>(grid, lds, st, args...);
+        }
     }
 }
 
 // level 1 of the record path: reads -> records bucketed by `lv` (radix digit or owner).
 // *out_recs (workspace slot `ws_slot`, or the caller's buffer d_dst of cap_dst records) receives
 // the records, d_seg_off[nb+1] their bucket offsets; *n_recs the total.
+template <bool WIDE = false>
 static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv, bool use_ws, int ws_slot,
-                              Rec *d_dst, int64_t cap_dst, uint64_t *d_seg_off, Rec **out_recs, int64_t *n_recs,
+                              std::conditional_t<WIDE, WRec, Rec> *d_dst, int64_t cap_dst, uint64_t *d_seg_off,
+                              std::conditional_t<WIDE, WRec, Rec> **out_recs, int64_t *n_recs,
                               const char *hn, const char *pn) {
+    using Rec = std::conditional_t<WIDE, WRec, ::Rec>;
     const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
     const int W = rsrc.k - SK_M + 1;
     const size_t sk_lds = (size_t)nb * (SKB * sizeof(Rec) + 16);
@@ -1996,10 +2188,10 @@ static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv
     }
     {
         ScopedTimer t(ctx, pn);
-        if (desc) RFX_HIP(launch_sk_scatter<true>(W, dim3(G), sk_lds, ctx->stream, rsrc, lv,
-                                                  (const uint64_t *)scanned.as<uint64_t>(), dst, (const uint32_t *)desc));
-        else RFX_HIP(launch_sk_scatter<false>(W, dim3(G), sk_lds, ctx->stream, rsrc, lv,
-                                              (const uint64_t *)scanned.as<uint64_t>(), dst, (const uint32_t *)nullptr));
+        if (desc) RFX_HIP((launch_sk_scatter<true, WIDE>(W, dim3(G), sk_lds, ctx->stream, rsrc, lv,
+                                                         (const uint64_t *)scanned.as<uint64_t>(), dst, (const uint32_t *)desc)));
+        else RFX_HIP((launch_sk_scatter<false, WIDE>(W, dim3(G), sk_lds, ctx->stream, rsrc, lv,
+                                                     (const uint64_t *)scanned.as<uint64_t>(), dst, (const uint32_t *)nullptr)));
     }
     *out_recs = dst;
     return RFX_OK;
@@ -2009,9 +2201,10 @@ static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv
 // (seg offsets in *seg_cur), then the leaves.
 // the partition levels of a record array: -> the fully partitioned array and its leaf offsets
 template <int MODE>
-static int partition_record_levels(rfx_ctx *ctx, const Rec *recs, int64_t n_recs, int ws_slot_of_recs,
+static int partition_record_levels(rfx_ctx *ctx, const typename LevelElem<MODE>::T *recs, int64_t n_recs, int ws_slot_of_recs,
                                    const std::vector<int> &bits, size_t first_level, int used, DevBuf **seg_cur_io,
-                                   DevBuf **seg_next_io, int64_t *nseg_io, const Rec **cur_out) {
+                                   DevBuf **seg_next_io, int64_t *nseg_io, const typename LevelElem<MODE>::T **cur_out) {
+    using Rec = typename LevelElem<MODE>::T;
     DevBuf *seg_cur = *seg_cur_io, *seg_next = *seg_next_io;
     int64_t nseg = *nseg_io;
     const Rec *cur = recs;
@@ -2054,7 +2247,19 @@ static int partition_record_levels(rfx_ctx *ctx, const Rec *recs, int64_t n_recs
         {
             ScopedTimer t(ctx, pn);
             const bool wc = !(getenv("RFX_WC") && atoi(getenv("RFX_WC")) == 0) && lv.bits >= 4;
-            if (wc && lv.bits <= 9) {
+            if (wc && MODE == 3) {                   // 32-byte records: 8 slots per bin fill the LDS at 512 bins
+                if (lv.bits > 9) {                   // 1024 bins: 4 slots each (64-byte lines)
+                    const size_t lds = (size_t)nb * (4 * sizeof(Rec) + 16);
+                    RFX_HIP(hipFuncSetAttribute((const void *)k_rec_scatter_wc<4, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((k_rec_scatter_wc<4, MODE>), dim3((unsigned)v_bound), dim3(WCT), lds, ctx->stream, cur, vm, lv,
+                                       used, (const uint64_t *)scanned.as<uint64_t>(), dst);
+                } else {
+                    const size_t lds = (size_t)nb * (8 * sizeof(Rec) + 16);
+                    RFX_HIP(hipFuncSetAttribute((const void *)k_rec_scatter_wc<8, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((k_rec_scatter_wc<8, MODE>), dim3((unsigned)v_bound), dim3(WCT), lds, ctx->stream, cur, vm, lv,
+                                       used, (const uint64_t *)scanned.as<uint64_t>(), dst);
+                }
+            } else if (wc && lv.bits <= 9) {
                 const size_t lds = (size_t)nb * (16 * sizeof(Rec) + 16);
                 RFX_HIP(hipFuncSetAttribute((const void *)k_rec_scatter_wc<16, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((k_rec_scatter_wc<16, MODE>), dim3((unsigned)v_bound), dim3(WCT), lds, ctx->stream, cur, vm, lv,
@@ -2410,16 +2615,19 @@ int merge_pairs(rfx_ctx *ctx, const void *d_pairs, int64_t n, int k, int min_cov
                             d_out_keys, d_out_counts, cap, out_n, out_distinct);
 }
 
-static int finish_wide2(rfx_ctx *ctx, const Rec *cur, const uint64_t *d_leaf_off, int64_t nseg, int min_cov, int max_cov,
-                        uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct) {
+template <bool RECS = false>
+static int finish_wide2(rfx_ctx *ctx, const std::conditional_t<RECS, WRec, Rec> *cur, const uint64_t *d_leaf_off, int64_t nseg,
+                        int min_cov, int max_cov, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n,
+                        int64_t *out_distinct, int k = 63) {
     DevBuf co_buf;
     RFX_HIP(co_buf.alloc(sizeof(CountOut), ctx->stream));
     RFX_HIP(hipMemsetAsync(co_buf.p, 0, sizeof(CountOut), ctx->stream));
     {
         ScopedTimer t(ctx, "leaf");
         const int64_t grid = std::min<int64_t>(nseg, (int64_t)ctx->num_cu);
-        hipLaunchKernelGGL(k_leaf_count_wide, dim3((unsigned)grid), dim3(WLT), 0, ctx->stream, cur, d_leaf_off, nseg, min_cov,
-                           max_cov, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>());
+        hipLaunchKernelGGL(k_leaf_count_wide<RECS>, dim3((unsigned)grid), dim3(WLT), 0, ctx->stream, cur, d_leaf_off, nseg, k,
+                           min_cov, max_cov, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>(),
+                           (uint32_t)(getenv("RFX_WIDE_PRESPLIT") ? atoi(getenv("RFX_WIDE_PRESPLIT")) : 2600));
         RFX_HIP(hipGetLastError());
     }
     CountOut co{};
@@ -2512,6 +2720,65 @@ int bucket_wide_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads,
     return RFX_OK;
 }
 
+// k = 33..63 through super-k-mer records (the default): the k = 31 / 30 front end on the CENTRAL window of
+// every k-mer (a thread's 16 windows, runs that share the central minimiser), 32-byte records that carry
+// the run's k + windows - 1 bases, record levels on the header, leaves that expand the records.  ~5 B per
+// instance through the levels instead of 16.
+// (measured, 5 Gbp at k = 63: levels 63 -> 27 ms, but the leaves 22 -> 68 ms: minimiser buckets are as skewed
+// as the genome's minimiser sites are few per leaf, a two-word table holds 4096 keys, and 10..40 % of the
+// leaves overflow into split passes that expand their records again -- so the element path stays the
+// default and RFX_WIDE_RECORDS=1 selects this one)
+static bool wide_records_enabled(int k) {
+    const char *e = getenv("RFX_WIDE_RECORDS");
+    return e && atoi(e) != 0 && k >= 33 && k <= 63;
+}
+
+static ReadSrc wide_read_src(const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc) {
+    ReadSrc s{};
+    const int c = (k & 1) ? 31 : 30;               // central window; (k - c) / 2 bases of the k-mer on either side
+    s.words = d_words; s.n_reads = n_reads; s.wpr = wpr;
+    s.wfl = (k - c) / 2;
+    s.fc = fc + s.wfl; s.k = c;
+    s.nk = (int)nk;
+    s.segs = s.nk > 0 ? (s.nk + PK - 1) / PK : 1;
+    s.n_threads = s.n_reads * s.segs;
+    return s;
+}
+
+static void plan_wide_record_levels(int64_t n, std::vector<int> &bits) {
+    plan_levels(n, true, bits, 6144.0);          // measured best of 3072 .. 49152 (tools/w63_sweep.sh)
+    int B = 0;
+    for (int b : bits) B += b;
+    if (getenv("RFX_LEVEL_BITS")) return;
+    // 32-byte records: the level-1 rings (8 slots) fill the LDS at 512 bins; later levels take up to 10 bits
+    bits.clear();
+    if (B <= 9) { bits.push_back(B); return; }
+    bits.push_back(9);
+    for (int rest = B - 9; rest > 0; rest -= MAX_BITS) bits.push_back(std::min(rest, MAX_BITS));
+}
+
+static int count_wide2_reads_records(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,
+                                     int min_cov, int max_cov, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap,
+                                     int64_t *out_n, int64_t *out_distinct) {
+    const int64_t n = nk * n_reads;
+    ReadSrc rsrc = wide_read_src(d_words, n_reads, wpr, nk, k, fc);
+    std::vector<int> bits;
+    plan_wide_record_levels(n, bits);
+    Level lv{};
+    lv.bits = bits[0];
+    DevBuf segA, segB;
+    RFX_HIP(segA.alloc(((size_t)(1 << lv.bits) + 1) * 8, ctx->stream));
+    WRec *recs = nullptr;
+    int64_t R = 0;
+    RFX_TRY(records_from_reads<true>(ctx, rsrc, lv, true, 0, nullptr, 0, segA.as<uint64_t>(), &recs, &R, "hist1", "part1"));
+    DevBuf *seg_cur = &segA, *seg_next = &segB;
+    int64_t nseg = (int64_t)1 << lv.bits;
+    const WRec *cur = nullptr;
+    RFX_TRY(partition_record_levels<3>(ctx, recs, R, 0, bits, 1, lv.bits, &seg_cur, &seg_next, &nseg, &cur));
+    return finish_wide2<true>(ctx, cur, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, min_cov, max_cov, d_out_keys,
+                              d_out_counts, cap, out_n, out_distinct, k);
+}
+
 // k = 33..63 from packed uniform reads: level 1 straight from the reads, then count_wide2's levels/leaves
 int count_wide2_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,
                       int min_cov, int max_cov, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n,
@@ -2520,6 +2787,9 @@ int count_wide2_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, in
     if (out_distinct) *out_distinct = 0;
     const int64_t n = nk * n_reads;
     if (n <= 0) return RFX_OK;
+    if (wide_records_enabled(k))
+        return count_wide2_reads_records(ctx, d_words, n_reads, wpr, nk, k, fc, min_cov, max_cov, d_out_keys, d_out_counts, cap,
+                                         out_n, out_distinct);
     std::vector<int> bits;
     plan_levels(n, true, bits, 8192.0);
     if (bits[0] > 9) {                               // the level-1 rings hold 512 bins: move the excess down

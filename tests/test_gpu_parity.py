@@ -1148,3 +1148,27 @@ def test_combine_bucket_merge_pairs(rfx, torch_mod, k, owners):
         assert d == int(np.sum(own_all == o))
         assert np.array_equal(dk[:m].cpu().numpy().view(np.uint64), gk[own == o])
         assert np.array_equal(dc[:m].cpu().numpy(), gc[own == o])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [33, 40, 47, 63])
+def test_wide_record_path_equals_oracle(rfx, torch_mod, k, monkeypatch):
+    """RFX_WIDE_RECORDS=1: k = 33..63 through 32-byte super-k-mer records (minimiser of the central 31/30
+    bases, record levels, expanding leaves) -- same counts as the oracle and as the default element path."""
+    torch = torch_mod
+    seed, G, n_reads, L = 77, 30_000, 20_000, 150
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    N = rfx.kmers_per_read_w(L, k) * n_reads
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RFX_WIDE_RECORDS", flag)
+        dk = torch.empty(2 * N, dtype=torch.int64, device="cuda"); dc = torch.empty(N, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        m, d, inst = rfx.count_reads_w_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, 2)
+        res.append((m, d, dk[:2 * m].cpu().numpy().view(np.uint64).reshape(m, 2), dc[:m].cpu().numpy()))
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+    wk, wc, wd = O.count_filter_w(O.extract_canon_w(bases, off, k), k, 2)
+    for m, d, kk, cc in res:
+        assert (m, d) == (len(wk), wd)
+        assert np.array_equal(kk, wk) and np.array_equal(cc, wc)

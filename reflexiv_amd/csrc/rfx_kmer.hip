@@ -917,10 +917,10 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<ELEM>
 
 // ---- leaves of the k > 32 path: two-word keys.  No 128-bit LDS atomic exists, so a slot is
 // claimed through its count word: 0 = empty, WLOCK = being written, otherwise the count.  The
-// claimer writes both key words and then publishes count 1; a lane that meets WLOCK simply tries the
-// same slot again on its next trip round the loop (the claimer's branch has run by then -- divergent
-// branches of a wave execute one after the other -- or runs in another wave), a lane that meets a
-// count compares the (now immutable) key words.  Same structure otherwise: persistent workgroups over
+// claimer writes both key words and then publishes count 1; a lane that meets WLOCK tries the same
+// slot again on the next trip round a loop that the WHOLE WAVE leaves together (ballot) -- so the
+// publish of a neighbouring lane can never sit on an exit path the spinning lane keeps it from
+// reaching -- and a lane that meets a count compares the (now immutable) key words.  Same structure otherwise: persistent workgroups over
 // contiguous leaf chunks, two barriers per leaf, table sweep, split on overflow.
 constexpr int WCAP_BITS = 12;
 constexpr int WCAP = 1 << WCAP_BITS;
@@ -1005,25 +1005,6 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
         }
         while (begin != end) {
             // one pass: the keys selected by (S, s) go into the table
-            auto insert = [&](const uint64_t w0, const uint64_t w1) __attribute__((always_inline)) {
-                const uint32_t g = ((uint32_t)w0 ^ __builtin_rotateleft32((uint32_t)(w0 >> 32), 13) ^
-                                    ((uint32_t)w1 * 0x85EBCA6Bu) ^ (uint32_t)(w1 >> 32)) * 0x9E3779B1u;
-                if (S > 1 && (((g >> 4) & 0xffffu) & (S - 1)) != s) return;
-                uint32_t slot = g >> (32 - WCAP_BITS);
-                for (int probe = 0;;) {
-                    const uint32_t c = atomicCAS(&tcnt[slot], 0u, WLOCK);
-                    if (c == 0u) {                                  // claimed: write the key, publish count 1
-                        thi[slot] = w0; tlo[slot] = w1;
-                        __threadfence_block();
-                        atomicExch(&tcnt[slot], 1u);
-                        break;
-                    }
-                    if (c == WLOCK) continue;                       // being written: look again
-                    if (thi[slot] == w0 && tlo[slot] == w1) { atomicAdd(&tcnt[slot], 1u); break; }
-                    slot = (slot + 1) & (WCAP - 1);
-                    if (++probe >= LPROBE) { overflow = 1; break; }
-                }
-            };
             // two keys: the first probes of both are issued before either is followed up
             auto insert2 = [&](const uint64_t a0, const uint64_t a1, bool va, const uint64_t b0, const uint64_t b1, bool vb)
                                __attribute__((always_inline)) {
@@ -1138,7 +1119,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                 for (uint64_t i = begin + threadIdx.x; i < end; i += WLT) {
                     if (__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
                     const Rec e = elems[i];
-                    insert(e.w0, e.w1);
+                    insert2(e.w0, e.w1, true, 0, 0, false);
                 }
             }
             __syncthreads();

@@ -156,7 +156,7 @@ def main():
         # (k <= 31: ~2.7 B of super-k-mer record per instance; k > 31: one 16-byte element per instance)
         # pairs: 16 B per distinct k-mer of a chunk, ~1.5 B per instance on this workload (a larger
         # message is still exchanged correctly, in rounds)
-        per_inst = 16.0 if wide else 1.6 if engine.combine else 2.7
+        per_inst = 16.0 if wide else 2.0 if engine.combine else 2.7
         est = per_inst * n_inst / world / rd.A2A_LIMIT_BYTES
         chunks = max(args.exchange_chunks, int(est) + 1)
         keys, counts, tot = rd.sharded_count(engine, reads, args.cover, 10_000_000, 0, chunks=chunks)

@@ -1172,3 +1172,39 @@ def test_wide_record_path_equals_oracle(rfx, torch_mod, k, monkeypatch):
     for m, d, kk, cc in res:
         assert (m, d) == (len(wk), wd)
         assert np.array_equal(kk, wk) and np.array_equal(cc, wc)
+
+
+@pytest.mark.gpu
+def test_combine_and_merge_edge_cases(rfx, torch_mod):
+    """empty read set, reads too short for a k-mer, no pairs to group or merge, and a merge whose partial
+    counts of one k-mer arrive in many pieces (sums, then the coverage filter on the SUM)."""
+    torch = torch_mod
+    k, L = 31, 100
+    wpr = (L + 31) // 32
+    cap = 9 << 20
+    scratch = torch.empty(2 * cap, dtype=torch.int64, device="cuda"); out = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+    doff = torch.empty(5, dtype=torch.int64, device="cuda")
+    dw = torch.zeros(4 * wpr, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    m, h, inst = rfx.combine_reads_dev(dw.data_ptr(), 0, wpr, L, k, 4, scratch.data_ptr(), out.data_ptr(), cap, doff.data_ptr())
+    assert (m, inst) == (0, 0) and not h.any()
+    m, h, inst = rfx.combine_reads_dev(dw.data_ptr(), 4, wpr, 20, k, 4, scratch.data_ptr(), out.data_ptr(), cap, doff.data_ptr())
+    assert (m, inst) == (0, 0) and not h.any()                       # 20-base reads hold no 31-mer
+    # four poly-A reads: one k-mer, count 4 * 70
+    m, h, inst = rfx.combine_reads_dev(dw.data_ptr(), 4, wpr, L, k, 4, scratch.data_ptr(), out.data_ptr(), cap, doff.data_ptr())
+    assert (m, inst) == (1, 4 * (L - k + 1))
+    assert out[:2].cpu().tolist() == [0, 4 * (L - k + 1)]
+    h2 = rfx.bucket_pairs_by_owner_dev(out.data_ptr(), 0, 4, scratch.data_ptr(), doff.data_ptr())
+    assert not h2.any()
+    dk = torch.empty(16, dtype=torch.int64, device="cuda"); dc = torch.empty(16, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    assert rfx.merge_pairs_dev(out.data_ptr(), 0, k, dk.data_ptr(), dc.data_ptr(), 16, 2) == (0, 0)
+    # 3 k-mers in 40 000 pieces: counts 1 each -> sums 20000, 19999, 1; the filter sees the sums
+    n = 40_000
+    keys = torch.tensor([5, 9], dtype=torch.int64).repeat(n // 2); keys[-1] = 77
+    pairs = torch.stack([keys, torch.ones(n, dtype=torch.int64)], dim=1).reshape(-1).cuda()
+    torch.cuda.synchronize()
+    m, d = rfx.merge_pairs_dev(pairs.data_ptr(), n, k, dk.data_ptr(), dc.data_ptr(), 16, 2, 19_999)
+    assert (m, d) == (1, 3) and dk[:1].cpu().tolist() == [9] and dc[:1].cpu().tolist() == [19_999]
+    m, d = rfx.merge_pairs_dev(pairs.data_ptr(), n, k, dk.data_ptr(), dc.data_ptr(), 16, 1)
+    assert (m, d) == (3, 3) and dk[:3].cpu().tolist() == [5, 9, 77] and dc[:3].cpu().tolist() == [20_000, 19_999, 1]

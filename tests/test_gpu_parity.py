@@ -1208,3 +1208,35 @@ def test_combine_and_merge_edge_cases(rfx, torch_mod):
     assert (m, d) == (1, 3) and dk[:1].cpu().tolist() == [9] and dc[:1].cpu().tolist() == [19_999]
     m, d = rfx.merge_pairs_dev(pairs.data_ptr(), n, k, dk.data_ptr(), dc.data_ptr(), 16, 1)
     assert (m, d) == (3, 3) and dk[:3].cpu().tolist() == [5, 9, 77] and dc[:3].cpu().tolist() == [20_000, 19_999, 1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [31, 17])
+def test_combine_and_merge_through_heavy_leaves(rfx, torch_mod, k, monkeypatch):
+    """The pair forms with every leaf forced through the heavy-leaf path (slices, partial counts sorted and
+    reduced): the combine emits pairs from k_reduce_partials, the merge sums weighted partials."""
+    torch = torch_mod
+    monkeypatch.setenv("RFX_HEAVY", "40,16,64" if k == 31 else "300,128,64")
+    seed, G, n_reads, L, owners = 11 + k, 20_000, 30_000, 150, 2
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    N = rfx.kmers_per_read(L, k) * n_reads
+    cap = N + (9 << 20)
+    scratch = torch.empty(2 * cap, dtype=torch.int64, device="cuda"); out = torch.empty(2 * cap, dtype=torch.int64, device="cuda")
+    doff = torch.empty(owners + 1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    m, h, inst = rfx.combine_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, owners, scratch.data_ptr(), out.data_ptr(), cap, doff.data_ptr())
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+    km = O.extract_canon(bases, off, k)
+    wk, wc, wd = O.count_filter(km, 1)
+    bp = out[:2 * m].cpu().numpy().view(np.uint64).reshape(m, 2)
+    order = np.argsort(bp[:, 0], kind="stable")
+    assert m == wd and np.array_equal(bp[order, 0], wk) and np.array_equal(bp[order, 1], wc.astype(np.uint64))
+    # merge everything (both owners' buckets, twice over: every partial count doubled)
+    twice = torch.cat([out[:2 * m], out[:2 * m]])
+    dk = torch.empty(2 * m, dtype=torch.int64, device="cuda"); dc = torch.empty(2 * m, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    mm, d = rfx.merge_pairs_dev(twice.data_ptr(), 2 * m, k, dk.data_ptr(), dc.data_ptr(), 2 * m, 6)
+    keep = 2 * wc >= 6
+    assert d == wd and mm == int(keep.sum())
+    assert np.array_equal(dk[:mm].cpu().numpy().view(np.uint64), wk[keep]) and np.array_equal(dc[:mm].cpu().numpy(), 2 * wc[keep])

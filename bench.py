@@ -156,7 +156,7 @@ def main():
         # (k <= 31: ~2.7 B of super-k-mer record per instance; k > 31: one 16-byte element per instance)
         # pairs: 16 B per distinct k-mer of a chunk, ~1.5 B per instance on this workload (a larger
         # message is still exchanged correctly, in rounds)
-        per_inst = 16.0 if wide else 2.0 if engine.combine else 2.7
+        per_inst = (5.6 if engine.wide_records else 16.0) if wide else 2.0 if engine.combine else 2.7
         est = per_inst * n_inst / world / rd.A2A_LIMIT_BYTES
         chunks = max(args.exchange_chunks, int(est) + 1)
         keys, counts, tot = rd.sharded_count(engine, reads, args.cover, 10_000_000, 0, chunks=chunks)
@@ -216,7 +216,7 @@ def main():
                    "kmers_kept": m,
                    "parallelism": "1 GPU" if not multi else f"k-mer space radix-sharded over {world} GPUs, "
                                                                "RCCL all-to-all(v) of " +
-                                                               ("two-word k-mers" if wide else "(k-mer, local count) pairs"
+                                                               ("32-byte super-k-mer records of two-word k-mers" if wide else "(k-mer, local count) pairs"
                                                                 if engine.combine else "super-k-mer records")},
         "roofline": roofline,
         "stage_hbm_frac": (((0.25 + 16 * W) * n_inst + (8 * W + 4) * m) / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS) if not multi else None,

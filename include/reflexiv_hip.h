@@ -233,6 +233,18 @@ int rfx_dev_count_wide_elems(rfx_ctx *ctx, const void *d_elems, int64_t n_elems,
                              uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap,
                              int64_t *out_n, int64_t *out_distinct);
 
+/* The same two steps on 32-byte super-k-mer RECORDS of two-word k-mers (k = 33..63): a run of <= 16
+ * consecutive windows that share the minimiser of their CENTRAL 31 (k odd) / 30 (k even) bases, carried
+ * as the run's k + windows - 1 bases + a header; ~5 B per instance across the exchange instead of 16.
+ * Bucketing: d_out_records = NULL / cap_records = 0 reports *out_n_records (RFX_E_CAP), as for k <= 31. */
+int rfx_dev_bucket_wide_records_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read,
+                                         int read_len, int k, int front_clip, int end_clip, int n_owners,
+                                         void *d_out_records, int64_t cap_records, int64_t *d_owner_off,
+                                         int64_t *h_owner_off, int64_t *out_n_records);
+int rfx_dev_count_wide_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_t n_instances_hint, int k,
+                               int min_cov, int max_cov, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap,
+                               int64_t *out_n, int64_t *out_distinct);
+
 /* Same, from an explicit k-mer array (the reduceByKey input) in HBM. */
 int rfx_dev_count_kmers(rfx_ctx *ctx, const uint64_t *d_kmers, int64_t n,
                         int min_cov, int max_cov, int twin,

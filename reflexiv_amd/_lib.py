@@ -53,6 +53,7 @@ SYMBOLS = [
     "rfx_extract_canon_w", "rfx_count_filter_w", "rfx_kmers_per_read_w", "rfx_dev_count_reads_w",
     "rfx_dev_count_reads_ragged", "rfx_assemble_reads", "rfx_dev_bucket_wide_by_owner", "rfx_dev_count_wide_elems",
     "rfx_dev_combine_reads", "rfx_dev_bucket_pairs_by_owner", "rfx_dev_merge_pairs",
+    "rfx_dev_bucket_wide_records_by_owner", "rfx_dev_count_wide_records",
 ]
 
 

@@ -376,6 +376,31 @@ class Reflexiv:
         self._check(st, "rfx_dev_count_records")
         return int(m.value), int(d.value)
 
+    def bucket_wide_records_by_owner_dev(self, d_words: int, n_reads: int, wpr: int, read_len: int, k: int, n_owners: int,
+                                         d_out_records: int, cap_records: int, d_owner_off: int, front_clip=0, end_clip=0):
+        """k = 33..63: 32-byte super-k-mer records grouped by owner -> (n_records, owner_off host or None when the
+        buffer is missing / short: n_records is then the capacity needed)."""
+        nrec = C.c_int64(0)
+        h = np.zeros(n_owners + 1, np.int64)
+        st = self.L.rfx_dev_bucket_wide_records_by_owner(self.ctx, C.c_void_p(d_words), C.c_int64(n_reads), wpr, read_len, k,
+                                                         front_clip, end_clip, n_owners, C.c_void_p(d_out_records),
+                                                         C.c_int64(cap_records), C.c_void_p(d_owner_off), _p(h), C.byref(nrec))
+        if st == RFX_E_CAP:
+            return int(nrec.value), None
+        self._check(st, "rfx_dev_bucket_wide_records_by_owner")
+        return int(nrec.value), h
+
+    def count_wide_records_dev(self, d_records: int, n_records: int, n_instances_hint: int, k: int, d_out_keys: int,
+                               d_out_counts: int, cap: int, min_cov=2, max_cov=10_000_000):
+        m, d = C.c_int64(0), C.c_int64(0)
+        st = self.L.rfx_dev_count_wide_records(self.ctx, C.c_void_p(d_records), C.c_int64(n_records),
+                                               C.c_int64(n_instances_hint), k, min_cov, max_cov, C.c_void_p(d_out_keys),
+                                               C.c_void_p(d_out_counts), C.c_int64(cap), C.byref(m), C.byref(d))
+        if st == RFX_E_CAP:
+            raise RfxError(st, "rfx_dev_count_wide_records", f"needs room for {m.value} survivors, cap is {cap}")
+        self._check(st, "rfx_dev_count_wide_records")
+        return int(m.value), int(d.value)
+
     # ---- the exchange after a local combine (reduceByKey's map-side combine, P/ReflexivMain.java:155)
     def combine_reads_dev(self, d_words: int, n_reads: int, wpr: int, read_len: int, k: int, n_owners: int,
                           d_scratch_pairs: int, d_out_pairs: int, cap_pairs: int, d_owner_off: int,

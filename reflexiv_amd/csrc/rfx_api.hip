@@ -527,6 +527,40 @@ int rfx_dev_bucket_wide_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t 
                                 d_owner_off, h_owner_off);
 }
 
+int rfx_dev_bucket_wide_records_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read,
+                                         int read_len, int k, int front_clip, int end_clip, int n_owners,
+                                         void *d_out_records, int64_t cap_records, int64_t *d_owner_off,
+                                         int64_t *h_owner_off, int64_t *out_n_records) {
+    if (!ctx || !d_words || !d_owner_off || n_reads < 0 || words_per_read * 32 < read_len) return RFX_E_ARG;
+    RFX_TRY(check_k_w(k));
+    if (!wide_fast_path(k) || front_clip < 0 || end_clip < 0) return RFX_E_ARG;      // two-word k-mers only
+    RFX_HIP(hipSetDevice(ctx->device));
+    ctx->timing.clear();
+    const int64_t nk = kmers_per_read_w(read_len, k, front_clip, end_clip);
+    const int st = bucket_wide_records_by_owner(ctx, d_words, n_reads, words_per_read, nk, k, front_clip, n_owners,
+                                                d_out_records, cap_records, d_owner_off, h_owner_off, out_n_records);
+    if (h_owner_off) ScopedTimer::collect(ctx);
+    return st;
+}
+
+int rfx_dev_count_wide_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_t n_instances_hint, int k,
+                               int min_cov, int max_cov, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap,
+                               int64_t *out_n, int64_t *out_distinct) {
+    if (!ctx || !out_n || n_records < 0 || (n_records > 0 && !d_records)) return RFX_E_ARG;
+    RFX_TRY(check_k_w(k));
+    if (!wide_fast_path(k)) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    ctx->timing.clear();
+    int64_t m = 0;
+    int st = count_wide_records(ctx, d_records, n_records, n_instances_hint, k, min_cov, max_cov, d_out_keys, d_out_counts,
+                                cap, &m, out_distinct);
+    *out_n = m;
+    if (st == RFX_OK) st = order_wide2(ctx, d_out_keys, d_out_counts, m, k);
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    ScopedTimer::collect(ctx);
+    return st;
+}
+
 int rfx_dev_count_wide_elems(rfx_ctx *ctx, const void *d_elems, int64_t n_elems, int k, int min_cov, int max_cov,
                              uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n,
                              int64_t *out_distinct) {

@@ -192,6 +192,12 @@ int bucket_records_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, 
 int count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_t n_instances_hint, int k,
                   int min_cov, int max_cov, int twin, uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap,
                   int64_t *out_n, int64_t *out_distinct);
+int bucket_wide_records_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,
+                                 int n_owners, void *d_out, int64_t cap_records, int64_t *d_owner_off, int64_t *h_owner_off,
+                                 int64_t *out_n_records);
+int count_wide_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_t n_instances_hint, int k, int min_cov,
+                       int max_cov, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n,
+                       int64_t *out_distinct);
 int count_wide2(rfx_ctx *ctx, const void *d_elems, int64_t n, int min_cov, int max_cov, uint64_t *d_out_keys,
                 int64_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct);
 int count_wide2_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,

@@ -2760,6 +2760,56 @@ static int count_wide2_reads_records(rfx_ctx *ctx, const uint64_t *d_words, int6
                               d_out_counts, cap, out_n, out_distinct, k);
 }
 
+// multi-GPU, k = 33..63: the 32-byte records grouped by the owner of their minimiser (~5 B per instance
+// across the exchange instead of 16), and the count of records that arrived
+int bucket_wide_records_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,
+                                 int n_owners, void *d_out, int64_t cap_records, int64_t *d_owner_off, int64_t *h_owner_off,
+                                 int64_t *out_n_records) {
+    if (n_owners < 1 || n_owners > 64 || k < 33 || k > 63) return RFX_E_ARG;
+    if (out_n_records) *out_n_records = 0;
+    if (nk <= 0 || n_reads <= 0) {
+        RFX_HIP(hipMemsetAsync(d_owner_off, 0, (size_t)(n_owners + 1) * 8, ctx->stream));
+        if (h_owner_off) memset(h_owner_off, 0, (size_t)(n_owners + 1) * 8);
+        return RFX_OK;
+    }
+    ReadSrc rsrc = wide_read_src(d_words, n_reads, wpr, nk, k, fc);
+    Level lv{};
+    lv.n_owners = n_owners;
+    WRec *recs = nullptr;
+    int64_t R = 0;
+    const int st = records_from_reads<true>(ctx, rsrc, lv, false, 0, (WRec *)d_out, cap_records,
+                                            reinterpret_cast<uint64_t *>(d_owner_off), &recs, &R, "hist1", "part1");
+    if (out_n_records) *out_n_records = R;
+    if (st != RFX_OK) return st;
+    if (h_owner_off) {
+        RFX_HIP(hipMemcpyAsync(h_owner_off, d_owner_off, (size_t)(n_owners + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return RFX_OK;
+}
+
+int count_wide_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_t n_instances_hint, int k, int min_cov,
+                       int max_cov, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n,
+                       int64_t *out_distinct) {
+    if (out_n) *out_n = 0;
+    if (out_distinct) *out_distinct = 0;
+    if (k < 33 || k > 63) return RFX_E_ARG;
+    if (n_records <= 0) return RFX_OK;
+    std::vector<int> bits;
+    plan_wide_record_levels(n_instances_hint > 0 ? n_instances_hint : n_records * 6, bits);
+    DevBuf segA, segB;
+    uint64_t seg_init[2] = {0, (uint64_t)n_records};
+    RFX_HIP(segA.alloc(2 * 8, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(segA.p, seg_init, 16, hipMemcpyHostToDevice, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    DevBuf *seg_cur = &segA, *seg_next = &segB;
+    int64_t nseg = 1;
+    const WRec *cur = nullptr;
+    RFX_TRY(partition_record_levels<3>(ctx, (const WRec *)d_records, n_records, 1, bits, 0, 0, &seg_cur, &seg_next, &nseg, &cur));
+    return finish_wide2<true>(ctx, cur, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, min_cov, max_cov, d_out_keys,
+                              d_out_counts, cap, out_n, out_distinct, k);
+}
+
 // k = 33..63 from packed uniform reads: level 1 straight from the reads, then count_wide2's levels/leaves
 int count_wide2_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,
                       int min_cov, int max_cov, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n,

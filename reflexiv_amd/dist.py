@@ -22,13 +22,18 @@ class HipEngine:
     For k = 21..31 the unit that crosses the exchange is the 16-byte super-k-mer record (two int64
     per record, ~2.6 B per k-mer instance); otherwise the 8-byte canonical k-mer."""
 
-    def __init__(self, rfx, records: bool = True, combine: bool = False):
+    def __init__(self, rfx, records: bool = True, combine: bool = False, wide_records: bool = True):
         self.rfx = rfx
         self.records = records
+        self.wide_records = wide_records      # k = 33..63: ship 32-byte super-k-mer records instead of 16-byte k-mers
         self.combine = combine    # k <= 31: count locally first, ship (k-mer, partial count) pairs
         self.k = None
         self.width = 1            # int64 words per exchanged unit
         self.timing = {}          # kernel family -> [ms, launches] over every library call since the last reset
+
+    def _take_hint(self):
+        h, self._inst_acc = int(getattr(self, "_inst_acc", 0) or 0), 0
+        return h
 
     def _acc_timing(self):
         for name, (ms, ln) in self.rfx.count_timing().items():
@@ -92,6 +97,26 @@ class HipEngine:
         """reads = dict(words=int64 cuda tensor, n_reads, wpr, read_len, k) ->
         (kmers int64[N] grouped by owner, owner_off int64[n_owners+1] on the host)."""
         self.k = reads["k"]
+        if reads["k"] > 31 and self.wide_records:       # k = 33..63: 32-byte super-k-mer records (~5 B per instance)
+            dev = reads["words"].device
+            nk = self.rfx.kmers_per_read_w(reads["read_len"], reads["k"])
+            self.n_instances, self.width = nk * reads["n_reads"], 4
+            self._inst_acc = getattr(self, "_inst_acc", 0) + self.n_instances
+            if getattr(self, "_wrec_per_read", None) is None:
+                self._wrec_per_read = nk / 5.0 + 1.0
+            doff = torch.empty(n_owners + 1, dtype=torch.int64, device=dev)
+            args = (reads["words"].data_ptr(), reads["n_reads"], reads["wpr"], reads["read_len"], reads["k"], n_owners)
+            cap = int(self._wrec_per_read * reads["n_reads"]) + 4096
+            while True:
+                out = torch.empty(4 * max(1, cap), dtype=torch.int64, device=dev)
+                torch.cuda.current_stream().synchronize()
+                nrec, h = self.rfx.bucket_wide_records_by_owner_dev(*args, out.data_ptr(), cap, doff.data_ptr())
+                if h is not None:
+                    self._acc_timing()
+                    return out[:4 * nrec], torch.from_numpy(h.copy())
+                del out
+                cap = nrec
+                self._wrec_per_read = 1.03 * nrec / max(1, reads["n_reads"])     # only ever grows
         if reads["k"] > 31:                             # two-word k-mers (k = 33..63): 16-byte elements
             n = self.rfx.kmers_per_read_w(reads["read_len"], reads["k"]) * reads["n_reads"]
             self.n_instances, self.width = n, 2
@@ -136,6 +161,9 @@ class HipEngine:
 
     def estimate_units(self, reads):
         """records (k-mers) this rank's reads produce, from the ratio seen in the previous call; 0 = unknown"""
+        if reads["k"] > 31 and self.wide_records:
+            nk = self.rfx.kmers_per_read_w(reads["read_len"], reads["k"])
+            return int((getattr(self, "_wrec_per_read", None) or nk / 5.0 + 1.0) * reads["n_reads"])
         if reads["k"] > 31:
             return self.rfx.kmers_per_read_w(reads["read_len"], reads["k"]) * reads["n_reads"]
         if self.combine:
@@ -169,19 +197,25 @@ class HipEngine:
     def count_kmers(self, kmers, min_cov, max_cov, twin):
         from ._lib import RfxError, RFX_E_CAP
         if self.k is not None and self.k > 31:          # -> keys int64[2m] (two words per k-mer), counts int64[m]
-            n = int(kmers.numel()) // 2
-            cap = max(1 << 20, n // 8)
+            recs = self.width == 4
+            hint = self._take_hint()        # (by symmetry a rank receives about as many instances as its own reads hold)
+            n = int(kmers.numel()) // self.width
+            cap = max(1 << 20, (6 * n if recs else n) // 8)
             while True:
                 keys = torch.empty(2 * cap, dtype=torch.int64, device=kmers.device)
                 counts = torch.empty(cap, dtype=torch.int64, device=kmers.device)
                 torch.cuda.current_stream().synchronize()
                 try:
-                    m, d = self.rfx.count_wide_elems_dev(kmers.data_ptr(), n, self.k, keys.data_ptr(), counts.data_ptr(), cap,
-                                                         min_cov, max_cov)
+                    if recs:
+                        m, d = self.rfx.count_wide_records_dev(kmers.data_ptr(), n, hint, self.k, keys.data_ptr(),
+                                                               counts.data_ptr(), cap, min_cov, max_cov)
+                    else:
+                        m, d = self.rfx.count_wide_elems_dev(kmers.data_ptr(), n, self.k, keys.data_ptr(), counts.data_ptr(),
+                                                             cap, min_cov, max_cov)
                     self._acc_timing()
                     return keys[:2 * m], counts[:m], d
                 except RfxError as e:
-                    if e.status != RFX_E_CAP or cap >= 2 * n:
+                    if e.status != RFX_E_CAP or cap >= 16 * n:
                         raise
                     del keys, counts
                     cap = cap * 4
@@ -310,7 +344,7 @@ def sharded_count(engine, reads, min_cov, max_cov, twin, group=None, chunks: int
         head = [big[:pos]] if big is not None and pos else []
         recv = (head + parts)[0] if len(head + parts) == 1 else torch.cat(head + parts) if head + parts else km[:0]
         del pending, parts
-        kmers_numel, n_inst = sent, (n_inst_total if width == 2 else None)
+        kmers_numel, n_inst = sent, (n_inst_total if width != 1 else None)
     else:
         kmers, owner_off = engine.bucket_by_owner(reads, world)
         width = getattr(engine, "width", 1)

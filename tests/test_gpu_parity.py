@@ -1079,12 +1079,14 @@ def test_wide_owner_buckets_and_sharded_count(rfx, torch_mod):
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         rfx.use_stream(torch.cuda.current_stream().cuda_stream)
-        eng = rd.HipEngine(rfx)
-        eng.force_exchange = True
         reads = dict(words=dw, n_reads=n_reads, wpr=wpr, read_len=L, k=k)
-        keys, counts, tot = rd.sharded_count(eng, reads, 2, 10_000_000, 0, chunks=3)
-        assert tot == [N, wd, len(wk)]
-        assert np.array_equal(keys.cpu().numpy().view(np.uint64).reshape(-1, 2), wk) and np.array_equal(counts.cpu().numpy(), wc)
+        for wide_records, chunks in ((True, 3), (False, 3), (True, 1)):       # 32-byte records / 16-byte k-mers
+            eng = rd.HipEngine(rfx, wide_records=wide_records)
+            eng.force_exchange = True
+            keys, counts, tot = rd.sharded_count(eng, reads, 2, 10_000_000, 0, chunks=chunks)
+            assert eng.width == (4 if wide_records else 2)
+            assert tot == [N, wd, len(wk)]
+            assert np.array_equal(keys.cpu().numpy().view(np.uint64).reshape(-1, 2), wk) and np.array_equal(counts.cpu().numpy(), wc)
     finally:
         if created:
             dist.destroy_process_group()
@@ -1240,3 +1242,42 @@ def test_combine_and_merge_through_heavy_leaves(rfx, torch_mod, k, monkeypatch):
     keep = 2 * wc >= 6
     assert d == wd and mm == int(keep.sum())
     assert np.array_equal(dk[:mm].cpu().numpy().view(np.uint64), wk[keep]) and np.array_equal(dc[:mm].cpu().numpy(), 2 * wc[keep])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,owners", [(63, 4), (40, 3), (33, 8)])
+def test_wide_record_owner_buckets(rfx, torch_mod, k, owners):
+    """k = 33..63 multi-GPU support, record form: the 32-byte records grouped by owner, a too-small buffer
+    reports the need, and the per-owner counts of the records are disjoint and add up to the global count."""
+    torch = torch_mod
+    seed, G, n_reads, L = 19 + k, 50_000, 24_000, 150
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    doff = torch.empty(owners + 1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    need, h = rfx.bucket_wide_records_by_owner_dev(dw.data_ptr(), n_reads, wpr, L, k, owners, 0, 0, doff.data_ptr())
+    assert h is None and need > n_reads
+    out = torch.empty(4 * need, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    nrec, h = rfx.bucket_wide_records_by_owner_dev(dw.data_ptr(), n_reads, wpr, L, k, owners, out.data_ptr(), need, doff.data_ptr())
+    assert nrec == need and h[0] == 0 and h[-1] == nrec and np.all(np.diff(h) > 0)
+    recs = out.cpu().numpy().view(np.uint64).reshape(nrec, 4)
+    nwin = ((recs[:, 3] >> np.uint64(32)) & np.uint64(15)).astype(np.int64) + 1
+    N = rfx.kmers_per_read_w(L, k) * n_reads
+    assert int(nwin.sum()) == N                                   # every window is in exactly one record
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+    wk, wc, wd = O.count_filter_w(O.extract_canon_w(bases, off, k), k, 2)
+    got_k, got_c, tot_d = [], [], 0
+    for o in range(owners):
+        n_o = int(h[o + 1] - h[o])
+        cap = 6 * n_o + 16
+        dk = torch.empty(2 * cap, dtype=torch.int64, device="cuda"); dc = torch.empty(cap, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        m, d = rfx.count_wide_records_dev(out[4 * int(h[o]):].data_ptr(), n_o, 0, k, dk.data_ptr(), dc.data_ptr(), cap, 2)
+        tot_d += d
+        kk = dk[:2 * m].cpu().numpy().view(np.uint64).reshape(m, 2)
+        assert m == 0 or np.all((kk[1:, 0] > kk[:-1, 0]) | ((kk[1:, 0] == kk[:-1, 0]) & (kk[1:, 1] > kk[:-1, 1])))
+        got_k.append(kk); got_c.append(dc[:m].cpu().numpy())
+    allk = np.concatenate(got_k); allc = np.concatenate(got_c)
+    order = np.lexsort((allk[:, 1], allk[:, 0]))
+    assert tot_d == wd and np.array_equal(allk[order], wk) and np.array_equal(allc[order], wc)

@@ -1005,65 +1005,47 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
         }
         while (begin != end) {
             // one pass: the keys selected by (S, s) go into the table
-            // two keys: the first probes of both are issued before either is followed up
-            auto insert2 = [&](const uint64_t a0, const uint64_t a1, bool va, const uint64_t b0, const uint64_t b1, bool vb)
-                               __attribute__((always_inline)) {
-                auto slot_hash = [](uint64_t w0, uint64_t w1) __attribute__((always_inline)) {
-                    return ((uint32_t)w0 ^ __builtin_rotateleft32((uint32_t)(w0 >> 32), 13) ^
-                            ((uint32_t)w1 * 0x85EBCA6Bu) ^ (uint32_t)(w1 >> 32)) * 0x9E3779B1u;
-                };
-                const uint32_t ga = slot_hash(a0, a1), gb = slot_hash(b0, b1);
-                if (S > 1) {
-                    va = va && (((ga >> 4) & 0xffffu) & (S - 1)) == s;
-                    vb = vb && (((gb >> 4) & 0xffffu) & (S - 1)) == s;
+            // one key into the table.  The first probe is straight-line code (nine in ten meet the key itself);
+            // the rest runs in a loop the WHOLE WAVE leaves together (ballot): a lane that leaves a loop early
+            // waits at the exit for the others, and code on an exit path -- a `break` after the publish -- runs
+            // only then, so a lane spinning on a lock its neighbour holds would spin for ever.  Here every
+            // publish sits inside an iteration every lane completes, and the claim of a first probe is
+            // published before anyone waits.
+            auto insert1 = [&](const uint64_t w0, const uint64_t w1, bool v) __attribute__((always_inline)) {
+                const uint32_t g = ((uint32_t)w0 ^ __builtin_rotateleft32((uint32_t)(w0 >> 32), 13) ^
+                                    ((uint32_t)w1 * 0x85EBCA6Bu) ^ (uint32_t)(w1 >> 32)) * 0x9E3779B1u;
+                if (S > 1) v = v && (((g >> 4) & 0xffffu) & (S - 1)) == s;
+                uint32_t slot = g >> (32 - WCAP_BITS);
+                uint32_t c = 1u;
+                if (v) c = atomicCAS(&tcnt[slot], 0u, WLOCK);
+                if (v && c == 0u) {                                   // claimed: write the key, publish count 1
+                    thi[slot] = w0; tlo[slot] = w1;
+                    __threadfence_block();
+                    atomicExch(&tcnt[slot], 1u);
                 }
-                uint32_t sa = ga >> (32 - WCAP_BITS), sb = gb >> (32 - WCAP_BITS);
-                uint32_t ca = 1u, cb = 1u;
-                if (va) ca = atomicCAS(&tcnt[sa], 0u, WLOCK);
-                if (vb) cb = atomicCAS(&tcnt[sb], 0u, WLOCK);
-                // follow one key up from the result of its first probe (c: what the CAS returned at `slot`)
-                // The loop runs until the whole wave is done (ballot): a lane that leaves a loop early waits at
-                // the exit for the others, and code on an exit path -- a `break` after the publish -- runs only
-                // then, so a lane spinning on a lock its neighbour holds would spin for ever.  Here the publish
-                // sits inside an iteration every lane completes.
-                auto follow = [&](const uint64_t w0, const uint64_t w1, uint32_t slot, uint32_t c, bool active) __attribute__((always_inline)) {
-                    int probe = 0;
-                    bool done = !active;
-                    while (__ballot(!done)) {
-                        if (!done) {
-                            if (c == 0u) {                              // claimed: write the key, publish count 1
-                                thi[slot] = w0; tlo[slot] = w1;
-                                __threadfence_block();
-                                atomicExch(&tcnt[slot], 1u);
-                                done = true;
-                            } else if (c != WLOCK) {
-                                if (thi[slot] == w0 && tlo[slot] == w1) { atomicAdd(&tcnt[slot], 1u); done = true; }
-                                else {
-                                    slot = (slot + 1) & (WCAP - 1);
-                                    if (++probe >= LPROBE) { overflow = 1; done = true; }
-                                }
+                const bool h = v && c != 0u && c != WLOCK;
+                const uint64_t t0 = h ? thi[slot] : 0, t1 = h ? tlo[slot] : 0;
+                const bool hit = h && t0 == w0 && t1 == w1;
+                if (hit) atomicAdd(&tcnt[slot], 1u);
+                int probe = 0;
+                bool done = !v || c == 0u || hit;
+                while (__ballot(!done)) {
+                    if (!done) {
+                        if (c == 0u) {
+                            thi[slot] = w0; tlo[slot] = w1;
+                            __threadfence_block();
+                            atomicExch(&tcnt[slot], 1u);
+                            done = true;
+                        } else if (c != WLOCK) {
+                            if (thi[slot] == w0 && tlo[slot] == w1) { atomicAdd(&tcnt[slot], 1u); done = true; }
+                            else {
+                                slot = (slot + 1) & (WCAP - 1);
+                                if (++probe >= LPROBE) { overflow = 1; done = true; }
                             }
-                            if (!done) c = atomicCAS(&tcnt[slot], 0u, WLOCK);   // next slot, or the same one while it is being written
                         }
+                        if (!done) c = atomicCAS(&tcnt[slot], 0u, WLOCK);   // next slot, or the same one while it is being written
                     }
-                };
-                // A slot claimed by a first probe is published BEFORE anyone waits for anything: a lane that waited
-                // in follow(a) for a slot its neighbour claimed for key b would wait for ever (the neighbour cannot
-                // reach its own follow(b) before the wave's follow(a) has ended).
-                if (va && ca == 0u) { thi[sa] = a0; tlo[sa] = a1; }
-                if (vb && cb == 0u) { thi[sb] = b0; tlo[sb] = b1; }
-                __threadfence_block();
-                if (va && ca == 0u) atomicExch(&tcnt[sa], 1u);
-                if (vb && cb == 0u) atomicExch(&tcnt[sb], 1u);
-                // nine in ten first probes meet the key itself: compare both keys' slots in one go
-                const bool ha = va && ca != 0u && ca != WLOCK, hb = vb && cb != 0u && cb != WLOCK;
-                const uint64_t ta0 = ha ? thi[sa] : 0, ta1 = ha ? tlo[sa] : 0;
-                const uint64_t tb0 = hb ? thi[sb] : 0, tb1 = hb ? tlo[sb] : 0;
-                const bool ma = ha && ta0 == a0 && ta1 == a1, mb = hb && tb0 == b0 && tb1 == b1;
-                if (ma) atomicAdd(&tcnt[sa], 1u);
-                if (mb) atomicAdd(&tcnt[sb], 1u);
-                follow(a0, a1, sa, ca, va && ca != 0u && !ma);
-                follow(b0, b1, sb, cb, vb && cb != 0u && !mb);
+                }
             };
             if constexpr (RECS) {
                 // every wave takes an equal contiguous share of the leaf, 64 records at a time: the records go
@@ -1111,7 +1093,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                         const bool va = ja < total;
                         uint64_t a0, a1;
                         kmer_at_pos(va ? ja : 0, &a0, &a1);
-                        insert2(a0, a1, va, 0, 0, false);
+                        insert1(a0, a1, va);
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -1119,7 +1101,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                 for (uint64_t i = begin + threadIdx.x; i < end; i += WLT) {
                     if (__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
                     const Rec e = elems[i];
-                    insert2(e.w0, e.w1, true, 0, 0, false);
+                    insert1(e.w0, e.w1, true);
                 }
             }
             __syncthreads();

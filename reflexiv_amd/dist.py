@@ -91,7 +91,9 @@ class HipEngine:
                 cap = min(n, cap * 4)
 
     def _use_records(self, k):
-        return self.records and 21 <= k <= 31
+        import os
+        # (RFX_SUPERKMER=0 is the library's ablation knob for the record path: follow it)
+        return self.records and 21 <= k <= 31 and os.environ.get("RFX_SUPERKMER", "1") != "0"
 
     def bucket_by_owner(self, reads, n_owners):
         """reads = dict(words=int64 cuda tensor, n_reads, wpr, read_len, k) ->

@@ -60,9 +60,13 @@ def parse():
                     help="run the multi-GPU code path (owner buckets, RCCL all-to-all, gather) even with one rank")
     ap.add_argument("--exchange-chunks", type=int, default=4,
                     help="N > 1: read chunks whose all-to-all overlaps the bucketing of the next chunk (1 = no overlap)")
-    ap.add_argument("--exchange", choices=["pairs", "records"], default="pairs",
+    ap.add_argument("--exchange", choices=["auto", "pairs", "records"], default="auto",
                     help="N > 1, k <= 31: what crosses the all-to-all -- (k-mer, local count) pairs after a local combine "
-                         "(reduceByKey's map-side combine; fewest bytes at high coverage) or super-k-mer records")
+                         "(reduceByKey's map-side combine: fewer bytes at high coverage, the local count hides the flight) or "
+                         "super-k-mer records in --generations of the hash space (less compute; the count of one generation "
+                         "hides the flight of the next).  auto: records from 8 GPUs on (a peer's share per link is small), "
+                         "pairs below")
+    ap.add_argument("--generations", type=int, default=4, help="--exchange records: generations of the hash space")
     return ap.parse_args()
 
 
@@ -138,11 +142,17 @@ def main():
     d_keys = torch.empty(cap * W, dtype=torch.int64, device=dev)
     d_counts = torch.empty(cap, dtype=torch.int64 if wide else torch.int32, device=dev)
     reads = dict(words=d_words, n_reads=n_reads, wpr=wpr, read_len=L, k=k)
+    if args.exchange == "auto":
+        args.exchange = "records" if world >= 8 else "pairs"
     engine = rd.HipEngine(rfx, combine=args.exchange == "pairs" and not wide)
     engine.force_exchange = args.force_dist
     timing_acc = {}
 
     shard = {}
+    # enough chunks that no per-peer message needs the staged rounds of dist._alltoallv (512 MiB cap);
+    # pairs: 16 B per distinct k-mer of a chunk, ~1.5 B per instance on this workload
+    per_inst = (5.6 if engine.wide_records else 16.0) if wide else 2.0 if engine.combine else 2.7
+    est_chunks = per_inst * n_inst / world / rd.A2A_LIMIT_BYTES
 
     def step():
         if wide and not multi:
@@ -152,14 +162,12 @@ def main():
             m, nd, inst = rfx.count_reads_dev(d_words.data_ptr(), n_reads, wpr, L, k, d_keys.data_ptr(),
                                               d_counts.data_ptr(), cap, args.cover)
             return m, nd, inst
-        # enough chunks that no per-peer message needs the staged rounds of dist._alltoallv (512 MiB cap)
-        # (k <= 31: ~2.7 B of super-k-mer record per instance; k > 31: one 16-byte element per instance)
-        # pairs: 16 B per distinct k-mer of a chunk, ~1.5 B per instance on this workload (a larger
-        # message is still exchanged correctly, in rounds)
-        per_inst = (5.6 if engine.wide_records else 16.0) if wide else 2.0 if engine.combine else 2.7
-        est = per_inst * n_inst / world / rd.A2A_LIMIT_BYTES
+        est = est_chunks
         chunks = max(args.exchange_chunks, int(est) + 1)
-        keys, counts, tot = rd.sharded_count(engine, reads, args.cover, 10_000_000, 0, chunks=chunks)
+        gens = args.generations if (args.exchange == "records" and not wide) else 1
+        while gens > 1 and world * gens > 64:
+            gens //= 2
+        keys, counts, tot = rd.sharded_count(engine, reads, args.cover, 10_000_000, 0, chunks=chunks, generations=gens)
         shard["keys"], shard["counts"] = keys, counts
         return tot[2], tot[1], tot[0] // world
 
@@ -172,6 +180,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
+    engine.bucketed_bytes = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         engine.timing.clear()
@@ -217,11 +226,19 @@ def main():
                    "parallelism": "1 GPU" if not multi else f"k-mer space radix-sharded over {world} GPUs, "
                                                                "RCCL all-to-all(v) of " +
                                                                ("32-byte super-k-mer records of two-word k-mers" if wide else "(k-mer, local count) pairs"
-                                                                if engine.combine else "super-k-mer records")},
+                                                                if engine.combine else f"super-k-mer records, {args.generations} generations")},
         "roofline": roofline,
         "stage_hbm_frac": (((0.25 + 16 * W) * n_inst + (8 * W + 4) * m) / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS) if not multi else None,
     }
 
+    if multi:
+        # what crosses the all-to-all: every rank buckets B bytes per step and keeps 1/N of them; each
+        # peer's share travels over its own xGMI link (7 links x ~153 GB/s per GPU, MI355X_MICROARCH.md)
+        B = engine.bucketed_bytes / args.steps
+        out["exchange"] = {"unit": out["config"]["parallelism"].split(" of ")[-1], "bytes_bucketed_per_gpu_per_step": B,
+                           "bytes_per_instance": B / n_inst, "bytes_leaving_per_gpu_per_step": B * (world - 1) / world,
+                           "per_link_floor_ms_at_153GBps": B / world / 153e9 * 1e3 if world > 1 else 0.0,
+                           "chunks": max(args.exchange_chunks, int(est_chunks) + 1)}
     if multi and not args.no_contigs:
         # the filtered list is small: gather it on rank 0, restore ascending k-mer order there
         # and run the extend stage on that one GPU

@@ -31,6 +31,23 @@ class HipEngine:
         self.width = 1            # int64 words per exchanged unit
         self.timing = {}          # kernel family -> [ms, launches] over every library call since the last reset
 
+    def hint_instances(self, n):
+        self._inst_acc = int(n)
+
+    def generations_ok(self, reads):
+        return reads["k"] <= 31 and not self.combine
+
+    def merge_sorted(self, keys_l, counts_l):
+        """ascending shards of disjoint k-mer sets -> one ascending shard (k <= 31)"""
+        keys, counts = torch.cat(keys_l), torch.cat(counts_l)
+        m = int(keys.numel())
+        if len(keys_l) > 1 and m > 1:
+            tk, tc = torch.empty_like(keys), torch.empty_like(counts)
+            torch.cuda.current_stream().synchronize()
+            self.rfx.sort_pairs_dev(keys.data_ptr(), counts.data_ptr(), m, 2 * self.k, tk.data_ptr(), tc.data_ptr())
+            self.rfx.sync()
+        return keys, counts
+
     def _take_hint(self):
         h, self._inst_acc = int(getattr(self, "_inst_acc", 0) or 0), 0
         return h
@@ -225,6 +242,7 @@ class HipEngine:
             return self._merge_pairs(kmers, min_cov, max_cov, twin)
         n = int(kmers.numel()) // self.width
         recs = self.width == 2
+        hint31 = self._take_hint() if recs else 0
         n_inst = n * 6 if recs else n
         cap = max(1 << 20, n_inst // 8)         # survivors are few; grow on RFX_E_CAP
         while True:
@@ -233,7 +251,7 @@ class HipEngine:
             torch.cuda.current_stream().synchronize()
             try:
                 if recs:
-                    m, d = self.rfx.count_records_dev(kmers.data_ptr(), n, 0, self.k, keys.data_ptr(),
+                    m, d = self.rfx.count_records_dev(kmers.data_ptr(), n, hint31, self.k, keys.data_ptr(),
                                                       counts.data_ptr(), cap, min_cov, max_cov, twin)
                 else:
                     m, d = self.rfx.count_kmers_dev(kmers.data_ptr(), n, keys.data_ptr(), counts.data_ptr(), cap,
@@ -254,20 +272,26 @@ class HipEngine:
 A2A_LIMIT_BYTES = 1 << 29      # per peer per call (512 MiB)
 
 
-def _alltoallv(send: torch.Tensor, send_counts, group=None, async_op: bool = False, limit: int = None, out=None):
+def _alltoallv(send: torch.Tensor, send_counts, group=None, async_op: bool = False, limit: int = None, out=None,
+               recv_counts=None, rounds: int = None):
     """all-to-all(v) of `send` (bucket d = send_counts[d] elements, buckets back to back) ->
     (recv, [work handles]); recv holds source 0's bucket, then source 1's, ...  Per-peer messages are
-    capped at `limit` elements per call (default: A2A_LIMIT_BYTES)."""
+    capped at `limit` elements per call (default: A2A_LIMIT_BYTES).  recv_counts / rounds: already
+    agreed by the caller (no handshake, no host synchronisation before the data moves)."""
     limit = limit or max(1, A2A_LIMIT_BYTES // send.element_size())
     world = dist.get_world_size(group)
     send_counts = [int(x) for x in send_counts]
-    sc = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
-    rc = torch.empty_like(sc)
-    dist.all_to_all_single(rc, sc, group=group)
-    recv_counts = [int(x) for x in rc.cpu()]
-    mx = torch.tensor([max(send_counts + recv_counts + [0])], dtype=torch.int64, device=send.device)
-    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
-    rounds = max(1, -(-int(mx.item()) // limit))
+    if recv_counts is None:
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=group)
+        recv_counts = [int(x) for x in rc.cpu()]
+    else:
+        recv_counts = [int(x) for x in recv_counts]
+    if rounds is None:
+        mx = torch.tensor([max(send_counts + recv_counts + [0])], dtype=torch.int64, device=send.device)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+        rounds = max(1, -(-int(mx.item()) // limit))
     need = sum(recv_counts)
     # `out` (optional): a caller-owned buffer whose head receives the data when it is large enough
     recv = out[:need] if out is not None and out.numel() >= need else torch.empty(need, dtype=send.dtype, device=send.device)
@@ -313,13 +337,62 @@ def exchange_by_owner_async(kmers: torch.Tensor, owner_off: torch.Tensor, group=
     return _alltoallv(kmers, send_counts.tolist(), group, async_op=True, out=out)
 
 
-def sharded_count(engine, reads, min_cov, max_cov, twin, group=None, chunks: int = 1):
+def _sharded_count_generations(engine, reads, min_cov, max_cov, twin, group, world, G):
+    """The hash space in G generations: the reads are bucketed ONCE by (generation, owner) -- bin g*world + o
+    of an owner function over G*world bins -- the G all-to-alls are launched back to back, and generation g
+    is counted while g+1.. are still travelling (a k-mer lives in exactly one generation, so the G counts
+    are independent).  The pipeline for a link-bound exchange: after the first generation has arrived the
+    step is bound by max(exchange, count) instead of their sum."""
+    km, off = engine.bucket_by_owner(reads, world * G)
+    width = getattr(engine, "width", 1)
+    engine.bucketed_bytes = getattr(engine, "bucketed_bytes", 0) + int(km.numel()) * km.element_size()
+    n_inst = getattr(engine, "n_instances", None)
+    off = off.to(torch.int64)
+    per = (off[1:] - off[:-1]).reshape(G, world)                      # [g, dest] units
+    dev = km.device
+    sc = (per.t().contiguous() * width).to(dev)                       # [dest, g] words: G numbers for every peer
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc.view(-1), sc.view(-1), group=group)                    # one handshake for all generations
+    rc = rc.cpu().reshape(world, G)                                    # [src, g] words coming from every peer
+    sc = sc.cpu()
+    limit = max(1, A2A_LIMIT_BYTES // km.element_size())
+    mx = torch.tensor([int(max(int(sc.max()) if sc.numel() else 0, int(rc.max()) if rc.numel() else 0))],
+                      dtype=torch.int64, device=dev)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    rounds = max(1, -(-int(mx.item()) // limit))
+    recvs, works = [], []
+    for g in range(G):
+        a, b = int(off[g * world]) * width, int(off[(g + 1) * world]) * width
+        r, w = _alltoallv(km[a:b], sc[:, g].tolist(), group, async_op=True, recv_counts=rc[:, g].tolist(), rounds=rounds)
+        recvs.append(r); works.append(w)
+    keys_l, counts_l, distinct = [], [], 0
+    for g in range(G):
+        for w in works[g]:
+            w.wait()
+        if hasattr(engine, "hint_instances") and n_inst:
+            engine.hint_instances(int(n_inst) // G)
+        k_, c_, d_ = engine.count_kmers(recvs[g], min_cov, max_cov, twin)
+        keys_l.append(k_); counts_l.append(c_); distinct += int(d_)
+        recvs[g] = None
+    keys, counts = engine.merge_sorted(keys_l, counts_l)
+    tot = torch.tensor([int(km.numel()) if n_inst is None or width == 1 else int(n_inst), distinct, int(counts.numel())],
+                       dtype=torch.int64, device=keys.device)
+    if world > 1:
+        dist.all_reduce(tot, group=group)
+    return keys, counts, [int(x) for x in tot.cpu()]
+
+
+def sharded_count(engine, reads, min_cov, max_cov, twin, group=None, chunks: int = 1, generations: int = 1):
     """-> (keys, counts) of this rank's shard (ascending), global (instances, distinct, survivors).
     chunks > 1 (and an engine that can split its reads): the reads are bucketed chunk by chunk and
-    chunk c travels while chunk c+1 is bucketed; counting starts when everything has arrived."""
+    chunk c travels while chunk c+1 is bucketed; counting starts when everything has arrived.
+    generations > 1 (engines with `merge_sorted`): see _sharded_count_generations."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     width = None
     exchange = world > 1 or (dist.is_initialized() and bool(getattr(engine, "force_exchange", False)))   # (tests: 1-rank RCCL)
+    if (exchange and generations > 1 and hasattr(engine, "merge_sorted") and world * generations <= 64
+            and getattr(engine, "generations_ok", lambda r: True)(reads)):
+        return _sharded_count_generations(engine, reads, min_cov, max_cov, twin, group, world, generations)
     if exchange and chunks > 1 and hasattr(engine, "split_reads"):
         parts, sent, n_inst_total, pending = [], 0, 0, []
         subs = engine.split_reads(reads, chunks)
@@ -333,6 +406,7 @@ def sharded_count(engine, reads, min_cov, max_cov, twin, group=None, chunks: int
             if big is None and est:
                 big = torch.empty(int(est * width * 1.1) + 4096, dtype=km.dtype, device=km.device)
             sent += int(km.numel())
+            engine.bucketed_bytes = getattr(engine, "bucketed_bytes", 0) + int(km.numel()) * km.element_size()
             n_inst_total += int(getattr(engine, "n_instances", 0) or 0)
             recv_c, works = exchange_by_owner_async(km, off, group, width, out=None if big is None else big[pos:])
             if big is not None and recv_c.numel() and recv_c.data_ptr() == big[pos:].data_ptr():
@@ -349,6 +423,7 @@ def sharded_count(engine, reads, min_cov, max_cov, twin, group=None, chunks: int
         kmers_numel, n_inst = sent, (n_inst_total if width != 1 else None)
     else:
         kmers, owner_off = engine.bucket_by_owner(reads, world)
+        engine.bucketed_bytes = getattr(engine, "bucketed_bytes", 0) + int(kmers.numel()) * kmers.element_size()
         width = getattr(engine, "width", 1)
         recv = exchange_by_owner(kmers, owner_off, group, width) if exchange else kmers
         kmers_numel, n_inst = int(kmers.numel()), getattr(engine, "n_instances", None)

@@ -83,6 +83,11 @@ class OracleEngine:
         k, c, d = O.count_filter(kmers.numpy().view(np.uint64), min_cov, max_cov, twin)
         return torch.from_numpy(k.view(np.int64)), torch.from_numpy(c), d
 
+    def merge_sorted(self, keys_l, counts_l):
+        k = np.concatenate([x.numpy() for x in keys_l]).view(np.uint64); c = np.concatenate([x.numpy() for x in counts_l])
+        o = np.argsort(k, kind="stable")
+        return torch.from_numpy(k[o].view(np.int64)), torch.from_numpy(c[o])
+
     def split_reads(self, reads, chunks):
         off = reads["read_off"]
         n = len(off) - 1
@@ -122,7 +127,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q, chunks=1, limit_bytes=None, combine=False):
+def _worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q, chunks=1, limit_bytes=None, combine=False, generations=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -133,7 +138,7 @@ def _worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q, chunks=1, li
         bases, off = O.synth_reads(seed, g, G, rank * per_rank, per_rank, L)    # this rank's read shard
         reads = dict(bases=bases, read_off=off, k=k)
         engine = OracleCombineEngine() if combine else OracleEngine()
-        keys, counts, tot = rd.sharded_count(engine, reads, min_cov, 10_000_000, O.TWIN_DS, chunks=chunks)
+        keys, counts, tot = rd.sharded_count(engine, reads, min_cov, 10_000_000, O.TWIN_DS, chunks=chunks, generations=generations)
         allk, allc = rd.gather_survivors(keys, counts)
         if rank == 0:
             q.put(("root", allk.numpy().view(np.uint64).copy(), allc.numpy().copy(), None))
@@ -147,13 +152,20 @@ def _worker(rank, world, port, seed, G, per_rank, L, k, min_cov, q, chunks=1, li
 
 @pytest.mark.parametrize("world,chunks,limit_bytes,combine", [(2, 1, None, False), (3, 1, None, False), (2, 4, None, False),
                                                               (3, 3, None, False), (2, 1, 40_000, False), (3, 2, 24_000, False),
-                                                              (2, 1, None, True), (3, 3, None, True), (2, 2, 24_000, True)])
+                                                              (2, 1, None, True), (3, 3, None, True), (2, 2, 24_000, True),
+                                                              (2, -4, None, False), (3, -3, None, False), (2, -2, 9_000, False)])
 def test_sharded_count_equals_global_count(world, chunks, limit_bytes, combine):
+    """chunks < 0: -chunks GENERATIONS of the hash space instead (bucketed once by (generation, owner), the
+    all-to-alls launched back to back, generation g counted while the later ones travel)."""
+    generations = 1
+    if chunks < 0:
+        generations, chunks = -chunks, 1
     seed, G, per_rank, L, k, min_cov = 42, 20_000, 1500, 100, 31, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, G, per_rank, L, k, min_cov, q, chunks, limit_bytes, combine))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, G, per_rank, L, k, min_cov, q, chunks, limit_bytes, combine,
+                                               generations))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -174,7 +186,7 @@ def test_sharded_count_equals_global_count(world, chunks, limit_bytes, combine):
     allk = np.concatenate([r[1] for r in res]); allc = np.concatenate([r[2] for r in res])
     for rank, kk, cc, _ in res:
         assert np.all(kk[1:] > kk[:-1])
-        assert np.all(owner_of(kk, world) == rank)
+        assert np.all(owner_of(kk, world * generations) % world == rank)       # bin g * world + o of an owner function over G * world bins
     order = np.argsort(allk, kind="stable")
     assert np.array_equal(allk[order], wk) and np.array_equal(allc[order], wc)
     # the root's gathered list is the same multiset, in rank order

@@ -972,10 +972,11 @@ def test_sharded_count_through_rccl_one_rank(rfx, torch_mod):
         dk = torch.empty(N, dtype=torch.int64, device="cuda"); dc = torch.empty(N, dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, 3)
-        for chunks, combine in ((1, False), (4, False), (1, True), (3, True)):
+        for chunks, combine in ((1, False), (4, False), (1, True), (3, True), (-4, False), (-16, False)):
             eng = rd.HipEngine(rfx, combine=combine)
             eng.force_exchange = True
-            keys, counts, tot = rd.sharded_count(eng, reads, 3, 10_000_000, 0, chunks=chunks)
+            gens = -chunks if chunks < 0 else 1            # chunks < 0: generations of the hash space instead
+            keys, counts, tot = rd.sharded_count(eng, reads, 3, 10_000_000, 0, chunks=max(1, chunks), generations=gens)
             assert tot == [N, nd, m]
             # one owner: the shard is everything, but in hash-leaf order -> compare as sorted sets
             o = torch.argsort(keys)

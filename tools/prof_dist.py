@@ -49,8 +49,8 @@ def _timed_exchange(*x, **kw):
     return r
 rd.exchange_by_owner_async = _timed_exchange
 
-for combine in (False, True):
-    eng = rd.HipEngine(rfx, combine=combine); eng.force_exchange = True
+for combine in (False, True, "gen"):
+    eng = rd.HipEngine(rfx, combine=combine is True); eng.force_exchange = True
     acc = {}
     timed(eng, "bucket_by_owner", acc); timed(eng, "count_kmers", acc)
     for name in ("combine_reads_dev", "bucket_pairs_by_owner_dev", "merge_pairs_dev", "bucket_records_by_owner_dev", "count_records_dev"):
@@ -58,9 +58,9 @@ for combine in (False, True):
     for step in range(a.steps):
         acc.clear(); xacc.clear()
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        keys, counts, tot = rd.sharded_count(eng, reads, a.cover, 10_000_000, 0, chunks=a.chunks)
+        keys, counts, tot = rd.sharded_count(eng, reads, a.cover, 10_000_000, 0, chunks=a.chunks, generations=4 if combine == 'gen' else 1)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
-        print(f"{'pairs  ' if combine else 'records'} step {step}: {dt:7.1f} ms  tot={tot}  " +
+        print(f"{'rec-gen' if combine == 'gen' else 'pairs  ' if combine else 'records'} step {step}: {dt:7.1f} ms  tot={tot}  " +
               "  ".join(f"{k}={v:.1f}" for k, v in sorted(list(acc.items()) + list(xacc.items()))), flush=True)
     del eng, keys, counts
     torch.cuda.empty_cache()

@@ -238,7 +238,7 @@ def main():
         out["exchange"] = {"unit": out["config"]["parallelism"].split(" of ")[-1], "bytes_bucketed_per_gpu_per_step": B,
                            "bytes_per_instance": B / n_inst, "bytes_leaving_per_gpu_per_step": B * (world - 1) / world,
                            "per_link_floor_ms_at_153GBps": B / world / 153e9 * 1e3 if world > 1 else 0.0,
-                           "chunks": max(args.exchange_chunks, int(est_chunks) + 1)}
+                           "chunks": 1 if (args.exchange == "records" and not wide) else max(args.exchange_chunks, int(est_chunks) + 1)}
     if multi and not args.no_contigs:
         # the filtered list is small: gather it on rank 0, restore ascending k-mer order there
         # and run the extend stage on that one GPU

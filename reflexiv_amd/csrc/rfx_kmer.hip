@@ -531,7 +531,7 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<ELEM>
                                                    int min_cov, int max_cov, int apply_filter,
                                                    uint64_t *__restrict__ out_keys, int32_t *__restrict__ out_counts,
                                                    unsigned long long cap, CountOut *__restrict__ co, int dbg,
-                                                   int pair_out) {
+                                                   int pair_out, uint32_t presplit) {
     constexpr bool RECS = ELEM == 1;
     __shared__ __attribute__((aligned(16))) unsigned long long tkey[LCAP];
     __shared__ __attribute__((aligned(16))) uint32_t tcnt[LCAP];
@@ -844,6 +844,14 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<ELEM>
         // stack is empty between leaves).
         uint32_t S = 1, s = 0;
         bool first = true;
+        // a leaf with this many elements will not fit one table: start it in 2, 4, ... hash-selected parts
+        // instead of finding that out from an abandoned pass (uniform: the bounds come from leaf_off)
+        if (presplit && end - begin > (uint64_t)presplit) {
+            while (end - begin > (uint64_t)presplit * S && S < 16) S *= 2;
+            __syncthreads();
+            if (threadIdx.x == 0) for (uint32_t q = S - 1; q >= 1; q--) { stackS[sp] = S; stacks[sp] = q; sp++; }
+            __syncthreads();
+        }
         while (true) {
             run_pass(S, s, first, begin_next, end_next);        // (an empty leaf still hands the prefetch chain on)
             first = false;
@@ -1977,6 +1985,9 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
         if (sscanf(e, "%llu,%llu,%llu", &a, &b, &c) == 3 && a && b && c) { heavy = a; slice = b; pcap_min = c; }
     }
     const int dbg = getenv("RFX_LEAF_DBG") ? atoi(getenv("RFX_LEAF_DBG")) : 0;
+    // records beyond which a leaf starts in 2, 4, .. parts (a record holds ~0.5 distinct k-mers at high coverage,
+    // a table takes ~3300 keys before probe sequences run long); measured neutral for pairs and not used there
+    const uint32_t presplit = getenv("RFX_PRESPLIT") ? (uint32_t)atoi(getenv("RFX_PRESPLIT")) : ELEM == 1 ? 6000u : 0u;
     DevBuf nsl, spos;
     RFX_HIP(nsl.alloc((size_t)nleaf * 8, ctx->stream));
     RFX_HIP(spos.alloc((size_t)(nleaf + 1) * 8, ctx->stream));
@@ -1992,7 +2003,7 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
         hipLaunchKernelGGL(k_leaf_count<ELEM>, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, elems, d_leaf_off, nleaf,
                            (const uint64_t *)nullptr, (const uint64_t *)nullptr, heavy, (uint64_t)elem_count, k, min_cov,
                            max_cov, apply, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>(), dbg,
-                           (int)pair_out);
+                           (int)pair_out, presplit);
         RFX_HIP(hipGetLastError());
     }
     RFX_HIP(hipStreamSynchronize(ctx->stream));
@@ -2017,7 +2028,7 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
                 hipLaunchKernelGGL(k_leaf_count<ELEM>, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, elems, d_leaf_off,
                                    (int64_t)n_slices, (const uint64_t *)sb.as<uint64_t>(), (const uint64_t *)se.as<uint64_t>(),
                                    (uint64_t)0, (uint64_t)elem_count, k, min_cov, max_cov, 0, pk.as<uint64_t>(),
-                                   pc.as<int32_t>(), (unsigned long long)pcap, co2.as<CountOut>(), dbg, 0);
+                                   pc.as<int32_t>(), (unsigned long long)pcap, co2.as<CountOut>(), dbg, 0, 0u);
                 RFX_HIP(hipGetLastError());
             }
             RFX_HIP(hipMemcpyAsync(&c2, co2.p, sizeof c2, hipMemcpyDeviceToHost, ctx->stream));

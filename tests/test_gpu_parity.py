@@ -496,11 +496,13 @@ def test_deep_coverage_recovers_exactly_the_genome_kmers(rfx, torch_mod):
     assert int(dc[:m].min()) >= 10
 
 
-def test_bucket_records_by_owner_then_count(rfx, torch_mod):
-    """multi-GPU record path on one GPU: super-k-mer records bucketed by owner; counting every
-    owner's bucket on its own gives disjoint shards whose union is the oracle's global count."""
+@pytest.mark.parametrize("k,owners", [(31, 4), (31, 32), (31, 64), (25, 3), (21, 24)])
+def test_bucket_records_by_owner_then_count(rfx, torch_mod, k, owners):
+    """multi-GPU record path on one GPU: super-k-mer records bucketed by owner (up to the 64 bins that 8 GPUs x 8
+    generations use); counting every owner's bucket on its own gives disjoint shards whose union is the
+    oracle's global count."""
     torch = torch_mod
-    seed, G, n_reads, L, k, owners = 8, 150_000, 40_000, 150, 31, 4
+    seed, G, n_reads, L = 8, 150_000, 40_000, 150
     dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
     doff = torch.empty(owners + 1, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()

@@ -150,8 +150,8 @@ def main():
 
     shard = {}
     # enough chunks that no per-peer message needs the staged rounds of dist._alltoallv (512 MiB cap);
-    # pairs: 16 B per distinct k-mer of a chunk, ~1.5 B per instance on this workload
-    per_inst = (5.6 if engine.wide_records else 16.0) if wide else 2.0 if engine.combine else 2.7
+    # pairs: 16 B per distinct k-mer of a chunk: 1.4 B per instance unchunked, 2.3 B in 8 chunks on this workload
+    per_inst = (5.6 if engine.wide_records else 16.0) if wide else 2.6 if engine.combine else 2.7
     est_chunks = per_inst * n_inst / world / rd.A2A_LIMIT_BYTES
 
     def step():

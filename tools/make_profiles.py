@@ -21,9 +21,10 @@ def main():
     dst = os.path.join(ROOT, "profiles")
     bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
     # kernel stats of the bench command
-    stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    # (gpurun merges new files into gpurun_out/ without deleting older runs' files: take the newest)
+    stats = sorted(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     assert stats, "no kernel_stats.csv"
-    rows = list(csv.DictReader(open(stats[0])))
+    rows = list(csv.DictReader(open(stats[-1])))
     with open(os.path.join(dst, tag + "_bench_kernel_stats.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=rows[0].keys())
         w.writeheader()
@@ -33,7 +34,8 @@ def main():
     launches = collections.defaultdict(lambda: collections.defaultdict(int))
     pmc_rows = []
     for which in ("fetch", "write"):
-        for fn in glob.glob(os.path.join(src, which, "**", "*counter_collection.csv"), recursive=True):
+        for fn in sorted(glob.glob(os.path.join(src, which, "**", "*counter_collection.csv"), recursive=True),
+                         key=os.path.getmtime)[-1:]:
             for r in csv.DictReader(open(fn)):
                 name = r["Kernel_Name"]
                 for fam, key in FAMILY:

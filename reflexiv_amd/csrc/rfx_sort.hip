@@ -107,9 +107,10 @@ __global__ __launch_bounds__(ST) void k_scatter(const uint64_t *__restrict__ key
     }
 }
 
-// One workgroup sorts up to STILE pairs entirely on chip (all passes), stable.
-__global__ __launch_bounds__(ST) void k_sort_small(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                   int n, int passes) {
+// One workgroup sorts up to STILE pairs entirely on chip (all passes), stable: (ikeys, ivals)[0..n) ->
+// (okeys, ovals)[0..n), in place when they are the same arrays.
+__device__ __forceinline__ void sort_tile_lds(const uint64_t *keys, const uint32_t *vals, int n, int passes,
+                                              uint64_t *okeys, uint32_t *ovals) {
     __shared__ uint64_t sk[2][STILE];
     __shared__ uint32_t sv[2][STILE];
     __shared__ volatile uint32_t wcnt[SW][256];
@@ -163,7 +164,39 @@ __global__ __launch_bounds__(ST) void k_sort_small(uint64_t *__restrict__ keys, 
         __syncthreads();
         cur ^= 1;
     }
-    for (int i = threadIdx.x; i < n; i += ST) { keys[i] = sk[cur][i]; vals[i] = sv[cur][i]; }
+    for (int i = threadIdx.x; i < n; i += ST) { okeys[i] = sk[cur][i]; ovals[i] = sv[cur][i]; }
+}
+
+__global__ __launch_bounds__(ST) void k_sort_small(uint64_t *keys, uint32_t *vals, int n, int passes) {
+    sort_tile_lds(keys, vals, n, passes, keys, vals);
+}
+
+// ---- mid-size inputs (a few tiles .. ~400 K pairs): ONE global pass on the TOP digit, then every digit's
+// bucket (<= one tile when the keys are spread) is finished on chip -- 4 launches instead of 16.
+// bstart[d] = first position of top digit d (bstart[256] = n); *maxc = the largest bucket
+__global__ __launch_bounds__(256) void k_bucket_bounds(const uint32_t *__restrict__ table, int64_t ntiles,
+                                                       uint32_t *__restrict__ bstart, uint32_t *__restrict__ maxc) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t mx;
+    if (threadIdx.x == 0) mx = 0;
+    uint32_t c = 0;
+    for (int64_t t = 0; t < ntiles; t++) c += table[(int64_t)threadIdx.x * ntiles + t];
+    uint32_t tot = 0;
+    const uint32_t ex = rfxd::block_exclusive_scan(c, wsum, &tot);
+    bstart[threadIdx.x] = ex;
+    if (threadIdx.x == 0) bstart[256] = tot;
+    __syncthreads();
+    atomicMax(&mx, c);
+    __syncthreads();
+    if (threadIdx.x == 0) *maxc = mx;
+}
+
+__global__ __launch_bounds__(ST) void k_sort_buckets(const uint64_t *__restrict__ ikeys, const uint32_t *__restrict__ ivals,
+                                                     const uint32_t *__restrict__ bstart, int passes,
+                                                     uint64_t *__restrict__ okeys, uint32_t *__restrict__ ovals) {
+    const uint32_t b = bstart[blockIdx.x], e = bstart[blockIdx.x + 1];
+    if (e <= b) return;                              // (uniform)
+    sort_tile_lds(ikeys + b, ivals + b, (int)(e - b), passes, okeys + b, ovals + b);
 }
 
 }  // namespace
@@ -188,6 +221,33 @@ int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int 
     uint64_t *sk = d_keys, *dk = d_tmp_keys;
     uint32_t *sv = d_vals, *dv = d_tmp_vals;
     const bool inline_scan = ntiles <= 64;           // <= 128 K pairs
+    static const bool msd_off = getenv("RFX_SORT_MSD") && atoi(getenv("RFX_SORT_MSD")) == 0;
+    if (ntiles <= 192 && key_bits > 8 && !msd_off) {
+        // top digit first; the 4-byte readback decides (a bucket larger than a tile -- skewed keys -- takes
+        // the LSD passes below instead)
+        const int shift = key_bits - 8;
+        DevBuf bounds;
+        RFX_HIP(bounds.alloc(258 * 4, ctx->stream));
+        hipLaunchKernelGGL(k_hist, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, n, shift, table.as<uint32_t>(), ntiles);
+        RFX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_bucket_bounds, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t *)table.as<uint32_t>(), ntiles,
+                           bounds.as<uint32_t>(), bounds.as<uint32_t>() + 257);
+        RFX_HIP(hipGetLastError());
+        uint32_t maxc = 0;
+        RFX_HIP(hipMemcpyAsync(&maxc, bounds.as<uint32_t>() + 257, 4, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        if (maxc <= (uint32_t)STILE) {
+            if (!inline_scan) RFX_TRY(exclusive_scan_u32_to_u64(ctx, table.as<uint32_t>(), offs.as<uint64_t>(), ntiles * 256));
+            hipLaunchKernelGGL(k_scatter, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, sv, n, shift,
+                               inline_scan ? (const uint64_t *)nullptr : (const uint64_t *)offs.as<uint64_t>(), ntiles, dk, dv,
+                               (const uint32_t *)table.as<uint32_t>());
+            RFX_HIP(hipGetLastError());
+            hipLaunchKernelGGL(k_sort_buckets, dim3(256), dim3(ST), 0, ctx->stream, (const uint64_t *)dk, (const uint32_t *)dv,
+                               (const uint32_t *)bounds.as<uint32_t>(), (shift + 7) / 8, d_keys, d_vals);
+            RFX_HIP(hipGetLastError());
+            return RFX_OK;
+        }
+    }
     for (int p = 0; p < passes; p++) {
         const int shift = 8 * p;
         hipLaunchKernelGGL(k_hist, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, n, shift,

@@ -391,6 +391,32 @@ def test_sort_pairs_is_stable(rfx, torch_mod):
         assert np.array_equal(dv.cpu().numpy().view(np.uint32), vals[order])
 
 
+def test_sort_pairs_top_digit_path_is_stable(rfx, torch_mod):
+    """2 K .. 400 K pairs whose top digit is spread take one global pass on that digit and finish the buckets
+    on chip; ties inside a bucket keep arrival order, odd key widths work, and one oversized bucket (skewed
+    keys) sends the call down the LSD passes."""
+    torch = torch_mod
+    rng = np.random.default_rng(31)
+    cases = []
+    for n, bits in ((2049, 60), (30_000, 60), (130_000, 62), (131_073, 60), (390_000, 64), (50_000, 13), (50_000, 9), (20_000, 37)):
+        top = rng.integers(0, 256, n, dtype=np.uint64) << np.uint64(max(0, bits - 8))
+        low = rng.integers(0, 1 << min(bits - 8, 4) if bits > 8 else 1, n, dtype=np.uint64)         # many ties inside a bucket
+        cases.append((n, bits, (top | low) & np.uint64((1 << bits) - 1 if bits < 64 else 0xFFFFFFFFFFFFFFFF)))
+        cases.append((n, bits, rng.integers(0, 1 << min(bits, 63), n, dtype=np.uint64)))              # spread keys, few ties
+    skew = rng.integers(0, 1 << 52, 100_000, dtype=np.uint64); skew[:3000] |= np.uint64(0xAB) << np.uint64(52)
+    cases.append((100_000, 60, skew))                                                                 # bucket 0 holds 97 000 pairs
+    for n, bits, keys in cases:
+        vals = np.arange(n, dtype=np.uint32)
+        dk = torch.from_numpy(keys.view(np.int64)).cuda(); dv = torch.from_numpy(vals.view(np.int32)).cuda()
+        tk = torch.empty_like(dk); tv = torch.empty_like(dv)
+        torch.cuda.synchronize()
+        rfx.sort_pairs_dev(dk.data_ptr(), dv.data_ptr(), n, bits, tk.data_ptr(), tv.data_ptr())
+        rfx.sync()
+        order = np.argsort(keys, kind="stable")
+        assert np.array_equal(dk.cpu().numpy().view(np.uint64), keys[order]), (n, bits)
+        assert np.array_equal(dv.cpu().numpy().view(np.uint32), vals[order]), (n, bits)
+
+
 # ------------------------------------------------ C++ host mirror of the reference driver
 
 def write_fastq(path, bases, read_off, gz=False):

@@ -992,25 +992,28 @@ def test_sharded_count_through_rccl_one_rank(rfx, torch_mod):
     if created:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        seed, G, n_reads, L, k = 23, 200_000, 100_000, 150, 31
+        seed, G, n_reads, L = 23, 200_000, 100_000, 150
         dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
         rfx.use_stream(torch.cuda.current_stream().cuda_stream)
-        reads = dict(words=dw, n_reads=n_reads, wpr=wpr, read_len=L, k=k)
-        N = rfx.kmers_per_read(L, k) * n_reads
-        dk = torch.empty(N, dtype=torch.int64, device="cuda"); dc = torch.empty(N, dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()
-        m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, 3)
-        for chunks, combine in ((1, False), (4, False), (1, True), (3, True), (-4, False), (-16, False)):
-            eng = rd.HipEngine(rfx, combine=combine)
-            eng.force_exchange = True
-            gens = -chunks if chunks < 0 else 1            # chunks < 0: generations of the hash space instead
-            keys, counts, tot = rd.sharded_count(eng, reads, 3, 10_000_000, 0, chunks=max(1, chunks), generations=gens)
-            assert tot == [N, nd, m]
-            # one owner: the shard is everything, but in hash-leaf order -> compare as sorted sets
-            o = torch.argsort(keys)
-            assert torch.equal(keys[o], dk[:m]) and torch.equal(counts[o], dc[:m])
-            gk, gc = rd.gather_survivors(keys, counts)
-            assert gk is keys or torch.equal(gk, keys)
+        # k = 31 / 24: super-k-mer records (or pairs) cross the exchange; k = 17: 8-byte k-mers (or pairs)
+        for k, forms in ((31, ((1, False), (4, False), (1, True), (3, True), (-4, False), (-16, False))),
+                         (24, ((2, False), (2, True), (-8, False))), (17, ((3, False), (2, True), (-4, False)))):
+            reads = dict(words=dw, n_reads=n_reads, wpr=wpr, read_len=L, k=k)
+            N = rfx.kmers_per_read(L, k) * n_reads
+            dk = torch.empty(N, dtype=torch.int64, device="cuda"); dc = torch.empty(N, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, 3)
+            for chunks, combine in forms:
+                eng = rd.HipEngine(rfx, combine=combine)
+                eng.force_exchange = True
+                gens = -chunks if chunks < 0 else 1            # chunks < 0: generations of the hash space instead
+                keys, counts, tot = rd.sharded_count(eng, reads, 3, 10_000_000, 0, chunks=max(1, chunks), generations=gens)
+                assert tot == [N, nd, m], (k, chunks, combine)
+                # one owner: the shard is everything, but in hash-leaf order -> compare as sorted sets
+                o = torch.argsort(keys)
+                assert torch.equal(keys[o], dk[:m]) and torch.equal(counts[o], dc[:m]), (k, chunks, combine)
+                gk, gc = rd.gather_survivors(keys, counts)
+                assert gk is keys or torch.equal(gk, keys)
         # RCCL 2.26 corrupts per-peer messages above 1 GiB; dist._alltoallv caps them (rounds of 512 MiB)
         gen = torch.Generator(device="cuda"); gen.manual_seed(5)
         n = (1 << 27) + 4099                                      # just over 1 GiB of int64

@@ -1002,8 +1002,8 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
         if constexpr (RECS) {
             // a leaf with many records will not fit one table: start it in 2, 4, ... hash-selected parts
             // instead of finding that out from an abandoned pass (presplit = records one table takes)
-            if (presplit) {
-                while ((end - begin) > (uint64_t)presplit * S && S < 16) S *= 2;
+            if (presplit & 0xffffffu) {
+                while ((end - begin) > (uint64_t)(presplit & 0xffffffu) * S && S < 16) S *= 2;
                 if (S > 1) {
                     __syncthreads();
                     if (threadIdx.x == 0) for (uint32_t q = S - 1; q >= 1; q--) { stackS[sp] = S; stacks[sp] = q; sp++; }
@@ -1101,6 +1101,10 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                         const bool va = ja < total;
                         uint64_t a0, a1;
                         kmer_at_pos(va ? ja : 0, &a0, &a1);
+                        if (presplit & 0x40000000u) {                       // ablation (RFX_WIDE_DBG=1): expand, no table
+                            if (va && (a0 ^ a1) == 0x123456789ULL) overflow = 1;
+                            continue;
+                        }
                         insert1(a0, a1, va);
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -2601,7 +2605,8 @@ static int finish_wide2(rfx_ctx *ctx, const std::conditional_t<RECS, WRec, Rec> 
         const int64_t grid = std::min<int64_t>(nseg, (int64_t)ctx->num_cu);
         hipLaunchKernelGGL(k_leaf_count_wide<RECS>, dim3((unsigned)grid), dim3(WLT), 0, ctx->stream, cur, d_leaf_off, nseg, k,
                            min_cov, max_cov, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>(),
-                           (uint32_t)(getenv("RFX_WIDE_PRESPLIT") ? atoi(getenv("RFX_WIDE_PRESPLIT")) : 2600));
+                           (uint32_t)(getenv("RFX_WIDE_PRESPLIT") ? atoi(getenv("RFX_WIDE_PRESPLIT")) : 2000) |
+                               (getenv("RFX_WIDE_DBG") ? (uint32_t)atoi(getenv("RFX_WIDE_DBG")) << 30 : 0u));
         RFX_HIP(hipGetLastError());
     }
     CountOut co{};

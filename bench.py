@@ -177,7 +177,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # N > 1: one extra untimed step ahead of the W warm-up steps (disclosed as "extra_untimed_steps"): the
+    # first step creates the RCCL communicator and settles every grow-only buffer, and on a fresh box the
+    # second one still pages code in (tools/prof_dist.py: 400 / 185 / 63 ms for steps 0 / 1 / 2)
+    extra_untimed = 1 if multi else 0
+    for _ in range(args.warmup + extra_untimed):
         step()
     sync_all()
     engine.bucketed_bytes = 0
@@ -217,7 +221,7 @@ def main():
     out = {
         "metric": "k-mers/sec (extract+count+filter; wall-clock to final contigs beside it)",
         "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "extra_untimed_steps": extra_untimed,
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"synthetic {args.gbp:g} Gbp per GPU, E.coli-like genome {args.genome} bp, "
                                f"PE{L}, k={k}, -cover {args.cover}, 0.5% substitutions",

@@ -545,6 +545,7 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<ELEM>
     // cursor (one global atomic per 16384 pairs; a per-wave atomic on that one counter costs 30 ns a piece)
     __shared__ unsigned long long blk_base, blk_next;
     __shared__ uint32_t blk_pos, have_next, need_grab;
+    __shared__ uint32_t ps_eff;              // elements one table takes (starts at `presplit`, shrinks on overflow)
     __shared__ __attribute__((aligned(16))) uint64_t stage[RECS ? LSTAGE : 2];  // records: per-wave expansion area
     uint32_t my_distinct = 0;                                                // every thread
     unsigned long long my_passes = 0, my_overflows = 0;                      // thread 0 only
@@ -570,6 +571,7 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<ELEM>
     if (threadIdx.x == 0) {
         ob_n = 0; ob_lim = 0xffffffffu; overflow = 0; sp = 0;
         blk_base = NOBLK; blk_next = NOBLK; blk_pos = PBLOCK; have_next = 0; need_grab = 1;
+        ps_eff = presplit ? presplit : 0xffffffffu;
     }
 
     // flush the survivor buffer (every thread calls)
@@ -643,16 +645,19 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<ELEM>
             if (a && dA) atomicAdd(&tcnt[slotA], wA);
             if (b && dB) atomicAdd(&tcnt[slotB], wB);
             // the rest walk their probe sequences one key at a time
-            auto walk = [&](uint64_t key, uint32_t slot, uint32_t w) __attribute__((always_inline)) {
+            // (double hashing: an odd step from other hash bits -- the wave waits for its longest probe sequence,
+            // and linear probing's clusters make that one long in a leaf that fills its table)
+            auto walk = [&](uint64_t key, uint32_t slot, uint32_t w, uint32_t g) __attribute__((always_inline)) {
+                const uint32_t step = (dbg & 16) ? 1u : (((g >> 8) & (LCAP - 1)) | 1u);
                 for (int probe = 1;; probe++) {
-                    slot = (slot + 1) & (LCAP - 1);
+                    slot = (slot + step) & (LCAP - 1);
                     const unsigned long long p = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
                     if (p == EMPTY || p == key) { atomicAdd(&tcnt[slot], w); break; }
                     if (probe >= LPROBE) { overflow = 1; break; }
                 }
             };
-            if (!dA) walk(keyA, slotA, wA);
-            if (!dB) walk(keyB, slotB, wB);
+            if (!dA) walk(keyA, slotA, wA, gA);
+            if (!dB) walk(keyB, slotB, wB, gB);
         };
         if constexpr (RECS) {
             // Records: every wave takes an equal contiguous share of the leaf and walks it 64 records
@@ -846,8 +851,8 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<ELEM>
         bool first = true;
         // a leaf with this many elements will not fit one table: start it in 2, 4, ... hash-selected parts
         // instead of finding that out from an abandoned pass (uniform: the bounds come from leaf_off)
-        if (presplit && end - begin > (uint64_t)presplit) {
-            while (end - begin > (uint64_t)presplit * S && S < 16) S *= 2;
+        if (end - begin > (uint64_t)ps_eff) {
+            while (end - begin > (uint64_t)ps_eff * S && S < 16) S *= 2;
             __syncthreads();
             if (threadIdx.x == 0) for (uint32_t q = S - 1; q >= 1; q--) { stackS[sp] = S; stacks[sp] = q; sp++; }
             __syncthreads();
@@ -871,6 +876,7 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<ELEM>
                     __syncthreads();
                 }
                 emit_pass();
+                if (threadIdx.x == 0 && S == 1 && end - begin > (uint64_t)ps_eff * 3 / 4 && ps_eff < (1u << 24)) ps_eff += ps_eff / 64 + 1;
                 if (pair_out && threadIdx.x == 0) {         // (all emission done; next read: after a later barrier)
                     if (blk_pos >= (uint32_t)PBLOCK) { blk_base = blk_next; blk_pos -= PBLOCK; have_next = 0; }
                     need_grab = blk_pos + (uint32_t)LCAP > (uint32_t)PBLOCK && !have_next;
@@ -883,6 +889,10 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<ELEM>
                 if (threadIdx.x == 0) {
                     my_overflows++;
                     overflow = 0;
+                    // what one table took too much of: later leaves of this workgroup start in parts sooner
+                    // (the distinct-per-element ratio is a property of the data set: coverage, error rate)
+                    // (additive increase / multiplicative decrease: one odd leaf must not decide for all)
+                    if ((end - begin) / S < 2ull * ps_eff && ps_eff > 64) ps_eff -= ps_eff / 8;
                     if (sp + 2 <= LSTACK && S < (1u << 16)) {
                         stackS[sp] = 2 * S; stacks[sp] = s + S; sp++;
                         stackS[sp] = 2 * S; stacks[sp] = s;     sp++;
@@ -963,6 +973,8 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                                                         uint64_t *__restrict__ out_keys, int64_t *__restrict__ out_counts,
                                                         unsigned long long cap, CountOut *__restrict__ co, uint32_t presplit) {
     __shared__ __attribute__((aligned(32))) uint64_t wstage[RECS ? WWS * (WLT / 64) : 4];
+    const bool dh = !(presplit & 0x20000000u);
+    __shared__ uint32_t ps_eff;              // records one table takes (starts at `presplit`, shrinks on overflow)
     __shared__ unsigned long long thi[WCAP], tlo[WCAP];
     __shared__ uint32_t tcnt[WCAP];
     __shared__ unsigned long long obh[OBUF], obl[OBUF];
@@ -978,7 +990,10 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
     const int64_t l1 = (int64_t)(((unsigned long long)(blockIdx.x + 1) * (unsigned long long)nleaf) / gridDim.x);
     if (l0 >= l1) return;
     for (int i = threadIdx.x; i < WCAP; i += WLT) tcnt[i] = 0;
-    if (threadIdx.x == 0) { ob_n = 0; ob_lim = 0xffffffffu; overflow = 0; sp = 0; }
+    if (threadIdx.x == 0) {
+        ob_n = 0; ob_lim = 0xffffffffu; overflow = 0; sp = 0;
+        ps_eff = (presplit & 0xffffffu) ? (presplit & 0xffffffu) : 0xffffffffu;
+    }
     __syncthreads();
 
     auto flush = [&]() {
@@ -1002,8 +1017,8 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
         if constexpr (RECS) {
             // a leaf with many records will not fit one table: start it in 2, 4, ... hash-selected parts
             // instead of finding that out from an abandoned pass (presplit = records one table takes)
-            if (presplit & 0xffffffu) {
-                while ((end - begin) > (uint64_t)(presplit & 0xffffffu) * S && S < 16) S *= 2;
+            if (end - begin > (uint64_t)ps_eff) {
+                while ((end - begin) > (uint64_t)ps_eff * S && S < 16) S *= 2;
                 if (S > 1) {
                     __syncthreads();
                     if (threadIdx.x == 0) for (uint32_t q = S - 1; q >= 1; q--) { stackS[sp] = S; stacks[sp] = q; sp++; }
@@ -1024,6 +1039,9 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                                     ((uint32_t)w1 * 0x85EBCA6Bu) ^ (uint32_t)(w1 >> 32)) * 0x9E3779B1u;
                 if (S > 1) v = v && (((g >> 4) & 0xffffu) & (S - 1)) == s;
                 uint32_t slot = g >> (32 - WCAP_BITS);
+                // double hashing: an odd step from other hash bits (the whole wave waits for its longest probe
+                // sequence, and linear probing's clusters make that one long when a leaf fills its table)
+                const uint32_t step = dh ? (((g >> 8) & (WCAP - 1)) | 1u) : 1u;
                 uint32_t c = 1u;
                 if (v) c = atomicCAS(&tcnt[slot], 0u, WLOCK);
                 if (v && c == 0u) {                                   // claimed: write the key, publish count 1
@@ -1047,7 +1065,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                         } else if (c != WLOCK) {
                             if (thi[slot] == w0 && tlo[slot] == w1) { atomicAdd(&tcnt[slot], 1u); done = true; }
                             else {
-                                slot = (slot + 1) & (WCAP - 1);
+                                slot = (slot + step) & (WCAP - 1);
                                 if (++probe >= LPROBE) { overflow = 1; done = true; }
                             }
                         }
@@ -1158,6 +1176,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                 __syncthreads();
                 const uint32_t raw = ob_n, lim = ob_lim;
                 if (raw >= (uint32_t)OBUF / 2 || lim != 0xffffffffu) flush();
+                if (RECS && threadIdx.x == 0 && S == 1 && end - begin > (uint64_t)ps_eff * 3 / 4 && ps_eff < (1u << 24)) ps_eff += ps_eff / 64 + 1;
                 if (S == 1) break;
             } else {
                 for (int i = threadIdx.x; i < WCAP; i += WLT) tcnt[i] = 0;
@@ -1165,6 +1184,9 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                 if (threadIdx.x == 0) {
                     my_overflows++;
                     overflow = 0;
+                    if constexpr (RECS) {
+                        if ((end - begin) / S < 2ull * ps_eff && ps_eff > 64) ps_eff -= ps_eff / 8;
+                    }
                     if (sp + 2 <= LSTACK && S < (1u << 16)) {
                         stackS[sp] = 2 * S; stacks[sp] = s + S; sp++;
                         stackS[sp] = 2 * S; stacks[sp] = s;     sp++;
@@ -1991,7 +2013,7 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
     const int dbg = getenv("RFX_LEAF_DBG") ? atoi(getenv("RFX_LEAF_DBG")) : 0;
     // records beyond which a leaf starts in 2, 4, .. parts (a record holds ~0.5 distinct k-mers at high coverage,
     // a table takes ~3300 keys before probe sequences run long); measured neutral for pairs and not used there
-    const uint32_t presplit = getenv("RFX_PRESPLIT") ? (uint32_t)atoi(getenv("RFX_PRESPLIT")) : ELEM == 1 ? 6000u : 0u;
+    const uint32_t presplit = getenv("RFX_PRESPLIT") ? (uint32_t)atoi(getenv("RFX_PRESPLIT")) : ELEM == 1 ? 8000u : 0u;
     DevBuf nsl, spos;
     RFX_HIP(nsl.alloc((size_t)nleaf * 8, ctx->stream));
     RFX_HIP(spos.alloc((size_t)(nleaf + 1) * 8, ctx->stream));
@@ -2285,7 +2307,7 @@ static int count_reads_superkmer(rfx_ctx *ctx, const ReadStore *reads, int min_c
     if (out_distinct) *out_distinct = 0;
     if (n <= 0) return RFX_OK;
     std::vector<int> bits;
-    plan_levels(n, true, bits, 8192.0);            // measured best for the record leaf (tools/ab_count.py)
+    plan_levels(n, true, bits, 16384.0);           // measured best for the record leaf with double hashing + pre-split (tools/bits_sweep.sh)
     Level lv{};
     lv.bits = bits[0];
     DevBuf segA, segB;
@@ -2493,7 +2515,7 @@ int count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_
     if (n_records <= 0) return RFX_OK;
     const int64_t n_inst = n_instances_hint > 0 ? n_instances_hint : n_records * 6;
     std::vector<int> bits;
-    plan_levels(n_inst, false, bits, 8192.0);
+    plan_levels(n_inst, false, bits, 16384.0);
     DevBuf segA, segB;
     uint64_t seg_init[2] = {0, (uint64_t)n_records};
     RFX_HIP(segA.alloc(2 * 8, ctx->stream));
@@ -2605,8 +2627,9 @@ static int finish_wide2(rfx_ctx *ctx, const std::conditional_t<RECS, WRec, Rec> 
         const int64_t grid = std::min<int64_t>(nseg, (int64_t)ctx->num_cu);
         hipLaunchKernelGGL(k_leaf_count_wide<RECS>, dim3((unsigned)grid), dim3(WLT), 0, ctx->stream, cur, d_leaf_off, nseg, k,
                            min_cov, max_cov, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>(),
-                           (uint32_t)(getenv("RFX_WIDE_PRESPLIT") ? atoi(getenv("RFX_WIDE_PRESPLIT")) : 2000) |
-                               (getenv("RFX_WIDE_DBG") ? (uint32_t)atoi(getenv("RFX_WIDE_DBG")) << 30 : 0u));
+                           (uint32_t)(getenv("RFX_WIDE_PRESPLIT") ? atoi(getenv("RFX_WIDE_PRESPLIT")) : 2600) |
+                               (getenv("RFX_WIDE_DBG") ? (uint32_t)atoi(getenv("RFX_WIDE_DBG")) << 30 : 0u) |
+                               (getenv("RFX_WIDE_LINEAR") ? 0x20000000u : 0u));
         RFX_HIP(hipGetLastError());
     }
     CountOut co{};
@@ -2703,13 +2726,12 @@ int bucket_wide_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads,
 // every k-mer (a thread's 16 windows, runs that share the central minimiser), 32-byte records that carry
 // the run's k + windows - 1 bases, record levels on the header, leaves that expand the records.  ~5 B per
 // instance through the levels instead of 16.
-// (measured, 5 Gbp at k = 63: levels 63 -> 27 ms, but the leaves 22 -> 68 ms: minimiser buckets are as skewed
-// as the genome's minimiser sites are few per leaf, a two-word table holds 4096 keys, and 10..40 % of the
-// leaves overflow into split passes that expand their records again -- so the element path stays the
-// default and RFX_WIDE_RECORDS=1 selects this one)
+// (measured, 5 Gbp at k = 63: levels 63 -> 27 ms, leaves 23 -> 44 ms, 76 ms per step against 90 for the
+// element path; RFX_WIDE_RECORDS=0 selects the element path.  The leaves pay for the minimiser buckets' skew:
+// DESIGN.md section 5)
 static bool wide_records_enabled(int k) {
     const char *e = getenv("RFX_WIDE_RECORDS");
-    return e && atoi(e) != 0 && k >= 33 && k <= 63;
+    return !(e && atoi(e) == 0) && k >= 33 && k <= 63;
 }
 
 static ReadSrc wide_read_src(const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc) {

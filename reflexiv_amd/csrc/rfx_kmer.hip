@@ -2005,7 +2005,9 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
     const int apply = !pair_out && !(twin == RFX_TWIN_RDD && min_cov <= 1);    // P/ReflexivMain.java:160
     // heavy leaves (low-complexity sequence: millions of instances of a few k-mers in one bucket) are
     // left out of the first launch, cut into slices and counted by the whole grid in a second one
-    uint64_t heavy = RECS ? 16384 : 131072, slice = RECS ? 2048 : 16384, pcap_min = 1 << 20;
+    // (record leaves hold ~2500 records; one of up to 16 x the pre-split threshold still goes through the
+    // main launch in hash-selected parts)
+    uint64_t heavy = RECS ? 65536 : 131072, slice = RECS ? 2048 : 16384, pcap_min = 1 << 20;
     if (const char *e = getenv("RFX_HEAVY")) {          // test knob: "heavy,slice,pcap" in elements
         unsigned long long a = 0, b = 0, c = 0;
         if (sscanf(e, "%llu,%llu,%llu", &a, &b, &c) == 3 && a && b && c) { heavy = a; slice = b; pcap_min = c; }

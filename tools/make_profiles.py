@@ -52,14 +52,16 @@ def main():
     out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 1 "
                    "--warmup 0 --no-cpu-baseline --no-contigs` on one MI355X (tools/refresh_profiles.sh); counters are KiB; "
                    "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); "
-                   "WRITE_SIZE as read; per launch = sum over the step / launches of the family in the step",
+                   "WRITE_SIZE as read; bytes of the family over the one step the pass runs (`hbm_bytes_per_launch`: a step launches every family once, the leaf kernel a second time when there are heavy leaves)",
            "kmer_instances": n_inst, "kernels": {}}
     for fam, key in FAMILY:
         if fam not in per:
             continue
+        # the passes run ONE step: the family's bytes per step (a step may launch the family more than once --
+        # heavy leaves go through a second launch of the leaf kernel), as bench.py prices its time per step
         nl = max(1, launches[fam].get("FETCH_SIZE", 1))
-        fetch = per[fam].get("FETCH_SIZE", 0.0) * 1024 * 2 / nl
-        write = per[fam].get("WRITE_SIZE", 0.0) * 1024 / max(1, launches[fam].get("WRITE_SIZE", 1))
+        fetch = per[fam].get("FETCH_SIZE", 0.0) * 1024 * 2
+        write = per[fam].get("WRITE_SIZE", 0.0) * 1024
         out["kernels"][fam] = {"kernel": key, "launches_per_step": nl, "fetch_bytes_corrected": fetch, "write_bytes": write,
                                "hbm_bytes_per_launch": fetch + write}
     json.dump(out, open(os.path.join(dst, tag + "_hbm_traffic.json"), "w"), indent=1)

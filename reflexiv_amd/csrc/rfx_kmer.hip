@@ -656,6 +656,7 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<ELEM>
                     if (probe >= LPROBE) { overflow = 1; break; }
                 }
             };
+            // (one loop per key; a single loop walking a lane's two sequences one after the other measured 10 % slower)
             if (!dA) walk(keyA, slotA, wA, gA);
             if (!dB) walk(keyB, slotB, wB, gB);
         };

@@ -2028,7 +2028,10 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
     RFX_HIP(hipMemcpyAsync(&n_slices, spos.as<uint64_t>() + nleaf, 8, hipMemcpyDeviceToHost, ctx->stream));
     {
         ScopedTimer t(ctx, "leaf");
-        int64_t grid = std::min<int64_t>(nleaf, (int64_t)ctx->num_cu * 2);      // persistent, <= 78 KB LDS each
+        // many more workgroups than fit (2 per CU are resident): a workgroup's contiguous chunk of leaves is
+        // short, and the chunks even out what the leaves' sizes do not (leaf 14.6 -> 13.3 ms against 2 per CU)
+        const int leaf_per_cu = getenv("RFX_LEAF_PER_CU") ? std::max(1, atoi(getenv("RFX_LEAF_PER_CU"))) : 32;
+        int64_t grid = std::min<int64_t>(nleaf, (int64_t)ctx->num_cu * leaf_per_cu);      // persistent, <= 78 KB LDS each
         hipLaunchKernelGGL(k_leaf_count<ELEM>, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, elems, d_leaf_off, nleaf,
                            (const uint64_t *)nullptr, (const uint64_t *)nullptr, heavy, (uint64_t)elem_count, k, min_cov,
                            max_cov, apply, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>(), dbg,
@@ -2157,9 +2160,9 @@ static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv
     const int nb = lv.n_owners > 0 ? lv.n_owners : (1 << lv.bits);
     const int W = rsrc.k - SK_M + 1;
     const size_t sk_lds = (size_t)nb * (SKB * sizeof(Rec) + 16);
-    // two workgroups fit a CU when the rings are small; twice as many are launched then (the second half
-    // queues behind the first and evens out the tail: hist1 5.0 -> 4.8 ms)
-    int per_cu = sk_lds <= 80 * 1024 ? 4 : 1;
+    // two workgroups fit a CU when the rings are small; four times as many are launched then (the rest queue
+    // behind the first and even out the tail: hist1 5.0 -> 4.6 ms)
+    int per_cu = sk_lds <= 80 * 1024 ? 8 : 1;
     if (const char *e = getenv("RFX_SK_PER_CU")) per_cu = std::max(1, atoi(e));
     const unsigned G = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(rsrc.n_threads, SKT), (int64_t)ctx->num_cu * per_cu));
     DevBuf bh, scanned;
@@ -2629,7 +2632,8 @@ static int finish_wide2(rfx_ctx *ctx, const std::conditional_t<RECS, WRec, Rec> 
     RFX_HIP(hipMemsetAsync(co_buf.p, 0, sizeof(CountOut), ctx->stream));
     {
         ScopedTimer t(ctx, "leaf");
-        const int64_t grid = std::min<int64_t>(nseg, (int64_t)ctx->num_cu);
+        const int wleaf_per_cu = getenv("RFX_WLEAF_PER_CU") ? std::max(1, atoi(getenv("RFX_WLEAF_PER_CU"))) : 1;
+        const int64_t grid = std::min<int64_t>(nseg, (int64_t)ctx->num_cu * wleaf_per_cu);
         hipLaunchKernelGGL(k_leaf_count_wide<RECS>, dim3((unsigned)grid), dim3(WLT), 0, ctx->stream, cur, d_leaf_off, nseg, k,
                            min_cov, max_cov, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>(),
                            (uint32_t)(getenv("RFX_WIDE_PRESPLIT") ? atoi(getenv("RFX_WIDE_PRESPLIT")) : 2600) |

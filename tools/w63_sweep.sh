@@ -1,5 +1,5 @@
 # k = 63 record path: knob sweep (one box, one run: only these numbers compare)
-for v in "RFX_X=1" "RFX_LEAF_TARGET=12288" "RFX_LEAF_TARGET=12288 RFX_WIDE_PRESPLIT=2000" "RFX_LEAF_TARGET=9000"; do
+for v in "RFX_X=1" "RFX_WLEAF_PER_CU=4" "RFX_WLEAF_PER_CU=16" "RFX_WLEAF_PER_CU=64" "RFX_WLEAF_PER_CU=16 RFX_WIDE_RECORDS=0"; do
   echo "== $v"
   env RFX_WIDE_RECORDS=1 $v RFX_TRACE=1 timeout -k 10 90 python bench.py --k 63 --steps 2 --warmup 1 > gpurun_out/w63.log 2>&1
   grep "wide leaves" gpurun_out/w63.log | tail -1

@@ -436,7 +436,7 @@ constexpr int LPROBE = 48;              // a probe sequence this long means the 
 constexpr uint64_t EMPTY = ~0ULL;
 constexpr int LSTACK = 48;
 constexpr int LB = 8;                   // instance loads in flight per lane
-constexpr int PBLOCK = 16384;           // pair_out: pairs per output block a workgroup reserves at a time
+constexpr int PBLOCK = 8192;            // pair_out: pairs per output block a workgroup reserves at a time (>= LCAP)
 constexpr unsigned long long NOBLK = ~0ULL;
 
 struct CountOut {
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<ELEM>
     __shared__ uint32_t overflow, ob_n, ob_lim;
     __shared__ unsigned long long g_emit;
     // pair_out: survivors go straight to blocks of PBLOCK pairs this workgroup takes from the global
-    // cursor (one global atomic per 16384 pairs; a per-wave atomic on that one counter costs 30 ns a piece)
+    // cursor (one global atomic per 8192 pairs; a per-wave atomic on that one counter costs 30 ns a piece)
     __shared__ unsigned long long blk_base, blk_next;
     __shared__ uint32_t blk_pos, have_next, need_grab;
     __shared__ uint32_t ps_eff;              // elements one table takes (starts at `presplit`, shrinks on overflow)
@@ -2030,7 +2030,8 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
         ScopedTimer t(ctx, "leaf");
         // many more workgroups than fit (2 per CU are resident): a workgroup's contiguous chunk of leaves is
         // short, and the chunks even out what the leaves' sizes do not (leaf 14.6 -> 13.3 ms against 2 per CU)
-        const int leaf_per_cu = getenv("RFX_LEAF_PER_CU") ? std::max(1, atoi(getenv("RFX_LEAF_PER_CU"))) : 32;
+        // (pair output: every workgroup leaves part of its last block(s) as holes, so fewer of them)
+        const int leaf_per_cu = getenv("RFX_LEAF_PER_CU") ? std::max(1, atoi(getenv("RFX_LEAF_PER_CU"))) : pair_out ? 4 : 32;
         int64_t grid = std::min<int64_t>(nleaf, (int64_t)ctx->num_cu * leaf_per_cu);      // persistent, <= 78 KB LDS each
         hipLaunchKernelGGL(k_leaf_count<ELEM>, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, elems, d_leaf_off, nleaf,
                            (const uint64_t *)nullptr, (const uint64_t *)nullptr, heavy, (uint64_t)elem_count, k, min_cov,

@@ -2225,6 +2225,7 @@ static int partition_record_levels(rfx_ctx *ctx, const typename LevelElem<MODE>:
         const int64_t nchild = nseg << lv.bits;
         const int64_t total_tiles = ceil_div(std::max<int64_t>(n_recs, 1), PTILE);
         int tpb = (int)std::min<int64_t>(32, std::max<int64_t>(1, total_tiles / ((int64_t)ctx->num_cu * 8)));
+        if (const char *e = getenv("RFX_TPB")) tpb = std::max(1, atoi(e));
         const int64_t v_bound = ceil_div(std::max<int64_t>(n_recs, 1), (int64_t)tpb * PTILE) + nseg;
         DevBuf nvb, vb_start, table, scanned;
         RFX_HIP(nvb.alloc((size_t)nseg * 8, ctx->stream));

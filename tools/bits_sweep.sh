@@ -1,5 +1,5 @@
 # k = 31 fused count: level-bit plans (one box, one run: only these numbers compare)
-for v in "RFX_X=1" "RFX_SK_PER_CU=8" "RFX_SK_PER_CU=16" "RFX_X=1"; do
+for v in "RFX_X=1" "RFX_TPB=8" "RFX_TPB=16" "RFX_TPB=64" "RFX_X=1"; do
   echo "== $v"
   env $v RFX_TRACE=1 timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-contigs --no-cpu-baseline > gpurun_out/bs.log 2>&1
   grep "^leaves" gpurun_out/bs.log | tail -1

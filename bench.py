@@ -7,9 +7,11 @@ reads, k = 31, with the kernel roofline and the CPU baseline beside it.
 A step = one pass of the hot path's count stage over one batch of synthetic reads that is
 already resident in HBM (2-bit packed): at N = 1 the batch is BASELINE.json configs[1]
 ("Synthetic 5 Gbp E.coli-like PE150, k=31, 1xMI355X": 33,333,334 reads of 150 bp from a
-4.64 Mbp genome, 0.5 % substitutions, -cover 30).  At N > 1 every rank holds its own 5 Gbp
-shard of the read set (weak scaling), k-mer space is radix-sharded over the ranks and one
-RCCL all-to-all(v) replaces the Spark shuffle.  After the timed steps the run goes on to
+4.64 Mbp genome, 0.5 % substitutions, -cover 30).  At N > 1 every rank holds its own 6.25 Gbp
+shard of the read set (weak scaling; 8 x 6.25 = the 50 Gbp of BASELINE configs[2] and of the
+metric), k-mer space is radix-sharded over the ranks and one RCCL all-to-all(v) replaces the
+Spark shuffle.  Run without a launcher, `--gpus N` starts its own N ranks (torch.distributed.run)
+and refuses to run when fewer than N GPUs are visible.  After the timed steps the run goes on to
 final contigs once and reports that wall-clock beside the metric.
 """
 import argparse
@@ -46,10 +48,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--gbp", type=float, default=5.0, help="Gbp of reads per GPU")
+    ap.add_argument("--gbp", type=float, default=None,
+                    help="Gbp of reads per GPU (default: 5 at N = 1 = BASELINE configs[1]; 6.25 at N > 1, i.e. the 50 Gbp of "
+                         "BASELINE configs[2] / the metric at 8 GPUs, the same per-GPU work at 2 and 4)")
     ap.add_argument("--genome", type=int, default=4_640_000, help="genome length (bases, multiple of 32)")
     ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--cover", type=int, default=30, help="-cover (minKmerCoverage) for this depth")
+    ap.add_argument("--cover", type=int, default=None,
+                    help="-cover (minKmerCoverage); default 30 per 5 Gbp of TOTAL reads on the 4.64 Mbp genome (error k-mers "
+                         "recur in proportion to the depth: 30 at 1078x, 300 at 10776x)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--partitions", type=int, default=8)
@@ -67,7 +73,29 @@ def parse():
                          "hides the flight of the next).  auto: records from 8 GPUs on (a peer's share per link is small), "
                          "pairs below")
     ap.add_argument("--generations", type=int, default=4, help="--exchange records: generations of the hash space")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.gbp is None:
+        args.gbp = 5.0 if args.gpus == 1 else 6.25
+    if args.cover is None:
+        args.cover = max(2, int(round(30 * args.gbp * args.gpus / 5.0 * 4_640_000 / args.genome)))
+    return args
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves as a
+    child `torch.distributed.run` (one process per GPU, RCCL rendezvous on 127.0.0.1) BEFORE this process
+    touches the GPU, and exit with the child's code."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()            # does not initialise the GPU runtime
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible on this box: refusing to run "
+                         f"(a {args.gpus}-GPU number can only come from {args.gpus} ranks)\n")
+        sys.exit(2)
+    port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd).returncode)
 
 
 def cpu_baseline(args, n_sample):
@@ -97,6 +125,8 @@ def cpu_baseline(args, n_sample):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                     # never returns
     import torch
     import torch.distributed as dist
     import reflexiv_amd
@@ -105,14 +135,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, (world, args.gpus)
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks\n")
+        sys.exit(2)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+        sys.stderr.write("bench.py needs one MI355X per rank (no CPU fallback)\n")
+        sys.exit(2)
     torch.cuda.set_device(local)
     multi = world > 1 or args.force_dist
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        # n_gpus in the JSON line is what RCCL saw, nothing else
+        world = dist.get_world_size()
+        probe = torch.ones(1, device=torch.device("cuda", local))
+        dist.all_reduce(probe)
+        if int(probe.item()) != args.gpus and not (args.force_dist and args.gpus == 1):
+            sys.stderr.write(f"bench.py: {int(probe.item())} ranks joined the RCCL group, --gpus {args.gpus} asked for\n")
+            sys.exit(2)
     rfx = reflexiv_amd.Reflexiv(local)
     rfx.use_stream(torch.cuda.current_stream().cuda_stream)   # kernels, copies and RCCL share one stream
     dev = torch.device("cuda", local)
@@ -224,8 +265,8 @@ def main():
         "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "extra_untimed_steps": extra_untimed,
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"synthetic {args.gbp:g} Gbp per GPU, E.coli-like genome {args.genome} bp, "
-                               f"PE{L}, k={k}, -cover {args.cover}, 0.5% substitutions",
+        "config": {"workload": f"synthetic {args.gbp * world:g} Gbp in all ({args.gbp:g} Gbp per GPU x {world}), "
+                               f"E.coli-like genome {args.genome} bp, PE{L}, k={k}, -cover {args.cover}, 0.5% substitutions",
                    "reads_per_gpu": n_reads, "kmer_instances_per_gpu": n_inst, "distinct_kmers": nd,
                    "kmers_kept": m,
                    "parallelism": "1 GPU" if not multi else f"k-mer space radix-sharded over {world} GPUs, "

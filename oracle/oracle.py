@@ -62,6 +62,9 @@ def lib():
         L.orc_assemble_from_counts.restype = C.c_int64
         L.orc_splitmix64.restype = C.c_uint64
         L.orc_splitmix64.argtypes = [C.c_uint64]
+        for f in ("orc_fork_filter_forward_w", "orc_fork_filter_reflected_w", "orc_extend_pass_w",
+                  "orc_contigs_text_w", "orc_assemble_from_counts_w"):
+            getattr(L, f).restype = C.c_int64
     return _LIB
 
 
@@ -82,7 +85,7 @@ def default_params(**kw) -> Params:
 @dataclass
 class Records:
     """Flat SoA in the reference's record layout."""
-    key: np.ndarray       # uint64 [n]
+    key: np.ndarray       # uint64 [n] (k <= 32) or [n, kw] (k > 32: kw = (k-2)//31+1 words of 31 bases)
     marker: np.ndarray    # int32  [n]
     ext_off: np.ndarray   # int64  [n+1]
     ext: np.ndarray       # uint64 [ext_off[n]]
@@ -96,12 +99,16 @@ class Records:
     @staticmethod
     def from_single(key, marker, ext, left, right) -> "Records":
         n = len(key)
-        return Records(np.ascontiguousarray(key, np.uint64), np.ascontiguousarray(marker, np.int32),
+        key = np.ascontiguousarray(key, np.uint64)
+        if key.ndim == 2 and key.shape[1] == 1:
+            key = key.reshape(-1)
+        return Records(key, np.ascontiguousarray(marker, np.int32),
                        np.arange(n + 1, dtype=np.int64), np.ascontiguousarray(ext, np.uint64),
                        np.ascontiguousarray(left, np.int32), np.ascontiguousarray(right, np.int32))
 
     def tuple_list(self):
-        return [(int(self.key[i]), int(self.marker[i]),
+        kk = self.key if self.key.ndim == 1 else [tuple(int(x) for x in r) for r in self.key]
+        return [(kk[i] if self.key.ndim > 1 else int(kk[i]), int(self.marker[i]),
                  tuple(int(x) for x in self.ext[self.ext_off[i]:self.ext_off[i + 1]]),
                  int(self.left[i]), int(self.right[i])) for i in range(self.n)]
 
@@ -212,39 +219,78 @@ def revcomp(kmer: int, k: int) -> int:
     return int(lib().orc_revcomp(C.c_uint64(kmer), k))
 
 
+def sub_words(k: int) -> int:
+    """words of a (k-1)-mer key: 1 up to k = 32, (k-2)//31+1 beyond (subKmerBinarySlots)."""
+    return int(lib().orc_sub_words(k))
+
+
+def asm_words(k: int) -> int:
+    """words of a k-mer in the assembler's 31-bases-per-word layout (kmerBinarySlotsAssemble)."""
+    return int(lib().orc_asm_words(k))
+
+
+def _kw_of(key: np.ndarray) -> int:
+    return 1 if key.ndim == 1 else int(key.shape[1])
+
+
+def _keybuf(n: int, kw: int) -> np.ndarray:
+    return np.empty(n, np.uint64) if kw == 1 else np.empty((n, kw), np.uint64)
+
+
+def kmer_binarize_w(kmer_text: str, count_text: str, k: int):
+    """KmerBinarizer.call (P/ReflexivDSMain64.java:10772-10836) on one CSV row -> (words, cover)."""
+    w = np.zeros(asm_words(k), np.uint64)
+    c = C.c_int32(0)
+    st = lib().orc_kmer_binarize_w(kmer_text.encode(), count_text.encode(), k, _p(w), C.byref(c))
+    if st != 0:
+        raise ValueError("k-mer text shorter than k")
+    return w, int(c.value)
+
+
+def counter_to_asm_w(kmers32: np.ndarray, k: int) -> np.ndarray:
+    """counter layout uint64[n, k//32+1] -> assembler layout uint64[n, (k-1)//31+1] (the CSV round trip)."""
+    kmers32 = np.ascontiguousarray(kmers32, np.uint64).reshape(-1, words_w(k))
+    out = np.empty((len(kmers32), asm_words(k)), np.uint64)
+    lib().orc_counter_to_asm_w(_p(kmers32), C.c_int64(len(kmers32)), k, _p(out))
+    return out
+
+
 def rc_expand_subkmer(keys, counts, k=31) -> Records:
+    """k <= 31: keys uint64[n]; k > 31: keys uint64[n, (k-1)//31+1] in the assembler layout."""
     keys = np.ascontiguousarray(keys, np.uint64)
     counts = np.ascontiguousarray(counts, np.int32)
-    n = len(keys)
-    key = np.empty(2 * n, np.uint64); ext = np.empty(2 * n, np.uint64)
+    n = len(counts)
+    kw = sub_words(k)
+    key = _keybuf(2 * n, kw); ext = np.empty(2 * n, np.uint64)
     marker = np.empty(2 * n, np.int32); left = np.empty(2 * n, np.int32); right = np.empty(2 * n, np.int32)
-    lib().orc_rc_expand_subkmer(_p(keys), _p(counts), C.c_int64(n), k, _p(key), _p(marker), _p(ext),
-                                _p(left), _p(right))
+    lib().orc_rc_expand_subkmer_w(_p(keys), _p(counts), C.c_int64(n), k, _p(key), _p(marker), _p(ext),
+                                  _p(left), _p(right))
     return Records.from_single(key, marker, ext, left, right)
 
 
 def sort_perm(key: np.ndarray) -> np.ndarray:
     key = np.ascontiguousarray(key, np.uint64)
     perm = np.empty(len(key), np.int64)
-    lib().orc_sort_perm(_p(key), C.c_int64(len(key)), _p(perm))
+    lib().orc_sort_perm_w(_p(key), C.c_int64(len(key)), _kw_of(key), _p(perm))
     return perm
 
 
 def partition_starts(sorted_key: np.ndarray, P: int) -> np.ndarray:
     sorted_key = np.ascontiguousarray(sorted_key, np.uint64)
     st = np.empty(P + 1, np.int64)
-    lib().orc_partition_starts(_p(sorted_key), C.c_int64(len(sorted_key)), P, _p(st))
+    lib().orc_partition_starts_w(_p(sorted_key), C.c_int64(len(sorted_key)), _kw_of(sorted_key), P, _p(st))
     return st
 
 
 def gather(r: Records, perm: np.ndarray) -> Records:
     perm = np.ascontiguousarray(perm, np.int64)
     n = len(perm)
-    out = Records(np.empty(n, np.uint64), np.empty(n, np.int32), np.empty(n + 1, np.int64),
+    kw = _kw_of(r.key)
+    out = Records(_keybuf(n, kw), np.empty(n, np.int32), np.empty(n + 1, np.int64),
                   np.empty(max(1, len(r.ext)), np.uint64), np.empty(n, np.int32), np.empty(n, np.int32))
-    lib().orc_gather(_p(perm), C.c_int64(n), _p(r.key), _p(r.marker), _p(r.ext_off), _p(r.ext),
-                     _p(r.left), _p(r.right), _p(out.key), _p(out.marker), _p(out.ext_off),
-                     _p(out.ext), _p(out.left), _p(out.right))
+    lib().orc_gather_w(_p(perm), C.c_int64(n), kw, _p(r.key), _p(r.marker), _p(r.ext_off), _p(r.ext),
+                       _p(r.left), _p(r.right), _p(out.key), _p(out.marker), _p(out.ext_off),
+                       _p(out.ext), _p(out.left), _p(out.right))
     out.ext = out.ext[:out.ext_off[n]].copy()
     return out
 
@@ -257,7 +303,8 @@ def _fork(fn, r: Records, part_start, k, min_error_cov, twin):
     n = r.n
     P = len(part_start) - 1
     part_start = np.ascontiguousarray(part_start, np.int64)
-    o = [np.empty(n, np.uint64), np.empty(n, np.int32), np.empty(n, np.uint64),
+    assert _kw_of(r.key) == sub_words(k), (r.key.shape, k)
+    o = [_keybuf(n, _kw_of(r.key)), np.empty(n, np.int32), np.empty(n, np.uint64),
          np.empty(n, np.int32), np.empty(n, np.int32)]
     ops = np.empty(P + 1, np.int64)
     m = fn(_p(r.key), _p(r.marker), _p(r.ext), _p(r.left), _p(r.right), C.c_int64(n),
@@ -268,70 +315,86 @@ def _fork(fn, r: Records, part_start, k, min_error_cov, twin):
 
 
 def fork_filter_forward(r, part_start, k=31, min_error_cov=8, twin=TWIN_DS):
-    return _fork(lib().orc_fork_filter_forward, r, part_start, k, min_error_cov, twin)
+    return _fork(lib().orc_fork_filter_forward_w, r, part_start, k, min_error_cov, twin)
 
 
 def fork_filter_reflected(r, part_start, k=31, min_error_cov=8, twin=TWIN_DS):
-    return _fork(lib().orc_fork_filter_reflected, r, part_start, k, min_error_cov, twin)
+    return _fork(lib().orc_fork_filter_reflected_w, r, part_start, k, min_error_cov, twin)
 
 
 def reflect_from_forward(r: Records, k=31) -> Records:
     n = r.n
-    key = np.empty(n, np.uint64); marker = np.empty(n, np.int32); ext = np.empty(n, np.uint64)
-    lib().orc_reflect_from_forward(_p(r.key), _p(r.ext), C.c_int64(n), k, _p(key), _p(marker), _p(ext))
+    assert _kw_of(r.key) == sub_words(k), (r.key.shape, k)
+    key = _keybuf(n, _kw_of(r.key)); marker = np.empty(n, np.int32); ext = np.empty(n, np.uint64)
+    lib().orc_reflect_from_forward_w(_p(r.key), _p(r.ext), C.c_int64(n), k, _p(key), _p(marker), _p(ext))
     return Records.from_single(key, marker, ext, r.left.copy(), r.right.copy())
 
 
 def random_reflection(r: Records, part_start, k=31) -> Records:
     part_start = np.ascontiguousarray(part_start, np.int64)
     out = Records.from_single(r.key.copy(), r.marker.copy(), r.ext.copy(), r.left.copy(), r.right.copy())
-    lib().orc_random_reflection(_p(out.key), _p(out.marker), _p(out.ext), C.c_int64(out.n),
-                                _p(part_start), len(part_start) - 1, k)
+    assert _kw_of(r.key) == sub_words(k), (r.key.shape, k)
+    lib().orc_random_reflection_w(_p(out.key), _p(out.marker), _p(out.ext), C.c_int64(out.n),
+                                  _p(part_start), len(part_start) - 1, k)
     return out
 
 
-def extend_pass(r: Records, part_start, k=31, twin=TWIN_DS):
+def extend_pass(r: Records, part_start, k=31, twin=TWIN_DS, start_marker=2):
     """One extend pass over records already sorted by key -> (Records, out_part_start)."""
     n = r.n
     P = len(part_start) - 1
     part_start = np.ascontiguousarray(part_start, np.int64)
     words = max(1, int(r.ext_off[n]))
-    o = Records(np.empty(max(1, n), np.uint64), np.empty(max(1, n), np.int32),
+    assert _kw_of(r.key) == sub_words(k), (r.key.shape, k)
+    o = Records(_keybuf(max(1, n), _kw_of(r.key)), np.empty(max(1, n), np.int32),
                 np.empty(n + 1, np.int64), np.empty(words, np.uint64),
                 np.empty(max(1, n), np.int32), np.empty(max(1, n), np.int32))
     ops = np.empty(P + 1, np.int64)
-    m = lib().orc_extend_pass(_p(r.key), _p(r.marker), _p(r.ext_off), _p(r.ext), _p(r.left), _p(r.right),
-                              C.c_int64(n), _p(part_start), P, k, twin,
-                              _p(o.key), _p(o.marker), _p(o.ext_off), _p(o.ext), _p(o.left), _p(o.right),
-                              _p(ops))
+    m = lib().orc_extend_pass_w(_p(r.key), _p(r.marker), _p(r.ext_off), _p(r.ext), _p(r.left), _p(r.right),
+                                C.c_int64(n), _p(part_start), P, k, twin, start_marker,
+                                _p(o.key), _p(o.marker), _p(o.ext_off), _p(o.ext), _p(o.left), _p(o.right),
+                                _p(ops))
     return Records(o.key[:m].copy(), o.marker[:m].copy(), o.ext_off[:m + 1].copy(),
                    o.ext[:o.ext_off[m]].copy(), o.left[:m].copy(), o.right[:m].copy()), ops
 
 
 def contigs_text(r: Records, k=31, min_contig=500, twin=TWIN_DS):
+    """k <= 31: the twin's header; k > 31 (P/ReflexivDSMain64.java:830-866): ">Contig-<len>-<idx>"."""
     n = r.n
     nc = C.c_int64(0)
-    args = (_p(r.key), _p(r.marker), _p(r.ext_off), _p(r.ext), _p(r.left), _p(r.right),
-            C.c_int64(n), k, min_contig, twin)
-    ln = lib().orc_contigs_text(*args, None, C.c_int64(0), C.byref(nc))
+    if k > 31:
+        assert _kw_of(r.key) == sub_words(k), (r.key.shape, k)
+        fn = lib().orc_contigs_text_w
+        args = (_p(r.key), _p(r.marker), _p(r.ext_off), _p(r.ext), _p(r.left), _p(r.right),
+                C.c_int64(n), k, min_contig)
+    else:
+        fn = lib().orc_contigs_text
+        args = (_p(r.key), _p(r.marker), _p(r.ext_off), _p(r.ext), _p(r.left), _p(r.right),
+                C.c_int64(n), k, min_contig, twin)
+    ln = fn(*args, None, C.c_int64(0), C.byref(nc))
     buf = np.empty(max(1, ln), np.uint8)
-    lib().orc_contigs_text(*args, _p(buf), C.c_int64(ln), C.byref(nc))
+    fn(*args, _p(buf), C.c_int64(ln), C.byref(nc))
     return bytes(buf[:ln]).decode(), int(nc.value)
 
 
 def assemble_from_counts(keys, counts, prm: Params):
-    """a-14 driver -> (text, n_contigs, trace[list of record counts per pass], final Records)."""
+    """a-14 driver -> (text, n_contigs, trace[list of record counts per pass], final Records).
+    k > 31: keys uint64[n, (k-1)//31+1] in the assembler layout, ReflexivDSMain64's driver."""
     keys = np.ascontiguousarray(keys, np.uint64)
     counts = np.ascontiguousarray(counts, np.int32)
-    n = len(keys)
+    n = len(counts)
+    wide = prm.k > 31
+    kw = sub_words(prm.k)
+    if wide:
+        assert keys.shape == (n, asm_words(prm.k)), keys.shape
     trace = np.zeros(prm.max_iter + 8, np.int64)
     ntr = C.c_int64(0); nc = C.c_int64(0)
     rec = _Records()
     cap = 4 * (n + 16) * (prm.k + 8) + 1024
     buf = np.empty(cap, np.uint8)
-    ln = lib().orc_assemble_from_counts(_p(keys), _p(counts), C.c_int64(n), C.byref(prm),
-                                        _p(buf), C.c_int64(cap), C.byref(nc),
-                                        _p(trace), C.c_int64(len(trace)), C.byref(ntr), C.byref(rec))
+    fn = lib().orc_assemble_from_counts_w if wide else lib().orc_assemble_from_counts
+    ln = fn(_p(keys), _p(counts), C.c_int64(n), C.byref(prm), _p(buf), C.c_int64(cap), C.byref(nc),
+            _p(trace), C.c_int64(len(trace)), C.byref(ntr), C.byref(rec))
     assert ln <= cap
     m = rec.n
 
@@ -341,7 +404,10 @@ def assemble_from_counts(keys, counts, prm: Params):
         a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(cnt * np.dtype(dt).itemsize,))
         return a.view(dt).copy()
     ext_off = arr(rec.ext_off, m + 1, np.int64)
-    out = Records(arr(rec.key, m, np.uint64), arr(rec.marker, m, np.int32), ext_off,
+    okey = arr(rec.key, m * kw, np.uint64)
+    if kw > 1:
+        okey = okey.reshape(m, kw)
+    out = Records(okey, arr(rec.marker, m, np.int32), ext_off,
                   arr(rec.ext, int(ext_off[m]) if m else 0, np.uint64),
                   arr(rec.left, m, np.int32), arr(rec.right, m, np.int32))
     lib().orc_free_records(C.byref(rec))

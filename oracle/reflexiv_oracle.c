@@ -301,6 +301,8 @@ int64_t orc_count_filter(uint64_t *kmers, int64_t n, int min_cov, int max_cov, i
 
 /* ------------------------------------------------------------ a-5/a-6 expand */
 
+static void pack_key_fwd(const uint8_t *b, int kw, int sub, uint64_t *key);
+
 uint64_t orc_revcomp(uint64_t kmer, int k) {
     /* KmerReverseComplement.call  P/ReflexivMain.java:2916-2923 */
     uint64_t rc = 0;
@@ -326,59 +328,151 @@ void orc_rc_expand_subkmer(const uint64_t *kmers, const int32_t *counts, int64_t
     }
 }
 
+/* ---- k > 31: the assembler's 31-bases-per-word layout  P/ReflexivDSMain64.java */
+
+int orc_sub_words(int k) { return k <= 32 ? 1 : (k - 2) / 31 + 1; }    /* subKmerBinarySlots    U/DefaultParam.java:94  */
+int orc_asm_words(int k) { return k <= 31 ? 1 : (k - 1) / 31 + 1; }    /* kmerBinarySlotsAssemble  U/DefaultParam.java:85 */
+
+/* KmerBinarizer.call :10772-10836 on one CSV row: the k-mer text (an optional leading '(' is
+ * dropped, :10790-10792) and the count text (an optional trailing ')' is dropped; 10 or more digits
+ * read as 1000000000, :10794-10806).  words: (k-1)/31+1, 31 bases each, the last one the rest
+ * (:10812-10819).  Returns 0, or -1 when the text is shorter than k. */
+int orc_kmer_binarize_w(const char *kmer_text, const char *count_text, int k, uint64_t *words, int32_t *cover) {
+    if (kmer_text[0] == '(') kmer_text++;
+    size_t cl = strlen(count_text);
+    if (cl && count_text[cl - 1] == ')') *cover = cl >= 11 ? 1000000000 : (int32_t)strtol(count_text, NULL, 10);
+    else *cover = cl >= 10 ? 1000000000 : (int32_t)strtol(count_text, NULL, 10);
+    if ((int)strlen(kmer_text) < k) return -1;
+    const int W = (k - 1) / 31 + 1;
+    for (int w = 0; w < W; w++) words[w] = 0;
+    for (int i = 0; i < k; i++) {
+        words[i / 31] <<= 2;
+        words[i / 31] |= nuc_value(kmer_text[i]);
+    }
+    return 0;
+}
+
+/* What the text round trip counter -> CSV -> KmerBinarizer does to a k-mer
+ * (DSBinaryKmerToString P/ReflexivDataFrameCounter64.java:340-369, then the above): from k/32+1
+ * words of 32 bases to (k-1)/31+1 words of 31. */
+void orc_counter_to_asm_w(const uint64_t *kmers32, int64_t n, int k, uint64_t *kmers31) {
+    const int W32 = k / 32 + 1, W31 = (k - 1) / 31 + 1;
+    char *txt = (char *)xmalloc((size_t)k + 1);
+    for (int64_t i = 0; i < n; i++) {
+        orc_kmer_text_w(kmers32 + i * W32, k, txt);
+        txt[k] = 0;
+        int32_t c;
+        orc_kmer_binarize_w(txt, "1", k, kmers31 + i * W31, &c);
+    }
+    free(txt);
+}
+
+/* DSKmerReverseComplement.call :10706-10755 + DSForwardSubKmerExtraction.call :10363-10403:
+ * n (k-mer, count) -> 2n records (k-mer then its reverse complement), key = the first k-1 bases in
+ * (k-2)/31+1 words, ext = the last base (no sentinel), marker 1, left = right = count. */
+void orc_rc_expand_subkmer_w(const uint64_t *kmers, const int32_t *counts, int64_t n, int k,
+                             uint64_t *key, int32_t *marker, uint64_t *ext,
+                             int32_t *left, int32_t *right) {
+    if (k <= 31) { orc_rc_expand_subkmer(kmers, counts, n, k, key, marker, ext, left, right); return; }
+    const int W = (k - 1) / 31 + 1, kw = orc_sub_words(k), sub = k - 1;
+    const int lastb = k - 31 * (W - 1);               /* bases in the last k-mer word */
+    uint8_t *b = (uint8_t *)xmalloc((size_t)k + 8), *r = (uint8_t *)xmalloc((size_t)k + 8);
+    for (int64_t i = 0; i < n; i++) {
+        const uint64_t *km = kmers + (size_t)i * W;
+        int o = 0;
+        for (int w = 0; w < W; w++) {
+            const int nb = w < W - 1 ? 31 : lastb;
+            for (int j = 0; j < nb; j++) b[o++] = (uint8_t)((km[w] >> (2 * (nb - 1 - j))) & 3);
+        }
+        for (int j = 0; j < k; j++) r[j] = (uint8_t)(b[k - 1 - j] ^ 3);     /* :10727-10743 */
+        const uint8_t *two[2] = { b, r };                                    /* :10749-10750 */
+        for (int t = 0; t < 2; t++) {
+            int64_t q = 2 * i + t;
+            pack_key_fwd(two[t], kw, sub, key + (size_t)q * kw);              /* :10381-10395 */
+            ext[q] = two[t][k - 1];                                          /* :10383 / :10390 */
+            marker[q] = 1; left[q] = counts[i]; right[q] = counts[i];        /* :10399 */
+        }
+    }
+    free(b); free(r);
+}
+
 /* ------------------------------------------------------------ order contract */
 
-void orc_sort_perm(const uint64_t *key, int64_t n, int64_t *perm) {
-    /* stable LSD radix sort of (key, index); ties keep arrival order (B.0) */
+/* keys are kw consecutive words per record (kw = 1 for k <= 32): a Spark sort on an
+ * array<long> column of equal-length arrays compares element by element, which for 31-base
+ * words is the order of the base strings */
+static inline int key_eq(const uint64_t *a, const uint64_t *b, int kw) {
+    for (int w = 0; w < kw; w++) if (a[w] != b[w]) return 0;
+    return 1;
+}
+
+void orc_sort_perm_w(const uint64_t *key, int64_t n, int kw, int64_t *perm) {
+    /* stable LSD radix sort of (key, index), last word first; ties keep arrival order (B.0) */
     int64_t *tmp = (int64_t *)xmalloc((size_t)(n ? n : 1) * sizeof(int64_t));
     int64_t *hist = (int64_t *)xmalloc(65536 * sizeof(int64_t));
     for (int64_t i = 0; i < n; i++) perm[i] = i;
     int64_t *src = perm, *dst = tmp;
-    for (int pass = 0; pass < 4 && n > 1; pass++) {
-        int sh = 16 * pass;
-        memset(hist, 0, 65536 * sizeof(int64_t));
-        for (int64_t i = 0; i < n; i++) hist[(key[src[i]] >> sh) & 0xFFFF]++;
-        if (hist[(key[src[0]] >> sh) & 0xFFFF] == n) continue;
-        int64_t s = 0;
-        for (int d = 0; d < 65536; d++) { int64_t c = hist[d]; hist[d] = s; s += c; }
-        for (int64_t i = 0; i < n; i++) dst[hist[(key[src[i]] >> sh) & 0xFFFF]++] = src[i];
-        int64_t *t = src; src = dst; dst = t;
+    for (int w = kw - 1; w >= 0 && n > 1; w--) {
+        for (int pass = 0; pass < 4; pass++) {
+            int sh = 16 * pass;
+            memset(hist, 0, 65536 * sizeof(int64_t));
+            for (int64_t i = 0; i < n; i++) hist[(key[src[i] * kw + w] >> sh) & 0xFFFF]++;
+            if (hist[(key[src[0] * kw + w] >> sh) & 0xFFFF] == n) continue;
+            int64_t s = 0;
+            for (int d = 0; d < 65536; d++) { int64_t c = hist[d]; hist[d] = s; s += c; }
+            for (int64_t i = 0; i < n; i++) dst[hist[(key[src[i] * kw + w] >> sh) & 0xFFFF]++] = src[i];
+            int64_t *t = src; src = dst; dst = t;
+        }
     }
     if (src != perm) memcpy(perm, src, (size_t)n * sizeof(int64_t));
     free(tmp); free(hist);
 }
 
-void orc_partition_starts(const uint64_t *sorted_key, int64_t n, int P, int64_t *start) {
+void orc_sort_perm(const uint64_t *key, int64_t n, int64_t *perm) { orc_sort_perm_w(key, n, 1, perm); }
+
+void orc_partition_starts_w(const uint64_t *sorted_key, int64_t n, int kw, int P, int64_t *start) {
     int64_t prev = 0;
     for (int p = 0; p < P; p++) {
         /* floor(p*n/P) without overflow for n < 2^62/P */
         int64_t s = (int64_t)(((__int128)p * (__int128)n) / P);
         if (s < prev) s = prev;
-        while (s > 0 && s < n && sorted_key[s] == sorted_key[s - 1]) s++;
+        while (s > 0 && s < n && key_eq(sorted_key + s * kw, sorted_key + (s - 1) * kw, kw)) s++;
         start[p] = s; prev = s;
     }
     start[P] = n;
 }
 
+void orc_partition_starts(const uint64_t *sorted_key, int64_t n, int P, int64_t *start) {
+    orc_partition_starts_w(sorted_key, n, 1, P, start);
+}
+
 /* --------------------------------------------------------- a-7 forward filter */
 
-int64_t orc_fork_filter_forward(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
-                                const int32_t *left, const int32_t *right, int64_t n,
-                                const int64_t *part_start, int P,
-                                int k, int min_error_cov, int twin,
-                                uint64_t *okey, int32_t *omarker, uint64_t *oext,
-                                int32_t *oleft, int32_t *oright, int64_t *out_part_start) {
-    (void)right;
+/* Generic over the key width kw (words per (k-1)-mer key, AoS).  k <= 31: P/ReflexivMain.java /
+ * P/ReflexivDSMain.java (twin selects the arithmetic); k > 31: P/ReflexivDSMain64.java, whose
+ * filters are the DS twin's statement for statement with subKmerSlotComparator (:10124-10132)
+ * in place of the key comparison. */
+#define KEY(a, i) ((a) + (size_t)(i) * (size_t)kw)
+#define KEYCPY(d, s_) memcpy((d), (s_), (size_t)kw * 8)
+
+int64_t orc_fork_filter_forward_w(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
+                                  const int32_t *left, const int32_t *right, int64_t n,
+                                  const int64_t *part_start, int P,
+                                  int k, int min_error_cov, int twin,
+                                  uint64_t *okey, int32_t *omarker, uint64_t *oext,
+                                  int32_t *oleft, int32_t *oright, int64_t *out_part_start) {
+    (void)right; (void)n;
+    const int kw = orc_sub_words(k);
     const int32_t sub = k - 1;                              /* param.subKmerSize */
     int64_t m = 0;
     for (int p = 0; p < P; p++) {
         out_part_start[p] = m;
         int64_t first = m;                                   /* list empty per task */
         for (int64_t i = part_start[p]; i < part_start[p + 1]; i++) {
-            /* free-end value: RDD -1 (:2478), DS -1-coverage (DS :3436) */
+            /* free-end value: RDD -1 (:2478), DS -1-coverage (DS :3436, 64 :10149) */
 #define FREE_OF(cov) ((twin == ORC_TWIN_DS && min_error_cov != 0) ? (-1 - (cov)) : -1)
-            if (m == first || key[i] != okey[m - 1]) {                       /* :2475,:2529 */
-                okey[m] = key[i]; omarker[m] = marker[i]; oext[m] = ext[i];
+            if (m == first || !key_eq(KEY(key, i), KEY(okey, m - 1), kw)) {      /* :2475,:2529 */
+                KEYCPY(KEY(okey, m), KEY(key, i)); omarker[m] = marker[i]; oext[m] = ext[i];
                 oleft[m] = left[i]; oright[m] = FREE_OF(left[i]); m++;
                 continue;
             }
@@ -404,29 +498,127 @@ int64_t orc_fork_filter_forward(const uint64_t *key, const int32_t *marker, cons
     return m;
 }
 
+int64_t orc_fork_filter_forward(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
+                                const int32_t *left, const int32_t *right, int64_t n,
+                                const int64_t *part_start, int P,
+                                int k, int min_error_cov, int twin,
+                                uint64_t *okey, int32_t *omarker, uint64_t *oext,
+                                int32_t *oleft, int32_t *oright, int64_t *out_part_start) {
+    return orc_fork_filter_forward_w(key, marker, ext, left, right, n, part_start, P, k, min_error_cov, twin,
+                                     okey, omarker, oext, oleft, oright, out_part_start);
+}
+
+/* --------------------------------------------- sequence-level record helpers */
+
+static int64_t ext_len_words(const uint64_t *w, int64_t nw) {
+    /* (length-1)*31 + firstBlockLength  P/ReflexivMain.java:820-823 */
+    return (nw - 1) * 31 + sentinel_len(w[0]);
+}
+
+/* key: words 0..kw-2 hold 31 bases each, the last word the remaining sub - 31*(kw-1) bases
+ * (subKmerSizeResidue), right-aligned  (P/ReflexivDSMain64.java:1928-1940; kw = 1: the
+ * single long of the k <= 31 classes) */
+static void unpack_key(const uint64_t *key, int kw, int sub, uint8_t *b) {
+    int o = 0;
+    for (int w = 0; w < kw; w++) {
+        const int nb = w < kw - 1 ? 31 : sub - 31 * (kw - 1);
+        for (int j = 0; j < nb; j++) b[o++] = (uint8_t)((key[w] >> (2 * (nb - 1 - j))) & 3);
+    }
+}
+static void pack_key(const uint8_t *b, int kw, int sub, uint64_t *key) {
+    int o = 0;
+    for (int w = 0; w < kw; w++) {
+        const int nb = w < kw - 1 ? 31 : sub - 31 * (kw - 1);
+        uint64_t x = 0;
+        for (int j = 0; j < nb; j++) x = (x << 2) | b[o++];
+        key[w] = x;
+    }
+}
+static void pack_key_fwd(const uint8_t *b, int kw, int sub, uint64_t *key) { pack_key(b, kw, sub, key); }
+static void unpack_ext(const uint64_t *w, int64_t nw, uint8_t *b) {
+    int f = sentinel_len(w[0]);
+    int64_t o = 0;
+    for (int j = 0; j < f; j++) b[o++] = (uint8_t)((w[0] >> (2 * (f - 1 - j))) & 3);
+    for (int64_t i = 1; i < nw; i++)
+        for (int j = 0; j < 31; j++) b[o++] = (uint8_t)((w[i] >> (2 * (30 - j))) & 3);
+}
+static int64_t ext_words_for(int64_t len) { return (len + 30) / 31; }
+static void pack_ext(const uint8_t *b, int64_t len, uint64_t *w) {
+    int64_t nw = ext_words_for(len);
+    int f = (int)(len - 31 * (nw - 1));
+    uint64_t x = 1;                                   /* the "C marker" sentinel */
+    int64_t o = 0;
+    for (int j = 0; j < f; j++) x = (x << 2) | b[o++];
+    w[0] = x;
+    for (int64_t i = 1; i < nw; i++) {
+        x = 0;
+        for (int j = 0; j < 31; j++) x = (x << 2) | b[o++];
+        w[i] = x;
+    }
+}
+
+/* full sequence of a record: marker 1 = key||ext, marker 2 = ext||key */
+static int64_t record_seq(const uint64_t *key, int kw, int marker, const uint64_t *w, int64_t nw, int sub,
+                          uint8_t *b) {
+    int64_t L = ext_len_words(w, nw);
+    if (marker == 1) { unpack_key(key, kw, sub, b); unpack_ext(w, nw, b + sub); }
+    else             { unpack_ext(w, nw, b); unpack_key(key, kw, sub, b + L); }
+    return L + sub;
+}
+
+/* store sequence b[0..len) in orientation m at output slot */
+typedef struct {
+    uint64_t *key; int32_t *marker; int64_t *ext_off; uint64_t *ext;
+    int32_t *left; int32_t *right; int64_t n; int kw;
+} out_set;
+
+static void emit_seq(out_set *o, const uint8_t *b, int64_t len, int sub, int m,
+                     int32_t left, int32_t right) {
+    int64_t i = o->n++;
+    int64_t L = len - sub;
+    const int kw = o->kw;
+    uint64_t *w = o->ext + o->ext_off[i];
+    if (m == 1) { pack_key(b, kw, sub, KEY(o->key, i));       pack_ext(b + sub, L, w); }
+    else        { pack_key(b + L, kw, sub, KEY(o->key, i));   pack_ext(b, L, w); }
+    o->marker[i] = m; o->left[i] = left; o->right[i] = right;
+    o->ext_off[i + 1] = o->ext_off[i] + ext_words_for(L);
+}
+
 /* ------------------------------------------------------- a-8 reflect records */
+
+void orc_reflect_from_forward_w(const uint64_t *key, const uint64_t *ext, int64_t n, int k,
+                                uint64_t *okey, int32_t *omarker, uint64_t *oext) {
+    /* ReflectedSubKmerExtractionFromForward  P/ReflexivMain.java:2742-2768; 64: :10426-10475 (the
+     * first base leaves word 0, every word shifts left by one base taking the top base of its
+     * right neighbour, the suffix base enters the last word): key' = key[1..] || suffix. */
+    const int kw = orc_sub_words(k), sub = k - 1;
+    uint8_t b[4 * 31 * 4 + 8];
+    uint8_t *bb = kw <= 16 ? b : (uint8_t *)xmalloc((size_t)sub + 8);
+    for (int64_t i = 0; i < n; i++) {
+        unpack_key(KEY(key, i), kw, sub, bb);
+        const uint64_t first = bb[0];                                        /* :2752-2754 / :10448 */
+        bb[sub] = (uint8_t)(ext[i] & 3);                                     /* :2757-2758 / :10455 */
+        pack_key(bb + 1, kw, sub, KEY(okey, i));
+        omarker[i] = 2; oext[i] = first | 4;                                 /* :2755,:2762 / :10450 */
+    }
+    if (bb != b) free(bb);
+}
 
 void orc_reflect_from_forward(const uint64_t *key, const uint64_t *ext, int64_t n, int k,
                               uint64_t *okey, int32_t *omarker, uint64_t *oext) {
-    const int sub = k - 1;
-    const int shift = 2 * (sub - 1);                                         /* :2739 */
-    const uint64_t mask = low_mask(sub);                                     /* :2740 */
-    for (int64_t i = 0; i < n; i++) {
-        uint64_t first = (key[i] >> shift) & 3;                              /* :2752-2754 */
-        uint64_t nk = ((key[i] << 2) & mask) | ext[i];                       /* :2757-2758 */
-        okey[i] = nk; omarker[i] = 2; oext[i] = first | 4;                   /* :2755,:2762 */
-    }
+    orc_reflect_from_forward_w(key, ext, n, k, okey, omarker, oext);
 }
 
 /* ------------------------------------------------------- a-9 reflected filter */
 
-int64_t orc_fork_filter_reflected(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
-                                  const int32_t *left, const int32_t *right, int64_t n,
-                                  const int64_t *part_start, int P,
-                                  int k, int min_error_cov, int twin,
-                                  uint64_t *okey, int32_t *omarker, uint64_t *oext,
-                                  int32_t *oleft, int32_t *oright, int64_t *out_part_start) {
+int64_t orc_fork_filter_reflected_w(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
+                                    const int32_t *left, const int32_t *right, int64_t n,
+                                    const int64_t *part_start, int P,
+                                    int k, int min_error_cov, int twin,
+                                    uint64_t *okey, int32_t *omarker, uint64_t *oext,
+                                    int32_t *oleft, int32_t *oright, int64_t *out_part_start) {
     (void)n;
+    const int kw = orc_sub_words(k);
     const int32_t sub = k - 1;
     const int ds_ec = (twin == ORC_TWIN_DS && min_error_cov != 0);
     int64_t m = 0;
@@ -436,10 +628,10 @@ int64_t orc_fork_filter_reflected(const uint64_t *key, const int32_t *marker, co
         int32_t last_cov = 0;                                /* HighCoverLastCoverage :2614 */
         for (int64_t i = part_start[p]; i < part_start[p + 1]; i++) {
             int32_t cs = left[i];
-            if (m == first || key[i] != okey[m - 1]) {                       /* :2622,:2684 */
+            if (m == first || !key_eq(KEY(key, i), KEY(okey, m - 1), kw)) {      /* :2622,:2684 */
                 last_cov = cs;
-                okey[m] = key[i]; omarker[m] = marker[i]; oext[m] = ext[i];
-                oleft[m] = ds_ec ? (-1 - cs) : -1;                            /* :2626 / DS :3556 */
+                KEYCPY(KEY(okey, m), KEY(key, i)); omarker[m] = marker[i]; oext[m] = ext[i];
+                oleft[m] = ds_ec ? (-1 - cs) : -1;                            /* :2626 / DS :3556 / 64 :10292 */
                 oright[m] = right[i]; m++;
                 continue;
             }
@@ -464,7 +656,7 @@ int64_t orc_fork_filter_reflected(const uint64_t *key, const int32_t *marker, co
             } else {                                                         /* :2667 */
                 int err = (min_error_cov != 0) && cs <= min_error_cov && last_cov >= 2 * cs;
                 if (err) {
-                    /* RDD :2672 stores -1; DS :3595 keeps the previous left */
+                    /* RDD :2672 stores -1; DS :3595 / 64 :10330 keep the previous left */
                     if (!ds_ec) oleft[h] = -1;
                 } else {
                     oleft[h] = sub;                                          /* :2679 */
@@ -476,122 +668,77 @@ int64_t orc_fork_filter_reflected(const uint64_t *key, const int32_t *marker, co
     return m;
 }
 
-/* --------------------------------------------- sequence-level record helpers */
-
-static int64_t ext_len_words(const uint64_t *w, int64_t nw) {
-    /* (length-1)*31 + firstBlockLength  P/ReflexivMain.java:820-823 */
-    return (nw - 1) * 31 + sentinel_len(w[0]);
-}
-
-static void unpack_key(uint64_t key, int sub, uint8_t *b) {
-    for (int i = 0; i < sub; i++) b[i] = (uint8_t)((key >> (2 * (sub - 1 - i))) & 3);
-}
-static uint64_t pack_key(const uint8_t *b, int sub) {
-    uint64_t k = 0;
-    for (int i = 0; i < sub; i++) k = (k << 2) | b[i];
-    return k;
-}
-static void unpack_ext(const uint64_t *w, int64_t nw, uint8_t *b) {
-    int f = sentinel_len(w[0]);
-    int64_t o = 0;
-    for (int j = 0; j < f; j++) b[o++] = (uint8_t)((w[0] >> (2 * (f - 1 - j))) & 3);
-    for (int64_t i = 1; i < nw; i++)
-        for (int j = 0; j < 31; j++) b[o++] = (uint8_t)((w[i] >> (2 * (30 - j))) & 3);
-}
-static int64_t ext_words_for(int64_t len) { return (len + 30) / 31; }
-static void pack_ext(const uint8_t *b, int64_t len, uint64_t *w) {
-    int64_t nw = ext_words_for(len);
-    int f = (int)(len - 31 * (nw - 1));
-    uint64_t x = 1;                                   /* the "C marker" sentinel */
-    int64_t o = 0;
-    for (int j = 0; j < f; j++) x = (x << 2) | b[o++];
-    w[0] = x;
-    for (int64_t i = 1; i < nw; i++) {
-        x = 0;
-        for (int j = 0; j < 31; j++) x = (x << 2) | b[o++];
-        w[i] = x;
-    }
-}
-
-/* full sequence of a record: marker 1 = key||ext, marker 2 = ext||key */
-static int64_t record_seq(uint64_t key, int marker, const uint64_t *w, int64_t nw, int sub,
-                          uint8_t *b) {
-    int64_t L = ext_len_words(w, nw);
-    if (marker == 1) { unpack_key(key, sub, b); unpack_ext(w, nw, b + sub); }
-    else             { unpack_ext(w, nw, b); unpack_key(key, sub, b + L); }
-    return L + sub;
-}
-
-/* store sequence b[0..len) in orientation m at output slot */
-typedef struct {
-    uint64_t *key; int32_t *marker; int64_t *ext_off; uint64_t *ext;
-    int32_t *left; int32_t *right; int64_t n;
-} out_set;
-
-static void emit_seq(out_set *o, const uint8_t *b, int64_t len, int sub, int m,
-                     int32_t left, int32_t right) {
-    int64_t i = o->n++;
-    int64_t L = len - sub;
-    uint64_t *w = o->ext + o->ext_off[i];
-    if (m == 1) { o->key[i] = pack_key(b, sub);       pack_ext(b + sub, L, w); }
-    else        { o->key[i] = pack_key(b + L, sub);   pack_ext(b, L, w); }
-    o->marker[i] = m; o->left[i] = left; o->right[i] = right;
-    o->ext_off[i + 1] = o->ext_off[i] + ext_words_for(L);
+int64_t orc_fork_filter_reflected(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
+                                  const int32_t *left, const int32_t *right, int64_t n,
+                                  const int64_t *part_start, int P,
+                                  int k, int min_error_cov, int twin,
+                                  uint64_t *okey, int32_t *omarker, uint64_t *oext,
+                                  int32_t *oleft, int32_t *oright, int64_t *out_part_start) {
+    return orc_fork_filter_reflected_w(key, marker, ext, left, right, n, part_start, P, k, min_error_cov, twin,
+                                       okey, omarker, oext, oleft, oright, out_part_start);
 }
 
 /* --------------------------------------------------- a-10 random reflection */
 
-void orc_random_reflection(uint64_t *key, int32_t *marker, uint64_t *ext, int64_t n,
-                           const int64_t *part_start, int P, int k) {
+void orc_random_reflection_w(uint64_t *key, int32_t *marker, uint64_t *ext, int64_t n,
+                             const int64_t *part_start, int P, int k) {
+    /* kmerRandomReflection  P/ReflexivMain.java:2783-2885; 64: DSkmerRandomReflection :10491-10690 */
     (void)n;
-    const int sub = k - 1;
-    uint8_t b[96];
+    const int kw = orc_sub_words(k), sub = k - 1;
+    uint8_t *b = (uint8_t *)xmalloc((size_t)sub + 96);
     for (int p = 0; p < P; p++) {
         int m = 2;                                   /* randomReflexivMarker = 2 :2777 */
         for (int64_t i = part_start[p]; i < part_start[p + 1]; i++) {
             if (marker[i] != m) {                    /* singleKmerRandomizer :2792-2876 */
-                int64_t len = record_seq(key[i], marker[i], &ext[i], 1, sub, b);
+                int64_t len = record_seq(KEY(key, i), kw, marker[i], &ext[i], 1, sub, b);
                 int64_t L = len - sub;
-                if (m == 1) { key[i] = pack_key(b, sub);     pack_ext(b + sub, L, &ext[i]); }
-                else        { key[i] = pack_key(b + L, sub); pack_ext(b, L, &ext[i]); }
+                if (m == 1) { pack_key(b, kw, sub, KEY(key, i));     pack_ext(b + sub, L, &ext[i]); }
+                else        { pack_key(b + L, kw, sub, KEY(key, i)); pack_ext(b, L, &ext[i]); }
                 marker[i] = m;
             }
             m = 3 - m;                                                      /* :2880-2884 */
         }
     }
+    free(b);
+}
+
+void orc_random_reflection(uint64_t *key, int32_t *marker, uint64_t *ext, int64_t n,
+                           const int64_t *part_start, int P, int k) {
+    orc_random_reflection_w(key, marker, ext, n, part_start, P, k);
 }
 
 /* ------------------------------------------------------ a-11..13 extend pass */
 
 #define ORC_BLOCK (INT32_MIN)
 
-int64_t orc_extend_pass(const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
-                        const uint64_t *ext, const int32_t *left, const int32_t *right,
-                        int64_t n, const int64_t *part_start, int P, int k, int twin,
-                        uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext,
-                        int32_t *oleft, int32_t *oright, int64_t *out_part_start) {
-    const int sub = k - 1;
+int64_t orc_extend_pass_w(const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
+                          const uint64_t *ext, const int32_t *left, const int32_t *right,
+                          int64_t n, const int64_t *part_start, int P, int k, int twin, int start_marker,
+                          uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext,
+                          int32_t *oleft, int32_t *oright, int64_t *out_part_start) {
+    const int kw = orc_sub_words(k), sub = k - 1;
     int64_t maxw = 1;
     for (int64_t i = 0; i < n; i++) { int64_t w = ext_off[i + 1] - ext_off[i]; if (w > maxw) maxw = w; }
     /* scratch big enough for a merged sequence */
     uint8_t *bs = (uint8_t *)xmalloc((size_t)(2 * maxw * 31 + 2 * sub + 64));
-    uint8_t *bh = (uint8_t *)xmalloc((size_t)(maxw * 31 + sub + 64));
-    out_set o = { okey, omarker, oext_off, oext, oleft, oright, 0 };
+    out_set o = { okey, omarker, oext_off, oext, oleft, oright, 0, kw };
     oext_off[0] = 0;
 
 #define EXTW(i)   (ext + ext_off[i])
 #define EXTN(i)   (ext_off[(i) + 1] - ext_off[i])
-#define FLIP_EMIT(i) do { /* singleKmerRandomizer  P/ReflexivMain.java:910-1063 */ \
-        int64_t len_ = record_seq(key[i], marker[i], EXTW(i), EXTN(i), sub, bs); \
+#define FLIP_EMIT(i) do { /* singleKmerRandomizer  P/ReflexivMain.java:910-1063 (64 :7605-8170) */ \
+        int64_t len_ = record_seq(KEY(key, i), kw, marker[i], EXTW(i), EXTN(i), sub, bs); \
         emit_seq(&o, bs, len_, sub, m, left[i], right[i]); m = 3 - m; } while (0)
 
     for (int p = 0; p < P; p++) {
         out_part_start[p] = o.n;
-        int m = 2;                                   /* randomReflexivMarker = 2 :770 */
+        /* randomReflexivMarker = 2 :770; the k > 31 array loop starts at 1 once param.scramble == 3
+         * (P/ReflexivDSMain64.java:7484-7486) */
+        int m = start_marker;
         int64_t holder = -1;                         /* tmpReflexivKmerExtendList (<= 1 element) */
         for (int64_t s = part_start[p]; s < part_start[p + 1]; s++) {
             if (holder < 0) { holder = s; continue; }                        /* :797-799,:813-814 */
-            if (key[s] != key[holder]) {                                     /* :886-893 */
+            if (!key_eq(KEY(key, s), KEY(key, holder), kw)) {                /* :886-893 */
                 FLIP_EMIT(holder); holder = s; continue;
             }
             if (marker[s] == marker[holder]) {                               /* :845-854 */
@@ -616,29 +763,53 @@ int64_t orc_extend_pass(const uint64_t *key, const int32_t *marker, const int64_
                     int32_t hr = right[F];
                     if (a >= 0 && hr - lenR >= 0) d = hr - lenR; else d = ORC_BLOCK;
                 } else {
-                    if (a >= 0 && a - lenR >= 0) d = a - lenR; else d = ORC_BLOCK; /* DS :1856-1857 */
+                    if (a >= 0 && a - lenR >= 0) d = a - lenR; else d = ORC_BLOCK; /* DS :1856-1857, 64 :7567 */
                 }
             }
             if (d == ORC_BLOCK) { FLIP_EMIT(s); continue; }                   /* :841-843 */
-            /* reflexivExtend: R.ext || key || F.ext   P/ReflexivMain.java:1077-1519 */
-            int64_t lr = record_seq(key[R], 2, EXTW(R), EXTN(R), sub, bs);   /* R.ext||key */
+            /* reflexivExtend: R.ext || key || F.ext   P/ReflexivMain.java:1077-1519 (64 :8199-8679) */
+            int64_t lr = record_seq(KEY(key, R), kw, 2, EXTW(R), EXTN(R), sub, bs);   /* R.ext||key */
             unpack_ext(EXTW(F), EXTN(F), bs + lr);
             int64_t len = lr + lenF;
             int32_t L, Rt;
-            if (d < 0)             { L = left[R];   Rt = right[F]; }          /* :1214-1218 */
-            else if (left[F] > 0)  { L = (int32_t)d; Rt = right[F]; }         /* :1220-1226 */
-            else                   { L = left[R];   Rt = (int32_t)d; }        /* :1227-1233 */
+            if (d < 0)             { L = left[R];   Rt = right[F]; }          /* :1214-1218 / 64 :8657-8660 */
+            else if (left[F] > 0)  { L = (int32_t)d; Rt = right[F]; }         /* :1220-1226 / 64 :8662-8665 */
+            else                   { L = left[R];   Rt = (int32_t)d; }        /* :1227-1233 / 64 :8667-8670 */
             emit_seq(&o, bs, len, sub, m, L, Rt); m = 3 - m;                 /* :1242,:1514 */
             holder = -1;
         }
         if (holder >= 0) FLIP_EMIT(holder);                                   /* :902 */
     }
     out_part_start[P] = o.n;
-    free(bs); free(bh);
+    free(bs);
     return o.n;
 #undef EXTW
 #undef EXTN
 #undef FLIP_EMIT
+}
+
+int64_t orc_extend_pass(const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
+                        const uint64_t *ext, const int32_t *left, const int32_t *right,
+                        int64_t n, const int64_t *part_start, int P, int k, int twin,
+                        uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext,
+                        int32_t *oleft, int32_t *oright, int64_t *out_part_start) {
+    return orc_extend_pass_w(key, marker, ext_off, ext, left, right, n, part_start, P, k, twin, 2,
+                             okey, omarker, oext_off, oext, oleft, oright, out_part_start);
+}
+
+void orc_gather_w(const int64_t *perm, int64_t n, int kw,
+                  const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
+                  const uint64_t *ext, const int32_t *left, const int32_t *right,
+                  uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext,
+                  int32_t *oleft, int32_t *oright) {
+    oext_off[0] = 0;
+    for (int64_t i = 0; i < n; i++) {
+        int64_t s = perm[i];
+        KEYCPY(KEY(okey, i), KEY(key, s)); omarker[i] = marker[s]; oleft[i] = left[s]; oright[i] = right[s];
+        int64_t nw = ext_off[s + 1] - ext_off[s];
+        memcpy(oext + oext_off[i], ext + ext_off[s], (size_t)nw * 8);
+        oext_off[i + 1] = oext_off[i] + nw;
+    }
 }
 
 void orc_gather(const int64_t *perm, int64_t n,
@@ -646,38 +817,33 @@ void orc_gather(const int64_t *perm, int64_t n,
                 const uint64_t *ext, const int32_t *left, const int32_t *right,
                 uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext,
                 int32_t *oleft, int32_t *oright) {
-    oext_off[0] = 0;
-    for (int64_t i = 0; i < n; i++) {
-        int64_t s = perm[i];
-        okey[i] = key[s]; omarker[i] = marker[s]; oleft[i] = left[s]; oright[i] = right[s];
-        int64_t nw = ext_off[s + 1] - ext_off[s];
-        memcpy(oext + oext_off[i], ext + ext_off[s], (size_t)nw * 8);
-        oext_off[i + 1] = oext_off[i] + nw;
-    }
+    orc_gather_w(perm, n, 1, key, marker, ext_off, ext, left, right, okey, omarker, oext_off, oext, oleft, oright);
 }
 
 /* --------------------------------------------------------------- a-15 contigs */
 
-int64_t orc_contigs_text(const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
-                         const uint64_t *ext, const int32_t *left, const int32_t *right,
-                         int64_t n, int k, int min_contig, int twin,
-                         char *out, int64_t cap, int64_t *n_contigs) {
+/* header: 0 = RDD twin ">Contig-<len>-<idx>" (also P/ReflexivDSMain64.java:830-866),
+ *         1 = DS twin  ">Contig-<len>-(<left>,<right>)-<idx>", which also skips records whose
+ *             markers are both <= -10,000,000 (P/ReflexivDSMain.java:749) */
+static int64_t contigs_text_impl(const uint64_t *key, int kw, const int32_t *marker, const int64_t *ext_off,
+                                 const uint64_t *ext, const int32_t *left, const int32_t *right,
+                                 int64_t n, int k, int min_contig, int ds_header,
+                                 char *out, int64_t cap, int64_t *n_contigs) {
     static const char NUC[4] = { 'A', 'C', 'G', 'T' };
     const int sub = k - 1;
     int64_t pos = 0, idx = 0;
     uint8_t *b = NULL; int64_t bcap = 0;
 #define PUTC(c) do { if (pos < cap) out[pos] = (c); pos++; } while (0)
     for (int64_t i = 0; i < n; i++) {
-        /* DS skips records with both markers <= -10,000,000  P/ReflexivDSMain.java:749 */
-        if (twin == ORC_TWIN_DS && left[i] <= -10000000 && right[i] <= -10000000) continue;
+        if (ds_header && left[i] <= -10000000 && right[i] <= -10000000) continue;
         int64_t nw = ext_off[i + 1] - ext_off[i];
         int64_t len = ext_len_words(ext + ext_off[i], nw) + sub;
         if (len < min_contig) continue;                                      /* :596,:606 */
         if (len + 64 > bcap) { free(b); bcap = 2 * len + 64; b = (uint8_t *)xmalloc((size_t)bcap); }
-        record_seq(key[i], marker[i], ext + ext_off[i], nw, sub, b);
+        record_seq(KEY(key, i), kw, marker[i], ext + ext_off[i], nw, sub, b);
         char hdr[96];
         int hl;
-        if (twin == ORC_TWIN_DS)                                             /* DS :755,:722 */
+        if (ds_header)                                                       /* DS :755,:722 */
             hl = snprintf(hdr, sizeof hdr, ">Contig-%lld-(%d,%d)-%lld\n", (long long)len,
                           left[i], right[i], (long long)idx);
         else                                                                 /* :597,:578 */
@@ -696,11 +862,27 @@ int64_t orc_contigs_text(const uint64_t *key, const int32_t *marker, const int64
     return pos;
 }
 
+int64_t orc_contigs_text(const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
+                         const uint64_t *ext, const int32_t *left, const int32_t *right,
+                         int64_t n, int k, int min_contig, int twin,
+                         char *out, int64_t cap, int64_t *n_contigs) {
+    return contigs_text_impl(key, 1, marker, ext_off, ext, left, right, n, k, min_contig, twin == ORC_TWIN_DS,
+                             out, cap, n_contigs);
+}
+
+int64_t orc_contigs_text_w(const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
+                           const uint64_t *ext, const int32_t *left, const int32_t *right,
+                           int64_t n, int k, int min_contig,
+                           char *out, int64_t cap, int64_t *n_contigs) {
+    return contigs_text_impl(key, orc_sub_words(k), marker, ext_off, ext, left, right, n, k, min_contig, 0,
+                             out, cap, n_contigs);
+}
+
 /* ---------------------------------------------------------------- a-14 driver */
 
-static void rec_alloc(orc_records *r, int64_t n, int64_t words) {
+static void rec_alloc(orc_records *r, int64_t n, int64_t words, int kw) {
     r->n = 0;
-    r->key = (uint64_t *)xmalloc((size_t)n * 8);
+    r->key = (uint64_t *)xmalloc((size_t)n * 8 * (size_t)kw);
     r->marker = (int32_t *)xmalloc((size_t)n * 4);
     r->ext_off = (int64_t *)xmalloc((size_t)(n + 1) * 8);
     r->ext = (uint64_t *)xmalloc((size_t)words * 8);
@@ -713,26 +895,86 @@ void orc_free_records(orc_records *r) {
     memset(r, 0, sizeof *r);
 }
 
-/* sort + one mapPartitions(extend pass); consumes *cur, returns the new set */
-static void sort_and_extend(orc_records *cur, int P, int k, int twin) {
+/* stable sort by key (sortByKey / sort("k-1")); consumes *cur */
+static void sort_records_w(orc_records *cur, int kw) {
     int64_t n = cur->n, words = cur->ext_off[n];
     int64_t *perm = (int64_t *)xmalloc((size_t)(n ? n : 1) * 8);
-    orc_sort_perm(cur->key, n, perm);                         /* sortByKey  :235,:247,:286 */
-    orc_records srt; rec_alloc(&srt, n ? n : 1, words ? words : 1);
-    orc_gather(perm, n, cur->key, cur->marker, cur->ext_off, cur->ext, cur->left, cur->right,
-               srt.key, srt.marker, srt.ext_off, srt.ext, srt.left, srt.right);
+    orc_sort_perm_w(cur->key, n, kw, perm);
+    orc_records srt; rec_alloc(&srt, n ? n : 1, words ? words : 1, kw);
+    orc_gather_w(perm, n, kw, cur->key, cur->marker, cur->ext_off, cur->ext, cur->left, cur->right,
+                 srt.key, srt.marker, srt.ext_off, srt.ext, srt.left, srt.right);
     srt.n = n;
     free(perm);
+    orc_free_records(cur);
+    *cur = srt;
+}
+
+/* sort + one mapPartitions(extend pass); consumes *cur, returns the new set */
+static void sort_and_extend(orc_records *cur, int P, int k, int twin, int start_marker) {
+    const int kw = orc_sub_words(k);
+    sort_records_w(cur, kw);                                  /* sortByKey  :235,:247,:286 */
+    int64_t n = cur->n, words = cur->ext_off[n];
     int64_t *ps = (int64_t *)xmalloc((size_t)(P + 1) * 8), *ops = (int64_t *)xmalloc((size_t)(P + 1) * 8);
-    orc_partition_starts(srt.key, n, P, ps);
-    orc_records out; rec_alloc(&out, n ? n : 1, words ? words : 1);
-    out.n = orc_extend_pass(srt.key, srt.marker, srt.ext_off, srt.ext, srt.left, srt.right, n,
-                            ps, P, k, twin,
-                            out.key, out.marker, out.ext_off, out.ext, out.left, out.right, ops);
+    orc_partition_starts_w(cur->key, n, kw, P, ps);
+    orc_records out; rec_alloc(&out, n ? n : 1, words ? words : 1, kw);
+    out.n = orc_extend_pass_w(cur->key, cur->marker, cur->ext_off, cur->ext, cur->left, cur->right, n,
+                              ps, P, k, twin, start_marker,
+                              out.key, out.marker, out.ext_off, out.ext, out.left, out.right, ops);
     free(ps); free(ops);
-    orc_free_records(&srt);
     orc_free_records(cur);
     *cur = out;
+}
+
+/* RC expand ... random reflection (the operators before the extend loop), shared by both drivers;
+ * kmers: n k-mers of (k-1)/31+1 words each in the assembler layout (one word for k <= 31) */
+static void records_before_loop(const uint64_t *kmers, const int32_t *counts, int64_t n, const orc_params *prm,
+                                int P, orc_records *cur) {
+    const int k = prm->k, twin = prm->twin, kw = orc_sub_words(k);
+    int64_t n2 = 2 * n;
+    int64_t a = n2 ? n2 : 1;
+    /* RC expand + forward sub-kmers  :168-176 */
+    uint64_t *key = (uint64_t *)xmalloc((size_t)a * 8 * kw), *ext = (uint64_t *)xmalloc((size_t)a * 8);
+    int32_t *marker = (int32_t *)xmalloc((size_t)a * 4), *left = (int32_t *)xmalloc((size_t)a * 4),
+            *right = (int32_t *)xmalloc((size_t)a * 4);
+    uint64_t *key2 = (uint64_t *)xmalloc((size_t)a * 8 * kw), *ext2 = (uint64_t *)xmalloc((size_t)a * 8);
+    int32_t *marker2 = (int32_t *)xmalloc((size_t)a * 4), *left2 = (int32_t *)xmalloc((size_t)a * 4),
+            *right2 = (int32_t *)xmalloc((size_t)a * 4);
+    int64_t *perm = (int64_t *)xmalloc((size_t)a * 8);
+    int64_t *ps = (int64_t *)xmalloc((size_t)(P + 1) * 8), *ps2 = (int64_t *)xmalloc((size_t)(P + 1) * 8);
+    orc_rc_expand_subkmer_w(kmers, counts, n, k, key, marker, ext, left, right);
+    int64_t m = n2;
+
+#define SORT_FIXED() do { \
+        orc_sort_perm_w(key, m, kw, perm); \
+        for (int64_t i_ = 0; i_ < m; i_++) { int64_t s_ = perm[i_]; KEYCPY(KEY(key2, i_), KEY(key, s_)); \
+            marker2[i_] = marker[s_]; ext2[i_] = ext[s_]; left2[i_] = left[s_]; right2[i_] = right[s_]; } \
+        orc_partition_starts_w(key2, m, kw, P, ps); } while (0)
+
+    /* sortByKey + forward fork filter  :179-186 */
+    SORT_FIXED();
+    m = orc_fork_filter_forward_w(key2, marker2, ext2, left2, right2, m, ps, P, k,
+                                  prm->min_error_cov, twin, key, marker, ext, left, right, ps2);
+    /* reflected extraction  :188-189 */
+    orc_reflect_from_forward_w(key, ext, m, k, key2, marker2, ext2);
+    memcpy(key, key2, (size_t)m * 8 * kw); memcpy(ext, ext2, (size_t)m * 8); memcpy(marker, marker2, (size_t)m * 4);
+    /* sortByKey + reflected fork filter  :191-198 */
+    SORT_FIXED();
+    m = orc_fork_filter_reflected_w(key2, marker2, ext2, left2, right2, m, ps, P, k,
+                                    prm->min_error_cov, twin, key, marker, ext, left, right, ps2);
+    /* random reflection on the filter's output partitions  :204-205 */
+    orc_random_reflection_w(key, marker, ext, m, ps2, P, k);
+#undef SORT_FIXED
+
+    /* move to the variable-length record set (single word == 1-word array) */
+    rec_alloc(cur, m ? m : 1, m ? m : 1, kw);
+    for (int64_t i = 0; i < m; i++) {
+        KEYCPY(KEY(cur->key, i), KEY(key, i)); cur->marker[i] = marker[i]; cur->left[i] = left[i]; cur->right[i] = right[i];
+        cur->ext[i] = ext[i]; cur->ext_off[i + 1] = i + 1;
+    }
+    cur->n = m;
+    free(key); free(ext); free(marker); free(left); free(right);
+    free(key2); free(ext2); free(marker2); free(left2); free(right2);
+    free(perm); free(ps); free(ps2);
 }
 
 int64_t orc_assemble_from_counts(const uint64_t *kmers, const int32_t *counts, int64_t n,
@@ -742,59 +984,17 @@ int64_t orc_assemble_from_counts(const uint64_t *kmers, const int32_t *counts, i
                                  orc_records *rec_out) {
     const int k = prm->k, twin = prm->twin;
     int P = prm->partitions > 0 ? prm->partitions : 1;
-    int64_t n2 = 2 * n, nt = 0;
-    int64_t a = n2 ? n2 : 1;
-    /* RC expand + forward sub-kmers  :168-176 */
-    uint64_t *key = (uint64_t *)xmalloc((size_t)a * 8), *ext = (uint64_t *)xmalloc((size_t)a * 8);
-    int32_t *marker = (int32_t *)xmalloc((size_t)a * 4), *left = (int32_t *)xmalloc((size_t)a * 4),
-            *right = (int32_t *)xmalloc((size_t)a * 4);
-    uint64_t *key2 = (uint64_t *)xmalloc((size_t)a * 8), *ext2 = (uint64_t *)xmalloc((size_t)a * 8);
-    int32_t *marker2 = (int32_t *)xmalloc((size_t)a * 4), *left2 = (int32_t *)xmalloc((size_t)a * 4),
-            *right2 = (int32_t *)xmalloc((size_t)a * 4);
-    int64_t *perm = (int64_t *)xmalloc((size_t)a * 8);
-    int64_t *ps = (int64_t *)xmalloc((size_t)(P + 1) * 8), *ps2 = (int64_t *)xmalloc((size_t)(P + 1) * 8);
-    orc_rc_expand_subkmer(kmers, counts, n, k, key, marker, ext, left, right);
-    int64_t m = n2;
-
-#define SORT_FIXED() do { \
-        orc_sort_perm(key, m, perm); \
-        for (int64_t i_ = 0; i_ < m; i_++) { int64_t s_ = perm[i_]; key2[i_] = key[s_]; \
-            marker2[i_] = marker[s_]; ext2[i_] = ext[s_]; left2[i_] = left[s_]; right2[i_] = right[s_]; } \
-        orc_partition_starts(key2, m, P, ps); } while (0)
-
-    /* sortByKey + forward fork filter  :179-186 */
-    SORT_FIXED();
-    m = orc_fork_filter_forward(key2, marker2, ext2, left2, right2, m, ps, P, k,
-                                prm->min_error_cov, twin, key, marker, ext, left, right, ps2);
-    /* reflected extraction  :188-189 */
-    orc_reflect_from_forward(key, ext, m, k, key2, marker2, ext2);
-    memcpy(key, key2, (size_t)m * 8); memcpy(ext, ext2, (size_t)m * 8); memcpy(marker, marker2, (size_t)m * 4);
-    /* sortByKey + reflected fork filter  :191-198 */
-    SORT_FIXED();
-    m = orc_fork_filter_reflected(key2, marker2, ext2, left2, right2, m, ps, P, k,
-                                  prm->min_error_cov, twin, key, marker, ext, left, right, ps2);
-    /* random reflection on the filter's output partitions  :204-205 */
-    orc_random_reflection(key, marker, ext, m, ps2, P, k);
-#undef SORT_FIXED
-
-    /* move to the variable-length record set (single word == 1-word array) */
-    orc_records cur; rec_alloc(&cur, m ? m : 1, m ? m : 1);
-    for (int64_t i = 0; i < m; i++) {
-        cur.key[i] = key[i]; cur.marker[i] = marker[i]; cur.left[i] = left[i]; cur.right[i] = right[i];
-        cur.ext[i] = ext[i]; cur.ext_off[i + 1] = i + 1;
-    }
-    cur.n = m;
-    free(key); free(ext); free(marker); free(left); free(right);
-    free(key2); free(ext2); free(marker2); free(left2); free(right2);
-    free(perm); free(ps); free(ps2);
+    int64_t nt = 0;
+    orc_records cur;
+    records_before_loop(kmers, counts, n, prm, P, &cur);
 
 #define TRACE() do { if (trace && nt < trace_cap) trace[nt] = cur.n; nt++; } while (0)
     /* 1 + 3 single-word passes, then the first-array pass  :211-254 */
     int iterations = 0;
-    sort_and_extend(&cur, P, k, twin); TRACE();
-    for (int i = 1; i < 4; i++) { iterations++; sort_and_extend(&cur, P, k, twin); TRACE(); }
+    sort_and_extend(&cur, P, k, twin, 2); TRACE();
+    for (int i = 1; i < 4; i++) { iterations++; sort_and_extend(&cur, P, k, twin, 2); TRACE(); }
     iterations++;
-    sort_and_extend(&cur, P, k, twin); TRACE();
+    sort_and_extend(&cur, P, k, twin, 2); TRACE();
     /* array loop with the stop rule  :263-296 */
     int partitionNumber = P;
     int64_t contigNumber = 0;
@@ -809,12 +1009,59 @@ int64_t orc_assemble_from_counts(const uint64_t *kmers, const int32_t *counts, i
                 P = partitionNumber;
             }
         }
-        sort_and_extend(&cur, P, k, twin); TRACE();
+        sort_and_extend(&cur, P, k, twin, 2); TRACE();
     }
-#undef TRACE
     if (n_trace) *n_trace = nt;
     int64_t len = orc_contigs_text(cur.key, cur.marker, cur.ext_off, cur.ext, cur.left, cur.right,
                                    cur.n, k, prm->min_contig, twin, out, cap, n_contigs);
+    if (rec_out) *rec_out = cur; else orc_free_records(&cur);
+    return len;
+}
+
+/* k > 31: ReflexivDSMain64.assemblyFromKmer  P/ReflexivDSMain64.java:374-826, without the
+ * from-counts extras of :584-619 and :672-712 (orientation doubling, extendable/unextendable split,
+ * end filters: SURVEY.md 8f-3) -- i.e. the loop of :621-661 iterates ALL records.  What differs
+ * from the k <= 31 driver: the stop rule starts at minimumIteration + 3 (:621), the first time the
+ * count repeats param.scramble goes 2 -> 3 instead of stopping (:639-645) and every later array pass
+ * starts its emission marker at 1 (:7484-7486; Spark evaluates the passes defined after a count() at
+ * the next action, so they see the new value), the coalesce of :651-655 is assigned to a variable the
+ * loop does not read (no effect), the surviving records are sorted once more before they become
+ * text (:714), and the header is ">Contig-<len>-<idx>" (:830-866).  prm->twin is ignored: this class
+ * has the DS arithmetic only. */
+int64_t orc_assemble_from_counts_w(const uint64_t *kmers, const int32_t *counts, int64_t n,
+                                   const orc_params *prm,
+                                   char *out, int64_t cap, int64_t *n_contigs,
+                                   int64_t *trace, int64_t trace_cap, int64_t *n_trace,
+                                   orc_records *rec_out) {
+    orc_params q = *prm; q.twin = ORC_TWIN_DS;
+    const int k = q.k, kw = orc_sub_words(k);
+    const int P = q.partitions > 0 ? q.partitions : 1;
+    int64_t nt = 0;
+    orc_records cur;
+    records_before_loop(kmers, counts, n, &q, P, &cur);                       /* :458-531 */
+    int iterations = 0;
+    sort_and_extend(&cur, P, k, ORC_TWIN_DS, 2); TRACE();                     /* :533-540 */
+    for (int i = 1; i < 4; i++) { iterations++; sort_and_extend(&cur, P, k, ORC_TWIN_DS, 2); TRACE(); }   /* :543-548 */
+    iterations++;                                                             /* :553 */
+    sort_and_extend(&cur, P, k, ORC_TWIN_DS, 2); TRACE();                     /* :550-563 */
+    int64_t contigNumber = 0;
+    int scramble = 2;                                                         /* U/DefaultParam.java:131 */
+    while (iterations <= q.max_iter) {                                        /* :582 */
+        iterations++;
+        if (iterations >= q.min_iter + 3 && iterations % 3 == 0) {            /* :621-622 */
+            int64_t current = cur.n;                                          /* :633-635 */
+            if (contigNumber == current) {                                    /* :639 */
+                if (scramble == 2) { scramble = 3; contigNumber = current; }  /* :640-642 */
+                else break;                                                   /* :644 */
+            } else contigNumber = current;                                    /* :647 */
+        }
+        sort_and_extend(&cur, P, k, ORC_TWIN_DS, scramble == 3 ? 1 : 2); TRACE();   /* :659-660 / :667-669 */
+    }
+#undef TRACE
+    if (n_trace) *n_trace = nt;
+    sort_records_w(&cur, kw);                                                 /* :714 */
+    int64_t len = orc_contigs_text_w(cur.key, cur.marker, cur.ext_off, cur.ext, cur.left, cur.right,
+                                     cur.n, k, q.min_contig, out, cap, n_contigs);
     if (rec_out) *rec_out = cur; else orc_free_records(&cur);
     return len;
 }

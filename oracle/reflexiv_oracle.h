@@ -183,6 +183,78 @@ int64_t orc_count_filter_w(uint64_t *kmers, int64_t n, int k, int min_cov, int m
 /* DSBinaryKmerToString.call :340-369: the k characters of one k-mer (no terminator). */
 void orc_kmer_text_w(const uint64_t *kmer, int k, char *out);
 
+
+/* ---- k > 31: the assembler's twin  P/ReflexivDSMain64.java:374-826 (assemblyFromKmer).
+ * Keys are (k-1)-mers in orc_sub_words(k) = (k-2)/31+1 words of 31 bases, the last word holding the
+ * remaining (k-2)%31+1 bases right-aligned (U/DefaultParam.java:93-94); key arrays are AoS, kw
+ * consecutive words per record, as the reference's Row(long[]).  k-mers entering the path hold k
+ * bases in orc_asm_words(k) = (k-1)/31+1 such words (KmerBinarizer :10812-10819) -- NOT the counter's
+ * 32-bases-per-word layout; the two meet through CSV text only (orc_counter_to_asm_w restates that
+ * round trip).  Extensions, markers and left/right are as for k <= 31.  The _w operators accept any
+ * k >= 3 (kw = 1 up to k = 32) and are what the k <= 31 entry points above call with kw = 1.
+ * Flips and merges are restated at sequence level; SURVEY.md C.9 records the one case where the
+ * reference's bit code differs (first-array stage, forward output, 16 + 16 bases: P/ReflexivDSMain64.java
+ * :9377-9379 leaves 15 junk bases above the length marker) -- the oracle keeps the sequence model.
+ * Parity pin: NONE held by the reference for k > 31 (the documented example is k = 31): "parity
+ * unpinned" beyond the cross-check against tests/pymodel.py and the k = 31 agreement of the shared code. */
+int orc_sub_words(int k);
+int orc_asm_words(int k);
+/* KmerBinarizer.call :10772-10836, one CSV row */
+int orc_kmer_binarize_w(const char *kmer_text, const char *count_text, int k, uint64_t *words, int32_t *cover);
+/* counter layout (k/32+1 words of 32 bases) -> assembler layout, as the CSV round trip does */
+void orc_counter_to_asm_w(const uint64_t *kmers32, int64_t n, int k, uint64_t *kmers31);
+/* DSKmerReverseComplement :10706-10755 + DSForwardSubKmerExtraction :10363-10403 */
+void orc_rc_expand_subkmer_w(const uint64_t *kmers, const int32_t *counts, int64_t n, int k,
+                             uint64_t *key, int32_t *marker, uint64_t *ext,
+                             int32_t *left, int32_t *right);
+void orc_sort_perm_w(const uint64_t *key, int64_t n, int kw, int64_t *perm);
+void orc_partition_starts_w(const uint64_t *sorted_key, int64_t n, int kw, int P, int64_t *start);
+/* DSFilterForkSubKmer[WithErrorCorrection] :10072-10208 */
+int64_t orc_fork_filter_forward_w(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
+                                  const int32_t *left, const int32_t *right, int64_t n,
+                                  const int64_t *part_start, int P,
+                                  int k, int min_error_cov, int twin,
+                                  uint64_t *okey, int32_t *omarker, uint64_t *oext,
+                                  int32_t *oleft, int32_t *oright, int64_t *out_part_start);
+/* DSReflectedSubKmerExtractionFromForward :10426-10475 */
+void orc_reflect_from_forward_w(const uint64_t *key, const uint64_t *ext, int64_t n, int k,
+                                uint64_t *okey, int32_t *omarker, uint64_t *oext);
+/* DSFilterForkReflectedSubKmer[WithErrorCorrection] :10210-10360 */
+int64_t orc_fork_filter_reflected_w(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
+                                    const int32_t *left, const int32_t *right, int64_t n,
+                                    const int64_t *part_start, int P,
+                                    int k, int min_error_cov, int twin,
+                                    uint64_t *okey, int32_t *omarker, uint64_t *oext,
+                                    int32_t *oleft, int32_t *oright, int64_t *out_part_start);
+/* DSkmerRandomReflection :10491-10690 */
+void orc_random_reflection_w(uint64_t *key, int32_t *marker, uint64_t *ext, int64_t n,
+                             const int64_t *part_start, int P, int k);
+/* DSExtendReflexivKmer :9465-10070, ...ToArrayFirstTime :8733-9463, ...ToArrayLoop :7446-8731.
+ * start_marker: the value randomReflexivMarker has when a task starts (2; 1 once param.scramble == 3,
+ * :7484-7486). */
+int64_t orc_extend_pass_w(const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
+                          const uint64_t *ext, const int32_t *left, const int32_t *right,
+                          int64_t n, const int64_t *part_start, int P, int k, int twin, int start_marker,
+                          uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext,
+                          int32_t *oleft, int32_t *oright, int64_t *out_part_start);
+void orc_gather_w(const int64_t *perm, int64_t n, int kw,
+                  const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
+                  const uint64_t *ext, const int32_t *left, const int32_t *right,
+                  uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext,
+                  int32_t *oleft, int32_t *oright);
+/* DSBinaryReflexivKmerArrayToString :1913-1975 + DSKmerToContig :842-892 + TagRowContigID :830-841 */
+int64_t orc_contigs_text_w(const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
+                           const uint64_t *ext, const int32_t *left, const int32_t *right,
+                           int64_t n, int k, int min_contig,
+                           char *out, int64_t cap, int64_t *n_contigs);
+/* assemblyFromKmer :374-826 without the extras of :584-619 / :672-712 (see the .c file) from the
+ * filtered (k-mer, count) list in ascending order, k-mers in the assembler layout. */
+int64_t orc_assemble_from_counts_w(const uint64_t *kmers, const int32_t *counts, int64_t n,
+                                   const orc_params *prm,
+                                   char *out, int64_t cap, int64_t *n_contigs,
+                                   int64_t *trace, int64_t trace_cap, int64_t *n_trace,
+                                   orc_records *rec_out);
+
 /* Synthetic reads, integer-only counter-based generator shared
  * bit-for-bit with reflexiv_amd/csrc (rfx_synth_*). */
 uint64_t orc_splitmix64(uint64_t x);

@@ -130,11 +130,11 @@ def random_reflection(recs, starts, sub):
     return out
 
 
-def extend_pass(recs, starts, sub, rdd=False):
+def extend_pass(recs, starts, sub, rdd=False, start_marker=2):
     out, ostarts = [], []
     for p in range(len(starts) - 1):
         ostarts.append(len(out))
-        m = 2
+        m = start_marker
         holder = None
 
         def flip(r):
@@ -215,3 +215,64 @@ def assemble(kmers, counts, k=31, P=4, min_err=8, min_iter=15, max_iter=150, ds=
             last = len(recs)
         recs = one_pass(recs)
     return recs
+
+
+# ---- k > 31: P/ReflexivDSMain64.java assemblyFromKmer (:374-826) without the extras of :584-619 / :672-712
+
+def rc_expand_str(kmers, counts):
+    """kmers as ACGT strings (the CSV rows KmerBinarizer reads)."""
+    out = []
+    for s, c in zip(kmers, counts):
+        for t in (s, revcomp(s)):
+            out.append((t[:-1], 1, t[-1], c, c))
+    return out
+
+
+def contigs_text_w(recs, min_contig):
+    """DSKmerToContig + TagRowContigID of ReflexivDSMain64 (:830-892): '>Contig-<len>-<idx>', 100 columns."""
+    out, idx = [], 0
+    for r in recs:
+        s = seq_of(r)
+        if len(s) < min_contig:
+            continue
+        out.append(f">Contig-{len(s)}-{idx}\n" + "\n".join(s[i:i + 100] for i in range(0, len(s), 100)) + "\n")
+        idx += 1
+    return "".join(out), idx
+
+
+def assemble_w(kmers, counts, k, P=4, min_err=8, min_iter=15, max_iter=150, trace=None):
+    """kmers: ascending ACGT strings.  Stop rule of :621-661: checks from min_iter + 3 on, the first repeat
+    of the count switches param.scramble 2 -> 3 (every later pass starts its marker at 1), the second stops;
+    the survivors are sorted by key before they become text (:714)."""
+    sub = k - 1
+    recs = stable_sort(rc_expand_str(kmers, counts))
+    recs, _ = fork_forward(recs, partition_starts([r[0] for r in recs], P), sub, min_err, True)
+    recs = stable_sort(reflect(recs))
+    recs, st = fork_reflected(recs, partition_starts([r[0] for r in recs], P), sub, min_err, True)
+    recs = random_reflection(recs, st, sub)
+
+    def one_pass(recs, start=2):
+        recs = stable_sort(recs)
+        out, _ = extend_pass(recs, partition_starts([r[0] for r in recs], P), sub, rdd=False, start_marker=start)
+        if trace is not None:
+            trace.append(len(out))
+        return out
+    it = 0
+    recs = one_pass(recs)
+    for _ in range(3):
+        it += 1
+        recs = one_pass(recs)
+    it += 1
+    recs = one_pass(recs)
+    last, scramble = 0, 2
+    while it <= max_iter:
+        it += 1
+        if it >= min_iter + 3 and it % 3 == 0:
+            if last == len(recs):
+                if scramble == 2:
+                    scramble = 3
+                else:
+                    break
+            last = len(recs)
+        recs = one_pass(recs, 1 if scramble == 3 else 2)
+    return stable_sort(recs)

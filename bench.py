@@ -167,7 +167,6 @@ def main():
     nk = rfx.kmers_per_read_w(L, k) if wide else rfx.kmers_per_read(L, k)
     n_inst = nk * n_reads                                     # instances per rank per step
     if wide:
-        args.no_contigs = True                                # the assembler's k > 31 twin is SURVEY.md 8f-3
         args.no_cpu_baseline = True
 
     # synthetic reads straight into HBM, 2-bit packed (data = "synthetic")
@@ -290,24 +289,42 @@ def main():
         # and run the extend stage on that one GPU
         torch.cuda.synchronize()
         t_g = time.perf_counter()
-        gk, gc = rd.gather_survivors(shard["keys"], shard["counts"])
+        gk, gc = rd.gather_survivors(shard["keys"], shard["counts"], words=W)
         if rank == 0:
-            m = int(gk.numel())
+            m = int(gc.numel())
             gk = gk.contiguous(); gc = gc.contiguous()
-            tk = torch.empty_like(gk); tv = torch.empty_like(gc)
             torch.cuda.synchronize()
-            rfx.sort_pairs_dev(gk.data_ptr(), gc.data_ptr(), m, 2 * k, tk.data_ptr(), tv.data_ptr())
+            if wide:
+                rfx.order_kmers_w_dev(gk.data_ptr(), gc.data_ptr(), m, k)
+            else:
+                tk = torch.empty_like(gk); tv = torch.empty_like(gc)
+                rfx.sort_pairs_dev(gk.data_ptr(), gc.data_ptr(), m, 2 * k, tk.data_ptr(), tv.data_ptr())
             rfx.sync()
             d_keys, d_counts = gk, gc
         t_gather = time.perf_counter() - t_g
     if rank == 0 and not args.no_contigs:
         prm = reflexiv_amd.default_params(k=k, min_cov=args.cover, partitions=args.partitions)
+        if wide:
+            # the counter's 32-bases-per-word k-mers -> the assembler's 31-bases-per-word layout + its count filter
+            # (KmerBinarizer, P/ReflexivDSMain64.java:10772-10836, :473-478), then assemblyFromKmer (:458-826)
+            aw = (k - 1) // 31 + 1
+            a_k = torch.empty(max(1, m) * aw, dtype=torch.int64, device=dev)
+            a_c = torch.empty(max(1, m), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+
+            def assemble():
+                m2 = rfx.counter_to_asm_dev(d_keys.data_ptr(), d_counts.data_ptr(), m, k, a_k.data_ptr(), a_c.data_ptr(),
+                                            args.cover)
+                return rfx.assemble_w_dev(a_k.data_ptr(), a_c.data_ptr(), m2, prm)
+        else:
+            def assemble():
+                return rfx.assemble_dev(d_keys.data_ptr(), d_counts.data_ptr(), m, prm)
         # one untimed run first, like the count stage's warm-up steps: the first call of a process loads the
         # extend kernels and grows the record arenas (30 .. 120 ms on a fresh box against 30 ms after)
-        rfx.assemble_dev(d_keys.data_ptr(), d_counts.data_ptr(), m, prm)
+        assemble()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        text, nc, trace = rfx.assemble_dev(d_keys.data_ptr(), d_counts.data_ptr(), m, prm)
+        text, nc, trace = assemble()
         t_asm = time.perf_counter() - t1
         if multi:
             t_asm += t_gather

@@ -51,7 +51,7 @@ typedef struct rfx_ctx rfx_ctx;
 
 /* U/DefaultParam.java:74-120 -- the fields that reach the hot path. */
 typedef struct {
-    int32_t k;               /* kmerSize (<= 31 in this build)                 :74  */
+    int32_t k;               /* kmerSize (<= 31: rfx_dev_assemble; 32..125: rfx_dev_assemble_w)  :74  */
     int32_t min_cov;         /* minKmerCoverage                                :103 */
     int32_t max_cov;         /* maxKmerCoverage                                :104 */
     int32_t min_error_cov;   /* minErrorCoverage (4 * 2)                       :105 */
@@ -81,6 +81,11 @@ typedef struct {
     int64_t   cap_words;
     int64_t   need_n;      /* set by the callee: records / words the output needs */
     int64_t   need_words;
+    int32_t   key_words;   /* words per key: 0 or 1 for k <= 32; (k-2)/31+1 for k > 32, key then holds n * key_words
+                            * words, record i at key[i * key_words ..] (31 bases per word, the last word the remaining
+                            * (k-2)%31+1 bases right-aligned: P/ReflexivDSMain64.java, U/DefaultParam.java:93-94).
+                            * The callee sets it on output records. */
+    int32_t   reserved_;
 } rfx_records;
 
 /* ------------------------------------------------------------------ context */
@@ -170,6 +175,23 @@ int rfx_random_reflection(rfx_ctx *ctx, const rfx_records *in, const int64_t *pa
  * word layout; stage 0 additionally checks that every output fits one word. */
 int rfx_extend_pass(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P,
                     int k, int twin, int stage, rfx_records *out, int64_t *out_part_start);
+
+/* ---- k > 31: the assembler's twin P/ReflexivDSMain64.java (assemblyFromKmer :374-826) ----
+ * Every record operator above also takes k = 32 .. 125: keys are then (k-1)-mers of key_words = (k-2)/31+1 words
+ * (rfx_records.key_words; 31 bases per word), the class bodies replaced are DSKmerReverseComplement +
+ * DSForwardSubKmerExtraction (:10706-10755, :10363-10403; rfx_rc_expand_subkmer: k-mers of (k-1)/31+1 words each in
+ * the layout KmerBinarizer writes, :10812-10819 -- NOT the counter's 32-bases-per-word layout), sort("k-1"),
+ * DSFilterForkSubKmer[WithErrorCorrection] (:10072-10208), DSReflectedSubKmerExtractionFromForward (:10426-10475),
+ * DSFilterForkReflectedSubKmer[WithErrorCorrection] (:10210-10360), DSkmerRandomReflection (:10491-10690),
+ * DSExtendReflexivKmer / ...ToArrayFirstTime / ...ToArrayLoop (:9465-10070, :8733-9463, :7446-8731; twin is ignored,
+ * this class has the DS arithmetic only) and DSBinaryReflexivKmerArrayToString + DSKmerToContig + TagRowContigID
+ * (:1913-1975, :842-892, :830-841; header ">Contig-<len>-<idx>").  Flips and merges follow the sequence model
+ * (SURVEY.md B.7); the one case where the reference's bit code differs is recorded in SURVEY.md C.9. */
+
+/* DSExtendReflexivKmerToArrayLoop.call with param.scramble (2 or 3) as the class reads it (:7484-7486: the task's
+ * emission marker starts at 1 instead of 2 once scramble == 3).  Any k the record operators take. */
+int rfx_extend_pass_w(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P, int k, int stage,
+                      int scramble, rfx_records *out, int64_t *out_part_start);
 
 /* BinaryReflexivKmerArrayToString + KmerToContig + TagContigID
  * P/ReflexivMain.java:696-741, 590-637, 573-581 (DS :855-900, :743-795, :717-725):
@@ -300,6 +322,27 @@ int rfx_dev_merge_pairs(rfx_ctx *ctx, const void *d_pairs, int64_t n_pairs, int 
 int rfx_dev_assemble(rfx_ctx *ctx, const uint64_t *d_keys, const int32_t *d_counts, int64_t n,
                      const rfx_params *prm, char *out, int64_t cap, int64_t *out_len,
                      int64_t *out_contigs, int64_t *trace, int64_t trace_cap, int64_t *n_trace);
+
+/* k = 33..63: put (two-word k-mer, count) pairs that are in any order (e.g. the shards of the hash-partitioned count
+ * gathered from several GPUs) into ascending k-mer order in place -- the order rfx_dev_count_reads_w returns and the
+ * from-counts driver expects (order contract: ascending by base string). */
+int rfx_dev_order_kmers_w(rfx_ctx *ctx, uint64_t *d_keys, int64_t *d_counts, int64_t n, int k);
+
+/* KmerBinarizer.call + the count filter of the from-counts driver (P/ReflexivDSMain64.java:10772-10836, :473-478) for
+ * k-mers that never left HBM: the counter's output (k/32+1 words of 32 bases per k-mer, int64 counts, ascending) ->
+ * the assembler's input ((k-1)/31+1 words of 31 bases, int32 counts read as the CSV text would be: 10 digits or more
+ * = 1000000000), keeping min_cov <= count <= max_cov.  Output buffers hold n entries.  All device pointers. */
+int rfx_dev_counter_to_asm(rfx_ctx *ctx, const uint64_t *d_keys32, const int64_t *d_counts64, int64_t n, int k,
+                           int min_cov, int max_cov, uint64_t *d_out_kmers, int32_t *d_out_counts, int64_t *out_n);
+
+/* Whole k > 31 driver ReflexivDSMain64.assemblyFromKmer (P/ReflexivDSMain64.java:458-826) from the filtered, ascending
+ * (k-mer, count) list in HBM (assembler layout) to the contig text, WITHOUT the from-counts extras of :584-619 and
+ * :672-712 (orientation doubling, extendable / unextendable split, end filters): the loop of
+ * :621-661 iterates all records.  Stop rule as there: checked from minimumIteration + 3 on, the first repeat of the
+ * count sets param.scramble = 3 (later passes start their emission marker at 1), the second stops. */
+int rfx_dev_assemble_w(rfx_ctx *ctx, const uint64_t *d_kmers, const int32_t *d_counts, int64_t n,
+                       const rfx_params *prm, char *out, int64_t cap, int64_t *out_len,
+                       int64_t *out_contigs, int64_t *trace, int64_t trace_cap, int64_t *n_trace);
 
 /* The whole resident path from ASCII reads in host memory (any lengths) to the contig text:
  * upload, 2-bit encode, extract + count + filter (prm->min_cov .. max_cov), the driver above --

@@ -36,7 +36,8 @@ class CRecords(C.Structure):
     """rfx_records."""
     _fields_ = [("n", C.c_int64), ("key", C.c_void_p), ("marker", C.c_void_p), ("ext_off", C.c_void_p),
                 ("ext", C.c_void_p), ("left", C.c_void_p), ("right", C.c_void_p),
-                ("cap_n", C.c_int64), ("cap_words", C.c_int64), ("need_n", C.c_int64), ("need_words", C.c_int64)]
+                ("cap_n", C.c_int64), ("cap_words", C.c_int64), ("need_n", C.c_int64), ("need_words", C.c_int64),
+                ("key_words", C.c_int32), ("reserved_", C.c_int32)]
 
 
 # every symbol include/reflexiv_hip.h declares (checked by tests/test_abi.py)
@@ -54,6 +55,7 @@ SYMBOLS = [
     "rfx_dev_count_reads_ragged", "rfx_assemble_reads", "rfx_dev_bucket_wide_by_owner", "rfx_dev_count_wide_elems",
     "rfx_dev_combine_reads", "rfx_dev_bucket_pairs_by_owner", "rfx_dev_merge_pairs",
     "rfx_dev_bucket_wide_records_by_owner", "rfx_dev_count_wide_records",
+    "rfx_extend_pass_w", "rfx_dev_counter_to_asm", "rfx_dev_assemble_w", "rfx_dev_order_kmers_w",
 ]
 
 

@@ -34,8 +34,14 @@ class Records:
     def n(self) -> int:
         return int(self.key.shape[0])
 
+    @property
+    def kw(self) -> int:
+        """words per key: 1 (key is uint64[n]) or the second dimension of uint64[n, kw] (k > 32)"""
+        return 1 if self.key.ndim == 1 else int(self.key.shape[1])
+
     def tuple_list(self):
-        return [(int(self.key[i]), int(self.marker[i]),
+        kk = [int(x) for x in self.key] if self.key.ndim == 1 else [tuple(int(x) for x in r) for r in self.key]
+        return [(kk[i], int(self.marker[i]),
                  tuple(int(x) for x in self.ext[self.ext_off[i]:self.ext_off[i + 1]]),
                  int(self.left[i]), int(self.right[i])) for i in range(self.n)]
 
@@ -45,12 +51,14 @@ class Records:
         c.key, c.marker, c.ext_off = _p(self.key), _p(self.marker), _p(self.ext_off)
         c.ext, c.left, c.right = _p(self.ext), _p(self.left), _p(self.right)
         c.cap_n, c.cap_words = self.n, len(self.ext)
+        c.key_words = self.kw
         return c
 
     @staticmethod
-    def empty(cap_n: int, cap_words: int) -> "Records":
+    def empty(cap_n: int, cap_words: int, kw: int = 1) -> "Records":
         cap_n, cap_words = max(1, cap_n), max(1, cap_words)
-        return Records(np.empty(cap_n, np.uint64), np.empty(cap_n, np.int32), np.empty(cap_n + 1, np.int64),
+        key = np.empty(cap_n, np.uint64) if kw == 1 else np.empty((cap_n, kw), np.uint64)
+        return Records(key, np.empty(cap_n, np.int32), np.empty(cap_n + 1, np.int64),
                        np.empty(cap_words, np.uint64), np.empty(cap_n, np.int32), np.empty(cap_n, np.int32))
 
     def _trim(self, c: CRecords) -> "Records":
@@ -65,6 +73,16 @@ def as_records(r) -> Records:
     return Records(np.ascontiguousarray(r.key, np.uint64), np.ascontiguousarray(r.marker, np.int32),
                    np.ascontiguousarray(r.ext_off, np.int64), np.ascontiguousarray(r.ext, np.uint64),
                    np.ascontiguousarray(r.left, np.int32), np.ascontiguousarray(r.right, np.int32))
+
+
+def sub_words(k: int) -> int:
+    """words of a (k-1)-mer key (subKmerBinarySlots, U/DefaultParam.java:94): 1 up to k = 32"""
+    return 1 if k <= 32 else (k - 2) // 31 + 1
+
+
+def asm_words(k: int) -> int:
+    """words of a k-mer in the assembler's 31-bases-per-word layout (kmerBinarySlotsAssemble, :85)"""
+    return 1 if k <= 31 else (k - 1) // 31 + 1
 
 
 def default_params(**kw) -> Params:
@@ -184,10 +202,13 @@ class Reflexiv:
         return int(n.value), int(d.value), int(inst.value)
 
     def KmerReverseComplement_and_ForwardSubKmerExtraction(self, keys, counts, k=31) -> Records:
+        """k > 31 (DSKmerReverseComplement + DSForwardSubKmerExtraction of ReflexivDSMain64): keys uint64[n, (k-1)//31+1]
+        in the assembler layout."""
         keys = np.ascontiguousarray(keys, np.uint64)
         counts = np.ascontiguousarray(counts, np.int32)
-        n = len(keys)
-        out = Records.empty(2 * n, 2 * n)
+        n = len(counts)
+        assert keys.size == n * asm_words(k), (keys.shape, k)
+        out = Records.empty(2 * n, 2 * n, sub_words(k))
         c = out._c(); c.cap_n = 2 * n; c.cap_words = 2 * n
         self._check(self.L.rfx_rc_expand_subkmer(self.ctx, _p(keys), _p(counts), C.c_int64(n), k, C.byref(c)),
                     "rfx_rc_expand_subkmer")
@@ -196,7 +217,7 @@ class Reflexiv:
     def sortByKey(self, r, P: int):
         """-> (sorted Records, part_start[P+1])."""
         r = as_records(r)
-        out = Records.empty(r.n, len(r.ext))
+        out = Records.empty(r.n, len(r.ext), r.kw)
         ci, co = r._c(), out._c()
         co.cap_n, co.cap_words = r.n, len(r.ext)
         ps = np.empty(P + 1, np.int64)
@@ -207,7 +228,7 @@ class Reflexiv:
         r = as_records(r)
         part_start = np.ascontiguousarray(part_start, np.int64)
         P = len(part_start) - 1
-        out = Records.empty(r.n, r.n)
+        out = Records.empty(r.n, r.n, r.kw)
         ci, co = r._c(), out._c()
         co.cap_n, co.cap_words = r.n, r.n
         ops = np.empty(P + 1, np.int64)
@@ -224,7 +245,7 @@ class Reflexiv:
 
     def ReflectedSubKmerExtractionFromForward(self, r, k=31) -> Records:
         r = as_records(r)
-        out = Records.empty(r.n, r.n)
+        out = Records.empty(r.n, r.n, r.kw)
         ci, co = r._c(), out._c()
         co.cap_n, co.cap_words = r.n, r.n
         self._check(self.L.rfx_reflect_from_forward(self.ctx, C.byref(ci), k, C.byref(co)),
@@ -234,24 +255,30 @@ class Reflexiv:
     def kmerRandomReflection(self, r, part_start, k=31) -> Records:
         r = as_records(r)
         part_start = np.ascontiguousarray(part_start, np.int64)
-        out = Records.empty(r.n, r.n)
+        out = Records.empty(r.n, r.n, r.kw)
         ci, co = r._c(), out._c()
         co.cap_n, co.cap_words = r.n, r.n
         self._check(self.L.rfx_random_reflection(self.ctx, C.byref(ci), _p(part_start), len(part_start) - 1, k,
                                                  C.byref(co)), "rfx_random_reflection")
         return out._trim(co)
 
-    def ExtendReflexivKmer(self, r, part_start, k=31, twin=TWIN_DS, stage=2):
-        """One extend pass (stage 0: ExtendReflexivKmer, 1: ...ToArrayFirstTime, 2: ...ToArrayLoop)."""
+    def ExtendReflexivKmer(self, r, part_start, k=31, twin=TWIN_DS, stage=2, scramble=2):
+        """One extend pass (stage 0: ExtendReflexivKmer, 1: ...ToArrayFirstTime, 2: ...ToArrayLoop).
+        scramble = 3: DSExtendReflexivKmerToArrayLoop of ReflexivDSMain64 after param.scramble went to 3
+        (the task's emission marker starts at 1, :7484-7486)."""
         r = as_records(r)
         part_start = np.ascontiguousarray(part_start, np.int64)
         P = len(part_start) - 1
-        out = Records.empty(r.n, len(r.ext))
+        out = Records.empty(r.n, len(r.ext), r.kw)
         ci, co = r._c(), out._c()
         co.cap_n, co.cap_words = r.n, len(r.ext)
         ops = np.empty(P + 1, np.int64)
-        self._check(self.L.rfx_extend_pass(self.ctx, C.byref(ci), _p(part_start), P, k, twin, stage, C.byref(co),
-                                           _p(ops)), "rfx_extend_pass")
+        if scramble != 2:
+            self._check(self.L.rfx_extend_pass_w(self.ctx, C.byref(ci), _p(part_start), P, k, stage, scramble,
+                                                 C.byref(co), _p(ops)), "rfx_extend_pass_w")
+        else:
+            self._check(self.L.rfx_extend_pass(self.ctx, C.byref(ci), _p(part_start), P, k, twin, stage, C.byref(co),
+                                               _p(ops)), "rfx_extend_pass")
         return out._trim(co), ops
 
     def KmerToContig(self, r, k=31, min_contig=500, twin=TWIN_DS):
@@ -449,6 +476,33 @@ class Reflexiv:
         self._check(self.L.rfx_dev_assemble(self.ctx, C.c_void_p(d_keys), C.c_void_p(d_counts), C.c_int64(n),
                                             C.byref(prm), _p(buf), C.c_int64(cap), C.byref(ln), C.byref(nc),
                                             _p(trace), C.c_int64(len(trace)), C.byref(ntr)), "rfx_dev_assemble")
+        return bytes(buf[:ln.value]).decode(), int(nc.value), [int(x) for x in trace[:ntr.value]]
+
+    def order_kmers_w_dev(self, d_keys: int, d_counts: int, n: int, k: int):
+        """k = 33..63: (two-word k-mer, int64 count) pairs in any order -> ascending k-mer order, in place."""
+        self._check(self.L.rfx_dev_order_kmers_w(self.ctx, C.c_void_p(d_keys), C.c_void_p(d_counts), C.c_int64(n), k),
+                    "rfx_dev_order_kmers_w")
+
+    def counter_to_asm_dev(self, d_keys32: int, d_counts64: int, n: int, k: int, d_out_kmers: int, d_out_counts: int,
+                           min_cov=2, max_cov=10_000_000) -> int:
+        """KmerBinarizer + the from-counts filter (P/ReflexivDSMain64.java:10772-10836, :473-478) in HBM: the counter's
+        (k//32+1)-word k-mers and int64 counts -> (k-1)//31+1 words of 31 bases and int32 counts -> kept."""
+        m = C.c_int64(0)
+        self._check(self.L.rfx_dev_counter_to_asm(self.ctx, C.c_void_p(d_keys32), C.c_void_p(d_counts64), C.c_int64(n), k,
+                                                  min_cov, max_cov, C.c_void_p(d_out_kmers), C.c_void_p(d_out_counts),
+                                                  C.byref(m)), "rfx_dev_counter_to_asm")
+        return int(m.value)
+
+    def assemble_w_dev(self, d_kmers: int, d_counts: int, n: int, prm: Params):
+        """k > 31 driver ReflexivDSMain64.assemblyFromKmer (:458-826, without the extras of :584-619 / :672-712)
+        from the filtered (k-mer, count) list in HBM (assembler layout) -> (contig text, n_contigs, trace)."""
+        trace = np.zeros(prm.max_iter + 8, np.int64)
+        ln, nc, ntr = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        cap = 4 * (n + 16) * (prm.k + 8) + 1024
+        buf = np.empty(cap, np.uint8)
+        self._check(self.L.rfx_dev_assemble_w(self.ctx, C.c_void_p(d_kmers), C.c_void_p(d_counts), C.c_int64(n),
+                                              C.byref(prm), _p(buf), C.c_int64(cap), C.byref(ln), C.byref(nc),
+                                              _p(trace), C.c_int64(len(trace)), C.byref(ntr)), "rfx_dev_assemble_w")
         return bytes(buf[:ln.value]).decode(), int(nc.value), [int(x) for x in trace[:ntr.value]]
 
     def synth_genome_dev(self, seed: int, genome_len: int, d_genome: int):

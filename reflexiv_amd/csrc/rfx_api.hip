@@ -10,6 +10,9 @@ using namespace rfx;
 namespace {
 
 int check_k(int k) { return (k >= 3 && k <= 31) ? RFX_OK : RFX_E_ARG; }
+// record operators: any k whose (k-1)-mer key fits MAX_KEY_WORDS words of 31 bases
+int check_k_rec(int k) { return (k >= 3 && sub_words(k) <= MAX_KEY_WORDS) ? RFX_OK : RFX_E_ARG; }
+int check_kw(const rfx_records *r, int k) { return (r->key_words > 1 ? r->key_words : 1) == sub_words(k) ? RFX_OK : RFX_E_ARG; }
 
 int download_to(rfx_ctx *ctx, const DevRecords &d, rfx_records *out) {
     if (!out) return RFX_E_ARG;
@@ -32,10 +35,13 @@ int download_part_start(rfx_ctx *ctx, const DevBuf &d, int P, int64_t *h) {
 }
 
 // a-15 on the host (tiny): BinaryReflexivKmerArrayToString + KmerToContig + TagContigID
+// k > 31 (P/ReflexivDSMain64.java:830-866, 1913-1975): the RDD-style header, no skip rule
 int64_t contigs_text_host(const rfx_records *r, int k, int min_contig, int twin, char *out, int64_t cap,
                           int64_t *n_contigs) {
     static const char NUC[4] = {'A', 'C', 'G', 'T'};
     const int sub = k - 1;
+    const int kw = r->key_words > 1 ? r->key_words : 1;
+    if (k > 31) twin = RFX_TWIN_RDD;
     int64_t pos = 0, idx = 0;
     std::vector<char> b;
     auto putc_ = [&](char c) { if (pos < cap) out[pos] = c; pos++; };
@@ -57,7 +63,14 @@ int64_t contigs_text_host(const rfx_records *r, int k, int min_contig, int twin,
         b.resize((size_t)len);
         char *e = r->marker[i] == 1 ? b.data() + sub : b.data();           // :593-594 / :603-604
         char *kb = r->marker[i] == 1 ? b.data() : b.data() + L;
-        for (int j = 0; j < sub; j++) kb[j] = NUC[(r->key[i] >> (2 * (sub - 1 - j))) & 3];         // :704-709
+        {                                                                                          // :704-709 / 64 :1928-1940
+            const uint64_t *kp = r->key + (size_t)i * kw;
+            int o2 = 0;
+            for (int w2 = 0; w2 < kw; w2++) {
+                const int nb = w2 < kw - 1 ? 31 : sub - 31 * (kw - 1);
+                for (int j = 0; j < nb; j++) kb[o2++] = NUC[(kp[w2] >> (2 * (nb - 1 - j))) & 3];
+            }
+        }
         int64_t o = 0;
         for (int j = 0; j < f; j++) e[o++] = NUC[(w[0] >> (2 * (f - 1 - j))) & 3];                 // :713-718
         for (int64_t x = 1; x < nw; x++) {                                                         // :720-729
@@ -89,6 +102,7 @@ struct HostRecords {
     void resize(int64_t n, int64_t words) {
         key.resize((size_t)std::max<int64_t>(n, 1)); marker.resize(key.size()); left.resize(key.size());
         right.resize(key.size()); ext_off.resize((size_t)n + 1); ext.resize((size_t)std::max<int64_t>(words, 1));
+        view = rfx_records{};
         view.n = 0; view.key = key.data(); view.marker = marker.data(); view.ext_off = ext_off.data();
         view.ext = ext.data(); view.left = left.data(); view.right = right.data(); view.cap_n = n;
         view.cap_words = words;
@@ -377,13 +391,14 @@ int rfx_count_filter(rfx_ctx *ctx, const uint64_t *kmers, int64_t n, int min_cov
 int rfx_rc_expand_subkmer(rfx_ctx *ctx, const uint64_t *kmers, const int32_t *counts, int64_t n, int k,
                           rfx_records *out) {
     if (!ctx || n < 0 || !out) return RFX_E_ARG;
-    RFX_TRY(check_k(k));
+    RFX_TRY(check_k_rec(k));
     RFX_HIP(hipSetDevice(ctx->device));
     DevBuf dk, dc;
-    RFX_HIP(dk.alloc((size_t)n * 8, ctx->stream));
+    const int aw = asm_words(k);
+    RFX_HIP(dk.alloc((size_t)n * 8 * aw, ctx->stream));
     RFX_HIP(dc.alloc((size_t)n * 4, ctx->stream));
     if (n > 0) {
-        RFX_HIP(hipMemcpyAsync(dk.p, kmers, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(dk.p, kmers, (size_t)n * 8 * aw, hipMemcpyHostToDevice, ctx->stream));
         RFX_HIP(hipMemcpyAsync(dc.p, counts, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     }
     DevRecords r;
@@ -397,7 +412,8 @@ int rfx_sort_records(rfx_ctx *ctx, const rfx_records *in, int P, rfx_records *ou
     DevRecords d, s;
     DevBuf ps;
     RFX_TRY(dev_records_upload(ctx, in, d));
-    RFX_TRY(sort_records(ctx, d, P, 64, s, ps));
+    if (d.kw > MAX_KEY_WORDS) return RFX_E_ARG;
+    RFX_TRY(sort_records(ctx, d, P, 64, s, ps, 0));
     RFX_TRY(download_to(ctx, s, out));
     return download_part_start(ctx, ps, P, part_start);
 }
@@ -405,7 +421,8 @@ int rfx_sort_records(rfx_ctx *ctx, const rfx_records *in, int P, rfx_records *ou
 static int fork_host(rfx_ctx *ctx, bool reflected, const rfx_records *in, const int64_t *part_start, int P, int k,
                      int min_error_cov, int twin, rfx_records *out, int64_t *out_part_start) {
     if (!ctx || !in || !out || !part_start || P < 1) return RFX_E_ARG;
-    RFX_TRY(check_k(k));
+    RFX_TRY(check_k_rec(k));
+    RFX_TRY(check_kw(in, k));
     RFX_HIP(hipSetDevice(ctx->device));
     DevRecords d, o;
     DevBuf ps, ops;
@@ -428,7 +445,8 @@ int rfx_fork_filter_reflected(rfx_ctx *ctx, const rfx_records *in, const int64_t
 
 int rfx_reflect_from_forward(rfx_ctx *ctx, const rfx_records *in, int k, rfx_records *out) {
     if (!ctx || !in || !out) return RFX_E_ARG;
-    RFX_TRY(check_k(k));
+    RFX_TRY(check_k_rec(k));
+    RFX_TRY(check_kw(in, k));
     RFX_HIP(hipSetDevice(ctx->device));
     DevRecords d, o;
     RFX_TRY(dev_records_upload(ctx, in, d));
@@ -439,7 +457,8 @@ int rfx_reflect_from_forward(rfx_ctx *ctx, const rfx_records *in, int k, rfx_rec
 int rfx_random_reflection(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P, int k,
                           rfx_records *out) {
     if (!ctx || !in || !out || !part_start || P < 1) return RFX_E_ARG;
-    RFX_TRY(check_k(k));
+    RFX_TRY(check_k_rec(k));
+    RFX_TRY(check_kw(in, k));
     RFX_HIP(hipSetDevice(ctx->device));
     DevRecords d, o;
     DevBuf ps;
@@ -449,24 +468,37 @@ int rfx_random_reflection(rfx_ctx *ctx, const rfx_records *in, const int64_t *pa
     return download_to(ctx, o, out);
 }
 
-int rfx_extend_pass(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P, int k, int twin,
-                    int stage, rfx_records *out, int64_t *out_part_start) {
+static int extend_host(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P, int k, int twin,
+                       int stage, int start_marker, rfx_records *out, int64_t *out_part_start) {
     if (!ctx || !in || !out || !part_start || P < 1 || stage < 0 || stage > 2) return RFX_E_ARG;
-    RFX_TRY(check_k(k));
+    RFX_TRY(check_k_rec(k));
+    RFX_TRY(check_kw(in, k));
     RFX_HIP(hipSetDevice(ctx->device));
     DevRecords d, o;
     DevBuf ps, ops;
     RFX_TRY(dev_records_upload(ctx, in, d));
     RFX_TRY(upload_part_start(ctx, part_start, P, ps));
-    RFX_TRY(extend_pass(ctx, d, ps.as<int64_t>(), P, k, twin, stage, o, ops));
+    RFX_TRY(extend_pass(ctx, d, ps.as<int64_t>(), P, k, twin, stage, o, ops, start_marker));
     RFX_TRY(download_to(ctx, o, out));
     return download_part_start(ctx, ops, P, out_part_start);
+}
+
+int rfx_extend_pass(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P, int k, int twin,
+                    int stage, rfx_records *out, int64_t *out_part_start) {
+    return extend_host(ctx, in, part_start, P, k, k > 31 ? RFX_TWIN_DS : twin, stage, 2, out, out_part_start);
+}
+
+int rfx_extend_pass_w(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P, int k, int stage,
+                      int scramble, rfx_records *out, int64_t *out_part_start) {
+    if (scramble != 2 && scramble != 3) return RFX_E_ARG;
+    return extend_host(ctx, in, part_start, P, k, RFX_TWIN_DS, stage, scramble == 3 ? 1 : 2, out, out_part_start);
 }
 
 int rfx_contigs_text(rfx_ctx *ctx, const rfx_records *in, int k, int min_contig, int twin, char *out, int64_t cap,
                      int64_t *out_len, int64_t *out_contigs) {
     if (!ctx || !in || !out_len) return RFX_E_ARG;
-    RFX_TRY(check_k(k));
+    RFX_TRY(check_k_rec(k));
+    RFX_TRY(check_kw(in, k));
     int64_t len = contigs_text_host(in, k, min_contig, twin, out, out ? cap : 0, out_contigs);
     *out_len = len;
     return len > cap ? RFX_E_CAP : RFX_OK;
@@ -693,23 +725,29 @@ int rfx_last_count_timing(rfx_ctx *ctx, const char *name, float *ms, int64_t *la
     return RFX_OK;
 }
 
-// Driver: P/ReflexivMain.java:168-310 (DS P/ReflexivDSMain.java:221-352)
-int rfx_dev_assemble(rfx_ctx *ctx, const uint64_t *d_keys, const int32_t *d_counts, int64_t n,
-                     const rfx_params *prm, char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs,
-                     int64_t *trace, int64_t trace_cap, int64_t *n_trace) {
+// Driver: P/ReflexivMain.java:168-310 (DS P/ReflexivDSMain.java:221-352); wide = the k > 31 driver
+// ReflexivDSMain64.assemblyFromKmer (P/ReflexivDSMain64.java:374-826) without the extras of :584-619 and :672-712
+// (SURVEY.md 8f-3): its loop :621-661 iterates all records, checks the count from minimumIteration + 3 on, the
+// first repeat of the count flips param.scramble 2 -> 3 (every later pass starts its marker at 1, :7484-7486) and
+// only the second stops; the survivors are sorted once more before they become text (:714).
+static int assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const int32_t *d_counts, int64_t n,
+                         const rfx_params *prm, char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs,
+                         int64_t *trace, int64_t trace_cap, int64_t *n_trace) {
     if (!ctx || !prm || !out_len || n < 0) return RFX_E_ARG;
-    RFX_TRY(check_k(prm->k));
+    if (wide) { RFX_TRY(check_k_rec(prm->k)); if (prm->k <= 31) return RFX_E_ARG; }
+    else RFX_TRY(check_k(prm->k));
     RFX_HIP(hipSetDevice(ctx->device));
-    const int k = prm->k, twin = prm->twin;
+    const int k = prm->k, twin = wide ? RFX_TWIN_DS : prm->twin;
     int P = prm->partitions > 0 ? prm->partitions : 1;
     const int key_bits = 2 * (k - 1);
+    const int kw = sub_words(k);
     int64_t nt = 0;
     DevRecords a, b;
     DevBuf ps, ops;
     // two alternating bump arenas hold every temporary and record set of a pass / stage
     Arena arena[2];
     {
-        const size_t per = (size_t)(2 * n) * 176 + ((size_t)64 << 20);
+        const size_t per = (size_t)(2 * n) * (176 + 24 * (size_t)(kw - 1)) + ((size_t)64 << 20);
         for (int i = 0; i < 2; i++) {
             arena[i].base = (char *)ctx->ws_get(2 + i, per);
             if (!arena[i].base) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
@@ -726,7 +764,7 @@ int rfx_dev_assemble(rfx_ctx *ctx, const uint64_t *d_keys, const int32_t *d_coun
     RFX_TRY(rc_expand_subkmer(ctx, d_keys, d_counts, n, k, a));
     // sortByKey + FilterForkSubKmer[WithErrorCorrection]  :179-186
     next_arena();
-    RFX_TRY(sort_records(ctx, a, P, key_bits, b, ps));
+    RFX_TRY(sort_records(ctx, a, P, key_bits, b, ps, k));
     next_arena();
     RFX_TRY(fork_filter(ctx, false, b, ps.as<int64_t>(), P, k, prm->min_error_cov, twin, a, ops));
     // ReflectedSubKmerExtractionFromForward  :188-189
@@ -734,7 +772,7 @@ int rfx_dev_assemble(rfx_ctx *ctx, const uint64_t *d_keys, const int32_t *d_coun
     RFX_TRY(reflect_from_forward(ctx, a, k, b));
     // sortByKey + FilterForkReflectedSubKmer[WithErrorCorrection]  :191-198
     next_arena();
-    RFX_TRY(sort_records(ctx, b, P, key_bits, a, ps));
+    RFX_TRY(sort_records(ctx, b, P, key_bits, a, ps, k));
     next_arena();
     RFX_TRY(fork_filter(ctx, true, a, ps.as<int64_t>(), P, k, prm->min_error_cov, twin, b, ops));
     // kmerRandomReflection on the filter's output partitions  :204-205
@@ -745,13 +783,13 @@ int rfx_dev_assemble(rfx_ctx *ctx, const uint64_t *d_keys, const int32_t *d_coun
     auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double t_loop0 = verbose ? ((void)hipStreamSynchronize(ctx->stream), now_ms()) : 0;
     if (verbose) fprintf(stderr, "assemble: stages before the loop %.3f ms\n", t_loop0 - t_enter);
-    auto one_pass = [&](int stage) -> int {
+    auto one_pass = [&](int stage, int start_marker = 2) -> int {
         const double t0 = verbose ? now_ms() : 0;
         next_arena();                     // `a` (this pass's input) stays valid in the other arena
-        RFX_TRY(sort_records(ctx, a, P, key_bits, b, ps));                        // sortByKey :211,:235,:247,:286
+        RFX_TRY(sort_records(ctx, a, P, key_bits, b, ps, k));                     // sortByKey :211,:235,:247,:286
         if (verbose) (void)hipStreamSynchronize(ctx->stream);
         const double t1 = verbose ? now_ms() : 0;
-        RFX_TRY(extend_pass(ctx, b, ps.as<int64_t>(), P, k, twin, stage, a, ops));
+        RFX_TRY(extend_pass(ctx, b, ps.as<int64_t>(), P, k, twin, stage, a, ops, start_marker));
         if (verbose) fprintf(stderr, "pass %lld: n_in %lld words %lld sort %.3f ms extend %.3f ms -> n %lld\n", (long long)nt,
                              (long long)b.n, (long long)b.words, t1 - t0, now_ms() - t1, (long long)a.n);
         if (trace && nt < trace_cap) trace[nt] = a.n;
@@ -765,7 +803,20 @@ int rfx_dev_assemble(rfx_ctx *ctx, const uint64_t *d_keys, const int32_t *d_coun
     RFX_TRY(one_pass(1));                                                         // :247-254
     int partitionNumber = P;
     int64_t contigNumber = 0;
-    while (iterations <= prm->max_iter) {                                         // :265-296
+    int scramble = 2;                                                             // U/DefaultParam.java:131
+    while (wide && iterations <= prm->max_iter) {                                 // 64 :582
+        iterations++;
+        if (iterations >= prm->min_iter + 3 && iterations % 3 == 0) {             // 64 :621-622
+            const int64_t current = a.n;                                          // 64 :633-635
+            if (contigNumber == current) {                                        // 64 :639
+                if (scramble == 2) { scramble = 3; contigNumber = current; }      // 64 :640-642
+                else break;                                                       // 64 :644
+            } else contigNumber = current;                                        // 64 :647
+            // the coalesce of 64 :651-655 is assigned to a variable the loop does not read: no effect
+        }
+        RFX_TRY(one_pass(2, scramble == 3 ? 1 : 2));                              // 64 :659-660, :667-669
+    }
+    while (!wide && iterations <= prm->max_iter) {                                // :265-296
         iterations++;
         if (iterations >= prm->min_iter && iterations % 3 == 0) {
             const int64_t current = a.n;                                          // count() :270
@@ -779,27 +830,63 @@ int rfx_dev_assemble(rfx_ctx *ctx, const uint64_t *d_keys, const int32_t *d_coun
         RFX_TRY(one_pass(2));
     }
     if (n_trace) *n_trace = nt;
+    DevRecords *fin = &a;
+    if (wide) {                                                                   // 64 :714
+        next_arena();
+        RFX_TRY(sort_records(ctx, a, P, key_bits, b, ps, k));
+        fin = &b;
+    }
     const double t_loop1 = verbose ? now_ms() : 0;
     // the surviving records come down through the context's pinned staging block
-    const int64_t hn = std::max<int64_t>(a.n, 1), hw = std::max<int64_t>(a.words, 1);
-    const size_t need = (size_t)hn * 8 + (size_t)(hn + 1) * 8 + (size_t)hw * 8 + (size_t)hn * 12 + 64;
+    const DevRecords &a_fin = *fin;
+    const int64_t hn = std::max<int64_t>(a_fin.n, 1), hw = std::max<int64_t>(a_fin.words, 1);
+    const size_t need = (size_t)hn * 8 * kw + (size_t)(hn + 1) * 8 + (size_t)hw * 8 + (size_t)hn * 12 + 64;
     char *pin = (char *)ctx->pinned_get(need);
     if (!pin) { ctx->last_error = "pinned staging allocation failed"; return RFX_E_HIP; }
     rfx_records hv{};
-    hv.key = (uint64_t *)pin; pin += (size_t)hn * 8;
+    hv.key = (uint64_t *)pin; pin += (size_t)hn * 8 * kw;
     hv.ext_off = (int64_t *)pin; pin += (size_t)(hn + 1) * 8;
     hv.ext = (uint64_t *)pin; pin += (size_t)hw * 8;
     hv.marker = (int32_t *)pin; pin += (size_t)hn * 4;
     hv.left = (int32_t *)pin; pin += (size_t)hn * 4;
     hv.right = (int32_t *)pin;
-    hv.cap_n = a.n; hv.cap_words = a.words;
-    RFX_TRY(dev_records_download(ctx, a, &hv));
+    hv.cap_n = a_fin.n; hv.cap_words = a_fin.words;
+    RFX_TRY(dev_records_download(ctx, a_fin, &hv));
     const double t_dl = verbose ? now_ms() : 0;
     int64_t len = contigs_text_host(&hv, k, prm->min_contig, twin, out, out ? cap : 0, out_contigs);
     if (verbose) fprintf(stderr, "assemble: loop %.3f ms, download %.3f ms, text %.3f ms\n", t_loop1 - t_loop0, t_dl - t_loop1,
                          now_ms() - t_dl);
     *out_len = len;
     return len > cap ? RFX_E_CAP : RFX_OK;
+}
+
+int rfx_dev_assemble(rfx_ctx *ctx, const uint64_t *d_keys, const int32_t *d_counts, int64_t n,
+                     const rfx_params *prm, char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs,
+                     int64_t *trace, int64_t trace_cap, int64_t *n_trace) {
+    return assemble_impl(ctx, false, d_keys, d_counts, n, prm, out, cap, out_len, out_contigs, trace, trace_cap, n_trace);
+}
+
+int rfx_dev_assemble_w(rfx_ctx *ctx, const uint64_t *d_kmers, const int32_t *d_counts, int64_t n,
+                       const rfx_params *prm, char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs,
+                       int64_t *trace, int64_t trace_cap, int64_t *n_trace) {
+    return assemble_impl(ctx, true, d_kmers, d_counts, n, prm, out, cap, out_len, out_contigs, trace, trace_cap, n_trace);
+}
+
+int rfx_dev_order_kmers_w(rfx_ctx *ctx, uint64_t *d_keys, int64_t *d_counts, int64_t n, int k) {
+    if (!ctx || n < 0 || (n > 0 && (!d_keys || !d_counts))) return RFX_E_ARG;
+    RFX_TRY(check_k_w(k));
+    if (!wide_fast_path(k)) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    return order_wide2(ctx, d_keys, d_counts, n, k);
+}
+
+int rfx_dev_counter_to_asm(rfx_ctx *ctx, const uint64_t *d_keys32, const int64_t *d_counts64, int64_t n, int k,
+                           int min_cov, int max_cov, uint64_t *d_out_kmers, int32_t *d_out_counts, int64_t *out_n) {
+    if (!ctx || n < 0 || !out_n || (n > 0 && (!d_keys32 || !d_counts64 || !d_out_kmers || !d_out_counts))) return RFX_E_ARG;
+    RFX_TRY(check_k_w(k));
+    RFX_TRY(check_k_rec(k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    return counter_to_asm(ctx, d_keys32, d_counts64, n, k, min_cov, max_cov, d_out_kmers, d_out_counts, out_n);
 }
 
 int rfx_assemble_reads(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_off, int64_t n_reads,

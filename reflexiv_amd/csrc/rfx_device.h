@@ -78,6 +78,43 @@ __device__ __forceinline__ unsigned key_base(uint64_t key, int sub, int i) {
     return (unsigned)((key >> (2 * (sub - 1 - i))) & 3);
 }
 
+// ---- (k-1)-mer keys of KW words (k > 32: P/ReflexivDSMain64.java, 31 bases per word, the last word the
+// remaining (k-2)%31+1 bases right-aligned, U/DefaultParam.java:93-94; KW = 1 is the single long of k <= 32).
+// Stored AoS, KW consecutive words per record, as the reference's Row(long[]).
+template <int KW> struct alignas(KW % 2 == 0 ? 16 : 8) KeyW { uint64_t w[KW]; };
+
+template <int KW> __device__ __forceinline__ bool key_eq(const KeyW<KW> &a, const KeyW<KW> &b) {
+    bool e = true;
+#pragma unroll
+    for (int i = 0; i < KW; i++) e = e && (a.w[i] == b.w[i]);
+    return e;
+}
+
+// base i (0 = first) of a key of `sub` bases
+template <int KW> __device__ __forceinline__ unsigned key_base_w(const KeyW<KW> &key, int sub, int i) {
+    if (KW == 1) return (unsigned)((key.w[0] >> (2 * (sub - 1 - i))) & 3);
+    const int wi = i / 31, j = i - 31 * wi;
+    const int nb = wi < KW - 1 ? 31 : sub - 31 * (KW - 1);
+    uint64_t x = key.w[0];
+#pragma unroll
+    for (int q = 1; q < KW; q++) if (wi == q) x = key.w[q];
+    return (unsigned)((x >> (2 * (nb - 1 - j))) & 3);
+}
+
+// key from a base function f(t), t = 0 .. sub-1
+template <int KW, class F> __device__ __forceinline__ KeyW<KW> build_key(int sub, F f) {
+    KeyW<KW> key;
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < KW; w++) {
+        const int nb = w < KW - 1 ? 31 : sub - 31 * (KW - 1);
+        uint64_t x = 0;
+        for (int j = 0; j < nb; j++) x = (x << 2) | (uint64_t)f(t++);
+        key.w[w] = x;
+    }
+    return key;
+}
+
 __device__ __host__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     uint64_t z = x + 0x9E3779B97F4A7C15ULL;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

@@ -7,6 +7,10 @@
 //   ReflectedSubKmerExtractionFromForward              P/ReflexivMain.java:2742-2768
 //   FilterForkReflectedSubKmer[WithErrorCorrection]    P/ReflexivMain.java:2550-2696 (DS :3493-3616)
 //   kmerRandomReflection                               P/ReflexivMain.java:2783-2885
+// and their k > 31 twins of P/ReflexivDSMain64.java (DSKmerReverseComplement :10706-10755,
+// DSForwardSubKmerExtraction :10363-10403, DSFilterFork* :10072-10360, DSReflectedSubKmerExtractionFromForward
+// :10426-10475, DSkmerRandomReflection :10491-10690, KmerBinarizer :10772-10836): the same operators on
+// (k-1)-mer keys of KW words of 31 bases (templates on KW; KW = 1 keeps the one-word code of k <= 31).
 //
 // Records live in HBM as flat struct-of-arrays in the reference's layout (include/
 // reflexiv_hip.h).  A sort moves (key, index) pairs only; fixed fields are gathered once
@@ -51,7 +55,84 @@ __global__ void k_rc_expand(const uint64_t *__restrict__ kmers, const int32_t *_
     if (i == n - 1) ext_off[2 * n] = 2 * n;
 }
 
+// k > 31: k-mers come in the assembler layout (AW = (k-1)/31+1 words of 31 bases, the last word the rest,
+// KmerBinarizer :10812-10819); base-wise, as DSKmerReverseComplement does (:10727-10743)
+template <int KW>
+__global__ void k_rc_expand_w(const uint64_t *__restrict__ kmers, int AW, const int32_t *__restrict__ counts, int64_t n,
+                              int k, KeyW<KW> *__restrict__ key, int32_t *__restrict__ marker,
+                              int64_t *__restrict__ ext_off, uint64_t *__restrict__ ext,
+                              int32_t *__restrict__ left, int32_t *__restrict__ right) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t *km = kmers + i * AW;
+    const int lastb = k - 31 * (AW - 1);
+    auto fwd = [&](int t) -> unsigned {
+        const int wi = t / 31, j = t - 31 * wi, nb = wi < AW - 1 ? 31 : lastb;
+        return (unsigned)((km[wi] >> (2 * (nb - 1 - j))) & 3);
+    };
+    auto rc = [&](int t) -> unsigned { return fwd(k - 1 - t) ^ 3u; };
+    const int32_t c = counts[i];
+    const int sub = k - 1;
+    key[2 * i] = build_key<KW>(sub, fwd);                  // :10381-10395
+    key[2 * i + 1] = build_key<KW>(sub, rc);
+    ext[2 * i] = fwd(k - 1); ext[2 * i + 1] = rc(k - 1);   // :10383 / :10390 (no sentinel yet)
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        int64_t o = 2 * i + t;
+        marker[o] = 1; left[o] = c; right[o] = c; ext_off[o] = o;          // :10399
+    }
+    if (i == n - 1) ext_off[2 * n] = 2 * n;
+}
+
+// KmerBinarizer + the count filter of the from-counts driver (P/ReflexivDSMain64.java:10772-10836, :473-478) for
+// k-mers that never left HBM: counter layout (k/32+1 words of 32 bases, the last word k%32 right-aligned,
+// P/ReflexivDataFrameCounter64.java:429-437) -> assembler layout; the count is read as the text would be
+// (10 digits or more -> 1000000000, :10801-10806)
+__global__ void k_counter_keep(const int64_t *__restrict__ counts, int64_t n, int min_cov, int max_cov,
+                               uint32_t *__restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t c64 = counts[i];
+    const int32_t c = c64 >= 1000000000LL ? 1000000000 : (int32_t)c64;
+    flag[i] = (c >= min_cov && c <= max_cov) ? 1u : 0u;
+}
+__global__ void k_counter_to_asm(const uint64_t *__restrict__ k32, const int64_t *__restrict__ counts, int64_t n, int k,
+                                 const uint32_t *__restrict__ flag, const uint64_t *__restrict__ pos,
+                                 uint64_t *__restrict__ k31, int32_t *__restrict__ ocounts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const int W32 = k / 32 + 1, W31 = (k - 1) / 31 + 1, res = k % 32;
+    const uint64_t *src = k32 + i * W32;
+    uint64_t *dst = k31 + (int64_t)pos[i] * W31;
+    auto base = [&](int t) -> uint64_t {
+        const int wi = t >> 5, j = t & 31;
+        return wi < W32 - 1 ? (src[wi] >> (2 * (31 - j))) & 3 : (src[wi] >> (2 * (res - 1 - j))) & 3;
+    };
+    int t = 0;
+    for (int w = 0; w < W31; w++) {
+        const int nb = w < W31 - 1 ? 31 : k - 31 * (W31 - 1);
+        uint64_t x = 0;
+        for (int j = 0; j < nb; j++) x = (x << 2) | base(t++);
+        dst[w] = x;
+    }
+    const int64_t c64 = counts[i];
+    ocounts[pos[i]] = c64 >= 1000000000LL ? 1000000000 : (int32_t)c64;
+}
+
 // ---- sort support
+template <int KW>
+__global__ void k_key_word(const KeyW<KW> *__restrict__ key, const uint32_t *__restrict__ perm, int64_t n, int w,
+                           uint64_t *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = key[perm ? perm[i] : (uint32_t)i].w[w];
+}
+template <int KW>
+__global__ void k_gather_key(const KeyW<KW> *__restrict__ key, const uint32_t *__restrict__ perm, int64_t n,
+                             KeyW<KW> *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = key[perm[i]];
+}
+
 __global__ void k_gather_fixed(const uint32_t *__restrict__ perm, int64_t n, const int32_t *__restrict__ marker,
                                const int32_t *__restrict__ left, const int32_t *__restrict__ right,
                                const int64_t *__restrict__ ext_off, int32_t *__restrict__ omarker,
@@ -107,38 +188,41 @@ __global__ void k_gather_ext_long(const uint32_t *__restrict__ perm, const int64
 }
 
 // Order contract B.0: start[p] = floor(p*n/P) moved forward so equal keys never split.
-__global__ void k_partition_starts(const uint64_t *__restrict__ skey, int64_t n, int P,
+template <int KW>
+__global__ void k_partition_starts(const KeyW<KW> *__restrict__ skey, int64_t n, int P,
                                    int64_t *__restrict__ start) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p > P) return;
     if (p == P) { start[P] = n; return; }
     int64_t s = (int64_t)(((uint64_t)p * (uint64_t)n) / (uint64_t)P);   // n < 2^32, p < 2^31
-    while (s > 0 && s < n && skey[s] == skey[s - 1]) s++;
+    while (s > 0 && s < n && key_eq(skey[s], skey[s - 1])) s++;
     start[p] = s;
 }
 
 // ---- run heads
-__global__ void k_head_flags(const uint64_t *__restrict__ key, int64_t n, uint32_t *__restrict__ flag) {
+template <int KW>
+__global__ void k_head_flags(const KeyW<KW> *__restrict__ key, int64_t n, uint32_t *__restrict__ flag) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = (i == 0 || key[i] != key[i - 1]) ? 1u : 0u;
+    if (i < n) flag[i] = (i == 0 || !key_eq(key[i], key[i - 1])) ? 1u : 0u;
 }
 
 // a-7: forward fork filter, one thread per run head
-__global__ void k_fork_forward(const uint64_t *__restrict__ key, const int32_t *__restrict__ marker,
+template <int KW>
+__global__ void k_fork_forward(const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
                                const uint64_t *__restrict__ ext, const int32_t *__restrict__ left, int64_t n,
                                const uint32_t *__restrict__ flag, const uint64_t *__restrict__ pos,
                                int sub, int min_err, int ds_ec,
-                               uint64_t *__restrict__ okey, int32_t *__restrict__ omarker,
+                               KeyW<KW> *__restrict__ okey, int32_t *__restrict__ omarker,
                                int64_t *__restrict__ oext_off, uint64_t *__restrict__ oext,
                                int32_t *__restrict__ oleft, int32_t *__restrict__ oright) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == n) { oext_off[pos[n]] = (int64_t)pos[n]; return; }
     if (i > n || !flag[i]) return;
-    const uint64_t kk = key[i];
+    const KeyW<KW> kk = key[i];
     int32_t hm = marker[i], hc = left[i];
     uint64_t he = ext[i];
-    int32_t hr = ds_ec ? (-1 - hc) : -1;                                   // :2478 / DS :3436
-    for (int64_t j = i + 1; j < n && key[j] == kk; j++) {
+    int32_t hr = ds_ec ? (-1 - hc) : -1;                                   // :2478 / DS :3436 / 64 :10149
+    for (int64_t j = i + 1; j < n && key_eq(key[j], kk); j++) {
         int32_t cs = left[j];
         if (cs > hc) {                                                     // :2483
             bool err = min_err != 0 && hc <= min_err && cs >= 2 * hc;      // :2484
@@ -157,23 +241,24 @@ __global__ void k_fork_forward(const uint64_t *__restrict__ key, const int32_t *
 }
 
 // a-9: reflected fork filter
-__global__ void k_fork_reflected(const uint64_t *__restrict__ key, const int32_t *__restrict__ marker,
+template <int KW>
+__global__ void k_fork_reflected(const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
                                  const uint64_t *__restrict__ ext, const int32_t *__restrict__ left,
                                  const int32_t *__restrict__ right, int64_t n,
                                  const uint32_t *__restrict__ flag, const uint64_t *__restrict__ pos,
                                  int sub, int min_err, int ds_ec,
-                                 uint64_t *__restrict__ okey, int32_t *__restrict__ omarker,
+                                 KeyW<KW> *__restrict__ okey, int32_t *__restrict__ omarker,
                                  int64_t *__restrict__ oext_off, uint64_t *__restrict__ oext,
                                  int32_t *__restrict__ oleft, int32_t *__restrict__ oright) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == n) { oext_off[pos[n]] = (int64_t)pos[n]; return; }
     if (i > n || !flag[i]) return;
-    const uint64_t kk = key[i];
+    const KeyW<KW> kk = key[i];
     int32_t last_cov = left[i];                                            // HighCoverLastCoverage :2623
     int32_t hm = marker[i], hr = right[i];
     uint64_t he = ext[i];
-    int32_t hl = ds_ec ? (-1 - last_cov) : -1;                             // :2626 / DS :3556
-    for (int64_t j = i + 1; j < n && key[j] == kk; j++) {
+    int32_t hl = ds_ec ? (-1 - last_cov) : -1;                             // :2626 / DS :3556 / 64 :10292
+    for (int64_t j = i + 1; j < n && key_eq(key[j], kk); j++) {
         int32_t cs = left[j];
         if (cs > last_cov) {                                               // :2631
             bool err = min_err != 0 && last_cov <= min_err && cs >= 2 * last_cov;
@@ -203,18 +288,37 @@ __global__ void k_map_part_start(const int64_t *__restrict__ ps, int P, const ui
 }
 
 // a-8
-__global__ void k_reflect(const uint64_t *__restrict__ key, const uint64_t *__restrict__ ext,
+template <int KW>
+__global__ void k_reflect(const KeyW<KW> *__restrict__ key, const uint64_t *__restrict__ ext,
                           const int32_t *__restrict__ left, const int32_t *__restrict__ right, int64_t n, int sub,
-                          uint64_t *__restrict__ okey, int32_t *__restrict__ omarker,
+                          KeyW<KW> *__restrict__ okey, int32_t *__restrict__ omarker,
                           int64_t *__restrict__ oext_off, uint64_t *__restrict__ oext,
                           int32_t *__restrict__ oleft, int32_t *__restrict__ oright) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == n) { oext_off[n] = n; return; }
     if (i > n) return;
-    uint64_t kk = key[i];
-    uint64_t first = (kk >> (2 * (sub - 1))) & 3;                          // :2752-2754
-    okey[i] = ((kk << 2) & low_mask(sub)) | ext[i];                        // :2757-2758
-    oext[i] = first | 4;                                                   // :2755
+    const KeyW<KW> kk = key[i];
+    uint64_t first;
+    KeyW<KW> nk;
+    if (KW == 1) {
+        first = (kk.w[0] >> (2 * (sub - 1))) & 3;                              // :2752-2754
+        nk.w[0] = ((kk.w[0] << 2) & low_mask(sub)) | ext[i];                   // :2757-2758
+    } else {
+        // every word moves one base to the left, taking the top base of its right neighbour; the suffix base
+        // enters the last word  (P/ReflexivDSMain64.java:10448-10466)
+        const int res = sub - 31 * (KW - 1);
+        first = kk.w[0] >> 60;                                                 // :10448
+        uint64_t in = ext[i] & 3;
+#pragma unroll
+        for (int w = KW - 1; w >= 0; w--) {
+            const int nb = w < KW - 1 ? 31 : res;
+            const uint64_t top = kk.w[w] >> (2 * (nb - 1));
+            nk.w[w] = ((kk.w[w] << 2) & low_mask(nb)) | in;
+            in = top;
+        }
+    }
+    okey[i] = nk;
+    oext[i] = first | 4;                                                   // :2755 / :10450
     omarker[i] = 2; oleft[i] = left[i]; oright[i] = right[i]; oext_off[i] = i;
 }
 
@@ -229,11 +333,12 @@ __device__ __forceinline__ int part_of(const int64_t *__restrict__ ps, int P, in
 }
 
 // a-10: single-word flip to the orientation the arrival index asks for
-__global__ void k_random_reflection(const uint64_t *__restrict__ key, const int32_t *__restrict__ marker,
+template <int KW>
+__global__ void k_random_reflection(const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
                                     const uint64_t *__restrict__ ext, const int32_t *__restrict__ left,
                                     const int32_t *__restrict__ right, int64_t n,
                                     const int64_t *__restrict__ ps, int P, int sub,
-                                    uint64_t *__restrict__ okey, int32_t *__restrict__ omarker,
+                                    KeyW<KW> *__restrict__ okey, int32_t *__restrict__ omarker,
                                     int64_t *__restrict__ oext_off, uint64_t *__restrict__ oext,
                                     int32_t *__restrict__ oleft, int32_t *__restrict__ oright) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -241,20 +346,39 @@ __global__ void k_random_reflection(const uint64_t *__restrict__ key, const int3
     if (i > n) return;
     int p = part_of(ps, P, i);
     int m = ((i - ps[p]) & 1) ? 1 : 2;                                      // :2777, :2880-2884
-    uint64_t kk = key[i], e = ext[i];
+    KeyW<KW> kk = key[i];
+    uint64_t e = ext[i];
     int mk = marker[i];
     if (mk != m) {
         int L = sentinel_len(e);
-        unsigned __int128 S;
         uint64_t eb = e & low_mask(L);
-        if (mk == 1) {                      // key||ext  -> keyed at its last k-1 bases
-            S = ((unsigned __int128)kk << (2 * L)) | eb;
-            kk = (uint64_t)(S & (unsigned __int128)low_mask(sub));
-            e = (uint64_t)(S >> (2 * sub)) | (1ULL << (2 * L));
-        } else {                            // ext||key  -> keyed at its first k-1 bases
-            S = ((unsigned __int128)eb << (2 * sub)) | kk;
-            kk = (uint64_t)(S >> (2 * L));
-            e = (uint64_t)(S & (unsigned __int128)low_mask(L)) | (1ULL << (2 * L));
+        if (KW == 1) {
+            unsigned __int128 S;
+            if (mk == 1) {                      // key||ext  -> keyed at its last k-1 bases
+                S = ((unsigned __int128)kk.w[0] << (2 * L)) | eb;
+                kk.w[0] = (uint64_t)(S & (unsigned __int128)low_mask(sub));
+                e = (uint64_t)(S >> (2 * sub)) | (1ULL << (2 * L));
+            } else {                            // ext||key  -> keyed at its first k-1 bases
+                S = ((unsigned __int128)eb << (2 * sub)) | kk.w[0];
+                kk.w[0] = (uint64_t)(S >> (2 * L));
+                e = (uint64_t)(S & (unsigned __int128)low_mask(L)) | (1ULL << (2 * L));
+            }
+        } else {
+            // base-wise (P/ReflexivDSMain64.java:10527-10680): S = key||ext or ext||key, re-cut at the other end
+            const KeyW<KW> src = kk;
+            auto sb = [&](int t) -> unsigned {      // base t of S
+                if (mk == 1) return t < sub ? key_base_w<KW>(src, sub, t) : (unsigned)((eb >> (2 * (L - 1 - (t - sub)))) & 3);
+                return t < L ? (unsigned)((eb >> (2 * (L - 1 - t))) & 3) : key_base_w<KW>(src, sub, t - L);
+            };
+            uint64_t ne = 1;
+            if (m == 1) {
+                kk = build_key<KW>(sub, sb);
+                for (int t = 0; t < L; t++) ne = (ne << 2) | sb(sub + t);
+            } else {
+                kk = build_key<KW>(sub, [&](int t) { return sb(L + t); });
+                for (int t = 0; t < L; t++) ne = (ne << 2) | sb(t);
+            }
+            e = ne;
         }
     }
     okey[i] = kk; omarker[i] = m; oext[i] = e; oleft[i] = left[i]; oright[i] = right[i]; oext_off[i] = i;
@@ -266,10 +390,21 @@ inline unsigned grid_for(int64_t n, int block = 256) { return (unsigned)ceil_div
 
 namespace rfx {
 
-int dev_records_alloc(rfx_ctx *ctx, DevRecords &r, int64_t cap_n, int64_t cap_words) {
+#define RFX_KW_SWITCH(kw, ...)                                                \
+    switch (kw) {                                                             \
+    case 1: { constexpr int KW = 1; __VA_ARGS__; } break;                     \
+    case 2: { constexpr int KW = 2; __VA_ARGS__; } break;                     \
+    case 3: { constexpr int KW = 3; __VA_ARGS__; } break;                     \
+    case 4: { constexpr int KW = 4; __VA_ARGS__; } break;                     \
+    default: return RFX_E_ARG;                                                \
+    }
+
+int dev_records_alloc(rfx_ctx *ctx, DevRecords &r, int64_t cap_n, int64_t cap_words, int kw) {
     if (cap_n < 1) cap_n = 1;
     if (cap_words < 1) cap_words = 1;
-    RFX_HIP(r.key.alloc((size_t)cap_n * 8, ctx->stream));
+    if (kw < 1 || kw > MAX_KEY_WORDS) return RFX_E_ARG;
+    r.kw = kw;
+    RFX_HIP(r.key.alloc((size_t)cap_n * 8 * kw, ctx->stream));
     RFX_HIP(r.marker.alloc((size_t)cap_n * 4, ctx->stream));
     RFX_HIP(r.ext_off.alloc((size_t)(cap_n + 1) * 8, ctx->stream));
     RFX_HIP(r.ext.alloc((size_t)cap_words * 8, ctx->stream));
@@ -282,9 +417,10 @@ int dev_records_alloc(rfx_ctx *ctx, DevRecords &r, int64_t cap_n, int64_t cap_wo
 int dev_records_upload(rfx_ctx *ctx, const rfx_records *h, DevRecords &d) {
     const int64_t n = h->n;
     const int64_t words = n > 0 ? h->ext_off[n] : 0;
-    RFX_TRY(dev_records_alloc(ctx, d, n, words));
+    const int kw = h->key_words > 1 ? h->key_words : 1;
+    RFX_TRY(dev_records_alloc(ctx, d, n, words, kw));
     if (n > 0) {
-        RFX_HIP(hipMemcpyAsync(d.key.p, h->key, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(d.key.p, h->key, (size_t)n * 8 * kw, hipMemcpyHostToDevice, ctx->stream));
         RFX_HIP(hipMemcpyAsync(d.marker.p, h->marker, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
         RFX_HIP(hipMemcpyAsync(d.left.p, h->left, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
         RFX_HIP(hipMemcpyAsync(d.right.p, h->right, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -305,8 +441,9 @@ int dev_records_download(rfx_ctx *ctx, const DevRecords &d, rfx_records *h) {
     if (d.n > h->cap_n || d.words > h->cap_words) return RFX_E_CAP;
     const int64_t n = d.n;
     h->n = n;
+    h->key_words = d.kw;
     if (n > 0) {
-        RFX_HIP(hipMemcpyAsync(h->key, d.key.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(h->key, d.key.p, (size_t)n * 8 * d.kw, hipMemcpyDeviceToHost, ctx->stream));
         RFX_HIP(hipMemcpyAsync(h->marker, d.marker.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
         RFX_HIP(hipMemcpyAsync(h->left, d.left.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
         RFX_HIP(hipMemcpyAsync(h->right, d.right.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -320,11 +457,18 @@ int dev_records_download(rfx_ctx *ctx, const DevRecords &d, rfx_records *h) {
 
 int rc_expand_subkmer(rfx_ctx *ctx, const uint64_t *d_kmers, const int32_t *d_counts, int64_t n, int k,
                       DevRecords &out) {
-    RFX_TRY(dev_records_alloc(ctx, out, 2 * n, 2 * n));
-    if (n > 0) {
+    const int kw = sub_words(k);
+    RFX_TRY(dev_records_alloc(ctx, out, 2 * n, 2 * n, kw));
+    if (n > 0 && k <= 31) {
         hipLaunchKernelGGL(k_rc_expand, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_kmers, d_counts, n, k,
                            out.key.as<uint64_t>(), out.marker.as<int32_t>(), out.ext_off.as<int64_t>(),
                            out.ext.as<uint64_t>(), out.left.as<int32_t>(), out.right.as<int32_t>());
+        RFX_HIP(hipGetLastError());
+    } else if (n > 0) {
+        RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_rc_expand_w<KW>, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_kmers,
+                                             asm_words(k), d_counts, n, k, out.key.as<KeyW<KW>>(), out.marker.as<int32_t>(),
+                                             out.ext_off.as<int64_t>(), out.ext.as<uint64_t>(), out.left.as<int32_t>(),
+                                             out.right.as<int32_t>()));
         RFX_HIP(hipGetLastError());
     } else {
         RFX_HIP(hipMemsetAsync(out.ext_off.p, 0, 8, ctx->stream));
@@ -333,10 +477,12 @@ int rc_expand_subkmer(rfx_ctx *ctx, const uint64_t *d_kmers, const int32_t *d_co
     return RFX_OK;
 }
 
-int sort_records(rfx_ctx *ctx, const DevRecords &in, int P, int key_bits, DevRecords &out, DevBuf &part_start) {
+int sort_records(rfx_ctx *ctx, const DevRecords &in, int P, int key_bits, DevRecords &out, DevBuf &part_start, int k) {
     const int64_t n = in.n;
+    const int kw = in.kw;
     if (n > (int64_t)0xFFFFFFFFLL) return RFX_E_LIMIT;
-    RFX_TRY(dev_records_alloc(ctx, out, n, in.words));
+    if (kw > 1 && k != 0 && sub_words(k) != kw) return RFX_E_ARG;
+    RFX_TRY(dev_records_alloc(ctx, out, n, in.words, kw));
     RFX_HIP(part_start.alloc((size_t)(P + 1) * 8, ctx->stream));
     DevBuf perm, tk, tv, nw, wscan, long_list, long_n;
     RFX_HIP(perm.alloc((size_t)(n ? n : 1) * 4, ctx->stream));
@@ -348,12 +494,35 @@ int sort_records(rfx_ctx *ctx, const DevRecords &in, int P, int key_bits, DevRec
     RFX_HIP(long_list.alloc((size_t)((n ? n : 1) + in.words / LONG_CHUNK + 1) * 8, ctx->stream));
     RFX_HIP(long_n.alloc(8, ctx->stream));
     RFX_HIP(hipMemsetAsync(long_n.p, 0, 8, ctx->stream));
-    if (n > 0) {
+    if (n > 0 && kw == 1) {
         RFX_HIP(hipMemcpyAsync(out.key.p, in.key.p, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
         hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n)), dim3(256), 0, ctx->stream, perm.as<uint32_t>(), n);
         RFX_HIP(hipGetLastError());
         RFX_TRY(sort_pairs(ctx, out.key.as<uint64_t>(), perm.as<uint32_t>(), n, key_bits, tk.as<uint64_t>(),
                            tv.as<uint32_t>()));
+    } else if (n > 0) {
+        // stable LSD over the key words, last word first, through the permutation: word w of the records in
+        // their current order is gathered, sorted together with the permutation, and so on; then the whole
+        // keys are gathered once
+        DevBuf wk;
+        RFX_HIP(wk.alloc((size_t)n * 8, ctx->stream));
+        hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n)), dim3(256), 0, ctx->stream, perm.as<uint32_t>(), n);
+        RFX_HIP(hipGetLastError());
+        const int res = k > 0 ? (k - 1) - 31 * (kw - 1) : 31;      // k unknown: every word may use its 62 bits
+        for (int w = kw - 1; w >= 0; w--) {
+            const uint32_t *pp = w == kw - 1 ? nullptr : perm.as<uint32_t>();
+            RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_key_word<KW>, dim3(grid_for(n)), dim3(256), 0, ctx->stream,
+                                                 (const KeyW<KW> *)in.key.as<KeyW<KW>>(), pp, n, w, wk.as<uint64_t>()));
+            RFX_HIP(hipGetLastError());
+            RFX_TRY(sort_pairs(ctx, wk.as<uint64_t>(), perm.as<uint32_t>(), n, 2 * (w == kw - 1 ? res : 31), tk.as<uint64_t>(),
+                               tv.as<uint32_t>()));
+        }
+        RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_gather_key<KW>, dim3(grid_for(n)), dim3(256), 0, ctx->stream,
+                                             (const KeyW<KW> *)in.key.as<KeyW<KW>>(), (const uint32_t *)perm.as<uint32_t>(), n,
+                                             out.key.as<KeyW<KW>>()));
+        RFX_HIP(hipGetLastError());
+    }
+    if (n > 0) {
         hipLaunchKernelGGL(k_gather_fixed, dim3(grid_for(n)), dim3(256), 0, ctx->stream,
                            (const uint32_t *)perm.as<uint32_t>(), n, (const int32_t *)in.marker.as<int32_t>(),
                            (const int32_t *)in.left.as<int32_t>(), (const int32_t *)in.right.as<int32_t>(),
@@ -376,8 +545,8 @@ int sort_records(rfx_ctx *ctx, const DevRecords &in, int P, int key_bits, DevRec
                            (const unsigned long long *)long_n.as<unsigned long long>());
         RFX_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_partition_starts, dim3(grid_for(P + 1)), dim3(256), 0, ctx->stream,
-                       (const uint64_t *)out.key.as<uint64_t>(), n, P, part_start.as<int64_t>());
+    RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_partition_starts<KW>, dim3(grid_for(P + 1)), dim3(256), 0, ctx->stream,
+                                         (const KeyW<KW> *)out.key.as<KeyW<KW>>(), n, P, part_start.as<int64_t>()));
     RFX_HIP(hipGetLastError());
     out.n = n; out.words = in.words;
     return RFX_OK;
@@ -387,34 +556,37 @@ int fork_filter(rfx_ctx *ctx, bool reflected, const DevRecords &in, const int64_
                 int min_error_cov, int twin, DevRecords &out, DevBuf &out_part_start) {
     const int64_t n = in.n;
     if (in.words != n) return RFX_E_ARG;             // single-word records only
-    RFX_TRY(dev_records_alloc(ctx, out, n, n));
+    const int kw = in.kw;
+    if (kw != sub_words(k)) return RFX_E_ARG;
+    RFX_TRY(dev_records_alloc(ctx, out, n, n, kw));
     RFX_HIP(out_part_start.alloc((size_t)(P + 1) * 8, ctx->stream));
     DevBuf flag, pos;
     RFX_HIP(flag.alloc((size_t)(n ? n : 1) * 4, ctx->stream));
     RFX_HIP(pos.alloc((size_t)(n + 1) * 8, ctx->stream));
     if (n > 0) {
-        hipLaunchKernelGGL(k_head_flags, dim3(grid_for(n)), dim3(256), 0, ctx->stream,
-                           (const uint64_t *)in.key.as<uint64_t>(), n, flag.as<uint32_t>());
+        RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_head_flags<KW>, dim3(grid_for(n)), dim3(256), 0, ctx->stream,
+                                             (const KeyW<KW> *)in.key.as<KeyW<KW>>(), n, flag.as<uint32_t>()));
         RFX_HIP(hipGetLastError());
     }
     RFX_TRY(exclusive_scan_u32_to_u64(ctx, flag.as<uint32_t>(), pos.as<uint64_t>(), n));
     const int ds_ec = (twin == RFX_TWIN_DS && min_error_cov != 0) ? 1 : 0;
-    if (!reflected)
-        hipLaunchKernelGGL(k_fork_forward, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream,
-                           (const uint64_t *)in.key.as<uint64_t>(), (const int32_t *)in.marker.as<int32_t>(),
+    if (!reflected) {
+        RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_fork_forward<KW>, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream,
+                           (const KeyW<KW> *)in.key.as<KeyW<KW>>(), (const int32_t *)in.marker.as<int32_t>(),
                            (const uint64_t *)in.ext.as<uint64_t>(), (const int32_t *)in.left.as<int32_t>(), n,
                            (const uint32_t *)flag.as<uint32_t>(), (const uint64_t *)pos.as<uint64_t>(), k - 1,
-                           min_error_cov, ds_ec, out.key.as<uint64_t>(), out.marker.as<int32_t>(),
+                           min_error_cov, ds_ec, out.key.as<KeyW<KW>>(), out.marker.as<int32_t>(),
                            out.ext_off.as<int64_t>(), out.ext.as<uint64_t>(), out.left.as<int32_t>(),
-                           out.right.as<int32_t>());
-    else
-        hipLaunchKernelGGL(k_fork_reflected, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream,
-                           (const uint64_t *)in.key.as<uint64_t>(), (const int32_t *)in.marker.as<int32_t>(),
+                           out.right.as<int32_t>()));
+    } else {
+        RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_fork_reflected<KW>, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream,
+                           (const KeyW<KW> *)in.key.as<KeyW<KW>>(), (const int32_t *)in.marker.as<int32_t>(),
                            (const uint64_t *)in.ext.as<uint64_t>(), (const int32_t *)in.left.as<int32_t>(),
                            (const int32_t *)in.right.as<int32_t>(), n, (const uint32_t *)flag.as<uint32_t>(),
                            (const uint64_t *)pos.as<uint64_t>(), k - 1, min_error_cov, ds_ec,
-                           out.key.as<uint64_t>(), out.marker.as<int32_t>(), out.ext_off.as<int64_t>(),
-                           out.ext.as<uint64_t>(), out.left.as<int32_t>(), out.right.as<int32_t>());
+                           out.key.as<KeyW<KW>>(), out.marker.as<int32_t>(), out.ext_off.as<int64_t>(),
+                           out.ext.as<uint64_t>(), out.left.as<int32_t>(), out.right.as<int32_t>()));
+    }
     RFX_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_map_part_start, dim3(grid_for(P + 1)), dim3(256), 0, ctx->stream, d_part_start, P,
                        (const uint64_t *)pos.as<uint64_t>(), out_part_start.as<int64_t>());
@@ -429,12 +601,14 @@ int fork_filter(rfx_ctx *ctx, bool reflected, const DevRecords &in, const int64_
 int reflect_from_forward(rfx_ctx *ctx, const DevRecords &in, int k, DevRecords &out) {
     const int64_t n = in.n;
     if (in.words != n) return RFX_E_ARG;
-    RFX_TRY(dev_records_alloc(ctx, out, n, n));
-    hipLaunchKernelGGL(k_reflect, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream,
-                       (const uint64_t *)in.key.as<uint64_t>(), (const uint64_t *)in.ext.as<uint64_t>(),
+    const int kw = in.kw;
+    if (kw != sub_words(k)) return RFX_E_ARG;
+    RFX_TRY(dev_records_alloc(ctx, out, n, n, kw));
+    RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_reflect<KW>, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream,
+                       (const KeyW<KW> *)in.key.as<KeyW<KW>>(), (const uint64_t *)in.ext.as<uint64_t>(),
                        (const int32_t *)in.left.as<int32_t>(), (const int32_t *)in.right.as<int32_t>(), n, k - 1,
-                       out.key.as<uint64_t>(), out.marker.as<int32_t>(), out.ext_off.as<int64_t>(),
-                       out.ext.as<uint64_t>(), out.left.as<int32_t>(), out.right.as<int32_t>());
+                       out.key.as<KeyW<KW>>(), out.marker.as<int32_t>(), out.ext_off.as<int64_t>(),
+                       out.ext.as<uint64_t>(), out.left.as<int32_t>(), out.right.as<int32_t>()));
     RFX_HIP(hipGetLastError());
     out.n = n; out.words = n;
     return RFX_OK;
@@ -444,15 +618,39 @@ int random_reflection(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_
                       DevRecords &out) {
     const int64_t n = in.n;
     if (in.words != n) return RFX_E_ARG;
-    RFX_TRY(dev_records_alloc(ctx, out, n, n));
-    hipLaunchKernelGGL(k_random_reflection, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream,
-                       (const uint64_t *)in.key.as<uint64_t>(), (const int32_t *)in.marker.as<int32_t>(),
+    const int kw = in.kw;
+    if (kw != sub_words(k)) return RFX_E_ARG;
+    RFX_TRY(dev_records_alloc(ctx, out, n, n, kw));
+    RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_random_reflection<KW>, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream,
+                       (const KeyW<KW> *)in.key.as<KeyW<KW>>(), (const int32_t *)in.marker.as<int32_t>(),
                        (const uint64_t *)in.ext.as<uint64_t>(), (const int32_t *)in.left.as<int32_t>(),
                        (const int32_t *)in.right.as<int32_t>(), n, d_part_start, P, k - 1,
-                       out.key.as<uint64_t>(), out.marker.as<int32_t>(), out.ext_off.as<int64_t>(),
-                       out.ext.as<uint64_t>(), out.left.as<int32_t>(), out.right.as<int32_t>());
+                       out.key.as<KeyW<KW>>(), out.marker.as<int32_t>(), out.ext_off.as<int64_t>(),
+                       out.ext.as<uint64_t>(), out.left.as<int32_t>(), out.right.as<int32_t>()));
     RFX_HIP(hipGetLastError());
     out.n = n; out.words = n;
+    return RFX_OK;
+}
+
+// KmerBinarizer (P/ReflexivDSMain64.java:10772-10836) + filter(count >= min && count <= max) (:473-478)
+int counter_to_asm(rfx_ctx *ctx, const uint64_t *d_keys32, const int64_t *d_counts64, int64_t n, int k, int min_cov,
+                   int max_cov, uint64_t *d_out31, int32_t *d_out_counts, int64_t *out_n) {
+    *out_n = 0;
+    if (n == 0) return RFX_OK;
+    DevBuf flag, pos;
+    RFX_HIP(flag.alloc((size_t)n * 4, ctx->stream));
+    RFX_HIP(pos.alloc((size_t)(n + 1) * 8, ctx->stream));
+    hipLaunchKernelGGL(k_counter_keep, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_counts64, n, min_cov, max_cov,
+                       flag.as<uint32_t>());
+    RFX_HIP(hipGetLastError());
+    RFX_TRY(exclusive_scan_u32_to_u64(ctx, flag.as<uint32_t>(), pos.as<uint64_t>(), n));
+    hipLaunchKernelGGL(k_counter_to_asm, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_keys32, d_counts64, n, k,
+                       (const uint32_t *)flag.as<uint32_t>(), (const uint64_t *)pos.as<uint64_t>(), d_out31, d_out_counts);
+    RFX_HIP(hipGetLastError());
+    uint64_t m = 0;
+    RFX_HIP(hipMemcpyAsync(&m, pos.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    *out_n = (int64_t)m;
     return RFX_OK;
 }
 

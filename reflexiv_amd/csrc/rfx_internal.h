@@ -229,16 +229,23 @@ int count_filter_w(rfx_ctx *ctx, uint64_t *d_soa, int64_t N, int k, int min_cov,
 // ---- rfx_graph.hip : device record set (reference layout, in HBM)
 struct DevRecords {
     int64_t n = 0, words = 0;
+    int kw = 1;                 // words per key (AoS): 1 up to k = 32, (k-2)/31+1 beyond
     DevBuf key, marker, ext_off, ext, left, right;
 };
-int dev_records_alloc(rfx_ctx *ctx, DevRecords &r, int64_t cap_n, int64_t cap_words);
+inline int sub_words(int k) { return k <= 32 ? 1 : (k - 2) / 31 + 1; }     // subKmerBinarySlots, U/DefaultParam.java:94
+inline int asm_words(int k) { return k <= 31 ? 1 : (k - 1) / 31 + 1; }     // kmerBinarySlotsAssemble, U/DefaultParam.java:85
+constexpr int MAX_KEY_WORDS = 4;                                           // k <= 125
+int dev_records_alloc(rfx_ctx *ctx, DevRecords &r, int64_t cap_n, int64_t cap_words, int kw = 1);
 int dev_records_upload(rfx_ctx *ctx, const rfx_records *h, DevRecords &d);
 int dev_records_download(rfx_ctx *ctx, const DevRecords &d, rfx_records *h);
 
 int rc_expand_subkmer(rfx_ctx *ctx, const uint64_t *d_kmers, const int32_t *d_counts, int64_t n,
                       int k, DevRecords &out);
+// key_bits: significant bits of a one-word key (ignored for kw > 1: k gives the word widths)
 int sort_records(rfx_ctx *ctx, const DevRecords &in, int P, int key_bits, DevRecords &out,
-                 DevBuf &part_start /* int64[P+1] */);
+                 DevBuf &part_start /* int64[P+1] */, int k = 0);
+int counter_to_asm(rfx_ctx *ctx, const uint64_t *d_keys32, const int64_t *d_counts64, int64_t n, int k, int min_cov,
+                   int max_cov, uint64_t *d_out31, int32_t *d_out_counts, int64_t *out_n);
 int fork_filter(rfx_ctx *ctx, bool reflected, const DevRecords &in, const int64_t *d_part_start,
                 int P, int k, int min_error_cov, int twin, DevRecords &out,
                 DevBuf &out_part_start);
@@ -246,6 +253,6 @@ int reflect_from_forward(rfx_ctx *ctx, const DevRecords &in, int k, DevRecords &
 int random_reflection(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start, int P,
                       int k, DevRecords &out);
 int extend_pass(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start, int P, int k,
-                int twin, int stage, DevRecords &out, DevBuf &out_part_start);
+                int twin, int stage, DevRecords &out, DevBuf &out_part_start, int start_marker = 2);
 
 }  // namespace rfx

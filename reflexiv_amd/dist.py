@@ -436,7 +436,7 @@ def sharded_count(engine, reads, min_cov, max_cov, twin, group=None, chunks: int
     return keys, counts, [int(x) for x in tot.cpu()]
 
 
-def gather_survivors(keys: torch.Tensor, counts: torch.Tensor, group=None, root: int = 0):
+def gather_survivors(keys: torch.Tensor, counts: torch.Tensor, group=None, root: int = 0, words: int = 1):
     """Collect every rank's (kmer, count) shard on `root` (all-gather of padded shards; the
     filtered list is tiny next to the instances: D' << N).  Shards are hash ranges, so the
     concatenation is NOT in k-mer order -- the caller sorts it (rfx sort_pairs) before the
@@ -444,12 +444,14 @@ def gather_survivors(keys: torch.Tensor, counts: torch.Tensor, group=None, root:
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return keys, counts
-    n = torch.tensor([int(keys.numel())], dtype=torch.int64, device=keys.device)
+    keys = keys.reshape(-1)                      # `words` words per k-mer (k > 31: the counter's AoS layout)
+    n = torch.tensor([int(counts.numel())], dtype=torch.int64, device=keys.device)
+    assert keys.numel() == counts.numel() * words
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
     sizes = [int(x.item()) for x in sizes]
     m = max(1, max(sizes))
-    pk = torch.zeros(m, dtype=keys.dtype, device=keys.device); pk[:keys.numel()] = keys
+    pk = torch.zeros(m * words, dtype=keys.dtype, device=keys.device); pk[:keys.numel()] = keys
     pc = torch.zeros(m, dtype=counts.dtype, device=counts.device); pc[:counts.numel()] = counts
     gk = [torch.empty_like(pk) for _ in range(world)]
     gc = [torch.empty_like(pc) for _ in range(world)]
@@ -457,7 +459,7 @@ def gather_survivors(keys: torch.Tensor, counts: torch.Tensor, group=None, root:
     dist.all_gather(gc, pc, group=group)
     if dist.get_rank(group) != root:
         return None, None
-    return (torch.cat([gk[r][:sizes[r]] for r in range(world)]),
+    return (torch.cat([gk[r][:sizes[r] * words] for r in range(world)]),
             torch.cat([gc[r][:sizes[r]] for r in range(world)]))
 
 

@@ -1,0 +1,211 @@
+"""GPU parity, k > 31 assembler (P/ReflexivDSMain64.java assemblyFromKmer): every operator on multi-word
+(k-1)-mer keys through the C ABI against the CPU oracle, the device driver against the oracle's driver,
+and the resident path reads -> counter -> KmerBinarizer -> contigs.  Bit-exact (integer work)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rfx():
+    import reflexiv_amd
+    r = reflexiv_amd.Reflexiv()
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture(scope="module")
+def planted(golden_dir):
+    return np.load(os.path.join(golden_dir, "planted.npz"))
+
+
+def same_records(a, b):
+    assert a.n == b.n
+    for f in ("key", "marker", "ext_off", "ext", "left", "right"):
+        x, y = np.asarray(getattr(a, f)), np.asarray(getattr(b, f))
+        assert x.shape == y.shape and np.array_equal(x, y), f
+
+
+def filtered_kmers(bases, off, k, min_cov):
+    """(k-mers in the assembler layout uint64[n, (k-1)//31+1], int32 counts) ascending, from the oracle's counter"""
+    if k % 32 == 0 or k <= 32:
+        # the k > 31 counter does not take these k: go through text
+        import collections
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+        text = bytes(bases).decode()
+        cnt = collections.Counter()
+        for r in range(len(off) - 1):
+            s = "".join(c if c in "ACG" else "T" for c in text[off[r]:off[r + 1]])
+            for p in range(len(s) - k + 1):
+                f = s[p:p + k]
+                rc = "".join(comp[c] for c in reversed(f))
+                cnt[f if f <= rc else rc] += 1
+        keep = sorted(x for x, c in cnt.items() if c >= min_cov)
+        km = np.stack([O.kmer_binarize_w(x, "1", k)[0] for x in keep])
+        return km, np.asarray([cnt[x] for x in keep], np.int32)
+    keys, counts, _ = O.count_filter_w(O.extract_canon_w(bases, off, k), k, min_cov)
+    return O.counter_to_asm_w(keys, k), counts.astype(np.int32)
+
+
+def run_chain_w(rfx, km, counts, k, P, min_err, n_pass=12):
+    """GPU and oracle side by side, every operator fed with the ORACLE's previous output."""
+    twin = O.TWIN_DS
+    o = O.rc_expand_subkmer(km, counts, k)
+    g = rfx.KmerReverseComplement_and_ForwardSubKmerExtraction(km, counts, k)
+    same_records(g, o)
+    o = O.sort_records(o)
+    ops = O.partition_starts(o.key, P)
+    g, gps = rfx.sortByKey(g, P)
+    same_records(g, o)
+    assert np.array_equal(gps, ops)
+    o2, ops2 = O.fork_filter_forward(o, ops, k, min_err, twin)
+    g2, gps2 = rfx.FilterForkSubKmer(o, ops, k, min_err, twin)
+    same_records(g2, o2)
+    assert np.array_equal(gps2, ops2)
+    o3 = O.reflect_from_forward(o2, k)
+    same_records(rfx.ReflectedSubKmerExtractionFromForward(o2, k), o3)
+    o3 = O.sort_records(o3)
+    ops3 = O.partition_starts(o3.key, P)
+    o4, ops4 = O.fork_filter_reflected(o3, ops3, k, min_err, twin)
+    g4, gps4 = rfx.FilterForkReflectedSubKmer(o3, ops3, k, min_err, twin)
+    same_records(g4, o4)
+    assert np.array_equal(gps4, ops4)
+    o5 = O.random_reflection(o4, ops4, k)
+    same_records(rfx.kmerRandomReflection(o4, ops4, k), o5)
+    cur = o5
+    for i in range(n_pass):
+        cur = O.sort_records(cur)
+        ps = O.partition_starts(cur.key, P)
+        gs, gps = rfx.sortByKey(cur, P)
+        same_records(gs, cur)
+        assert np.array_equal(gps, ps)
+        scramble = 3 if i >= n_pass - 3 else 2
+        nxt, nps = O.extend_pass(cur, ps, k, twin, 1 if scramble == 3 else 2)
+        stage = 0 if i < 4 else (1 if i == 4 else 2)
+        g, gps = rfx.ExtendReflexivKmer(cur, ps, k, twin, stage, scramble)
+        same_records(g, nxt)
+        assert np.array_equal(gps, nps)
+        cur = nxt
+    text, nc = rfx.KmerToContig(cur, k, 100)
+    assert (text, nc) == O.contigs_text(cur, k, 100)
+    return cur
+
+
+@pytest.mark.parametrize("k,P,min_err", [(63, 4, 8), (63, 1, 0), (47, 3, 8), (33, 4, 8), (32, 2, 8), (62, 4, 8),
+                                         (64, 4, 8), (95, 2, 8)])
+def test_operator_chain_w(rfx, planted, k, P, min_err):
+    km, counts = filtered_kmers(planted["bases"], planted["read_off"], k, 2)
+    assert len(km) > 1000
+    run_chain_w(rfx, km, counts, k, P, min_err)
+
+
+def test_operator_edge_cases_w(rfx):
+    k = 63
+    empty = O.Records(np.zeros((0, 2), np.uint64), np.zeros(0, np.int32), np.zeros(1, np.int64),
+                      np.zeros(0, np.uint64), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    ps = np.zeros(3, np.int64)
+    g, gps = rfx.ExtendReflexivKmer(empty, ps, k)
+    assert g.n == 0 and list(gps) == [0, 0, 0]
+    g = rfx.KmerReverseComplement_and_ForwardSubKmerExtraction(np.zeros((0, 3), np.uint64), np.zeros(0, np.int32), k)
+    assert g.n == 0
+    # one k-mer: two records (itself and its reverse complement), one pass each way
+    s = "ACGT" * 15 + "ACG"
+    km = O.kmer_binarize_w(s, "5", k)[0].reshape(1, 3)
+    o = O.rc_expand_subkmer(km, np.array([5], np.int32), k)
+    same_records(rfx.KmerReverseComplement_and_ForwardSubKmerExtraction(km, np.array([5], np.int32), k), o)
+    # a key-width that does not belong to k is refused, not misread
+    import reflexiv_amd
+    with pytest.raises(reflexiv_amd.RfxError):
+        rfx.ReflectedSubKmerExtractionFromForward(o, 31)
+
+
+def to_dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64 if a.dtype == np.uint64 else a.dtype)).cuda()
+
+
+@pytest.mark.parametrize("k,P", [(63, 4), (63, 8), (47, 4), (33, 1), (95, 4), (64, 2)])
+def test_driver_w_matches_oracle(rfx, torch_mod, planted, k, P):
+    import reflexiv_amd
+    torch = torch_mod
+    km, counts = filtered_kmers(planted["bases"], planted["read_off"], k, 2)
+    dk, dc = to_dev(torch, km), to_dev(torch, counts)
+    torch.cuda.synchronize()
+    text, nc, trace = rfx.assemble_w_dev(dk.data_ptr(), dc.data_ptr(), len(counts),
+                                         reflexiv_amd.default_params(k=k, min_cov=2, partitions=P, min_contig=100))
+    otext, onc, otrace, _ = O.assemble_from_counts(km, counts, O.default_params(k=k, min_cov=2, partitions=P, min_contig=100))
+    assert trace == otrace and nc == onc and text == otext
+    assert nc >= 2
+
+
+@pytest.mark.parametrize("k", [63, 47, 33, 95])
+def test_counter_to_asm_dev(rfx, torch_mod, planted, k):
+    torch = torch_mod
+    keys, counts, _ = O.count_filter_w(O.extract_canon_w(planted["bases"], planted["read_off"], k), k, 1)
+    counts = counts.copy()
+    counts[::97] = 12_345_678_901                         # >= 10 digits reads as 1000000000 (:10801-10806)
+    for lo, hi in ((1, 10_000_000), (3, 40), (2, 1_000_000_000)):
+        c32 = np.where(counts >= 1_000_000_000, 1_000_000_000, counts).astype(np.int32)
+        keep = (c32 >= lo) & (c32 <= hi)
+        want_k = O.counter_to_asm_w(keys[keep], k)
+        dk, dc = to_dev(torch, keys), to_dev(torch, counts)
+        ok = torch.empty(len(keys) * O.asm_words(k), dtype=torch.int64, device="cuda")
+        oc = torch.empty(len(keys), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        m = rfx.counter_to_asm_dev(dk.data_ptr(), dc.data_ptr(), len(keys), k, ok.data_ptr(), oc.data_ptr(), lo, hi)
+        assert m == int(keep.sum())
+        assert np.array_equal(ok[:m * O.asm_words(k)].cpu().numpy().view(np.uint64).reshape(m, -1), want_k)
+        assert np.array_equal(oc[:m].cpu().numpy(), c32[keep])
+
+
+def make_reads_dev(rfx, torch, seed, genome_len, n_reads, read_len):
+    wpr = (read_len + 31) // 32
+    dg = torch.empty((genome_len + 31) // 32, dtype=torch.int64, device="cuda")
+    dw = torch.empty(n_reads * wpr, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    rfx.synth_genome_dev(seed, genome_len, dg.data_ptr())
+    rfx.synth_reads_dev(seed, dg.data_ptr(), genome_len, 0, n_reads, read_len, wpr, dw.data_ptr())
+    rfx.sync()
+    return dg, dw, wpr
+
+
+@pytest.mark.parametrize("k,G,n_reads,P", [(63, 200_000, 60_000, 8), (47, 60_000, 16_000, 4)])
+def test_resident_reads_to_contigs_w(rfx, torch_mod, k, G, n_reads, P):
+    """reads in HBM -> k > 31 counter -> KmerBinarizer + filter -> driver -> text, against the oracle end to end;
+    contigs of tens of kbp: the long-extension emit path on two-word keys."""
+    import reflexiv_amd
+    torch = torch_mod
+    seed, L, cov = 5, 150, 3
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    W = k // 32 + 1
+    N = rfx.kmers_per_read_w(L, k) * n_reads
+    cap = N // 2
+    dk = torch.empty(cap * W, dtype=torch.int64, device="cuda"); dc = torch.empty(cap, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    m, nd, inst = rfx.count_reads_w_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), cap, cov)
+    ak = torch.empty(m * O.asm_words(k), dtype=torch.int64, device="cuda"); ac = torch.empty(m, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    m2 = rfx.counter_to_asm_dev(dk.data_ptr(), dc.data_ptr(), m, k, ak.data_ptr(), ac.data_ptr(), cov)
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+    wk, wc, wd = O.count_filter_w(O.extract_canon_w(bases, off, k), k, cov)
+    assert (m, nd, m2) == (len(wk), wd, len(wk))
+    km = O.counter_to_asm_w(wk, k)
+    assert np.array_equal(ak.cpu().numpy().view(np.uint64).reshape(m, -1), km)
+    prm = reflexiv_amd.default_params(k=k, min_cov=cov, partitions=P)
+    text, nc, trace = rfx.assemble_w_dev(ak.data_ptr(), ac.data_ptr(), m2, prm)
+    otext, onc, otrace, _ = O.assemble_from_counts(km, wc.astype(np.int32), O.default_params(k=k, min_cov=cov, partitions=P))
+    assert trace == otrace and nc == onc and text == otext
+    lens = [int(h.split("-")[1]) for h in text.split("\n") if h.startswith(">")]
+    assert max(lens) > 20_000

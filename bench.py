@@ -30,17 +30,23 @@ ALGO_BYTES = {"hist1": 0.25, "part1": 8.25, "hist2": 8.0, "part2": 16.0, "hist3"
               "leaf": 8.0, "extract_w": 0.25 + 16.0, "count_w": 16.0}      # k = 63: W = 2 words per instance
 
 
+TRAFFIC_PROFILES = ("profiles/r02_hbm_traffic.json", "profiles/r01_hbm_traffic.json")
+
+
 def measured_traffic(kernel, n_inst):
-    """HBM bytes per launch of `kernel` from the committed PMC profile (separate FETCH_SIZE /
-    WRITE_SIZE passes, FETCH doubled per MI355X_MICROARCH.md), if it was taken on this workload."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    try:
-        prof = json.load(open(path))
-        if prof.get("kmer_instances") == n_inst and kernel in prof["kernels"]:
-            return prof["kernels"][kernel]["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    """HBM bytes per launch of `kernel` from a COMMITTED PMC profile of this same command (rocprofv3 --pmc, separate
+    FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per MI355X_MICROARCH.md) when one exists for this workload.  PMC
+    counters cannot be read from inside the run, so this is evidence from the builder's box, named as such in
+    `traffic_source`; (None, None) when no profile matches.  -> (bytes per launch, source)"""
+    for rel in TRAFFIC_PROFILES:
+        try:
+            prof = json.load(open(os.path.join(ROOT, rel)))
+            if prof.get("kmer_instances") == n_inst and kernel in prof["kernels"]:
+                return prof["kernels"][kernel]["hbm_bytes_per_launch"], \
+                    rel + " (rocprofv3 --pmc passes of this command on the builder's box; not measured in this run)"
+        except (OSError, ValueError, KeyError):
+            pass
+    return None, None
 
 
 def parse():
@@ -98,29 +104,47 @@ def self_launch(args):
     sys.exit(subprocess.run(cmd).returncode)
 
 
-def cpu_baseline(args, n_sample):
-    """The oracle (CPU restatement of the same operators, one core) on a bounded sample of the
-    same workload: the first n_sample reads."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, n_sample, n_reads_total):
+    """The oracle (CPU restatement of the same operators) over ALL host cores, OpenMP, one logical partition per
+    task (SURVEY.md 8d / BASELINE.md 3: "reference-equivalent CPU path (C restatement), not Spark/JVM"), on a bounded
+    sample of the same workload -- the first n_sample reads -- through the WHOLE path: extract + count + filter
+    (k-mers/s) and on to final contigs (wall-clock).  -cover is scaled to the sample's depth."""
     import numpy as np
     from oracle import oracle as O
-    import ctypes as C
+    cores = O.host_cores()
+    O.set_threads(cores)
+    cover = max(2, int(round(args.cover * n_sample / n_reads_total)))
     g = O.synth_genome(args.seed, args.genome)
     bases, off = O.synth_reads(args.seed, g, args.genome, 0, n_sample, args.read_len)
-    nk = (args.read_len - args.k + 1) * n_sample
-    out = np.empty(nk, np.uint64)
-    keys = np.empty(nk, np.uint64); counts = np.empty(nk, np.int32)
-    L = O.lib()
     t0 = time.perf_counter()
-    n = L.orc_extract_canon(bases.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), C.c_int64(n_sample),
-                            args.k, 0, 0, out.ctypes.data_as(C.c_void_p), C.c_int64(nk))
-    nd = C.c_int64(0)
-    L.orc_count_filter(out.ctypes.data_as(C.c_void_p), C.c_int64(n), args.cover, 10_000_000, 0,
-                       keys.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), C.c_int64(nk),
-                       C.byref(nd))
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
-            "sample": f"first {n_sample} reads of the workload ({n} k-mer instances), extract+count+filter, "
-                      f"{dt:.1f} s on one host core (oracle/reflexiv_oracle.c)"}
+    keys, counts, nd, n = O.count_reads_omp(bases, off, args.k, cover, 10_000_000, 0,
+                                            cap=max(1 << 20, 4 * args.genome))
+    t_count = time.perf_counter() - t0
+    prm = O.default_params(k=args.k, min_cov=cover, partitions=args.partitions)
+    t1 = time.perf_counter()
+    text, nc, trace, _ = O.assemble_from_counts(keys, counts, prm)
+    t_asm = time.perf_counter() - t1
+    O.set_threads(1)
+    lens = sorted((int(h.split("-")[1]) for h in text.split("\n") if h.startswith(">")), reverse=True)
+    return {"value": n / t_count, "unit": "k-mers/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "label": "reference-equivalent CPU path (C restatement of the Spark operators, OpenMP, one logical partition "
+                     "per task), not Spark/JVM",
+            "sample": f"first {n_sample} reads of the workload ({n} k-mer instances, {n_sample * args.read_len / args.genome:.0f}x, "
+                      f"-cover {cover}): extract+count+filter {t_count:.2f} s, counts -> contigs {t_asm:.2f} s "
+                      f"({len(trace)} extend passes, {args.partitions} logical partitions), on {cores} host cores "
+                      "(oracle/reflexiv_oracle.c, orc_count_reads_omp + orc_assemble_from_counts)",
+            "count_stage_s": t_count, "counts_to_contigs_s": t_asm, "reads_to_contigs_s": t_count + t_asm,
+            "kmers_kept": int(len(keys)), "distinct_kmers": int(nd), "n_contigs": nc, "longest": lens[:3]}
 
 
 def main():
@@ -154,14 +178,19 @@ def main():
         if int(probe.item()) != args.gpus and not (args.force_dist and args.gpus == 1):
             sys.stderr.write(f"bench.py: {int(probe.item())} ranks joined the RCCL group, --gpus {args.gpus} asked for\n")
             sys.exit(2)
-    rfx = reflexiv_amd.Reflexiv(local)
-    rfx.use_stream(torch.cuda.current_stream().cuda_stream)   # kernels, copies and RCCL share one stream
-    dev = torch.device("cuda", local)
-
     L, k = args.read_len, args.k
     wpr = (L + 31) // 32
     n_reads = int(round(args.gbp * 1e9 / L))
     n_reads += n_reads & 1                                    # whole pairs
+    # the CPU baseline runs FIRST (rank 0, N = 1, k <= 31 only), before anything touches the GPU: the GPU phase of
+    # the run is then one uninterrupted stretch at the end
+    cpu_record = None
+    if rank == 0 and not multi and not args.no_cpu_baseline and k <= 31:
+        cpu_record = cpu_baseline(args, min(args.cpu_sample_reads, n_reads), n_reads)
+    rfx = reflexiv_amd.Reflexiv(local)
+    rfx.use_stream(torch.cuda.current_stream().cuda_stream)   # kernels, copies and RCCL share one stream
+    dev = torch.device("cuda", local)
+
     wide = k > 31                                             # the counter's multi-word k-mers
     W = k // 32 + 1 if wide else 1
     nk = rfx.kmers_per_read_w(L, k) if wide else rfx.kmers_per_read(L, k)
@@ -253,8 +282,9 @@ def main():
         # it over parts of the batch): price the family's time per STEP against the batch's algorithmic bytes
         avg_s = ms / 1e3 / args.steps
         achieved = per_launch_bytes / avg_s / 1e9
+        traffic, traffic_source = measured_traffic(dom, n_inst)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(dom, n_inst),
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_s * 1e3,
                     "launches_per_step": launches / args.steps,
                     "per_kernel_ms_per_step": {n: v[0] / args.steps for n, v in sorted(timing_acc.items())}}
@@ -332,8 +362,8 @@ def main():
         out["contigs"] = {"wall_ms_from_counts": t_asm * 1e3, "wall_ms_reads_to_contigs": t_asm * 1e3 + dt / args.steps * 1e3,
                           "untimed_warmup_runs": 1, "extend_passes": len(trace), "n_contigs": nc, "longest": lens[:3],
                           "total_bases": sum(lens)}
-    if rank == 0 and not multi and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, min(args.cpu_sample_reads, n_reads))
+    if cpu_record is not None:
+        out["cpu_baseline"] = cpu_record
     if rank == 0:
         print(json.dumps(out))
     if multi:

@@ -62,6 +62,7 @@ def lib():
         L.orc_assemble_from_counts.restype = C.c_int64
         L.orc_splitmix64.restype = C.c_uint64
         L.orc_splitmix64.argtypes = [C.c_uint64]
+        L.orc_count_reads_omp.restype = C.c_int64
         for f in ("orc_fork_filter_forward_w", "orc_fork_filter_reflected_w", "orc_extend_pass_w",
                   "orc_contigs_text_w", "orc_assemble_from_counts_w"):
             getattr(L, f).restype = C.c_int64
@@ -175,6 +176,32 @@ def count_filter(kmers: np.ndarray, min_cov=2, max_cov=10_000_000, twin=TWIN_DS)
     m = lib().orc_count_filter(_p(work), C.c_int64(n), min_cov, max_cov, twin,
                                _p(keys), _p(counts), C.c_int64(n), C.byref(nd))
     return keys[:m].copy(), counts[:m].copy(), int(nd.value)
+
+
+def set_threads(t: int):
+    """threads for the CPU-baseline leg (1 = strictly serial, the default and what the parity tests use)"""
+    lib().orc_set_threads(int(t))
+
+
+def host_cores() -> int:
+    return int(lib().orc_host_cores())
+
+
+def count_reads_omp(bases, read_off, k=31, min_cov=2, max_cov=10_000_000, twin=TWIN_DS, front_clip=0, end_clip=0,
+                    cap=None):
+    """extract + reduceByKey + filter over the threads of set_threads() -> (keys, counts, n_distinct, n_instances)"""
+    bases = np.ascontiguousarray(bases, np.uint8)
+    read_off = np.ascontiguousarray(read_off, np.int64)
+    nr = len(read_off) - 1
+    if cap is None:
+        cap = max(1, int(read_off[-1] - read_off[0]))
+    keys = np.empty(cap, np.uint64); counts = np.empty(cap, np.int32)
+    nd, ni = C.c_int64(0), C.c_int64(0)
+    m = lib().orc_count_reads_omp(_p(bases), _p(read_off), C.c_int64(nr), k, front_clip, end_clip, min_cov, max_cov, twin,
+                                  _p(keys), _p(counts), C.c_int64(cap), C.byref(nd), C.byref(ni))
+    if m > cap:
+        raise ValueError(f"cap {cap} < {m} survivors")
+    return keys[:m].copy(), counts[:m].copy(), int(nd.value), int(ni.value)
 
 
 def words_w(k: int) -> int:

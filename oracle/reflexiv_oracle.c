@@ -16,8 +16,33 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* ------------------------------------------------------------------ helpers */
+
+/* Threads for the CPU-baseline leg of bench.py ("OpenMP, one logical partition per
+ * thread ~ local[N]").  1 (the default) keeps every function below strictly serial, which is what the
+ * parity tests use; with more, the partition-wise operators run one logical partition per task -- the
+ * serial function applied to that partition alone, exactly as a Spark task would -- sorts and gathers
+ * split by index range, and the results are identical (tests/test_oracle_omp.py). */
+static int g_threads = 1;
+void orc_set_threads(int t) {
+#ifdef _OPENMP
+    g_threads = t < 1 ? 1 : t;
+#else
+    (void)t; g_threads = 1;
+#endif
+}
+int orc_get_threads(void) { return g_threads; }
+int orc_host_cores(void) {
+#ifdef _OPENMP
+    return omp_get_num_procs();
+#else
+    return 1;
+#endif
+}
 
 static void *xmalloc(size_t n) {
     void *p = malloc(n ? n : 1);
@@ -273,6 +298,24 @@ static void radix_sort_u64(uint64_t *a, int64_t n) {
     free(tmp); free(hist);
 }
 
+/* LSD radix sort of the low `bits` bits, 11-bit digits, caller's scratch (the buckets of
+ * orc_count_reads_omp: the top bits are equal inside a bucket) */
+static void radix_sort_low(uint64_t *a, int64_t n, int bits, uint64_t *tmp) {
+    if (n < 2) return;
+    int64_t hist[2048];
+    uint64_t *src = a, *dst = tmp;
+    for (int sh = 0; sh < bits; sh += 11) {
+        memset(hist, 0, sizeof hist);
+        for (int64_t i = 0; i < n; i++) hist[(src[i] >> sh) & 2047]++;
+        if (hist[(src[0] >> sh) & 2047] == n) continue;
+        int64_t s = 0;
+        for (int d = 0; d < 2048; d++) { int64_t c = hist[d]; hist[d] = s; s += c; }
+        for (int64_t i = 0; i < n; i++) dst[hist[(src[i] >> sh) & 2047]++] = src[i];
+        uint64_t *t = src; src = dst; dst = t;
+    }
+    if (src != a) memcpy(a, src, (size_t)n * 8);
+}
+
 /* ----------------------------------------------------- a-3/a-4 count, filter */
 
 int64_t orc_count_filter(uint64_t *kmers, int64_t n, int min_cov, int max_cov, int twin,
@@ -297,6 +340,133 @@ int64_t orc_count_filter(uint64_t *kmers, int64_t n, int min_cov, int max_cov, i
     }
     if (n_distinct) *n_distinct = d;
     return m;
+}
+
+/* ---- a-2 + a-3 + a-4 over all host cores (bench.py's cpu_baseline) ----
+ * The same operators as orc_extract_canon + orc_count_filter, organised the way Spark's local[N] runs
+ * them: every thread extracts the canonical k-mers of its own slice of the reads (one map task per
+ * slice) straight into range buckets of the k-mer space (the shuffle write; bucket = top 12 bits of the
+ * k-mer), then buckets are sorted, run-length counted and filtered by whichever thread is free (the
+ * reduce side of reduceByKey, P/ReflexivMain.java:155, 2895-2899, 3115-3119).  Buckets are ranges, so their
+ * concatenation is the ascending order of the order contract.  Result identical to the serial pair. */
+static inline void read_kmers(const char *read, int64_t len, int k, int front_clip, int end_clip, uint64_t mask,
+                              int shift, int64_t *hist, uint64_t *arr, int64_t *cursor) {
+    if (len - k - end_clip <= 1 || front_clip > len) return;                 /* :3020 */
+    uint64_t fwd = 0, rc = 0;
+    for (int64_t i = front_clip; i < len - end_clip; i++) {                  /* :3027 */
+        int64_t j = i - front_clip;
+        uint64_t v = nuc_value(read[i]);
+        fwd = (fwd << 2) | v;                                                /* :3032-3033 */
+        if (j >= k) fwd &= mask;                                             /* :3034-3036 */
+        uint64_t c = v ^ 3;                                                  /* :3039 */
+        if (j >= k) { rc >>= 2; c <<= 2 * (k - 1); }                         /* :3041-3043 */
+        else        { c <<= 2 * j; }                                         /* :3045 */
+        rc |= c;                                                             /* :3047 */
+        if (j >= k - 1) {                                                    /* :3050 */
+            uint64_t canon = ((int64_t)fwd < (int64_t)rc) ? fwd : rc;        /* :3051-3055 */
+            if (arr) arr[cursor[canon >> shift]++] = canon; else hist[canon >> shift]++;
+        }
+    }
+}
+
+int64_t orc_count_reads_omp(const char *bases, const int64_t *read_off, int64_t n_reads,
+                            int k, int front_clip, int end_clip, int min_cov, int max_cov, int twin,
+                            uint64_t *out_keys, int32_t *out_counts, int64_t cap,
+                            int64_t *n_distinct, int64_t *n_instances) {
+    const int T = g_threads;
+    const int BB = k >= 6 ? 12 : 2 * k;                 /* bucket bits */
+    const int NB = 1 << BB, shift = 2 * k - BB;
+    const uint64_t mask = low_mask(k);
+    int64_t *hist = (int64_t *)xmalloc((size_t)T * NB * sizeof(int64_t));
+    memset(hist, 0, (size_t)T * NB * sizeof(int64_t));
+#ifdef _OPENMP
+#pragma omp parallel num_threads(T)
+#endif
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num();
+#else
+        const int t = 0;
+#endif
+        const int64_t lo = n_reads * t / T, hi = n_reads * (t + 1) / T;
+        for (int64_t r = lo; r < hi; r++)
+            read_kmers(bases + read_off[r], read_off[r + 1] - read_off[r], k, front_clip, end_clip, mask, shift,
+                       hist + (size_t)t * NB, NULL, NULL);
+    }
+    int64_t *bstart = (int64_t *)xmalloc((size_t)(NB + 1) * sizeof(int64_t));
+    int64_t N = 0;
+    for (int b = 0; b < NB; b++) {
+        bstart[b] = N;
+        for (int t = 0; t < T; t++) { int64_t c = hist[(size_t)t * NB + b]; hist[(size_t)t * NB + b] = N; N += c; }
+    }
+    bstart[NB] = N;
+    if (n_instances) *n_instances = N;
+    uint64_t *arr = (uint64_t *)xmalloc((size_t)(N ? N : 1) * 8);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(T)
+#endif
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num();
+#else
+        const int t = 0;
+#endif
+        const int64_t lo = n_reads * t / T, hi = n_reads * (t + 1) / T;
+        for (int64_t r = lo; r < hi; r++)
+            read_kmers(bases + read_off[r], read_off[r + 1] - read_off[r], k, front_clip, end_clip, mask, shift,
+                       NULL, arr, hist + (size_t)t * NB);
+    }
+    /* reduce side: sort + run-length + filter per bucket; two sweeps so that survivors land in order */
+    const int apply = !(twin == ORC_TWIN_RDD && min_cov <= 1);                /* :160 vs DS :211-216 */
+    int64_t *bm = (int64_t *)xmalloc((size_t)(NB + 1) * sizeof(int64_t)), *bd = (int64_t *)xmalloc((size_t)NB * sizeof(int64_t));
+    int64_t maxb = 1;
+    for (int b = 0; b < NB; b++) if (bstart[b + 1] - bstart[b] > maxb) maxb = bstart[b + 1] - bstart[b];
+    uint64_t *scratch = (uint64_t *)xmalloc((size_t)T * (size_t)maxb * 8);
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(T) schedule(dynamic, 4)
+#endif
+    for (int b = 0; b < NB; b++) {
+        uint64_t *a = arr + bstart[b];
+        const int64_t n = bstart[b + 1] - bstart[b];
+#ifdef _OPENMP
+        radix_sort_low(a, n, shift, scratch + (size_t)omp_get_thread_num() * (size_t)maxb);
+#else
+        radix_sort_low(a, n, shift, scratch);
+#endif
+        int64_t m = 0, d = 0;
+        for (int64_t i = 0; i < n;) {
+            int64_t j = i + 1;
+            while (j < n && a[j] == a[i]) j++;
+            const int32_t c = (int32_t)(j - i);                              /* i1 + i2 on Integer :2897 */
+            d++;
+            if (!apply || (c >= min_cov && c <= max_cov)) m++;               /* :3117 */
+            i = j;
+        }
+        bm[b] = m; bd[b] = d;
+    }
+    int64_t M = 0, D = 0;
+    for (int b = 0; b < NB; b++) { int64_t c = bm[b]; bm[b] = M; M += c; D += bd[b]; }
+    bm[NB] = M;
+    if (n_distinct) *n_distinct = D;
+    if (M <= cap) {
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(T) schedule(dynamic, 4)
+#endif
+        for (int b = 0; b < NB; b++) {
+            const uint64_t *a = arr + bstart[b];
+            const int64_t n = bstart[b + 1] - bstart[b];
+            int64_t o = bm[b];
+            for (int64_t i = 0; i < n;) {
+                int64_t j = i + 1;
+                while (j < n && a[j] == a[i]) j++;
+                const int32_t c = (int32_t)(j - i);
+                if (!apply || (c >= min_cov && c <= max_cov)) { out_keys[o] = a[i]; out_counts[o] = c; o++; }
+                i = j;
+            }
+        }
+    }
+    free(hist); free(bstart); free(arr); free(bm); free(bd); free(scratch);
+    return M;
 }
 
 /* ------------------------------------------------------------ a-5/a-6 expand */
@@ -406,8 +576,54 @@ static inline int key_eq(const uint64_t *a, const uint64_t *b, int kw) {
     return 1;
 }
 
+#ifdef _OPENMP
+/* the same stable LSD radix sort with the index range cut into T chunks: per-chunk histograms, offsets
+ * in (digit, chunk) order, every chunk scatters its own elements in order -> the same permutation */
+static void sort_perm_par(const uint64_t *key, int64_t n, int kw, int64_t *perm, int T) {
+    int64_t *tmp = (int64_t *)xmalloc((size_t)n * sizeof(int64_t));
+    int64_t *hist = (int64_t *)xmalloc((size_t)T * 65536 * sizeof(int64_t));
+#pragma omp parallel for num_threads(T) schedule(static)
+    for (int64_t i = 0; i < n; i++) perm[i] = i;
+    int64_t *src = perm, *dst = tmp;
+    for (int w = kw - 1; w >= 0; w--) {
+        for (int pass = 0; pass < 4; pass++) {
+            const int sh = 16 * pass;
+            int same = 0;
+#pragma omp parallel num_threads(T)
+            {
+                const int t = omp_get_thread_num();
+                const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+                int64_t *h = hist + (size_t)t * 65536;
+                memset(h, 0, 65536 * sizeof(int64_t));
+                for (int64_t i = lo; i < hi; i++) h[(key[src[i] * kw + w] >> sh) & 0xFFFF]++;
+#pragma omp barrier
+#pragma omp single
+                {
+                    int64_t tot0 = 0;
+                    const int d0 = (int)((key[src[0] * kw + w] >> sh) & 0xFFFF);
+                    for (int q = 0; q < T; q++) tot0 += hist[(size_t)q * 65536 + d0];
+                    same = tot0 == n;
+                    if (!same) {
+                        int64_t sum = 0;
+                        for (int d = 0; d < 65536; d++)
+                            for (int q = 0; q < T; q++) { int64_t c = hist[(size_t)q * 65536 + d]; hist[(size_t)q * 65536 + d] = sum; sum += c; }
+                    }
+                }
+                if (!same) for (int64_t i = lo; i < hi; i++) dst[h[(key[src[i] * kw + w] >> sh) & 0xFFFF]++] = src[i];
+            }
+            if (!same) { int64_t *x = src; src = dst; dst = x; }
+        }
+    }
+    if (src != perm) memcpy(perm, src, (size_t)n * sizeof(int64_t));
+    free(tmp); free(hist);
+}
+#endif
+
 void orc_sort_perm_w(const uint64_t *key, int64_t n, int kw, int64_t *perm) {
     /* stable LSD radix sort of (key, index), last word first; ties keep arrival order (B.0) */
+#ifdef _OPENMP
+    if (g_threads > 1 && n >= (1 << 18)) { sort_perm_par(key, n, kw, perm, g_threads); return; }
+#endif
     int64_t *tmp = (int64_t *)xmalloc((size_t)(n ? n : 1) * sizeof(int64_t));
     int64_t *hist = (int64_t *)xmalloc(65536 * sizeof(int64_t));
     for (int64_t i = 0; i < n; i++) perm[i] = i;
@@ -455,7 +671,45 @@ void orc_partition_starts(const uint64_t *sorted_key, int64_t n, int P, int64_t 
 #define KEY(a, i) ((a) + (size_t)(i) * (size_t)kw)
 #define KEYCPY(d, s_) memcpy((d), (s_), (size_t)kw * 8)
 
-int64_t orc_fork_filter_forward_w(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
+typedef int64_t (*fork_fn)(const uint64_t *, const int32_t *, const uint64_t *, const int32_t *, const int32_t *, int64_t,
+                           const int64_t *, int, int, int, int, uint64_t *, int32_t *, uint64_t *, int32_t *, int32_t *,
+                           int64_t *);
+
+/* one task per logical partition: the serial filter applied to that partition alone, results concatenated */
+static int64_t fork_by_tasks(fork_fn fn, const uint64_t *key, const int32_t *marker, const uint64_t *ext,
+                             const int32_t *left, const int32_t *right,
+                             const int64_t *part_start, int P, int k, int min_error_cov, int twin,
+                             uint64_t *okey, int32_t *omarker, uint64_t *oext,
+                             int32_t *oleft, int32_t *oright, int64_t *out_part_start) {
+    const int kw = orc_sub_words(k);
+    int64_t *cnt = (int64_t *)xmalloc((size_t)(P + 1) * 8);
+    /* a partition's survivors are no more than its records: write them at the partition's own start */
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
+#endif
+    for (int p = 0; p < P; p++) {
+        const int64_t b = part_start[p], np_ = part_start[p + 1] - b;
+        int64_t one[2] = { 0, np_ }, oone[2];
+        cnt[p] = fn(key + (size_t)b * kw, marker + b, ext + b, left + b, right + b, np_, one, 1, k, min_error_cov, twin,
+                    okey + (size_t)b * kw, omarker + b, oext + b, oleft + b, oright + b, oone);
+    }
+    int64_t m = 0;
+    for (int p = 0; p < P; p++) {                          /* compact towards the front, in order */
+        const int64_t b = part_start[p], c = cnt[p];
+        out_part_start[p] = m;
+        if (b != m && c > 0) {
+            memmove(okey + (size_t)m * kw, okey + (size_t)b * kw, (size_t)c * 8 * kw);
+            memmove(omarker + m, omarker + b, (size_t)c * 4); memmove(oext + m, oext + b, (size_t)c * 8);
+            memmove(oleft + m, oleft + b, (size_t)c * 4); memmove(oright + m, oright + b, (size_t)c * 4);
+        }
+        m += c;
+    }
+    out_part_start[P] = m;
+    free(cnt);
+    return m;
+}
+
+static int64_t fork_filter_forward_serial(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
                                   const int32_t *left, const int32_t *right, int64_t n,
                                   const int64_t *part_start, int P,
                                   int k, int min_error_cov, int twin,
@@ -496,6 +750,19 @@ int64_t orc_fork_filter_forward_w(const uint64_t *key, const int32_t *marker, co
     }
     out_part_start[P] = m;
     return m;
+}
+
+int64_t orc_fork_filter_forward_w(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
+                                  const int32_t *left, const int32_t *right, int64_t n,
+                                  const int64_t *part_start, int P,
+                                  int k, int min_error_cov, int twin,
+                                  uint64_t *okey, int32_t *omarker, uint64_t *oext,
+                                  int32_t *oleft, int32_t *oright, int64_t *out_part_start) {
+    if (g_threads > 1 && P > 1)
+        return fork_by_tasks(fork_filter_forward_serial, key, marker, ext, left, right, part_start, P, k, min_error_cov, twin,
+                             okey, omarker, oext, oleft, oright, out_part_start);
+    return fork_filter_forward_serial(key, marker, ext, left, right, n, part_start, P, k, min_error_cov, twin,
+                                      okey, omarker, oext, oleft, oright, out_part_start);
 }
 
 int64_t orc_fork_filter_forward(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
@@ -611,7 +878,7 @@ void orc_reflect_from_forward(const uint64_t *key, const uint64_t *ext, int64_t 
 
 /* ------------------------------------------------------- a-9 reflected filter */
 
-int64_t orc_fork_filter_reflected_w(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
+static int64_t fork_filter_reflected_serial(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
                                     const int32_t *left, const int32_t *right, int64_t n,
                                     const int64_t *part_start, int P,
                                     int k, int min_error_cov, int twin,
@@ -668,6 +935,19 @@ int64_t orc_fork_filter_reflected_w(const uint64_t *key, const int32_t *marker, 
     return m;
 }
 
+int64_t orc_fork_filter_reflected_w(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
+                                    const int32_t *left, const int32_t *right, int64_t n,
+                                    const int64_t *part_start, int P,
+                                    int k, int min_error_cov, int twin,
+                                    uint64_t *okey, int32_t *omarker, uint64_t *oext,
+                                    int32_t *oleft, int32_t *oright, int64_t *out_part_start) {
+    if (g_threads > 1 && P > 1)
+        return fork_by_tasks(fork_filter_reflected_serial, key, marker, ext, left, right, part_start, P, k, min_error_cov, twin,
+                             okey, omarker, oext, oleft, oright, out_part_start);
+    return fork_filter_reflected_serial(key, marker, ext, left, right, n, part_start, P, k, min_error_cov, twin,
+                                        okey, omarker, oext, oleft, oright, out_part_start);
+}
+
 int64_t orc_fork_filter_reflected(const uint64_t *key, const int32_t *marker, const uint64_t *ext,
                                   const int32_t *left, const int32_t *right, int64_t n,
                                   const int64_t *part_start, int P,
@@ -685,6 +965,18 @@ void orc_random_reflection_w(uint64_t *key, int32_t *marker, uint64_t *ext, int6
     /* kmerRandomReflection  P/ReflexivMain.java:2783-2885; 64: DSkmerRandomReflection :10491-10690 */
     (void)n;
     const int kw = orc_sub_words(k), sub = k - 1;
+    if (g_threads > 1 && P > 1) {                    /* one task per logical partition */
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
+#endif
+        for (int p = 0; p < P; p++) {
+            const int64_t b0 = part_start[p];
+            int64_t one[2] = { 0, part_start[p + 1] - b0 };
+            /* P = 1 below: the serial branch */
+            orc_random_reflection_w(key + (size_t)b0 * kw, marker + b0, ext + b0, one[1], one, 1, k);
+        }
+        return;
+    }
     uint8_t *b = (uint8_t *)xmalloc((size_t)sub + 96);
     for (int p = 0; p < P; p++) {
         int m = 2;                                   /* randomReflexivMarker = 2 :2777 */
@@ -711,7 +1003,70 @@ void orc_random_reflection(uint64_t *key, int32_t *marker, uint64_t *ext, int64_
 
 #define ORC_BLOCK (INT32_MIN)
 
+static int64_t extend_pass_serial(const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
+                          const uint64_t *ext, const int32_t *left, const int32_t *right,
+                          int64_t n, const int64_t *part_start, int P, int k, int twin, int start_marker,
+                          uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext,
+                          int32_t *oleft, int32_t *oright, int64_t *out_part_start);
+
+/* one task per logical partition (P/ReflexivMain.java: one call() per partition): the serial pass applied
+ * to that partition alone into private buffers, then concatenated in partition order */
+static int64_t extend_by_tasks(const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
+                               const uint64_t *ext, const int32_t *left, const int32_t *right,
+                               const int64_t *part_start, int P, int k, int twin, int start_marker,
+                               uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext,
+                               int32_t *oleft, int32_t *oright, int64_t *out_part_start) {
+    const int kw = orc_sub_words(k);
+    orc_records *tmp = (orc_records *)xmalloc((size_t)P * sizeof(orc_records));
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
+#endif
+    for (int p = 0; p < P; p++) {
+        const int64_t b = part_start[p], np_ = part_start[p + 1] - b;
+        const int64_t wp = ext_off[b + np_] - ext_off[b];
+        orc_records *t = &tmp[p];
+        t->key = (uint64_t *)xmalloc((size_t)(np_ ? np_ : 1) * 8 * kw);
+        t->marker = (int32_t *)xmalloc((size_t)(np_ ? np_ : 1) * 4);
+        t->ext_off = (int64_t *)xmalloc((size_t)(np_ + 1) * 8);
+        t->ext = (uint64_t *)xmalloc((size_t)(wp ? wp : 1) * 8);
+        t->left = (int32_t *)xmalloc((size_t)(np_ ? np_ : 1) * 4);
+        t->right = (int32_t *)xmalloc((size_t)(np_ ? np_ : 1) * 4);
+        int64_t one[2] = { 0, np_ }, oone[2];
+        /* ext_off + b keeps absolute word offsets into ext */
+        t->n = extend_pass_serial(key + (size_t)b * kw, marker + b, ext_off + b, ext, left + b, right + b, np_, one, 1, k,
+                                  twin, start_marker, t->key, t->marker, t->ext_off, t->ext, t->left, t->right, oone);
+    }
+    int64_t m = 0, w = 0;
+    oext_off[0] = 0;
+    for (int p = 0; p < P; p++) {
+        orc_records *t = &tmp[p];
+        out_part_start[p] = m;
+        const int64_t c = t->n, cw = t->ext_off[c];
+        memcpy(okey + (size_t)m * kw, t->key, (size_t)c * 8 * kw);
+        memcpy(omarker + m, t->marker, (size_t)c * 4); memcpy(oleft + m, t->left, (size_t)c * 4);
+        memcpy(oright + m, t->right, (size_t)c * 4); memcpy(oext + w, t->ext, (size_t)cw * 8);
+        for (int64_t i = 0; i < c; i++) oext_off[m + i + 1] = w + t->ext_off[i + 1];
+        m += c; w += cw;
+        free(t->key); free(t->marker); free(t->ext_off); free(t->ext); free(t->left); free(t->right);
+    }
+    out_part_start[P] = m;
+    free(tmp);
+    return m;
+}
+
 int64_t orc_extend_pass_w(const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
+                          const uint64_t *ext, const int32_t *left, const int32_t *right,
+                          int64_t n, const int64_t *part_start, int P, int k, int twin, int start_marker,
+                          uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext,
+                          int32_t *oleft, int32_t *oright, int64_t *out_part_start) {
+    if (g_threads > 1 && P > 1)
+        return extend_by_tasks(key, marker, ext_off, ext, left, right, part_start, P, k, twin, start_marker,
+                               okey, omarker, oext_off, oext, oleft, oright, out_part_start);
+    return extend_pass_serial(key, marker, ext_off, ext, left, right, n, part_start, P, k, twin, start_marker,
+                              okey, omarker, oext_off, oext, oleft, oright, out_part_start);
+}
+
+static int64_t extend_pass_serial(const uint64_t *key, const int32_t *marker, const int64_t *ext_off,
                           const uint64_t *ext, const int32_t *left, const int32_t *right,
                           int64_t n, const int64_t *part_start, int P, int k, int twin, int start_marker,
                           uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext,
@@ -803,12 +1158,15 @@ void orc_gather_w(const int64_t *perm, int64_t n, int kw,
                   uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext,
                   int32_t *oleft, int32_t *oright) {
     oext_off[0] = 0;
+    for (int64_t i = 0; i < n; i++) { int64_t s = perm[i]; oext_off[i + 1] = oext_off[i] + (ext_off[s + 1] - ext_off[s]); }
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1 && n >= (1 << 16))
+#endif
     for (int64_t i = 0; i < n; i++) {
         int64_t s = perm[i];
         KEYCPY(KEY(okey, i), KEY(key, s)); omarker[i] = marker[s]; oleft[i] = left[s]; oright[i] = right[s];
         int64_t nw = ext_off[s + 1] - ext_off[s];
         memcpy(oext + oext_off[i], ext + ext_off[s], (size_t)nw * 8);
-        oext_off[i + 1] = oext_off[i] + nw;
     }
 }
 

@@ -255,6 +255,22 @@ int64_t orc_assemble_from_counts_w(const uint64_t *kmers, const int32_t *counts,
                                    int64_t *trace, int64_t trace_cap, int64_t *n_trace,
                                    orc_records *rec_out);
 
+/* ---- CPU baseline over all host cores (bench.py cpu_baseline; SURVEY.md 8d "OpenMP, one logical partition
+ * per thread ~ local[N]").  orc_set_threads(t > 1) makes sorts and gathers split their index range and the
+ * partition-wise operators (fork filters, random reflection, extend pass) run one logical partition per task,
+ * each task being the serial function on that partition alone; results are identical to t = 1
+ * (tests/test_oracle_omp.py).  The parity tests leave it at 1. */
+void orc_set_threads(int t);
+int orc_get_threads(void);
+int orc_host_cores(void);
+/* a-2 + a-3 + a-4 fused over the threads set above: map side = per-thread slices of the reads into range
+ * buckets of the k-mer space, reduce side = per-bucket sort + count + filter.  Same output as
+ * orc_extract_canon + orc_count_filter (ascending).  Returns the survivors (written if <= cap). */
+int64_t orc_count_reads_omp(const char *bases, const int64_t *read_off, int64_t n_reads,
+                            int k, int front_clip, int end_clip, int min_cov, int max_cov, int twin,
+                            uint64_t *out_keys, int32_t *out_counts, int64_t cap,
+                            int64_t *n_distinct, int64_t *n_instances);
+
 /* Synthetic reads, integer-only counter-based generator shared
  * bit-for-bit with reflexiv_amd/csrc (rfx_synth_*). */
 uint64_t orc_splitmix64(uint64_t x);

@@ -1,0 +1,67 @@
+package uni.bielefeld.cmg.reflexiv.gpu;
+
+import java.util.concurrent.ConcurrentHashMap;
+
+/**
+ * Native entry points of libreflexiv_hip.so (include/reflexiv_hip.h) through jni/reflexiv_jni.c: one method per
+ * C-ABI entry point of the hot path, each replacing the body of one Spark operator class of
+ * pipeline/ReflexivMain.java (cited on the C side).  There is no CPU fallback: without a gfx950 GPU
+ * {@link #ctxCreate} throws.
+ *
+ * A context (one GPU + one HIP stream) is not shared between threads: executor threads ask
+ * {@link #ctxForThisTask(int)} and get their own, on GPU partitionId % gpuCount.
+ */
+public final class Rfx {
+    static {
+        System.loadLibrary("reflexiv_jni");        // which links libreflexiv_hip.so
+    }
+
+    private Rfx() { }
+
+    public static final int TWIN_DS = 0;            // arithmetic of pipeline/ReflexivDSMain.java
+    public static final int TWIN_RDD = 1;           // arithmetic of pipeline/ReflexivMain.java
+
+    /** index of each field in the int[12] parameter block (rfx_params, include/reflexiv_hip.h) */
+    public static final int P_K = 0, P_MIN_COV = 1, P_MAX_COV = 2, P_MIN_ERROR_COV = 3, P_MIN_CONTIG = 4, P_MIN_ITER = 5,
+            P_MAX_ITER = 6, P_FRONT_CLIP = 7, P_END_CLIP = 8, P_PARTITIONS = 9, P_TWIN = 10, P_COALESCE = 11;
+
+    private static final ConcurrentHashMap<Long, Long> CTX_OF_THREAD = new ConcurrentHashMap<Long, Long>();
+    private static volatile int gpuCount = Integer.getInteger("reflexiv.gpus", 1);
+
+    public static void setGpuCount(int n) { gpuCount = Math.max(1, n); }
+
+    /** the calling thread's context, created on first use on GPU partitionId % gpuCount */
+    public static long ctxForThisTask(int partitionId) {
+        final long tid = Thread.currentThread().getId();
+        Long h = CTX_OF_THREAD.get(tid);
+        if (h == null) {
+            h = ctxCreate(partitionId % gpuCount);
+            CTX_OF_THREAD.put(tid, h);
+        }
+        return h;
+    }
+
+    public static native int version();
+    public static native long ctxCreate(int device);
+    public static native void ctxDestroy(long ctx);
+    public static native int[] defaultParams();
+
+    public static native long[] extractCanon(long ctx, byte[] bases, long[] readOff, int k, int frontClip, int endClip);
+    public static native long[] extractCanonW(long ctx, byte[] bases, long[] readOff, int k, int frontClip, int endClip);
+    public static native long countFilter(long ctx, long[] kmers, int minCov, int maxCov, int twin, long[] outKeys, int[] outCounts);
+    public static native long countFilterW(long ctx, long[] kmers, int k, int minCov, int maxCov, long[] outKeys, long[] outCounts);
+
+    public static native void rcExpandSubkmer(long ctx, long[] kmers, int[] counts, int k, RfxRecords out);
+    public static native void sortRecords(long ctx, RfxRecords in, int P, RfxRecords out, long[] partStart);
+    public static native void forkFilterForward(long ctx, RfxRecords in, long[] partStart, int k, int minErrorCov, int twin,
+                                                RfxRecords out, long[] outPartStart);
+    public static native void forkFilterReflected(long ctx, RfxRecords in, long[] partStart, int k, int minErrorCov, int twin,
+                                                  RfxRecords out, long[] outPartStart);
+    public static native void reflectFromForward(long ctx, RfxRecords in, int k, RfxRecords out);
+    public static native void randomReflection(long ctx, RfxRecords in, long[] partStart, int k, RfxRecords out);
+    public static native void extendPass(long ctx, RfxRecords in, long[] partStart, int k, int twin, int stage, int scramble,
+                                         RfxRecords out, long[] outPartStart);
+    public static native byte[] contigsText(long ctx, RfxRecords in, int k, int minContig, int twin);
+
+    public static native byte[] assembleReads(long ctx, byte[] bases, long[] readOff, int[] params);
+}

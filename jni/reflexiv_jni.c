@@ -1,0 +1,390 @@
+/*
+ * reflexiv_jni.c -- the JNI layer between Reflexiv's Java driver and libreflexiv_hip.so
+ * (include/reflexiv_hip.h).  One native method of uni.bielefeld.cmg.reflexiv.gpu.Rfx per C-ABI entry
+ * point of the hot path; each replaces the body of one Spark operator class of the reference (cited in the
+ * header next to the entry point it forwards to).
+ *
+ * Build (on a machine with a JDK; none exists in the build container, so this file is compiled there by
+ * nobody -- tests/test_jni_sources.py checks it against the header and Rfx.java instead):
+ *   gcc -O2 -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
+ *       jni/reflexiv_jni.c -Lreflexiv_amd -lreflexiv_hip -Wl,-rpath,'$ORIGIN' -o reflexiv_amd/libreflexiv_jni.so
+ *
+ * Conventions: a context handle is the rfx_ctx pointer as a jlong; record sets travel as
+ * uni.bielefeld.cmg.reflexiv.gpu.RfxRecords (six primitive arrays + n + keyWords), pinned with
+ * GetPrimitiveArrayCritical for the duration of the call; output record sets are allocated by the Java
+ * side at their upper bound and trimmed there (n is written back).  A negative rfx_status becomes a
+ * RuntimeException, so Spark's task retry / job abort semantics are those of the reference.
+ */
+#include <jni.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "reflexiv_hip.h"
+
+#define RFX_CLASS(name) Java_uni_bielefeld_cmg_reflexiv_gpu_Rfx_##name
+
+static void throw_rfx(JNIEnv *env, rfx_ctx *ctx, int st, const char *where) {
+    char msg[640];
+    snprintf(msg, sizeof msg, "%s: rfx status %d%s%s", where, st, ctx ? ": " : "", ctx ? rfx_last_error(ctx) : "");
+    jclass ex = (*env)->FindClass(env, "java/lang/RuntimeException");
+    if (ex) (*env)->ThrowNew(env, ex, msg);
+}
+
+static rfx_ctx *ctx_of(jlong h) { return (rfx_ctx *)(intptr_t)h; }
+
+/* ------------------------------------------------------------------ RfxRecords <-> rfx_records */
+
+typedef struct {
+    jobject obj;
+    jlongArray key, ext_off, ext;
+    jintArray marker, left, right;
+    rfx_records r;
+} pinned_records;
+
+static jfieldID F_n, F_keyWords, F_key, F_marker, F_extOff, F_ext, F_left, F_right;
+
+static int records_ids(JNIEnv *env) {
+    if (F_n) return 1;
+    jclass c = (*env)->FindClass(env, "uni/bielefeld/cmg/reflexiv/gpu/RfxRecords");
+    if (!c) return 0;
+    F_n = (*env)->GetFieldID(env, c, "n", "J");
+    F_keyWords = (*env)->GetFieldID(env, c, "keyWords", "I");
+    F_key = (*env)->GetFieldID(env, c, "key", "[J");
+    F_marker = (*env)->GetFieldID(env, c, "marker", "[I");
+    F_extOff = (*env)->GetFieldID(env, c, "extOff", "[J");
+    F_ext = (*env)->GetFieldID(env, c, "ext", "[J");
+    F_left = (*env)->GetFieldID(env, c, "left", "[I");
+    F_right = (*env)->GetFieldID(env, c, "right", "[I");
+    return F_n && F_keyWords && F_key && F_marker && F_extOff && F_ext && F_left && F_right;
+}
+
+/* pins the six arrays; capacities come from the array lengths */
+static int records_pin(JNIEnv *env, jobject o, pinned_records *p) {
+    memset(p, 0, sizeof *p);
+    if (!records_ids(env)) return 0;
+    p->obj = o;
+    p->key = (jlongArray)(*env)->GetObjectField(env, o, F_key);
+    p->marker = (jintArray)(*env)->GetObjectField(env, o, F_marker);
+    p->ext_off = (jlongArray)(*env)->GetObjectField(env, o, F_extOff);
+    p->ext = (jlongArray)(*env)->GetObjectField(env, o, F_ext);
+    p->left = (jintArray)(*env)->GetObjectField(env, o, F_left);
+    p->right = (jintArray)(*env)->GetObjectField(env, o, F_right);
+    const int kw = (*env)->GetIntField(env, o, F_keyWords);
+    p->r.n = (*env)->GetLongField(env, o, F_n);
+    p->r.key_words = kw;
+    p->r.cap_n = (*env)->GetArrayLength(env, p->marker);
+    p->r.cap_words = (*env)->GetArrayLength(env, p->ext);
+    p->r.key = (uint64_t *)(*env)->GetPrimitiveArrayCritical(env, p->key, NULL);
+    p->r.marker = (int32_t *)(*env)->GetPrimitiveArrayCritical(env, p->marker, NULL);
+    p->r.ext_off = (int64_t *)(*env)->GetPrimitiveArrayCritical(env, p->ext_off, NULL);
+    p->r.ext = (uint64_t *)(*env)->GetPrimitiveArrayCritical(env, p->ext, NULL);
+    p->r.left = (int32_t *)(*env)->GetPrimitiveArrayCritical(env, p->left, NULL);
+    p->r.right = (int32_t *)(*env)->GetPrimitiveArrayCritical(env, p->right, NULL);
+    return p->r.key && p->r.marker && p->r.ext_off && p->r.ext && p->r.left && p->r.right;
+}
+
+/* mode 0: copy back (outputs), JNI_ABORT: inputs */
+static void records_unpin(JNIEnv *env, pinned_records *p, jint mode) {
+    if (p->r.right) (*env)->ReleasePrimitiveArrayCritical(env, p->right, p->r.right, mode);
+    if (p->r.left) (*env)->ReleasePrimitiveArrayCritical(env, p->left, p->r.left, mode);
+    if (p->r.ext) (*env)->ReleasePrimitiveArrayCritical(env, p->ext, p->r.ext, mode);
+    if (p->r.ext_off) (*env)->ReleasePrimitiveArrayCritical(env, p->ext_off, p->r.ext_off, mode);
+    if (p->r.marker) (*env)->ReleasePrimitiveArrayCritical(env, p->marker, p->r.marker, mode);
+    if (p->r.key) (*env)->ReleasePrimitiveArrayCritical(env, p->key, p->r.key, mode);
+    if (mode == 0 && p->obj) {
+        (*env)->SetLongField(env, p->obj, F_n, (jlong)p->r.n);
+        (*env)->SetIntField(env, p->obj, F_keyWords, (jint)(p->r.key_words > 1 ? p->r.key_words : 1));
+    }
+}
+
+/* ------------------------------------------------------------------------------------ context */
+
+JNIEXPORT jint JNICALL RFX_CLASS(version)(JNIEnv *env, jclass c) {
+    (void)env; (void)c;
+    return rfx_version();
+}
+
+JNIEXPORT jlong JNICALL RFX_CLASS(ctxCreate)(JNIEnv *env, jclass c, jint device) {
+    (void)c;
+    rfx_ctx *ctx = NULL;
+    const int st = rfx_ctx_create(device, &ctx);
+    if (st != RFX_OK) { throw_rfx(env, NULL, st, "rfx_ctx_create (a gfx950 GPU is required; there is no CPU fallback)"); return 0; }
+    return (jlong)(intptr_t)ctx;
+}
+
+JNIEXPORT void JNICALL RFX_CLASS(ctxDestroy)(JNIEnv *env, jclass c, jlong h) {
+    (void)env; (void)c;
+    rfx_ctx_destroy(ctx_of(h));
+}
+
+/* U/DefaultParam.java defaults as the library sees them: int[12] in rfx_params field order */
+JNIEXPORT jintArray JNICALL RFX_CLASS(defaultParams)(JNIEnv *env, jclass c) {
+    (void)c;
+    rfx_params p;
+    rfx_default_params(&p);
+    jintArray a = (*env)->NewIntArray(env, 12);
+    if (a) (*env)->SetIntArrayRegion(env, a, 0, 12, (const jint *)&p);
+    return a;
+}
+
+/* ---------------------------------------------------------------------- extraction and counting */
+
+/* ReverseComplementKmerBinaryExtraction.call (P/ReflexivMain.java:3013-3075) and, wide != 0,
+ * ReverseComplementKmerBinaryExtractionFromDataset64.call (P/ReflexivDataFrameCounter64.java:401-650):
+ * -> long[n * W] canonical k-mers in read / window order (W = 1, or k/32+1) */
+static jlongArray extract_common(JNIEnv *env, jlong h, jbyteArray bases, jlongArray readOff, jint k, jint fc, jint ec, int wide) {
+    rfx_ctx *ctx = ctx_of(h);
+    const jsize nOff = (*env)->GetArrayLength(env, readOff);
+    const int W = wide ? k / 32 + 1 : 1;
+    int64_t n = 0;
+    jlongArray out = NULL;
+    for (int pass = 0; pass < 2; pass++) {                 /* size query, then the real call */
+        if (pass == 1) { out = (*env)->NewLongArray(env, (jsize)(n * W)); if (!out) return NULL; }
+        jbyte *b = (jbyte *)(*env)->GetPrimitiveArrayCritical(env, bases, NULL);
+        jlong *o = (jlong *)(*env)->GetPrimitiveArrayCritical(env, readOff, NULL);
+        jlong *dst = pass ? (jlong *)(*env)->GetPrimitiveArrayCritical(env, out, NULL) : NULL;
+        int st = wide ? rfx_extract_canon_w(ctx, (const uint8_t *)b, (const int64_t *)o, nOff - 1, k, fc, ec, (uint64_t *)dst, pass ? n : 0, &n)
+                      : rfx_extract_canon(ctx, (const uint8_t *)b, (const int64_t *)o, nOff - 1, k, fc, ec, (uint64_t *)dst, pass ? n : 0, &n);
+        if (dst) (*env)->ReleasePrimitiveArrayCritical(env, out, dst, 0);
+        (*env)->ReleasePrimitiveArrayCritical(env, readOff, o, JNI_ABORT);
+        (*env)->ReleasePrimitiveArrayCritical(env, bases, b, JNI_ABORT);
+        if (st != RFX_OK && !(pass == 0 && st == RFX_E_CAP)) { throw_rfx(env, ctx, st, wide ? "rfx_extract_canon_w" : "rfx_extract_canon"); return NULL; }
+    }
+    return out;
+}
+
+JNIEXPORT jlongArray JNICALL RFX_CLASS(extractCanon)(JNIEnv *env, jclass c, jlong h, jbyteArray bases, jlongArray readOff,
+                                                    jint k, jint frontClip, jint endClip) {
+    (void)c;
+    return extract_common(env, h, bases, readOff, k, frontClip, endClip, 0);
+}
+
+JNIEXPORT jlongArray JNICALL RFX_CLASS(extractCanonW)(JNIEnv *env, jclass c, jlong h, jbyteArray bases, jlongArray readOff,
+                                                     jint k, jint frontClip, jint endClip) {
+    (void)c;
+    return extract_common(env, h, bases, readOff, k, frontClip, endClip, 1);
+}
+
+/* reduceByKey(KmerCounting) + filter(KmerCoverageFilter) (P/ReflexivMain.java:155,160-163,2895-2899,3115-3119):
+ * outKeys / outCounts hold kmers.length entries; returns the number of survivors (ascending by k-mer) */
+JNIEXPORT jlong JNICALL RFX_CLASS(countFilter)(JNIEnv *env, jclass c, jlong h, jlongArray kmers, jint minCov, jint maxCov, jint twin,
+                                              jlongArray outKeys, jintArray outCounts) {
+    (void)c;
+    rfx_ctx *ctx = ctx_of(h);
+    const jsize n = (*env)->GetArrayLength(env, kmers);
+    int64_t m = 0, d = 0;
+    jlong *in = (jlong *)(*env)->GetPrimitiveArrayCritical(env, kmers, NULL);
+    jlong *ok = (jlong *)(*env)->GetPrimitiveArrayCritical(env, outKeys, NULL);
+    jint *oc = (jint *)(*env)->GetPrimitiveArrayCritical(env, outCounts, NULL);
+    const int st = rfx_count_filter(ctx, (const uint64_t *)in, n, minCov, maxCov, twin, (uint64_t *)ok, (int32_t *)oc,
+                                    (*env)->GetArrayLength(env, outCounts), &m, &d);
+    (*env)->ReleasePrimitiveArrayCritical(env, outCounts, oc, 0);
+    (*env)->ReleasePrimitiveArrayCritical(env, outKeys, ok, 0);
+    (*env)->ReleasePrimitiveArrayCritical(env, kmers, in, JNI_ABORT);
+    if (st != RFX_OK) { throw_rfx(env, ctx, st, "rfx_count_filter"); return -1; }
+    return (jlong)m;
+}
+
+/* groupBy("kmerBlocks").count() + the two filters (P/ReflexivDataFrameCounter64.java:191-205), k > 31 */
+JNIEXPORT jlong JNICALL RFX_CLASS(countFilterW)(JNIEnv *env, jclass c, jlong h, jlongArray kmers, jint k, jint minCov, jint maxCov,
+                                               jlongArray outKeys, jlongArray outCounts) {
+    (void)c;
+    rfx_ctx *ctx = ctx_of(h);
+    const int W = k / 32 + 1;
+    const jsize n = (*env)->GetArrayLength(env, kmers) / W;
+    int64_t m = 0, d = 0;
+    jlong *in = (jlong *)(*env)->GetPrimitiveArrayCritical(env, kmers, NULL);
+    jlong *ok = (jlong *)(*env)->GetPrimitiveArrayCritical(env, outKeys, NULL);
+    jlong *oc = (jlong *)(*env)->GetPrimitiveArrayCritical(env, outCounts, NULL);
+    const int st = rfx_count_filter_w(ctx, (const uint64_t *)in, n, k, minCov, maxCov, (uint64_t *)ok, (int64_t *)oc,
+                                      (*env)->GetArrayLength(env, outCounts), &m, &d);
+    (*env)->ReleasePrimitiveArrayCritical(env, outCounts, oc, 0);
+    (*env)->ReleasePrimitiveArrayCritical(env, outKeys, ok, 0);
+    (*env)->ReleasePrimitiveArrayCritical(env, kmers, in, JNI_ABORT);
+    if (st != RFX_OK) { throw_rfx(env, ctx, st, "rfx_count_filter_w"); return -1; }
+    return (jlong)m;
+}
+
+/* ---------------------------------------------------------------------------- record operators */
+
+/* KmerReverseComplement.call + ForwardSubKmerExtraction.call (P/ReflexivMain.java:2910-2930, 2709-2730;
+ * k > 31: DSKmerReverseComplement + DSForwardSubKmerExtraction, P/ReflexivDSMain64.java:10706-10755, 10363-10403) */
+JNIEXPORT void JNICALL RFX_CLASS(rcExpandSubkmer)(JNIEnv *env, jclass c, jlong h, jlongArray kmers, jintArray counts, jint k, jobject out) {
+    (void)c;
+    rfx_ctx *ctx = ctx_of(h);
+    const jsize n = (*env)->GetArrayLength(env, counts);
+    pinned_records po;
+    int st = RFX_E_ARG;
+    if (records_pin(env, out, &po)) {
+        jlong *km = (jlong *)(*env)->GetPrimitiveArrayCritical(env, kmers, NULL);
+        jint *cn = (jint *)(*env)->GetPrimitiveArrayCritical(env, counts, NULL);
+        st = rfx_rc_expand_subkmer(ctx, (const uint64_t *)km, (const int32_t *)cn, n, k, &po.r);
+        (*env)->ReleasePrimitiveArrayCritical(env, counts, cn, JNI_ABORT);
+        (*env)->ReleasePrimitiveArrayCritical(env, kmers, km, JNI_ABORT);
+    }
+    records_unpin(env, &po, 0);
+    if (st != RFX_OK) throw_rfx(env, ctx, st, "rfx_rc_expand_subkmer");
+}
+
+/* sortByKey() (P/ReflexivMain.java:179,191,211,235,247,286) for callers that keep a whole RDD on one GPU;
+ * under Spark's own shuffle the driver keeps sortByKey() and does not call this */
+JNIEXPORT void JNICALL RFX_CLASS(sortRecords)(JNIEnv *env, jclass c, jlong h, jobject in, jint P, jobject out, jlongArray partStart) {
+    (void)c;
+    rfx_ctx *ctx = ctx_of(h);
+    pinned_records pi, po;
+    int st = RFX_E_ARG;
+    const int ok_i = records_pin(env, in, &pi), ok_o = records_pin(env, out, &po);
+    if (ok_i && ok_o) {
+        jlong *ps = (jlong *)(*env)->GetPrimitiveArrayCritical(env, partStart, NULL);
+        st = rfx_sort_records(ctx, &pi.r, P, &po.r, (int64_t *)ps);
+        (*env)->ReleasePrimitiveArrayCritical(env, partStart, ps, 0);
+    }
+    records_unpin(env, &po, 0);
+    records_unpin(env, &pi, JNI_ABORT);
+    if (st != RFX_OK) throw_rfx(env, ctx, st, "rfx_sort_records");
+}
+
+/* which: 0 FilterForkSubKmer[WithErrorCorrection].call (P/ReflexivMain.java:2412-2540),
+ *        1 FilterForkReflectedSubKmer[WithErrorCorrection].call (:2550-2696) */
+static void fork_common(JNIEnv *env, jlong h, int which, jobject in, jlongArray partStart, jint k, jint minErr, jint twin,
+                        jobject out, jlongArray outPartStart) {
+    rfx_ctx *ctx = ctx_of(h);
+    pinned_records pi, po;
+    int st = RFX_E_ARG;
+    const int P = (*env)->GetArrayLength(env, partStart) - 1;
+    const int ok_i = records_pin(env, in, &pi), ok_o = records_pin(env, out, &po);
+    if (ok_i && ok_o && P >= 1) {
+        jlong *ps = (jlong *)(*env)->GetPrimitiveArrayCritical(env, partStart, NULL);
+        jlong *ops = (jlong *)(*env)->GetPrimitiveArrayCritical(env, outPartStart, NULL);
+        st = which ? rfx_fork_filter_reflected(ctx, &pi.r, (const int64_t *)ps, P, k, minErr, twin, &po.r, (int64_t *)ops)
+                   : rfx_fork_filter_forward(ctx, &pi.r, (const int64_t *)ps, P, k, minErr, twin, &po.r, (int64_t *)ops);
+        (*env)->ReleasePrimitiveArrayCritical(env, outPartStart, ops, 0);
+        (*env)->ReleasePrimitiveArrayCritical(env, partStart, ps, JNI_ABORT);
+    }
+    records_unpin(env, &po, 0);
+    records_unpin(env, &pi, JNI_ABORT);
+    if (st != RFX_OK) throw_rfx(env, ctx, st, which ? "rfx_fork_filter_reflected" : "rfx_fork_filter_forward");
+}
+
+JNIEXPORT void JNICALL RFX_CLASS(forkFilterForward)(JNIEnv *env, jclass c, jlong h, jobject in, jlongArray partStart, jint k,
+                                                   jint minErrorCov, jint twin, jobject out, jlongArray outPartStart) {
+    (void)c;
+    fork_common(env, h, 0, in, partStart, k, minErrorCov, twin, out, outPartStart);
+}
+
+JNIEXPORT void JNICALL RFX_CLASS(forkFilterReflected)(JNIEnv *env, jclass c, jlong h, jobject in, jlongArray partStart, jint k,
+                                                     jint minErrorCov, jint twin, jobject out, jlongArray outPartStart) {
+    (void)c;
+    fork_common(env, h, 1, in, partStart, k, minErrorCov, twin, out, outPartStart);
+}
+
+/* ReflectedSubKmerExtractionFromForward.call (P/ReflexivMain.java:2742-2768) */
+JNIEXPORT void JNICALL RFX_CLASS(reflectFromForward)(JNIEnv *env, jclass c, jlong h, jobject in, jint k, jobject out) {
+    (void)c;
+    rfx_ctx *ctx = ctx_of(h);
+    pinned_records pi, po;
+    int st = RFX_E_ARG;
+    const int ok_i = records_pin(env, in, &pi), ok_o = records_pin(env, out, &po);
+    if (ok_i && ok_o) st = rfx_reflect_from_forward(ctx, &pi.r, k, &po.r);
+    records_unpin(env, &po, 0);
+    records_unpin(env, &pi, JNI_ABORT);
+    if (st != RFX_OK) throw_rfx(env, ctx, st, "rfx_reflect_from_forward");
+}
+
+/* kmerRandomReflection.call (P/ReflexivMain.java:2783-2885) */
+JNIEXPORT void JNICALL RFX_CLASS(randomReflection)(JNIEnv *env, jclass c, jlong h, jobject in, jlongArray partStart, jint k, jobject out) {
+    (void)c;
+    rfx_ctx *ctx = ctx_of(h);
+    pinned_records pi, po;
+    int st = RFX_E_ARG;
+    const int P = (*env)->GetArrayLength(env, partStart) - 1;
+    const int ok_i = records_pin(env, in, &pi), ok_o = records_pin(env, out, &po);
+    if (ok_i && ok_o && P >= 1) {
+        jlong *ps = (jlong *)(*env)->GetPrimitiveArrayCritical(env, partStart, NULL);
+        st = rfx_random_reflection(ctx, &pi.r, (const int64_t *)ps, P, k, &po.r);
+        (*env)->ReleasePrimitiveArrayCritical(env, partStart, ps, JNI_ABORT);
+    }
+    records_unpin(env, &po, 0);
+    records_unpin(env, &pi, JNI_ABORT);
+    if (st != RFX_OK) throw_rfx(env, ctx, st, "rfx_random_reflection");
+}
+
+/* ExtendReflexivKmer / ...ToArrayFirstTime / ...ToArrayLoop .call (P/ReflexivMain.java:2048-2362, 1594-1974, 792-1519);
+ * stage 0 / 1 / 2.  scramble: param.scramble as DSExtendReflexivKmerToArrayLoop of P/ReflexivDSMain64.java reads it
+ * (:7484-7486); 2 everywhere else. */
+JNIEXPORT void JNICALL RFX_CLASS(extendPass)(JNIEnv *env, jclass c, jlong h, jobject in, jlongArray partStart, jint k, jint twin,
+                                            jint stage, jint scramble, jobject out, jlongArray outPartStart) {
+    (void)c;
+    rfx_ctx *ctx = ctx_of(h);
+    pinned_records pi, po;
+    int st = RFX_E_ARG;
+    const int P = (*env)->GetArrayLength(env, partStart) - 1;
+    const int ok_i = records_pin(env, in, &pi), ok_o = records_pin(env, out, &po);
+    if (ok_i && ok_o && P >= 1) {
+        jlong *ps = (jlong *)(*env)->GetPrimitiveArrayCritical(env, partStart, NULL);
+        jlong *ops = (jlong *)(*env)->GetPrimitiveArrayCritical(env, outPartStart, NULL);
+        st = scramble == 2 ? rfx_extend_pass(ctx, &pi.r, (const int64_t *)ps, P, k, twin, stage, &po.r, (int64_t *)ops)
+                           : rfx_extend_pass_w(ctx, &pi.r, (const int64_t *)ps, P, k, stage, scramble, &po.r, (int64_t *)ops);
+        (*env)->ReleasePrimitiveArrayCritical(env, outPartStart, ops, 0);
+        (*env)->ReleasePrimitiveArrayCritical(env, partStart, ps, JNI_ABORT);
+    }
+    records_unpin(env, &po, 0);
+    records_unpin(env, &pi, JNI_ABORT);
+    if (st != RFX_OK) throw_rfx(env, ctx, st, "rfx_extend_pass");
+}
+
+/* BinaryReflexivKmerArrayToString + KmerToContig + TagContigID (P/ReflexivMain.java:696-741, 590-637, 573-581):
+ * the text saveAsTextFile writes for these records, ids counted from 0 (the caller adds zipWithIndex offsets
+ * when it formats partition by partition) */
+JNIEXPORT jbyteArray JNICALL RFX_CLASS(contigsText)(JNIEnv *env, jclass c, jlong h, jobject in, jint k, jint minContig, jint twin) {
+    (void)c;
+    rfx_ctx *ctx = ctx_of(h);
+    pinned_records pi;
+    if (!records_pin(env, in, &pi)) { records_unpin(env, &pi, JNI_ABORT); throw_rfx(env, ctx, RFX_E_ARG, "rfx_contigs_text"); return NULL; }
+    int64_t len = 0, nc = 0;
+    int st = rfx_contigs_text(ctx, &pi.r, k, minContig, twin, NULL, 0, &len, &nc);
+    jbyteArray out = NULL;
+    if (st == RFX_OK || st == RFX_E_CAP) {
+        records_unpin(env, &pi, JNI_ABORT);
+        out = (*env)->NewByteArray(env, (jsize)len);
+        if (!out || !records_pin(env, in, &pi)) { records_unpin(env, &pi, JNI_ABORT); return NULL; }
+        jbyte *dst = (jbyte *)(*env)->GetPrimitiveArrayCritical(env, out, NULL);
+        st = rfx_contigs_text(ctx, &pi.r, k, minContig, twin, (char *)dst, len, &len, &nc);
+        (*env)->ReleasePrimitiveArrayCritical(env, out, dst, 0);
+    }
+    records_unpin(env, &pi, JNI_ABORT);
+    if (st != RFX_OK) { throw_rfx(env, ctx, st, "rfx_contigs_text"); return NULL; }
+    return out;
+}
+
+/* ---------------------------------------------------------------------------- resident pipeline */
+
+/* The whole path (P/ReflexivMain.java:95-322) in one call: ASCII reads of any length up, contig text back.
+ * params: int[12] in rfx_params field order (Rfx.defaultParams()).  k <= 31. */
+JNIEXPORT jbyteArray JNICALL RFX_CLASS(assembleReads)(JNIEnv *env, jclass c, jlong h, jbyteArray bases, jlongArray readOff, jintArray params) {
+    (void)c;
+    rfx_ctx *ctx = ctx_of(h);
+    if ((*env)->GetArrayLength(env, params) != 12) { throw_rfx(env, ctx, RFX_E_ARG, "rfx_assemble_reads (params must hold 12 ints)"); return NULL; }
+    rfx_params prm;
+    (*env)->GetIntArrayRegion(env, params, 0, 12, (jint *)&prm);
+    const jsize nOff = (*env)->GetArrayLength(env, readOff);
+    int64_t cap = (int64_t)(*env)->GetArrayLength(env, bases) * 3 + (1 << 20);    /* both strands + headers + line breaks */
+    for (;;) {
+        char *buf = (char *)malloc((size_t)cap);             /* native staging: no JNI call is made while arrays are pinned */
+        if (!buf) { throw_rfx(env, ctx, RFX_E_HIP, "rfx_assemble_reads (out of host memory)"); return NULL; }
+        jbyte *b = (jbyte *)(*env)->GetPrimitiveArrayCritical(env, bases, NULL);
+        jlong *o = (jlong *)(*env)->GetPrimitiveArrayCritical(env, readOff, NULL);
+        int64_t len = 0, nc = 0, ntr = 0, kept = 0;
+        const int st = rfx_assemble_reads(ctx, (const uint8_t *)b, (const int64_t *)o, nOff - 1, &prm, buf, cap, &len, &nc,
+                                          NULL, 0, &ntr, &kept);
+        (*env)->ReleasePrimitiveArrayCritical(env, readOff, o, JNI_ABORT);
+        (*env)->ReleasePrimitiveArrayCritical(env, bases, b, JNI_ABORT);
+        if (st == RFX_E_CAP && len > cap) { cap = len; free(buf); continue; }
+        if (st != RFX_OK) { free(buf); throw_rfx(env, ctx, st, "rfx_assemble_reads"); return NULL; }
+        jbyteArray out = (*env)->NewByteArray(env, (jsize)len);
+        if (out) (*env)->SetByteArrayRegion(env, out, 0, (jsize)len, (const jbyte *)buf);
+        free(buf);
+        return out;
+    }
+}

@@ -63,6 +63,8 @@ def lib():
         L.orc_splitmix64.restype = C.c_uint64
         L.orc_splitmix64.argtypes = [C.c_uint64]
         L.orc_count_reads_omp.restype = C.c_int64
+        L.orc_count_reads_range_omp.restype = C.c_int64
+        L.orc_count_reads_w2_range_omp.restype = C.c_int64
         for f in ("orc_fork_filter_forward_w", "orc_fork_filter_reflected_w", "orc_extend_pass_w",
                   "orc_contigs_text_w", "orc_assemble_from_counts_w"):
             getattr(L, f).restype = C.c_int64
@@ -188,17 +190,28 @@ def host_cores() -> int:
 
 
 def count_reads_omp(bases, read_off, k=31, min_cov=2, max_cov=10_000_000, twin=TWIN_DS, front_clip=0, end_clip=0,
-                    cap=None):
-    """extract + reduceByKey + filter over the threads of set_threads() -> (keys, counts, n_distinct, n_instances)"""
+                    cap=None, buckets=(0, 4096)):
+    """extract + reduceByKey + filter over the threads of set_threads() -> (keys, counts, n_distinct, n_instances).
+    buckets = (lo, hi): only the k-mers whose top 12 bits fall in [lo, hi) (passes over shares of the k-mer space).
+    k = 33..63: two-word k-mers uint64[m, 2], int64 counts (ReflexivDataFrameCounter64's filters)."""
     bases = np.ascontiguousarray(bases, np.uint8)
     read_off = np.ascontiguousarray(read_off, np.int64)
     nr = len(read_off) - 1
     if cap is None:
         cap = max(1, int(read_off[-1] - read_off[0]))
-    keys = np.empty(cap, np.uint64); counts = np.empty(cap, np.int32)
     nd, ni = C.c_int64(0), C.c_int64(0)
-    m = lib().orc_count_reads_omp(_p(bases), _p(read_off), C.c_int64(nr), k, front_clip, end_clip, min_cov, max_cov, twin,
-                                  _p(keys), _p(counts), C.c_int64(cap), C.byref(nd), C.byref(ni))
+    if k > 31:
+        keys = np.empty((cap, 2), np.uint64); counts = np.empty(cap, np.int64)
+        m = lib().orc_count_reads_w2_range_omp(_p(bases), _p(read_off), C.c_int64(nr), k, front_clip, end_clip, min_cov,
+                                               max_cov, buckets[0], buckets[1], _p(keys), _p(counts), C.c_int64(cap),
+                                               C.byref(nd), C.byref(ni))
+        if m < 0:
+            raise ValueError("k must be 33..63")
+    else:
+        keys = np.empty(cap, np.uint64); counts = np.empty(cap, np.int32)
+        m = lib().orc_count_reads_range_omp(_p(bases), _p(read_off), C.c_int64(nr), k, front_clip, end_clip, min_cov, max_cov,
+                                            twin, buckets[0], buckets[1], _p(keys), _p(counts), C.c_int64(cap),
+                                            C.byref(nd), C.byref(ni))
     if m > cap:
         raise ValueError(f"cap {cap} < {m} survivors")
     return keys[:m].copy(), counts[:m].copy(), int(nd.value), int(ni.value)

@@ -277,6 +277,167 @@ void orc_kmer_text_w(const uint64_t *kmer, int k, char *out) {
     for (int i = (k / 32) * 32; i < k; i++) out[i] = nt[(kmer[i / 32] >> (2 * (res - 1 - i % 32))) & 3];  /* :354-360 */
 }
 
+/* ---- a-2w + count + filter over all host cores, k > 32, W = k/32+1 = 2 words (k = 33..63), with the same range
+ * restriction: buckets = top 12 bits of word 0.  Same output as orc_extract_canon_w + orc_count_filter_w
+ * (tests/test_oracle_omp.py); used by tests/golden/make_c2_full.py for the full-size k = 63 pin. */
+typedef struct { uint64_t w0, w1; } kw2;
+
+static inline void read_kmers_w2(const char *read, int64_t len, int k, int front_clip, int end_clip,
+                                 int b_lo, int b_hi, int64_t *hist, kw2 *arr, int64_t *cursor) {
+    const int W = 2, res = k % 32;
+    const uint64_t mask = ~((~0ULL) << (2 * res));
+    if (len - k - end_clip + 1 <= 0 || front_clip > len) return;             /* :410 */
+    uint64_t acc = 0, racc = 0, f[2] = {0, 0}, rc[2] = {0, 0};
+    for (int64_t i = front_clip; i < len - end_clip; i++) {                  /* :419 (the loop of orc_extract_canon_w) */
+        const int64_t j = i - front_clip;
+        const uint64_t v = nuc_value(read[i]);
+        if (j <= k - 1) {
+            acc = (acc << 2) | v;
+            if ((j + 1) % 32 == 0) { f[(j + 1) / 32 - 1] = acc; acc = 0; }
+            if (j == k - 1) { acc &= mask; f[(j + 1) / 32] = acc; acc = 0; }
+        } else {
+            uint64_t t1 = f[W - 1] >> (2 * (res - 1));
+            f[W - 1] = ((f[W - 1] << 2) | v) & mask;
+            f[0] = (f[0] << 2) | t1;
+        }
+        uint64_t c = v ^ 3;
+        if (j <= k - 1) {
+            if (j < res - 1) { racc |= c << (2 * j); }
+            else if (j == res - 1) { racc |= c << (2 * j); rc[W - 1] = racc; racc = 0; }
+            else if ((j - res + 1) % 32 == 0) { racc |= c << (2 * ((j - res) % 32)); rc[W - (j - res + 1) / 32 - 1] = racc; racc = 0; }
+            else { racc |= c << (2 * ((j - res) % 32)); }
+        } else {
+            uint64_t t1 = rc[0] << 62;
+            rc[0] = (rc[0] >> 2) | (c << 62);
+            rc[W - 1] >>= 2;
+            rc[W - 1] |= t1 >> (2 * (31 - res + 1));
+        }
+        if (j >= k - 1) {
+            const uint64_t *src = fwd_not_after_rc(f, rc, W, res) ? f : rc;
+            const int bkt = (int)(src[0] >> 52);
+            if (bkt < b_lo || bkt >= b_hi) continue;
+            if (arr) { kw2 e = { src[0], src[1] }; arr[cursor[bkt]++] = e; } else hist[bkt]++;
+        }
+    }
+}
+
+/* LSD radix sort of 16-byte elements by (w0 low bits, w1), 11-bit digits */
+static void radix_sort_kw2(kw2 *a, int64_t n, int bits0, int bits1, kw2 *tmp) {
+    if (n < 2) return;
+    int64_t hist[2048];
+    kw2 *src = a, *dst = tmp;
+    for (int word = 1; word >= 0; word--) {
+        const int bits = word ? bits1 : bits0;
+        for (int sh = 0; sh < bits; sh += 11) {
+            memset(hist, 0, sizeof hist);
+            if (word) { for (int64_t i = 0; i < n; i++) hist[(src[i].w1 >> sh) & 2047]++; }
+            else      { for (int64_t i = 0; i < n; i++) hist[(src[i].w0 >> sh) & 2047]++; }
+            const uint64_t d0 = word ? (src[0].w1 >> sh) & 2047 : (src[0].w0 >> sh) & 2047;
+            if (hist[d0] == n) continue;
+            int64_t s = 0;
+            for (int d = 0; d < 2048; d++) { int64_t c = hist[d]; hist[d] = s; s += c; }
+            if (word) { for (int64_t i = 0; i < n; i++) dst[hist[(src[i].w1 >> sh) & 2047]++] = src[i]; }
+            else      { for (int64_t i = 0; i < n; i++) dst[hist[(src[i].w0 >> sh) & 2047]++] = src[i]; }
+            kw2 *t = src; src = dst; dst = t;
+        }
+    }
+    if (src != a) memcpy(a, src, (size_t)n * sizeof(kw2));
+}
+
+int64_t orc_count_reads_w2_range_omp(const char *bases, const int64_t *read_off, int64_t n_reads,
+                                     int k, int front_clip, int end_clip, int min_cov, int max_cov,
+                                     int b_lo, int b_hi,
+                                     uint64_t *out_keys, int64_t *out_counts, int64_t cap,
+                                     int64_t *n_distinct, int64_t *n_instances) {
+    if (k <= 32 || k >= 64) return -1;
+    const int T = g_threads, NB = 4096, res = k % 32;
+    int64_t *hist = (int64_t *)xmalloc((size_t)T * NB * sizeof(int64_t));
+    memset(hist, 0, (size_t)T * NB * sizeof(int64_t));
+#ifdef _OPENMP
+#pragma omp parallel num_threads(T)
+#endif
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num();
+#else
+        const int t = 0;
+#endif
+        const int64_t lo = n_reads * t / T, hi = n_reads * (t + 1) / T;
+        for (int64_t r = lo; r < hi; r++)
+            read_kmers_w2(bases + read_off[r], read_off[r + 1] - read_off[r], k, front_clip, end_clip, b_lo, b_hi,
+                          hist + (size_t)t * NB, NULL, NULL);
+    }
+    int64_t *bstart = (int64_t *)xmalloc((size_t)(NB + 1) * sizeof(int64_t));
+    int64_t N = 0;
+    for (int b = 0; b < NB; b++) {
+        bstart[b] = N;
+        for (int t = 0; t < T; t++) { int64_t c = hist[(size_t)t * NB + b]; hist[(size_t)t * NB + b] = N; N += c; }
+    }
+    bstart[NB] = N;
+    if (n_instances) *n_instances = N;
+    kw2 *arr = (kw2 *)xmalloc((size_t)(N ? N : 1) * sizeof(kw2));
+#ifdef _OPENMP
+#pragma omp parallel num_threads(T)
+#endif
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num();
+#else
+        const int t = 0;
+#endif
+        const int64_t lo = n_reads * t / T, hi = n_reads * (t + 1) / T;
+        for (int64_t r = lo; r < hi; r++)
+            read_kmers_w2(bases + read_off[r], read_off[r + 1] - read_off[r], k, front_clip, end_clip, b_lo, b_hi,
+                          NULL, arr, hist + (size_t)t * NB);
+    }
+    int64_t *bm = (int64_t *)xmalloc((size_t)(NB + 1) * sizeof(int64_t)), *bd = (int64_t *)xmalloc((size_t)NB * sizeof(int64_t));
+    int64_t maxb = 1;
+    for (int b = 0; b < NB; b++) if (bstart[b + 1] - bstart[b] > maxb) maxb = bstart[b + 1] - bstart[b];
+    kw2 *scratch = (kw2 *)xmalloc((size_t)T * (size_t)maxb * sizeof(kw2));
+    for (int sweep = 0; sweep < 2; sweep++) {
+        if (sweep == 1) {
+            int64_t M = 0, D = 0;
+            for (int b = 0; b < NB; b++) { int64_t c = bm[b]; bm[b] = M; M += c; D += bd[b]; }
+            bm[NB] = M;
+            if (n_distinct) *n_distinct = D;
+            if (M > cap) break;
+        }
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(T) schedule(dynamic, 4)
+#endif
+        for (int b = 0; b < NB; b++) {
+            kw2 *a = arr + bstart[b];
+            const int64_t n = bstart[b + 1] - bstart[b];
+            if (sweep == 0) {
+#ifdef _OPENMP
+                radix_sort_kw2(a, n, 52, 2 * res, scratch + (size_t)omp_get_thread_num() * (size_t)maxb);
+#else
+                radix_sort_kw2(a, n, 52, 2 * res, scratch);
+#endif
+            }
+            int64_t m = 0, d = 0, o = sweep ? bm[b] : 0;
+            for (int64_t i = 0; i < n;) {
+                int64_t j = i + 1;
+                while (j < n && a[j].w0 == a[i].w0 && a[j].w1 == a[i].w1) j++;
+                const int64_t c = j - i;
+                d++;
+                int keep = 1;
+                if (min_cov > 1 && c < min_cov) keep = 0;                    /* P/ReflexivDataFrameCounter64.java:197-200 */
+                if (max_cov < 10000000 && c > max_cov) keep = 0;             /* :202-205 */
+                if (keep) {
+                    if (sweep) { out_keys[2 * o] = a[i].w0; out_keys[2 * o + 1] = a[i].w1; out_counts[o] = c; o++; }
+                    m++;
+                }
+                i = j;
+            }
+            if (!sweep) { bm[b] = m; bd[b] = d; }
+        }
+    }
+    const int64_t M = bm[NB];
+    free(hist); free(bstart); free(arr); free(bm); free(bd); free(scratch);
+    return M;
+}
+
 /* ---------------------------------------------------------- radix sort u64 */
 
 static void radix_sort_u64(uint64_t *a, int64_t n) {
@@ -349,8 +510,14 @@ int64_t orc_count_filter(uint64_t *kmers, int64_t n, int min_cov, int max_cov, i
  * k-mer), then buckets are sorted, run-length counted and filtered by whichever thread is free (the
  * reduce side of reduceByKey, P/ReflexivMain.java:155, 2895-2899, 3115-3119).  Buckets are ranges, so their
  * concatenation is the ascending order of the order contract.  Result identical to the serial pair. */
+int64_t orc_count_reads_range_omp(const char *bases, const int64_t *read_off, int64_t n_reads,
+                                  int k, int front_clip, int end_clip, int min_cov, int max_cov, int twin,
+                                  int b_lo, int b_hi,
+                                  uint64_t *out_keys, int32_t *out_counts, int64_t cap,
+                                  int64_t *n_distinct, int64_t *n_instances);
+
 static inline void read_kmers(const char *read, int64_t len, int k, int front_clip, int end_clip, uint64_t mask,
-                              int shift, int64_t *hist, uint64_t *arr, int64_t *cursor) {
+                              int shift, int b_lo, int b_hi, int64_t *hist, uint64_t *arr, int64_t *cursor) {
     if (len - k - end_clip <= 1 || front_clip > len) return;                 /* :3020 */
     uint64_t fwd = 0, rc = 0;
     for (int64_t i = front_clip; i < len - end_clip; i++) {                  /* :3027 */
@@ -364,7 +531,9 @@ static inline void read_kmers(const char *read, int64_t len, int k, int front_cl
         rc |= c;                                                             /* :3047 */
         if (j >= k - 1) {                                                    /* :3050 */
             uint64_t canon = ((int64_t)fwd < (int64_t)rc) ? fwd : rc;        /* :3051-3055 */
-            if (arr) arr[cursor[canon >> shift]++] = canon; else hist[canon >> shift]++;
+            const int bkt = (int)(canon >> shift);
+            if (bkt < b_lo || bkt >= b_hi) continue;         /* another pass's share of the k-mer space */
+            if (arr) arr[cursor[bkt]++] = canon; else hist[bkt]++;
         }
     }
 }
@@ -373,6 +542,18 @@ int64_t orc_count_reads_omp(const char *bases, const int64_t *read_off, int64_t 
                             int k, int front_clip, int end_clip, int min_cov, int max_cov, int twin,
                             uint64_t *out_keys, int32_t *out_counts, int64_t cap,
                             int64_t *n_distinct, int64_t *n_instances) {
+    return orc_count_reads_range_omp(bases, read_off, n_reads, k, front_clip, end_clip, min_cov, max_cov, twin, 0, 1 << 30,
+                                     out_keys, out_counts, cap, n_distinct, n_instances);
+}
+
+/* the same, restricted to the range buckets [b_lo, b_hi) of the 4096 (top 12 bits of the k-mer): a read set whose
+ * instances do not fit in memory at once is counted in several passes over disjoint shares of the k-mer space;
+ * the passes' outputs concatenate to the full ascending list (tests/golden/make_c2_full.py) */
+int64_t orc_count_reads_range_omp(const char *bases, const int64_t *read_off, int64_t n_reads,
+                                  int k, int front_clip, int end_clip, int min_cov, int max_cov, int twin,
+                                  int b_lo, int b_hi,
+                                  uint64_t *out_keys, int32_t *out_counts, int64_t cap,
+                                  int64_t *n_distinct, int64_t *n_instances) {
     const int T = g_threads;
     const int BB = k >= 6 ? 12 : 2 * k;                 /* bucket bits */
     const int NB = 1 << BB, shift = 2 * k - BB;
@@ -390,7 +571,7 @@ int64_t orc_count_reads_omp(const char *bases, const int64_t *read_off, int64_t 
 #endif
         const int64_t lo = n_reads * t / T, hi = n_reads * (t + 1) / T;
         for (int64_t r = lo; r < hi; r++)
-            read_kmers(bases + read_off[r], read_off[r + 1] - read_off[r], k, front_clip, end_clip, mask, shift,
+            read_kmers(bases + read_off[r], read_off[r + 1] - read_off[r], k, front_clip, end_clip, mask, shift, b_lo, b_hi,
                        hist + (size_t)t * NB, NULL, NULL);
     }
     int64_t *bstart = (int64_t *)xmalloc((size_t)(NB + 1) * sizeof(int64_t));
@@ -413,7 +594,7 @@ int64_t orc_count_reads_omp(const char *bases, const int64_t *read_off, int64_t 
 #endif
         const int64_t lo = n_reads * t / T, hi = n_reads * (t + 1) / T;
         for (int64_t r = lo; r < hi; r++)
-            read_kmers(bases + read_off[r], read_off[r + 1] - read_off[r], k, front_clip, end_clip, mask, shift,
+            read_kmers(bases + read_off[r], read_off[r + 1] - read_off[r], k, front_clip, end_clip, mask, shift, b_lo, b_hi,
                        NULL, arr, hist + (size_t)t * NB);
     }
     /* reduce side: sort + run-length + filter per bucket; two sweeps so that survivors land in order */
@@ -1453,6 +1634,9 @@ void orc_synth_reads(uint64_t seed, const uint64_t *genome, int64_t genome_len,
     static const char NUC[4] = { 'A', 'C', 'G', 'T' };
     uint64_t sp = orc_splitmix64(seed ^ SYNTH_TAG_PAIRS);
     uint64_t se = orc_splitmix64(seed ^ SYNTH_TAG_ERRORS);
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
+#endif
     for (int64_t t = 0; t < n_reads; t++) {
         int64_t r = first_read + t;
         uint64_t pair = (uint64_t)r >> 1;

@@ -271,6 +271,21 @@ int64_t orc_count_reads_omp(const char *bases, const int64_t *read_off, int64_t 
                             uint64_t *out_keys, int32_t *out_counts, int64_t cap,
                             int64_t *n_distinct, int64_t *n_instances);
 
+/* The same restricted to the range buckets [b_lo, b_hi) of 4096 (top 12 bits of the k-mer): several passes over
+ * disjoint shares of the k-mer space count a read set whose instances do not fit in memory at once; outputs
+ * concatenate to the full ascending list.  And its k = 33..63 twin (two-word k-mers, int64 counts, the filters of
+ * P/ReflexivDataFrameCounter64.java:197-205; buckets = top 12 bits of word 0). */
+int64_t orc_count_reads_range_omp(const char *bases, const int64_t *read_off, int64_t n_reads,
+                                  int k, int front_clip, int end_clip, int min_cov, int max_cov, int twin,
+                                  int b_lo, int b_hi,
+                                  uint64_t *out_keys, int32_t *out_counts, int64_t cap,
+                                  int64_t *n_distinct, int64_t *n_instances);
+int64_t orc_count_reads_w2_range_omp(const char *bases, const int64_t *read_off, int64_t n_reads,
+                                     int k, int front_clip, int end_clip, int min_cov, int max_cov,
+                                     int b_lo, int b_hi,
+                                     uint64_t *out_keys, int64_t *out_counts, int64_t cap,
+                                     int64_t *n_distinct, int64_t *n_instances);
+
 /* Synthetic reads, integer-only counter-based generator shared
  * bit-for-bit with reflexiv_amd/csrc (rfx_synth_*). */
 uint64_t orc_splitmix64(uint64_t x);

@@ -26,6 +26,36 @@ def test_count_reads_omp_equals_serial(k, fc, ec, twin, min_cov):
         assert np.array_equal(keys, wk) and np.array_equal(counts, wc)
 
 
+@pytest.mark.parametrize("k,min_cov,clips", [(63, 2, (0, 0)), (47, 1, (2, 3)), (33, 3, (0, 0))])
+def test_count_reads_w2_omp_equals_serial_in_passes(k, min_cov, clips):
+    g = O.synth_genome(9, 20_000)
+    bases, off = O.synth_reads(9, g, 20_000, 0, 5000, 100)
+    fc, ec = clips
+    km = O.extract_canon_w(bases, off, k, fc, ec)
+    wk, wc, wd = O.count_filter_w(km, k, min_cov)
+    for t, cuts in ((1, [0, 4096]), (8, [0, 100, 1000, 1001, 4096])):
+        O.set_threads(t)
+        ks, cs, nd, ni = [], [], 0, 0
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            a, b, d, i = O.count_reads_omp(bases, off, k, min_cov, front_clip=fc, end_clip=ec, buckets=(lo, hi))
+            ks.append(a); cs.append(b); nd += d; ni += i
+        assert ni == len(km) and nd == wd
+        assert np.array_equal(np.concatenate(ks), wk) and np.array_equal(np.concatenate(cs), wc)
+
+
+def test_count_reads_omp_in_passes():
+    g = O.synth_genome(7, 20_000)
+    bases, off = O.synth_reads(7, g, 20_000, 0, 6000, 100)
+    wk, wc, wd = O.count_filter(O.extract_canon(bases, off, 31), 2)
+    O.set_threads(4)
+    ks, cs, nd, ni = [], [], 0, 0
+    for lo, hi in ((0, 7), (7, 2000), (2000, 4096)):
+        a, b, d, i = O.count_reads_omp(bases, off, 31, 2, buckets=(lo, hi))
+        ks.append(a); cs.append(b); nd += d; ni += i
+    assert nd == wd and ni == 6000 * 70
+    assert np.array_equal(np.concatenate(ks), wk) and np.array_equal(np.concatenate(cs), wc)
+
+
 @pytest.mark.parametrize("k,P", [(31, 8), (31, 3), (63, 4)])
 def test_threaded_driver_equals_serial(k, P):
     G, n_reads = 120_000, 40_000

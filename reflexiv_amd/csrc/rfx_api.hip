@@ -804,7 +804,25 @@ static int assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const 
     int partitionNumber = P;
     int64_t contigNumber = 0;
     int scramble = 2;                                                             // U/DefaultParam.java:131
+    // once the record set is small the rest of the loop runs as two launches per pass with the loop state in HBM
+    static const bool small_off = getenv("RFX_NO_SMALL_PASSES") != nullptr;
+    auto small_tail = [&](bool *took) -> int {
+        *took = false;
+        if (small_off || a.n > small_pass_limit() || P > small_pass_max_partitions()) return RFX_OK;
+        Arena *saved = tl_arena;
+        tl_arena = nullptr;                 // its second record set and scratch outlive the alternating arenas
+        const double t0 = verbose ? now_ms() : 0;
+        const int64_t n0 = a.n;
+        const int st = small_passes(ctx, a, k, twin, wide, prm->coalesce, prm->min_iter, prm->max_iter, &iterations, &contigNumber,
+                                    &scramble, &P, &partitionNumber, trace, trace_cap, &nt);
+        tl_arena = saved;
+        if (verbose) fprintf(stderr, "small passes from n %lld: %.3f ms -> n %lld after pass %lld\n", (long long)n0, now_ms() - t0,
+                             (long long)a.n, (long long)nt);
+        *took = st == RFX_OK;
+        return st;
+    };
     while (wide && iterations <= prm->max_iter) {                                 // 64 :582
+        { bool took; RFX_TRY(small_tail(&took)); if (took) break; }
         iterations++;
         if (iterations >= prm->min_iter + 3 && iterations % 3 == 0) {             // 64 :621-622
             const int64_t current = a.n;                                          // 64 :633-635
@@ -817,6 +835,7 @@ static int assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const 
         RFX_TRY(one_pass(2, scramble == 3 ? 1 : 2));                              // 64 :659-660, :667-669
     }
     while (!wide && iterations <= prm->max_iter) {                                // :265-296
+        { bool took; RFX_TRY(small_tail(&took)); if (took) break; }
         iterations++;
         if (iterations >= prm->min_iter && iterations % 3 == 0) {
             const int64_t current = a.n;                                          // count() :270

@@ -25,6 +25,8 @@
 // Integer/byte work bound by HBM; no MFMA.
 #include "rfx_internal.h"
 #include "rfx_device.h"
+#include <utility>
+#include <vector>
 
 using namespace rfxd;
 
@@ -50,12 +52,11 @@ __global__ void k_ext_len(const int64_t *__restrict__ ext_off, const uint64_t *_
 
 // B.5 on one equal-key run; descriptors go to desc[i .. i+emissions)
 template <int KW>
-__global__ void k_resolve(const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
+__device__ __forceinline__ void resolve_at(int64_t i, const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
                           const int32_t *__restrict__ left, const int32_t *__restrict__ right,
                           const uint32_t *__restrict__ len, int64_t n, int twin, int stage,
                           Desc *__restrict__ desc, uint32_t *__restrict__ flag, uint32_t *__restrict__ onw,
                           int *__restrict__ status) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const KeyW<KW> kk = key[i];
     if (i > 0 && key_eq(key[i - 1], kk)) return;               // not a run head
@@ -101,6 +102,16 @@ __global__ void k_resolve(const KeyW<KW> *__restrict__ key, const int32_t *__res
     if (holder >= 0) PUT(1u, holder, 0, left[holder], right[holder], len[holder]);  // :886-893, :902
     for (; o < s; o++) { flag[o] = 0u; onw[o] = 0u; desc[o].type = 0u; }
 #undef PUT
+}
+
+template <int KW>
+__global__ void k_resolve(const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
+                          const int32_t *__restrict__ left, const int32_t *__restrict__ right,
+                          const uint32_t *__restrict__ len, int64_t n, int twin, int stage,
+                          Desc *__restrict__ desc, uint32_t *__restrict__ flag, uint32_t *__restrict__ onw,
+                          int *__restrict__ status) {
+    resolve_at<KW>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, key, marker, left, right, len, n, twin, stage, desc, flag,
+                   onw, status);
 }
 
 // view of a source record
@@ -157,7 +168,7 @@ __device__ __forceinline__ int part_of(const int64_t *__restrict__ ps, int P, in
 }
 
 template <int KW>
-__global__ void k_emit(const Desc *__restrict__ desc, const uint32_t *__restrict__ flag,
+__device__ __forceinline__ void emit_at(int64_t i, const Desc *__restrict__ desc, const uint32_t *__restrict__ flag,
                        const uint64_t *__restrict__ oidx, const uint64_t *__restrict__ owoff, int64_t n,
                        const int64_t *__restrict__ ps, int P, int sub, int start_marker,
                        const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
@@ -165,7 +176,6 @@ __global__ void k_emit(const Desc *__restrict__ desc, const uint32_t *__restrict
                        const uint32_t *__restrict__ len,
                        KeyW<KW> *__restrict__ okey, int32_t *__restrict__ omarker, int64_t *__restrict__ oext_off,
                        uint64_t *__restrict__ oext, int32_t *__restrict__ oleft, int32_t *__restrict__ oright) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == n) { oext_off[oidx[n]] = (int64_t)owoff[n]; return; }
     if (i > n || !flag[i]) return;
     const Desc d = desc[i];
@@ -212,17 +222,29 @@ __global__ void k_emit(const Desc *__restrict__ desc, const uint32_t *__restrict
     emit_words<KW>(s, sub, m == 1 ? sub : 0, L, 0, nw, 1, oext + wo);
 }
 
+template <int KW>
+__global__ void k_emit(const Desc *__restrict__ desc, const uint32_t *__restrict__ flag,
+                       const uint64_t *__restrict__ oidx, const uint64_t *__restrict__ owoff, int64_t n,
+                       const int64_t *__restrict__ ps, int P, int sub, int start_marker,
+                       const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
+                       const int64_t *__restrict__ ext_off, const uint64_t *__restrict__ ext,
+                       const uint32_t *__restrict__ len,
+                       KeyW<KW> *__restrict__ okey, int32_t *__restrict__ omarker, int64_t *__restrict__ oext_off,
+                       uint64_t *__restrict__ oext, int32_t *__restrict__ oleft, int32_t *__restrict__ oright) {
+    emit_at<KW>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, desc, flag, oidx, owoff, n, ps, P, sub, start_marker, key, marker,
+                ext_off, ext, len, okey, omarker, oext_off, oext, oleft, oright);
+}
+
 // Extensions longer than EMIT_SHORT words, one thread per OUTPUT WORD: thread t finds the emission
 // that owns word t of the output array by a binary search in the word-offset scan (zero-length
 // entries share their successor's offset, so the last entry with offset <= t is the owner) and
 // writes that one word.  A 2.6 Mbp contig (84 K words) is 84 K threads; no per-record queues.
 template <int KW>
-__global__ void k_emit_words(const Desc *__restrict__ desc, const uint64_t *__restrict__ oidx,
+__device__ __forceinline__ void emit_word_at(int64_t t, const Desc *__restrict__ desc, const uint64_t *__restrict__ oidx,
                              const uint64_t *__restrict__ owoff, int64_t n, const int64_t *__restrict__ ps, int P, int sub,
                              int start_marker, const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
                              const int64_t *__restrict__ ext_off, const uint64_t *__restrict__ ext,
                              const uint32_t *__restrict__ len, uint64_t *__restrict__ oext) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)owoff[n]) return;
     int64_t lo = 0, hi = n;                          // owoff[lo] <= t < owoff[hi]
     while (hi - lo > 1) {
@@ -243,6 +265,233 @@ __global__ void k_emit_words(const Desc *__restrict__ desc, const uint64_t *__re
     if (d.type == 2) s.b = load_src<KW>(d.b, key, marker, ext_off, ext, len); else s.b = s.a;
     if (d.type == 1 && s.a.marker == m) oext[wo + w] = s.a.w[w];
     else emit_words<KW>(s, sub, m == 1 ? sub : 0, L, w, w + 1, 1, oext + wo);
+}
+
+template <int KW>
+__global__ void k_emit_words(const Desc *__restrict__ desc, const uint64_t *__restrict__ oidx,
+                             const uint64_t *__restrict__ owoff, int64_t n, const int64_t *__restrict__ ps, int P, int sub,
+                             int start_marker, const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
+                             const int64_t *__restrict__ ext_off, const uint64_t *__restrict__ ext,
+                             const uint32_t *__restrict__ len, uint64_t *__restrict__ oext) {
+    emit_word_at<KW>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, desc, oidx, owoff, n, ps, P, sub, start_marker, key, marker,
+                     ext_off, ext, len, oext);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Small passes.  Most passes of the loop touch a few thousand records or fewer (the record count
+// shrinks by a quarter per pass; on a 4.6 Mbp genome 29 of 54 passes see <= 4096 records), and a pass built from ~35
+// launches and one readback costs ~0.2 ms however small it is.  Below SP_N records a pass is TWO launches:
+//   k_small_pass   ONE workgroup does everything that is control flow: the stop rule of the driver, the stable sort
+//                  of the keys (LDS radix sort of (key word, position) pairs, word by word for multi-word keys), the
+//                  logical partition starts, the run resolution, both scans, and the emission of keys, markers and the
+//                  short extensions -- the same device functions as the big-pass kernels, fed through the sort's
+//                  permutation instead of physically sorted records (a sorted VIEW of the fixed fields is written to
+//                  scratch; extension words stay where they are);
+//   k_small_words  the whole grid writes the long extensions (late passes: few records, several hundred thousand
+//                  words), one thread per output word.
+// The driver's state (iteration counter, last count, scramble, partition number, which of the two record sets is
+// current, the trace) lives in HBM, so the host queues several passes back to back and reads the state once per batch;
+// passes queued after the stop rule fired find `done` set and return at once.
+constexpr int SP_N = 4096;
+constexpr int SP_T = 1024;
+constexpr int SP_W = SP_T / 64;
+constexpr int SP_MAXP = 1024;           // logical partitions the single workgroup handles
+
+struct SmallState {
+    int64_t n, words, contig_number, nt;
+    int32_t iterations, scramble, P, partition_number, cur, io, done, status, start_marker, pad;
+};
+struct SmallSet { void *key; int32_t *marker; int64_t *ext_off; uint64_t *ext; int32_t *left; int32_t *right; };
+struct SmallScratch {
+    void *skey; int32_t *smarker, *sleft, *sright; uint32_t *slen; int64_t *sext;
+    Desc *desc; uint32_t *flag, *onw; uint64_t *oidx, *owoff; int64_t *ps; int *status;
+};
+struct SmallRule { int wide, coalesce, min_iter, max_iter, twin, sub, res_bits; int64_t trace_cap; };
+
+template <int KW>
+__global__ __launch_bounds__(SP_T) void k_small_pass(SmallSet A, SmallSet B, SmallScratch sc, SmallState *__restrict__ st,
+                                                     SmallRule rule, int64_t *__restrict__ trace) {
+    __shared__ uint64_t sk[2][SP_N];
+    __shared__ uint16_t sv[2][SP_N];
+    __shared__ volatile uint32_t wcnt[SP_W][256];
+    __shared__ uint32_t wbase[SP_W][256];
+    __shared__ uint32_t wsum[SP_W];
+    __shared__ int sh_go, sh_P, sh_start;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        // the driver's loop head: P/ReflexivMain.java:265-283 (k <= 31), P/ReflexivDSMain64.java:582, 621-655 (k > 31)
+        int go = 0;
+        if (!st->done) {
+            if (st->iterations <= rule.max_iter) {
+                st->iterations++;
+                go = 1;
+                const int64_t current = st->n;
+                if (!rule.wide) {
+                    if (st->iterations >= rule.min_iter && st->iterations % 3 == 0) {
+                        if (st->contig_number == current) go = 0;
+                        else {
+                            st->contig_number = current;
+                            if (rule.coalesce && st->partition_number >= 16 && current / st->partition_number <= 20) {
+                                st->partition_number = st->partition_number / 4 + 1;
+                                st->P = st->partition_number;
+                            }
+                        }
+                    }
+                } else if (st->iterations >= rule.min_iter + 3 && st->iterations % 3 == 0) {
+                    if (st->contig_number == current) {
+                        if (st->scramble == 2) st->scramble = 3; else go = 0;
+                    } else st->contig_number = current;
+                }
+            }
+            if (!go) st->done = 1;
+        }
+        if (go) { st->io = st->cur; st->start_marker = (rule.wide && st->scramble == 3) ? 1 : 2; }
+        sh_go = go; sh_P = st->P; sh_start = st->start_marker;
+    }
+    __syncthreads();
+    if (!sh_go) return;
+    const int P = sh_P, start_marker = sh_start, sub = rule.sub;
+    const int n = (int)st->n;
+    const SmallSet &in = st->io ? B : A;
+    const SmallSet &out = st->io ? A : B;
+    const KeyW<KW> *ikey = (const KeyW<KW> *)in.key;
+    KeyW<KW> *skey = (KeyW<KW> *)sc.skey;
+
+    // ---- stable sort of the keys, last word first: (sk, sv) = (key word, source position)
+    int cur = 0;
+    const int per_wave = ((n + SP_T - 1) / SP_T) * 64;
+    const int rounds = per_wave >> 6;                       // <= SP_N / SP_T = 4
+    const uint64_t lt = (1ULL << lane) - 1;
+    for (int w = KW - 1; w >= 0; w--) {
+        for (int i = tid; i < n; i += SP_T) {
+            const int src = (w == KW - 1) ? i : (int)sv[cur][i];
+            sk[cur][i] = ikey[src].w[w];
+            sv[cur][i] = (uint16_t)src;
+        }
+        const int bits = (w == KW - 1) ? rule.res_bits : 62;
+        for (int sh = 0; sh < bits; sh += 8) {
+            for (int i = tid; i < SP_W * 256; i += SP_T) ((volatile uint32_t *)wcnt)[i] = 0;
+            __syncthreads();
+            uint32_t rank[SP_N / SP_T];
+            const int cbase = wave * per_wave;
+#pragma unroll
+            for (int r = 0; r < SP_N / SP_T; r++) {
+                if (r < rounds) {
+                    const int idx = cbase + r * 64 + lane;
+                    const bool ok = idx < n;
+                    const unsigned d = ok ? (unsigned)(sk[cur][idx] >> sh) & 255u : 0u;
+                    uint64_t peers = __ballot(ok);
+#pragma unroll
+                    for (int b = 0; b < 8; b++) {
+                        const uint64_t m = __ballot((d >> b) & 1u);
+                        peers &= ((d >> b) & 1u) ? m : ~m;
+                    }
+                    uint32_t before = 0;
+                    if (ok) { before = wcnt[wave][d]; rank[r] = before + (uint32_t)__popcll(peers & lt); }
+                    if (ok && (peers & lt) == 0) wcnt[wave][d] = before + (uint32_t)__popcll(peers);
+                }
+            }
+            __syncthreads();
+            uint32_t tot = 0;
+            if (tid < 256) {
+#pragma unroll
+                for (int q = 0; q < SP_W; q++) tot += wcnt[q][tid];
+            }
+            uint32_t dbase = block_exclusive_scan(tot, wsum, nullptr);
+            if (tid < 256) {
+#pragma unroll
+                for (int q = 0; q < SP_W; q++) { wbase[q][tid] = dbase; dbase += wcnt[q][tid]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < SP_N / SP_T; r++) {
+                if (r < rounds) {
+                    const int idx = cbase + r * 64 + lane;
+                    if (idx < n) {
+                        const uint64_t kk = sk[cur][idx];
+                        const uint32_t dst = wbase[wave][(unsigned)(kk >> sh) & 255u] + rank[r];
+                        sk[cur ^ 1][dst] = kk;
+                        sv[cur ^ 1][dst] = sv[cur][idx];
+                    }
+                }
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    // ---- sorted view of the fixed fields (extension words are read where they lie)
+    for (int i = tid; i < n; i += SP_T) {
+        const int src = (int)sv[cur][i];
+        skey[i] = ikey[src];
+        sc.smarker[i] = in.marker[src]; sc.sleft[i] = in.left[src]; sc.sright[i] = in.right[src];
+        const int64_t b = in.ext_off[src], nw = in.ext_off[src + 1] - b;
+        sc.slen[i] = (uint32_t)((nw - 1) * 31 + sentinel_len(in.ext[b]));
+        sc.sext[i] = b;
+    }
+    if (tid == 0) sc.status[0] = 0;
+    __syncthreads();
+    // ---- logical partition starts (order contract B.0)
+    for (int p = tid; p <= P; p += SP_T) {
+        int64_t s = p == P ? n : (int64_t)(((uint64_t)p * (uint64_t)n) / (uint64_t)P);
+        while (p < P && s > 0 && s < n && key_eq(skey[s], skey[s - 1])) s++;
+        sc.ps[p] = s;
+    }
+    // ---- run resolution
+    for (int i = tid; i < n; i += SP_T)
+        resolve_at<KW>(i, (const KeyW<KW> *)skey, sc.smarker, sc.sleft, sc.sright, sc.slen, n, rule.twin, 2, sc.desc, sc.flag, sc.onw,
+                       sc.status);
+    __syncthreads();
+    // ---- both scans: every thread owns SP_N / SP_T consecutive entries
+    {
+        constexpr int E = SP_N / SP_T;
+        uint32_t f[E], w[E], fs = 0, ws = 0;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int i = tid * E + e;
+            f[e] = i < n ? sc.flag[i] : 0u; w[e] = i < n ? sc.onw[i] : 0u;
+            fs += f[e]; ws += w[e];
+        }
+        uint32_t ftot = 0, wtot = 0;
+        uint32_t fb = block_exclusive_scan(fs, wsum, &ftot);
+        uint32_t wb = block_exclusive_scan(ws, wsum, &wtot);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const int i = tid * E + e;
+            if (i < n) { sc.oidx[i] = fb; sc.owoff[i] = wb; }
+            fb += f[e]; wb += w[e];
+        }
+        if (tid == 0) { sc.oidx[n] = ftot; sc.owoff[n] = wtot; }
+    }
+    __syncthreads();
+    // ---- keys, markers, left / right, offsets and the short extensions
+    for (int i = tid; i <= n; i += SP_T)
+        emit_at<KW>(i, sc.desc, sc.flag, sc.oidx, sc.owoff, n, sc.ps, P, sub, start_marker, (const KeyW<KW> *)skey, sc.smarker, sc.sext,
+                    in.ext, sc.slen, (KeyW<KW> *)out.key, out.marker, out.ext_off, out.ext, out.left, out.right);
+    __syncthreads();
+    if (tid == 0) {
+        const int64_t m = (int64_t)sc.oidx[n];
+        st->n = m; st->words = (int64_t)sc.owoff[n];
+        st->cur = 1 - st->io;
+        st->status |= sc.status[0];
+        if (trace && st->nt < rule.trace_cap) trace[st->nt] = m;
+        st->nt++;
+    }
+}
+
+// the long extensions of the pass k_small_pass just resolved (its scans are still in the scratch arrays)
+template <int KW>
+__global__ void k_small_words(SmallSet A, SmallSet B, SmallScratch sc, const SmallState *__restrict__ st, int sub, int64_t n_in_of_pass_unused) {
+    (void)n_in_of_pass_unused;
+    if (st->done) return;
+    // st->cur was flipped at the end of k_small_pass: this pass read set `io` and wrote the other one
+    const SmallSet &in = st->io ? B : A;
+    const SmallSet &out = st->io ? A : B;
+    // the scans' last entries hold this pass's record count / word total; n_in = number of descriptors = ps[P]
+    const int P = st->P;
+    const int64_t n_in = sc.ps[P];
+    emit_word_at<KW>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, sc.desc, sc.oidx, sc.owoff, n_in, sc.ps, P, sub, st->start_marker,
+                     (const KeyW<KW> *)sc.skey, sc.smarker, sc.sext, in.ext, sc.slen, out.ext);
 }
 
 // output partition starts + the pass summary the host reads back in ONE copy:
@@ -334,5 +583,84 @@ int extend_pass(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start,
     if (st) { ctx->last_error = "extend pass: single-word stage produced an extension > 31 bases"; return RFX_E_STATE; }
     return RFX_OK;
 }
+
+// Runs the rest of the driver's loop (P/ReflexivMain.java:265-296; k > 31: P/ReflexivDSMain64.java:582-670) on a record set of
+// at most SP_N records: see k_small_pass.  io: iterations / contig_number / scramble / P / partition_number as the host
+// loop left them; on return they are what the loop would have left, `recs` holds the surviving records and the trace has
+// grown by the passes run.
+int small_passes(rfx_ctx *ctx, DevRecords &recs, int k, int twin, bool wide, int coalesce, int min_iter, int max_iter,
+                 int *iterations, int64_t *contig_number, int *scramble, int *P, int *partition_number,
+                 int64_t *trace, int64_t trace_cap, int64_t *nt) {
+    const int kw = recs.kw, sub = k - 1;
+    if (recs.n > SP_N || *P > SP_MAXP || *P < 1) return RFX_E_ARG;
+    const int64_t capn = recs.n > 0 ? recs.n : 1, capw = recs.words > 0 ? recs.words : 1;
+    DevRecords other;
+    RFX_TRY(dev_records_alloc(ctx, other, capn, capw, kw));
+    DevBuf skey, smarker, sleft, sright, slen, sext, desc, flag, onw, oidx, owoff, ps, status, state, dtrace;
+    RFX_HIP(skey.alloc((size_t)capn * 8 * kw, ctx->stream));
+    RFX_HIP(smarker.alloc((size_t)capn * 4, ctx->stream)); RFX_HIP(sleft.alloc((size_t)capn * 4, ctx->stream));
+    RFX_HIP(sright.alloc((size_t)capn * 4, ctx->stream)); RFX_HIP(slen.alloc((size_t)capn * 4, ctx->stream));
+    RFX_HIP(sext.alloc((size_t)capn * 8, ctx->stream)); RFX_HIP(desc.alloc((size_t)capn * sizeof(Desc), ctx->stream));
+    RFX_HIP(flag.alloc((size_t)capn * 4, ctx->stream)); RFX_HIP(onw.alloc((size_t)capn * 4, ctx->stream));
+    RFX_HIP(oidx.alloc((size_t)(capn + 1) * 8, ctx->stream)); RFX_HIP(owoff.alloc((size_t)(capn + 1) * 8, ctx->stream));
+    RFX_HIP(ps.alloc((size_t)(SP_MAXP + 1) * 8, ctx->stream)); RFX_HIP(status.alloc(4, ctx->stream));
+    RFX_HIP(state.alloc(sizeof(SmallState), ctx->stream));
+    const int64_t tcap = max_iter + 8;
+    RFX_HIP(dtrace.alloc((size_t)tcap * 8, ctx->stream));
+    SmallState h{};
+    h.n = recs.n; h.words = recs.words; h.contig_number = *contig_number; h.nt = 0;
+    h.iterations = *iterations; h.scramble = *scramble; h.P = *P; h.partition_number = *partition_number;
+    h.cur = 0; h.io = 0; h.done = 0; h.status = 0; h.start_marker = 2;
+    RFX_HIP(hipMemcpyAsync(state.p, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+    const SmallSet A{recs.key.p, recs.marker.as<int32_t>(), recs.ext_off.as<int64_t>(), recs.ext.as<uint64_t>(),
+                     recs.left.as<int32_t>(), recs.right.as<int32_t>()};
+    const SmallSet B{other.key.p, other.marker.as<int32_t>(), other.ext_off.as<int64_t>(), other.ext.as<uint64_t>(),
+                     other.left.as<int32_t>(), other.right.as<int32_t>()};
+    const SmallScratch sc{skey.p, smarker.as<int32_t>(), sleft.as<int32_t>(), sright.as<int32_t>(), slen.as<uint32_t>(),
+                          sext.as<int64_t>(), desc.as<Desc>(), flag.as<uint32_t>(), onw.as<uint32_t>(), oidx.as<uint64_t>(),
+                          owoff.as<uint64_t>(), ps.as<int64_t>(), status.as<int>()};
+    const int res = sub - 31 * (kw - 1);
+    const SmallRule rule{wide ? 1 : 0, coalesce, min_iter, max_iter, twin, sub, 2 * res, tcap};
+    constexpr int BATCH = 6;                 // passes queued between two looks at the state (two checks of the stop rule)
+    int64_t words_bound = recs.words;
+    for (;;) {
+        for (int b = 0; b < BATCH; b++) {
+            RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_small_pass<KW>, dim3(1), dim3(SP_T), 0, ctx->stream, A, B, sc, state.as<SmallState>(), rule,
+                                                 dtrace.as<int64_t>()));
+            RFX_HIP(hipGetLastError());
+            if (words_bound > 0) {
+                RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_small_words<KW>, dim3(grid_for(words_bound)), dim3(256), 0, ctx->stream, A, B, sc,
+                                                     (const SmallState *)state.as<SmallState>(), sub, (int64_t)0));
+                RFX_HIP(hipGetLastError());
+            }
+        }
+        RFX_HIP(hipMemcpyAsync(&h, state.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        words_bound = h.words;                // the word total never grows from pass to pass
+        if (h.done || h.iterations > max_iter) break;
+    }
+    if (h.status) { ctx->last_error = "extend pass: impossible record state"; return RFX_E_STATE; }
+    std::vector<int64_t> ht((size_t)(h.nt > 0 ? h.nt : 1));
+    if (h.nt > 0) {
+        RFX_HIP(hipMemcpyAsync(ht.data(), dtrace.p, (size_t)h.nt * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    for (int64_t i = 0; i < h.nt; i++) { if (trace && *nt < trace_cap) trace[*nt] = ht[(size_t)i]; (*nt)++; }
+    if (h.cur == 1) {        // the survivors are in the second set: hand its buffers over
+        std::swap(recs.key.p, other.key.p); std::swap(recs.key.borrowed, other.key.borrowed); std::swap(recs.key.s, other.key.s);
+        std::swap(recs.marker.p, other.marker.p); std::swap(recs.marker.borrowed, other.marker.borrowed); std::swap(recs.marker.s, other.marker.s);
+        std::swap(recs.ext_off.p, other.ext_off.p); std::swap(recs.ext_off.borrowed, other.ext_off.borrowed); std::swap(recs.ext_off.s, other.ext_off.s);
+        std::swap(recs.ext.p, other.ext.p); std::swap(recs.ext.borrowed, other.ext.borrowed); std::swap(recs.ext.s, other.ext.s);
+        std::swap(recs.left.p, other.left.p); std::swap(recs.left.borrowed, other.left.borrowed); std::swap(recs.left.s, other.left.s);
+        std::swap(recs.right.p, other.right.p); std::swap(recs.right.borrowed, other.right.borrowed); std::swap(recs.right.s, other.right.s);
+    }
+    recs.n = h.n; recs.words = h.words;
+    *iterations = h.iterations; *contig_number = h.contig_number; *scramble = h.scramble; *P = h.P;
+    *partition_number = h.partition_number;
+    return RFX_OK;
+}
+
+int small_pass_limit() { return SP_N; }
+int small_pass_max_partitions() { return SP_MAXP; }
 
 }  // namespace rfx

@@ -255,4 +255,11 @@ int random_reflection(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_
 int extend_pass(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start, int P, int k,
                 int twin, int stage, DevRecords &out, DevBuf &out_part_start, int start_marker = 2);
 
+// the rest of the driver's loop on <= small_pass_limit() records: two launches per pass, state in HBM (rfx_extend.hip)
+int small_passes(rfx_ctx *ctx, DevRecords &recs, int k, int twin, bool wide, int coalesce, int min_iter, int max_iter,
+                 int *iterations, int64_t *contig_number, int *scramble, int *P, int *partition_number,
+                 int64_t *trace, int64_t trace_cap, int64_t *nt);
+int small_pass_limit();
+int small_pass_max_partitions();
+
 }  // namespace rfx

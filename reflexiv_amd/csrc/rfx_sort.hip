@@ -19,45 +19,84 @@ constexpr int SI = 8;               // keys per thread
 constexpr int STILE = ST * SI;      // 2048 keys per tile
 constexpr int SW = ST / 64;         // waves per workgroup
 
+// Second MSD level (large inputs): tiles must not straddle the buckets of the first level.  Bucket b of the 256
+// has nt_b = ceil(size_b / STILE) "virtual tiles"; vtile v = tstart[b] + t covers [bstart[b] + t*STILE, ...) inside
+// the bucket, and its histogram row sits at table[tstart[b]*D + d*nt_b + t]: scanned flat, that layout is the order
+// (bucket, digit, tile), i.e. the output position of every (tile, digit) group.
+struct SegMap {
+    const uint32_t *bstart;     // [257] first position of every level-1 bucket (bstart[256] = n)
+    const uint32_t *tstart;     // [257] first virtual tile of every bucket (tstart[256] = number of virtual tiles)
+    int D;                      // digits of this level (power of two <= 256)
+};
+struct SegPos { int64_t begin, end, row; int64_t stride; bool ok; };
+__device__ __forceinline__ SegPos seg_pos(const SegMap &m, uint32_t v) {
+    SegPos p; p.ok = v < m.tstart[256];
+    if (!p.ok) { p.begin = p.end = p.row = 0; p.stride = 1; return p; }
+    int lo = 0, hi = 256;                              // last b with tstart[b] <= v
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (m.tstart[mid] <= v) lo = mid; else hi = mid; }
+    const uint32_t t = v - m.tstart[lo];
+    p.begin = (int64_t)m.bstart[lo] + (int64_t)t * STILE;
+    p.end = (int64_t)m.bstart[lo + 1];
+    if (p.end > p.begin + STILE) p.end = p.begin + STILE;
+    p.stride = (int64_t)(m.tstart[lo + 1] - m.tstart[lo]);
+    p.row = (int64_t)m.tstart[lo] * m.D + t;           // + d * stride
+    return p;
+}
+
+template <bool SEG>
 __global__ __launch_bounds__(ST) void k_hist(const uint64_t *__restrict__ keys, int64_t n, int shift,
-                                             uint32_t *__restrict__ table, int64_t ntiles) {
+                                             uint32_t *__restrict__ table, int64_t ntiles, SegMap sm) {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
-    int64_t base = (int64_t)blockIdx.x * STILE;
+    int64_t base = (int64_t)blockIdx.x * STILE, end = n, row = blockIdx.x, stride = ntiles;
+    unsigned mask = 255u;
+    if (SEG) {
+        const SegPos p = seg_pos(sm, blockIdx.x);
+        if (!p.ok) return;                              // (uniform)
+        base = p.begin; end = p.end; row = p.row; stride = p.stride; mask = (unsigned)sm.D - 1u;
+    }
 #pragma unroll
     for (int i = 0; i < SI; i++) {
         int64_t idx = base + (int64_t)i * ST + threadIdx.x;
-        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 255], 1u);
+        if (idx < end) atomicAdd(&h[(unsigned)(keys[idx] >> shift) & mask], 1u);
     }
     __syncthreads();
-    table[(int64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+    if (!SEG || (int)threadIdx.x < sm.D) table[(int64_t)threadIdx.x * stride + row] = h[threadIdx.x];
 }
 
+template <bool SEG>
 __global__ __launch_bounds__(ST) void k_scatter(const uint64_t *__restrict__ keys,
                                                 const uint32_t *__restrict__ vals, int64_t n, int shift,
                                                 const uint64_t *__restrict__ offs, int64_t ntiles,
                                                 uint64_t *__restrict__ okeys, uint32_t *__restrict__ ovals,
-                                                const uint32_t *__restrict__ table) {
+                                                const uint32_t *__restrict__ table, SegMap sm) {
     __shared__ volatile uint32_t wcnt[SW][256];
     __shared__ uint64_t wbase[SW][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t tbase = (int64_t)blockIdx.x * STILE, tend = n, row = blockIdx.x, stride = ntiles;
+    unsigned mask = 255u;
+    if (SEG) {
+        const SegPos p = seg_pos(sm, blockIdx.x);
+        if (!p.ok) return;                              // (uniform)
+        tbase = p.begin; tend = p.end; row = p.row; stride = p.stride; mask = (unsigned)sm.D - 1u;
+    }
     for (int i = threadIdx.x; i < SW * 256; i += ST) ((volatile uint32_t *)wcnt)[i] = 0;
     __syncthreads();
 
     // wave `wave` owns the contiguous chunk [wave*512, wave*512+512) of the tile, read in
     // 8 rounds of 64 consecutive keys: arrival order = (round, lane)
-    const int64_t cbase = (int64_t)blockIdx.x * STILE + (int64_t)wave * (64 * SI);
+    const int64_t cbase = tbase + (int64_t)wave * (64 * SI);
     uint64_t key[SI];
     uint32_t val[SI], rank[SI];
     const uint64_t lt = (1ULL << lane) - 1;
 #pragma unroll
     for (int r = 0; r < SI; r++) {
         int64_t idx = cbase + r * 64 + lane;
-        bool ok = idx < n;
+        bool ok = idx < tend;
         key[r] = ok ? keys[idx] : 0;
         val[r] = ok ? vals[idx] : 0;
-        unsigned d = (unsigned)(key[r] >> shift) & 255u;
+        unsigned d = (unsigned)(key[r] >> shift) & mask;
         uint64_t peers = __ballot(ok);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
@@ -76,7 +115,9 @@ __global__ __launch_bounds__(ST) void k_scatter(const uint64_t *__restrict__ key
     {
         const int d = threadIdx.x;                 // ST == 256 digits
         uint64_t run;
-        if (offs) {
+        if (SEG) {
+            run = d < sm.D ? offs[(int64_t)d * stride + row] : 0;
+        } else if (offs) {
             run = offs[(int64_t)d * ntiles + blockIdx.x];
         } else {
             // few tiles: every workgroup scans the [digit][tile] histogram table itself -- two launches
@@ -98,13 +139,48 @@ __global__ __launch_bounds__(ST) void k_scatter(const uint64_t *__restrict__ key
 #pragma unroll
     for (int r = 0; r < SI; r++) {
         int64_t idx = cbase + r * 64 + lane;
-        if (idx < n) {
-            unsigned d = (unsigned)(key[r] >> shift) & 255u;
+        if (idx < tend) {
+            unsigned d = (unsigned)(key[r] >> shift) & mask;
             uint64_t dst = wbase[wave][d] + rank[r];
             okeys[dst] = key[r];
             ovals[dst] = val[r];
         }
     }
+}
+
+// level-1 bucket starts from the scanned [digit][tile] table, and the virtual tiles of the second level
+__global__ __launch_bounds__(256) void k_l2_setup(const uint64_t *__restrict__ offs1, int64_t ntiles, int64_t n,
+                                                  uint32_t *__restrict__ bstart, uint32_t *__restrict__ tstart) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t bs[257];
+    bs[threadIdx.x] = (uint32_t)offs1[(int64_t)threadIdx.x * ntiles];
+    if (threadIdx.x == 0) bs[256] = (uint32_t)n;
+    __syncthreads();
+    const uint32_t size = bs[threadIdx.x + 1] - bs[threadIdx.x];
+    const uint32_t nt = (size + STILE - 1) / STILE;
+    uint32_t tot = 0;
+    const uint32_t ex = rfxd::block_exclusive_scan(nt, wsum, &tot);
+    bstart[threadIdx.x] = bs[threadIdx.x];
+    tstart[threadIdx.x] = ex;
+    if (threadIdx.x == 0) { bstart[256] = (uint32_t)n; tstart[256] = tot; }
+}
+
+// starts of the 256*D final buckets (bucket b, digit d) from the scanned level-2 table, and the largest bucket
+__global__ void k_l3_bounds(const uint64_t *__restrict__ offs2, SegMap sm, int64_t n, uint32_t *__restrict__ b3,
+                            uint32_t *__restrict__ maxc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int NB = 256 * sm.D;
+    if (i > NB) return;
+    auto start_of = [&](int q) -> uint32_t {
+        if (q >= NB) return (uint32_t)n;
+        const int b = q / sm.D, d = q - b * sm.D;
+        const int64_t stride = (int64_t)(sm.tstart[b + 1] - sm.tstart[b]);
+        if (stride == 0) return sm.bstart[b];           // empty level-1 bucket
+        return (uint32_t)offs2[(int64_t)sm.tstart[b] * sm.D + (int64_t)d * stride];
+    };
+    const uint32_t s0 = start_of(i);
+    b3[i] = s0;
+    if (i < NB) atomicMax(maxc, start_of(i + 1) - s0);
 }
 
 // One workgroup sorts up to STILE pairs entirely on chip (all passes), stable: (ikeys, ivals)[0..n) ->
@@ -119,26 +195,32 @@ __device__ __forceinline__ void sort_tile_lds(const uint64_t *keys, const uint32
     const uint64_t lt = (1ULL << lane) - 1;
     for (int i = threadIdx.x; i < n; i += ST) { sk[0][i] = keys[i]; sv[0][i] = vals[i]; }
     int cur = 0;
+    // the waves take equal contiguous chunks of the n pairs (a multiple of 64 each), so a bucket of a few hundred
+    // pairs costs a few rounds per pass, not the eight of a full tile; arrival order = (wave, round, lane)
+    const int per_wave = ((n + SW * 64 - 1) / (SW * 64)) * 64;
+    const int rounds = per_wave >> 6;
     for (int p = 0; p < passes; p++) {
         const int shift = 8 * p;
         for (int i = threadIdx.x; i < SW * 256; i += ST) ((volatile uint32_t *)wcnt)[i] = 0;
         __syncthreads();
         uint32_t rank[SI];
-        const int cbase = wave * (64 * SI);
+        const int cbase = wave * per_wave;
 #pragma unroll
         for (int r = 0; r < SI; r++) {
-            int idx = cbase + r * 64 + lane;
-            bool ok = idx < n;
-            unsigned d = ok ? (unsigned)(sk[cur][idx] >> shift) & 255u : 0u;
-            uint64_t peers = __ballot(ok);
+            if (r < rounds) {                           // (uniform)
+                int idx = cbase + r * 64 + lane;
+                bool ok = idx < n;
+                unsigned d = ok ? (unsigned)(sk[cur][idx] >> shift) & 255u : 0u;
+                uint64_t peers = __ballot(ok);
 #pragma unroll
-            for (int b = 0; b < 8; b++) {
-                uint64_t m = __ballot((d >> b) & 1u);
-                peers &= ((d >> b) & 1u) ? m : ~m;
+                for (int b = 0; b < 8; b++) {
+                    uint64_t m = __ballot((d >> b) & 1u);
+                    peers &= ((d >> b) & 1u) ? m : ~m;
+                }
+                uint32_t before = 0;
+                if (ok) { before = wcnt[wave][d]; rank[r] = before + (uint32_t)__popcll(peers & lt); }
+                if (ok && (peers & lt) == 0) wcnt[wave][d] = before + (uint32_t)__popcll(peers);
             }
-            uint32_t before = 0;
-            if (ok) { before = wcnt[wave][d]; rank[r] = before + (uint32_t)__popcll(peers & lt); }
-            if (ok && (peers & lt) == 0) wcnt[wave][d] = before + (uint32_t)__popcll(peers);
         }
         __syncthreads();
         // exclusive scan over (digit, wave): thread d sums its digit, then a block scan over digits
@@ -152,13 +234,15 @@ __device__ __forceinline__ void sort_tile_lds(const uint64_t *keys, const uint32
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < SI; r++) {
-            int idx = cbase + r * 64 + lane;
-            if (idx < n) {
-                uint64_t kk = sk[cur][idx];
-                unsigned d = (unsigned)(kk >> shift) & 255u;
-                uint32_t dst = wbase[wave][d] + rank[r];
-                sk[cur ^ 1][dst] = kk;
-                sv[cur ^ 1][dst] = sv[cur][idx];
+            if (r < rounds) {
+                int idx = cbase + r * 64 + lane;
+                if (idx < n) {
+                    uint64_t kk = sk[cur][idx];
+                    unsigned d = (unsigned)(kk >> shift) & 255u;
+                    uint32_t dst = wbase[wave][d] + rank[r];
+                    sk[cur ^ 1][dst] = kk;
+                    sv[cur ^ 1][dst] = sv[cur][idx];
+                }
             }
         }
         __syncthreads();
@@ -222,13 +306,63 @@ int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int 
     uint32_t *sv = d_vals, *dv = d_tmp_vals;
     const bool inline_scan = ntiles <= 64;           // <= 128 K pairs
     static const bool msd_off = getenv("RFX_SORT_MSD") && atoi(getenv("RFX_SORT_MSD")) == 0;
+    const SegMap nomap{nullptr, nullptr, 256};
+    if (ntiles > 192 && key_bits > 16 && n <= ((int64_t)1 << 26) && !msd_off) {
+        // Large inputs: TWO stable MSD levels (8 bits, then as many as bring a bucket to ~1000 pairs), then every
+        // final bucket is finished on chip -- ~90 B of HBM traffic per pair instead of 32 B x (key_bits / 8) LSD passes.
+        // A bucket larger than a tile (skewed keys) sends the whole thing down the LSD passes below instead, which
+        // give the same result from the partly grouped state (every level is stable).
+        const int shift1 = key_bits - 8;
+        int b2 = 1;
+        while (b2 < 8 && (n >> (8 + b2)) > 1000) b2++;
+        if (b2 > shift1) b2 = shift1;
+        const int shift2 = shift1 - b2, D2 = 1 << b2;
+        const int64_t vmax = ntiles + 256;               // upper bound of the virtual tiles
+        DevBuf table2, offs2, maps, b3;
+        RFX_HIP(table2.alloc((size_t)vmax * D2 * 4, ctx->stream));
+        RFX_HIP(offs2.alloc((size_t)(vmax * D2 + 1) * 8, ctx->stream));
+        RFX_HIP(maps.alloc(2 * 257 * 4, ctx->stream));
+        RFX_HIP(b3.alloc((size_t)(256 * D2 + 2) * 4, ctx->stream));
+        uint32_t *d_bstart = maps.as<uint32_t>(), *d_tstart = maps.as<uint32_t>() + 257;
+        uint32_t *d_maxc = b3.as<uint32_t>() + 256 * D2 + 1;
+        hipLaunchKernelGGL(k_hist<false>, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, n, shift1, table.as<uint32_t>(), ntiles, nomap);
+        RFX_HIP(hipGetLastError());
+        RFX_TRY(exclusive_scan_u32_to_u64(ctx, table.as<uint32_t>(), offs.as<uint64_t>(), ntiles * 256));
+        hipLaunchKernelGGL(k_scatter<false>, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, sv, n, shift1,
+                           (const uint64_t *)offs.as<uint64_t>(), ntiles, dk, dv, (const uint32_t *)table.as<uint32_t>(), nomap);
+        RFX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_l2_setup, dim3(1), dim3(256), 0, ctx->stream, (const uint64_t *)offs.as<uint64_t>(), ntiles, n, d_bstart, d_tstart);
+        RFX_HIP(hipGetLastError());
+        const SegMap sm{d_bstart, d_tstart, D2};
+        RFX_HIP(hipMemsetAsync(table2.p, 0, (size_t)vmax * D2 * 4, ctx->stream));
+        RFX_HIP(hipMemsetAsync(d_maxc, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_hist<true>, dim3((unsigned)vmax), dim3(ST), 0, ctx->stream, (const uint64_t *)dk, n, shift2, table2.as<uint32_t>(), vmax, sm);
+        RFX_HIP(hipGetLastError());
+        RFX_TRY(exclusive_scan_u32_to_u64(ctx, table2.as<uint32_t>(), offs2.as<uint64_t>(), vmax * D2));
+        hipLaunchKernelGGL(k_scatter<true>, dim3((unsigned)vmax), dim3(ST), 0, ctx->stream, (const uint64_t *)dk, (const uint32_t *)dv, n, shift2,
+                           (const uint64_t *)offs2.as<uint64_t>(), vmax, sk, sv, (const uint32_t *)table2.as<uint32_t>(), sm);
+        RFX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_l3_bounds, dim3((unsigned)ceil_div(256 * D2 + 1, 256)), dim3(256), 0, ctx->stream,
+                           (const uint64_t *)offs2.as<uint64_t>(), sm, n, b3.as<uint32_t>(), d_maxc);
+        RFX_HIP(hipGetLastError());
+        uint32_t maxc = 0;
+        RFX_HIP(hipMemcpyAsync(&maxc, d_maxc, 4, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        if (maxc <= (uint32_t)STILE) {
+            hipLaunchKernelGGL(k_sort_buckets, dim3((unsigned)(256 * D2)), dim3(ST), 0, ctx->stream, (const uint64_t *)sk, (const uint32_t *)sv,
+                               (const uint32_t *)b3.as<uint32_t>(), (shift2 + 7) / 8, d_keys, d_vals);
+            RFX_HIP(hipGetLastError());
+            return RFX_OK;
+        }
+        // skewed: (sk, sv) = (d_keys, d_vals) hold a stable regrouping of the input; the LSD passes finish it
+    }
     if (ntiles <= 192 && key_bits > 8 && !msd_off) {
         // top digit first; the 4-byte readback decides (a bucket larger than a tile -- skewed keys -- takes
         // the LSD passes below instead)
         const int shift = key_bits - 8;
         DevBuf bounds;
         RFX_HIP(bounds.alloc(258 * 4, ctx->stream));
-        hipLaunchKernelGGL(k_hist, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, n, shift, table.as<uint32_t>(), ntiles);
+        hipLaunchKernelGGL(k_hist<false>, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, n, shift, table.as<uint32_t>(), ntiles, nomap);
         RFX_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_bucket_bounds, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t *)table.as<uint32_t>(), ntiles,
                            bounds.as<uint32_t>(), bounds.as<uint32_t>() + 257);
@@ -238,9 +372,9 @@ int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int 
         RFX_HIP(hipStreamSynchronize(ctx->stream));
         if (maxc <= (uint32_t)STILE) {
             if (!inline_scan) RFX_TRY(exclusive_scan_u32_to_u64(ctx, table.as<uint32_t>(), offs.as<uint64_t>(), ntiles * 256));
-            hipLaunchKernelGGL(k_scatter, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, sv, n, shift,
+            hipLaunchKernelGGL(k_scatter<false>, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, sv, n, shift,
                                inline_scan ? (const uint64_t *)nullptr : (const uint64_t *)offs.as<uint64_t>(), ntiles, dk, dv,
-                               (const uint32_t *)table.as<uint32_t>());
+                               (const uint32_t *)table.as<uint32_t>(), nomap);
             RFX_HIP(hipGetLastError());
             hipLaunchKernelGGL(k_sort_buckets, dim3(256), dim3(ST), 0, ctx->stream, (const uint64_t *)dk, (const uint32_t *)dv,
                                (const uint32_t *)bounds.as<uint32_t>(), (shift + 7) / 8, d_keys, d_vals);
@@ -250,13 +384,13 @@ int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int 
     }
     for (int p = 0; p < passes; p++) {
         const int shift = 8 * p;
-        hipLaunchKernelGGL(k_hist, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, n, shift,
-                           table.as<uint32_t>(), ntiles);
+        hipLaunchKernelGGL(k_hist<false>, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, n, shift,
+                           table.as<uint32_t>(), ntiles, nomap);
         RFX_HIP(hipGetLastError());
         if (!inline_scan) RFX_TRY(exclusive_scan_u32_to_u64(ctx, table.as<uint32_t>(), offs.as<uint64_t>(), ntiles * 256));
-        hipLaunchKernelGGL(k_scatter, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, sv, n, shift,
+        hipLaunchKernelGGL(k_scatter<false>, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, sv, n, shift,
                            inline_scan ? (const uint64_t *)nullptr : (const uint64_t *)offs.as<uint64_t>(), ntiles, dk, dv,
-                           (const uint32_t *)table.as<uint32_t>());
+                           (const uint32_t *)table.as<uint32_t>(), nomap);
         RFX_HIP(hipGetLastError());
         uint64_t *tk = sk; sk = dk; dk = tk;
         uint32_t *tv = sv; sv = dv; dv = tv;

@@ -417,6 +417,37 @@ def test_sort_pairs_top_digit_path_is_stable(rfx, torch_mod):
         assert np.array_equal(dv.cpu().numpy().view(np.uint32), vals[order]), (n, bits)
 
 
+def test_sort_pairs_two_level_msd_is_stable(rfx, torch_mod):
+    """more than 400 K pairs: two stable MSD levels, then the final buckets on chip.  Spread keys with few ties, keys
+    with many ties inside a final bucket, values that are NOT the arrival index (the multi-word key sort feeds a
+    permutation), empty first-level buckets, odd key widths, and skew that sends the call down the LSD passes."""
+    torch = torch_mod
+    rng = np.random.default_rng(77)
+    cases = []
+    for n, bits in ((400_000, 60), (1_000_003, 60), (3_000_000, 62), (9_300_000, 60), (2_000_000, 64), (700_000, 17), (5_000_000, 33)):
+        cases.append((bits, rng.integers(0, 1 << min(bits, 63), n, dtype=np.uint64)))
+    # ties: only 5000 distinct keys among 2 M
+    pool = rng.integers(0, 1 << 60, 5000, dtype=np.uint64)
+    cases.append((60, pool[rng.integers(0, 5000, 2_000_000)]))
+    # empty first-level buckets: top byte only takes 3 values -> buckets far larger than a tile -> LSD fallback
+    few = (rng.integers(0, 3, 1_500_000, dtype=np.uint64) << np.uint64(52)) | rng.integers(0, 1 << 40, 1_500_000, dtype=np.uint64)
+    cases.append((60, few))
+    # half of the first-level buckets empty, the others spread
+    half = ((rng.integers(0, 128, 2_500_000, dtype=np.uint64) * np.uint64(2)) << np.uint64(52)) | rng.integers(0, 1 << 52, 2_500_000, dtype=np.uint64)
+    cases.append((60, half))
+    for bits, keys in cases:
+        n = len(keys)
+        vals = rng.permutation(n).astype(np.uint32)
+        dk = torch.from_numpy(keys.view(np.int64)).cuda(); dv = torch.from_numpy(vals.view(np.int32)).cuda()
+        tk = torch.empty_like(dk); tv = torch.empty_like(dv)
+        torch.cuda.synchronize()
+        rfx.sort_pairs_dev(dk.data_ptr(), dv.data_ptr(), n, bits, tk.data_ptr(), tv.data_ptr())
+        rfx.sync()
+        order = np.argsort(keys, kind="stable")
+        assert np.array_equal(dk.cpu().numpy().view(np.uint64), keys[order]), (n, bits)
+        assert np.array_equal(dv.cpu().numpy().view(np.uint32), vals[order]), (n, bits)
+
+
 # ------------------------------------------------ C++ host mirror of the reference driver
 
 def write_fastq(path, bases, read_off, gz=False):

@@ -65,9 +65,12 @@ __device__ __forceinline__ void resolve_at(int64_t i, const KeyW<KW> *__restrict
     int64_t s = i + 1;
 #define PUT(TYPE, A, B, L, R, LEN) do { \
         Desc d_; d_.a = (uint32_t)(A); d_.b = (uint32_t)(B); d_.left = (L); d_.right = (R); \
-        d_.type = (TYPE); d_.len = (uint32_t)(LEN); desc[o] = d_; flag[o] = 1u; \
-        onw[o] = ((uint32_t)(LEN) + 30u) / 31u; \
-        if (stage == 0 && (LEN) > 31) atomicOr(status, 1); \
+        d_.type = (TYPE); d_.len = (uint32_t)(LEN); \
+        /* single-word stage: a longer output is an error (RFX_E_STATE); it is cut to one word so that nothing is */ \
+        /* written past the one word per emission that stage reserves */ \
+        if (stage == 0 && (LEN) > 31) { atomicOr(status, 1); d_.len = 31u; } \
+        desc[o] = d_; flag[o] = 1u; \
+        onw[o] = (d_.len + 30u) / 31u; \
         o++; } while (0)
     for (; s < n && key_eq(key[s], kk); s++) {
         if (holder < 0) { holder = s; continue; }                                   // :813-814
@@ -551,7 +554,10 @@ int extend_pass(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start,
         RFX_HIP(hipGetLastError());
     }
     RFX_TRY(exclusive_scan_u32_to_u64(ctx, flag.as<uint32_t>(), oidx.as<uint64_t>(), n));
-    RFX_TRY(exclusive_scan_u32_to_u64(ctx, onw.as<uint32_t>(), owoff.as<uint64_t>(), n));
+    // single-word stage: every emission has exactly one word (a longer one is the RFX_E_STATE below), so the word
+    // offsets ARE the emission indices
+    if (stage == 0) RFX_HIP(hipMemcpyAsync(owoff.p, oidx.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    else RFX_TRY(exclusive_scan_u32_to_u64(ctx, onw.as<uint32_t>(), owoff.as<uint64_t>(), n));
     RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_emit<KW>, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream, (const Desc *)desc.as<Desc>(),
                        (const uint32_t *)flag.as<uint32_t>(), (const uint64_t *)oidx.as<uint64_t>(),
                        (const uint64_t *)owoff.as<uint64_t>(), n, d_part_start, P, sub, start_marker,

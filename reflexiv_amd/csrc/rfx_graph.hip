@@ -145,6 +145,21 @@ __global__ void k_gather_fixed(const uint32_t *__restrict__ perm, int64_t n, con
     onw[i] = (uint32_t)(ext_off[s + 1] - ext_off[s]);
 }
 
+// every record holds exactly one extension word (the single-word stages): fixed fields and that word in one go, the
+// output offsets are the identity -- no scan of word counts, no second gather
+__global__ void k_gather_single(const uint32_t *__restrict__ perm, int64_t n, const int32_t *__restrict__ marker,
+                                const int32_t *__restrict__ left, const int32_t *__restrict__ right,
+                                const uint64_t *__restrict__ ext, int32_t *__restrict__ omarker,
+                                int32_t *__restrict__ oleft, int32_t *__restrict__ oright,
+                                int64_t *__restrict__ oext_off, uint64_t *__restrict__ oext) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    oext_off[i] = i;
+    if (i == n) return;
+    uint32_t s = perm[i];
+    omarker[i] = marker[s]; oleft[i] = left[s]; oright[i] = right[s]; oext[i] = ext[s];
+}
+
 constexpr int SHORT_WORDS = 8;
 
 // copy extension words record by record; records longer than SHORT_WORDS are queued as chunks of
@@ -521,6 +536,19 @@ int sort_records(rfx_ctx *ctx, const DevRecords &in, int P, int key_bits, DevRec
                                              (const KeyW<KW> *)in.key.as<KeyW<KW>>(), (const uint32_t *)perm.as<uint32_t>(), n,
                                              out.key.as<KeyW<KW>>()));
         RFX_HIP(hipGetLastError());
+    }
+    if (in.words == n) {
+        // (ext_off is the identity on both sides)
+        hipLaunchKernelGGL(k_gather_single, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream, (const uint32_t *)perm.as<uint32_t>(), n,
+                           (const int32_t *)in.marker.as<int32_t>(), (const int32_t *)in.left.as<int32_t>(),
+                           (const int32_t *)in.right.as<int32_t>(), (const uint64_t *)in.ext.as<uint64_t>(), out.marker.as<int32_t>(),
+                           out.left.as<int32_t>(), out.right.as<int32_t>(), out.ext_off.as<int64_t>(), out.ext.as<uint64_t>());
+        RFX_HIP(hipGetLastError());
+        RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_partition_starts<KW>, dim3(grid_for(P + 1)), dim3(256), 0, ctx->stream,
+                                             (const KeyW<KW> *)out.key.as<KeyW<KW>>(), n, P, part_start.as<int64_t>()));
+        RFX_HIP(hipGetLastError());
+        out.n = n; out.words = in.words;
+        return RFX_OK;
     }
     if (n > 0) {
         hipLaunchKernelGGL(k_gather_fixed, dim3(grid_for(n)), dim3(256), 0, ctx->stream,

@@ -185,22 +185,35 @@ __global__ void k_l3_bounds(const uint64_t *__restrict__ offs2, SegMap sm, int64
 
 // One workgroup sorts up to STILE pairs entirely on chip (all passes), stable: (ikeys, ivals)[0..n) ->
 // (okeys, ovals)[0..n), in place when they are the same arrays.
-__device__ __forceinline__ void sort_tile_lds(const uint64_t *keys, const uint32_t *vals, int n, int passes,
+// `bits` = low key bits that are still unsorted (the bits above them are equal over the whole tile or do not exist).
+// First try: ONE stable pass on the top 8 of those bits, then thread d finishes sub-bucket d (a couple of pairs when the
+// keys are spread) by a stable insertion sort on the whole key -- 4 barriers instead of 4 per 8 bits.  A sub-bucket
+// longer than MSD_INS pairs (keys that share long prefixes: repeats) sends the tile down the LSD passes instead.
+constexpr int MSD_INS = 24;
+__device__ __forceinline__ void sort_tile_lds(const uint64_t *keys, const uint32_t *vals, int n, int bits,
                                               uint64_t *okeys, uint32_t *ovals) {
     __shared__ uint64_t sk[2][STILE];
     __shared__ uint32_t sv[2][STILE];
     __shared__ volatile uint32_t wcnt[SW][256];
     __shared__ uint32_t wbase[SW][256];
+    __shared__ uint32_t dstart[257];
+    __shared__ int too_long;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t lt = (1ULL << lane) - 1;
     for (int i = threadIdx.x; i < n; i += ST) { sk[0][i] = keys[i]; sv[0][i] = vals[i]; }
+    if (threadIdx.x == 0) too_long = 0;
     int cur = 0;
     // the waves take equal contiguous chunks of the n pairs (a multiple of 64 each), so a bucket of a few hundred
     // pairs costs a few rounds per pass, not the eight of a full tile; arrival order = (wave, round, lane)
     const int per_wave = ((n + SW * 64 - 1) / (SW * 64)) * 64;
     const int rounds = per_wave >> 6;
-    for (int p = 0; p < passes; p++) {
-        const int shift = 8 * p;
+    const int passes = (bits + 7) / 8;
+    const int msd_shift = bits > 8 ? bits - 8 : 0;
+    for (int p = -1; p < passes; p++) {
+        // p = -1: the MSD attempt (reads sk[0], writes sk[1]); p >= 0: the LSD passes, restarted from sk[0]
+        const int shift = p < 0 ? msd_shift : 8 * p;
+        const unsigned dmask = (p < 0 && bits < 8) ? ((1u << bits) - 1u) : 255u;
+        if (p == 0) cur = 0;
         for (int i = threadIdx.x; i < SW * 256; i += ST) ((volatile uint32_t *)wcnt)[i] = 0;
         __syncthreads();
         uint32_t rank[SI];
@@ -210,7 +223,7 @@ __device__ __forceinline__ void sort_tile_lds(const uint64_t *keys, const uint32
             if (r < rounds) {                           // (uniform)
                 int idx = cbase + r * 64 + lane;
                 bool ok = idx < n;
-                unsigned d = ok ? (unsigned)(sk[cur][idx] >> shift) & 255u : 0u;
+                unsigned d = ok ? (unsigned)(sk[cur][idx] >> shift) & dmask : 0u;
                 uint64_t peers = __ballot(ok);
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
@@ -229,6 +242,7 @@ __device__ __forceinline__ void sort_tile_lds(const uint64_t *keys, const uint32
         for (int w = 0; w < SW; w++) tot += wcnt[w][threadIdx.x];
         __shared__ uint32_t wsum[SW];
         uint32_t dbase = rfxd::block_exclusive_scan(tot, wsum, nullptr);
+        if (p < 0) { dstart[threadIdx.x] = dbase; if (threadIdx.x == 255) dstart[256] = dbase + tot; }
 #pragma unroll
         for (int w = 0; w < SW; w++) { wbase[w][threadIdx.x] = dbase; dbase += wcnt[w][threadIdx.x]; }
         __syncthreads();
@@ -238,7 +252,7 @@ __device__ __forceinline__ void sort_tile_lds(const uint64_t *keys, const uint32
                 int idx = cbase + r * 64 + lane;
                 if (idx < n) {
                     uint64_t kk = sk[cur][idx];
-                    unsigned d = (unsigned)(kk >> shift) & 255u;
+                    unsigned d = (unsigned)(kk >> shift) & dmask;
                     uint32_t dst = wbase[wave][d] + rank[r];
                     sk[cur ^ 1][dst] = kk;
                     sv[cur ^ 1][dst] = sv[cur][idx];
@@ -247,12 +261,29 @@ __device__ __forceinline__ void sort_tile_lds(const uint64_t *keys, const uint32
         }
         __syncthreads();
         cur ^= 1;
+        if (p < 0) {
+            // sub-bucket d = [dstart[d], dstart[d+1]) of sk[1]; finish it, or give up
+            const uint32_t b = dstart[threadIdx.x], e = dstart[threadIdx.x + 1];
+            if (e - b > (uint32_t)MSD_INS) too_long = 1;
+            __syncthreads();
+            if (!too_long) {
+                for (uint32_t i = b + 1; i < e; i++) {
+                    const uint64_t x = sk[1][i];
+                    const uint32_t xv = sv[1][i];
+                    uint32_t j = i;
+                    while (j > b && sk[1][j - 1] > x) { sk[1][j] = sk[1][j - 1]; sv[1][j] = sv[1][j - 1]; j--; }
+                    sk[1][j] = x; sv[1][j] = xv;
+                }
+                __syncthreads();
+                break;                                  // (uniform) sorted in sk[1]: cur == 1
+            }
+        }
     }
     for (int i = threadIdx.x; i < n; i += ST) { okeys[i] = sk[cur][i]; ovals[i] = sv[cur][i]; }
 }
 
-__global__ __launch_bounds__(ST) void k_sort_small(uint64_t *keys, uint32_t *vals, int n, int passes) {
-    sort_tile_lds(keys, vals, n, passes, keys, vals);
+__global__ __launch_bounds__(ST) void k_sort_small(uint64_t *keys, uint32_t *vals, int n, int bits) {
+    sort_tile_lds(keys, vals, n, bits, keys, vals);
 }
 
 // ---- mid-size inputs (a few tiles .. ~400 K pairs): ONE global pass on the TOP digit, then every digit's
@@ -276,11 +307,11 @@ __global__ __launch_bounds__(256) void k_bucket_bounds(const uint32_t *__restric
 }
 
 __global__ __launch_bounds__(ST) void k_sort_buckets(const uint64_t *__restrict__ ikeys, const uint32_t *__restrict__ ivals,
-                                                     const uint32_t *__restrict__ bstart, int passes,
+                                                     const uint32_t *__restrict__ bstart, int bits,
                                                      uint64_t *__restrict__ okeys, uint32_t *__restrict__ ovals) {
     const uint32_t b = bstart[blockIdx.x], e = bstart[blockIdx.x + 1];
     if (e <= b) return;                              // (uniform)
-    sort_tile_lds(ikeys + b, ivals + b, (int)(e - b), passes, okeys + b, ovals + b);
+    sort_tile_lds(ikeys + b, ivals + b, (int)(e - b), bits, okeys + b, ovals + b);
 }
 
 }  // namespace
@@ -294,7 +325,7 @@ int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int 
     if (key_bits > 64) key_bits = 64;
     const int passes = (key_bits + 7) / 8;
     if (n <= STILE) {
-        hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(ST), 0, ctx->stream, d_keys, d_vals, (int)n, passes);
+        hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(ST), 0, ctx->stream, d_keys, d_vals, (int)n, key_bits);
         RFX_HIP(hipGetLastError());
         return RFX_OK;
     }
@@ -350,7 +381,7 @@ int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int 
         RFX_HIP(hipStreamSynchronize(ctx->stream));
         if (maxc <= (uint32_t)STILE) {
             hipLaunchKernelGGL(k_sort_buckets, dim3((unsigned)(256 * D2)), dim3(ST), 0, ctx->stream, (const uint64_t *)sk, (const uint32_t *)sv,
-                               (const uint32_t *)b3.as<uint32_t>(), (shift2 + 7) / 8, d_keys, d_vals);
+                               (const uint32_t *)b3.as<uint32_t>(), shift2, d_keys, d_vals);
             RFX_HIP(hipGetLastError());
             return RFX_OK;
         }
@@ -377,7 +408,7 @@ int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int 
                                (const uint32_t *)table.as<uint32_t>(), nomap);
             RFX_HIP(hipGetLastError());
             hipLaunchKernelGGL(k_sort_buckets, dim3(256), dim3(ST), 0, ctx->stream, (const uint64_t *)dk, (const uint32_t *)dv,
-                               (const uint32_t *)bounds.as<uint32_t>(), (shift + 7) / 8, d_keys, d_vals);
+                               (const uint32_t *)bounds.as<uint32_t>(), shift, d_keys, d_vals);
             RFX_HIP(hipGetLastError());
             return RFX_OK;
         }

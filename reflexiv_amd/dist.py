@@ -293,6 +293,14 @@ def _alltoallv(send: torch.Tensor, send_counts, group=None, async_op: bool = Fal
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
         rounds = max(1, -(-int(mx.item()) // limit))
     need = sum(recv_counts)
+    if world == 1:
+        # one rank (the rehearsal of the multi-GPU branch on a single GPU): the only bucket is this rank's own, which on
+        # N ranks is the 1/N that never crosses a link -- hand it over as it is (or by one device copy into the caller's
+        # buffer) instead of through RCCL's self-copy, which moves it at a sixth of the HBM rate
+        if out is None or out.numel() < need:
+            return send[:need], []
+        out[:need].copy_(send[:need])
+        return out[:need], []
     # `out` (optional): a caller-owned buffer whose head receives the data when it is large enough
     recv = out[:need] if out is not None and out.numel() >= need else torch.empty(need, dtype=send.dtype, device=send.device)
     if rounds == 1:

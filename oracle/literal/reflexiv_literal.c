@@ -1,0 +1,177 @@
+/*
+ * reflexiv_literal.c -- the reference's OWN bit arithmetic for the flips and merges of the single-word
+ * and first-array extend stages (k <= 31), written out statement by statement from
+ *   P/ReflexivDSMain.java:3153-3226 (DSExtendReflexivKmer.singleKmerRandomizer)
+ *   P/ReflexivDSMain.java:3241-3325 (DSExtendReflexivKmer.reflexivExtend)
+ *   P/ReflexivDSMain.java:2702-2810 (DSExtendReflexivKmerToArrayFirstTime.singleKmerRandomizer)
+ *   P/ReflexivDSMain.java:2830-2967 (DSExtendReflexivKmerToArrayFirstTime.reflexivExtend)
+ * with Java's integer semantics (64-bit two's complement, shift counts taken mod 64, >>> logical,
+ * Long.numberOfLeadingZeros(0) = 64).  P = src/main/java/uni/bielefeld/cmg/reflexiv/pipeline.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Purpose: the oracle restates flips and
+ * merges at SEQUENCE level (unpack, concatenate, repack); this file is the mechanical counterpart, so that
+ * tests/test_oracle_literal.py can fuzz one against the other -- a pin of the sequence model to the reference's
+ * bit code that does not go through anybody's reading of what the code "means".  The array-loop stage
+ * (P/ReflexivDSMain.java:1894-2514, ~620 lines of word shuffling) is NOT transliterated here; SURVEY.md C.9
+ * records the survey's own fuzz of it.
+ */
+#include <stdint.h>
+
+typedef int64_t jlong;
+static inline jlong jshl(jlong a, int n) { return (jlong)((uint64_t)a << (n & 63)); }
+static inline jlong jushr(jlong a, int n) { return (jlong)((uint64_t)a >> (n & 63)); }
+static inline int jnlz(jlong a) { return a ? __builtin_clzll((uint64_t)a) : 64; }
+
+typedef struct {
+    jlong key; int32_t marker; jlong ext[2]; int32_t n_ext; int32_t left, right;
+} lit_rec;
+
+/* maxSubKmerBinary = ~((~0L) << 2*param.subKmerSize)  (:3026);  maxBlockBinary = ~((~0L) << 2*31)  (:2575) */
+static inline jlong max_sub(int sub) { return ~jshl(~(jlong)0, 2 * sub); }
+static inline jlong max_block(void) { return ~jshl(~(jlong)0, 2 * 31); }
+
+/* DSExtendReflexivKmer.singleKmerRandomizer :3153-3226; m = randomReflexivMarker on entry.
+ * Returns 0, or -1 where the reference prints "what? not possible" (and emits zeros). */
+int lit_flip_single(const lit_rec *cur, int m, int sub, lit_rec *out) {
+    int bad = 0;
+    if (cur->marker == 1) {                                                                  /* :3156 */
+        int currentSuffixLength = 64 / 2 - (jnlz(cur->ext[0]) / 2 + 1);                      /* :3157 */
+        jlong maxSuffixLengthBinary = ~jshl(~(jlong)0, 2 * currentSuffixLength);             /* :3158 */
+        jlong newReflexivSubKmer = 0, newReflexivLong = 0;
+        if (m == 2) {                                                                        /* :3162 */
+            if (currentSuffixLength >= sub) bad = -1;                                        /* :3163-3168 */
+            else {
+                newReflexivSubKmer = jshl(cur->key, currentSuffixLength * 2);                /* :3170 */
+                newReflexivSubKmer &= max_sub(sub);                                          /* :3171 */
+                newReflexivSubKmer |= (cur->ext[0] & maxSuffixLengthBinary);                 /* :3172 */
+                newReflexivLong = jushr(cur->key, 2 * (sub - currentSuffixLength));          /* :3175 */
+                newReflexivLong |= jshl(1, 2 * currentSuffixLength);                         /* :3176 */
+            }
+            out->key = newReflexivSubKmer; out->marker = m; out->ext[0] = newReflexivLong; out->n_ext = 1;   /* :3181-3183 */
+            out->left = cur->left; out->right = cur->right;
+        } else { *out = *cur; out->n_ext = 1; }                                              /* :3185 */
+    } else {                                                                                 /* :3187 */
+        int currentPrefixLength = 64 / 2 - (jnlz(cur->ext[0]) / 2 + 1);                      /* :3188 */
+        jlong maxSuffixLengthBinary = ~jshl(~(jlong)0, 2 * currentPrefixLength);             /* :3189 */
+        jlong newReflexivSubKmer = 0, newReflexivLong = 0;
+        if (m == 2) { *out = *cur; out->n_ext = 1; }                                         /* :3192-3193 */
+        else {
+            if (currentPrefixLength >= sub) bad = -1;                                        /* :3195-3200 */
+            else {
+                newReflexivSubKmer = jshl(cur->ext[0] & maxSuffixLengthBinary, 2 * (sub - currentPrefixLength));   /* :3202 */
+                newReflexivSubKmer |= jushr(cur->key, 2 * currentPrefixLength);              /* :3204 */
+                newReflexivLong = cur->key & maxSuffixLengthBinary;                          /* :3206 */
+                newReflexivLong |= jshl(1, 2 * currentPrefixLength);                         /* :3207 */
+            }
+            out->key = newReflexivSubKmer; out->marker = m; out->ext[0] = newReflexivLong; out->n_ext = 1;   /* :3210-3212 */
+            out->left = cur->left; out->right = cur->right;
+        }
+    }
+    return bad;
+}
+
+/* left / right of a merged record: :3272-3288 (and :3308-3324, :2880-2900, :2946-2966) */
+static void merged_ends(const lit_rec *f, const lit_rec *r, int bubbleDistance, lit_rec *out) {
+    if (bubbleDistance < 0) { out->left = r->left; out->right = f->right; }
+    else if (f->left > 0) { out->left = bubbleDistance; out->right = f->right; }
+    else { out->left = r->left; out->right = bubbleDistance; }
+}
+
+/* DSExtendReflexivKmer.reflexivExtend :3241-3325 */
+int lit_merge_single(const lit_rec *f, const lit_rec *r, int bubbleDistance, int m, int sub, lit_rec *out) {
+    int bad = 0;
+    int forwardSuffixLength = 64 / 2 - (jnlz(f->ext[0]) / 2 + 1);                            /* :3246 */
+    int reflexedPrefixLength = 64 / 2 - (jnlz(r->ext[0]) / 2 + 1);                           /* :3247 */
+    jlong maxSuffixLengthBinary = ~jshl(~(jlong)0, 2 * forwardSuffixLength);                 /* :3248 */
+    jlong maxPrefixLengthBinary = ~jshl(~(jlong)0, 2 * reflexedPrefixLength);                /* :3249 */
+    if (m == 2) {                                                                            /* :3252 */
+        jlong newReflexivSubKmer = 0, newReflexivLong = 0;
+        if (forwardSuffixLength >= sub) bad = -1;                                            /* :3256-3259 */
+        else {
+            newReflexivSubKmer = jshl(f->key, 2 * forwardSuffixLength);                      /* :3261 */
+            newReflexivSubKmer &= max_sub(sub);                                              /* :3262 */
+            newReflexivSubKmer |= (f->ext[0] & maxSuffixLengthBinary);                       /* :3263 */
+            newReflexivLong = jshl(r->ext[0], 2 * forwardSuffixLength);                      /* :3265 */
+            newReflexivLong |= jushr(f->key, 2 * (sub - forwardSuffixLength));               /* :3266 */
+        }
+        out->key = newReflexivSubKmer; out->marker = 2; out->ext[0] = newReflexivLong; out->n_ext = 1;
+    } else {                                                                                 /* :3291 */
+        jlong newForwardSubKmer = 0, newForwardLong = 0;
+        if (reflexedPrefixLength >= sub) bad = -1;                                           /* :3295-3298 */
+        else {
+            newForwardSubKmer = jshl(r->ext[0] & maxPrefixLengthBinary, 2 * (sub - reflexedPrefixLength));   /* :3300 */
+            newForwardSubKmer |= jushr(r->key, 2 * reflexedPrefixLength);                    /* :3301 */
+            newForwardLong = r->key & maxPrefixLengthBinary;                                 /* :3303 */
+            newForwardLong |= jshl(1, 2 * reflexedPrefixLength);                             /* :3304 */
+            newForwardLong = jshl(newForwardLong, 2 * forwardSuffixLength);                  /* :3305 */
+            newForwardLong |= (f->ext[0] & maxSuffixLengthBinary);                           /* :3306 */
+        }
+        out->key = newForwardSubKmer; out->marker = 1; out->ext[0] = newForwardLong; out->n_ext = 1;
+    }
+    merged_ends(f, r, bubbleDistance, out);
+    return bad;
+}
+
+/* DSExtendReflexivKmerToArrayFirstTime.singleKmerRandomizer :2702-2810: the same flips, output as a one-element array */
+int lit_flip_first(const lit_rec *cur, int m, int sub, lit_rec *out) {
+    return lit_flip_single(cur, m, sub, out);        /* :2717-2727 = :3170-3176, :2771-2781 = :3202-3207 word for word */
+}
+
+/* DSExtendReflexivKmerToArrayFirstTime.reflexivExtend :2830-2967 */
+int lit_merge_first(const lit_rec *f, const lit_rec *r, int bubbleDistance, int m, int sub, lit_rec *out) {
+    int bad = 0;
+    int forwardSuffixLength = 64 / 2 - (jnlz(f->ext[0]) / 2 + 1);                            /* :2835 */
+    int reflexedPrefixLength = 64 / 2 - (jnlz(r->ext[0]) / 2 + 1);                           /* :2836 */
+    int concatenateLength = forwardSuffixLength + reflexedPrefixLength;                      /* :2837 */
+    jlong maxSuffixLengthBinary = ~jshl(~(jlong)0, 2 * forwardSuffixLength);                 /* :2838 */
+    jlong maxPrefixLengthBinary = ~jshl(~(jlong)0, 2 * reflexedPrefixLength);                /* :2839 */
+    out->ext[0] = out->ext[1] = 0; out->n_ext = 1;
+    if (m == 2) {                                                                            /* :2842 */
+        jlong newReflexivSubKmer = 0, newReflexivLong = 0;
+        if (forwardSuffixLength >= sub) bad = -1;                                            /* :2847-2852 */
+        else {
+            newReflexivSubKmer = jshl(f->key, 2 * forwardSuffixLength);                      /* :2855 */
+            newReflexivSubKmer &= max_sub(sub);                                              /* :2856 */
+            newReflexivSubKmer |= (f->ext[0] & maxSuffixLengthBinary);                       /* :2857 */
+            if (concatenateLength > 31) {                                                    /* :2858 */
+                jlong newReflexivLonghead = jushr(r->ext[0], 2 * (31 - forwardSuffixLength));    /* :2859 */
+                newReflexivLong = jshl(r->ext[0], 2 * forwardSuffixLength);                  /* :2860 */
+                newReflexivLong &= max_block();                                              /* :2861 */
+                newReflexivLong |= jushr(f->key, 2 * (sub - forwardSuffixLength));           /* :2862 */
+                out->n_ext = concatenateLength / 31 + 1;                                     /* :2864 */
+                out->ext[0] = newReflexivLonghead; out->ext[1] = newReflexivLong;            /* :2865-2866 */
+            } else {
+                newReflexivLong = jshl(r->ext[0], 2 * forwardSuffixLength);                  /* :2868 */
+                newReflexivLong |= jushr(f->key, 2 * (sub - forwardSuffixLength));           /* :2869 */
+                out->ext[0] = newReflexivLong;                                               /* :2872-2873 */
+            }
+        }
+        out->key = newReflexivSubKmer; out->marker = 2;
+    } else {                                                                                 /* :2902 */
+        jlong newForwardSubKmer = 0, newForwardLong = 0;
+        if (reflexedPrefixLength >= sub) bad = -1;                                           /* :2907-2912 */
+        else {
+            newForwardSubKmer = jshl(r->ext[0] & maxPrefixLengthBinary, 2 * (sub - reflexedPrefixLength));   /* :2914 */
+            newForwardSubKmer |= jushr(r->key, 2 * reflexedPrefixLength);                    /* :2915 */
+            if (concatenateLength > 31) {                                                    /* :2917 */
+                jlong newForwardLonghead = f->key & maxPrefixLengthBinary;                   /* :2918 */
+                newForwardLonghead = jushr(newForwardLonghead, 2 * (31 - forwardSuffixLength));  /* :2919 */
+                newForwardLonghead |= jshl(1, 2 * (concatenateLength - 31));                 /* :2920 */
+                newForwardLong = jshl(f->key, 2 * forwardSuffixLength);                      /* :2922 */
+                newForwardLong |= (f->ext[0] & maxSuffixLengthBinary);                       /* :2923 */
+                newForwardLong &= max_block();                                               /* :2924 */
+                out->n_ext = concatenateLength / 31 + 1;                                     /* :2926 */
+                out->ext[0] = newForwardLonghead; out->ext[1] = newForwardLong;              /* :2927-2928 */
+            } else {
+                newForwardLong = r->key & maxPrefixLengthBinary;                             /* :2930 */
+                newForwardLong |= jshl(1, 2 * reflexedPrefixLength);                         /* :2931 */
+                newForwardLong = jshl(newForwardLong, 2 * forwardSuffixLength);              /* :2932 */
+                newForwardLong |= (f->ext[0] & maxSuffixLengthBinary);                       /* :2933 */
+                out->ext[0] = newForwardLong;                                                /* :2936-2937 */
+            }
+        }
+        out->key = newForwardSubKmer; out->marker = 1;
+    }
+    merged_ends(f, r, bubbleDistance, out);
+    return bad;
+}

@@ -185,8 +185,9 @@ def extend_pass(recs, starts, sub, rdd=False, start_marker=2):
     return out, ostarts
 
 
-def assemble(kmers, counts, k=31, P=4, min_err=8, min_iter=15, max_iter=150, ds=True, trace=None):
+def assemble(kmers, counts, k=31, P=4, min_err=8, min_iter=15, max_iter=150, ds=True, trace=None, coalesce=False):
     sub = k - 1
+    part = [P]                      # the loop below may coalesce it (P/ReflexivMain.java:277-281)
     recs = stable_sort(rc_expand(kmers, counts, k))
     recs, _ = fork_forward(recs, partition_starts([r[0] for r in recs], P), sub, min_err, ds)
     recs = stable_sort(reflect(recs))
@@ -195,7 +196,7 @@ def assemble(kmers, counts, k=31, P=4, min_err=8, min_iter=15, max_iter=150, ds=
 
     def one_pass(recs):
         recs = stable_sort(recs)
-        out, _ = extend_pass(recs, partition_starts([r[0] for r in recs], P), sub, rdd=not ds)
+        out, _ = extend_pass(recs, partition_starts([r[0] for r in recs], part[0]), sub, rdd=not ds)
         if trace is not None:
             trace.append(len(out))
         return out
@@ -207,12 +208,16 @@ def assemble(kmers, counts, k=31, P=4, min_err=8, min_iter=15, max_iter=150, ds=
     it += 1
     recs = one_pass(recs)
     last = 0
+    partition_number = P
     while it <= max_iter:
         it += 1
         if it >= min_iter and it % 3 == 0:
             if last == len(recs):
                 break
             last = len(recs)
+            if coalesce and partition_number >= 16 and len(recs) // partition_number <= 20:
+                partition_number = partition_number // 4 + 1
+                part[0] = partition_number
         recs = one_pass(recs)
     return recs
 

@@ -239,6 +239,18 @@ def test_assemble_example_matches_golden(rfx, torch_mod, ex, P, tn):
     assert trace == [int(x) for x in ex[f"trace_{tn}_P{P}"]]
 
 
+@pytest.mark.parametrize("P", [16, 64, 200])
+def test_assemble_with_the_coalesce_rule(rfx, torch_mod, ex, planted, P):
+    """rfx_params.coalesce (P/ReflexivMain.java:277-281): the partition number drops to P/4+1 at a check that finds
+    <= 20 records per partition; both the big-pass loop and the small-pass kernel carry it"""
+    import reflexiv_amd
+    for keys, counts, cov, mc in ((ex["keys_cov3"], ex["counts_cov3"], 3, 500), (planted["k31_keys"], planted["k31_counts"], 2, 100)):
+        prm = reflexiv_amd.default_params(min_cov=cov, partitions=P, coalesce=1, min_contig=mc)
+        text, nc, trace = dev_assemble(rfx, torch_mod, keys, counts, prm)
+        otext, onc, otrace, _ = O.assemble_from_counts(keys, counts, O.default_params(min_cov=cov, partitions=P, coalesce=1, min_contig=mc))
+        assert trace == otrace and (text, nc) == (otext, onc)
+
+
 def test_documented_known_answer_on_gpu(rfx, torch_mod, ex):
     """docs/example.html:303,320-343 end to end on the GPU: reads -> k-mers -> contigs."""
     import reflexiv_amd

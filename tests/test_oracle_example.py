@@ -222,3 +222,23 @@ def test_counter_line_filter_only_seq():
             o1, l1 = O.fastq_only_seq(t)
             o2, l2 = O.fastq_group(t)
             assert np.array_equal(o1, o2) and np.array_equal(l1, l2)
+
+
+@pytest.mark.parametrize("P", [16, 64, 200])
+def test_coalesce_rule_matches_string_model(ex, P):
+    """P/ReflexivMain.java:277-281: from 16 partitions on, a check that finds <= 20 records per partition cuts the
+    partition number to P/4+1 -- which moves every logical partition boundary of the later passes"""
+    from tests import pymodel as M
+    keys, counts = ex["keys_cov3"], ex["counts_cov3"]
+    for coalesce in (0, 1):
+        prm = O.default_params(min_cov=3, partitions=P, coalesce=coalesce, min_contig=100)
+        text, nc, trace, rec = O.assemble_from_counts(keys, counts, prm)
+        wtrace = []
+        want = M.assemble([int(x) for x in keys], [int(c) for c in counts], 31, P, 8, 15, 150, True, wtrace, bool(coalesce))
+        assert trace == wtrace, coalesce
+        got = [(M.decode_kmer(int(rec.key[i]), 30), int(rec.marker[i])) for i in range(rec.n)]
+        assert got == [(r[0], r[1]) for r in want]
+    # the rule really fires on this input: the traces with and without it differ
+    t0 = O.assemble_from_counts(keys, counts, O.default_params(min_cov=3, partitions=P, coalesce=0))[2]
+    t1 = O.assemble_from_counts(keys, counts, O.default_params(min_cov=3, partitions=P, coalesce=1))[2]
+    assert t0 != t1 or P == 16

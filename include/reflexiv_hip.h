@@ -63,6 +63,9 @@ typedef struct {
     int32_t partitions;      /* logical partitions P of the order contract */
     int32_t twin;            /* RFX_TWIN_DS / RFX_TWIN_RDD                      */
     int32_t coalesce;        /* apply P/ReflexivMain.java:277-281               */
+    int32_t extras;          /* k > 31 only (rfx_dev_assemble_w): the from-counts extras of P/ReflexivDSMain64.java:584-619,
+                              * 672-712 -- orientation doubling, extendable / unextendable split, end filters.  Default 1
+                              * (the reference's driver always runs them); 0 iterates every record to the end. */
 } rfx_params;
 
 /* Flat record set.  n and the pointers are filled by the caller on input; on output the
@@ -192,6 +195,26 @@ int rfx_extend_pass(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_sta
  * emission marker starts at 1 instead of 2 once scramble == 3).  Any k the record operators take. */
 int rfx_extend_pass_w(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P, int k, int stage,
                       int scramble, rfx_records *out, int64_t *out_part_start);
+
+/* The operator classes of the k > 31 from-counts extras (P/ReflexivDSMain64.java:584-619, 672-712), one `op` each, on
+ * records sorted by key with their partition starts (any k the record operators take):
+ *   RFX_OP_DOUBLE            DSReflexivAndForwardKmer :2126-3042: every record, then its other orientation (out: 2n
+ *                            records, 2 x words; out_part_start = 2 x part_start)
+ *   RFX_OP_EXTENDABLE_PAIRS  DSFilterExtendableKmerPairs :5305-6375: both members of every (forward, reflected) pair on
+ *                            one key that the extend pass would merge, both as forward records; a task's last holder too
+ *   RFX_OP_UNEXTENDABLE      DSFilterUnExtendableKmer :6377-7444: the rest (reflected holders come out forward)
+ *   RFX_OP_FIRST_OF_KEY      DSFilterStillExtendableKmerFromPairs :3228-3390: of two records on one key the first
+ *   RFX_OP_LONGER_OF_KEY     DSFilterStillExtendableKmerEnds :3044-3226: ... the one with the larger length*31+first word
+ *   RFX_OP_ALL_FORWARD / RFX_OP_ALL_REFLECTED   DSFilterUnExtendableKmerLeftEnds :3392-4347 / ...RightEnds :4349-5303 */
+#define RFX_OP_DOUBLE           0
+#define RFX_OP_EXTENDABLE_PAIRS 1
+#define RFX_OP_UNEXTENDABLE     2
+#define RFX_OP_FIRST_OF_KEY     3
+#define RFX_OP_LONGER_OF_KEY    4
+#define RFX_OP_ALL_FORWARD      5
+#define RFX_OP_ALL_REFLECTED    6
+int rfx_extras_operator(rfx_ctx *ctx, int op, const rfx_records *in, const int64_t *part_start, int P, int k,
+                        rfx_records *out, int64_t *out_part_start);
 
 /* BinaryReflexivKmerArrayToString + KmerToContig + TagContigID
  * P/ReflexivMain.java:696-741, 590-637, 573-581 (DS :855-900, :743-795, :717-725):
@@ -336,10 +359,12 @@ int rfx_dev_counter_to_asm(rfx_ctx *ctx, const uint64_t *d_keys32, const int64_t
                            int min_cov, int max_cov, uint64_t *d_out_kmers, int32_t *d_out_counts, int64_t *out_n);
 
 /* Whole k > 31 driver ReflexivDSMain64.assemblyFromKmer (P/ReflexivDSMain64.java:458-826) from the filtered, ascending
- * (k-mer, count) list in HBM (assembler layout) to the contig text, WITHOUT the from-counts extras of :584-619 and
- * :672-712 (orientation doubling, extendable / unextendable split, end filters): the loop of
- * :621-661 iterates all records.  Stop rule as there: checked from minimumIteration + 3 on, the first repeat of the
- * count sets param.scramble = 3 (later passes start their emission marker at 1), the second stops. */
+ * (k-mer, count) list in HBM (assembler layout) to the contig text.  prm->extras = 1 (default): at iteration
+ * minimumIteration + 3 the records are doubled into both orientations and split into the members of mergeable pairs
+ * and the rest (:584-619), only the first set is iterated further (:621-661), and after the loop the two are united and
+ * records that share an end with a longer one are dropped (:672-712).  prm->extras = 0: the loop iterates all records.
+ * Stop rule: checked from minimumIteration + 3 on, the first repeat of the count sets param.scramble = 3 (later passes
+ * start their emission marker at 1), the second stops. */
 int rfx_dev_assemble_w(rfx_ctx *ctx, const uint64_t *d_kmers, const int32_t *d_counts, int64_t n,
                        const rfx_params *prm, char *out, int64_t cap, int64_t *out_len,
                        int64_t *out_contigs, int64_t *trace, int64_t trace_cap, int64_t *n_trace);

@@ -21,9 +21,13 @@ public final class Rfx {
     public static final int TWIN_DS = 0;            // arithmetic of pipeline/ReflexivDSMain.java
     public static final int TWIN_RDD = 1;           // arithmetic of pipeline/ReflexivMain.java
 
-    /** index of each field in the int[12] parameter block (rfx_params, include/reflexiv_hip.h) */
+    /** index of each field in the int[13] parameter block (rfx_params, include/reflexiv_hip.h) */
     public static final int P_K = 0, P_MIN_COV = 1, P_MAX_COV = 2, P_MIN_ERROR_COV = 3, P_MIN_CONTIG = 4, P_MIN_ITER = 5,
-            P_MAX_ITER = 6, P_FRONT_CLIP = 7, P_END_CLIP = 8, P_PARTITIONS = 9, P_TWIN = 10, P_COALESCE = 11;
+            P_MAX_ITER = 6, P_FRONT_CLIP = 7, P_END_CLIP = 8, P_PARTITIONS = 9, P_TWIN = 10, P_COALESCE = 11, P_EXTRAS = 12;
+
+    /** operator classes of the k > 31 from-counts extras (ReflexivDSMain64.java:584-619, 672-712) for {@link #extrasOperator} */
+    public static final int OP_DOUBLE = 0, OP_EXTENDABLE_PAIRS = 1, OP_UNEXTENDABLE = 2, OP_FIRST_OF_KEY = 3, OP_LONGER_OF_KEY = 4,
+            OP_ALL_FORWARD = 5, OP_ALL_REFLECTED = 6;
 
     private static final ConcurrentHashMap<Long, Long> CTX_OF_THREAD = new ConcurrentHashMap<Long, Long>();
     private static volatile int gpuCount = Integer.getInteger("reflexiv.gpus", 1);
@@ -61,6 +65,7 @@ public final class Rfx {
     public static native void randomReflection(long ctx, RfxRecords in, long[] partStart, int k, RfxRecords out);
     public static native void extendPass(long ctx, RfxRecords in, long[] partStart, int k, int twin, int stage, int scramble,
                                          RfxRecords out, long[] outPartStart);
+    public static native void extrasOperator(long ctx, int op, RfxRecords in, long[] partStart, int k, RfxRecords out, long[] outPartStart);
     public static native byte[] contigsText(long ctx, RfxRecords in, int k, int minContig, int twin);
 
     public static native byte[] assembleReads(long ctx, byte[] bases, long[] readOff, int[] params);

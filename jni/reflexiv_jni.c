@@ -23,6 +23,7 @@
 #include "reflexiv_hip.h"
 
 #define RFX_CLASS(name) Java_uni_bielefeld_cmg_reflexiv_gpu_Rfx_##name
+#define RFX_N_PARAMS ((int)(sizeof(rfx_params) / sizeof(int32_t)))        /* 13 */
 
 static void throw_rfx(JNIEnv *env, rfx_ctx *ctx, int st, const char *where) {
     char msg[640];
@@ -118,13 +119,13 @@ JNIEXPORT void JNICALL RFX_CLASS(ctxDestroy)(JNIEnv *env, jclass c, jlong h) {
     rfx_ctx_destroy(ctx_of(h));
 }
 
-/* U/DefaultParam.java defaults as the library sees them: int[12] in rfx_params field order */
+/* U/DefaultParam.java defaults as the library sees them: int[13] in rfx_params field order */
 JNIEXPORT jintArray JNICALL RFX_CLASS(defaultParams)(JNIEnv *env, jclass c) {
     (void)c;
     rfx_params p;
     rfx_default_params(&p);
-    jintArray a = (*env)->NewIntArray(env, 12);
-    if (a) (*env)->SetIntArrayRegion(env, a, 0, 12, (const jint *)&p);
+    jintArray a = (*env)->NewIntArray(env, RFX_N_PARAMS);
+    if (a) (*env)->SetIntArrayRegion(env, a, 0, RFX_N_PARAMS, (const jint *)&p);
     return a;
 }
 
@@ -334,6 +335,27 @@ JNIEXPORT void JNICALL RFX_CLASS(extendPass)(JNIEnv *env, jclass c, jlong h, job
     if (st != RFX_OK) throw_rfx(env, ctx, st, "rfx_extend_pass");
 }
 
+/* one operator class of the k > 31 from-counts extras (P/ReflexivDSMain64.java:584-619, 672-712); op = RFX_OP_* */
+JNIEXPORT void JNICALL RFX_CLASS(extrasOperator)(JNIEnv *env, jclass c, jlong h, jint op, jobject in, jlongArray partStart, jint k,
+                                                jobject out, jlongArray outPartStart) {
+    (void)c;
+    rfx_ctx *ctx = ctx_of(h);
+    pinned_records pi, po;
+    int st = RFX_E_ARG;
+    const int P = (*env)->GetArrayLength(env, partStart) - 1;
+    const int ok_i = records_pin(env, in, &pi), ok_o = records_pin(env, out, &po);
+    if (ok_i && ok_o && P >= 1) {
+        jlong *ps = (jlong *)(*env)->GetPrimitiveArrayCritical(env, partStart, NULL);
+        jlong *ops = (jlong *)(*env)->GetPrimitiveArrayCritical(env, outPartStart, NULL);
+        st = rfx_extras_operator(ctx, op, &pi.r, (const int64_t *)ps, P, k, &po.r, (int64_t *)ops);
+        (*env)->ReleasePrimitiveArrayCritical(env, outPartStart, ops, 0);
+        (*env)->ReleasePrimitiveArrayCritical(env, partStart, ps, JNI_ABORT);
+    }
+    records_unpin(env, &po, 0);
+    records_unpin(env, &pi, JNI_ABORT);
+    if (st != RFX_OK) throw_rfx(env, ctx, st, "rfx_extras_operator");
+}
+
 /* BinaryReflexivKmerArrayToString + KmerToContig + TagContigID (P/ReflexivMain.java:696-741, 590-637, 573-581):
  * the text saveAsTextFile writes for these records, ids counted from 0 (the caller adds zipWithIndex offsets
  * when it formats partition by partition) */
@@ -361,13 +383,13 @@ JNIEXPORT jbyteArray JNICALL RFX_CLASS(contigsText)(JNIEnv *env, jclass c, jlong
 /* ---------------------------------------------------------------------------- resident pipeline */
 
 /* The whole path (P/ReflexivMain.java:95-322) in one call: ASCII reads of any length up, contig text back.
- * params: int[12] in rfx_params field order (Rfx.defaultParams()).  k <= 31. */
+ * params: int[13] in rfx_params field order (Rfx.defaultParams()).  k <= 31. */
 JNIEXPORT jbyteArray JNICALL RFX_CLASS(assembleReads)(JNIEnv *env, jclass c, jlong h, jbyteArray bases, jlongArray readOff, jintArray params) {
     (void)c;
     rfx_ctx *ctx = ctx_of(h);
-    if ((*env)->GetArrayLength(env, params) != 12) { throw_rfx(env, ctx, RFX_E_ARG, "rfx_assemble_reads (params must hold 12 ints)"); return NULL; }
+    if ((*env)->GetArrayLength(env, params) != RFX_N_PARAMS) { throw_rfx(env, ctx, RFX_E_ARG, "rfx_assemble_reads (params: Rfx.defaultParams())"); return NULL; }
     rfx_params prm;
-    (*env)->GetIntArrayRegion(env, params, 0, 12, (jint *)&prm);
+    (*env)->GetIntArrayRegion(env, params, 0, RFX_N_PARAMS, (jint *)&prm);
     const jsize nOff = (*env)->GetArrayLength(env, readOff);
     int64_t cap = (int64_t)(*env)->GetArrayLength(env, bases) * 3 + (1 << 20);    /* both strands + headers + line breaks */
     for (;;) {

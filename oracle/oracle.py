@@ -24,7 +24,7 @@ class Params(C.Structure):
     """orc_params (mirrors U/DefaultParam.java:74-120 for the hot path)."""
     _fields_ = [(n, C.c_int32) for n in (
         "k", "min_cov", "max_cov", "min_error_cov", "min_contig", "min_iter", "max_iter",
-        "front_clip", "end_clip", "partitions", "twin", "coalesce")]
+        "front_clip", "end_clip", "partitions", "twin", "coalesce", "extras")]
 
 
 class _Records(C.Structure):
@@ -65,6 +65,8 @@ def lib():
         L.orc_count_reads_omp.restype = C.c_int64
         L.orc_count_reads_range_omp.restype = C.c_int64
         L.orc_count_reads_w2_range_omp.restype = C.c_int64
+        for f in ("orc_double_w", "orc_key_filter_w", "orc_flip_all_w"):
+            getattr(L, f).restype = C.c_int64
         for f in ("orc_fork_filter_forward_w", "orc_fork_filter_reflected_w", "orc_extend_pass_w",
                   "orc_contigs_text_w", "orc_assemble_from_counts_w"):
             getattr(L, f).restype = C.c_int64
@@ -396,6 +398,50 @@ def extend_pass(r: Records, part_start, k=31, twin=TWIN_DS, start_marker=2):
                                 _p(ops))
     return Records(o.key[:m].copy(), o.marker[:m].copy(), o.ext_off[:m + 1].copy(),
                    o.ext[:o.ext_off[m]].copy(), o.left[:m].copy(), o.right[:m].copy()), ops
+
+
+OP_EXTENDABLE_PAIRS, OP_UNEXTENDABLE, OP_FIRST_OF_KEY, OP_LONGER_OF_KEY = 1, 2, 3, 4
+
+
+def _out_records(n_cap, w_cap, kw):
+    return Records(_keybuf(max(1, n_cap), kw), np.empty(max(1, n_cap), np.int32), np.empty(n_cap + 1, np.int64),
+                   np.empty(max(1, w_cap), np.uint64), np.empty(max(1, n_cap), np.int32), np.empty(max(1, n_cap), np.int32))
+
+
+def _trim(o: Records, m: int) -> Records:
+    return Records(o.key[:m].copy(), o.marker[:m].copy(), o.ext_off[:m + 1].copy(), o.ext[:o.ext_off[m]].copy(),
+                   o.left[:m].copy(), o.right[:m].copy())
+
+
+def double_records(r: Records, k: int) -> Records:
+    """DSReflexivAndForwardKmer (P/ReflexivDSMain64.java:2126-3042): every record, then its other orientation"""
+    kw = sub_words(k)
+    o = _out_records(2 * r.n, 2 * int(r.ext_off[r.n]), kw)
+    m = lib().orc_double_w(_p(r.key), _p(r.marker), _p(r.ext_off), _p(r.ext), _p(r.left), _p(r.right), C.c_int64(r.n), k,
+                           _p(o.key), _p(o.marker), _p(o.ext_off), _p(o.ext), _p(o.left), _p(o.right))
+    return _trim(o, m)
+
+
+def key_filter(op: int, r: Records, part_start, k: int):
+    """the four run filters of the k > 31 from-counts extras (OP_*) on records sorted by key -> (Records, out_part_start)"""
+    kw = sub_words(k)
+    part_start = np.ascontiguousarray(part_start, np.int64)
+    P = len(part_start) - 1
+    o = _out_records(r.n, int(r.ext_off[r.n]), kw)
+    ops = np.empty(P + 1, np.int64)
+    m = lib().orc_key_filter_w(op, _p(r.key), _p(r.marker), _p(r.ext_off), _p(r.ext), _p(r.left), _p(r.right), C.c_int64(r.n),
+                               _p(part_start), P, k, _p(o.key), _p(o.marker), _p(o.ext_off), _p(o.ext), _p(o.left),
+                               _p(o.right), _p(ops))
+    return _trim(o, m), ops
+
+
+def flip_all(r: Records, k: int, m: int) -> Records:
+    """DSFilterUnExtendableKmerLeftEnds (m = 1) / ...RightEnds (m = 2): every record in orientation m"""
+    kw = sub_words(k)
+    o = _out_records(r.n, int(r.ext_off[r.n]), kw)
+    n = lib().orc_flip_all_w(_p(r.key), _p(r.marker), _p(r.ext_off), _p(r.ext), _p(r.left), _p(r.right), C.c_int64(r.n), k, m,
+                             _p(o.key), _p(o.marker), _p(o.ext_off), _p(o.ext), _p(o.left), _p(o.right))
+    return _trim(o, n)
 
 
 def contigs_text(r: Records, k=31, min_contig=500, twin=TWIN_DS):

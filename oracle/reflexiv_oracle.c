@@ -72,7 +72,7 @@ void orc_default_params(orc_params *p) {
     p->k = 31; p->min_cov = 2; p->max_cov = 10000000; p->min_error_cov = 8;
     p->min_contig = 500; p->min_iter = 15; p->max_iter = 150;
     p->front_clip = 0; p->end_clip = 0; p->partitions = 8;
-    p->twin = ORC_TWIN_DS; p->coalesce = 0;
+    p->twin = ORC_TWIN_DS; p->coalesce = 0; p->extras = 1;
 }
 
 /* ---------------------------------------------------------- a-1 fastq filter */
@@ -1359,6 +1359,111 @@ void orc_gather(const int64_t *perm, int64_t n,
     orc_gather_w(perm, n, 1, key, marker, ext_off, ext, left, right, okey, omarker, oext_off, oext, oleft, oright);
 }
 
+
+/* ------------------------------------------- k > 31 from-counts extras */
+
+int64_t orc_double_w(const uint64_t *key, const int32_t *marker, const int64_t *ext_off, const uint64_t *ext,
+                     const int32_t *left, const int32_t *right, int64_t n, int k,
+                     uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext, int32_t *oleft, int32_t *oright) {
+    /* DSReflexivAndForwardKmer.call :2153-2168: add s, then singleKmerRandomizer(s) with the marker s does not have */
+    const int kw = orc_sub_words(k), sub = k - 1;
+    int64_t maxw = 1;
+    for (int64_t i = 0; i < n; i++) { int64_t w = ext_off[i + 1] - ext_off[i]; if (w > maxw) maxw = w; }
+    uint8_t *bs = (uint8_t *)xmalloc((size_t)(maxw * 31 + sub + 64));
+    out_set o = { okey, omarker, oext_off, oext, oleft, oright, 0, kw };
+    oext_off[0] = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t nw = ext_off[i + 1] - ext_off[i];
+        int64_t len = record_seq(KEY(key, i), kw, marker[i], ext + ext_off[i], nw, sub, bs);
+        emit_seq(&o, bs, len, sub, marker[i], left[i], right[i]);                 /* :2157 */
+        emit_seq(&o, bs, len, sub, marker[i] == 1 ? 2 : 1, left[i], right[i]);    /* :2158-2163 */
+    }
+    free(bs);
+    return o.n;
+}
+
+int64_t orc_flip_all_w(const uint64_t *key, const int32_t *marker, const int64_t *ext_off, const uint64_t *ext,
+                       const int32_t *left, const int32_t *right, int64_t n, int k, int m,
+                       uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext, int32_t *oleft, int32_t *oright) {
+    /* DSFilterUnExtendableKmerLeftEnds.call :3424-3444 (randomReflexivMarker constantly 1) /
+     * DSFilterUnExtendableKmerRightEnds.call :4381-4401 (constantly 2) */
+    const int kw = orc_sub_words(k), sub = k - 1;
+    int64_t maxw = 1;
+    for (int64_t i = 0; i < n; i++) { int64_t w = ext_off[i + 1] - ext_off[i]; if (w > maxw) maxw = w; }
+    uint8_t *bs = (uint8_t *)xmalloc((size_t)(maxw * 31 + sub + 64));
+    out_set o = { okey, omarker, oext_off, oext, oleft, oright, 0, kw };
+    oext_off[0] = 0;
+    for (int64_t i = 0; i < n; i++) {
+        int64_t len = record_seq(KEY(key, i), kw, marker[i], ext + ext_off[i], ext_off[i + 1] - ext_off[i], sub, bs);
+        emit_seq(&o, bs, len, sub, m, left[i], right[i]);
+    }
+    free(bs);
+    return o.n;
+}
+
+int64_t orc_key_filter_w(int op, const uint64_t *key, const int32_t *marker, const int64_t *ext_off, const uint64_t *ext,
+                         const int32_t *left, const int32_t *right, int64_t n, const int64_t *part_start, int P, int k,
+                         uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext, int32_t *oleft,
+                         int32_t *oright, int64_t *out_part_start) {
+    (void)n;
+    const int kw = orc_sub_words(k), sub = k - 1;
+    int64_t maxw = 1;
+    for (int64_t i = 0; i < n; i++) { int64_t w = ext_off[i + 1] - ext_off[i]; if (w > maxw) maxw = w; }
+    uint8_t *bs = (uint8_t *)xmalloc((size_t)(maxw * 31 + sub + 64));
+    out_set o = { okey, omarker, oext_off, oext, oleft, oright, 0, kw };
+    oext_off[0] = 0;
+#define EXTW(i)   (ext + ext_off[i])
+#define EXTN(i)   (ext_off[(i) + 1] - ext_off[i])
+#define ADD(i, M) do { int64_t len_ = record_seq(KEY(key, i), kw, marker[i], EXTW(i), EXTN(i), sub, bs); \
+                       emit_seq(&o, bs, len_, sub, (M), left[i], right[i]); } while (0)
+#define ADD_ASIS(i) ADD(i, marker[i])
+    for (int p = 0; p < P; p++) {
+        out_part_start[p] = o.n;
+        int64_t holder = -1;                         /* tmpReflexivKmerExtendList (<= 1 element) */
+        for (int64_t s = part_start[p]; s < part_start[p + 1]; s++) {
+            if (holder < 0) { holder = s; continue; }                         /* lineMarker == 1 / size() == 0 */
+            const int64_t h = holder;
+            if (!key_eq(KEY(key, s), KEY(key, h), kw)) {                     /* new sub-kmer group */
+                if (op != ORC_OP_EXTENDABLE_PAIRS) ADD_ASIS(h);              /* :6518 / :3328 / :3160; the pairs filter drops it (:5455) */
+                holder = s; continue;
+            }
+            if (op == ORC_OP_FIRST_OF_KEY) { ADD_ASIS(h); holder = -1; continue; }          /* :3289-3312 */
+            const int64_t lenH = ext_len_words(EXTW(h), EXTN(h)), lenS = ext_len_words(EXTW(s), EXTN(s));
+            if (op == ORC_OP_LONGER_OF_KEY) {                                /* :3103-3145 */
+                const int64_t fh = sentinel_len(EXTW(h)[0]), fs = sentinel_len(EXTW(s)[0]);
+                if (lenH * 31 + fh >= lenS * 31 + fs) ADD_ASIS(h); else ADD_ASIS(s);
+                holder = -1; continue;
+            }
+            /* the merge test of the extend pass on (forward, reflected) of one key:  :5376-5399 / :6448-6467 */
+            int mergeable = 0, opposite = marker[s] != marker[h];
+            if (opposite) {
+                const int32_t a = marker[s] == 1 ? left[s] : right[s];       /* current's junction side  */
+                const int32_t b = marker[s] == 1 ? right[h] : left[h];       /* holder's junction side   */
+                mergeable = (a < 0 && b < 0) || (a >= 0 && b >= 0) || (a >= 0 && a - lenH >= 0) || (b >= 0 && b - lenS >= 0);
+            }
+            if (op == ORC_OP_EXTENDABLE_PAIRS) {
+                if (mergeable) {
+                    if (marker[s] == 1) { ADD_ASIS(s); ADD(h, 1); }          /* :5377-5379 */
+                    else                { ADD_ASIS(h); ADD(s, 1); }          /* :5416-5418 */
+                    holder = -1;
+                } else holder = s;                                           /* resetSubKmerGroup(s) :5397, :5402, :5408, :5436 */
+            } else {                                                         /* ORC_OP_UNEXTENDABLE */
+                if (mergeable) { holder = -1; continue; }                    /* "already extended": both dropped */
+                if (marker[h] == 2) ADD(h, 1); else ADD_ASIS(h);             /* :6469, :6482 (singleKmerRandomizer, marker 1) / :6475, :6503 */
+                holder = s;
+            }
+        }
+        if (holder >= 0) ADD_ASIS(holder);                                   /* :5462-5466 / :6532-6536 / :3335 / :3167 */
+    }
+    out_part_start[P] = o.n;
+    free(bs);
+    return o.n;
+#undef EXTW
+#undef EXTN
+#undef ADD
+#undef ADD_ASIS
+}
+
 /* --------------------------------------------------------------- a-15 contigs */
 
 /* header: 0 = RDD twin ">Contig-<len>-<idx>" (also P/ReflexivDSMain64.java:830-866),
@@ -1557,9 +1662,12 @@ int64_t orc_assemble_from_counts(const uint64_t *kmers, const int32_t *counts, i
     return len;
 }
 
-/* k > 31: ReflexivDSMain64.assemblyFromKmer  P/ReflexivDSMain64.java:374-826, without the
- * from-counts extras of :584-619 and :672-712 (orientation doubling, extendable/unextendable split,
- * end filters: SURVEY.md 8f-3) -- i.e. the loop of :621-661 iterates ALL records.  What differs
+/* k > 31: ReflexivDSMain64.assemblyFromKmer  P/ReflexivDSMain64.java:374-826.  prm->extras (default 1)
+ * selects the from-counts extras: at iteration minimumIteration + 3 every record is doubled
+ * into both orientations (:588), the doubled set is split into the members of mergeable pairs ("extendable")
+ * and the rest ("unextendable", :593-605), only the extendable set is iterated further (:659-660), and after the
+ * loop the two are united and records that share an end with a longer one are dropped (:672-712).  With extras
+ * = 0 the loop of :621-661 iterates ALL records and nothing is split or filtered.  What differs
  * from the k <= 31 driver: the stop rule starts at minimumIteration + 3 (:621), the first time the
  * count repeats param.scramble goes 2 -> 3 instead of stopping (:639-645) and every later array pass
  * starts its emission marker at 1 (:7484-7486; Spark evaluates the passes defined after a count() at
@@ -1585,8 +1693,41 @@ int64_t orc_assemble_from_counts_w(const uint64_t *kmers, const int32_t *counts,
     sort_and_extend(&cur, P, k, ORC_TWIN_DS, 2); TRACE();                     /* :550-563 */
     int64_t contigNumber = 0;
     int scramble = 2;                                                         /* U/DefaultParam.java:131 */
+    orc_records unext; memset(&unext, 0, sizeof unext);
+    int have_split = 0;
     while (iterations <= q.max_iter) {                                        /* :582 */
         iterations++;
+        if (q.extras && iterations == q.min_iter + 3) {                       /* :584-619 */
+            sort_records_w(&cur, kw);                                         /* :587 */
+            {   /* DSReflexivAndForwardKmer :588 */
+                orc_records d; rec_alloc(&d, 2 * cur.n + 1, 2 * cur.ext_off[cur.n] + 1, kw);
+                d.n = orc_double_w(cur.key, cur.marker, cur.ext_off, cur.ext, cur.left, cur.right, cur.n, k,
+                                   d.key, d.marker, d.ext_off, d.ext, d.left, d.right);
+                orc_free_records(&cur); cur = d;
+            }
+            sort_records_w(&cur, kw);                                         /* :590 */
+            int64_t *ps = (int64_t *)xmalloc((size_t)(P + 1) * 8), *ops = (int64_t *)xmalloc((size_t)(P + 1) * 8);
+            orc_partition_starts_w(cur.key, cur.n, kw, P, ps);
+            orc_records pe, pu;
+            rec_alloc(&pe, cur.n + 1, cur.ext_off[cur.n] + 1, kw); rec_alloc(&pu, cur.n + 1, cur.ext_off[cur.n] + 1, kw);
+            pe.n = orc_key_filter_w(ORC_OP_EXTENDABLE_PAIRS, cur.key, cur.marker, cur.ext_off, cur.ext, cur.left, cur.right, cur.n,
+                                    ps, P, k, pe.key, pe.marker, pe.ext_off, pe.ext, pe.left, pe.right, ops);     /* :593 */
+            pu.n = orc_key_filter_w(ORC_OP_UNEXTENDABLE, cur.key, cur.marker, cur.ext_off, cur.ext, cur.left, cur.right, cur.n,
+                                    ps, P, k, pu.key, pu.marker, pu.ext_off, pu.ext, pu.left, pu.right, ops);     /* :594 */
+            orc_free_records(&cur);
+            sort_records_w(&pe, kw); sort_records_w(&pu, kw);                 /* :601-602 */
+            orc_records *two[2] = { &pe, &pu };
+            for (int t = 0; t < 2; t++) {                                     /* :604-605 */
+                orc_records *src = two[t], dst;
+                orc_partition_starts_w(src->key, src->n, kw, P, ps);
+                rec_alloc(&dst, src->n + 1, src->ext_off[src->n] + 1, kw);
+                dst.n = orc_key_filter_w(ORC_OP_FIRST_OF_KEY, src->key, src->marker, src->ext_off, src->ext, src->left, src->right,
+                                         src->n, ps, P, k, dst.key, dst.marker, dst.ext_off, dst.ext, dst.left, dst.right, ops);
+                orc_free_records(src); *src = dst;
+            }
+            free(ps); free(ops);
+            cur = pe; unext = pu; have_split = 1;                             /* ExtendableReflexivKmer / UnExtendableReflexivKmer */
+        }
         if (iterations >= q.min_iter + 3 && iterations % 3 == 0) {            /* :621-622 */
             int64_t current = cur.n;                                          /* :633-635 */
             if (contigNumber == current) {                                    /* :639 */
@@ -1595,6 +1736,37 @@ int64_t orc_assemble_from_counts_w(const uint64_t *kmers, const int32_t *counts,
             } else contigNumber = current;                                    /* :647 */
         }
         sort_and_extend(&cur, P, k, ORC_TWIN_DS, scramble == 3 ? 1 : 2); TRACE();   /* :659-660 / :667-669 */
+    }
+    if (have_split) {                                                         /* :672-712 */
+        /* union: the extendable set's partitions, then the unextendable set's (:678) */
+        orc_records u; rec_alloc(&u, cur.n + unext.n + 1, cur.ext_off[cur.n] + unext.ext_off[unext.n] + 1, kw);
+        int64_t m = 0, w = 0;
+        orc_records *two[2] = { &cur, &unext };
+        for (int t = 0; t < 2; t++) {
+            orc_records *r = two[t];
+            for (int64_t i = 0; i < r->n; i++) {
+                KEYCPY(KEY(u.key, m), KEY(r->key, i)); u.marker[m] = r->marker[i]; u.left[m] = r->left[i]; u.right[m] = r->right[i];
+                const int64_t nw = r->ext_off[i + 1] - r->ext_off[i];
+                memcpy(u.ext + w, r->ext + r->ext_off[i], (size_t)nw * 8);
+                w += nw; m++; u.ext_off[m] = w;
+            }
+            orc_free_records(r);
+        }
+        u.n = m; cur = u;
+        int64_t *ps = (int64_t *)xmalloc((size_t)(P + 1) * 8), *ops = (int64_t *)xmalloc((size_t)(P + 1) * 8);
+        for (int side = 1; side <= 2; side++) {                               /* left ends (:689-697), then right ends (:699-707) */
+            orc_records f; rec_alloc(&f, cur.n + 1, cur.ext_off[cur.n] + 1, kw);
+            f.n = orc_flip_all_w(cur.key, cur.marker, cur.ext_off, cur.ext, cur.left, cur.right, cur.n, k, side,
+                                 f.key, f.marker, f.ext_off, f.ext, f.left, f.right);
+            orc_free_records(&cur); cur = f;
+            sort_records_w(&cur, kw);
+            orc_partition_starts_w(cur.key, cur.n, kw, P, ps);
+            orc_records g; rec_alloc(&g, cur.n + 1, cur.ext_off[cur.n] + 1, kw);
+            g.n = orc_key_filter_w(ORC_OP_LONGER_OF_KEY, cur.key, cur.marker, cur.ext_off, cur.ext, cur.left, cur.right, cur.n,
+                                   ps, P, k, g.key, g.marker, g.ext_off, g.ext, g.left, g.right, ops);
+            orc_free_records(&cur); cur = g;
+        }
+        free(ps); free(ops);
     }
 #undef TRACE
     if (n_trace) *n_trace = nt;

@@ -46,6 +46,8 @@ typedef struct {
     int32_t partitions;       /* logical partitions P of the order contract    */
     int32_t twin;             /* ORC_TWIN_DS / ORC_TWIN_RDD                     */
     int32_t coalesce;         /* apply the partition coalesce rule (:277-281)   */
+    int32_t extras;           /* k > 31 only: the from-counts extras of P/ReflexivDSMain64.java:584-619, 672-712
+                               * (orientation doubling, extendable / unextendable split, end filters); default 1 */
 } orc_params;
 
 void orc_default_params(orc_params *p);
@@ -247,8 +249,33 @@ int64_t orc_contigs_text_w(const uint64_t *key, const int32_t *marker, const int
                            const uint64_t *ext, const int32_t *left, const int32_t *right,
                            int64_t n, int k, int min_contig,
                            char *out, int64_t cap, int64_t *n_contigs);
-/* assemblyFromKmer :374-826 without the extras of :584-619 / :672-712 (see the .c file) from the
- * filtered (k-mer, count) list in ascending order, k-mers in the assembler layout. */
+/* The from-counts extras, one function per operator class of P/ReflexivDSMain64.java, on records
+ * sorted by key with their partition starts (outputs need room for 2n records / 2 * words where noted):
+ *   orc_double_w            DSReflexivAndForwardKmer :2126-3042          every record, then its other orientation (2n out)
+ *   orc_extendable_pairs_w  DSFilterExtendableKmerPairs :5305-6375       both members of every mergeable (forward,
+ *                           reflected) pair on one key, both as forward records; the task's last holder too
+ *   orc_unextendable_w      DSFilterUnExtendableKmer :6377-7444          what is left when the mergeable pairs are dropped
+ *   orc_first_of_key_w      DSFilterStillExtendableKmerFromPairs :3228-3390   one record per key (the first)
+ *   orc_longer_of_key_w     DSFilterStillExtendableKmerEnds :3044-3226   of two records on one key the one with the
+ *                           larger (length * 31 + first word length)
+ *   orc_flip_all_w          DSFilterUnExtendableKmerLeftEnds :3392-4347 (m = 1) / ...RightEnds :4349-5303 (m = 2) */
+int64_t orc_double_w(const uint64_t *key, const int32_t *marker, const int64_t *ext_off, const uint64_t *ext,
+                     const int32_t *left, const int32_t *right, int64_t n, int k,
+                     uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext, int32_t *oleft, int32_t *oright);
+int64_t orc_key_filter_w(int op, const uint64_t *key, const int32_t *marker, const int64_t *ext_off, const uint64_t *ext,
+                         const int32_t *left, const int32_t *right, int64_t n, const int64_t *part_start, int P, int k,
+                         uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext, int32_t *oleft,
+                         int32_t *oright, int64_t *out_part_start);
+#define ORC_OP_EXTENDABLE_PAIRS 1
+#define ORC_OP_UNEXTENDABLE     2
+#define ORC_OP_FIRST_OF_KEY     3
+#define ORC_OP_LONGER_OF_KEY    4
+int64_t orc_flip_all_w(const uint64_t *key, const int32_t *marker, const int64_t *ext_off, const uint64_t *ext,
+                       const int32_t *left, const int32_t *right, int64_t n, int k, int m,
+                       uint64_t *okey, int32_t *omarker, int64_t *oext_off, uint64_t *oext, int32_t *oleft, int32_t *oright);
+
+/* assemblyFromKmer :374-826 from the filtered (k-mer, count) list in ascending order, k-mers in the assembler
+ * layout; prm->extras selects whether :584-619 / :672-712 run (see the .c file). */
 int64_t orc_assemble_from_counts_w(const uint64_t *kmers, const int32_t *counts, int64_t n,
                                    const orc_params *prm,
                                    char *out, int64_t cap, int64_t *n_contigs,

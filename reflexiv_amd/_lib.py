@@ -29,7 +29,7 @@ class Params(C.Structure):
     """rfx_params (U/DefaultParam.java:74-120)."""
     _fields_ = [(n, C.c_int32) for n in (
         "k", "min_cov", "max_cov", "min_error_cov", "min_contig", "min_iter", "max_iter",
-        "front_clip", "end_clip", "partitions", "twin", "coalesce")]
+        "front_clip", "end_clip", "partitions", "twin", "coalesce", "extras")]
 
 
 class CRecords(C.Structure):
@@ -55,7 +55,7 @@ SYMBOLS = [
     "rfx_dev_count_reads_ragged", "rfx_assemble_reads", "rfx_dev_bucket_wide_by_owner", "rfx_dev_count_wide_elems",
     "rfx_dev_combine_reads", "rfx_dev_bucket_pairs_by_owner", "rfx_dev_merge_pairs",
     "rfx_dev_bucket_wide_records_by_owner", "rfx_dev_count_wide_records",
-    "rfx_extend_pass_w", "rfx_dev_counter_to_asm", "rfx_dev_assemble_w", "rfx_dev_order_kmers_w",
+    "rfx_extras_operator", "rfx_extend_pass_w", "rfx_dev_counter_to_asm", "rfx_dev_assemble_w", "rfx_dev_order_kmers_w",
 ]
 
 

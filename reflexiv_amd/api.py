@@ -281,6 +281,22 @@ class Reflexiv:
                                                _p(ops)), "rfx_extend_pass")
         return out._trim(co), ops
 
+    def extras_operator(self, op: int, r, part_start, k: int):
+        """One operator class of the k > 31 from-counts extras (P/ReflexivDSMain64.java:584-619, 672-712): op 0
+        DSReflexivAndForwardKmer, 1 DSFilterExtendableKmerPairs, 2 DSFilterUnExtendableKmer, 3 DSFilterStillExtendableKmerFromPairs,
+        4 DSFilterStillExtendableKmerEnds, 5 / 6 DSFilterUnExtendableKmerLeftEnds / ...RightEnds -> (Records, out_part_start)"""
+        r = as_records(r)
+        part_start = np.ascontiguousarray(part_start, np.int64)
+        P = len(part_start) - 1
+        mul = 2 if op == 0 else 1
+        out = Records.empty(mul * r.n, mul * len(r.ext), r.kw)
+        ci, co = r._c(), out._c()
+        co.cap_n, co.cap_words = mul * r.n, mul * len(r.ext)
+        ops = np.empty(P + 1, np.int64)
+        self._check(self.L.rfx_extras_operator(self.ctx, op, C.byref(ci), _p(part_start), P, k, C.byref(co), _p(ops)),
+                    "rfx_extras_operator")
+        return out._trim(co), ops
+
     def KmerToContig(self, r, k=31, min_contig=500, twin=TWIN_DS):
         r = as_records(r)
         ci = r._c()

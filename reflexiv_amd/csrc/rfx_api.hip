@@ -118,7 +118,7 @@ int rfx_version(void) { return 100; }
 void rfx_default_params(rfx_params *p) {
     p->k = 31; p->min_cov = 2; p->max_cov = 10000000; p->min_error_cov = 8; p->min_contig = 500;
     p->min_iter = 15; p->max_iter = 150; p->front_clip = 0; p->end_clip = 0; p->partitions = 8;
-    p->twin = RFX_TWIN_DS; p->coalesce = 0;
+    p->twin = RFX_TWIN_DS; p->coalesce = 0; p->extras = 1;
 }
 
 int rfx_ctx_create(int device, rfx_ctx **out) {
@@ -494,6 +494,21 @@ int rfx_extend_pass_w(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_s
     return extend_host(ctx, in, part_start, P, k, RFX_TWIN_DS, stage, scramble == 3 ? 1 : 2, out, out_part_start);
 }
 
+int rfx_extras_operator(rfx_ctx *ctx, int op, const rfx_records *in, const int64_t *part_start, int P, int k,
+                        rfx_records *out, int64_t *out_part_start) {
+    if (!ctx || !in || !out || !part_start || P < 1 || op < 0 || op > 6) return RFX_E_ARG;
+    RFX_TRY(check_k_rec(k));
+    RFX_TRY(check_kw(in, k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    DevRecords d, o;
+    DevBuf ps, ops;
+    RFX_TRY(dev_records_upload(ctx, in, d));
+    RFX_TRY(upload_part_start(ctx, part_start, P, ps));
+    RFX_TRY(extras_operator(ctx, op, d, ps.as<int64_t>(), P, k, o, ops));
+    RFX_TRY(download_to(ctx, o, out));
+    return download_part_start(ctx, ops, P, out_part_start);
+}
+
 int rfx_contigs_text(rfx_ctx *ctx, const rfx_records *in, int k, int min_contig, int twin, char *out, int64_t cap,
                      int64_t *out_len, int64_t *out_contigs) {
     if (!ctx || !in || !out_len) return RFX_E_ARG;
@@ -806,9 +821,13 @@ static int assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const 
     int scramble = 2;                                                             // U/DefaultParam.java:131
     // once the record set is small the rest of the loop runs as two launches per pass with the loop state in HBM
     static const bool small_off = getenv("RFX_NO_SMALL_PASSES") != nullptr;
+    const bool extras = wide && prm->extras != 0;
+    bool split_done = false;
+    DevRecords unext;                       // UnExtendableReflexivKmer (64 :605); lives outside the alternating arenas
     auto small_tail = [&](bool *took) -> int {
         *took = false;
         if (small_off || a.n > small_pass_limit() || P > small_pass_max_partitions()) return RFX_OK;
+        if (extras && !split_done && iterations + 1 <= prm->min_iter + 3) return RFX_OK;   // the split of 64 :584-619 comes first
         Arena *saved = tl_arena;
         tl_arena = nullptr;                 // its second record set and scratch outlive the alternating arenas
         const double t0 = verbose ? now_ms() : 0;
@@ -821,9 +840,69 @@ static int assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const 
         *took = st == RFX_OK;
         return st;
     };
+    // a record set copied out of the arenas (plain stream-ordered allocations)
+    auto detach = [&](const DevRecords &src, DevRecords &dst) -> int {
+        Arena *saved = tl_arena;
+        tl_arena = nullptr;
+        int st = dev_records_alloc(ctx, dst, src.n, src.words, src.kw);
+        tl_arena = saved;
+        RFX_TRY(st);
+        if (src.n > 0) {
+            RFX_HIP(hipMemcpyAsync(dst.key.p, src.key.p, (size_t)src.n * 8 * src.kw, hipMemcpyDeviceToDevice, ctx->stream));
+            RFX_HIP(hipMemcpyAsync(dst.marker.p, src.marker.p, (size_t)src.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            RFX_HIP(hipMemcpyAsync(dst.left.p, src.left.p, (size_t)src.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            RFX_HIP(hipMemcpyAsync(dst.right.p, src.right.p, (size_t)src.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            if (src.words > 0) RFX_HIP(hipMemcpyAsync(dst.ext.p, src.ext.p, (size_t)src.words * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        RFX_HIP(hipMemcpyAsync(dst.ext_off.p, src.ext_off.p, (size_t)(src.n + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        dst.n = src.n; dst.words = src.words;
+        return RFX_OK;
+    };
     while (wide && iterations <= prm->max_iter) {                                 // 64 :582
         { bool took; RFX_TRY(small_tail(&took)); if (took) break; }
         iterations++;
+        if (extras && iterations == prm->min_iter + 3) {                          // 64 :584-619
+            DevRecords dbl, pe, pu, tmp;
+            // sort, DSReflexivAndForwardKmer, sort  (:587-590)
+            next_arena();
+            RFX_TRY(sort_records(ctx, a, P, key_bits, b, ps, k));
+            next_arena();
+            RFX_TRY(extras_operator(ctx, RFX_OP_DOUBLE, b, ps.as<int64_t>(), P, k, a, ops));
+            RFX_TRY(detach(a, tmp));                                              // (the doubled set is read twice below)
+            next_arena();
+            RFX_TRY(sort_records(ctx, tmp, P, key_bits, b, ps, k));
+            RFX_TRY(detach(b, dbl));
+            DevBuf dps;
+            { Arena *sv = tl_arena; tl_arena = nullptr; hipError_t e = dps.alloc((size_t)(P + 1) * 8, ctx->stream); tl_arena = sv; RFX_HIP(e); }
+            RFX_HIP(hipMemcpyAsync(dps.p, ps.p, (size_t)(P + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            // the two filters on the doubled set, each followed by sort + first-of-key  (:593-605)
+            for (int t = 0; t < 2; t++) {
+                next_arena();
+                RFX_TRY(extras_operator(ctx, t == 0 ? RFX_OP_EXTENDABLE_PAIRS : RFX_OP_UNEXTENDABLE, dbl, dps.as<int64_t>(), P, k, a, ops));
+                next_arena();
+                RFX_TRY(sort_records(ctx, a, P, key_bits, b, ps, k));
+                next_arena();
+                RFX_TRY(extras_operator(ctx, RFX_OP_FIRST_OF_KEY, b, ps.as<int64_t>(), P, k, a, ops));
+                RFX_TRY(detach(a, t == 0 ? pe : pu));
+            }
+            // ExtendableReflexivKmer is what the loop goes on with; UnExtendableReflexivKmer waits for the union
+            next_arena();
+            RFX_TRY(detach(pu, unext));
+            {   // pe -> a in the current arena
+                RFX_TRY(dev_records_alloc(ctx, a, pe.n, pe.words, pe.kw));
+                if (pe.n > 0) {
+                    RFX_HIP(hipMemcpyAsync(a.key.p, pe.key.p, (size_t)pe.n * 8 * pe.kw, hipMemcpyDeviceToDevice, ctx->stream));
+                    RFX_HIP(hipMemcpyAsync(a.marker.p, pe.marker.p, (size_t)pe.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                    RFX_HIP(hipMemcpyAsync(a.left.p, pe.left.p, (size_t)pe.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                    RFX_HIP(hipMemcpyAsync(a.right.p, pe.right.p, (size_t)pe.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                    if (pe.words > 0) RFX_HIP(hipMemcpyAsync(a.ext.p, pe.ext.p, (size_t)pe.words * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                }
+                RFX_HIP(hipMemcpyAsync(a.ext_off.p, pe.ext_off.p, (size_t)(pe.n + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                a.n = pe.n; a.words = pe.words;
+            }
+            RFX_HIP(hipStreamSynchronize(ctx->stream));
+            split_done = true;
+        }
         if (iterations >= prm->min_iter + 3 && iterations % 3 == 0) {             // 64 :621-622
             const int64_t current = a.n;                                          // 64 :633-635
             if (contigNumber == current) {                                        // 64 :639
@@ -849,6 +928,55 @@ static int assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const 
         RFX_TRY(one_pass(2));
     }
     if (n_trace) *n_trace = nt;
+    if (split_done) {                                                             // 64 :672-712
+        // union: the extendable set's records, then the unextendable set's (:678)
+        DevRecords u;
+        { Arena *sv = tl_arena; tl_arena = nullptr; int st = dev_records_alloc(ctx, u, a.n + unext.n, a.words + unext.words, kw); tl_arena = sv; RFX_TRY(st); }
+        const DevRecords *two[2] = {&a, &unext};
+        int64_t m = 0, w = 0;
+        for (int t = 0; t < 2; t++) {
+            const DevRecords &r = *two[t];
+            if (r.n > 0) {
+                RFX_HIP(hipMemcpyAsync(u.key.as<uint64_t>() + m * kw, r.key.p, (size_t)r.n * 8 * kw, hipMemcpyDeviceToDevice, ctx->stream));
+                RFX_HIP(hipMemcpyAsync(u.marker.as<int32_t>() + m, r.marker.p, (size_t)r.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                RFX_HIP(hipMemcpyAsync(u.left.as<int32_t>() + m, r.left.p, (size_t)r.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                RFX_HIP(hipMemcpyAsync(u.right.as<int32_t>() + m, r.right.p, (size_t)r.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                if (r.words > 0) RFX_HIP(hipMemcpyAsync(u.ext.as<uint64_t>() + w, r.ext.p, (size_t)r.words * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            m += r.n; w += r.words;
+        }
+        // ext_off of the union: built on the host (the sets are small by now)
+        {
+            std::vector<int64_t> ha((size_t)a.n + 1), hu((size_t)unext.n + 1), ho((size_t)(a.n + unext.n) + 1);
+            RFX_HIP(hipMemcpyAsync(ha.data(), a.ext_off.p, ha.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            RFX_HIP(hipMemcpyAsync(hu.data(), unext.ext_off.p, hu.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            RFX_HIP(hipStreamSynchronize(ctx->stream));
+            for (int64_t i = 0; i <= a.n; i++) ho[(size_t)i] = ha[(size_t)i];
+            for (int64_t i = 0; i <= unext.n; i++) ho[(size_t)(a.n + i)] = a.words + hu[(size_t)i];
+            RFX_HIP(hipMemcpyAsync(u.ext_off.p, ho.data(), ho.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            RFX_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        u.n = a.n + unext.n; u.words = a.words + unext.words;
+        // left ends: all forward, sort, longer-of-key; right ends: all reflected, sort, longer-of-key  (:689-707)
+        DevBuf one;
+        { Arena *sv = tl_arena; tl_arena = nullptr; hipError_t e = one.alloc(16, ctx->stream); tl_arena = sv; RFX_HIP(e); }
+        const DevRecords *cur = &u;
+        for (int side = 0; side < 2; side++) {
+            int64_t h1[2] = {0, cur->n};
+            RFX_HIP(hipMemcpyAsync(one.p, h1, 16, hipMemcpyHostToDevice, ctx->stream));
+            RFX_HIP(hipStreamSynchronize(ctx->stream));
+            next_arena();
+            DevBuf ops1;
+            RFX_TRY(extras_operator(ctx, side == 0 ? RFX_OP_ALL_FORWARD : RFX_OP_ALL_REFLECTED, *cur, one.as<int64_t>(), 1, k, b, ops1));
+            next_arena();
+            DevRecords srt;
+            RFX_TRY(sort_records(ctx, b, P, key_bits, srt, ps, k));
+            next_arena();
+            RFX_TRY(extras_operator(ctx, RFX_OP_LONGER_OF_KEY, srt, ps.as<int64_t>(), P, k, a, ops));
+            cur = &a;
+            if (side == 0) { RFX_TRY(detach(a, u)); cur = &u; }                   // (a's arena is about to be reused)
+        }
+    }
     DevRecords *fin = &a;
     if (wide) {                                                                   // 64 :714
         next_arena();

@@ -36,7 +36,8 @@ constexpr int32_t BLOCKED = INT32_MIN;
 constexpr int EMIT_SHORT = 2;           // words the record's own thread emits; longer ones go word-parallel
 
 struct Desc {          // one emission
-    uint32_t a, b;     // flip: a = source; merge: a = reflected source R, b = forward source F
+    uint32_t a, b;     // flip: a = source, b = the orientation to emit in (0: the one the emission index gives);
+                       // merge: a = reflected source R, b = forward source F
     int32_t left, right;
     uint32_t type;     // 0 none, 1 flip, 2 merge
     uint32_t len;      // extension length of the output in bases
@@ -187,7 +188,7 @@ __device__ __forceinline__ void emit_at(int64_t i, const Desc *__restrict__ desc
     // randomReflexivMarker starts at 2 in every task (1 once param.scramble == 3 in the k > 31 array loop,
     // P/ReflexivDSMain64.java:7484-7486) and toggles on every emission (:770, :1058-1062, :1242, :1514):
     // orientation = parity of the emission index
-    const int m = ((j - (int64_t)oidx[ps[p]]) & 1) ? 3 - start_marker : start_marker;
+    const int m = (d.type == 1 && d.b) ? (int)d.b : ((j - (int64_t)oidx[ps[p]]) & 1) ? 3 - start_marker : start_marker;
     OutSeq<KW> s;
     s.type = (int)d.type;
     s.a = load_src<KW>(d.a, key, marker, ext_off, ext, len);
@@ -260,7 +261,7 @@ __device__ __forceinline__ void emit_word_at(int64_t t, const Desc *__restrict__
     if (nw <= EMIT_SHORT) return;                    // k_emit wrote it
     const int64_t j = (int64_t)oidx[i];
     const int p = part_of(ps, P, i);
-    const int m = ((j - (int64_t)oidx[ps[p]]) & 1) ? 3 - start_marker : start_marker;
+    const int m = (d.type == 1 && d.b) ? (int)d.b : ((j - (int64_t)oidx[ps[p]]) & 1) ? 3 - start_marker : start_marker;
     OutSeq<KW> s;
     s.type = (int)d.type;
     s.a = load_src<KW>(d.a, key, marker, ext_off, ext, len);
@@ -497,6 +498,90 @@ __global__ void k_small_words(SmallSet A, SmallSet B, SmallScratch sc, const Sma
                      (const KeyW<KW> *)sc.skey, sc.smarker, sc.sext, in.ext, sc.slen, out.ext);
 }
 
+
+// ---- the k > 31 from-counts extras (P/ReflexivDSMain64.java:584-619, 672-712): operators that copy or
+// re-orient records, expressed as emission descriptors for the same emit kernels as the extend pass
+// DSReflexivAndForwardKmer :2153-2168: descriptor 2i = record i as it is, 2i+1 = its other orientation
+__global__ void k_desc_double(const int32_t *__restrict__ marker, const int32_t *__restrict__ left, const int32_t *__restrict__ right,
+                              const uint32_t *__restrict__ len, int64_t n, Desc *__restrict__ desc, uint32_t *__restrict__ flag,
+                              uint32_t *__restrict__ onw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int mk = marker[i];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        Desc d; d.a = (uint32_t)i; d.b = (uint32_t)(t == 0 ? mk : 3 - mk); d.left = left[i]; d.right = right[i]; d.type = 1u; d.len = len[i];
+        desc[2 * i + t] = d; flag[2 * i + t] = 1u; onw[2 * i + t] = (len[i] + 30u) / 31u;
+    }
+}
+// DSFilterUnExtendableKmerLeftEnds (m = 1, :3424-3444) / ...RightEnds (m = 2, :4381-4401): every record in orientation m
+__global__ void k_desc_flip_all(const int32_t *__restrict__ left, const int32_t *__restrict__ right, const uint32_t *__restrict__ len,
+                                int64_t n, int m, Desc *__restrict__ desc, uint32_t *__restrict__ flag, uint32_t *__restrict__ onw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Desc d; d.a = (uint32_t)i; d.b = (uint32_t)m; d.left = left[i]; d.right = right[i]; d.type = 1u; d.len = len[i];
+    desc[i] = d; flag[i] = 1u; onw[i] = (len[i] + 30u) / 31u;
+}
+
+// The four run filters (op 1 DSFilterExtendableKmerPairs :5305-6375, 2 DSFilterUnExtendableKmer :6377-7444,
+// 3 DSFilterStillExtendableKmerFromPairs :3228-3390, 4 DSFilterStillExtendableKmerEnds :3044-3226) on records sorted by key:
+// the reference walks a task with a one-record holder that never survives a key change except to be emitted (ops 2-4) or
+// dropped (op 1; only a task's LAST holder is emitted there, :5462-5466), so every equal-key run resolves on its own; the
+// thread that owns a run head walks it and writes the run's emissions into the run's own index range.
+template <int KW>
+__global__ void k_key_filter(int op, const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
+                             const int32_t *__restrict__ left, const int32_t *__restrict__ right, const uint32_t *__restrict__ len,
+                             const uint64_t *__restrict__ word0, int64_t n, const int64_t *__restrict__ ps, int P,
+                             Desc *__restrict__ desc, uint32_t *__restrict__ flag, uint32_t *__restrict__ onw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const KeyW<KW> kk = key[i];
+    if (i > 0 && key_eq(key[i - 1], kk)) return;               // not a run head
+    int64_t o = i, holder = i, s = i + 1;
+#define PUTF(SRC, M) do { \
+        Desc d_; d_.a = (uint32_t)(SRC); d_.b = (uint32_t)(M); d_.left = left[SRC]; d_.right = right[SRC]; d_.type = 1u; \
+        d_.len = len[SRC]; desc[o] = d_; flag[o] = 1u; onw[o] = (len[SRC] + 30u) / 31u; o++; } while (0)
+    for (; s < n && key_eq(key[s], kk); s++) {
+        if (holder < 0) { holder = s; continue; }
+        const int64_t h = holder;
+        if (op == 3) { PUTF(h, marker[h]); holder = -1; continue; }                         // :3289-3312
+        if (op == 4) {                                                                      // :3103-3145
+            const int64_t sh = (int64_t)len[h] * 31 + sentinel_len(word0[h]), ss = (int64_t)len[s] * 31 + sentinel_len(word0[s]);
+            if (sh >= ss) PUTF(h, marker[h]); else PUTF(s, marker[s]);
+            holder = -1; continue;
+        }
+        bool mergeable = false;
+        if (marker[s] != marker[h]) {                                                       // :5376-5399 / :6448-6467
+            const int32_t a = marker[s] == 1 ? left[s] : right[s], b = marker[s] == 1 ? right[h] : left[h];
+            mergeable = (a < 0 && b < 0) || (a >= 0 && b >= 0) || (a >= 0 && a - (int64_t)len[h] >= 0) || (b >= 0 && b - (int64_t)len[s] >= 0);
+        }
+        if (op == 1) {
+            if (mergeable) {
+                if (marker[s] == 1) { PUTF(s, 1); PUTF(h, 1); }                             // :5377-5379
+                else { PUTF(h, 1); PUTF(s, 1); }                                            // :5416-5418
+                holder = -1;
+            } else holder = s;
+        } else {                                                                            // op 2
+            if (mergeable) { holder = -1; continue; }
+            PUTF(h, marker[h] == 2 ? 1 : marker[h]);                                        // :6469, :6482 / :6475, :6503
+            holder = s;
+        }
+    }
+    if (holder >= 0) {
+        // the run ends: a key change emits the holder (ops 2-4) or drops it (op 1), the end of the task always emits it
+        bool emit = op != 1;
+        if (!emit) { const int p = part_of(ps, P, i); emit = s == ps[p + 1]; }
+        if (emit) PUTF(holder, marker[holder]);
+    }
+    for (; o < s; o++) { flag[o] = 0u; onw[o] = 0u; desc[o].type = 0u; }
+#undef PUTF
+}
+
+__global__ void k_word0(const int64_t *__restrict__ ext_off, const uint64_t *__restrict__ ext, int64_t n, uint64_t *__restrict__ w0) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w0[i] = ext[ext_off[i]];
+}
+
 // output partition starts + the pass summary the host reads back in ONE copy:
 // summary = {records out, words out, status}
 __global__ void k_out_part_start(const int64_t *__restrict__ ps, int P, const uint64_t *__restrict__ oidx,
@@ -522,23 +607,68 @@ namespace rfx {
     default: return RFX_E_ARG;                                                \
     }
 
+static DevBuf &ops_tmp_alloc(rfx_ctx *ctx, DevBuf &b, int P) { (void)b.alloc((size_t)(P + 1) * 8, ctx->stream); return b; }
+
+// everything after the descriptors: scans, emission, output partition starts, the 24-byte summary.
+// nd = number of descriptor slots (= n of the input except for the doubling operator); single_word: one word per emission.
+static int desc_tail(rfx_ctx *ctx, const DevRecords &in, int64_t nd, DevBuf &len, DevBuf &desc, DevBuf &flag, DevBuf &onw, DevBuf &status,
+                     const int64_t *d_part_start, int P, int k, bool single_word, int start_marker, int64_t words_bound,
+                     DevRecords &out, DevBuf &out_part_start) {
+    const int sub = k - 1, kw = in.kw;
+    DevBuf oidx, owoff;
+    RFX_HIP(oidx.alloc((size_t)(nd + 1) * 8, ctx->stream));
+    RFX_HIP(owoff.alloc((size_t)(nd + 1) * 8, ctx->stream));
+    RFX_TRY(exclusive_scan_u32_to_u64(ctx, flag.as<uint32_t>(), oidx.as<uint64_t>(), nd));
+    // single-word stage: every emission has exactly one word (a longer one is the RFX_E_STATE below), so the word
+    // offsets ARE the emission indices
+    if (single_word) RFX_HIP(hipMemcpyAsync(owoff.p, oidx.p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    else RFX_TRY(exclusive_scan_u32_to_u64(ctx, onw.as<uint32_t>(), owoff.as<uint64_t>(), nd));
+    RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_emit<KW>, dim3(grid_for(nd + 1)), dim3(256), 0, ctx->stream, (const Desc *)desc.as<Desc>(),
+                       (const uint32_t *)flag.as<uint32_t>(), (const uint64_t *)oidx.as<uint64_t>(),
+                       (const uint64_t *)owoff.as<uint64_t>(), nd, d_part_start, P, sub, start_marker,
+                       (const KeyW<KW> *)in.key.as<KeyW<KW>>(), (const int32_t *)in.marker.as<int32_t>(),
+                       (const int64_t *)in.ext_off.as<int64_t>(), (const uint64_t *)in.ext.as<uint64_t>(),
+                       (const uint32_t *)len.as<uint32_t>(), out.key.as<KeyW<KW>>(), out.marker.as<int32_t>(),
+                       out.ext_off.as<int64_t>(), out.ext.as<uint64_t>(), out.left.as<int32_t>(),
+                       out.right.as<int32_t>()));
+    RFX_HIP(hipGetLastError());
+    if (words_bound > nd || in.words > in.n) {          // some record may have more than one word
+        RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_emit_words<KW>, dim3(grid_for(words_bound)), dim3(256), 0, ctx->stream, (const Desc *)desc.as<Desc>(),
+                           (const uint64_t *)oidx.as<uint64_t>(), (const uint64_t *)owoff.as<uint64_t>(), nd, d_part_start, P,
+                           sub, start_marker, (const KeyW<KW> *)in.key.as<KeyW<KW>>(), (const int32_t *)in.marker.as<int32_t>(),
+                           (const int64_t *)in.ext_off.as<int64_t>(), (const uint64_t *)in.ext.as<uint64_t>(),
+                           (const uint32_t *)len.as<uint32_t>(), out.ext.as<uint64_t>()));
+        RFX_HIP(hipGetLastError());
+    }
+    DevBuf summary;
+    RFX_HIP(summary.alloc(24, ctx->stream));
+    hipLaunchKernelGGL(k_out_part_start, dim3(grid_for(P + 1)), dim3(256), 0, ctx->stream, d_part_start, P,
+                       (const uint64_t *)oidx.as<uint64_t>(), out_part_start.as<int64_t>(),
+                       (const uint64_t *)owoff.as<uint64_t>(), nd, (const int *)status.as<int>(), summary.as<uint64_t>());
+    RFX_HIP(hipGetLastError());
+    uint64_t tot[3] = {0, 0, 0};
+    RFX_HIP(hipMemcpyAsync(tot, summary.p, 24, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    const int st = (int)tot[2];
+    out.n = (int64_t)tot[0]; out.words = (int64_t)tot[1];
+    if (st) { ctx->last_error = "extend pass: single-word stage produced an extension > 31 bases"; return RFX_E_STATE; }
+    return RFX_OK;
+}
+
 int extend_pass(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start, int P, int k, int twin,
                 int stage, DevRecords &out, DevBuf &out_part_start, int start_marker) {
     const int64_t n = in.n;
-    const int sub = k - 1;
     const int kw = in.kw;
     if (n > (int64_t)0xFFFFFFFFLL) return RFX_E_LIMIT;
     if (kw != sub_words(k) || (start_marker != 1 && start_marker != 2)) return RFX_E_ARG;
     RFX_TRY(dev_records_alloc(ctx, out, n, in.words, kw));
     RFX_HIP(out_part_start.alloc((size_t)(P + 1) * 8, ctx->stream));
-    DevBuf len, desc, flag, onw, oidx, owoff, status;
+    DevBuf len, desc, flag, onw, status;
     const int64_t a = n ? n : 1;
     RFX_HIP(len.alloc((size_t)a * 4, ctx->stream));
     RFX_HIP(desc.alloc((size_t)a * sizeof(Desc), ctx->stream));
     RFX_HIP(flag.alloc((size_t)a * 4, ctx->stream));
     RFX_HIP(onw.alloc((size_t)a * 4, ctx->stream));
-    RFX_HIP(oidx.alloc((size_t)(n + 1) * 8, ctx->stream));
-    RFX_HIP(owoff.alloc((size_t)(n + 1) * 8, ctx->stream));
     RFX_HIP(status.alloc(4, ctx->stream));
     RFX_HIP(hipMemsetAsync(status.p, 0, 4, ctx->stream));
     if (n > 0) {
@@ -553,40 +683,74 @@ int extend_pass(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start,
                            flag.as<uint32_t>(), onw.as<uint32_t>(), status.as<int>()));
         RFX_HIP(hipGetLastError());
     }
-    RFX_TRY(exclusive_scan_u32_to_u64(ctx, flag.as<uint32_t>(), oidx.as<uint64_t>(), n));
-    // single-word stage: every emission has exactly one word (a longer one is the RFX_E_STATE below), so the word
-    // offsets ARE the emission indices
-    if (stage == 0) RFX_HIP(hipMemcpyAsync(owoff.p, oidx.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    else RFX_TRY(exclusive_scan_u32_to_u64(ctx, onw.as<uint32_t>(), owoff.as<uint64_t>(), n));
-    RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_emit<KW>, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream, (const Desc *)desc.as<Desc>(),
-                       (const uint32_t *)flag.as<uint32_t>(), (const uint64_t *)oidx.as<uint64_t>(),
-                       (const uint64_t *)owoff.as<uint64_t>(), n, d_part_start, P, sub, start_marker,
-                       (const KeyW<KW> *)in.key.as<KeyW<KW>>(), (const int32_t *)in.marker.as<int32_t>(),
-                       (const int64_t *)in.ext_off.as<int64_t>(), (const uint64_t *)in.ext.as<uint64_t>(),
-                       (const uint32_t *)len.as<uint32_t>(), out.key.as<KeyW<KW>>(), out.marker.as<int32_t>(),
-                       out.ext_off.as<int64_t>(), out.ext.as<uint64_t>(), out.left.as<int32_t>(),
-                       out.right.as<int32_t>()));
-    RFX_HIP(hipGetLastError());
-    if (in.words > n) {          // some record has more than one word (output words <= input words)
-        RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_emit_words<KW>, dim3(grid_for(in.words)), dim3(256), 0, ctx->stream, (const Desc *)desc.as<Desc>(),
-                           (const uint64_t *)oidx.as<uint64_t>(), (const uint64_t *)owoff.as<uint64_t>(), n, d_part_start, P,
-                           sub, start_marker, (const KeyW<KW> *)in.key.as<KeyW<KW>>(), (const int32_t *)in.marker.as<int32_t>(),
-                           (const int64_t *)in.ext_off.as<int64_t>(), (const uint64_t *)in.ext.as<uint64_t>(),
-                           (const uint32_t *)len.as<uint32_t>(), out.ext.as<uint64_t>()));
+    return desc_tail(ctx, in, n, len, desc, flag, onw, status, d_part_start, P, k, stage == 0, start_marker, in.words, out, out_part_start);
+}
+
+// op 0: DSReflexivAndForwardKmer (2n out); 1..4: the run filters (see k_key_filter); 5 / 6: every record forward / reflected
+int extras_operator(rfx_ctx *ctx, int op, const DevRecords &in, const int64_t *d_part_start, int P, int k, DevRecords &out,
+                    DevBuf &out_part_start) {
+    const int64_t n = in.n;
+    const int kw = in.kw;
+    if (2 * n > (int64_t)0xFFFFFFFFLL) return RFX_E_LIMIT;
+    if (kw != sub_words(k) || op < 0 || op > 6) return RFX_E_ARG;
+    const int64_t nd = op == 0 ? 2 * n : n, wcap = op == 0 ? 2 * in.words : in.words;
+    RFX_TRY(dev_records_alloc(ctx, out, nd, wcap, kw));
+    RFX_HIP(out_part_start.alloc((size_t)(P + 1) * 8, ctx->stream));
+    DevBuf len, desc, flag, onw, status, w0, ps1;
+    const int64_t a = nd ? nd : 1;
+    RFX_HIP(len.alloc((size_t)(n ? n : 1) * 4, ctx->stream));
+    RFX_HIP(desc.alloc((size_t)a * sizeof(Desc), ctx->stream));
+    RFX_HIP(flag.alloc((size_t)a * 4, ctx->stream));
+    RFX_HIP(onw.alloc((size_t)a * 4, ctx->stream));
+    RFX_HIP(status.alloc(4, ctx->stream));
+    RFX_HIP(hipMemsetAsync(status.p, 0, 4, ctx->stream));
+    const int64_t *ps = d_part_start;
+    int Pn = P;
+    if (op == 0) {
+        // the doubled set keeps the input's partitions: partition p holds the descriptors [2 ps[p], 2 ps[p+1]); nothing in
+        // this operator looks at them (every descriptor names its orientation), so one partition over everything will do
+        int64_t one[2] = {0, nd};
+        RFX_HIP(ps1.alloc(16, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(ps1.p, one, 16, hipMemcpyHostToDevice, ctx->stream));
+        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        ps = ps1.as<int64_t>(); Pn = 1;
+    }
+    if (n > 0) {
+        hipLaunchKernelGGL(k_ext_len, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (const int64_t *)in.ext_off.as<int64_t>(),
+                           (const uint64_t *)in.ext.as<uint64_t>(), n, len.as<uint32_t>());
+        RFX_HIP(hipGetLastError());
+        if (op == 0) {
+            hipLaunchKernelGGL(k_desc_double, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (const int32_t *)in.marker.as<int32_t>(),
+                               (const int32_t *)in.left.as<int32_t>(), (const int32_t *)in.right.as<int32_t>(), (const uint32_t *)len.as<uint32_t>(),
+                               n, desc.as<Desc>(), flag.as<uint32_t>(), onw.as<uint32_t>());
+        } else if (op >= 5) {
+            hipLaunchKernelGGL(k_desc_flip_all, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (const int32_t *)in.left.as<int32_t>(),
+                               (const int32_t *)in.right.as<int32_t>(), (const uint32_t *)len.as<uint32_t>(), n, op == 5 ? 1 : 2,
+                               desc.as<Desc>(), flag.as<uint32_t>(), onw.as<uint32_t>());
+        } else {
+            RFX_HIP(w0.alloc((size_t)n * 8, ctx->stream));
+            hipLaunchKernelGGL(k_word0, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (const int64_t *)in.ext_off.as<int64_t>(),
+                               (const uint64_t *)in.ext.as<uint64_t>(), n, w0.as<uint64_t>());
+            RFX_HIP(hipGetLastError());
+            RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_key_filter<KW>, dim3(grid_for(n)), dim3(256), 0, ctx->stream, op,
+                               (const KeyW<KW> *)in.key.as<KeyW<KW>>(), (const int32_t *)in.marker.as<int32_t>(),
+                               (const int32_t *)in.left.as<int32_t>(), (const int32_t *)in.right.as<int32_t>(),
+                               (const uint32_t *)len.as<uint32_t>(), (const uint64_t *)w0.as<uint64_t>(), n, d_part_start, P,
+                               desc.as<Desc>(), flag.as<uint32_t>(), onw.as<uint32_t>()));
+        }
         RFX_HIP(hipGetLastError());
     }
-    DevBuf summary;
-    RFX_HIP(summary.alloc(24, ctx->stream));
-    hipLaunchKernelGGL(k_out_part_start, dim3(grid_for(P + 1)), dim3(256), 0, ctx->stream, d_part_start, P,
-                       (const uint64_t *)oidx.as<uint64_t>(), out_part_start.as<int64_t>(),
-                       (const uint64_t *)owoff.as<uint64_t>(), n, (const int *)status.as<int>(), summary.as<uint64_t>());
-    RFX_HIP(hipGetLastError());
-    uint64_t tot[3] = {0, 0, 0};
-    RFX_HIP(hipMemcpyAsync(tot, summary.p, 24, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
-    const int st = (int)tot[2];
-    out.n = (int64_t)tot[0]; out.words = (int64_t)tot[1];
-    if (st) { ctx->last_error = "extend pass: single-word stage produced an extension > 31 bases"; return RFX_E_STATE; }
+    DevBuf ops_tmp;
+    RFX_TRY(desc_tail(ctx, in, nd, len, desc, flag, onw, status, ps, Pn, k, false, 2, wcap, out, op == 0 ? ops_tmp_alloc(ctx, ops_tmp, Pn) : out_part_start));
+    if (op == 0) {
+        // output partition starts of the doubled set: twice the input's
+        std::vector<int64_t> h((size_t)P + 1);
+        RFX_HIP(hipMemcpyAsync(h.data(), d_part_start, (size_t)(P + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        for (auto &x : h) x *= 2;
+        RFX_HIP(hipMemcpyAsync(out_part_start.p, h.data(), (size_t)(P + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        RFX_HIP(hipStreamSynchronize(ctx->stream));
+    }
     return RFX_OK;
 }
 

@@ -255,6 +255,11 @@ int random_reflection(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_
 int extend_pass(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start, int P, int k,
                 int twin, int stage, DevRecords &out, DevBuf &out_part_start, int start_marker = 2);
 
+// the k > 31 from-counts extras (P/ReflexivDSMain64.java:584-619, 672-712): op 0 DSReflexivAndForwardKmer (2n out),
+// 1 DSFilterExtendableKmerPairs, 2 DSFilterUnExtendableKmer, 3 DSFilterStillExtendableKmerFromPairs,
+// 4 DSFilterStillExtendableKmerEnds, 5 / 6 DSFilterUnExtendableKmerLeftEnds / ...RightEnds
+int extras_operator(rfx_ctx *ctx, int op, const DevRecords &in, const int64_t *d_part_start, int P, int k, DevRecords &out,
+                    DevBuf &out_part_start);
 // the rest of the driver's loop on <= small_pass_limit() records: two launches per pass, state in HBM (rfx_extend.hip)
 int small_passes(rfx_ctx *ctx, DevRecords &recs, int k, int twin, bool wide, int coalesce, int min_iter, int max_iter,
                  int *iterations, int64_t *contig_number, int *scramble, int *P, int *partition_number,

@@ -55,6 +55,10 @@ def main():
     out = {"workload": {"seed": seed, "genome": args.genome, "reads": args.reads, "read_len": L, "cover": args.cover,
                         "partitions": args.partitions, "err_per_2_32": 21474836},
            "made_by": "tests/golden/make_c2_full.py (oracle/reflexiv_oracle.c, threaded form)"}
+    if os.path.exists(args.out):                         # --ks 63 alone refreshes that record and keeps the others
+        old = json.load(open(args.out))
+        if old.get("workload") == out["workload"]:
+            out.update({k: v for k, v in old.items() if k.startswith("k")})
     for k in [int(x) for x in args.ks.split(",")]:
         keys, counts, nd, ni, hk, hc = count_in_passes(bases, off, k, args.cover, args.passes)
         rec = {"n_instances": ni, "n_distinct": nd, "n_kept": int(len(counts)), "sha256_keys": hk, "sha256_counts": hc}
@@ -66,7 +70,7 @@ def main():
             prm = O.default_params(k=k, min_cov=args.cover, partitions=args.partitions)
             text, nc, trace, _ = O.assemble_from_counts(O.counter_to_asm_w(keys, k), counts.astype(np.int32), prm)
         lens = sorted((int(h.split("-")[1]) for h in text.split("\n") if h.startswith(">")), reverse=True)
-        rec.update({"trace": trace, "n_contigs": nc, "sha256_contig_text": hashlib.sha256(text.encode()).hexdigest(),
+        rec.update({"extras": int(prm.extras) if k > 31 else None, "trace": trace, "n_contigs": nc, "sha256_contig_text": hashlib.sha256(text.encode()).hexdigest(),
                     "contig_lengths": lens, "contig_text_bytes": len(text)})
         print(f"  k={k}: assembled in {time.time() - t:.0f} s: {nc} contigs {lens[:4]}, {len(trace)} passes", flush=True)
         out[f"k{k}"] = rec

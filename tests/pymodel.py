@@ -245,7 +245,71 @@ def contigs_text_w(recs, min_contig):
     return "".join(out), idx
 
 
-def assemble_w(kmers, counts, k, P=4, min_err=8, min_iter=15, max_iter=150, trace=None):
+# from-counts extras of ReflexivDSMain64 (:584-619, :672-712), one function per operator class; records are
+# (key_str, marker, ext_str, left, right), inputs sorted by key, `starts` = logical partition starts
+
+def double_w(recs, sub):
+    """DSReflexivAndForwardKmer: every record, then the same sequence keyed at its other end"""
+    out = []
+    for r in recs:
+        out.append(r)
+        out.append(oriented(seq_of(r), 3 - r[1], sub, r[3], r[4]))
+    return out
+
+
+def _can_merge(s, h):
+    """the four conditions under which the extend pass would join current `s` and holder `h` (opposite markers)"""
+    a, b = (s[3], h[4]) if s[1] == 1 else (s[4], h[3])
+    return (a < 0 and b < 0) or (a >= 0 and b >= 0) or (a >= 0 and a - len(h[2]) >= 0) or (b >= 0 and b - len(s[2]) >= 0)
+
+
+def key_filter_w(op, recs, starts, sub):
+    """op: 'pairs' DSFilterExtendableKmerPairs, 'unext' DSFilterUnExtendableKmer, 'first' ...StillExtendableKmerFromPairs,
+    'longer' ...StillExtendableKmerEnds"""
+    out = []
+    fwd = lambda r: oriented(seq_of(r), 1, sub, r[3], r[4])
+    for p in range(len(starts) - 1):
+        holder = None
+        for s in recs[starts[p]:starts[p + 1]]:
+            if holder is None:
+                holder = s
+                continue
+            h = holder
+            if s[0] != h[0]:
+                if op != "pairs":
+                    out.append(h)
+                holder = s
+            elif op == "first":
+                out.append(h)
+                holder = None
+            elif op == "longer":
+                score = lambda r: len(r[2]) * 31 + ((len(r[2]) - 1) % 31 + 1)
+                out.append(h if score(h) >= score(s) else s)
+                holder = None
+            elif op == "pairs":
+                if s[1] != h[1] and _can_merge(s, h):
+                    f, r = (s, h) if s[1] == 1 else (h, s)
+                    out.append(f)               # the forward member as it is ...
+                    out.append(fwd(r))          # ... the reflected one turned forward
+                    holder = None
+                else:
+                    holder = s
+            else:                               # 'unext'
+                if s[1] != h[1] and _can_merge(s, h):
+                    holder = None
+                else:
+                    out.append(fwd(h) if h[1] == 2 else h)
+                    holder = s
+        if holder is not None:
+            out.append(holder)
+    return out
+
+
+def flip_all_w(recs, m, sub):
+    return [oriented(seq_of(r), m, sub, r[3], r[4]) for r in recs]
+
+
+def assemble_w(kmers, counts, k, P=4, min_err=8, min_iter=15, max_iter=150, trace=None, extras=False):
     """kmers: ascending ACGT strings.  Stop rule of :621-661: checks from min_iter + 3 on, the first repeat
     of the count switches param.scramble 2 -> 3 (every later pass starts its marker at 1), the second stops;
     the survivors are sorted by key before they become text (:714)."""
@@ -270,8 +334,16 @@ def assemble_w(kmers, counts, k, P=4, min_err=8, min_iter=15, max_iter=150, trac
     it += 1
     recs = one_pass(recs)
     last, scramble = 0, 2
+    unext = None
+    ps = lambda rr: partition_starts([r[0] for r in rr], P)
     while it <= max_iter:
         it += 1
+        if extras and it == min_iter + 3:
+            both = stable_sort(double_w(stable_sort(recs), sub))
+            pe = stable_sort(key_filter_w("pairs", both, ps(both), sub))
+            pu = stable_sort(key_filter_w("unext", both, ps(both), sub))
+            recs = key_filter_w("first", pe, ps(pe), sub)
+            unext = key_filter_w("first", pu, ps(pu), sub)
         if it >= min_iter + 3 and it % 3 == 0:
             if last == len(recs):
                 if scramble == 2:
@@ -280,4 +352,9 @@ def assemble_w(kmers, counts, k, P=4, min_err=8, min_iter=15, max_iter=150, trac
                     break
             last = len(recs)
         recs = one_pass(recs, 1 if scramble == 3 else 2)
+    if unext is not None:
+        recs = recs + unext
+        for m in (1, 2):
+            recs = stable_sort(flip_all_w(recs, m, sub))
+            recs = key_filter_w("longer", recs, ps(recs), sub)
     return stable_sort(recs)

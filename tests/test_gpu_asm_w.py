@@ -209,3 +209,85 @@ def test_resident_reads_to_contigs_w(rfx, torch_mod, k, G, n_reads, P):
     assert trace == otrace and nc == onc and text == otext
     lens = [int(h.split("-")[1]) for h in text.split("\n") if h.startswith(">")]
     assert max(lens) > 20_000
+
+
+# ---- the from-counts extras (P/ReflexivDSMain64.java:584-619, 672-712)
+
+def _before_extras(k, P, n_pass):
+    from tests.test_oracle_asm_w import state_before_extras
+    return state_before_extras(k, P, n_pass)
+
+
+@pytest.mark.parametrize("k,P,n_pass", [(63, 4, 13), (47, 3, 6), (33, 8, 9), (95, 2, 4)])
+def test_extras_operators_match_oracle(rfx, k, P, n_pass):
+    """every operator class of the extras through the C ABI against the oracle, each fed with the oracle's previous output"""
+    r = O.sort_records(_before_extras(k, P, n_pass))
+    ps = O.partition_starts(r.key, P)
+    d = O.double_records(r, k)
+    g, gps = rfx.extras_operator(0, r, ps, k)
+    same_records(g, d)
+    assert np.array_equal(gps, 2 * ps)
+    d = O.sort_records(d)
+    ps = O.partition_starts(d.key, P)
+    outs = []
+    for op in (O.OP_EXTENDABLE_PAIRS, O.OP_UNEXTENDABLE):
+        want, wps = O.key_filter(op, d, ps, k)
+        g, gps = rfx.extras_operator(op, d, ps, k)
+        same_records(g, want)
+        assert np.array_equal(gps, wps)
+        s = O.sort_records(want)
+        sps = O.partition_starts(s.key, P)
+        want2, wps2 = O.key_filter(O.OP_FIRST_OF_KEY, s, sps, k)
+        g2, gps2 = rfx.extras_operator(O.OP_FIRST_OF_KEY, s, sps, k)
+        same_records(g2, want2)
+        assert np.array_equal(gps2, wps2)
+        outs.append(want2)
+    a, b = outs
+    u = O.Records(np.concatenate([a.key, b.key]), np.concatenate([a.marker, b.marker]),
+                  np.concatenate([a.ext_off[:-1], b.ext_off + a.ext_off[-1]]), np.concatenate([a.ext, b.ext]),
+                  np.concatenate([a.left, b.left]), np.concatenate([a.right, b.right]))
+    for m, op in ((1, 5), (2, 6)):
+        want = O.flip_all(u, k, m)
+        g, _ = rfx.extras_operator(op, u, np.array([0, u.n], np.int64), k)
+        same_records(g, want)
+        u = O.sort_records(want)
+        ps = O.partition_starts(u.key, P)
+        want, wps = O.key_filter(O.OP_LONGER_OF_KEY, u, ps, k)
+        g, gps = rfx.extras_operator(O.OP_LONGER_OF_KEY, u, ps, k)
+        same_records(g, want)
+        assert np.array_equal(gps, wps)
+        u = want
+
+
+@pytest.mark.parametrize("k,P", [(63, 4), (47, 8), (33, 1)])
+@pytest.mark.parametrize("extras", [0, 1])
+def test_driver_w_with_and_without_extras(rfx, torch_mod, planted, k, P, extras):
+    import reflexiv_amd
+    torch = torch_mod
+    km, counts = filtered_kmers(planted["bases"], planted["read_off"], k, 2)
+    dk, dc = to_dev(torch, km), to_dev(torch, counts)
+    torch.cuda.synchronize()
+    text, nc, trace = rfx.assemble_w_dev(dk.data_ptr(), dc.data_ptr(), len(counts),
+                                         reflexiv_amd.default_params(k=k, min_cov=2, partitions=P, min_contig=100, extras=extras))
+    otext, onc, otrace, _ = O.assemble_from_counts(km, counts, O.default_params(k=k, min_cov=2, partitions=P, min_contig=100, extras=extras))
+    assert trace == otrace and nc == onc and text == otext
+
+
+def test_extras_on_a_large_record_set(rfx, torch_mod):
+    """the split happens while the record set is still large (big-pass kernels): 1.2 Mbp genome, k = 63"""
+    import reflexiv_amd
+    torch = torch_mod
+    seed, G, n_reads, L, k, cov, P = 9, 1_200_000, 320_000, 150, 63, 3, 8
+    O.set_threads(O.host_cores())
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+    wk, wc, _, _ = O.count_reads_omp(bases, off, k, cov, cap=1 << 23)
+    O.set_threads(1)
+    km = O.counter_to_asm_w(wk, k)
+    c32 = wc.astype(np.int32)
+    dk, dc = to_dev(torch, km), to_dev(torch, c32)
+    torch.cuda.synchronize()
+    text, nc, trace = rfx.assemble_w_dev(dk.data_ptr(), dc.data_ptr(), len(c32), reflexiv_amd.default_params(k=k, min_cov=cov, partitions=P))
+    otext, onc, otrace, _ = O.assemble_from_counts(km, c32, O.default_params(k=k, min_cov=cov, partitions=P))
+    assert trace == otrace and nc == onc and text == otext
+    assert trace[12] > 4096                       # the record set was beyond the small-pass kernel when it was split

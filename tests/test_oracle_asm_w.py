@@ -165,7 +165,7 @@ def test_operator_chain_matches_string_model(k, P, min_err):
 def test_driver_matches_string_model(k, P):
     bases, off = planted_reads()
     kmers, counts = kmers_of_reads(bases, off, k, 2)
-    prm = O.default_params(k=k, min_cov=2, partitions=P, min_contig=100)
+    prm = O.default_params(k=k, min_cov=2, partitions=P, min_contig=100, extras=0)
     text, nc, trace, rec = O.assemble_from_counts(binarize(kmers, k), np.asarray(counts, np.int32), prm)
     wtrace = []
     want = M.assemble_w(kmers, counts, k, P, prm.min_error_cov, prm.min_iter, prm.max_iter, trace=wtrace)
@@ -188,10 +188,85 @@ def test_scramble_gives_a_second_chance():
     k, P = 63, 4
     bases, off = planted_reads()
     kmers, counts = kmers_of_reads(bases, off, k, 2)
-    prm = O.default_params(k=k, min_cov=2, partitions=P, min_contig=100)
+    prm = O.default_params(k=k, min_cov=2, partitions=P, min_contig=100, extras=0)
     _, _, trace, _ = O.assemble_from_counts(binarize(kmers, k), np.asarray(counts, np.int32), prm)
     # checks happen at iterations 18, 21, ... = trace indices 13, 16, ... (trace[i] = count after pass i)
     checks = [trace[i] for i in range(prm.min_iter + 3 - 5, len(trace), 3)]
     repeats = [i for i in range(1, len(checks)) if checks[i] == checks[i - 1]]
     assert repeats, "the count must repeat at least once before the loop stops"
     assert len(trace) > (prm.min_iter + 3 - 5) + 3 * repeats[0]
+
+
+# ---- the from-counts extras (P/ReflexivDSMain64.java:584-619, 672-712)
+
+def state_before_extras(k, P, n_pass=13):
+    """records as the driver holds them when iteration minimumIteration + 3 starts (13 passes with the defaults)"""
+    bases, off = planted_reads()
+    kmers, counts = kmers_of_reads(bases, off, k, 2)
+    r = O.rc_expand_subkmer(binarize(kmers, k), np.asarray(counts, np.int32), k)
+    r = O.sort_records(r)
+    r, ops = O.fork_filter_forward(r, O.partition_starts(r.key, P), k, 8, O.TWIN_DS)
+    r = O.sort_records(O.reflect_from_forward(r, k))
+    r, ops = O.fork_filter_reflected(r, O.partition_starts(r.key, P), k, 8, O.TWIN_DS)
+    r = O.random_reflection(r, ops, k)
+    for _ in range(n_pass):
+        r = O.sort_records(r)
+        r, _ = O.extend_pass(r, O.partition_starts(r.key, P), k, O.TWIN_DS)
+    return r
+
+
+@pytest.mark.parametrize("k,P,n_pass", [(63, 4, 13), (47, 3, 6), (33, 8, 9), (95, 2, 4)])
+def test_extras_operators_match_string_model(k, P, n_pass):
+    sub = k - 1
+    r = O.sort_records(state_before_extras(k, P, n_pass))
+    want = M.stable_sort(to_model(r, sub))
+    assert to_model(r, sub) == want
+    d = O.double_records(r, k)
+    wd = M.double_w(want, sub)
+    assert to_model(d, sub) == wd and d.n == 2 * r.n
+    d = O.sort_records(d); wd = M.stable_sort(wd)
+    ps = O.partition_starts(d.key, P)
+    outs = {}
+    for op, name in ((O.OP_EXTENDABLE_PAIRS, "pairs"), (O.OP_UNEXTENDABLE, "unext")):
+        g, ops = O.key_filter(op, d, ps, k)
+        w = M.key_filter_w(name, wd, list(ps), sub)
+        assert to_model(g, sub) == w, name
+        outs[name] = (O.sort_records(g), M.stable_sort(w))
+    assert outs["pairs"][0].n > 0 and outs["unext"][0].n > 0
+    for name in ("pairs", "unext"):
+        g, w = outs[name]
+        ps = O.partition_starts(g.key, P)
+        f, _ = O.key_filter(O.OP_FIRST_OF_KEY, g, ps, k)
+        wf = M.key_filter_w("first", w, list(ps), sub)
+        assert to_model(f, sub) == wf
+        outs[name] = (f, wf)
+    u = O.Records(np.concatenate([outs["pairs"][0].key, outs["unext"][0].key]),
+                  np.concatenate([outs["pairs"][0].marker, outs["unext"][0].marker]),
+                  np.concatenate([outs["pairs"][0].ext_off[:-1], outs["unext"][0].ext_off + outs["pairs"][0].ext_off[-1]]),
+                  np.concatenate([outs["pairs"][0].ext, outs["unext"][0].ext]),
+                  np.concatenate([outs["pairs"][0].left, outs["unext"][0].left]),
+                  np.concatenate([outs["pairs"][0].right, outs["unext"][0].right]))
+    wu = outs["pairs"][1] + outs["unext"][1]
+    for m in (1, 2):
+        u = O.flip_all(u, k, m); wu = M.flip_all_w(wu, m, sub)
+        assert to_model(u, sub) == wu
+        u = O.sort_records(u); wu = M.stable_sort(wu)
+        ps = O.partition_starts(u.key, P)
+        u, _ = O.key_filter(O.OP_LONGER_OF_KEY, u, ps, k)
+        wu = M.key_filter_w("longer", wu, list(ps), sub)
+        assert to_model(u, sub) == wu
+
+
+@pytest.mark.parametrize("k,P", [(63, 4), (63, 8), (47, 4), (33, 1), (95, 4)])
+def test_driver_with_extras_matches_string_model(k, P):
+    bases, off = planted_reads()
+    kmers, counts = kmers_of_reads(bases, off, k, 2)
+    prm = O.default_params(k=k, min_cov=2, partitions=P, min_contig=100)
+    assert prm.extras == 1                       # the reference's from-counts driver always runs them
+    text, nc, trace, rec = O.assemble_from_counts(binarize(kmers, k), np.asarray(counts, np.int32), prm)
+    wtrace = []
+    want = M.assemble_w(kmers, counts, k, P, prm.min_error_cov, prm.min_iter, prm.max_iter, trace=wtrace, extras=True)
+    assert trace == wtrace
+    assert to_model(rec, k - 1) == want
+    assert (text, nc) == M.contigs_text_w(want, 100)
+    assert nc >= 1

@@ -369,6 +369,12 @@ int rfx_dev_assemble_w(rfx_ctx *ctx, const uint64_t *d_kmers, const int32_t *d_c
                        const rfx_params *prm, char *out, int64_t cap, int64_t *out_len,
                        int64_t *out_contigs, int64_t *trace, int64_t trace_cap, int64_t *n_trace);
 
+/* The same driver from HOST arrays (what `run -kmerc COUNTS -kmer 63` holds after KmerBinarizer and the count filter,
+ * P/ReflexivDSMain64.java:458-478): n k-mers of (k-1)/31+1 words each, ascending, with their int32 counts. */
+int rfx_assemble_counts_w(rfx_ctx *ctx, const uint64_t *kmers, const int32_t *counts, int64_t n,
+                          const rfx_params *prm, char *out, int64_t cap, int64_t *out_len,
+                          int64_t *out_contigs, int64_t *trace, int64_t trace_cap, int64_t *n_trace);
+
 /* The whole resident path from ASCII reads in host memory (any lengths) to the contig text:
  * upload, 2-bit encode, extract + count + filter (prm->min_cov .. max_cov), the driver above --
  * nothing but the reads goes up and nothing but the text comes back.  k <= 31.

@@ -55,7 +55,7 @@ SYMBOLS = [
     "rfx_dev_count_reads_ragged", "rfx_assemble_reads", "rfx_dev_bucket_wide_by_owner", "rfx_dev_count_wide_elems",
     "rfx_dev_combine_reads", "rfx_dev_bucket_pairs_by_owner", "rfx_dev_merge_pairs",
     "rfx_dev_bucket_wide_records_by_owner", "rfx_dev_count_wide_records",
-    "rfx_extras_operator", "rfx_extend_pass_w", "rfx_dev_counter_to_asm", "rfx_dev_assemble_w", "rfx_dev_order_kmers_w",
+    "rfx_extras_operator", "rfx_assemble_counts_w", "rfx_extend_pass_w", "rfx_dev_counter_to_asm", "rfx_dev_assemble_w", "rfx_dev_order_kmers_w",
 ]
 
 

@@ -347,6 +347,70 @@ std::string ReflexivMain::assemblyFromKmer(const std::string &csvText, std::vect
     return assemblyFromCounts(f, trace);
 }
 
+// KmerBinarizer.call  P/ReflexivDSMain64.java:10772-10836: the same row rules as above, the k-mer into words of 31 bases
+void ReflexivMain::KmerBinarizer64::call(const std::string &csvText, std::vector<uint64_t> &kmers, std::vector<int32_t> &counts) const {
+    const int k = m.param.kmerSize, W = (k - 1) / 31 + 1;                                 // kmerBinarySlotsAssemble
+    size_t pos = 0;
+    while (pos < csvText.size()) {
+        size_t e = csvText.find('\n', pos);
+        if (e == std::string::npos) e = csvText.size();
+        size_t l = e - pos;
+        if (l > 0 && csvText[e - 1] == '\r') l--;
+        std::string line = csvText.substr(pos, l);
+        pos = e + 1;
+        if (line.empty()) continue;
+        size_t comma = line.find(',');
+        if (comma == std::string::npos) throw std::runtime_error("k-mer count row without a comma: " + line);
+        std::string kmer = line.substr(0, comma), cnt = line.substr(comma + 1);
+        if (!kmer.empty() && kmer[0] == '(') kmer = kmer.substr(1);                       // :10790-10792
+        int cover;
+        if (!cnt.empty() && cnt.back() == ')') cover = cnt.size() >= 11 ? 1000000000 : std::stoi(cnt.substr(0, cnt.size() - 1));   // :10794-10799
+        else cover = cnt.size() >= 10 ? 1000000000 : std::stoi(cnt);                      // :10800-10806
+        if ((int)kmer.size() < k) throw std::runtime_error("k-mer shorter than -kmer: " + kmer);
+        const size_t at = kmers.size();
+        kmers.resize(at + (size_t)W, 0);
+        for (int i = 0; i < k; i++) {                                                     // :10811-10819
+            const char c = kmer[(size_t)i];
+            kmers[at + (size_t)(i / 31)] = (kmers[at + (size_t)(i / 31)] << 2) | (c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : 3u);
+        }
+        counts.push_back(cover);
+    }
+}
+
+// `run -kmerc COUNTS -kmer 63`: load -> filter(min <= count <= max) (:458-478) -> the k > 31 driver in one call.
+// The order contract wants the list ascending by base string, whatever order the files came in.
+std::string ReflexivMain::assemblyFromKmer64(const std::string &csvText, std::vector<int64_t> *trace) {
+    const int W = (param.kmerSize - 1) / 31 + 1;
+    std::vector<uint64_t> km; std::vector<int32_t> cn;
+    KmerBinarizer64{*this}.call(csvText, km, cn);
+    std::vector<size_t> idx;
+    for (size_t i = 0; i < cn.size(); i++)
+        if (cn[i] >= param.minKmerCoverage && cn[i] <= param.maxKmerCoverage) idx.push_back(i);
+    std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) {
+        return std::lexicographical_compare(km.begin() + a * W, km.begin() + (a + 1) * W, km.begin() + b * W, km.begin() + (b + 1) * W);
+    });
+    std::vector<uint64_t> fk; std::vector<int32_t> fc;
+    for (size_t i : idx) { fk.insert(fk.end(), km.begin() + i * W, km.begin() + (i + 1) * W); fc.push_back(cn[i]); }
+    rfx_params prm; rfx_default_params(&prm);
+    prm.k = param.kmerSize; prm.min_cov = param.minKmerCoverage; prm.max_cov = param.maxKmerCoverage;
+    prm.min_error_cov = param.minErrorCoverage; prm.min_contig = param.minContig; prm.min_iter = param.minimumIteration;
+    prm.max_iter = param.maximumIteration; prm.front_clip = param.frontClip; prm.end_clip = param.endClip;
+    prm.partitions = param.logicalPartitions;
+    std::vector<int64_t> tr((size_t)param.maximumIteration + 8);
+    int64_t nt = 0, nc = 0, len = 0;
+    std::string out((size_t)(4 * (fc.size() + 16) * (size_t)(param.kmerSize + 8) + 1024), '\0');
+    for (;;) {
+        const int st = rfx_assemble_counts_w(ctx, fk.data(), fc.data(), (int64_t)fc.size(), &prm, &out[0], (int64_t)out.size(), &len, &nc,
+                                             tr.data(), (int64_t)tr.size(), &nt);
+        if (st == RFX_E_CAP && len > (int64_t)out.size()) { out.resize((size_t)len); continue; }
+        check(st, "rfx_assemble_counts_w");
+        break;
+    }
+    out.resize((size_t)len);
+    if (trace) trace->assign(tr.begin(), tr.begin() + nt);
+    return out;
+}
+
 // P/ReflexivCounter.java:109-191: k-mer, count text lines
 std::string ReflexivMain::counter(const std::string &fastqText) {
     static const char NUC[4] = {'A', 'C', 'G', 'T'};

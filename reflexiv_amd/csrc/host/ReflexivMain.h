@@ -129,6 +129,13 @@ public:
         KmerBinaryRDD call(const std::string &csvText) const;
     };
     std::string assemblyFromKmer(const std::string &csvText, std::vector<int64_t> *trace = nullptr);
+    // k > 31: ReflexivDSMain64.assemblyFromKmer (P/ReflexivDSMain64.java:374-826) -- `run -kmerc COUNTS -kmer 63`.
+    // KmerBinarizer :10772-10836 writes kmerBinarySlotsAssemble = (k-1)/31+1 words of 31 bases per k-mer.
+    struct KmerBinarizer64 {
+        ReflexivMain &m;
+        void call(const std::string &csvText, std::vector<uint64_t> &kmers, std::vector<int32_t> &counts) const;
+    };
+    std::string assemblyFromKmer64(const std::string &csvText, std::vector<int64_t> *trace = nullptr);
 
     rfx_ctx *ctx = nullptr;
     DefaultParam param;

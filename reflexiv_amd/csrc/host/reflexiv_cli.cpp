@@ -58,6 +58,14 @@ int main(int argc, char **argv) {
         mkdir(dir.c_str(), 0755);
         if (cmd == "run") {
             // M/Main.java:74-78 -> Pipelines.reflexivDSMainPipe(): -kmerc routes to assemblyFromKmer()
+            // k > 31: Pipelines.reflexivDSMainPipe64() -> ReflexivDSMain64.assemblyFromKmer(), output under Assemble_<k>
+            // (P/ReflexivDSMain64.java:820-824); only the from-counts route exists for k > 31
+            if (param.kmerSize > 31) {
+                if (param.inputKmerPath.empty()) throw std::runtime_error("-kmer > 31 needs -kmerc (counter -> run -kmerc; the reference's run -fastq is inconsistent for k > 31)");
+                out = m.assemblyFromKmer64(read_all(param.inputKmerPath));
+                dir += "/Assemble_" + std::to_string(param.kmerSize);
+                mkdir(dir.c_str(), 0755);
+            } else
             out = !param.inputKmerPath.empty() ? m.assemblyFromKmer(read_all(param.inputKmerPath))
                   : param.resident          ? m.assemblyResident(read_all(param.inputFqPath))
                                             : m.assembly(read_all(param.inputFqPath));

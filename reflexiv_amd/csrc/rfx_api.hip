@@ -39,6 +39,12 @@ int download_part_start(rfx_ctx *ctx, const DevBuf &d, int P, int64_t *h) {
 int64_t contigs_text_host(const rfx_records *r, int k, int min_contig, int twin, char *out, int64_t cap,
                           int64_t *n_contigs) {
     static const char NUC[4] = {'A', 'C', 'G', 'T'};
+    static char QUAD[256][4];
+    static bool quad_ready = false;
+    if (!quad_ready) {
+        for (int b = 0; b < 256; b++) for (int j = 0; j < 4; j++) QUAD[b][j] = NUC[(b >> (6 - 2 * j)) & 3];
+        quad_ready = true;
+    }
     const int sub = k - 1;
     const int kw = r->key_words > 1 ? r->key_words : 1;
     if (k > 31) twin = RFX_TWIN_RDD;
@@ -74,9 +80,11 @@ int64_t contigs_text_host(const rfx_records *r, int k, int min_contig, int twin,
         int64_t o = 0;
         for (int j = 0; j < f; j++) e[o++] = NUC[(w[0] >> (2 * (f - 1 - j))) & 3];                 // :713-718
         for (int64_t x = 1; x < nw; x++) {                                                         // :720-729
-            const uint64_t v = w[x];
+            // 31 bases per word, four at a time through a byte table (a 2.6 Mbp contig is 84 K words)
+            const uint64_t v = w[x] << 2;                                  // first base in the top pair
             char *q = e + o;
-            for (int j = 0; j < 31; j++) q[j] = NUC[(v >> (2 * (30 - j))) & 3];
+            for (int j = 0; j < 7; j++) memcpy(q + 4 * j, QUAD[(v >> (56 - 8 * j)) & 255], 4);
+            memcpy(q + 28, QUAD[v & 255], 3);
             o += 31;
         }
         char hdr[96];
@@ -1017,6 +1025,25 @@ int rfx_dev_assemble_w(rfx_ctx *ctx, const uint64_t *d_kmers, const int32_t *d_c
                        const rfx_params *prm, char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs,
                        int64_t *trace, int64_t trace_cap, int64_t *n_trace) {
     return assemble_impl(ctx, true, d_kmers, d_counts, n, prm, out, cap, out_len, out_contigs, trace, trace_cap, n_trace);
+}
+
+int rfx_assemble_counts_w(rfx_ctx *ctx, const uint64_t *kmers, const int32_t *counts, int64_t n, const rfx_params *prm,
+                          char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs, int64_t *trace, int64_t trace_cap,
+                          int64_t *n_trace) {
+    if (!ctx || !prm || !out_len || n < 0 || (n > 0 && (!kmers || !counts))) return RFX_E_ARG;
+    RFX_TRY(check_k_rec(prm->k));
+    if (prm->k <= 31) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    const int aw = asm_words(prm->k);
+    DevBuf dk, dc;
+    RFX_HIP(dk.alloc((size_t)std::max<int64_t>(n, 1) * 8 * aw, ctx->stream));
+    RFX_HIP(dc.alloc((size_t)std::max<int64_t>(n, 1) * 4, ctx->stream));
+    if (n > 0) {
+        RFX_HIP(hipMemcpyAsync(dk.p, kmers, (size_t)n * 8 * aw, hipMemcpyHostToDevice, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(dc.p, counts, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        RFX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return assemble_impl(ctx, true, dk.as<uint64_t>(), dc.as<int32_t>(), n, prm, out, cap, out_len, out_contigs, trace, trace_cap, n_trace);
 }
 
 int rfx_dev_order_kmers_w(rfx_ctx *ctx, uint64_t *d_keys, int64_t *d_counts, int64_t n, int k) {

@@ -291,3 +291,36 @@ def test_extras_on_a_large_record_set(rfx, torch_mod):
     otext, onc, otrace, _ = O.assemble_from_counts(km, c32, O.default_params(k=k, min_cov=cov, partitions=P))
     assert trace == otrace and nc == onc and text == otext
     assert trace[12] > 4096                       # the record set was beyond the small-pass kernel when it was split
+
+
+def test_cpp_host_counter_then_run_kmerc_k63(tmp_path, planted):
+    """the only working k > 31 route of the reference: `counter -kmer 63` writes "KMER,count"
+    rows (P/ReflexivDataFrameCounter64.java:222-233), `run -kmerc ... -kmer 63` parses them into 31-base words
+    (KmerBinarizer, P/ReflexivDSMain64.java:10772-10836) and assembles (assemblyFromKmer :374-826) into
+    <outfile>/Assemble_63 -- through the C++ mirror of the driver; rows shuffled and in the legacy tuple text."""
+    import subprocess
+    import reflexiv_amd._lib as L
+    host = os.path.join(os.path.dirname(L.LIB_PATH), "reflexiv_host")
+    k = 63
+    fq = str(tmp_path / "p.fq")
+    bases, off = planted["bases"], planted["read_off"]
+    with open(fq, "w") as f:
+        for i in range(len(off) - 1):
+            s = bytes(bases[off[i]:off[i + 1]]).decode()
+            f.write(f"@r{i}\n{s}\n+\n{'I' * len(s)}\n")
+    out = str(tmp_path / "cnt")
+    subprocess.check_call([host, "counter", "-fastq", fq, "-outfile", out, "-kmer", str(k), "-cover", "2"])
+    cdir = os.path.join(out, f"Count_{k}")
+    lines = open(os.path.join(cdir, "part-00000.csv")).read().split("\n")[:-1]
+    wk, wc, _ = O.count_filter_w(O.extract_canon_w(bases, off, k), k, 2)
+    assert lines == [O.kmer_text_w(a, k) + "," + str(int(c)) for a, c in zip(wk, wc)]
+    rng = np.random.default_rng(1)
+    legacy = ["(" + l + ")" for l in lines]
+    rng.shuffle(legacy)
+    open(os.path.join(cdir, "part-00000.csv"), "w").write("\n".join(legacy) + "\n")
+    res = str(tmp_path / "asm")
+    subprocess.check_call([host, "run", "-kmerc", cdir, "-outfile", res, "-kmer", str(k), "-cover", "2", "-mincontig", "100",
+                           "--logical-partitions", "4"])
+    want, _, _, _ = O.assemble_from_counts(O.counter_to_asm_w(wk, k), wc.astype(np.int32),
+                                           O.default_params(k=k, min_cov=2, partitions=4, min_contig=100))
+    assert open(os.path.join(res, f"Assemble_{k}", "part-00000")).read() == want

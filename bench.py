@@ -79,6 +79,10 @@ def parse():
                          "hides the flight of the next).  auto: records from 8 GPUs on (a peer's share per link is small), "
                          "pairs below")
     ap.add_argument("--generations", type=int, default=4, help="--exchange records: generations of the hash space")
+    ap.add_argument("--sharded-extend", action="store_true",
+                    help="N > 1 (or --force-dist): run the extend stage range-sharded over the ranks with the records resident "
+                         "in HBM (reflexiv_amd.dist.sharded_assemble_dev: one RCCL all-to-all of whole records per sortByKey) "
+                         "instead of gathering the survivors on rank 0 -- what a genome beyond one GPU needs; k <= 31")
     args = ap.parse_args()
     if args.gbp is None:
         args.gbp = 5.0 if args.gpus == 1 else 6.25
@@ -314,6 +318,25 @@ def main():
                            "bytes_per_instance": B / n_inst, "bytes_leaving_per_gpu_per_step": B * (world - 1) / world,
                            "per_link_floor_ms_at_153GBps": B / world / 153e9 * 1e3 if world > 1 else 0.0,
                            "chunks": 1 if (args.exchange == "records" and not wide) else max(args.exchange_chunks, int(est_chunks) + 1)}
+    if multi and not args.no_contigs and args.sharded_extend and not wide:
+        # every sortByKey of the loop = local sort + splitters + ONE all-to-all of whole records + local sort, records in HBM
+        prm = reflexiv_amd.default_params(k=k, min_cov=args.cover, partitions=max(args.partitions, world))
+        ops = rd.HipDevOps(rfx)
+        sk, sc = shard["keys"].contiguous(), shard["counts"].contiguous()
+        rd.sharded_assemble_dev(ops, sk, sc, prm, force_exchange=args.force_dist)          # untimed warm-up, as below
+        sync_all()
+        t1 = time.perf_counter()
+        tr = []
+        text, nc = rd.sharded_assemble_dev(ops, sk, sc, prm, trace=tr, force_exchange=args.force_dist)
+        sync_all()
+        t_asm = time.perf_counter() - t1
+        if rank == 0:
+            lens = sorted((int(h.split("-")[1]) for h in text.split("\n") if h.startswith(">")), reverse=True)
+            out["contigs"] = {"driver": "range-sharded over the ranks, records resident in HBM (dist.sharded_assemble_dev)",
+                              "wall_ms_from_counts": t_asm * 1e3, "wall_ms_reads_to_contigs": t_asm * 1e3 + dt / args.steps * 1e3,
+                              "untimed_warmup_runs": 1, "extend_passes": len(tr), "n_contigs": nc, "longest": lens[:3],
+                              "total_bases": sum(lens)}
+        args.no_contigs = True
     if multi and not args.no_contigs:
         # the filtered list is small: gather it on rank 0, restore ascending k-mer order there
         # and run the extend stage on that one GPU

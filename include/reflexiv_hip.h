@@ -339,6 +339,28 @@ int rfx_dev_merge_pairs(rfx_ctx *ctx, const void *d_pairs, int64_t n_pairs, int 
                         uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n,
                         int64_t *out_distinct);
 
+/* ---- the record operators on sets that STAY in HBM (the multi-GPU extend stage: reflexiv_amd/dist.py puts the RCCL
+ * all-to-all of whole records between them).  Same operators, same reference classes as the host
+ * entry points above; here every pointer inside rfx_records, every part_start and the k-mer / count arrays are DEVICE
+ * pointers.  Inputs: in->n records, in->need_words = ext_off[n] (the value the producing call reported), key_words
+ * as above.  Outputs: caller-allocated arrays of cap_n records / cap_words words (ext_off: cap_n + 1); on return
+ * n / need_n / need_words are set (host fields); RFX_E_CAP when a capacity is short.  All run on the context's stream
+ * and return after it has drained. */
+int rfx_dev_rc_expand_subkmer(rfx_ctx *ctx, const uint64_t *d_kmers, const int32_t *d_counts, int64_t n, int k,
+                              rfx_records *d_out);
+int rfx_dev_sort_records(rfx_ctx *ctx, const rfx_records *d_in, int P, int k, rfx_records *d_out, int64_t *d_part_start);
+int rfx_dev_fork_filter(rfx_ctx *ctx, int reflected, const rfx_records *d_in, const int64_t *d_part_start, int P, int k,
+                        int min_error_cov, int twin, rfx_records *d_out, int64_t *d_out_part_start);
+int rfx_dev_reflect_from_forward(rfx_ctx *ctx, const rfx_records *d_in, int k, rfx_records *d_out);
+int rfx_dev_random_reflection(rfx_ctx *ctx, const rfx_records *d_in, const int64_t *d_part_start, int P, int k,
+                              rfx_records *d_out);
+int rfx_dev_extend_pass(rfx_ctx *ctx, const rfx_records *d_in, const int64_t *d_part_start, int P, int k, int twin,
+                        int stage, int scramble, rfx_records *d_out, int64_t *d_out_part_start);
+/* positions of m values in n ascending one-word keys: d_out[j] = number of keys < values[j] (upper = 0) or <= (upper = 1)
+ * -- the splitter search of the range shuffle that stands in for sortByKey's range partitioner */
+int rfx_dev_lower_bound(rfx_ctx *ctx, const uint64_t *d_sorted_keys, int64_t n, const uint64_t *d_values, int64_t m,
+                        int upper, int64_t *d_out);
+
 /* Whole driver  P/ReflexivMain.java:168-310 (DS :221-352) from the filtered, ascending
  * (kmer,count) list in HBM to the contig text in host memory.  trace (optional) receives
  * the record count after every extend pass. */

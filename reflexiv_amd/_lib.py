@@ -55,7 +55,8 @@ SYMBOLS = [
     "rfx_dev_count_reads_ragged", "rfx_assemble_reads", "rfx_dev_bucket_wide_by_owner", "rfx_dev_count_wide_elems",
     "rfx_dev_combine_reads", "rfx_dev_bucket_pairs_by_owner", "rfx_dev_merge_pairs",
     "rfx_dev_bucket_wide_records_by_owner", "rfx_dev_count_wide_records",
-    "rfx_extras_operator", "rfx_assemble_counts_w", "rfx_extend_pass_w", "rfx_dev_counter_to_asm", "rfx_dev_assemble_w", "rfx_dev_order_kmers_w",
+    "rfx_extras_operator", "rfx_assemble_counts_w", "rfx_dev_rc_expand_subkmer", "rfx_dev_sort_records", "rfx_dev_fork_filter",
+    "rfx_dev_reflect_from_forward", "rfx_dev_random_reflection", "rfx_dev_extend_pass", "rfx_dev_lower_bound", "rfx_extend_pass_w", "rfx_dev_counter_to_asm", "rfx_dev_assemble_w", "rfx_dev_order_kmers_w",
 ]
 
 

@@ -527,6 +527,145 @@ int rfx_contigs_text(rfx_ctx *ctx, const rfx_records *in, int k, int min_contig,
     return len > cap ? RFX_E_CAP : RFX_OK;
 }
 
+// ------------------------------------------------------------ record operators on device-resident sets
+
+namespace {
+
+void wrap_dev(rfx_ctx *ctx, const rfx_records *d, DevRecords &r) {
+    r.kw = d->key_words > 1 ? d->key_words : 1;
+    r.n = d->n; r.words = d->need_words;
+    DevBuf *bufs[6] = {&r.key, &r.marker, &r.ext_off, &r.ext, &r.left, &r.right};
+    void *ptrs[6] = {d->key, d->marker, d->ext_off, d->ext, d->left, d->right};
+    for (int i = 0; i < 6; i++) { bufs[i]->release(); bufs[i]->p = ptrs[i]; bufs[i]->borrowed = true; bufs[i]->s = ctx->stream; }
+}
+
+int copy_out_dev(rfx_ctx *ctx, const DevRecords &o, rfx_records *d) {
+    d->need_n = o.n; d->need_words = o.words; d->key_words = o.kw;
+    if (o.n > d->cap_n || o.words > d->cap_words) return RFX_E_CAP;
+    const int64_t n = o.n;
+    if (n > 0) {
+        RFX_HIP(hipMemcpyAsync(d->key, o.key.p, (size_t)n * 8 * o.kw, hipMemcpyDeviceToDevice, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(d->marker, o.marker.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(d->left, o.left.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(d->right, o.right.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (o.words > 0) RFX_HIP(hipMemcpyAsync(d->ext, o.ext.p, (size_t)o.words * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    RFX_HIP(hipMemcpyAsync(d->ext_off, o.ext_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    d->n = n;
+    return RFX_OK;
+}
+
+int copy_ps_dev(rfx_ctx *ctx, const DevBuf &ps, int P, int64_t *d_dst) {
+    if (!d_dst) return RFX_OK;
+    RFX_HIP(hipMemcpyAsync(d_dst, ps.p, (size_t)(P + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    return RFX_OK;
+}
+
+__global__ void k_lower_bound(const uint64_t *__restrict__ keys, int64_t n, const uint64_t *__restrict__ values, int64_t m,
+                              int upper, int64_t *__restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint64_t v = values[j];
+    int64_t lo = 0, hi = n;                            // first index with key >= v (upper: > v)
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const uint64_t kk = keys[mid];
+        if (upper ? kk <= v : kk < v) lo = mid + 1; else hi = mid;
+    }
+    out[j] = lo;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rfx_dev_rc_expand_subkmer(rfx_ctx *ctx, const uint64_t *d_kmers, const int32_t *d_counts, int64_t n, int k, rfx_records *d_out) {
+    if (!ctx || n < 0 || !d_out) return RFX_E_ARG;
+    RFX_TRY(check_k_rec(k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    DevRecords o;
+    RFX_TRY(rc_expand_subkmer(ctx, d_kmers, d_counts, n, k, o));
+    return copy_out_dev(ctx, o, d_out);
+}
+
+int rfx_dev_sort_records(rfx_ctx *ctx, const rfx_records *d_in, int P, int k, rfx_records *d_out, int64_t *d_part_start) {
+    if (!ctx || !d_in || !d_out || P < 1) return RFX_E_ARG;
+    RFX_TRY(check_k_rec(k));
+    RFX_TRY(check_kw(d_in, k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    DevRecords in, o;
+    DevBuf ps;
+    wrap_dev(ctx, d_in, in);
+    RFX_TRY(sort_records(ctx, in, P, 2 * (k - 1), o, ps, k));
+    RFX_TRY(copy_out_dev(ctx, o, d_out));
+    return copy_ps_dev(ctx, ps, P, d_part_start);
+}
+
+int rfx_dev_fork_filter(rfx_ctx *ctx, int reflected, const rfx_records *d_in, const int64_t *d_part_start, int P, int k,
+                        int min_error_cov, int twin, rfx_records *d_out, int64_t *d_out_part_start) {
+    if (!ctx || !d_in || !d_out || !d_part_start || P < 1) return RFX_E_ARG;
+    RFX_TRY(check_k_rec(k));
+    RFX_TRY(check_kw(d_in, k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    DevRecords in, o;
+    DevBuf ops;
+    wrap_dev(ctx, d_in, in);
+    RFX_TRY(fork_filter(ctx, reflected != 0, in, d_part_start, P, k, min_error_cov, twin, o, ops));
+    RFX_TRY(copy_out_dev(ctx, o, d_out));
+    return copy_ps_dev(ctx, ops, P, d_out_part_start);
+}
+
+int rfx_dev_reflect_from_forward(rfx_ctx *ctx, const rfx_records *d_in, int k, rfx_records *d_out) {
+    if (!ctx || !d_in || !d_out) return RFX_E_ARG;
+    RFX_TRY(check_k_rec(k));
+    RFX_TRY(check_kw(d_in, k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    DevRecords in, o;
+    wrap_dev(ctx, d_in, in);
+    RFX_TRY(reflect_from_forward(ctx, in, k, o));
+    return copy_out_dev(ctx, o, d_out);
+}
+
+int rfx_dev_random_reflection(rfx_ctx *ctx, const rfx_records *d_in, const int64_t *d_part_start, int P, int k, rfx_records *d_out) {
+    if (!ctx || !d_in || !d_out || !d_part_start || P < 1) return RFX_E_ARG;
+    RFX_TRY(check_k_rec(k));
+    RFX_TRY(check_kw(d_in, k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    DevRecords in, o;
+    wrap_dev(ctx, d_in, in);
+    RFX_TRY(random_reflection(ctx, in, d_part_start, P, k, o));
+    return copy_out_dev(ctx, o, d_out);
+}
+
+int rfx_dev_extend_pass(rfx_ctx *ctx, const rfx_records *d_in, const int64_t *d_part_start, int P, int k, int twin, int stage,
+                        int scramble, rfx_records *d_out, int64_t *d_out_part_start) {
+    if (!ctx || !d_in || !d_out || !d_part_start || P < 1 || stage < 0 || stage > 2 || (scramble != 2 && scramble != 3)) return RFX_E_ARG;
+    RFX_TRY(check_k_rec(k));
+    RFX_TRY(check_kw(d_in, k));
+    RFX_HIP(hipSetDevice(ctx->device));
+    DevRecords in, o;
+    DevBuf ops;
+    wrap_dev(ctx, d_in, in);
+    RFX_TRY(extend_pass(ctx, in, d_part_start, P, k, k > 31 ? RFX_TWIN_DS : twin, stage, o, ops, scramble == 3 ? 1 : 2));
+    RFX_TRY(copy_out_dev(ctx, o, d_out));
+    return copy_ps_dev(ctx, ops, P, d_out_part_start);
+}
+
+int rfx_dev_lower_bound(rfx_ctx *ctx, const uint64_t *d_sorted_keys, int64_t n, const uint64_t *d_values, int64_t m, int upper,
+                        int64_t *d_out) {
+    if (!ctx || n < 0 || m < 0 || (m > 0 && (!d_values || !d_out)) || (n > 0 && !d_sorted_keys)) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    if (m == 0) return RFX_OK;
+    hipLaunchKernelGGL(k_lower_bound, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx->stream, d_sorted_keys, n, d_values, m, upper, d_out);
+    RFX_HIP(hipGetLastError());
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    return RFX_OK;
+}
+
+}  // extern "C"
+
 // ------------------------------------------------------------ device pipeline
 
 int rfx_dev_encode_reads(rfx_ctx *ctx, const uint8_t *d_bases, const int64_t *d_read_off, int64_t n_reads,

@@ -696,3 +696,284 @@ def sharded_assemble(ops, keys: np.ndarray, counts: np.ndarray, prm, group=None,
         off = np.concatenate([[0], np.cumsum(fields["len"])]).astype(np.int64)
         r = ops.make(fields["key"], fields["marker"], off, fields["ext"], fields["left"], fields["right"])
     return ops.contigs_text(r, k, prm.min_contig, twin)
+
+
+# ----------------------------------------------------------------------------------------------
+# The same range-sharded extend stage with the records RESIDENT in HBM: record sets are torch tensors on the rank's
+# GPU, every operator is a device-level C-ABI call (rfx_dev_*, include/reflexiv_hip.h), the splitter search is
+# rfx_dev_lower_bound on the locally sorted keys (eight key bits per round: 255 candidates per boundary, one
+# all-reduce of the counts), and the shuffle is all_to_all_single on the device tensors -- nothing but a few
+# boundary values and counts ever visits the host.  What C5-scale inputs need (6e9 records do not fit one GPU and
+# cannot be staged through numpy).  The driver below is written against an `ops` object and plain tensor slicing, so
+# the CPU test-suite runs it on 2 / 4 gloo ranks with an oracle-backed stand-in (tests/test_dist_gloo.py) and the GPU
+# suite runs it with the real operators on a one-rank RCCL group.
+
+from dataclasses import dataclass
+
+
+@dataclass
+class TRecs:
+    """a record set as tensors on one device (reference layout; key: int64 bit patterns, kw words per record)"""
+    key: torch.Tensor
+    marker: torch.Tensor
+    ext_off: torch.Tensor
+    ext: torch.Tensor
+    left: torch.Tensor
+    right: torch.Tensor
+    n: int
+    words: int
+    kw: int = 1
+
+
+class HipDevOps:
+    """device-level record operators of libreflexiv_hip.so on TRecs (every tensor on the context's GPU)"""
+
+    def __init__(self, rfx):
+        self.rfx = rfx
+        import ctypes as C
+        from ._lib import CRecords
+        self.C, self.CRecords = C, CRecords
+
+    def _c(self, r: TRecs):
+        c = self.CRecords()
+        c.n, c.need_words, c.key_words = r.n, r.words, r.kw
+        c.key, c.marker, c.ext_off = r.key.data_ptr(), r.marker.data_ptr(), r.ext_off.data_ptr()
+        c.ext, c.left, c.right = r.ext.data_ptr(), r.left.data_ptr(), r.right.data_ptr()
+        c.cap_n, c.cap_words = int(r.marker.numel()), int(r.ext.numel())
+        return c
+
+    def _empty(self, dev, cap_n, cap_words, kw):
+        cap_n, cap_words = max(1, cap_n), max(1, cap_words)
+        i64, i32 = torch.int64, torch.int32
+        return TRecs(torch.empty(cap_n * kw, dtype=i64, device=dev), torch.empty(cap_n, dtype=i32, device=dev),
+                     torch.empty(cap_n + 1, dtype=i64, device=dev), torch.empty(cap_words, dtype=i64, device=dev),
+                     torch.empty(cap_n, dtype=i32, device=dev), torch.empty(cap_n, dtype=i32, device=dev), 0, 0, kw)
+
+    def _trim(self, o: TRecs, c):
+        n, w = int(c.n), int(c.need_words)
+        return TRecs(o.key[:n * o.kw], o.marker[:n], o.ext_off[:n + 1], o.ext[:w], o.left[:n], o.right[:n], n, w, o.kw)
+
+    def _run(self, name, fn, *args):
+        torch.cuda.current_stream().synchronize()
+        self.rfx._check(fn(self.rfx.ctx, *args), name)
+
+    def make(self, key, marker, ext_off, ext, left, right, kw=1):
+        n = int(marker.numel())
+        return TRecs(key.contiguous(), marker.contiguous(), ext_off.contiguous(), ext.contiguous(), left.contiguous(),
+                     right.contiguous(), n, int(ext.numel()), kw)
+
+    def sort_pairs(self, keys, counts, k):
+        keys, counts = keys.contiguous().clone(), counts.contiguous().clone()
+        tk, tc = torch.empty_like(keys), torch.empty_like(counts)
+        torch.cuda.current_stream().synchronize()
+        self.rfx.sort_pairs_dev(keys.data_ptr(), counts.data_ptr(), int(keys.numel()), 2 * k, tk.data_ptr(), tc.data_ptr())
+        self.rfx.sync()
+        return keys, counts
+
+    def rc_expand(self, keys, counts, k):
+        from .api import sub_words
+        n = int(counts.numel())
+        o = self._empty(keys.device, 2 * n, 2 * n, sub_words(k))
+        c = self._c(o)
+        self._run("rfx_dev_rc_expand_subkmer", self.rfx.L.rfx_dev_rc_expand_subkmer, self.C.c_void_p(keys.data_ptr()),
+                  self.C.c_void_p(counts.data_ptr()), self.C.c_int64(n), k, self.C.byref(c))
+        return self._trim(o, c)
+
+    def sort(self, r: TRecs, k):
+        o = self._empty(r.marker.device, r.n, r.words, r.kw)
+        ci, co = self._c(r), self._c(o)
+        self._run("rfx_dev_sort_records", self.rfx.L.rfx_dev_sort_records, self.C.byref(ci), 1, k, self.C.byref(co), None)
+        return self._trim(o, co)
+
+    def _with_ps(self, name, fn, r, ps, pre, post):
+        P = int(ps.numel()) - 1
+        o = self._empty(r.marker.device, r.n, r.words, r.kw)
+        ops = torch.empty(P + 1, dtype=torch.int64, device=r.marker.device)
+        ci, co = self._c(r), self._c(o)
+        self._run(name, fn, *pre, self.C.byref(ci), self.C.c_void_p(ps.data_ptr()), P, *post, self.C.byref(co),
+                  self.C.c_void_p(ops.data_ptr()))
+        return self._trim(o, co), ops
+
+    def fork_forward(self, r, ps, k, min_err, twin):
+        return self._with_ps("rfx_dev_fork_filter", self.rfx.L.rfx_dev_fork_filter, r, ps, (0,), (k, min_err, twin))
+
+    def fork_reflected(self, r, ps, k, min_err, twin):
+        return self._with_ps("rfx_dev_fork_filter", self.rfx.L.rfx_dev_fork_filter, r, ps, (1,), (k, min_err, twin))
+
+    def reflect(self, r, k):
+        o = self._empty(r.marker.device, r.n, r.words, r.kw)
+        ci, co = self._c(r), self._c(o)
+        self._run("rfx_dev_reflect_from_forward", self.rfx.L.rfx_dev_reflect_from_forward, self.C.byref(ci), k, self.C.byref(co))
+        return self._trim(o, co)
+
+    def random_reflection(self, r, ps, k):
+        P = int(ps.numel()) - 1
+        o = self._empty(r.marker.device, r.n, r.words, r.kw)
+        ci, co = self._c(r), self._c(o)
+        self._run("rfx_dev_random_reflection", self.rfx.L.rfx_dev_random_reflection, self.C.byref(ci),
+                  self.C.c_void_p(ps.data_ptr()), P, k, self.C.byref(co))
+        return self._trim(o, co)
+
+    def extend_pass(self, r, ps, k, twin, stage):
+        return self._with_ps("rfx_dev_extend_pass", self.rfx.L.rfx_dev_extend_pass, r, ps, (), (k, twin, stage, 2))
+
+    def lower_bound(self, sorted_keys, values, upper):
+        out = torch.empty(int(values.numel()), dtype=torch.int64, device=sorted_keys.device)
+        self._run("rfx_dev_lower_bound", self.rfx.L.rfx_dev_lower_bound, self.C.c_void_p(sorted_keys.data_ptr()),
+                  self.C.c_int64(int(sorted_keys.numel())), self.C.c_void_p(values.data_ptr()), self.C.c_int64(int(values.numel())),
+                  1 if upper else 0, self.C.c_void_p(out.data_ptr()))
+        return out
+
+    def contigs_text(self, r: TRecs, k, min_contig, twin):
+        from .api import Records
+        h = Records(r.key.cpu().numpy().view(np.uint64), r.marker.cpu().numpy(), r.ext_off.cpu().numpy(),
+                    r.ext.cpu().numpy().view(np.uint64), r.left.cpu().numpy(), r.right.cpu().numpy())
+        return self.rfx.KmerToContig(h, k, min_contig, twin)
+
+
+def _allreduce_t(t: torch.Tensor, group=None) -> torch.Tensor:
+    if dist.is_initialized():
+        dist.all_reduce(t, group=group)
+    return t
+
+
+def splitters_t(ops, sorted_keys: torch.Tensor, P: int, key_bits: int, group=None):
+    """splitters() on a device tensor of locally sorted one-word keys: eight key bits per round -- 255 candidate
+    values per boundary, their local positions by ops.lower_bound, one all-reduce of the counts.  -> (v uint64[P-1],
+    incl bool[P-1], global count)"""
+    dev = sorted_keys.device
+    n_glob = int(_allreduce_t(torch.tensor([int(sorted_keys.numel())], dtype=torch.int64, device=dev), group).item())
+    q = np.array([(p * n_glob) // P for p in range(1, P)], np.int64)
+    v = np.zeros(P - 1, np.uint64)
+    if n_glob == 0 or P == 1:
+        return v, np.ones(P - 1, bool), n_glob
+    levels = (key_bits + 7) // 8
+    steps = np.arange(1, 256, dtype=np.uint64)
+    for lvl in range(levels - 1, -1, -1):
+        shift = np.uint64(8 * lvl)
+        cand = (v[:, None] | (steps[None, :] << shift)).reshape(-1)                 # ascending per boundary
+        ct = torch.from_numpy(cand.view(np.int64).copy()).to(dev)
+        cnt = _allreduce_t(ops.lower_bound(sorted_keys, ct, False), group).cpu().numpy().reshape(P - 1, 255)
+        sel = (cnt <= q[:, None]).sum(axis=1).astype(np.uint64)                      # the largest candidate that still fits
+        v = v | (sel << shift)
+    vt = torch.from_numpy(v.view(np.int64).copy()).to(dev)
+    c_lt = _allreduce_t(ops.lower_bound(sorted_keys, vt, False), group).cpu().numpy()
+    return v, c_lt == q, n_glob
+
+
+def _local_bounds_t(ops, sorted_keys, v, incl):
+    dev = sorted_keys.device
+    vt = torch.from_numpy(v.view(np.int64).copy()).to(dev)
+    lo = ops.lower_bound(sorted_keys, vt, False).cpu().numpy()
+    hi = ops.lower_bound(sorted_keys, vt, True).cpu().numpy()
+    return np.where(incl, lo, hi).astype(np.int64)
+
+
+def _exchange_t(t: torch.Tensor, cuts, group=None):
+    """slices [cuts[d], cuts[d+1]) of t to rank d -> what every rank sent here, in rank order (one tensor)"""
+    counts = [int(cuts[d + 1] - cuts[d]) for d in range(len(cuts) - 1)]
+    recv, _ = _alltoallv(t[int(cuts[0]):int(cuts[-1])].contiguous(), counts, group)
+    return recv
+
+
+def sort_exchange_t(ops, r: TRecs, P: int, k: int, group=None, force_exchange: bool = False):
+    """sort_exchange() on device-resident records (one-word keys) -> (this rank's logical partitions sorted by key,
+    their partition starts as a device tensor)"""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    assert P % world == 0, "the logical partition count must be a multiple of the number of ranks"
+    assert r.kw == 1, "the range shuffle handles one-word keys (k <= 32)"
+    per = P // world
+    dev = r.marker.device
+    r = ops.sort(r, k)
+    v, incl, _ = splitters_t(ops, r.key[:r.n], P, 2 * (k - 1), group)
+    b = np.concatenate([[0], _local_bounds_t(ops, r.key[:r.n], v, incl), [r.n]]).astype(np.int64)
+    if world == 1 and not force_exchange:
+        return r, torch.from_numpy(b).to(dev)
+    rcut = b[::per]
+    wcut = r.ext_off[torch.from_numpy(rcut).to(dev)].cpu().numpy()
+    lens = (r.ext_off[1:r.n + 1] - r.ext_off[:r.n])
+    key = _exchange_t(r.key, rcut, group)
+    marker = _exchange_t(r.marker, rcut, group)
+    left = _exchange_t(r.left, rcut, group)
+    right = _exchange_t(r.right, rcut, group)
+    lens = _exchange_t(lens, rcut, group)
+    ext = _exchange_t(r.ext, wcut, group)
+    ext_off = torch.zeros(int(lens.numel()) + 1, dtype=torch.int64, device=dev)
+    if lens.numel():
+        ext_off[1:] = torch.cumsum(lens, 0)
+    merged = ops.sort(ops.make(key, marker, ext_off, ext, left, right), k)
+    p0 = rank * per
+    full = np.concatenate([[0], _local_bounds_t(ops, merged.key[:merged.n], v, incl), [merged.n]]).astype(np.int64)
+    ps = full[p0:p0 + per + 1].copy()
+    ps[0], ps[-1] = 0, merged.n
+    return merged, torch.from_numpy(ps).to(dev)
+
+
+def sharded_assemble_dev(ops, keys: torch.Tensor, counts: torch.Tensor, prm, group=None, root: int = 0, trace=None,
+                         force_exchange: bool = False):
+    """sharded_assemble() with the records resident on the ranks' devices.  keys (int64 bit patterns) / counts (int32):
+    this rank's shard of the filtered (k-mer, count) list, any order, on its device.  k <= 31.  Returns (contig text,
+    n_contigs) on `root`, (None, None) elsewhere; identical to the single-GPU driver for the same prm.partitions."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    k, twin, P = prm.k, prm.twin, max(1, prm.partitions)
+    dev = keys.device
+    exchange = world > 1 or force_exchange
+    # the count stage's order contract: ascending canonical k-mer -> range-shard the survivors first
+    keys, counts = ops.sort_pairs(keys, counts, k)
+    if exchange:
+        v, incl, _ = splitters_t(ops, keys, world, 2 * k, group)
+        cut = np.concatenate([[0], _local_bounds_t(ops, keys, v, incl), [int(keys.numel())]]).astype(np.int64)
+        keys, counts = _exchange_t(keys, cut, group), _exchange_t(counts, cut, group)
+        keys, counts = ops.sort_pairs(keys, counts, k)
+    r = ops.rc_expand(keys, counts, k)
+    r, ps = sort_exchange_t(ops, r, P, k, group, force_exchange)
+    r, ps = ops.fork_forward(r, ps, k, prm.min_error_cov, twin)
+    r = ops.reflect(r, k)
+    r, ps = sort_exchange_t(ops, r, P, k, group, force_exchange)
+    r, ps = ops.fork_reflected(r, ps, k, prm.min_error_cov, twin)
+    r = ops.random_reflection(r, ps, k)
+
+    def count(rr):
+        return int(_allreduce_t(torch.tensor([rr.n], dtype=torch.int64, device=dev), group).item())
+
+    def one_pass(rr, stage):
+        rr, pst = sort_exchange_t(ops, rr, P, k, group, force_exchange)
+        rr, _ = ops.extend_pass(rr, pst, k, twin, stage)
+        if trace is not None:
+            trace.append(count(rr))
+        return rr
+    r = one_pass(r, 0)
+    it = 0
+    for _ in range(3):
+        it += 1
+        r = one_pass(r, 0)
+    it += 1
+    r = one_pass(r, 1)
+    last = 0
+    while it <= prm.max_iter:
+        it += 1
+        if it >= prm.min_iter and it % 3 == 0:
+            c = count(r)
+            if c == last:
+                break
+            last = c
+        r = one_pass(r, 2)
+    # the surviving records are few: contig ids follow the global record order, so the text is made on root
+    if world > 1:
+        lens = (r.ext_off[1:r.n + 1] - r.ext_off[:r.n])
+
+        def to_root(t, n):
+            cuts = np.array([0] * (root + 1) + [n] * (world - root), np.int64)
+            return _exchange_t(t, cuts, group)
+        key, marker = to_root(r.key, r.n), to_root(r.marker, r.n)
+        left, right = to_root(r.left, r.n), to_root(r.right, r.n)
+        lens, ext = to_root(lens, r.n), to_root(r.ext, r.words)
+        if rank != root:
+            return None, None
+        off = torch.zeros(int(lens.numel()) + 1, dtype=torch.int64, device=dev)
+        if lens.numel():
+            off[1:] = torch.cumsum(lens, 0)
+        r = ops.make(key, marker, off, ext, left, right)
+    return ops.contigs_text(r, k, prm.min_contig, twin)

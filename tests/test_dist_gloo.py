@@ -348,3 +348,134 @@ def test_sharded_wide_count_equals_global_count(world, chunks):
     allk = np.concatenate([r[1] for r in res]); allc = np.concatenate([r[2] for r in res])
     order = np.lexsort((allk[:, 1], allk[:, 0]))
     assert np.array_equal(allk[order], wk) and np.array_equal(allc[order], wc)
+
+
+# ------------------------------------------------------------------ the same stage, records resident on the device
+# (reflexiv_amd.dist.sharded_assemble_dev): here the "device" is the CPU and the operators are the oracle's
+
+class OracleTOps:
+    """CPU stand-in for reflexiv_amd.dist.HipDevOps (tests only): the oracle's operators on tensor record sets."""
+
+    def _rec(self, r):
+        return O.Records(r.key[:r.n].numpy().view(np.uint64).copy(), r.marker[:r.n].numpy().copy(),
+                         r.ext_off[:r.n + 1].numpy().copy(), r.ext[:r.words].numpy().view(np.uint64).copy(),
+                         r.left[:r.n].numpy().copy(), r.right[:r.n].numpy().copy())
+
+    def _t(self, o):
+        from reflexiv_amd.dist import TRecs
+        tt = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt).copy())
+        return TRecs(tt(o.key, np.int64), tt(o.marker, np.int32), tt(o.ext_off, np.int64), tt(o.ext, np.int64),
+                     tt(o.left, np.int32), tt(o.right, np.int32), o.n, int(o.ext_off[o.n]), 1)
+
+    def make(self, key, marker, ext_off, ext, left, right, kw=1):
+        from reflexiv_amd.dist import TRecs
+        return TRecs(key.contiguous(), marker.contiguous(), ext_off.contiguous(), ext.contiguous(), left.contiguous(),
+                     right.contiguous(), int(marker.numel()), int(ext.numel()), kw)
+
+    def sort_pairs(self, keys, counts, k):
+        kk = keys.numpy().view(np.uint64)
+        o = np.argsort(kk, kind="stable")
+        return torch.from_numpy(kk[o].view(np.int64).copy()), torch.from_numpy(counts.numpy()[o].copy())
+
+    def rc_expand(self, keys, counts, k):
+        return self._t(O.rc_expand_subkmer(keys.numpy().view(np.uint64), counts.numpy(), k))
+
+    def sort(self, r, k):
+        return self._t(O.sort_records(self._rec(r)))
+
+    def fork_forward(self, r, ps, k, min_err, twin):
+        o, ops = O.fork_filter_forward(self._rec(r), ps.numpy(), k, min_err, twin)
+        return self._t(o), torch.from_numpy(ops)
+
+    def fork_reflected(self, r, ps, k, min_err, twin):
+        o, ops = O.fork_filter_reflected(self._rec(r), ps.numpy(), k, min_err, twin)
+        return self._t(o), torch.from_numpy(ops)
+
+    def reflect(self, r, k):
+        return self._t(O.reflect_from_forward(self._rec(r), k))
+
+    def random_reflection(self, r, ps, k):
+        return self._t(O.random_reflection(self._rec(r), ps.numpy(), k))
+
+    def extend_pass(self, r, ps, k, twin, stage):
+        o, ops = O.extend_pass(self._rec(r), ps.numpy(), k, twin)
+        return self._t(o), torch.from_numpy(ops)
+
+    def lower_bound(self, sorted_keys, values, upper):
+        return torch.from_numpy(np.searchsorted(sorted_keys.numpy().view(np.uint64), values.numpy().view(np.uint64),
+                                                side="right" if upper else "left").astype(np.int64))
+
+    def contigs_text(self, r, k, min_contig, twin):
+        return O.contigs_text(self._rec(r), k, min_contig, twin)
+
+
+def _asm_dev_worker(rank, world, port, keys, counts, prm_kw, q, limit_bytes=None):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from reflexiv_amd import dist as rd
+        if limit_bytes:
+            rd.A2A_LIMIT_BYTES = limit_bytes
+        mine = owner_of(keys, world) == rank
+        prm = O.default_params(**prm_kw)
+        trace = []
+        text, nc = rd.sharded_assemble_dev(OracleTOps(), torch.from_numpy(keys[mine].view(np.int64).copy()),
+                                           torch.from_numpy(counts[mine].astype(np.int32)), prm, trace=trace)
+        if rank == 0:
+            q.put((text, nc, trace))
+        else:
+            assert text is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_sharded_assemble_dev(world, keys, counts, prm_kw, limit_bytes=None):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_asm_dev_worker, args=(r, world, port, keys, counts, prm_kw, q, limit_bytes)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("world,P,twin", [(2, 4, "ds"), (4, 4, "rdd"), (2, 8, "ds")])
+def test_device_resident_sharded_extend_reproduces_the_example(golden_dir, world, P, twin):
+    ex = np.load(os.path.join(golden_dir, "example.npz"))
+    tw = O.TWIN_DS if twin == "ds" else O.TWIN_RDD
+    text, nc, trace = _run_sharded_assemble_dev(world, ex["keys_cov3"], ex["counts_cov3"], dict(min_cov=3, partitions=P, twin=tw))
+    assert text == str(ex[f"contigs_{twin}_P{P}"])
+    assert trace == [int(x) for x in ex[f"trace_{twin}_P{P}"]]
+
+
+def test_device_resident_sharded_extend_with_bubbles_and_repeat(golden_dir):
+    pl = np.load(os.path.join(golden_dir, "planted.npz"))
+    text, nc, trace = _run_sharded_assemble_dev(2, pl["k31_keys"], pl["k31_counts"],
+                                                dict(k=31, min_cov=2, partitions=4, twin=O.TWIN_DS, min_contig=100),
+                                                limit_bytes=4096)          # record exchanges in several rounds
+    assert text == str(pl["k31_ds_contigs"])
+    assert trace == [int(x) for x in pl["k31_ds_trace"]]
+
+
+def test_device_resident_sharded_extend_world1_and_splitter_rounds(golden_dir):
+    """no process group: the one-rank path; and the eight-bits-per-round splitter search against the exact boundaries"""
+    from reflexiv_amd import dist as rd
+    ex = np.load(os.path.join(golden_dir, "example.npz"))
+    prm = O.default_params(min_cov=3, partitions=4, twin=O.TWIN_DS)
+    rng = np.random.default_rng(3)
+    o = rng.permutation(len(ex["keys_cov3"]))
+    text, nc = rd.sharded_assemble_dev(OracleTOps(), torch.from_numpy(ex["keys_cov3"][o].view(np.int64).copy()),
+                                       torch.from_numpy(ex["counts_cov3"][o].astype(np.int32)), prm)
+    assert text == str(ex["contigs_ds_P4"])
+    for bits, n, P in ((60, 5000, 7), (62, 100, 4), (13, 3000, 16), (60, 3, 5)):
+        keys = np.sort(rng.integers(0, 1 << bits, n, dtype=np.uint64))
+        keys[n // 3:n // 3 + n // 10] = keys[n // 3]                       # a long run of equal keys across a boundary
+        keys = np.sort(keys)
+        v, incl, ng = rd.splitters_t(OracleTOps(), torch.from_numpy(keys.view(np.int64).copy()), P, bits)
+        wv, wincl, _ = rd._splitters_local(keys, P)
+        assert ng == n and np.array_equal(v, wv) and np.array_equal(incl, wincl)

@@ -807,6 +807,55 @@ def test_sharded_extend_hip_ops_world1(rfx, ex, planted):
 
 
 @pytest.mark.gpu
+def test_device_resident_sharded_extend_one_rank_rccl(rfx, torch_mod, ex, planted):
+    """reflexiv_amd.dist.sharded_assemble_dev: records stay in HBM, every operator is a device-level C-ABI call, the
+    splitter search runs on the device and the shuffle is all_to_all_single on device tensors -- on a one-rank RCCL
+    group with the exchange forced, against the golden contigs, and on a 640 kbp genome against the oracle."""
+    torch = torch_mod
+    import torch.distributed as dist
+    import reflexiv_amd
+    from reflexiv_amd import dist as rd
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rfx.use_stream(torch.cuda.current_stream().cuda_stream)
+        ops = rd.HipDevOps(rfx)
+        rng = np.random.default_rng(9)
+        o = rng.permutation(len(ex["keys_cov3"]))
+        dk = torch.from_numpy(ex["keys_cov3"][o].view(np.int64).copy()).cuda()
+        dc = torch.from_numpy(ex["counts_cov3"][o].astype(np.int32)).cuda()
+        for P, twin, tn, force in ((4, O.TWIN_DS, "ds", True), (8, O.TWIN_RDD, "rdd", True), (4, O.TWIN_RDD, "rdd", False)):
+            prm = reflexiv_amd.default_params(min_cov=3, partitions=P, twin=twin)
+            trace = []
+            text, nc = rd.sharded_assemble_dev(ops, dk, dc, prm, trace=trace, force_exchange=force)
+            assert text == str(ex[f"contigs_{tn}_P{P}"])
+            assert trace == [int(x) for x in ex[f"trace_{tn}_P{P}"]]
+        prm = reflexiv_amd.default_params(k=31, min_cov=2, partitions=4, twin=O.TWIN_DS, min_contig=100)
+        text, nc = rd.sharded_assemble_dev(ops, torch.from_numpy(planted["k31_keys"].view(np.int64).copy()).cuda(),
+                                           torch.from_numpy(planted["k31_counts"].astype(np.int32)).cuda(), prm, force_exchange=True)
+        assert text == str(planted["k31_ds_contigs"])
+        # a larger record set: 640 kbp at 40x
+        seed, G, n_reads, L, k = 3, 640_000, 170_000, 150, 31
+        dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+        N = rfx.kmers_per_read(L, k) * n_reads
+        kk = torch.empty(N // 4, dtype=torch.int64, device="cuda"); cc = torch.empty(N // 4, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, kk.data_ptr(), cc.data_ptr(), N // 4, 3)
+        prm = reflexiv_amd.default_params(min_cov=3, partitions=8)
+        trace = []
+        text, nc = rd.sharded_assemble_dev(ops, kk[:m], cc[:m], prm, trace=trace, force_exchange=True)
+        otext, onc, otrace, _ = O.assemble_from_counts(kk[:m].cpu().numpy().view(np.uint64), cc[:m].cpu().numpy(),
+                                                       O.default_params(min_cov=3, partitions=8))
+        assert trace == otrace and (text, nc) == (otext, onc)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+@pytest.mark.gpu
 def test_cpp_host_counter_uses_the_counters_line_filter(tmp_path):
     """`counter` reads lines through DSFastqFilterOnlySeq (P/ReflexivDataFrameCounter.java:238-290), not
     through the assembler's 4-line grouping: a quality line that looks like sequence is counted, reads of

@@ -31,8 +31,12 @@ __device__ __host__ __forceinline__ uint64_t kmer_hash(uint64_t x) {
 }
 
 // swap the two bits of every base pair
+// (on the two 32-bit halves: a pair never straddles them, and 32-bit shifts issue at full rate where the 64-bit ones do not)
+__device__ __forceinline__ uint32_t pair_swap32(uint32_t x) {
+    return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);
+}
 __device__ __forceinline__ uint64_t pair_swap(uint64_t x) {
-    return ((x & 0x5555555555555555ULL) << 1) | ((x >> 1) & 0x5555555555555555ULL);
+    return ((uint64_t)pair_swap32((uint32_t)(x >> 32)) << 32) | pair_swap32((uint32_t)x);
 }
 
 // reverse complement of a right-aligned k-mer (k <= 32): complement = ~, reversal of base

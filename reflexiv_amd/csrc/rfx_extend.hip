@@ -618,11 +618,14 @@ static int desc_tail(rfx_ctx *ctx, const DevRecords &in, int64_t nd, DevBuf &len
     DevBuf oidx, owoff;
     RFX_HIP(oidx.alloc((size_t)(nd + 1) * 8, ctx->stream));
     RFX_HIP(owoff.alloc((size_t)(nd + 1) * 8, ctx->stream));
-    RFX_TRY(exclusive_scan_u32_to_u64(ctx, flag.as<uint32_t>(), oidx.as<uint64_t>(), nd));
     // single-word stage: every emission has exactly one word (a longer one is the RFX_E_STATE below), so the word
     // offsets ARE the emission indices
-    if (single_word) RFX_HIP(hipMemcpyAsync(owoff.p, oidx.p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    else RFX_TRY(exclusive_scan_u32_to_u64(ctx, onw.as<uint32_t>(), owoff.as<uint64_t>(), nd));
+    if (single_word) {
+        RFX_TRY(exclusive_scan_u32_to_u64(ctx, flag.as<uint32_t>(), oidx.as<uint64_t>(), nd));
+        RFX_HIP(hipMemcpyAsync(owoff.p, oidx.p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        RFX_TRY(exclusive_scan2_u32_to_u64(ctx, flag.as<uint32_t>(), onw.as<uint32_t>(), oidx.as<uint64_t>(), owoff.as<uint64_t>(), nd));
+    }
     RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_emit<KW>, dim3(grid_for(nd + 1)), dim3(256), 0, ctx->stream, (const Desc *)desc.as<Desc>(),
                        (const uint32_t *)flag.as<uint32_t>(), (const uint64_t *)oidx.as<uint64_t>(),
                        (const uint64_t *)owoff.as<uint64_t>(), nd, d_part_start, P, sub, start_marker,

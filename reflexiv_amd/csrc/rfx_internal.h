@@ -37,6 +37,11 @@ struct rfx_ctx {
         for (auto &w : ws) { if (w.p) (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
         if (pinned) (void)hipHostFree(pinned);
         pinned = nullptr; pinned_bytes = 0;
+        if (scan_desc) (void)hipFree(scan_desc);
+        if (scan_ticket) (void)hipFree(scan_ticket);
+        if (scan_fault) (void)hipHostFree(scan_fault);
+        scan_fault = nullptr;
+        scan_desc = nullptr; scan_ticket = nullptr; scan_desc_cap = 0;
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         ev_pool.clear(); ev_next = 0;
     }
@@ -49,6 +54,14 @@ struct rfx_ctx {
         if (ev_next == ev_pool.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; ev_pool.push_back(e); }
         return ev_pool[ev_next++];
     }
+    // single-pass scans (rfx_scan.hip): tile descriptors and the ticket counter live in the context; a descriptor is
+    // valid only under the epoch of the call that wrote it, so nothing is cleared between calls
+    uint64_t *scan_desc = nullptr;
+    size_t scan_desc_cap = 0;              // descriptors (two per tile for the dual scan)
+    unsigned long long *scan_ticket = nullptr;
+    int *scan_fault = nullptr;             // host-mapped: set by a look-back that gave up (never expected)
+    unsigned long long scan_tickets_issued = 0;
+    uint32_t scan_epoch = 0;
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
     void *pinned_get(size_t bytes) {
@@ -153,6 +166,9 @@ namespace rfx {
 // ---- rfx_scan.hip
 int exclusive_scan_u64(rfx_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int64_t n);   // out[n] = total (n+1 entries)
 int exclusive_scan_u32_to_u64(rfx_ctx *ctx, const uint32_t *d_in, uint64_t *d_out, int64_t n);
+// two arrays in one launch (the emission indices and the word offsets of an extend pass)
+int exclusive_scan2_u32_to_u64(rfx_ctx *ctx, const uint32_t *d_in_a, const uint32_t *d_in_b, uint64_t *d_out_a,
+                               uint64_t *d_out_b, int64_t n);
 
 // ---- rfx_sort.hip
 int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int key_bits,

@@ -425,9 +425,18 @@ __global__ __launch_bounds__(PT) void k_vb_scatter(const uint64_t *__restrict__ 
 
 // ------------------------------------------------------------------- leaves
 
-constexpr int LT = 512;                 // threads per leaf workgroup
+#ifndef RFX_LT
+#define RFX_LT 768
+#endif
+#ifndef RFX_LEAF_WAVES_PER_EU
+#define RFX_LEAF_WAVES_PER_EU 6
+#endif
+// 12 waves per workgroup, two workgroups per CU, registers capped for 6 waves per SIMD: the kernel is bound by LDS and
+// issue latency (one workgroup per CU instead of two: 13.1 -> 21.7 ms), and 8 waves with 4 per SIMD measured 13.2 ms
+// against 12.6 (tools/build_variant.sh + tools/ab_many.sh; 10 waves per workgroup: 20 ms)
+constexpr int LT = RFX_LT;              // threads per leaf workgroup
 constexpr int OBUF = 512;               // survivors buffered in LDS between flushes
-constexpr int WSTAGE = 256;             // u64 words of a wave's private expansion area (record leaves)
+constexpr int WSTAGE = 160;             // u64 words of a wave's private expansion area (record leaves)
 constexpr int LSTAGE = WSTAGE * (LT / 64);
 constexpr int LCAP = 4096;              // hash slots
 constexpr int LCAP_BITS = 12;
@@ -489,7 +498,10 @@ template <> struct LeafElem<2> {
 };
 template <> struct LeafElem<1> {
     using T = Rec;
-    static constexpr int PER_LANE = 3;       // 64-record steps a wave holds in registers per leaf
+#ifndef RFX_RPF
+#define RFX_RPF 2
+#endif
+    static constexpr int PER_LANE = RFX_RPF; // 64-record steps a wave holds in registers per leaf
     __device__ static __forceinline__ T none() { return Rec{0, 0}; }
     __device__ static __forceinline__ uint64_t key(const T &e) { return e.w0; }
     __device__ static __forceinline__ uint32_t weight(const T &) { return 1u; }
@@ -523,16 +535,19 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
     return x;
 }
 
-template <int ELEM>
-__global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<ELEM>::T *__restrict__ keys,
+// KC: the k-mer length as a compile-time constant (0 = the run-time argument): the window shifts, the reverse
+// complement's alignment and the masks of the record path fold into immediates
+template <int ELEM, int KC = 0>
+__global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const typename LeafElem<ELEM>::T *__restrict__ keys,
                                                    const uint64_t *__restrict__ leaf_off, int64_t nleaf,
                                                    const uint64_t *__restrict__ sl_begin, const uint64_t *__restrict__ sl_end,
-                                                   uint64_t heavy, uint64_t n_elems, int k,
+                                                   uint64_t heavy, uint64_t n_elems, int k_rt,
                                                    int min_cov, int max_cov, int apply_filter,
                                                    uint64_t *__restrict__ out_keys, int32_t *__restrict__ out_counts,
                                                    unsigned long long cap, CountOut *__restrict__ co, int dbg,
                                                    int pair_out, uint32_t presplit) {
     constexpr bool RECS = ELEM == 1;
+    const int k = KC ? KC : k_rt;
     __shared__ __attribute__((aligned(16))) unsigned long long tkey[LCAP];
     __shared__ __attribute__((aligned(16))) uint32_t tcnt[LCAP];
     __shared__ unsigned long long obk[OBUF];
@@ -688,20 +703,45 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<ELEM>
             }
             uint32_t *wbits = (uint32_t *)(stage + wave_ * WSTAGE);   // 32 words of head bits
             uint32_t *wcum = wbits + 32;                              // exclusive popcount per word
-            Rec *wrec = (Rec *)(wbits + 64);                          // the wave's 64 records
+            uint4 *wrec = (uint4 *)(wbits + 64);                      // the wave's 64 records (see step)
             const int k2 = 2 * k;
             // Records hold 1..16 windows each.  The wave lays its 64 records out in LDS, marks where
             // each record's windows start in the wave's output sequence (one bit per output position)
             // and then every lane extracts k-mers by position: lane j finds its record by a prefix
             // popcount of the head bits.  Balanced lanes; no workgroup barrier (LDS ops of one wave
-            // stay in order).
+            // stay in order).  A record lies in LDS as its base string shifted right by ONE bit (x, y, z) with
+            // its first output position in w: window i then starts 31 - 2i bits up in (x, y) and (y, z), a
+            // shift in 1..31, which is what one 32-bit funnel shift takes (64-bit shifts issue at a fraction
+            // of the rate).
             auto kmer_at_pos = [&](uint32_t j) __attribute__((always_inline)) -> uint64_t {
                 const uint32_t wd = wbits[j >> 5];
                 const uint32_t r = wcum[j >> 5] + (uint32_t)__popc(wd & (0xffffffffu >> (31 - (j & 31)))) - 1u;
-                const Rec rr = wrec[r];
-                const uint32_t sh = 2u * (j - (uint32_t)rr.w1);                  // 2 * window index, <= 30
-                const uint64_t fwd = ((rr.w0 << sh) | ((rr.w1 >> 1) >> (63 - sh))) >> (64 - k2);
-                const uint64_t rc = revcomp(fwd, k);
+                const uint4 rr = wrec[r];
+                const uint32_t t = 31u - 2u * (j - rr.w);                        // window index <= 15
+                const uint32_t W0 = __builtin_amdgcn_alignbit(rr.x, rr.y, t), W1 = __builtin_amdgcn_alignbit(rr.y, rr.z, t);
+                uint32_t fh, fl;
+                if constexpr (KC != 0) {
+                    constexpr int sft = 64 - 2 * KC;
+                    if constexpr (sft >= 32) { fh = 0; fl = W0 >> (sft - 32); }
+                    else if constexpr (sft == 0) { fh = W0; fl = W1; }
+                    else { fh = W0 >> sft; fl = __builtin_amdgcn_alignbit(W0, W1, sft); }
+                } else {
+                    const uint64_t f = (((uint64_t)W0 << 32) | W1) >> (64 - k2);
+                    fh = (uint32_t)(f >> 32); fl = (uint32_t)f;
+                }
+                // reverse complement: the halves swap under the 64-bit reversal
+                const uint32_t rh = pair_swap32(__brev(~fl)), rl = pair_swap32(__brev(~fh));
+                uint32_t ch, cl;
+                if constexpr (KC != 0) {
+                    constexpr int sft = 64 - 2 * KC;
+                    if constexpr (sft >= 32) { ch = 0; cl = rh >> (sft - 32); }
+                    else if constexpr (sft == 0) { ch = rh; cl = rl; }
+                    else { ch = rh >> sft; cl = __builtin_amdgcn_alignbit(rh, rl, sft); }
+                } else {
+                    const uint64_t c = (((uint64_t)rh << 32) | rl) >> (64 - k2);
+                    ch = (uint32_t)(c >> 32); cl = (uint32_t)c;
+                }
+                const uint64_t fwd = ((uint64_t)fh << 32) | fl, rc = ((uint64_t)ch << 32) | cl;
                 return fwd < rc ? fwd : rc;
             };
             auto step = [&](const Rec rcur, const bool valid) __attribute__((always_inline)) {
@@ -716,7 +756,10 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<ELEM>
                 if (lane_ < 32) wbits[lane_] = 0;
                 __builtin_amdgcn_wave_barrier();
                 if (nwin) atomicOr(&wbits[off >> 5], 1u << (off & 31));
-                wrec[lane_] = Rec{rcur.w0, (rcur.w1 & ~0xffffffffULL) | off};       // hdr is spent: carry `off`
+                {
+                    const uint32_t s0 = (uint32_t)(rcur.w0 >> 32), s1 = (uint32_t)rcur.w0, s2 = (uint32_t)(rcur.w1 >> 32);
+                    wrec[lane_] = make_uint4(s0 >> 1, __builtin_amdgcn_alignbit(s0, s1, 1), __builtin_amdgcn_alignbit(s1, s2, 1), off);
+                }
                 __builtin_amdgcn_wave_barrier();
                 {
                     const uint32_t c = (uint32_t)__popc(wbits[lane_ & 31]);
@@ -785,10 +828,11 @@ __global__ __launch_bounds__(LT) void k_leaf_count(const typename LeafElem<ELEM>
     // its survivors with one LDS add; when the buffer is full the wave writes straight to the
     // output instead (one global add per wave), so no barrier depends on how many keys survive.
     auto emit_pass = [&]() __attribute__((always_inline)) {
-        static_assert(LCAP == 8 * LT, "two 4-slot chunks per thread");
+        static_assert(LT % 64 == 0 && (LCAP / 4) % 64 == 0, "whole waves sweep whole chunks");
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < (LCAP / 4 + LT - 1) / LT; h++) {
             const uint32_t c4 = threadIdx.x + h * LT;                    // chunk of 4 slots
+            if (c4 >= (uint32_t)(LCAP / 4)) break;                       // (wave-uniform)
             const uint4 cv = *(const uint4 *)&tcnt[4 * c4];
             const uint32_t cs[4] = {cv.x, cv.y, cv.z, cv.w};
 #pragma unroll
@@ -2034,7 +2078,11 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
         // (pair output: every workgroup leaves part of its last block(s) as holes, so fewer of them)
         const int leaf_per_cu = getenv("RFX_LEAF_PER_CU") ? std::max(1, atoi(getenv("RFX_LEAF_PER_CU"))) : pair_out ? 4 : 32;
         int64_t grid = std::min<int64_t>(nleaf, (int64_t)ctx->num_cu * leaf_per_cu);      // persistent, <= 78 KB LDS each
-        hipLaunchKernelGGL(k_leaf_count<ELEM>, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, elems, d_leaf_off, nleaf,
+        static const bool kc_off = getenv("RFX_LEAF_KC") && atoi(getenv("RFX_LEAF_KC")) == 0;
+        auto *kern = k_leaf_count<ELEM, 0>;
+        if (RECS && k == 31 && !kc_off) kern = k_leaf_count<ELEM, RECS ? 31 : 0>;
+        static const int extra_lds = getenv("RFX_LEAF_EXTRA_LDS") ? atoi(getenv("RFX_LEAF_EXTRA_LDS")) : 0;   // occupancy experiment
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(LT), (size_t)extra_lds, ctx->stream, elems, d_leaf_off, nleaf,
                            (const uint64_t *)nullptr, (const uint64_t *)nullptr, heavy, (uint64_t)elem_count, k, min_cov,
                            max_cov, apply, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>(), dbg,
                            (int)pair_out, presplit);

@@ -312,14 +312,16 @@ struct VbMap {
     const uint64_t *vb_start;    // nseg+1 exclusive scan of virtual workgroups per parent
     int64_t nseg;
     int tpb;                     // tiles per virtual workgroup
+    const uint64_t *seg_end = nullptr;   // parents with gaps between them (the one-sweep level 1): parent p ends at
+                                         // seg_end[p], not at seg_off[p + 1]
 };
 
-__global__ void k_vb_per_seg(const uint64_t *__restrict__ seg_off, int64_t nseg, int tpb,
+__global__ void k_vb_per_seg(const uint64_t *__restrict__ seg_off, const uint64_t *__restrict__ seg_end, int64_t nseg, int tpb,
                              uint64_t *__restrict__ nvb) {
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s < nseg) {
         const uint64_t per = (uint64_t)tpb * PTILE;
-        nvb[s] = (seg_off[s + 1] - seg_off[s] + per - 1) / per;
+        nvb[s] = ((seg_end ? seg_end[s] : seg_off[s + 1]) - seg_off[s] + per - 1) / per;
     }
 }
 
@@ -337,7 +339,7 @@ __device__ __forceinline__ bool locate_vb(const VbMap &m, int64_t vb, VbPos *q) 
     q->G = (int64_t)m.vb_start[lo + 1] - (int64_t)m.vb_start[lo];
     const uint64_t per = (uint64_t)m.tpb * PTILE;
     q->begin = m.seg_off[lo] + (uint64_t)q->g * per;
-    const uint64_t e = m.seg_off[lo + 1];
+    const uint64_t e = m.seg_end ? m.seg_end[lo] : m.seg_off[lo + 1];
     q->end = q->begin + per < e ? q->begin + per : e;
     return true;
 }
@@ -455,6 +457,7 @@ struct CountOut {
     unsigned long long n_passes;     // table passes run (>= non-empty leaves)
     unsigned long long n_overflow;   // passes abandoned because the table filled up
     unsigned long long n_leaves;     // non-empty leaves
+    unsigned long long t_wait, t_all; // RFX_LEAF_DBG & 32: clocks waves spent at the two barriers of a leaf / in the kernel
 };
 
 // Persistent workgroups each walk a CONTIGUOUS chunk of leaf buckets, i.e. one contiguous
@@ -563,6 +566,8 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
     __shared__ uint32_t ps_eff;              // elements one table takes (starts at `presplit`, shrinks on overflow)
     __shared__ __attribute__((aligned(16))) uint64_t stage[RECS ? LSTAGE : 2];  // records: per-wave expansion area
     uint32_t my_distinct = 0;                                                // every thread
+    long long t_wait = 0;
+    const long long t_begin = (dbg & 32) ? clock64() : 0;
     unsigned long long my_passes = 0, my_overflows = 0;                      // thread 0 only
     const int lane_ = threadIdx.x & 63;
     const int wave_ = threadIdx.x >> 6;
@@ -881,7 +886,8 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
             *(ulonglong2 *)&tkey[4 * c4] = make_ulonglong2(EMPTY, EMPTY);
             *(ulonglong2 *)&tkey[4 * c4 + 2] = make_ulonglong2(EMPTY, EMPTY);
         }
-        __syncthreads();
+        if (dbg & 32) { const long long t0 = clock64(); __syncthreads(); t_wait += clock64() - t0; }
+        else __syncthreads();
         const uint32_t raw = ob_n, lim = ob_lim;      // stable until the next emit_pass
         if (raw >= (uint32_t)OBUF / 2 || lim != 0xffffffffu) flush();
     };
@@ -907,7 +913,8 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
             run_pass(S, s, first, begin_next, end_next);        // (an empty leaf still hands the prefetch chain on)
             first = false;
             if (begin == end) break;
-            __syncthreads();
+            if (dbg & 32) { const long long t0 = clock64(); __syncthreads(); t_wait += clock64() - t0; }
+            else __syncthreads();
             const bool ov = overflow != 0;
             if (threadIdx.x == 0) my_passes++;
             if (!ov) {
@@ -976,6 +983,10 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
     if (threadIdx.x == 0) {
         atomicAdd(&co->n_passes, my_passes);
         if (my_overflows) atomicAdd(&co->n_overflow, my_overflows);
+    }
+    if ((dbg & 32) && lane_ == 0) {
+        atomicAdd(&co->t_wait, (unsigned long long)t_wait);
+        atomicAdd(&co->t_all, (unsigned long long)(clock64() - t_begin));
     }
 }
 
@@ -1627,6 +1638,303 @@ __global__ __launch_bounds__(SKT, WIDE ? 4 : 8) void k_sk_scatter(ReadSrc s, Lev
 #undef tail
 #undef head
 
+// ---- level 1 in ONE sweep over the reads.  The two-pass form above computes every minimiser in the histogram pass
+// and carries 5.4 GB of run descriptors to the scatter so as not to compute them twice.  Here nothing is counted first:
+// a sampled histogram (one tile of 1024 segments in every `sample`) sizes a REGION per bucket with room to spare, and a
+// workgroup takes its output positions from the bucket's cursor in EXTENTS of OSE records (one global atomic per
+// extent).  A workgroup always owns the extent it is filling and the next one, so the write-combining rings and the
+// direct stores of a busy round never wait for an allocation; extents change hands only at the round's barrier.
+// What a workgroup leaves unused of its last two extents are HOLES; k_fix_holes moves the records at the end of every
+// bucket into the holes before it, so the next level reads a gap-free [seg_begin, seg_end) per bucket.  A region that
+// runs out (a sample that missed the skew) raises `overflow` and the caller falls back to the two-pass form.
+constexpr int OSE = 64;                  // records per extent (a round must not put more than OSE records of one
+                                         // workgroup into one bucket: 5 on average at 512 buckets)
+constexpr int OS_CSTRIDE = 16;           // cursors 128 bytes apart: one atomic unit each
+constexpr int OS_MAXG = 512;             // workgroups of the sweep
+constexpr int OS_HOLES = 3;              // extents a workgroup has in hand per bucket: filling, next, requested
+struct OneSweep {
+    const uint64_t *reg_start;           // [nb + 1] first record of every region (multiples of OSE); [nb] = a dump extent
+    const uint32_t *reg_cap;             // [nb] records a region holds
+    unsigned long long *cursor;          // [nb * OS_CSTRIDE] next record to hand out (absolute; starts at reg_start)
+    uint64_t *holes;                     // [nb][OS_HOLES * G] (absolute start << 8) | length, 0 = none
+    int *overflow;
+    uint64_t total;                      // records allocated (regions + the dump extent)
+    unsigned long long *tile_counter;    // tiles of SKT segments handed out beyond every workgroup's first
+};
+
+template <int W>
+__global__ __launch_bounds__(SKT) void k_sk_sample_hist(ReadSrc s, Level lv, int sample, unsigned long long *__restrict__ hist) {
+    __shared__ uint32_t h[1 << MAX_BITS];
+    const int nb = 1 << lv.bits;
+    for (int i = threadIdx.x; i < nb; i += SKT) h[i] = 0;
+    __syncthreads();
+    const int64_t ntile = (s.n_threads + SKT - 1) / SKT;
+    for (int64_t T = (int64_t)blockIdx.x * sample; T < ntile; T += (int64_t)gridDim.x * sample) {
+        const int64_t g = T * SKT + threadIdx.x;
+        if (g < s.n_threads) {
+            SegPos q;
+            q.r = g / s.segs;
+            q.sgm = (int)(g - q.r * s.segs);
+            uint64_t w[3], hi, lo;
+            seg_load(s, q, w);
+            seg_runs<W, SK_HIST_RUNLOOP>(s, read_nk(s, q.r), q.sgm, w, [&](int, int, uint32_t canon) { atomicAdd(&h[sk_digit(canon, lv)], 1u); }, &hi, &lo);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += SKT) if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+// regions from the sampled histogram: estimate + six standard deviations of the sample + 1/64 + what the workgroups
+// hold in hand; totals[0] = records to allocate (regions + the dump extent)
+__global__ __launch_bounds__(1024) void k_plan_regions(const unsigned long long *__restrict__ hist, int nb, double scale, int G, int cap_pct,
+                                                       uint64_t *__restrict__ reg_start, uint32_t *__restrict__ reg_cap,
+                                                       unsigned long long *__restrict__ cursor, unsigned long long *__restrict__ totals) {
+    __shared__ uint64_t caps[1 << MAX_BITS];
+    const int d = threadIdx.x;
+    if (d < nb) {
+        const double c = (double)hist[d];
+        const double est = c * scale;
+        double room = (est + 6.0 * scale * sqrt(c + 1.0) + est / 64.0 + 1024.0) * (double)cap_pct / 100.0;
+        uint64_t cap = (uint64_t)room + (uint64_t)G * OS_HOLES * OSE;
+        cap = (cap + OSE - 1) / OSE * OSE;
+        if (cap > 0xFFFFFF00ULL) cap = 0xFFFFFF00ULL / OSE * OSE;      // bucket-local positions are 32-bit
+        caps[d] = cap;
+        reg_cap[d] = (uint32_t)cap;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t at = 0;
+        for (int i = 0; i < nb; i++) { reg_start[i] = at; cursor[(size_t)i * OS_CSTRIDE] = at; at += caps[i]; }
+        reg_start[nb] = at;
+        totals[0] = at + OSE;
+        totals[1] = 0;
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(SKT, 8) void k_sk_onesweep(ReadSrc s, Level lv, OneSweep os, Rec *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(32))) unsigned char sk_smem[];
+    const int nb = 1 << lv.bits;
+#define buf ((Rec *)sk_smem)
+#define tail ((uint32_t *)(sk_smem + (size_t)nb * SKB * sizeof(Rec)))       /* records given a (workgroup-local) position */
+#define head (tail + nb)                                                    /* ... of them stored */
+#define cstart (tail + 2 * nb)                                              /* local position the current extent starts at */
+#define cbase (tail + 3 * nb)                                               /* the current extent (its number: record / OSE) */
+#define nbase (tail + 4 * nb)                                               /* the next one */
+#define pbase (tail + 5 * nb)                                               /* the one after that, or NONE while it is on order */
+    constexpr uint32_t DUMP = 0xFFFFFFFFu;
+    const uint64_t dump_at = os.total - OSE;
+    // An extent off bucket d's cursor.  Only the END OF THE ALLOCATION is checked here (no load on this path): an extent
+    // past the bucket's own region lands in its neighbour's, which k_fix_holes sees from the cursor and declares the
+    // whole sweep void.
+    auto grab = [&](int d) __attribute__((always_inline)) -> uint32_t {
+        const unsigned long long b = atomicAdd(&os.cursor[(size_t)d * OS_CSTRIDE], (unsigned long long)OSE);
+        return b + OSE <= dump_at ? (uint32_t)(b / OSE) : DUMP;
+    };
+    // where local position v of a bucket lives (v - cs < 2 * OSE)
+    auto phys = [&](uint32_t v, uint32_t cs, uint32_t cb, uint32_t nx) __attribute__((always_inline)) -> uint64_t {
+        const uint32_t o = v - cs;
+        const uint32_t b = o < (uint32_t)OSE ? cb : nx;
+        return (b == DUMP ? dump_at : (uint64_t)b * OSE) + (o & (OSE - 1));
+    };
+    // The extent after the next one is requested a round ahead: thread d asks for bucket d's at the top of a round and
+    // files it (pbase) at the end of the round's arithmetic, so the atomic has the whole round to come back -- waited
+    // for inside the drain it would hold up the wave's stores behind it, round after round.
+    constexpr uint32_t NONE = 0xFFFFFFFEu;
+    for (int i = threadIdx.x; i < nb; i += SKT) {
+        tail[i] = 0; head[i] = 0; cstart[i] = 0;
+        cbase[i] = grab(i);
+        nbase[i] = grab(i);
+        pbase[i] = grab(i);
+    }
+    __syncthreads();
+    auto drain = [&](bool final) __attribute__((always_inline)) {
+        for (int d = threadIdx.x / SKB; d < nb; d += SKT / SKB) {
+            const int j = threadIdx.x % SKB;
+            const uint32_t h = head[d], t = tail[d], cs = cstart[d], cb = cbase[d], nx = nbase[d];
+            uint32_t e, nh;
+            if (t - h > (uint32_t)SKB) { e = h + SKB; nh = t; }               // the excess went out directly
+            else {
+                e = final ? t : (t & ~(uint32_t)(SKA - 1));
+                if (e < h) e = h;
+                nh = e;
+            }
+            const uint32_t g = h + j;
+            if (g < e) out[phys(g, cs, cb, nx)] = buf[(size_t)d * SKB + (g & (SKB - 1))];
+            if (j == 0) {
+                head[d] = nh;
+                // extents that lie wholly behind the stored position are done with: move up (the 8 lanes of this
+                // bucket read the old values above, in lock-step)
+                if (nh - cs >= (uint32_t)OSE) {
+                    uint32_t c = cs, b0 = cb, b1 = nx, b2 = pbase[d];
+                    while (nh - c >= (uint32_t)OSE) { c += OSE; b0 = b1; b1 = b2 != NONE ? b2 : grab(d); b2 = NONE; }
+                    cstart[d] = c; cbase[d] = b0; nbase[d] = b1; pbase[d] = b2;
+                }
+            }
+        }
+    };
+    // Tiles of SKT segments are handed out by a global counter (the first one is the workgroup's number): the
+    // workgroups stay as few as the holes allow and still finish together.  The next tile is asked for at the top of a
+    // round, like the extents.
+    __shared__ long long tile_lds[2];
+    const int64_t ntile = (s.n_threads + SKT - 1) / SKT;
+    const int my_d = (int)threadIdx.x;                  // the bucket this thread keeps supplied (nb <= SKT)
+    int64_t T = blockIdx.x;
+    for (int rnd = 0; T < ntile; rnd++) {
+        long long t_next = 0;
+        if (threadIdx.x == SKT - 1) t_next = (long long)gridDim.x + (long long)atomicAdd(os.tile_counter, 1ULL);
+        const bool ask = my_d < nb && pbase[my_d] == NONE;
+        uint32_t req = DUMP;
+        if (ask) req = grab(my_d);
+        const int64_t g = T * SKT + threadIdx.x;
+        if (g < s.n_threads) {
+            SegPos q;
+            q.r = g / s.segs;
+            q.sgm = (int)(g - q.r * s.segs);
+            uint64_t w[3], hi = 0, lo = 0;
+            seg_load(s, q, w);
+            seg_runs<W, SK_SCATTER_RUNLOOP>(s, read_nk(s, q.r), q.sgm, w, [&](int i0, int n, uint32_t canon) {
+                const uint64_t hh = mmer_hash64(canon);
+                const uint32_t hdr = (uint32_t)((hh << OWNER_BITS) >> 32);
+                const unsigned d = rec_digit(hdr, 0, lv.bits);
+                Rec r;
+                const int sft = 2 * i0;
+                r.w0 = sft ? (hi << sft) | (lo >> (64 - sft)) : hi;
+                r.w1 = ((lo << sft) & 0xFFFFFFF000000000ULL) | ((uint64_t)(n - 1) << 32) | (uint64_t)hdr;
+                const uint32_t pos = atomicAdd(&tail[d], 1u);
+                if (pos - head[d] < (uint32_t)SKB) buf[(size_t)d * SKB + (pos & (SKB - 1))] = r;
+                else {
+                    const uint32_t cs = cstart[d];
+                    if (pos - cs < 2u * OSE) out[phys(pos, cs, cbase[d], nbase[d])] = r;
+                    else *os.overflow = 1;             // more than the two extents in hand take: the caller starts over
+                }
+            }, &hi, &lo);
+        }
+        if (threadIdx.x == SKT - 1) tile_lds[rnd & 1] = t_next;
+        if (ask) pbase[my_d] = req;
+        __syncthreads();
+        drain(false);
+        T = tile_lds[rnd & 1];
+        __syncthreads();
+    }
+    drain(true);
+    __syncthreads();
+    // what is left of the extents in hand (after the last drain: head == tail, tail - cstart < OSE)
+    for (int d = threadIdx.x; d < nb; d += SKT) {
+        const uint32_t used = tail[d] - cstart[d], cb = cbase[d], nx = nbase[d], px = pbase[d];
+        uint64_t *hl = os.holes + ((size_t)d * gridDim.x + blockIdx.x) * OS_HOLES;
+        hl[0] = cb != DUMP && used < (uint32_t)OSE ? (((uint64_t)cb * OSE + used) << 8) | (uint64_t)(OSE - used) : 0;
+        hl[1] = nx != DUMP ? (((uint64_t)nx * OSE) << 8) | (uint64_t)OSE : 0;
+        hl[2] = px != DUMP && px != NONE ? (((uint64_t)px * OSE) << 8) | (uint64_t)OSE : 0;
+    }
+}
+#undef buf
+#undef tail
+#undef head
+#undef cstart
+#undef cbase
+#undef nbase
+#undef pbase
+
+// One workgroup per bucket: the bucket's cursor says how far extents were handed out (alloc), the holes sum to H, so
+// the bucket holds size = alloc - H records and the last H positions [size, alloc) -- the tail zone -- hold as many
+// records as there are hole positions before `size`.  Tail record i goes to hole position i.
+constexpr int FH_T = 1024;
+__global__ __launch_bounds__(FH_T) void k_fix_holes(OneSweep os, int G, Rec *__restrict__ out, uint64_t *__restrict__ seg_begin,
+                                                   uint64_t *__restrict__ seg_end, unsigned long long *__restrict__ totals) {
+    constexpr int NHMAX = 2048;                                // holes of a bucket (>= OS_HOLES * OS_MAXG, a multiple of FH_T)
+    static_assert(NHMAX >= OS_HOLES * OS_MAXG && NHMAX % FH_T == 0, "holes per bucket");
+    constexpr int NWMAX = NHMAX * OSE / 32;                    // words of the tail-zone bitmap
+    __shared__ uint32_t hstart[NHMAX], hoff[NHMAX + 1];
+    __shared__ uint32_t bitmap[NWMAX];
+    __shared__ uint32_t wsum[FH_T / 64];
+    const int d = blockIdx.x;
+    const int NH = OS_HOLES * G;
+    const uint64_t base = os.reg_start[d];
+    const unsigned long long alloc = os.cursor[(size_t)d * OS_CSTRIDE] - base;
+    if (alloc > (unsigned long long)os.reg_cap[d]) {           // ran over its region: the sweep is void
+        if (threadIdx.x == 0) { seg_begin[d] = base; seg_end[d] = base; *os.overflow = 1; }
+        return;
+    }
+    auto block_excl_scan = [&](uint32_t v, uint32_t *total) __attribute__((always_inline)) -> uint32_t {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint32_t x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t b = 0, tot = 0;
+        for (int i = 0; i < FH_T / 64; i++) { const uint32_t sv = wsum[i]; if (i < wave) b += sv; tot += sv; }
+        __syncthreads();
+        *total = tot;
+        return b + x - v;
+    };
+    for (int i = threadIdx.x; i < NWMAX; i += FH_T) bitmap[i] = 0;
+    constexpr int HPT = NHMAX / FH_T;
+    uint32_t hs[HPT], hl[HPT];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int r = 0; r < HPT; r++) {
+        const int t = threadIdx.x * HPT + r;
+        const uint64_t x = t < NH ? os.holes[(size_t)d * NH + t] : 0;
+        hl[r] = (uint32_t)(x & 255u);
+        hs[r] = hl[r] ? (uint32_t)((x >> 8) - base) : 0u;
+        mine += hl[r];
+    }
+    uint32_t H;
+    block_excl_scan(mine, &H);
+    const uint32_t size = (uint32_t)alloc - H;
+    // hole positions before `size` (to be filled) / inside the tail zone (marked)
+    uint32_t fill[HPT], fsum = 0;
+#pragma unroll
+    for (int r = 0; r < HPT; r++) {
+        fill[r] = hs[r] < size ? (hs[r] + hl[r] <= size ? hl[r] : size - hs[r]) : 0u;
+        fsum += fill[r];
+        for (uint32_t p = hs[r] + fill[r]; p < hs[r] + hl[r]; p++) atomicOr(&bitmap[(p - size) >> 5], 1u << ((p - size) & 31));
+    }
+    uint32_t F;
+    uint32_t fo = block_excl_scan(fsum, &F);
+#pragma unroll
+    for (int r = 0; r < HPT; r++) {
+        const int t = threadIdx.x * HPT + r;
+        hstart[t] = hs[r]; hoff[t] = fo; fo += fill[r];
+    }
+    if (threadIdx.x == 0) hoff[NHMAX] = F;
+    __syncthreads();
+    // records of the tail zone, in position order
+    constexpr int WPT = NWMAX / FH_T;
+    uint32_t valid[WPT], vsum = 0;
+#pragma unroll
+    for (int r = 0; r < WPT; r++) {
+        const uint32_t w = threadIdx.x * WPT + r;
+        const uint32_t lim = w * 32 >= H ? 0u : (H - w * 32 >= 32 ? 0xFFFFFFFFu : (1u << (H - w * 32)) - 1u);
+        valid[r] = ~bitmap[w] & lim;
+        vsum += (uint32_t)__popc(valid[r]);
+    }
+    uint32_t V;
+    uint32_t vo = block_excl_scan(vsum, &V);
+#pragma unroll
+    for (int r = 0; r < WPT; r++) {
+        uint32_t m = valid[r];
+        const uint32_t w = threadIdx.x * WPT + r;
+        while (m) {
+            const int b = __ffs((int)m) - 1;
+            m &= m - 1;
+            const uint32_t i = vo++;                           // i-th record of the tail zone -> i-th hole position
+            if (i < F) {
+                int lo = 0, hi = NHMAX;                        // the entry with hoff <= i < hoff of the next
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (hoff[mid] <= i) lo = mid; else hi = mid; }
+                out[base + hstart[lo] + (i - hoff[lo])] = out[base + size + w * 32 + b];
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        seg_begin[d] = base; seg_end[d] = base + size;
+        atomicAdd(&totals[1], (unsigned long long)size);
+        if (V != F) *os.overflow = 2;                          // cannot happen: the books of the sweep do not balance
+    }
+}
+
 // 16-byte elements of the k > 32 path (two-word canonical k-mers, rfx_wide.hip) go through the same
 // level kernels; their digits come from a hash of both words
 __device__ __forceinline__ uint64_t wide_hash(uint64_t hi, uint64_t lo) {
@@ -2141,6 +2449,8 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
     if (out_distinct) *out_distinct = (int64_t)co.n_distinct;
     if (getenv("RFX_TRACE"))
         fprintf(stderr, "leaves: %lld buckets, %llu table passes, %llu overflowed\n", (long long)nleaf, co.n_passes, co.n_overflow);
+    if (dbg & 32)
+        fprintf(stderr, "leaf waves: %.1f %% of their clocks at the leaf barriers\n", 100.0 * (double)co.t_wait / (double)std::max<unsigned long long>(co.t_all, 1));
     if (co.n_failed) { ctx->last_error = "leaf split depth exhausted"; ScopedTimer::collect(ctx); return RFX_E_LIMIT; }
     if ((int64_t)co.n_out > cap) { ScopedTimer::collect(ctx); return RFX_E_CAP; }
     if ((int64_t)co.n_out > (int64_t)0xFFFFFFFFLL) { ScopedTimer::collect(ctx); return RFX_E_LIMIT; }
@@ -2255,13 +2565,89 @@ static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv
     return RFX_OK;
 }
 
+// level 1 of the record path in one sweep (k_sk_onesweep): -> records in workspace slot `ws_slot`, bucket b in
+// [d_seg_begin[b], d_seg_end[b]).  *done = false: a region overflowed, nothing is valid, take the two-pass form.
+static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv, int ws_slot, uint64_t *d_seg_begin,
+                            uint64_t *d_seg_end, Rec **out_recs, int64_t *n_recs, bool *done, const char *hn, const char *pn) {
+    *done = false;
+    const int nb = 1 << lv.bits;
+    const int W = rsrc.k - SK_M + 1;
+    const int64_t ntile = ceil_div(rsrc.n_threads, SKT);
+    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(OS_MAXG, (int64_t)ctx->num_cu * 2), ntile));
+    int sample = getenv("RFX_SK_SAMPLE") ? std::max(1, atoi(getenv("RFX_SK_SAMPLE"))) : 32;
+    if (ntile < 64 * (int64_t)sample) sample = (int)std::max<int64_t>(1, ntile / 64);      // small inputs: at least 64 tiles
+    const int64_t n_sampled = ceil_div(ntile, sample);
+    const int cap_pct = getenv("RFX_SK_ONESWEEP_CAP") ? std::max(1, atoi(getenv("RFX_SK_ONESWEEP_CAP"))) : 100;
+    DevBuf hist, reg_start, reg_cap, cursor, totals, holes;
+    RFX_HIP(hist.alloc((size_t)nb * 8 + 16, ctx->stream));                 // + the overflow flag
+    RFX_HIP(reg_start.alloc((size_t)(nb + 1) * 8, ctx->stream));
+    RFX_HIP(reg_cap.alloc((size_t)nb * 4, ctx->stream));
+    RFX_HIP(cursor.alloc((size_t)nb * OS_CSTRIDE * 8, ctx->stream));
+    RFX_HIP(totals.alloc(16, ctx->stream));
+    RFX_HIP(holes.alloc((size_t)nb * OS_HOLES * G * 8, ctx->stream));
+    RFX_HIP(hipMemsetAsync(hist.p, 0, (size_t)nb * 8 + 16, ctx->stream));
+    int *d_overflow = (int *)(hist.as<unsigned long long>() + nb);
+    {
+        ScopedTimer t(ctx, hn);
+        const dim3 gs((unsigned)std::min<int64_t>(n_sampled, (int64_t)ctx->num_cu * 8));
+        switch (W) {
+#define X(w) case w: hipLaunchKernelGGL((k_sk_sample_hist<w>), gs, dim3(SKT), 0, ctx->stream, rsrc, lv, sample, hist.as<unsigned long long>()); break;
+            RFX_SK_W_CASES(X)
+#undef X
+            default: hipLaunchKernelGGL((k_sk_sample_hist<19>), gs, dim3(SKT), 0, ctx->stream, rsrc, lv, sample, hist.as<unsigned long long>()); break;
+        }
+        RFX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_plan_regions, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long *)hist.as<unsigned long long>(), nb,
+                           (double)ntile / (double)n_sampled, G, cap_pct, reg_start.as<uint64_t>(), reg_cap.as<uint32_t>(),
+                           cursor.as<unsigned long long>(), totals.as<unsigned long long>());
+        RFX_HIP(hipGetLastError());
+    }
+    unsigned long long h_tot[2] = {0, 0};
+    RFX_HIP(hipMemcpyAsync(h_tot, totals.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    Rec *dst = (Rec *)ctx->ws_get(ws_slot, (size_t)h_tot[0] * sizeof(Rec));
+    if (!dst) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
+    const OneSweep os{reg_start.as<uint64_t>(), reg_cap.as<uint32_t>(), cursor.as<unsigned long long>(), holes.as<uint64_t>(), d_overflow,
+                      (uint64_t)h_tot[0], hist.as<unsigned long long>() + nb + 1};
+    const size_t lds = (size_t)nb * (SKB * sizeof(Rec) + 24);
+    {
+        ScopedTimer t(ctx, pn);
+        switch (W) {
+#define X(w) case w: RFX_HIP(hipFuncSetAttribute((const void *)k_sk_onesweep<w>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                     hipLaunchKernelGGL((k_sk_onesweep<w>), dim3((unsigned)G), dim3(SKT), lds, ctx->stream, rsrc, lv, os, dst); break;
+            RFX_SK_W_CASES(X)
+#undef X
+            default: RFX_HIP(hipFuncSetAttribute((const void *)k_sk_onesweep<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                     hipLaunchKernelGGL((k_sk_onesweep<19>), dim3((unsigned)G), dim3(SKT), lds, ctx->stream, rsrc, lv, os, dst); break;
+        }
+        RFX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_fix_holes, dim3((unsigned)nb), dim3(FH_T), 0, ctx->stream, os, G, dst, d_seg_begin, d_seg_end,
+                           totals.as<unsigned long long>());
+        RFX_HIP(hipGetLastError());
+    }
+    int h_over = 0;
+    RFX_HIP(hipMemcpyAsync(h_tot, totals.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(&h_over, d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    if (getenv("RFX_TRACE"))
+        fprintf(stderr, "one-sweep level 1: %llu records in regions of %llu (sample 1/%d, %d workgroups)%s\n", h_tot[1], h_tot[0], sample, G,
+                h_over ? " -- a region overflowed: two passes instead" : "");
+    if (h_over == 2) { ctx->last_error = "one-sweep level 1: holes and tail records do not balance"; return RFX_E_STATE; }
+    if (h_over) return RFX_OK;
+    *out_recs = dst;
+    *n_recs = (int64_t)h_tot[1];
+    *done = true;
+    return RFX_OK;
+}
+
 // levels [first_level, ...) of the record path on records already bucketed by `used` bits
 // (seg offsets in *seg_cur), then the leaves.
 // the partition levels of a record array: -> the fully partitioned array and its leaf offsets
 template <int MODE>
 static int partition_record_levels(rfx_ctx *ctx, const typename LevelElem<MODE>::T *recs, int64_t n_recs, int ws_slot_of_recs,
                                    const std::vector<int> &bits, size_t first_level, int used, DevBuf **seg_cur_io,
-                                   DevBuf **seg_next_io, int64_t *nseg_io, const typename LevelElem<MODE>::T **cur_out) {
+                                   DevBuf **seg_next_io, int64_t *nseg_io, const typename LevelElem<MODE>::T **cur_out,
+                                   const uint64_t *seg_end_first = nullptr) {
     using Rec = typename LevelElem<MODE>::T;
     DevBuf *seg_cur = *seg_cur_io, *seg_next = *seg_next_io;
     int64_t nseg = *nseg_io;
@@ -2283,11 +2669,12 @@ static int partition_record_levels(rfx_ctx *ctx, const typename LevelElem<MODE>:
         RFX_HIP(scanned.alloc(((size_t)nb * v_bound + 1) * 8, ctx->stream));
         RFX_HIP(seg_next->alloc((size_t)(nchild + 1) * 8, ctx->stream));
         RFX_HIP(hipMemsetAsync(table.p, 0, (size_t)nb * v_bound * 4, ctx->stream));
+        const uint64_t *seg_end = l == first_level ? seg_end_first : nullptr;
         hipLaunchKernelGGL(k_vb_per_seg, dim3((unsigned)ceil_div(nseg, 256)), dim3(256), 0, ctx->stream,
-                           (const uint64_t *)seg_cur->as<uint64_t>(), nseg, tpb, nvb.as<uint64_t>());
+                           (const uint64_t *)seg_cur->as<uint64_t>(), seg_end, nseg, tpb, nvb.as<uint64_t>());
         RFX_HIP(hipGetLastError());
         RFX_TRY(exclusive_scan_u64(ctx, nvb.as<uint64_t>(), vb_start.as<uint64_t>(), nseg));
-        VbMap vm{seg_cur->as<uint64_t>(), vb_start.as<uint64_t>(), nseg, tpb};
+        VbMap vm{seg_cur->as<uint64_t>(), vb_start.as<uint64_t>(), nseg, tpb, seg_end};
         const char *hn = l == 0 ? "hist1" : l == 1 ? "hist2" : "hist3";
         const char *pn = l == 0 ? "part1" : l == 1 ? "part2" : "part3";
         {
@@ -2347,10 +2734,10 @@ static int count_records_levels(rfx_ctx *ctx, const Rec *recs, int64_t n_recs, i
                                 const std::vector<int> &bits, size_t first_level, int used, DevBuf *seg_cur,
                                 DevBuf *seg_next, int64_t nseg, int k, int min_cov, int max_cov, int twin,
                                 uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n,
-                                int64_t *out_distinct, bool pair_out = false) {
+                                int64_t *out_distinct, bool pair_out = false, const uint64_t *seg_end_first = nullptr) {
     const Rec *cur = nullptr;
     RFX_TRY(partition_record_levels<0>(ctx, recs, n_recs, ws_slot_of_recs, bits, first_level, used, &seg_cur, &seg_next,
-                                           &nseg, &cur));
+                                           &nseg, &cur, seg_end_first));
     return finish_leaves<1>(ctx, cur, n_recs, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, k, min_cov, max_cov, twin,
                             2 * k, d_out_keys, d_out_counts, cap, out_n, out_distinct, pair_out);
 }
@@ -2373,9 +2760,19 @@ static int count_reads_superkmer(rfx_ctx *ctx, const ReadStore *reads, int min_c
     RFX_HIP(segA.alloc(((size_t)(1 << lv.bits) + 1) * 8, ctx->stream));
     Rec *recs = nullptr;
     int64_t R = 0;
-    RFX_TRY(records_from_reads(ctx, rsrc, lv, true, 0, nullptr, 0, segA.as<uint64_t>(), &recs, &R, "hist1", "part1"));
+    // level 1 in one sweep when the input is large enough for a sampled histogram to size the regions (and another
+    // level follows: the leaves want gap-free buckets); RFX_SK_ONESWEEP=0 two passes always, =2 one sweep at any size
+    const int os_mode = getenv("RFX_SK_ONESWEEP") ? atoi(getenv("RFX_SK_ONESWEEP")) : 1;
+    bool swept = false;
+    DevBuf segE;
+    if (os_mode && bits.size() >= 2 && (os_mode == 2 || rsrc.n_threads >= ((int64_t)1 << 22))) {
+        RFX_HIP(segE.alloc((size_t)(1 << lv.bits) * 8, ctx->stream));
+        RFX_TRY(records_onesweep(ctx, rsrc, lv, 0, segA.as<uint64_t>(), segE.as<uint64_t>(), &recs, &R, &swept, "hist1", "part1"));
+    }
+    if (!swept) RFX_TRY(records_from_reads(ctx, rsrc, lv, true, 0, nullptr, 0, segA.as<uint64_t>(), &recs, &R, "hist1", "part1"));
     return count_records_levels(ctx, recs, R, 0, bits, 1, lv.bits, &segA, &segB, (int64_t)1 << lv.bits, reads->k,
-                                min_cov, max_cov, twin, d_out_keys, d_out_counts, cap, out_n, out_distinct, pair_out);
+                                min_cov, max_cov, twin, d_out_keys, d_out_counts, cap, out_n, out_distinct, pair_out,
+                                swept ? (const uint64_t *)segE.as<uint64_t>() : nullptr);
 }
 
 int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, int64_t n,
@@ -2469,7 +2866,7 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
             RFX_HIP(scanned.alloc(((size_t)nb * v_bound + 1) * 8, ctx->stream));
             RFX_HIP(hipMemsetAsync(table.p, 0, (size_t)nb * v_bound * 4, ctx->stream));
             hipLaunchKernelGGL(k_vb_per_seg, dim3((unsigned)ceil_div(nseg, 256)), dim3(256), 0, ctx->stream,
-                               (const uint64_t *)seg_cur->as<uint64_t>(), nseg, tpb, nvb.as<uint64_t>());
+                               (const uint64_t *)seg_cur->as<uint64_t>(), (const uint64_t *)nullptr, nseg, tpb, nvb.as<uint64_t>());
             RFX_HIP(hipGetLastError());
             RFX_TRY(exclusive_scan_u64(ctx, nvb.as<uint64_t>(), vb_start.as<uint64_t>(), nseg));
             VbMap vm{seg_cur->as<uint64_t>(), vb_start.as<uint64_t>(), nseg, tpb};
@@ -2613,7 +3010,7 @@ int bucket_pairs_by_owner(rfx_ctx *ctx, const void *d_pairs, int64_t n, int n_ow
     RFX_HIP(table.alloc((size_t)nb * v_bound * 4, ctx->stream));
     RFX_HIP(scanned.alloc(((size_t)nb * v_bound + 1) * 8, ctx->stream));
     RFX_HIP(hipMemsetAsync(table.p, 0, (size_t)nb * v_bound * 4, ctx->stream));
-    hipLaunchKernelGGL(k_vb_per_seg, dim3(1), dim3(256), 0, ctx->stream, (const uint64_t *)seg.as<uint64_t>(), (int64_t)1, tpb,
+    hipLaunchKernelGGL(k_vb_per_seg, dim3(1), dim3(256), 0, ctx->stream, (const uint64_t *)seg.as<uint64_t>(), (const uint64_t *)nullptr, (int64_t)1, tpb,
                        nvb.as<uint64_t>());
     RFX_HIP(hipGetLastError());
     RFX_TRY(exclusive_scan_u64(ctx, nvb.as<uint64_t>(), vb_start.as<uint64_t>(), 1));

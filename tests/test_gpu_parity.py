@@ -927,6 +927,44 @@ def test_count_survives_extreme_skew(rfx, torch_mod, k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,mode", [(31, "sweep"), (25, "sweep"), (31, "overflow"), (31, "skew")])
+def test_one_sweep_level1_matches_oracle(rfx, torch_mod, k, mode, monkeypatch):
+    """Level 1 of the record path in ONE sweep (k_sk_onesweep: regions sized from a sampled histogram, extents off
+    per-bucket cursors, holes closed by k_fix_holes) forced at a size the default would send through the two-pass
+    form: counts equal the oracle's.  'overflow': regions a hundredth of the estimate -- the sweep must notice and
+    the two-pass form take over; 'skew': half the reads poly-A, one bucket far beyond its sampled estimate or not,
+    either way the oracle's counts."""
+    torch = torch_mod
+    monkeypatch.setenv("RFX_SK_ONESWEEP", "2")
+    if mode == "overflow":
+        monkeypatch.setenv("RFX_SK_ONESWEEP_CAP", "1")
+    seed, G, n_reads, L = 11 + k, 30_000, 40_000, 150
+    if mode == "skew":
+        rng = np.random.default_rng(3)
+        g = O.synth_genome(seed, G)
+        bases, off = O.synth_reads(seed, g, G, 0, n_reads // 2, L)
+        reads = [bytes(bases[off[i]:off[i + 1]]).decode() for i in range(n_reads // 2)] + ["A" * L] * (n_reads // 2)
+        rng.shuffle(reads)
+        b2, o2, gk, gc, nd, inst = _count_ascii_reads_dev(rfx, torch, reads, L, k, 2)
+        km = O.extract_canon(b2, o2, k)
+        wk, wc, wd = O.count_filter(km, 2)
+        assert inst == len(km) and nd == wd and np.array_equal(gk, wk) and np.array_equal(gc, wc)
+        return
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    N = rfx.kmers_per_read(L, k) * n_reads
+    dk = torch.empty(N, dtype=torch.int64, device="cuda"); dc = torch.empty(N, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+    km = O.extract_canon(bases, off, k)
+    for min_cov in (1, 2):
+        m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, min_cov)
+        wk, wc, wd = O.count_filter(km, min_cov)
+        assert inst == len(km) and nd == wd and m == len(wk)
+        assert np.array_equal(dk[:m].cpu().numpy().view(np.uint64), wk) and np.array_equal(dc[:m].cpu().numpy(), wc)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k", [31, 21])
 def test_heavy_leaf_slices_merge_exactly(rfx, torch_mod, k, monkeypatch):
     """Force every leaf through the heavy-leaf path (slices counted by the whole grid, partial counts

@@ -440,9 +440,24 @@ constexpr int LT = RFX_LT;              // threads per leaf workgroup
 constexpr int OBUF = 512;               // survivors buffered in LDS between flushes
 constexpr int WSTAGE = 160;             // u64 words of a wave's private expansion area (record leaves)
 constexpr int LSTAGE = WSTAGE * (LT / 64);
-constexpr int LCAP = 4096;              // hash slots
+#ifndef RFX_LCAP
+#define RFX_LCAP 4096
+#endif
+constexpr int LCAP = RFX_LCAP;          // hash slots: 4096, or 3072 (three quarters of 12 hash bits; probe steps prime to it)
 constexpr int LCAP_BITS = 12;
-static_assert(LCAP == 1 << LCAP_BITS, "slot bits");
+static_assert(LCAP == 4096 || LCAP == 3072, "slots");
+__device__ __forceinline__ uint32_t leaf_slot(uint32_t g) {
+    const uint32_t x = g >> (32 - LCAP_BITS);
+    return LCAP == 4096 ? x : (x * 3u) >> 2;
+}
+__device__ __forceinline__ uint32_t leaf_step(uint32_t g) {
+    return LCAP == 4096 ? (((g >> 8) & (LCAP - 1)) | 1u) : ((g >> 8) & 511u) * 6u + 1u;      // (6 t + 1 is prime to 2^10 x 3)
+}
+__device__ __forceinline__ uint32_t leaf_next(uint32_t slot, uint32_t step) {
+    if (LCAP == 4096) return (slot + step) & (LCAP - 1);
+    const uint32_t x = slot + step;
+    return x >= (uint32_t)LCAP ? x - LCAP : x;
+}
 constexpr int LPROBE = 48;              // a probe sequence this long means the table is too full: split the leaf
 constexpr uint64_t EMPTY = ~0ULL;
 constexpr int LSTACK = 48;
@@ -652,7 +667,7 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
         auto insert2 = [&](uint64_t keyA, bool a, uint64_t keyB, bool b, uint32_t wA, uint32_t wB) __attribute__((always_inline)) {
             const uint32_t gA = ((uint32_t)keyA ^ __builtin_rotateleft32((uint32_t)(keyA >> 32), 13)) * 0x9E3779B1u;
             const uint32_t gB = ((uint32_t)keyB ^ __builtin_rotateleft32((uint32_t)(keyB >> 32), 13)) * 0x9E3779B1u;
-            uint32_t slotA = gA >> (32 - LCAP_BITS), slotB = gB >> (32 - LCAP_BITS);
+            uint32_t slotA = leaf_slot(gA), slotB = leaf_slot(gB);
             if (S > 1) {
                 a = a && (((gA >> 4) & 0xffffu) & (S - 1)) == s;
                 b = b && (((gB >> 4) & 0xffffu) & (S - 1)) == s;
@@ -668,10 +683,10 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
             // (double hashing: an odd step from other hash bits -- the wave waits for its longest probe sequence,
             // and linear probing's clusters make that one long in a leaf that fills its table)
             auto walk = [&](uint64_t key, uint32_t slot, uint32_t w, uint32_t g) __attribute__((always_inline)) {
-                const uint32_t step = (dbg & 16) ? 1u : (((g >> 8) & (LCAP - 1)) | 1u);
+                const uint32_t step = (dbg & 16) ? 1u : leaf_step(g);
                 // (left to the compiler's full unroll: `#pragma unroll 1` shrinks the kernel threefold and is 2 % slower)
                 for (int probe = 1;; probe++) {
-                    slot = (slot + step) & (LCAP - 1);
+                    slot = leaf_next(slot, step);
                     const unsigned long long p = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
                     if (p == EMPTY || p == key) { atomicAdd(&tcnt[slot], w); break; }
                     if (probe >= LPROBE) { overflow = 1; break; }

@@ -11,8 +11,10 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAMILY = [("hist1", "k_sk_hist"), ("part1", "k_sk_scatter"), ("hist2", "k_rec_hist"), ("part2", "k_rec_scatter"),
-          ("leaf", "k_leaf_count")]
+# (level 1 is one sweep by default: k_sk_sample_hist + k_plan_regions, then k_sk_onesweep + k_fix_holes; the two-pass
+# kernels k_sk_hist / k_sk_scatter appear when it falls back)
+FAMILY = [("hist1", ("k_sk_sample_hist", "k_plan_regions", "k_sk_hist")), ("part1", ("k_sk_onesweep", "k_fix_holes", "k_sk_scatter")),
+          ("hist2", ("k_rec_hist",)), ("part2", ("k_rec_scatter",)), ("leaf", ("k_leaf_count",))]
 
 
 def main():
@@ -39,7 +41,7 @@ def main():
             for r in csv.DictReader(open(fn)):
                 name = r["Kernel_Name"]
                 for fam, key in FAMILY:
-                    if key in name:
+                    if any(x in name for x in key):
                         per[fam][r["Counter_Name"]] += float(r["Counter_Value"])
                         launches[fam][r["Counter_Name"]] += 1
                         pmc_rows.append({"family": fam, "kernel": name[:80], "counter": r["Counter_Name"],

@@ -482,17 +482,24 @@ class Reflexiv:
         self._check(st, "rfx_dev_merge_pairs")
         return int(m.value), int(d.value)
 
+    def _text_buffer(self, cap: int):
+        """The contig text of the device-resident drivers lands in one host buffer that the object keeps (grow-only):
+        a fresh multi-hundred-megabyte mapping per call costs its page faults on every megabyte the text touches."""
+        buf = getattr(self, "_textbuf", None)
+        if buf is None or len(buf) < cap:
+            buf = self._textbuf = np.empty(cap, np.uint8)
+        return buf, len(buf)
+
     def assemble_dev(self, d_keys: int, d_counts: int, n: int, prm: Params):
         """Driver P/ReflexivMain.java:168-310 from the filtered (kmer,count) list in HBM
         -> (contig text, n_contigs, trace)."""
         trace = np.zeros(prm.max_iter + 8, np.int64)
         ln, nc, ntr = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        cap = 4 * (n + 16) * (prm.k + 8) + 1024
-        buf = np.empty(cap, np.uint8)
+        buf, cap = self._text_buffer(4 * (n + 16) * (prm.k + 8) + 1024)
         self._check(self.L.rfx_dev_assemble(self.ctx, C.c_void_p(d_keys), C.c_void_p(d_counts), C.c_int64(n),
                                             C.byref(prm), _p(buf), C.c_int64(cap), C.byref(ln), C.byref(nc),
                                             _p(trace), C.c_int64(len(trace)), C.byref(ntr)), "rfx_dev_assemble")
-        return bytes(buf[:ln.value]).decode(), int(nc.value), [int(x) for x in trace[:ntr.value]]
+        return str(memoryview(buf)[:ln.value], "ascii"), int(nc.value), [int(x) for x in trace[:ntr.value]]
 
     def order_kmers_w_dev(self, d_keys: int, d_counts: int, n: int, k: int):
         """k = 33..63: (two-word k-mer, int64 count) pairs in any order -> ascending k-mer order, in place."""
@@ -514,12 +521,11 @@ class Reflexiv:
         from the filtered (k-mer, count) list in HBM (assembler layout) -> (contig text, n_contigs, trace)."""
         trace = np.zeros(prm.max_iter + 8, np.int64)
         ln, nc, ntr = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        cap = 4 * (n + 16) * (prm.k + 8) + 1024
-        buf = np.empty(cap, np.uint8)
+        buf, cap = self._text_buffer(4 * (n + 16) * (prm.k + 8) + 1024)
         self._check(self.L.rfx_dev_assemble_w(self.ctx, C.c_void_p(d_kmers), C.c_void_p(d_counts), C.c_int64(n),
                                               C.byref(prm), _p(buf), C.c_int64(cap), C.byref(ln), C.byref(nc),
                                               _p(trace), C.c_int64(len(trace)), C.byref(ntr)), "rfx_dev_assemble_w")
-        return bytes(buf[:ln.value]).decode(), int(nc.value), [int(x) for x in trace[:ntr.value]]
+        return str(memoryview(buf)[:ln.value], "ascii"), int(nc.value), [int(x) for x in trace[:ntr.value]]
 
     def synth_genome_dev(self, seed: int, genome_len: int, d_genome: int):
         self._check(self.L.rfx_dev_synth_genome(self.ctx, C.c_uint64(seed), C.c_int64(genome_len),

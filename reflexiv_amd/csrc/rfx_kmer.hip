@@ -438,7 +438,14 @@ __global__ __launch_bounds__(PT) void k_vb_scatter(const uint64_t *__restrict__ 
 // against 12.6 (tools/build_variant.sh + tools/ab_many.sh; 10 waves per workgroup: 20 ms)
 constexpr int LT = RFX_LT;              // threads per leaf workgroup
 constexpr int OBUF = 512;               // survivors buffered in LDS between flushes
-constexpr int WSTAGE = 160;             // u64 words of a wave's private expansion area (record leaves)
+// (experiment, off: parking the keys whose first probe failed and walking 64 of them at once, one per lane, instead of
+// on the spot -- halves the SGPR spills, same 12.7 ms: the probe walks are not what the wave waits for)
+#ifndef RFX_LEAF_QUEUE
+#define RFX_LEAF_QUEUE 0
+#endif
+constexpr int LQCAP = RFX_LEAF_QUEUE ? 128 : 0;   // keys a wave parks for a later, dense walk of their probe sequences (record leaves)
+constexpr int LOBUF = RFX_LEAF_QUEUE ? 256 : 512; // survivors k_leaf_count buffers in LDS between flushes
+constexpr int WSTAGE = 160 + LQCAP;     // u64 words of a wave's private expansion area (record leaves)
 constexpr int LSTAGE = WSTAGE * (LT / 64);
 #ifndef RFX_LCAP
 #define RFX_LCAP 4096
@@ -568,8 +575,8 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
     const int k = KC ? KC : k_rt;
     __shared__ __attribute__((aligned(16))) unsigned long long tkey[LCAP];
     __shared__ __attribute__((aligned(16))) uint32_t tcnt[LCAP];
-    __shared__ unsigned long long obk[OBUF];
-    __shared__ int32_t obc[OBUF];
+    __shared__ unsigned long long obk[LOBUF];
+    __shared__ int32_t obc[LOBUF];
     __shared__ uint32_t stackS[LSTACK], stacks[LSTACK];
     __shared__ int sp;
     __shared__ uint32_t overflow, ob_n, ob_lim;
@@ -660,6 +667,7 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
 
     // one table pass over the leaf [begin, end): inserts the keys selected by (S, s); no barriers
     auto run_pass = [&](uint32_t S, uint32_t s, bool first, uint64_t begin_next, uint64_t end_next) __attribute__((always_inline)) {
+        uint32_t qn = 0;                 // keys parked in this wave's queue (wave-uniform; < 64 between rounds)
         // Two keys per lane probe in lock-step so that two LDS compare-and-swaps are in flight.  A key
         // is done when its slot held EMPTY (claimed) or the key itself; either way its count goes up.
         // There is no occupancy counter: a probe sequence longer than LPROBE flags the pass as
@@ -693,8 +701,56 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
                 }
             };
             // (one loop per key; a single loop walking a lane's two sequences one after the other measured 10 % slower)
-            if (!dA) walk(keyA, slotA, wA, gA);
-            if (!dB) walk(keyB, slotB, wB, gB);
+            if constexpr (RECS && LQCAP > 0) {
+                // Records: a key whose first probe met another key is PARKED in the wave's queue; the probe sequences
+                // are walked once 64 keys wait, one per lane.  Walked on the spot, one or two lanes in ten hold the
+                // whole wave through its longest probe sequence (four or five LDS round trips) in every round.
+                uint64_t *wq = stage + wave_ * WSTAGE + 160;
+#pragma nounroll
+                for (int ph = 0; ph < 2; ph++) {
+                    const bool u = ph == 0 ? !dA : !dB;
+                    const uint64_t m = __ballot(u);
+                    if (m) {
+                        const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if (u) wq[qn + r] = ph == 0 ? keyA : keyB;
+                        qn += (uint32_t)__popcll(m);
+                        __builtin_amdgcn_wave_barrier();
+                        if (qn >= 64u) {
+                            qn -= 64u;
+                            const uint64_t key = wq[qn + lane_];
+                            const uint32_t g = ((uint32_t)key ^ __builtin_rotateleft32((uint32_t)(key >> 32), 13)) * 0x9E3779B1u;
+                            walk(key, leaf_slot(g), 1u, g);
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                }
+            } else {
+                if (!dA) walk(keyA, slotA, wA, gA);
+                if (!dB) walk(keyB, slotB, wB, gB);
+            }
+        };
+        // the keys still parked when the wave has been through its share of the leaf
+        auto drain_queue = [&]() __attribute__((always_inline)) {
+            if constexpr (RECS && LQCAP > 0) {
+                uint64_t *wq = stage + wave_ * WSTAGE + 160;
+                if (qn) {
+                    const bool mine = (uint32_t)lane_ < qn;
+                    const uint64_t key = mine ? wq[lane_] : 0;
+                    const uint32_t g = ((uint32_t)key ^ __builtin_rotateleft32((uint32_t)(key >> 32), 13)) * 0x9E3779B1u;
+                    if (mine) {
+                        const uint32_t step = (dbg & 16) ? 1u : leaf_step(g);
+                        uint32_t slot = leaf_slot(g);
+#pragma unroll 1
+                        for (int probe = 1;; probe++) {
+                            slot = leaf_next(slot, step);
+                            const unsigned long long p = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
+                            if (p == EMPTY || p == key) { atomicAdd(&tcnt[slot], 1u); break; }
+                            if (probe >= LPROBE) { overflow = 1; break; }
+                        }
+                    }
+                    qn = 0;
+                }
+            }
         };
         if constexpr (RECS) {
             // Records: every wave takes an equal contiguous share of the leaf and walks it 64 records
@@ -810,6 +866,7 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
                 const bool valid = r0 + lane_ < we;
                 step(valid ? keys[r0 + lane_] : Rec{0, 0}, valid);
             }
+            drain_queue();
         } else {
             for (uint64_t base = begin; base < end; base += (uint64_t)LT * NB) {
                 // an overflowing pass is abandoned: stop feeding a table that is filling up
@@ -878,7 +935,7 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
                     }
                     if (lane_ == leader) base = atomicAdd(&ob_n, cntw);
                     base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-                    if (base + cntw <= (uint32_t)OBUF) {
+                    if (base + cntw <= (uint32_t)LOBUF) {
                         if (keep) { obk[base + r] = tkey[slot]; obc[base + r] = c; }
                     } else {
                         uint32_t glo = 0, ghi = 0;
@@ -904,7 +961,7 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
         if (dbg & 32) { const long long t0 = clock64(); __syncthreads(); t_wait += clock64() - t0; }
         else __syncthreads();
         const uint32_t raw = ob_n, lim = ob_lim;      // stable until the next emit_pass
-        if (raw >= (uint32_t)OBUF / 2 || lim != 0xffffffffu) flush();
+        if (raw >= (uint32_t)LOBUF / 2 || lim != 0xffffffffu) flush();
     };
 
     for (int64_t leaf = l0; leaf < l1; leaf++) {
@@ -1662,19 +1719,21 @@ __global__ __launch_bounds__(SKT, WIDE ? 4 : 8) void k_sk_scatter(ReadSrc s, Lev
 // What a workgroup leaves unused of its last two extents are HOLES; k_fix_holes moves the records at the end of every
 // bucket into the holes before it, so the next level reads a gap-free [seg_begin, seg_end) per bucket.  A region that
 // runs out (a sample that missed the skew) raises `overflow` and the caller falls back to the two-pass form.
-constexpr int OSE = 64;                  // records per extent (a round must not put more than OSE records of one
-                                         // workgroup into one bucket: 5 on average at 512 buckets)
+constexpr int OSE_MIN = 64, OSE_MAX = 256;   // records per extent: a round must not put more than one extent of one
+                                         // workgroup into one bucket (5 records on average at 512 buckets); the sampled
+                                         // histogram picks 64, 128 or 256 by the busiest bucket, or no sweep at all
 constexpr int OS_CSTRIDE = 16;           // cursors 128 bytes apart: one atomic unit each
 constexpr int OS_MAXG = 512;             // workgroups of the sweep
 constexpr int OS_HOLES = 3;              // extents a workgroup has in hand per bucket: filling, next, requested
 struct OneSweep {
-    const uint64_t *reg_start;           // [nb + 1] first record of every region (multiples of OSE); [nb] = a dump extent
+    const uint64_t *reg_start;           // [nb + 1] first record of every region (multiples of the extent); [nb] = a dump extent
     const uint32_t *reg_cap;             // [nb] records a region holds
     unsigned long long *cursor;          // [nb * OS_CSTRIDE] next record to hand out (absolute; starts at reg_start)
-    uint64_t *holes;                     // [nb][OS_HOLES * G] (absolute start << 8) | length, 0 = none
+    uint64_t *holes;                     // [nb][OS_HOLES * G] (absolute start << 16) | length, 0 = none
     int *overflow;
     uint64_t total;                      // records allocated (regions + the dump extent)
     unsigned long long *tile_counter;    // tiles of SKT segments handed out beyond every workgroup's first
+    uint32_t ose, ose_shift;             // records per extent (a power of two)
 };
 
 template <int W>
@@ -1700,19 +1759,33 @@ __global__ __launch_bounds__(SKT) void k_sk_sample_hist(ReadSrc s, Level lv, int
 }
 
 // regions from the sampled histogram: estimate + six standard deviations of the sample + 1/64 + what the workgroups
-// hold in hand; totals[0] = records to allocate (regions + the dump extent)
+// hold in hand; totals[0] = records to allocate (regions + the dump extent), totals[2] = records per extent: four times
+// what a tile is expected to put into the busiest bucket, or 0 = no sweep (low-complexity reads on one minimiser)
 __global__ __launch_bounds__(1024) void k_plan_regions(const unsigned long long *__restrict__ hist, int nb, double scale, int G, int cap_pct,
+                                                       double tiles,
                                                        uint64_t *__restrict__ reg_start, uint32_t *__restrict__ reg_cap,
                                                        unsigned long long *__restrict__ cursor, unsigned long long *__restrict__ totals) {
     __shared__ uint64_t caps[1 << MAX_BITS];
+    __shared__ unsigned long long busiest;
+    __shared__ uint32_t ose_s;
     const int d = threadIdx.x;
+    if (d == 0) busiest = 0;
+    __syncthreads();
+    if (d < nb) atomicMax(&busiest, hist[d]);
+    __syncthreads();
+    if (d == 0) {
+        const double per_tile = (double)busiest * scale / tiles;       // records a tile puts into the busiest bucket
+        ose_s = per_tile <= 16.0 ? 64u : per_tile <= 32.0 ? 128u : per_tile <= 64.0 ? 256u : 0u;
+    }
+    __syncthreads();
+    const uint32_t E = ose_s ? ose_s : OSE_MIN;
     if (d < nb) {
         const double c = (double)hist[d];
         const double est = c * scale;
         double room = (est + 6.0 * scale * sqrt(c + 1.0) + est / 64.0 + 1024.0) * (double)cap_pct / 100.0;
-        uint64_t cap = (uint64_t)room + (uint64_t)G * OS_HOLES * OSE;
-        cap = (cap + OSE - 1) / OSE * OSE;
-        if (cap > 0xFFFFFF00ULL) cap = 0xFFFFFF00ULL / OSE * OSE;      // bucket-local positions are 32-bit
+        uint64_t cap = (uint64_t)room + (uint64_t)G * OS_HOLES * E;
+        cap = (cap + E - 1) / E * E;
+        if (cap > 0xFFFFFF00ULL) cap = 0xFFFFFF00ULL / E * E;          // bucket-local positions are 32-bit
         caps[d] = cap;
         reg_cap[d] = (uint32_t)cap;
     }
@@ -1721,8 +1794,9 @@ __global__ __launch_bounds__(1024) void k_plan_regions(const unsigned long long 
         uint64_t at = 0;
         for (int i = 0; i < nb; i++) { reg_start[i] = at; cursor[(size_t)i * OS_CSTRIDE] = at; at += caps[i]; }
         reg_start[nb] = at;
-        totals[0] = at + OSE;
+        totals[0] = at + E;
         totals[1] = 0;
+        totals[2] = ose_s;
     }
 }
 
@@ -1738,19 +1812,20 @@ __global__ __launch_bounds__(SKT, 8) void k_sk_onesweep(ReadSrc s, Level lv, One
 #define nbase (tail + 4 * nb)                                               /* the next one */
 #define pbase (tail + 5 * nb)                                               /* the one after that, or NONE while it is on order */
     constexpr uint32_t DUMP = 0xFFFFFFFFu;
+    const uint32_t OSE = os.ose, OSH = os.ose_shift;
     const uint64_t dump_at = os.total - OSE;
     // An extent off bucket d's cursor.  Only the END OF THE ALLOCATION is checked here (no load on this path): an extent
     // past the bucket's own region lands in its neighbour's, which k_fix_holes sees from the cursor and declares the
     // whole sweep void.
     auto grab = [&](int d) __attribute__((always_inline)) -> uint32_t {
         const unsigned long long b = atomicAdd(&os.cursor[(size_t)d * OS_CSTRIDE], (unsigned long long)OSE);
-        return b + OSE <= dump_at ? (uint32_t)(b / OSE) : DUMP;
+        return b + OSE <= dump_at ? (uint32_t)(b >> OSH) : DUMP;
     };
     // where local position v of a bucket lives (v - cs < 2 * OSE)
     auto phys = [&](uint32_t v, uint32_t cs, uint32_t cb, uint32_t nx) __attribute__((always_inline)) -> uint64_t {
         const uint32_t o = v - cs;
         const uint32_t b = o < (uint32_t)OSE ? cb : nx;
-        return (b == DUMP ? dump_at : (uint64_t)b * OSE) + (o & (OSE - 1));
+        return (b == DUMP ? dump_at : (uint64_t)b << OSH) + (o & (OSE - 1));
     };
     // The extent after the next one is requested a round ahead: thread d asks for bucket d's at the top of a round and
     // files it (pbase) at the end of the round's arithmetic, so the atomic has the whole round to come back -- waited
@@ -1838,9 +1913,9 @@ __global__ __launch_bounds__(SKT, 8) void k_sk_onesweep(ReadSrc s, Level lv, One
     for (int d = threadIdx.x; d < nb; d += SKT) {
         const uint32_t used = tail[d] - cstart[d], cb = cbase[d], nx = nbase[d], px = pbase[d];
         uint64_t *hl = os.holes + ((size_t)d * gridDim.x + blockIdx.x) * OS_HOLES;
-        hl[0] = cb != DUMP && used < (uint32_t)OSE ? (((uint64_t)cb * OSE + used) << 8) | (uint64_t)(OSE - used) : 0;
-        hl[1] = nx != DUMP ? (((uint64_t)nx * OSE) << 8) | (uint64_t)OSE : 0;
-        hl[2] = px != DUMP && px != NONE ? (((uint64_t)px * OSE) << 8) | (uint64_t)OSE : 0;
+        hl[0] = cb != DUMP && used < OSE ? ((((uint64_t)cb << OSH) + used) << 16) | (uint64_t)(OSE - used) : 0;
+        hl[1] = nx != DUMP ? (((uint64_t)nx << OSH) << 16) | (uint64_t)OSE : 0;
+        hl[2] = px != DUMP && px != NONE ? (((uint64_t)px << OSH) << 16) | (uint64_t)OSE : 0;
     }
 }
 #undef buf
@@ -1859,7 +1934,7 @@ __global__ __launch_bounds__(FH_T) void k_fix_holes(OneSweep os, int G, Rec *__r
                                                    uint64_t *__restrict__ seg_end, unsigned long long *__restrict__ totals) {
     constexpr int NHMAX = 2048;                                // holes of a bucket (>= OS_HOLES * OS_MAXG, a multiple of FH_T)
     static_assert(NHMAX >= OS_HOLES * OS_MAXG && NHMAX % FH_T == 0, "holes per bucket");
-    constexpr int NWMAX = NHMAX * OSE / 32;                    // words of the tail-zone bitmap
+    constexpr int NWMAX = NHMAX * OSE_MAX / 32;                // words of the tail-zone bitmap
     __shared__ uint32_t hstart[NHMAX], hoff[NHMAX + 1];
     __shared__ uint32_t bitmap[NWMAX];
     __shared__ uint32_t wsum[FH_T / 64];
@@ -1884,7 +1959,6 @@ __global__ __launch_bounds__(FH_T) void k_fix_holes(OneSweep os, int G, Rec *__r
         *total = tot;
         return b + x - v;
     };
-    for (int i = threadIdx.x; i < NWMAX; i += FH_T) bitmap[i] = 0;
     constexpr int HPT = NHMAX / FH_T;
     uint32_t hs[HPT], hl[HPT];
     uint32_t mine = 0;
@@ -1892,13 +1966,17 @@ __global__ __launch_bounds__(FH_T) void k_fix_holes(OneSweep os, int G, Rec *__r
     for (int r = 0; r < HPT; r++) {
         const int t = threadIdx.x * HPT + r;
         const uint64_t x = t < NH ? os.holes[(size_t)d * NH + t] : 0;
-        hl[r] = (uint32_t)(x & 255u);
-        hs[r] = hl[r] ? (uint32_t)((x >> 8) - base) : 0u;
+        hl[r] = (uint32_t)(x & 0xFFFFu);
+        hs[r] = hl[r] ? (uint32_t)((x >> 16) - base) : 0u;
         mine += hl[r];
     }
     uint32_t H;
     block_excl_scan(mine, &H);
     const uint32_t size = (uint32_t)alloc - H;
+    const uint32_t nw = (H + 31) / 32;                         // words of the tail zone's bitmap (<= NWMAX)
+    const uint32_t wpt = (nw + FH_T - 1) / FH_T;               // ... a thread looks after: [tid * wpt, tid * wpt + wpt)
+    for (uint32_t i = threadIdx.x; i < nw; i += FH_T) bitmap[i] = 0;
+    __syncthreads();
     // hole positions before `size` (to be filled) / inside the tail zone (marked)
     uint32_t fill[HPT], fsum = 0;
 #pragma unroll
@@ -1917,21 +1995,18 @@ __global__ __launch_bounds__(FH_T) void k_fix_holes(OneSweep os, int G, Rec *__r
     if (threadIdx.x == 0) hoff[NHMAX] = F;
     __syncthreads();
     // records of the tail zone, in position order
-    constexpr int WPT = NWMAX / FH_T;
-    uint32_t valid[WPT], vsum = 0;
-#pragma unroll
-    for (int r = 0; r < WPT; r++) {
-        const uint32_t w = threadIdx.x * WPT + r;
-        const uint32_t lim = w * 32 >= H ? 0u : (H - w * 32 >= 32 ? 0xFFFFFFFFu : (1u << (H - w * 32)) - 1u);
-        valid[r] = ~bitmap[w] & lim;
-        vsum += (uint32_t)__popc(valid[r]);
-    }
+    auto valid_word = [&](uint32_t w) __attribute__((always_inline)) -> uint32_t {
+        if (w >= nw) return 0u;
+        const uint32_t lim = H - w * 32 >= 32 ? 0xFFFFFFFFu : (1u << (H - w * 32)) - 1u;
+        return ~bitmap[w] & lim;
+    };
+    uint32_t vsum = 0;
+    for (uint32_t r = 0; r < wpt; r++) vsum += (uint32_t)__popc(valid_word(threadIdx.x * wpt + r));
     uint32_t V;
     uint32_t vo = block_excl_scan(vsum, &V);
-#pragma unroll
-    for (int r = 0; r < WPT; r++) {
-        uint32_t m = valid[r];
-        const uint32_t w = threadIdx.x * WPT + r;
+    for (uint32_t r = 0; r < wpt; r++) {
+        const uint32_t w = threadIdx.x * wpt + r;
+        uint32_t m = valid_word(w);
         while (m) {
             const int b = __ffs((int)m) - 1;
             m &= m - 1;
@@ -2598,7 +2673,7 @@ static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv, 
     RFX_HIP(reg_start.alloc((size_t)(nb + 1) * 8, ctx->stream));
     RFX_HIP(reg_cap.alloc((size_t)nb * 4, ctx->stream));
     RFX_HIP(cursor.alloc((size_t)nb * OS_CSTRIDE * 8, ctx->stream));
-    RFX_HIP(totals.alloc(16, ctx->stream));
+    RFX_HIP(totals.alloc(24, ctx->stream));
     RFX_HIP(holes.alloc((size_t)nb * OS_HOLES * G * 8, ctx->stream));
     RFX_HIP(hipMemsetAsync(hist.p, 0, (size_t)nb * 8 + 16, ctx->stream));
     int *d_overflow = (int *)(hist.as<unsigned long long>() + nb);
@@ -2613,17 +2688,24 @@ static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv, 
         }
         RFX_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_plan_regions, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long *)hist.as<unsigned long long>(), nb,
-                           (double)ntile / (double)n_sampled, G, cap_pct, reg_start.as<uint64_t>(), reg_cap.as<uint32_t>(),
+                           (double)ntile / (double)n_sampled, G, cap_pct, (double)ntile, reg_start.as<uint64_t>(), reg_cap.as<uint32_t>(),
                            cursor.as<unsigned long long>(), totals.as<unsigned long long>());
         RFX_HIP(hipGetLastError());
     }
-    unsigned long long h_tot[2] = {0, 0};
-    RFX_HIP(hipMemcpyAsync(h_tot, totals.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long h_tot[3] = {0, 0, 0};
+    RFX_HIP(hipMemcpyAsync(h_tot, totals.p, 24, hipMemcpyDeviceToHost, ctx->stream));
     RFX_HIP(hipStreamSynchronize(ctx->stream));
+    const uint32_t ose = (uint32_t)h_tot[2];
+    if (ose == 0) {                       // one bucket takes more of a tile than the largest extent: two passes straight away
+        if (getenv("RFX_TRACE")) fprintf(stderr, "one-sweep level 1: not tried (the sample puts too much on one bucket)\n");
+        return RFX_OK;
+    }
+    int ose_shift = 0;
+    while ((1u << ose_shift) < ose) ose_shift++;
     Rec *dst = (Rec *)ctx->ws_get(ws_slot, (size_t)h_tot[0] * sizeof(Rec));
     if (!dst) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
     const OneSweep os{reg_start.as<uint64_t>(), reg_cap.as<uint32_t>(), cursor.as<unsigned long long>(), holes.as<uint64_t>(), d_overflow,
-                      (uint64_t)h_tot[0], hist.as<unsigned long long>() + nb + 1};
+                      (uint64_t)h_tot[0], hist.as<unsigned long long>() + nb + 1, ose, (uint32_t)ose_shift};
     const size_t lds = (size_t)nb * (SKB * sizeof(Rec) + 24);
     {
         ScopedTimer t(ctx, pn);
@@ -2645,7 +2727,7 @@ static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv, 
     RFX_HIP(hipMemcpyAsync(&h_over, d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
     RFX_HIP(hipStreamSynchronize(ctx->stream));
     if (getenv("RFX_TRACE"))
-        fprintf(stderr, "one-sweep level 1: %llu records in regions of %llu (sample 1/%d, %d workgroups)%s\n", h_tot[1], h_tot[0], sample, G,
+        fprintf(stderr, "one-sweep level 1: %llu records in regions of %llu (sample 1/%d, %d workgroups, extents of %u)%s\n", h_tot[1], h_tot[0], sample, G, ose,
                 h_over ? " -- a region overflowed: two passes instead" : "");
     if (h_over == 2) { ctx->last_error = "one-sweep level 1: holes and tail records do not balance"; return RFX_E_STATE; }
     if (h_over) return RFX_OK;

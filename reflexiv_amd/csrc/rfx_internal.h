@@ -23,7 +23,7 @@ struct rfx_ctx {
     // grow-only workspace slots for the large, reused buffers (instance arrays of the count
     // stage): allocated once with hipMalloc, kept until the context dies
     struct WsSlot { void *p = nullptr; size_t bytes = 0; };
-    WsSlot ws[4];
+    WsSlot ws[5];          // 0, 1: the count stage's record / instance buffers; 2, 3: the extend stage's arenas; 4: the count stage's arena
     void *ws_get(int slot, size_t bytes) {
         WsSlot &w = ws[slot];
         if (w.bytes >= bytes && w.p) return w.p;
@@ -127,6 +127,24 @@ struct DevBuf {
         p = nullptr; borrowed = false;
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// The temporaries of one count-stage call (histogram tables, scans, hole lists, sort buffers) from one bump arena the
+// context keeps (workspace slot 4): the stream-ordered allocator left the GPU idle for half a millisecond between the
+// levels of every step (30.9 -> 28.6 ms per step).  Nothing if an arena is already active; a request the arena cannot
+// take goes to the stream-ordered allocator as before.
+struct StageArena {
+    Arena arena;
+    Arena *prev;
+    bool on = false;
+    StageArena(rfx_ctx *ctx, size_t bytes) : prev(tl_arena) {
+        if (tl_arena || (getenv("RFX_COUNT_ARENA") && atoi(getenv("RFX_COUNT_ARENA")) == 0)) return;
+        arena.base = (char *)ctx->ws_get(4, bytes);
+        if (arena.base) { arena.cap = bytes; tl_arena = &arena; on = true; }
+    }
+    ~StageArena() { if (on) tl_arena = prev; }
+    StageArena(const StageArena &) = delete;
+    StageArena &operator=(const StageArena &) = delete;
 };
 
 // Event pair that accumulates into ctx->timing[name].

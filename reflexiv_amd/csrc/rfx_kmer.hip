@@ -2663,7 +2663,9 @@ static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv, 
     const int nb = 1 << lv.bits;
     const int W = rsrc.k - SK_M + 1;
     const int64_t ntile = ceil_div(rsrc.n_threads, SKT);
-    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(OS_MAXG, (int64_t)ctx->num_cu * 2), ntile));
+    // two workgroups per CU; fewer on small inputs (every workgroup holds three extents per bucket: at least 32 tiles each)
+    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(OS_MAXG, (int64_t)ctx->num_cu * 2),
+                                                                std::max<int64_t>(std::min<int64_t>(ntile, 64), ntile / 32)));
     int sample = getenv("RFX_SK_SAMPLE") ? std::max(1, atoi(getenv("RFX_SK_SAMPLE"))) : 32;
     if (ntile < 64 * (int64_t)sample) sample = (int)std::max<int64_t>(1, ntile / 64);      // small inputs: at least 64 tiles
     const int64_t n_sampled = ceil_div(ntile, sample);
@@ -2853,6 +2855,7 @@ static int count_reads_superkmer(rfx_ctx *ctx, const ReadStore *reads, int min_c
     plan_levels(n, true, bits, 16384.0);           // measured best for the record leaf with double hashing + pre-split (tools/bits_sweep.sh)
     Level lv{};
     lv.bits = bits[0];
+    StageArena stage_arena(ctx, ((size_t)64 << 20) + (size_t)n / 8);
     DevBuf segA, segB;
     RFX_HIP(segA.alloc(((size_t)(1 << lv.bits) + 1) * 8, ctx->stream));
     Rec *recs = nullptr;
@@ -2880,6 +2883,7 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
     if (reads && superkmer_enabled(reads->k))
         return count_reads_superkmer(ctx, reads, min_cov, max_cov, twin, d_out_keys, d_out_counts, cap, out_n,
                                      out_distinct, pair_out);
+    StageArena stage_arena(ctx, (size_t)256 << 20);       // temporaries of this call (see StageArena)
     ctx->timing.clear();
     ReadSrc rsrc{};
     int k_bits = 64;
@@ -2998,6 +3002,7 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
 
 int bucket_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, uint64_t *d_out, int64_t cap,
                     int64_t *d_owner_off, int64_t *h_owner_off) {
+    StageArena stage_arena(ctx, (size_t)256 << 20);       // temporaries of this call (see StageArena)
     if (n_owners < 1 || n_owners > 64) return RFX_E_ARG;
     ReadSrc rsrc = make_read_src(reads);
     const int64_t n = instances_of(reads, rsrc);
@@ -3033,6 +3038,7 @@ int bucket_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, uint64_t
 // (owner = mulhi(hash(minimiser), n_owners)) -- the exchange then ships ~2.6 B per instance
 int bucket_records_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, void *d_out, int64_t cap_records,
                             int64_t *d_owner_off, int64_t *h_owner_off, int64_t *out_n_records) {
+    StageArena stage_arena(ctx, (size_t)256 << 20);       // temporaries of this call (see StageArena)
     if (n_owners < 1 || n_owners > 64 || !superkmer_enabled(reads->k)) return RFX_E_ARG;
     ReadSrc rsrc = make_read_src(reads);
     if (out_n_records) *out_n_records = 0;
@@ -3061,6 +3067,7 @@ int bucket_records_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, 
 int count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_t n_instances_hint, int k,
                   int min_cov, int max_cov, int twin, uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap,
                   int64_t *out_n, int64_t *out_distinct) {
+    StageArena stage_arena(ctx, (size_t)256 << 20);       // temporaries of this call (see StageArena)
     if (!superkmer_enabled(k)) return RFX_E_ARG;
     ctx->timing.clear();
     if (out_n) *out_n = 0;
@@ -3085,6 +3092,7 @@ int count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_
 // and the owner sums what arrives.  At high coverage this ships ~1.4 B per instance instead of ~2.6.
 int bucket_pairs_by_owner(rfx_ctx *ctx, const void *d_pairs, int64_t n, int n_owners, void *d_out,
                           int64_t *d_owner_off, int64_t *h_owner_off) {
+    StageArena stage_arena(ctx, (size_t)256 << 20);       // temporaries of this call (see StageArena)
     if (n_owners < 1 || n_owners > 64 || n < 0) return RFX_E_ARG;
     if (n == 0) {
         RFX_HIP(hipMemsetAsync(d_owner_off, 0, (size_t)(n_owners + 1) * 8, ctx->stream));
@@ -3149,6 +3157,7 @@ int bucket_pairs_by_owner(rfx_ctx *ctx, const void *d_pairs, int64_t n, int n_ow
 // the owner's half: sum the partial counts of every k-mer that arrived, filter, ascending order
 int merge_pairs(rfx_ctx *ctx, const void *d_pairs, int64_t n, int k, int min_cov, int max_cov, int twin,
                 uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct) {
+    StageArena stage_arena(ctx, (size_t)256 << 20);       // temporaries of this call (see StageArena)
     ctx->timing.clear();
     if (out_n) *out_n = 0;
     if (out_distinct) *out_distinct = 0;
@@ -3203,6 +3212,7 @@ static int finish_wide2(rfx_ctx *ctx, const std::conditional_t<RECS, WRec, Rec> 
 // histograms, write-combining scatters, LDS-table leaves.
 int count_wide2(rfx_ctx *ctx, const void *d_elems, int64_t n, int min_cov, int max_cov, uint64_t *d_out_keys,
                 int64_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct) {
+    StageArena stage_arena(ctx, (size_t)256 << 20);       // temporaries of this call (see StageArena)
     if (out_n) *out_n = 0;
     if (out_distinct) *out_distinct = 0;
     if (n <= 0) return RFX_OK;
@@ -3256,6 +3266,7 @@ static int wide_level1(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, i
 // multi-GPU support: the two-word k-mers of packed uniform reads, grouped by owning rank
 int bucket_wide_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,
                          int n_owners, void *d_out, int64_t cap_elems, int64_t *d_owner_off, int64_t *h_owner_off) {
+    StageArena stage_arena(ctx, (size_t)256 << 20);       // temporaries of this call (see StageArena)
     if (n_owners < 1 || n_owners > 64) return RFX_E_ARG;
     const int64_t n = nk * n_reads;
     if (n > cap_elems) return RFX_E_CAP;
@@ -3339,6 +3350,7 @@ static int count_wide2_reads_records(rfx_ctx *ctx, const uint64_t *d_words, int6
 int bucket_wide_records_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,
                                  int n_owners, void *d_out, int64_t cap_records, int64_t *d_owner_off, int64_t *h_owner_off,
                                  int64_t *out_n_records) {
+    StageArena stage_arena(ctx, (size_t)256 << 20);       // temporaries of this call (see StageArena)
     if (n_owners < 1 || n_owners > 64 || k < 33 || k > 63) return RFX_E_ARG;
     if (out_n_records) *out_n_records = 0;
     if (nk <= 0 || n_reads <= 0) {
@@ -3365,6 +3377,7 @@ int bucket_wide_records_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t 
 int count_wide_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_t n_instances_hint, int k, int min_cov,
                        int max_cov, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n,
                        int64_t *out_distinct) {
+    StageArena stage_arena(ctx, (size_t)256 << 20);       // temporaries of this call (see StageArena)
     if (out_n) *out_n = 0;
     if (out_distinct) *out_distinct = 0;
     if (k < 33 || k > 63) return RFX_E_ARG;
@@ -3388,6 +3401,7 @@ int count_wide_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, i
 int count_wide2_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,
                       int min_cov, int max_cov, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n,
                       int64_t *out_distinct) {
+    StageArena stage_arena(ctx, (size_t)256 << 20);       // temporaries of this call (see StageArena)
     if (out_n) *out_n = 0;
     if (out_distinct) *out_distinct = 0;
     const int64_t n = nk * n_reads;

@@ -927,7 +927,8 @@ def test_count_survives_extreme_skew(rfx, torch_mod, k):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,mode", [(31, "sweep"), (25, "sweep"), (31, "overflow"), (31, "skew")])
+@pytest.mark.parametrize("k,mode", [(31, "sweep"), (25, "sweep"), (31, "overflow"), (31, "skew"), (31, "bits10,4"), (31, "bits7,7"),
+                                    (31, "bits5,5")])
 def test_one_sweep_level1_matches_oracle(rfx, torch_mod, k, mode, monkeypatch):
     """Level 1 of the record path in ONE sweep (k_sk_onesweep: regions sized from a sampled histogram, extents off
     per-bucket cursors, holes closed by k_fix_holes) forced at a size the default would send through the two-pass
@@ -938,6 +939,10 @@ def test_one_sweep_level1_matches_oracle(rfx, torch_mod, k, mode, monkeypatch):
     monkeypatch.setenv("RFX_SK_ONESWEEP", "2")
     if mode == "overflow":
         monkeypatch.setenv("RFX_SK_ONESWEEP_CAP", "1")
+    if mode.startswith("bits"):
+        # 1024 buckets (one workgroup per CU), 128 (extents of 128 or 256), 32 (a tile puts more on a bucket than the largest
+        # extent takes: the sweep is not tried)
+        monkeypatch.setenv("RFX_LEVEL_BITS", mode[4:])
     seed, G, n_reads, L = 11 + k, 30_000, 40_000, 150
     if mode == "skew":
         rng = np.random.default_rng(3)

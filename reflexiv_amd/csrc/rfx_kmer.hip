@@ -437,7 +437,6 @@ __global__ __launch_bounds__(PT) void k_vb_scatter(const uint64_t *__restrict__ 
 // issue latency (one workgroup per CU instead of two: 13.1 -> 21.7 ms), and 8 waves with 4 per SIMD measured 13.2 ms
 // against 12.6 (tools/build_variant.sh + tools/ab_many.sh; 10 waves per workgroup: 20 ms)
 constexpr int LT = RFX_LT;              // threads per leaf workgroup
-constexpr int OBUF = 512;               // survivors buffered in LDS between flushes
 // (experiment, off: parking the keys whose first probe failed and walking 64 of them at once, one per lane, instead of
 // on the spot -- halves the SGPR spills, same 12.7 ms: the probe walks are not what the wave waits for)
 #ifndef RFX_LEAF_QUEUE
@@ -1000,8 +999,10 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
                     }
                     __syncthreads();
                 }
-                emit_pass();
+                // (before emit_pass, whose closing barrier stands between this store and the next leaf's read of ps_eff:
+                // after it, a workgroup whose threads saw different thresholds would disagree on S and on its barriers)
                 if (threadIdx.x == 0 && S == 1 && end - begin > (uint64_t)ps_eff * 3 / 4 && ps_eff < (1u << 24)) ps_eff += ps_eff / 64 + 1;
+                emit_pass();
                 if (pair_out && threadIdx.x == 0) {         // (all emission done; next read: after a later barrier)
                     if (blk_pos >= (uint32_t)PBLOCK) { blk_base = blk_next; blk_pos -= PBLOCK; have_next = 0; }
                     need_grab = blk_pos + (uint32_t)LCAP > (uint32_t)PBLOCK && !have_next;
@@ -1069,9 +1070,16 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
 // publish of a neighbouring lane can never sit on an exit path the spinning lane keeps it from
 // reaching -- and a lane that meets a count compares the (now immutable) key words.  Same structure otherwise: persistent workgroups over
 // contiguous leaf chunks, two barriers per leaf, table sweep, split on overflow.
-constexpr int WCAP_BITS = 12;
+#ifndef RFX_WCAP_BITS
+#define RFX_WCAP_BITS 12
+#endif
+#ifndef RFX_WLT
+#define RFX_WLT 1024
+#endif
+constexpr int WCAP_BITS = RFX_WCAP_BITS;
 constexpr int WCAP = 1 << WCAP_BITS;
-constexpr int WLT = 1024;               // threads per workgroup (one workgroup per CU: the table is 80 KB)
+constexpr int WLT = RFX_WLT;            // threads per workgroup (1024 threads and 4096 slots: one workgroup per CU, the table is 80 KB)
+constexpr int WOBUF = WCAP >= 4096 ? 512 : 256;   // survivors buffered in LDS between flushes
 constexpr uint32_t WLOCK = 0xFFFFFFFFu;
 
 // canonical two-word k-mer (counter layout: word0 = bases 0..31, word1 = the last t = k - 32 bases,
@@ -1106,8 +1114,8 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
     __shared__ uint32_t ps_eff;              // records one table takes (starts at `presplit`, shrinks on overflow)
     __shared__ unsigned long long thi[WCAP], tlo[WCAP];
     __shared__ uint32_t tcnt[WCAP];
-    __shared__ unsigned long long obh[OBUF], obl[OBUF];
-    __shared__ uint32_t obc[OBUF];
+    __shared__ unsigned long long obh[WOBUF], obl[WOBUF];
+    __shared__ uint32_t obc[WOBUF];
     __shared__ uint32_t stackS[LSTACK], stacks[LSTACK];
     __shared__ int sp;
     __shared__ uint32_t overflow, ob_n, ob_lim;
@@ -1267,9 +1275,13 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
             const bool ov = overflow != 0;
             if (threadIdx.x == 0) my_passes++;
             if (!ov) {
+                // (the threshold moves BEFORE the sweep, whose closing barrier stands between this store and the next
+                // leaf's read of ps_eff: threads that saw different thresholds would disagree on S and on their barriers)
+                if (RECS && threadIdx.x == 0 && S == 1 && end - begin > (uint64_t)ps_eff * 3 / 4 && ps_eff < (1u << 24)) ps_eff += ps_eff / 64 + 1;
                 // sweep: survivors -> LDS buffer (one add per wave), slots reset
                 for (int base = 0; base < WCAP; base += WLT) {
                     const int slot = base + threadIdx.x;
+                    if (slot >= WCAP) break;                         // (wave-uniform: WCAP is a multiple of 64)
                     const uint32_t c = tcnt[slot];
                     my_distinct += c != 0;
                     bool keep = c != 0;                              // counter64 filters :197-205
@@ -1283,7 +1295,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                         uint32_t b0 = 0;
                         if (lane_ == leader) b0 = atomicAdd(&ob_n, cntw);
                         b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, leader);
-                        if (b0 + cntw <= (uint32_t)OBUF) {
+                        if (b0 + cntw <= (uint32_t)WOBUF) {
                             if (keep) { obh[b0 + r] = thi[slot]; obl[b0 + r] = tlo[slot]; obc[b0 + r] = c; }
                         } else {
                             uint32_t glo = 0, ghi = 0;
@@ -1304,8 +1316,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                 }
                 __syncthreads();
                 const uint32_t raw = ob_n, lim = ob_lim;
-                if (raw >= (uint32_t)OBUF / 2 || lim != 0xffffffffu) flush();
-                if (RECS && threadIdx.x == 0 && S == 1 && end - begin > (uint64_t)ps_eff * 3 / 4 && ps_eff < (1u << 24)) ps_eff += ps_eff / 64 + 1;
+                if (raw >= (uint32_t)WOBUF / 2 || lim != 0xffffffffu) flush();
                 if (S == 1) break;
             } else {
                 for (int i = threadIdx.x; i < WCAP; i += WLT) tcnt[i] = 0;

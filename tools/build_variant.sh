@@ -7,4 +7,4 @@ name=$1; shift
     -Rpass-analysis=kernel-resource-usage -c rfx_kmer.hip -o /tmp/rfx_kmer_$name.o 2> /tmp/rfx_kmer_$name.res
 objs=$(ls *.o | grep -v rfx_kmer.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib_$name.so.bak $objs /tmp/rfx_kmer_$name.o
-grep -A12 "k_leaf_countILi1ELi31" /tmp/rfx_kmer_$name.res | grep -E "VGPRs:|AGPRs|Spill|ScratchSize|Occupancy|LDS Size" | head -8
+grep -A12 "${KERN:-k_leaf_countILi1ELi31}" /tmp/rfx_kmer_$name.res | grep -E "VGPRs:|AGPRs|Spill|ScratchSize|Occupancy|LDS Size" | head -8

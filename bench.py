@@ -134,7 +134,10 @@ def cpu_baseline(args, n_sample, n_reads_total):
     keys, counts, nd, n = O.count_reads_omp(bases, off, args.k, cover, 10_000_000, 0,
                                             cap=max(1 << 20, 4 * args.genome))
     t_count = time.perf_counter() - t0
-    prm = O.default_params(k=args.k, min_cov=cover, partitions=args.partitions)
+    # one logical partition per host thread (the extend loop is a task per partition: at the GPU run's 8 partitions
+    # it would leave 248 of a GPU box's 256 cores idle)
+    p_cpu = max(args.partitions, min(cores, 1024))
+    prm = O.default_params(k=args.k, min_cov=cover, partitions=p_cpu)
     t1 = time.perf_counter()
     text, nc, trace, _ = O.assemble_from_counts(keys, counts, prm)
     t_asm = time.perf_counter() - t1
@@ -145,7 +148,7 @@ def cpu_baseline(args, n_sample, n_reads_total):
                      "per task), not Spark/JVM",
             "sample": f"first {n_sample} reads of the workload ({n} k-mer instances, {n_sample * args.read_len / args.genome:.0f}x, "
                       f"-cover {cover}): extract+count+filter {t_count:.2f} s, counts -> contigs {t_asm:.2f} s "
-                      f"({len(trace)} extend passes, {args.partitions} logical partitions), on {cores} host cores "
+                      f"({len(trace)} extend passes, {p_cpu} logical partitions), on {cores} host cores "
                       "(oracle/reflexiv_oracle.c, orc_count_reads_omp + orc_assemble_from_counts)",
             "count_stage_s": t_count, "counts_to_contigs_s": t_asm, "reads_to_contigs_s": t_count + t_asm,
             "kmers_kept": int(len(keys)), "distinct_kmers": int(nd), "n_contigs": nc, "longest": lens[:3]}

@@ -2167,10 +2167,12 @@ __global__ __launch_bounds__(WCT) void k_rec_scatter_wc(const typename LevelElem
     };
     for (uint64_t base = q.begin; base < q.end; base += (uint64_t)WCT * WC_PER) {
         Rec r[WC_PER];
+        // (unconditional loads -- a lane past the end re-reads the last element: with the assignment under a condition
+        // the 32-byte records of MODE 3 stayed in scratch memory, 128 bytes per lane)
 #pragma unroll
         for (int i = 0; i < WC_PER; i++) {
             const uint64_t idx = base + (uint64_t)i * WCT + threadIdx.x;
-            if (idx < q.end) r[i] = recs[idx];
+            r[i] = recs[idx < q.end ? idx : q.end - 1];
         }
 #pragma unroll
         for (int i = 0; i < WC_PER; i++) {

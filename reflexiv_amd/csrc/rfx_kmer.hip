@@ -523,7 +523,7 @@ template <> struct LeafElem<2> {
 template <> struct LeafElem<1> {
     using T = Rec;
 #ifndef RFX_RPF
-#define RFX_RPF 2
+#define RFX_RPF 1
 #endif
     static constexpr int PER_LANE = RFX_RPF; // 64-record steps a wave holds in registers per leaf
     __device__ static __forceinline__ T none() { return Rec{0, 0}; }

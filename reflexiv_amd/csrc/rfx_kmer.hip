@@ -1827,12 +1827,15 @@ __global__ __launch_bounds__(1024) void k_plan_regions(const unsigned long long 
     }
 }
 
-template <int W>
-__global__ __launch_bounds__(SKT, 8) void k_sk_onesweep(ReadSrc s, Level lv, OneSweep os, Rec *__restrict__ out) {
+// WIDE: the 32-byte records of the k = 33..63 path (as in k_sk_scatter)
+template <int W, bool WIDE = false>
+__global__ __launch_bounds__(SKT, WIDE ? 4 : 8) void k_sk_onesweep(ReadSrc s, Level lv, OneSweep os,
+                                                               std::conditional_t<WIDE, WRec, Rec> *__restrict__ out) {
+    using RT = std::conditional_t<WIDE, WRec, Rec>;
     extern __shared__ __attribute__((aligned(32))) unsigned char sk_smem[];
     const int nb = 1 << lv.bits;
-#define buf ((Rec *)sk_smem)
-#define tail ((uint32_t *)(sk_smem + (size_t)nb * SKB * sizeof(Rec)))       /* records given a (workgroup-local) position */
+#define buf ((RT *)sk_smem)
+#define tail ((uint32_t *)(sk_smem + (size_t)nb * SKB * sizeof(RT)))        /* records given a (workgroup-local) position */
 #define head (tail + nb)                                                    /* ... of them stored */
 #define cstart (tail + 2 * nb)                                              /* local position the current extent starts at */
 #define cbase (tail + 3 * nb)                                               /* the current extent (its number: record / OSE) */
@@ -1914,10 +1917,23 @@ __global__ __launch_bounds__(SKT, 8) void k_sk_onesweep(ReadSrc s, Level lv, One
                 const uint64_t hh = mmer_hash64(canon);
                 const uint32_t hdr = (uint32_t)((hh << OWNER_BITS) >> 32);
                 const unsigned d = rec_digit(hdr, 0, lv.bits);
-                Rec r;
-                const int sft = 2 * i0;
-                r.w0 = sft ? (hi << sft) | (lo >> (64 - sft)) : hi;
-                r.w1 = ((lo << sft) & 0xFFFFFFF000000000ULL) | ((uint64_t)(n - 1) << 32) | (uint64_t)hdr;
+                RT r;
+                if constexpr (WIDE) {
+                    // 96 bases from the first base of the run's first k-mer (see k_sk_scatter)
+                    const uint64_t *gw = s.words + q.r * s.wpr;
+                    const int p = s.fc - s.wfl + q.sgm * PK + i0;
+                    const int wi = p >> 5, sft = 2 * (p & 31), last = s.wpr - 1;
+                    const uint64_t a0 = gw[wi < last ? wi : last], a1 = gw[wi + 1 < last ? wi + 1 : last];
+                    const uint64_t a2 = gw[wi + 2 < last ? wi + 2 : last], a3 = gw[wi + 3 < last ? wi + 3 : last];
+                    r.b0 = sft ? (a0 << sft) | (a1 >> (64 - sft)) : a0;
+                    r.b1 = sft ? (a1 << sft) | (a2 >> (64 - sft)) : a1;
+                    r.b2 = sft ? (a2 << sft) | (a3 >> (64 - sft)) : a2;
+                    r.hd = ((uint64_t)(n - 1) << 32) | (uint64_t)hdr;
+                } else {
+                    const int sft = 2 * i0;
+                    r.w0 = sft ? (hi << sft) | (lo >> (64 - sft)) : hi;
+                    r.w1 = ((lo << sft) & 0xFFFFFFF000000000ULL) | ((uint64_t)(n - 1) << 32) | (uint64_t)hdr;
+                }
                 const uint32_t pos = atomicAdd(&tail[d], 1u);
                 if (pos - head[d] < (uint32_t)SKB) buf[(size_t)d * SKB + (pos & (SKB - 1))] = r;
                 else {
@@ -1957,7 +1973,8 @@ __global__ __launch_bounds__(SKT, 8) void k_sk_onesweep(ReadSrc s, Level lv, One
 // the bucket holds size = alloc - H records and the last H positions [size, alloc) -- the tail zone -- hold as many
 // records as there are hole positions before `size`.  Tail record i goes to hole position i.
 constexpr int FH_T = 1024;
-__global__ __launch_bounds__(FH_T) void k_fix_holes(OneSweep os, int G, Rec *__restrict__ out, uint64_t *__restrict__ seg_begin,
+template <class RT>
+__global__ __launch_bounds__(FH_T) void k_fix_holes(OneSweep os, int G, RT *__restrict__ out, uint64_t *__restrict__ seg_begin,
                                                    uint64_t *__restrict__ seg_end, unsigned long long *__restrict__ totals) {
     constexpr int NHMAX = 2048;                                // holes of a bucket (>= OS_HOLES * OS_MAXG, a multiple of FH_T)
     static_assert(NHMAX >= OS_HOLES * OS_MAXG && NHMAX % FH_T == 0, "holes per bucket");
@@ -2686,14 +2703,17 @@ static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv
 
 // level 1 of the record path in one sweep (k_sk_onesweep): -> records in workspace slot `ws_slot`, bucket b in
 // [d_seg_begin[b], d_seg_end[b]).  *done = false: a region overflowed, nothing is valid, take the two-pass form.
+template <bool WIDE = false>
 static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv, int ws_slot, uint64_t *d_seg_begin,
-                            uint64_t *d_seg_end, Rec **out_recs, int64_t *n_recs, bool *done, const char *hn, const char *pn) {
+                            uint64_t *d_seg_end, std::conditional_t<WIDE, WRec, Rec> **out_recs, int64_t *n_recs, bool *done,
+                            const char *hn, const char *pn) {
+    using Rec = std::conditional_t<WIDE, WRec, ::Rec>;
     *done = false;
     const int nb = 1 << lv.bits;
     const int W = rsrc.k - SK_M + 1;
     const int64_t ntile = ceil_div(rsrc.n_threads, SKT);
     // two workgroups per CU; fewer on small inputs (every workgroup holds three extents per bucket: at least 32 tiles each)
-    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(OS_MAXG, (int64_t)ctx->num_cu * 2),
+    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(OS_MAXG, (int64_t)ctx->num_cu * (WIDE ? 1 : 2)),
                                                                 std::max<int64_t>(std::min<int64_t>(ntile, 64), ntile / 32)));
     int sample = getenv("RFX_SK_SAMPLE") ? std::max(1, atoi(getenv("RFX_SK_SAMPLE"))) : 32;
     if (ntile < 64 * (int64_t)sample) sample = (int)std::max<int64_t>(1, ntile / 64);      // small inputs: at least 64 tiles
@@ -2740,16 +2760,26 @@ static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv, 
     const size_t lds = (size_t)nb * (SKB * sizeof(Rec) + 24);
     {
         ScopedTimer t(ctx, pn);
-        switch (W) {
+        if constexpr (WIDE) {                  // the central window is 30 or 31 bases: W = 18 or 19
+            if (W == 18) {
+                RFX_HIP(hipFuncSetAttribute((const void *)k_sk_onesweep<18, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_sk_onesweep<18, true>), dim3((unsigned)G), dim3(SKT), lds, ctx->stream, rsrc, lv, os, dst);
+            } else {
+                RFX_HIP(hipFuncSetAttribute((const void *)k_sk_onesweep<19, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_sk_onesweep<19, true>), dim3((unsigned)G), dim3(SKT), lds, ctx->stream, rsrc, lv, os, dst);
+            }
+        } else {
+            switch (W) {
 #define X(w) case w: RFX_HIP(hipFuncSetAttribute((const void *)k_sk_onesweep<w>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                      hipLaunchKernelGGL((k_sk_onesweep<w>), dim3((unsigned)G), dim3(SKT), lds, ctx->stream, rsrc, lv, os, dst); break;
-            RFX_SK_W_CASES(X)
+                RFX_SK_W_CASES(X)
 #undef X
-            default: RFX_HIP(hipFuncSetAttribute((const void *)k_sk_onesweep<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                     hipLaunchKernelGGL((k_sk_onesweep<19>), dim3((unsigned)G), dim3(SKT), lds, ctx->stream, rsrc, lv, os, dst); break;
+                default: RFX_HIP(hipFuncSetAttribute((const void *)k_sk_onesweep<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                         hipLaunchKernelGGL((k_sk_onesweep<19>), dim3((unsigned)G), dim3(SKT), lds, ctx->stream, rsrc, lv, os, dst); break;
+            }
         }
         RFX_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_fix_holes, dim3((unsigned)nb), dim3(FH_T), 0, ctx->stream, os, G, dst, d_seg_begin, d_seg_end,
+        hipLaunchKernelGGL(k_fix_holes<Rec>, dim3((unsigned)nb), dim3(FH_T), 0, ctx->stream, os, G, dst, d_seg_begin, d_seg_end,
                            totals.as<unsigned long long>());
         RFX_HIP(hipGetLastError());
     }
@@ -3365,11 +3395,20 @@ static int count_wide2_reads_records(rfx_ctx *ctx, const uint64_t *d_words, int6
     RFX_HIP(segA.alloc(((size_t)(1 << lv.bits) + 1) * 8, ctx->stream));
     WRec *recs = nullptr;
     int64_t R = 0;
-    RFX_TRY(records_from_reads<true>(ctx, rsrc, lv, true, 0, nullptr, 0, segA.as<uint64_t>(), &recs, &R, "hist1", "part1"));
+    // level 1 in one sweep, as on the k <= 31 path (count_reads_superkmer)
+    const int os_mode = getenv("RFX_SK_ONESWEEP") ? atoi(getenv("RFX_SK_ONESWEEP")) : 1;
+    bool swept = false;
+    DevBuf segE;
+    if (os_mode && bits.size() >= 2 && (os_mode == 2 || rsrc.n_threads >= ((int64_t)1 << 22))) {
+        RFX_HIP(segE.alloc((size_t)(1 << lv.bits) * 8, ctx->stream));
+        RFX_TRY(records_onesweep<true>(ctx, rsrc, lv, 0, segA.as<uint64_t>(), segE.as<uint64_t>(), &recs, &R, &swept, "hist1", "part1"));
+    }
+    if (!swept) RFX_TRY(records_from_reads<true>(ctx, rsrc, lv, true, 0, nullptr, 0, segA.as<uint64_t>(), &recs, &R, "hist1", "part1"));
     DevBuf *seg_cur = &segA, *seg_next = &segB;
     int64_t nseg = (int64_t)1 << lv.bits;
     const WRec *cur = nullptr;
-    RFX_TRY(partition_record_levels<3>(ctx, recs, R, 0, bits, 1, lv.bits, &seg_cur, &seg_next, &nseg, &cur));
+    RFX_TRY(partition_record_levels<3>(ctx, recs, R, 0, bits, 1, lv.bits, &seg_cur, &seg_next, &nseg, &cur,
+                                       swept ? (const uint64_t *)segE.as<uint64_t>() : nullptr));
     return finish_wide2<true>(ctx, cur, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, min_cov, max_cov, d_out_keys,
                               d_out_counts, cap, out_n, out_distinct, k);
 }

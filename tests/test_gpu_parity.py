@@ -1329,8 +1329,10 @@ def test_wide_record_path_equals_oracle(rfx, torch_mod, k, monkeypatch):
     dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
     N = rfx.kmers_per_read_w(L, k) * n_reads
     res = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("RFX_WIDE_RECORDS", flag)
+    for flag in ("0", "1", "sweep"):
+        # "sweep": the record path with its level 1 in one sweep (k_sk_onesweep<W, true>), forced at this size
+        monkeypatch.setenv("RFX_WIDE_RECORDS", "0" if flag == "0" else "1")
+        monkeypatch.setenv("RFX_SK_ONESWEEP", "2" if flag == "sweep" else "0")
         dk = torch.empty(2 * N, dtype=torch.int64, device="cuda"); dc = torch.empty(N, dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
         m, d, inst = rfx.count_reads_w_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, 2)

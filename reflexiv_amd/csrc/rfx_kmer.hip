@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
     __shared__ __attribute__((aligned(32))) uint64_t wstage[RECS ? WWS * (WLT / 64) : 4];
     const bool dh = !(presplit & 0x20000000u);
     __shared__ uint32_t ps_eff;              // records one table takes (starts at `presplit`, shrinks on overflow)
-    __shared__ unsigned long long thi[WCAP], tlo[WCAP];
+    __shared__ __attribute__((aligned(16))) ulonglong2 tk[WCAP];     // both key words of a slot in one 16-byte LDS access
     __shared__ uint32_t tcnt[WCAP];
     __shared__ unsigned long long obh[WOBUF], obl[WOBUF];
     __shared__ uint32_t obc[WOBUF];
@@ -1198,25 +1198,26 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                 uint32_t c = 1u;
                 if (v) c = atomicCAS(&tcnt[slot], 0u, WLOCK);
                 if (v && c == 0u) {                                   // claimed: write the key, publish count 1
-                    thi[slot] = w0; tlo[slot] = w1;
+                    tk[slot] = make_ulonglong2(w0, w1);
                     __threadfence_block();
                     atomicExch(&tcnt[slot], 1u);
                 }
                 const bool h = v && c != 0u && c != WLOCK;
-                const uint64_t t0 = h ? thi[slot] : 0, t1 = h ? tlo[slot] : 0;
-                const bool hit = h && t0 == w0 && t1 == w1;
+                const ulonglong2 t01 = h ? tk[slot] : make_ulonglong2(0, 0);
+                const bool hit = h && t01.x == w0 && t01.y == w1;
                 if (hit) atomicAdd(&tcnt[slot], 1u);
                 int probe = 0;
                 bool done = !v || c == 0u || hit;
                 while (__ballot(!done)) {
                     if (!done) {
                         if (c == 0u) {
-                            thi[slot] = w0; tlo[slot] = w1;
+                            tk[slot] = make_ulonglong2(w0, w1);
                             __threadfence_block();
                             atomicExch(&tcnt[slot], 1u);
                             done = true;
                         } else if (c != WLOCK) {
-                            if (thi[slot] == w0 && tlo[slot] == w1) { atomicAdd(&tcnt[slot], 1u); done = true; }
+                            const ulonglong2 t = tk[slot];
+                            if (t.x == w0 && t.y == w1) { atomicAdd(&tcnt[slot], 1u); done = true; }
                             else {
                                 slot = wide_next(slot, step);
                                 if (++probe >= LPROBE) { overflow = 1; done = true; }
@@ -1312,7 +1313,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                         if (lane_ == leader) b0 = atomicAdd(&ob_n, cntw);
                         b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, leader);
                         if (b0 + cntw <= (uint32_t)WOBUF) {
-                            if (keep) { obh[b0 + r] = thi[slot]; obl[b0 + r] = tlo[slot]; obc[b0 + r] = c; }
+                            if (keep) { const ulonglong2 t = tk[slot]; obh[b0 + r] = t.x; obl[b0 + r] = t.y; obc[b0 + r] = c; }
                         } else {
                             uint32_t glo = 0, ghi = 0;
                             if (lane_ == leader) {
@@ -1324,7 +1325,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                             ghi = (uint32_t)__builtin_amdgcn_readlane((int)ghi, leader);
                             const unsigned long long pos = (((unsigned long long)ghi << 32) | glo) + r;
                             if (keep && pos < cap) {
-                                out_keys[2 * pos] = thi[slot]; out_keys[2 * pos + 1] = tlo[slot]; out_counts[pos] = (int64_t)c;
+                                const ulonglong2 t = tk[slot]; out_keys[2 * pos] = t.x; out_keys[2 * pos + 1] = t.y; out_counts[pos] = (int64_t)c;
                             }
                         }
                     }

@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
 #define RFX_WLT 768
 #endif
 #ifndef RFX_WCAP_X3
-#define RFX_WCAP_X3 1
+#define RFX_WCAP_X3 0
 #endif
 constexpr int WCAP_BITS = RFX_WCAP_BITS;
 constexpr int WCAP = RFX_WCAP_X3 ? 3 << (WCAP_BITS - 1) : 1 << WCAP_BITS;     // 2^bits slots, or three halves of that
@@ -1092,8 +1092,9 @@ __device__ __forceinline__ uint32_t wide_next(uint32_t slot, uint32_t step) {
     const uint32_t x = slot + step;
     return x >= (uint32_t)WCAP ? x - WCAP : x;
 }
-// 768 threads and 6144 slots (120 KB of table, one workgroup per CU): the site-laden leaves of the record path split
-// less often than with 1024 threads and 4096 slots -- 39.5 ms against 44.2 at k = 63 (two workgroups of 2048 slots: 55 ms)
+// 768 threads, 4096 slots and a queue of probe attempts per wave (RFX_WIDE_QUEUE): 34.0 ms at k = 63.  Measured on the
+// way: 1024 threads and 4096 slots 44.2 ms, 768 threads and 6144 slots (RFX_WCAP_X3: the site-laden leaves split less
+// often) 39.5 ms, two workgroups of 2048 slots per CU 55 ms, 512 threads with the queue 41.5 ms
 constexpr int WLT = RFX_WLT;            // threads per workgroup
 constexpr int WOBUF = WCAP == 4096 ? 512 : 256;   // survivors buffered in LDS between flushes
 constexpr uint32_t WLOCK = 0xFFFFFFFFu;
@@ -1115,7 +1116,12 @@ __device__ __forceinline__ void wrec_kmer(const WRec &r, uint32_t j, int t, uint
     *k1 = fwd ? f1 : r1;
 }
 
-constexpr int WWS = 64 * 4 + 32;        // u64 words of a wave's expansion area: 64 records + head bits + prefix counts
+#ifndef RFX_WIDE_QUEUE
+#define RFX_WIDE_QUEUE 1
+#endif
+constexpr int WQCAP = RFX_WIDE_QUEUE ? 128 : 0;   // probe attempts a wave has pending (record leaves)
+constexpr int WWS0 = 64 * 4 + 32;       // u64 words of a wave's expansion area: 64 records + head bits + prefix counts
+constexpr int WWS = WWS0 + WQCAP * 2 + WQCAP / 2;   // ... + the queue: 16-byte keys, then 4-byte (slot | probes << 16)
 
 // RECS: the leaf's elements are super-k-mer records (WRec) expanded here, k-mer by k-mer, balanced over the
 // lanes as in k_leaf_count<1>; else two-word k-mers (Rec = {word0, word1}).
@@ -1227,6 +1233,60 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                     }
                 }
             };
+            // Record leaves, RFX_WIDE_QUEUE: probing as a queue of ATTEMPTS.  An attempt looks at one slot: empty -> claim,
+            // write the key, publish; the key itself -> count; another key -> the next slot of the sequence; a slot
+            // being written -> the same slot again.  An attempt that did not finish the key goes (back) to the wave's
+            // queue, and whenever 64 wait they are made together, one per lane.  No lane ever waits for another, so there is
+            // no loop the wave must leave together, and the wave pays the AVERAGE number of probes per key instead of
+            // the longest sequence among 64 in every round (site-laden leaves run their tables at 60-80 %).
+            uint32_t qn = 0;
+            ulonglong2 *wqk = (ulonglong2 *)(wstage + (size_t)(threadIdx.x >> 6) * WWS + WWS0);
+            uint32_t *wqs = (uint32_t *)(wqk + WQCAP);
+            auto attempt = [&](const uint64_t w0, const uint64_t w1, uint32_t slot, uint32_t probe, bool v) __attribute__((always_inline)) {
+                uint32_t c = 1u;
+                if (v) c = atomicCAS(&tcnt[slot], 0u, WLOCK);
+                bool done = !v;
+                if (v) {
+                    if (c == 0u) {
+                        tk[slot] = make_ulonglong2(w0, w1);
+                        __threadfence_block();
+                        atomicExch(&tcnt[slot], 1u);
+                        done = true;
+                    } else if (c != WLOCK) {
+                        const ulonglong2 t = tk[slot];
+                        if (t.x == w0 && t.y == w1) { atomicAdd(&tcnt[slot], 1u); done = true; }
+                        else {
+                            const uint32_t g = ((uint32_t)w0 ^ __builtin_rotateleft32((uint32_t)(w0 >> 32), 13) ^
+                                                ((uint32_t)w1 * 0x85EBCA6Bu) ^ (uint32_t)(w1 >> 32)) * 0x9E3779B1u;
+                            slot = wide_next(slot, dh ? wide_step(g) : 1u);
+                            if (++probe >= (uint32_t)LPROBE) { overflow = 1; done = true; }
+                        }
+                    }
+                }
+                const uint64_t m = __ballot(!done);
+                if (m) {
+                    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (!done) { wqk[qn + r] = make_ulonglong2(w0, w1); wqs[qn + r] = slot | (probe << 16); }
+                    qn += (uint32_t)__popcll(m);
+                }
+                __builtin_amdgcn_wave_barrier();
+            };
+            auto pending = [&](uint32_t n) __attribute__((always_inline)) {      // the top n <= 64 entries of the queue
+                qn -= n;
+                const bool v = (uint32_t)lane_ < n;
+                const ulonglong2 key = v ? wqk[qn + lane_] : make_ulonglong2(0, 0);
+                const uint32_t st = v ? wqs[qn + lane_] : 0u;
+                __builtin_amdgcn_wave_barrier();
+                attempt(key.x, key.y, st & 0xffffu, st >> 16, v);
+            };
+            auto insertq = [&](const uint64_t w0, const uint64_t w1, bool v) __attribute__((always_inline)) {
+                const uint32_t g = ((uint32_t)w0 ^ __builtin_rotateleft32((uint32_t)(w0 >> 32), 13) ^
+                                    ((uint32_t)w1 * 0x85EBCA6Bu) ^ (uint32_t)(w1 >> 32)) * 0x9E3779B1u;
+                if (S > 1) v = v && (((g >> 4) & 0xffffu) & (S - 1)) == s;
+                attempt(w0, w1, wide_slot(g), 0u, v);
+#pragma nounroll
+                while (qn >= 64u) pending(64u);
+            };
             if constexpr (RECS) {
                 // every wave takes an equal contiguous share of the leaf, 64 records at a time: the records go
                 // to the wave's LDS area, a bit per output position marks where each record's windows start,
@@ -1277,9 +1337,13 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                             if (va && (a0 ^ a1) == 0x123456789ULL) overflow = 1;
                             continue;
                         }
-                        insert1(a0, a1, va);
+                        if constexpr (WQCAP > 0) insertq(a0, a1, va); else insert1(a0, a1, va);
                     }
                     __builtin_amdgcn_wave_barrier();
+                }
+                if constexpr (WQCAP > 0) {
+#pragma nounroll
+                    while (qn > 0u && !__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) pending(qn < 64u ? qn : 64u);
                 }
             } else {
                 for (uint64_t i = begin + threadIdx.x; i < end; i += WLT) {

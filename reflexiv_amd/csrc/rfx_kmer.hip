@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
 #define RFX_WCAP_BITS 12
 #endif
 #ifndef RFX_WLT
-#define RFX_WLT 768
+#define RFX_WLT 1024
 #endif
 #ifndef RFX_WCAP_X3
 #define RFX_WCAP_X3 0
@@ -1092,11 +1092,15 @@ __device__ __forceinline__ uint32_t wide_next(uint32_t slot, uint32_t step) {
     const uint32_t x = slot + step;
     return x >= (uint32_t)WCAP ? x - WCAP : x;
 }
-// 768 threads, 4096 slots and a queue of probe attempts per wave (RFX_WIDE_QUEUE): 34.0 ms at k = 63.  Measured on the
+// 1024 threads, 4096 slots, a queue of probe attempts per wave (RFX_WIDE_QUEUE) and a 64-entry survivor buffer -- all the
+// LDS there is: 31.1 ms at k = 63 (768 threads: 34.0, 896: 33.1).  Measured on the
 // way: 1024 threads and 4096 slots 44.2 ms, 768 threads and 6144 slots (RFX_WCAP_X3: the site-laden leaves split less
 // often) 39.5 ms, two workgroups of 2048 slots per CU 55 ms, 512 threads with the queue 41.5 ms
 constexpr int WLT = RFX_WLT;            // threads per workgroup
-constexpr int WOBUF = WCAP == 4096 ? 512 : 256;   // survivors buffered in LDS between flushes
+#ifndef RFX_WOBUF
+#define RFX_WOBUF 64
+#endif
+constexpr int WOBUF = RFX_WOBUF;        // survivors buffered in LDS between flushes
 constexpr uint32_t WLOCK = 0xFFFFFFFFu;
 
 // canonical two-word k-mer (counter layout: word0 = bases 0..31, word1 = the last t = k - 32 bases,

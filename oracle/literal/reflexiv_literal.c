@@ -1,6 +1,7 @@
 /*
  * reflexiv_literal.c -- the reference's OWN bit arithmetic for the flips and merges of the single-word
- * and first-array extend stages (k <= 31), written out statement by statement from
+ * and first-array extend stages (k <= 31) and for the k > 31 counter's extraction (further down), written out
+ * statement by statement from
  *   P/ReflexivDSMain.java:3153-3226 (DSExtendReflexivKmer.singleKmerRandomizer)
  *   P/ReflexivDSMain.java:3241-3325 (DSExtendReflexivKmer.reflexivExtend)
  *   P/ReflexivDSMain.java:2702-2810 (DSExtendReflexivKmerToArrayFirstTime.singleKmerRandomizer)
@@ -174,4 +175,124 @@ int lit_merge_first(const lit_rec *f, const lit_rec *r, int bubbleDistance, int 
     }
     merged_ends(f, r, bubbleDistance, out);
     return bad;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * k > 31 counter: ReflexivDataFrameCounter64.ReverseComplementKmerBinaryExtractionFromDataset64, the rolling
+ * multi-word forward / reverse-complement arrays and the choice between them, statement by statement from
+ *   P/ReflexivDataFrameCounter64.java:391 (maxKmerBits), :403-647 (the read loop), :652-687 (compareLongArrayBlocks),
+ *   :704-716 (nucleotideValue), U/DefaultParam.java:80-81 (kmerSizeResidue = k % 32, kmerBinarySlots = k / 32 + 1).
+ * One read (ASCII, `len` characters) -> the canonical k-mers of its windows, `slots` words each, appended to out
+ * (at most cap k-mers are written); returns the number of k-mers the read emits.  The oracle's sequence-level
+ * orc_extract_canon_w is fuzzed against this in tests/test_oracle_literal.py.
+ */
+static jlong lit_nucleotide_value(int a) {                   /* :704-716 */
+    if (a == 'A') return 0;
+    if (a == 'C') return 1;
+    if (a == 'G') return 2;
+    return 3;
+}
+
+static int lit_compare_blocks(const jlong *forward, const jlong *reverse, int slots, int residue) {   /* :652-687 */
+    for (int i = 0; i < slots; i++) {
+        if (i < slots - 1) {
+            for (int j = 0; j < 32; j++) {
+                jlong s1 = jushr(forward[i], 2 * (31 - j)) & 3;
+                jlong s2 = jushr(reverse[i], 2 * (31 - j)) & 3;
+                if (s1 < s2) return 1;
+                else if (s1 > s2) return 0;
+            }
+        } else {
+            for (int j = 0; j < residue; j++) {
+                jlong s1 = jushr(forward[i], 2 * (residue - 1 - j)) & 3;
+                jlong s2 = jushr(reverse[i], 2 * (residue - 1 - j)) & 3;
+                if (s1 < s2) return 1;
+                else if (s1 > s2) return 0;
+            }
+        }
+    }
+    return 1;                                                 /* "should not happen": a palindrome keeps the forward strand */
+}
+
+#define LIT_MAX_SLOTS 8
+int64_t lit_counter64_extract(const uint8_t *read, int len, int k, int frontClip, int endClip, uint64_t *out, int64_t cap) {
+    const int residue = k % 32, slots = k / 32 + 1;           /* DefaultParam :80-81 */
+    if (slots > LIT_MAX_SLOTS || slots < 2) return -1;
+    const jlong maxKmerBits = ~jshl(~(jlong)0, 2 * residue);   /* :391 */
+    int64_t emitted = 0;
+    if (len - k - endClip + 1 <= 0 || frontClip > len) return 0;           /* :410-412 */
+    jlong nb = 0, nbrc = 0;
+    jlong fs[LIT_MAX_SLOTS] = {0}, rs[LIT_MAX_SLOTS] = {0};
+    for (int i = frontClip; i < len - endClip; i++) {                      /* :419 */
+        const jlong v = lit_nucleotide_value(read[i]);
+        /* forward k-mer in bits  :424-463 */
+        if (i - frontClip <= k - 1) {
+            nb = jshl(nb, 2);
+            nb |= v;
+            if ((i - frontClip + 1) % 32 == 0) {
+                fs[(i - frontClip + 1) / 32 - 1] = nb;
+                nb = 0;
+            }
+            if (i - frontClip == k - 1) {
+                nb &= maxKmerBits;
+                fs[(i - frontClip + 1) / 32] = nb;
+                nb = 0;
+            }
+        } else {
+            jlong t1 = jushr(fs[slots - 1], 2 * (residue - 1));
+            jlong t2;
+            fs[slots - 1] = jshl(fs[slots - 1], 2);
+            fs[slots - 1] |= v;
+            fs[slots - 1] &= maxKmerBits;
+            for (int j = slots - 2; j >= 0; j--) {
+                t2 = jushr(fs[j], 2 * 31);
+                fs[j] = jshl(fs[j], 2);
+                fs[j] |= t1;
+                t1 = t2;
+            }
+        }
+        /* reverse complement  :466-515 */
+        jlong c = v ^ 3;
+        if (i - frontClip <= k - 1) {
+            if (i - frontClip < residue - 1) {
+                c = jshl(c, 2 * (i - frontClip));
+                nbrc |= c;
+            } else if (i - frontClip == residue - 1) {
+                c = jshl(c, 2 * (i - frontClip));
+                nbrc |= c;
+                rs[slots - 1] = nbrc;
+                nbrc = 0;
+            } else if ((i - frontClip - residue + 1) % 32 == 0) {
+                c = jshl(c, 2 * ((i - frontClip - residue) % 32));
+                nbrc |= c;
+                rs[slots - ((i - frontClip - residue + 1) / 32) - 1] = nbrc;
+                nbrc = 0;
+            } else {
+                c = jshl(c, 2 * ((i - frontClip - residue) % 32));
+                nbrc |= c;
+            }
+        } else {
+            jlong t1 = jshl(rs[0], 2 * 31);
+            jlong t2;
+            rs[0] = jushr(rs[0], 2);
+            c = jshl(c, 2 * 31);
+            rs[0] |= c;
+            for (int j = 1; j < slots - 1; j++) {
+                t2 = jshl(rs[j], 2 * 31);
+                rs[j] = jushr(rs[j], 2);
+                rs[j] |= t1;
+                t1 = t2;
+            }
+            rs[slots - 1] = jushr(rs[slots - 1], 2);
+            t1 = jushr(t1, 2 * (31 - residue + 1));
+            rs[slots - 1] |= t1;
+        }
+        /* the first complete k-mer and every one after it  :526, :626-645 */
+        if (i - frontClip >= k - 1) {
+            const jlong *pick = lit_compare_blocks(fs, rs, slots, residue) ? fs : rs;
+            if (emitted < cap) for (int j = 0; j < slots; j++) out[emitted * slots + j] = (uint64_t)pick[j];
+            emitted++;
+        }
+    }
+    return emitted;
 }

@@ -2932,7 +2932,7 @@ static int partition_record_levels(rfx_ctx *ctx, const typename LevelElem<MODE>:
                     hipLaunchKernelGGL((k_rec_scatter_wc<8, MODE>), dim3((unsigned)v_bound), dim3(WCT), lds, ctx->stream, cur, vm, lv,
                                        used, (const uint64_t *)scanned.as<uint64_t>(), dst);
                 }
-            } else if (wc && lv.bits <= 9) {
+            } else if (wc && lv.bits <= 9 && !(getenv("RFX_WC_B") && atoi(getenv("RFX_WC_B")) == 8)) {
                 const size_t lds = (size_t)nb * (16 * sizeof(Rec) + 16);
                 RFX_HIP(hipFuncSetAttribute((const void *)k_rec_scatter_wc<16, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((k_rec_scatter_wc<16, MODE>), dim3((unsigned)v_bound), dim3(WCT), lds, ctx->stream, cur, vm, lv,

@@ -131,3 +131,39 @@ def test_first_array_merges_equal_the_reference_bit_code(lit, k):
         two_word += nw == 2
         same(oracle_pass([(key, 1, eF, a, fr), (key, 2, eR, rl, b)], k, m), got, nw)
     assert two_word > 3000
+
+
+@pytest.mark.parametrize("k", [33, 40, 47, 63, 65, 95, 127])
+@pytest.mark.parametrize("clips", [(0, 0), (3, 5)])
+def test_counter64_extraction_literal_equals_oracle(lit, k, clips):
+    """k > 31 counter: the reference's rolling multi-word forward / reverse-complement arrays and
+    compareLongArrayBlocks, written out statement by statement (lit_counter64_extract, from
+    P/ReflexivDataFrameCounter64.java:391-687), against the oracle's sequence-level orc_extract_canon_w -- random
+    reads with N's and lower case, reads shorter than k, palindromes, both clips."""
+    fc, ec = clips
+    rng = np.random.default_rng(1000 * k + fc)
+    W = k // 32 + 1
+    lit.lit_counter64_extract.restype = C.c_int64
+    reads = []
+    for _ in range(300):
+        L = int(rng.integers(k - 3, 3 * k + 40))
+        alphabet = np.frombuffer(b"ACGTACGTACGTNacgt", np.uint8)
+        reads.append(bytes(alphabet[rng.integers(0, len(alphabet), L)]))
+    # a reverse-complement palindrome of length >= k + clips: forward == reverse complement, the forward strand is kept
+    half = bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, k)])
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads.append(b"A" * fc + half + half.translate(comp)[::-1] + b"C" * ec)
+    bases = np.frombuffer(b"".join(reads), np.uint8)
+    off = np.zeros(len(reads) + 1, np.int64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    want = O.extract_canon_w(bases, off, k, fc, ec)
+    got = []
+    for r in reads:
+        cap = max(1, len(r))
+        buf = np.zeros((cap, W), np.uint64)
+        n = lit.lit_counter64_extract(r, len(r), k, fc, ec, buf.ctypes.data_as(C.c_void_p), C.c_int64(cap))
+        assert 0 <= n <= cap
+        got.append(buf[:n])
+    got = np.concatenate(got) if got else np.zeros((0, W), np.uint64)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)

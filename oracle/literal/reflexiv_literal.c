@@ -296,3 +296,76 @@ int64_t lit_counter64_extract(const uint8_t *read, int len, int k, int frontClip
     }
     return emitted;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Fork filters of the DS twin (min_error_cov off), P/ReflexivDSMain.java:3369-3417 (DSFilterForkSubKmer) and
+ * :3486-3538 (DSFilterForkReflectedSubKmer): one partition of rows (key, marker, ext, left, right) in, the kept rows
+ * out (n_out returned).  Row fields as the reference's getLong(0), getInt(1), getLong(2), getInt(3), getInt(4).
+ */
+typedef struct { jlong key; int32_t marker; jlong ext; int32_t left, right; } lit_row;
+
+int64_t lit_fork_forward(const lit_row *in, int64_t n, int subKmerSize, lit_row *out) {      /* :3375-3416 */
+    int64_t m = 0;
+    for (int64_t q = 0; q < n; q++) {
+        lit_row s = in[q];
+        if (m == 0) {
+            out[m++] = (lit_row){s.key, s.marker, s.ext, s.left, -1};
+        } else {
+            if (s.key == out[m - 1].key) {
+                if (s.left > out[m - 1].left) {
+                    out[m - 1] = (lit_row){s.key, s.marker, s.ext, s.left, subKmerSize};
+                } else if (s.left == out[m - 1].left) {
+                    if (s.ext > out[m - 1].ext) {
+                        out[m - 1] = (lit_row){s.key, s.marker, s.ext, s.left, subKmerSize};
+                    } else {
+                        s = out[m - 1];
+                        out[m - 1] = (lit_row){s.key, s.marker, s.ext, s.left, subKmerSize};
+                    }
+                } else {
+                    s = out[m - 1];
+                    out[m - 1] = (lit_row){s.key, s.marker, s.ext, s.left, subKmerSize};
+                }
+            } else {
+                out[m++] = (lit_row){s.key, s.marker, s.ext, s.left, -1};
+            }
+        }
+    }
+    return m;
+}
+
+int64_t lit_fork_reflected(const lit_row *in, int64_t n, int subKmerSize, lit_row *out) {    /* :3493-3537 */
+    int64_t m = 0;
+    int32_t lastCoverage = 0;
+    for (int64_t q = 0; q < n; q++) {
+        lit_row s = in[q];
+        if (m == 0) {
+            lastCoverage = s.left;
+            out[m++] = (lit_row){s.key, s.marker, s.ext, -1, s.right};
+        } else {
+            if (s.key == out[m - 1].key) {
+                if (s.left > lastCoverage) {
+                    lastCoverage = s.left;
+                    out[m - 1] = (lit_row){s.key, s.marker, s.ext, subKmerSize, s.right};
+                } else if (s.left == lastCoverage) {
+                    int l1 = 64 / 2 - (jnlz(s.ext) / 2 + 1);
+                    int l2 = 64 / 2 - (jnlz(out[m - 1].ext) / 2 + 1);
+                    jlong f1 = jushr(s.ext, 2 * (l1 - 1));
+                    jlong f2 = jushr(out[m - 1].ext, 2 * (l2));          /* (as written: the kept row's sentinel, not its first base) */
+                    if (f1 > f2) {
+                        out[m - 1] = (lit_row){s.key, s.marker, s.ext, subKmerSize, s.right};
+                    } else {
+                        s = out[m - 1];
+                        out[m - 1] = (lit_row){s.key, s.marker, s.ext, subKmerSize, s.right};
+                    }
+                } else {
+                    s = out[m - 1];
+                    out[m - 1] = (lit_row){s.key, s.marker, s.ext, subKmerSize, s.right};
+                }
+            } else {
+                lastCoverage = s.left;
+                out[m++] = (lit_row){s.key, s.marker, s.ext, -1, s.right};
+            }
+        }
+    }
+    return m;
+}

@@ -167,3 +167,40 @@ def test_counter64_extraction_literal_equals_oracle(lit, k, clips):
     got = np.concatenate(got) if got else np.zeros((0, W), np.uint64)
     assert got.shape == want.shape
     assert np.array_equal(got, want)
+
+
+class LitRow(C.Structure):
+    _fields_ = [("key", C.c_int64), ("marker", C.c_int32), ("ext", C.c_int64), ("left", C.c_int32), ("right", C.c_int32)]
+
+
+@pytest.mark.parametrize("reflected", [False, True])
+@pytest.mark.parametrize("k", [31, 21])
+def test_fork_filters_literal_equal_oracle(lit, k, reflected):
+    """DSFilterForkSubKmer / DSFilterForkReflectedSubKmer (P/ReflexivDSMain.java:3369-3417, :3486-3538) written out
+    statement by statement against the oracle's segmented fold, on sorted partitions with runs of 1..5 equal keys,
+    tied coverages and tied / differing first extension bases (the reflected filter's comparison of a first base with
+    the kept row's SENTINEL included)."""
+    rng = np.random.default_rng(7 * k + int(reflected))
+    sub = k - 1
+    fn = lit.lit_fork_reflected if reflected else lit.lit_fork_forward
+    fn.restype = C.c_int64
+    for _ in range(300):
+        rows = []
+        for _g in range(int(rng.integers(1, 12))):
+            key = int(rng.integers(0, 1 << 40))
+            for _r in range(int(rng.integers(1, 6))):
+                L = int(rng.integers(1, 4))
+                ext = sentinel(rng.integers(0, 4, L))
+                rows.append((key, int(rng.integers(1, 3)), ext, int(rng.integers(1, 4)), int(rng.integers(1, 4))))
+        rows.sort(key=lambda r: r[0])                    # (stable: equal keys keep their order, as after sortByKey)
+        n = len(rows)
+        arr = (LitRow * n)(*[LitRow(*r) for r in rows])
+        out = (LitRow * n)()
+        m = fn(arr, C.c_int64(n), sub, out)
+        recs = as_records(rows)
+        f = O.fork_filter_reflected if reflected else O.fork_filter_forward
+        got, _ = f(recs, np.array([0, n], np.int64), k, 0, O.TWIN_DS)
+        assert got.n == m
+        for i in range(m):
+            assert (int(got.key[i]), int(got.marker[i]), int(got.ext[i]), int(got.left[i]), int(got.right[i])) == \
+                   (out[i].key, out[i].marker, out[i].ext, out[i].left, out[i].right), (i, rows)

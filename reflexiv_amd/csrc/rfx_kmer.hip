@@ -2981,6 +2981,9 @@ static int count_reads_superkmer(rfx_ctx *ctx, const ReadStore *reads, int min_c
     if (n <= 0) return RFX_OK;
     std::vector<int> bits;
     plan_levels(n, true, bits, 16384.0);           // measured best for the record leaf with double hashing + pre-split (tools/bits_sweep.sh)
+    // 1024 bins at level 1 leave one workgroup per CU (the rings fill the LDS): 20 Gbp on one GPU measured 138.8 ms
+    // with levels of 10 + 10 bits, 131.7 ms with 9 + 10 and leaves twice as large, 139 ms with three levels
+    if (bits.size() == 2 && bits[0] > 9 && !getenv("RFX_LEVEL_BITS")) bits[0] = 9;
     Level lv{};
     lv.bits = bits[0];
     StageArena stage_arena(ctx, ((size_t)64 << 20) + (size_t)n / 8);

@@ -126,6 +126,47 @@ __global__ void k_key_word(const KeyW<KW> *__restrict__ key, const uint32_t *__r
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = key[perm ? perm[i] : (uint32_t)i].w[w];
 }
+// Two-word keys (k = 33..63) sorted in ONE radix sort: on the key's first 64 bits (word 0's 31 bases and the first base
+// of word 1) -- k_key_prefix2 -- after which k_tie_fix2 orders the runs of equal prefixes by the rest of word 1.  Equal
+// prefixes are mostly equal KEYS (the sort exists to bring them together: runs of 2..4), so the mending is a stable
+// insertion sort of a few permutation entries by the owner of the run's head; a run longer than TIE_MAX (low-complexity
+// keys) raises a flag and the caller takes the two-pass LSD form instead.
+constexpr int TIE_MAX = 32;
+__global__ void k_key_prefix2(const KeyW<2> *__restrict__ key, int64_t n, int res, uint64_t *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (key[i].w[0] << 2) | (key[i].w[1] >> (2 * res - 2));
+}
+__global__ void k_tie_fix2(const uint64_t *__restrict__ prefix, uint32_t *__restrict__ perm, int64_t n,
+                           const KeyW<2> *__restrict__ key, int res, int *__restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t p = prefix[i];
+    if ((i > 0 && prefix[i - 1] == p) || i + 1 >= n || prefix[i + 1] != p) return;      // not the head of a run of >= 2
+    int r = 2;
+    while (i + r < n && r <= TIE_MAX && prefix[i + r] == p) r++;
+    if (r > TIE_MAX) { *flag = 1; return; }
+    const uint64_t rm = res > 1 ? ~((~0ULL) << (2 * res - 2)) : 0ULL;
+    // (nearly every run is already in order -- equal keys: checked on the fly, the arrays below stay untouched)
+    bool sorted = true;
+    uint64_t prev = 0;
+    for (int j = 0; j < r; j++) {
+        const uint64_t x = key[perm[i + j]].w[1] & rm;
+        if (j && x < prev) sorted = false;
+        prev = x;
+    }
+    if (sorted) return;
+    uint32_t idx[TIE_MAX];
+    uint64_t rest[TIE_MAX];
+    for (int j = 0; j < r; j++) { idx[j] = perm[i + j]; rest[j] = key[idx[j]].w[1] & rm; }
+    for (int j = 1; j < r; j++) {                     // stable insertion sort by the rest of word 1
+        const uint64_t x = rest[j];
+        const uint32_t xi = idx[j];
+        int q = j - 1;
+        while (q >= 0 && rest[q] > x) { rest[q + 1] = rest[q]; idx[q + 1] = idx[q]; q--; }
+        rest[q + 1] = x; idx[q + 1] = xi;
+    }
+    for (int j = 0; j < r; j++) perm[i + j] = idx[j];
+}
 template <int KW>
 __global__ void k_gather_key(const KeyW<KW> *__restrict__ key, const uint32_t *__restrict__ perm, int64_t n,
                              KeyW<KW> *__restrict__ out) {
@@ -524,7 +565,31 @@ int sort_records(rfx_ctx *ctx, const DevRecords &in, int P, int key_bits, DevRec
         hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n)), dim3(256), 0, ctx->stream, perm.as<uint32_t>(), n);
         RFX_HIP(hipGetLastError());
         const int res = k > 0 ? (k - 1) - 31 * (kw - 1) : 31;      // k unknown: every word may use its 62 bits
-        for (int w = kw - 1; w >= 0; w--) {
+        bool done = false;
+        static const bool tie_off = getenv("RFX_SORT_TIEFIX") && atoi(getenv("RFX_SORT_TIEFIX")) == 0;
+        if (kw == 2 && !tie_off) {       // (k unknown: res = 31, a prefix that splits less but orders the same)
+            // one sort on the first 64 bits, then the runs of equal prefixes mended (see k_tie_fix2)
+            DevBuf flag;
+            RFX_HIP(flag.alloc(4, ctx->stream));
+            RFX_HIP(hipMemsetAsync(flag.p, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(k_key_prefix2, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (const KeyW<2> *)in.key.as<KeyW<2>>(), n, res,
+                               wk.as<uint64_t>());
+            RFX_HIP(hipGetLastError());
+            const int pbits = 62 + 2 * res < 64 ? 62 + 2 * res : 64;
+            RFX_TRY(sort_pairs(ctx, wk.as<uint64_t>(), perm.as<uint32_t>(), n, pbits, tk.as<uint64_t>(), tv.as<uint32_t>()));
+            hipLaunchKernelGGL(k_tie_fix2, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (const uint64_t *)wk.as<uint64_t>(),
+                               perm.as<uint32_t>(), n, (const KeyW<2> *)in.key.as<KeyW<2>>(), res, flag.as<int>());
+            RFX_HIP(hipGetLastError());
+            int h_flag = 0;
+            RFX_HIP(hipMemcpyAsync(&h_flag, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            RFX_HIP(hipStreamSynchronize(ctx->stream));
+            done = h_flag == 0;
+            if (!done) {                       // a long run of equal prefixes: start over with the two passes below
+                hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n)), dim3(256), 0, ctx->stream, perm.as<uint32_t>(), n);
+                RFX_HIP(hipGetLastError());
+            }
+        }
+        for (int w = kw - 1; w >= 0 && !done; w--) {
             const uint32_t *pp = w == kw - 1 ? nullptr : perm.as<uint32_t>();
             RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_key_word<KW>, dim3(grid_for(n)), dim3(256), 0, ctx->stream,
                                                  (const KeyW<KW> *)in.key.as<KeyW<KW>>(), pp, n, w, wk.as<uint64_t>()));

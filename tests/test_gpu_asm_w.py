@@ -111,6 +111,40 @@ def test_operator_chain_w(rfx, planted, k, P, min_err):
     run_chain_w(rfx, km, counts, k, P, min_err)
 
 
+@pytest.mark.parametrize("k", [63, 40, 33])
+@pytest.mark.parametrize("run", [3, 40])
+def test_sort_two_word_keys_with_equal_prefixes(rfx, k, run):
+    """sortByKey on two-word keys is ONE radix sort on the first 64 bits plus a mending of the runs of equal prefixes
+    (k_tie_fix2).  Groups of `run` keys that share those 64 bits and differ only beyond them (or not at all), in random
+    order: short runs are mended in place, runs of 40 (> TIE_MAX) send the call down the two-pass form -- either way
+    the oracle's stable order."""
+    rng = np.random.default_rng(100 * k + run)
+    sub = k - 1
+    res = sub - 31
+    n_groups = 600
+    w0 = rng.integers(0, 1 << 62, n_groups, dtype=np.uint64)
+    keys = []
+    for g in range(n_groups):
+        top = int(rng.integers(0, 4)) << (2 * res - 2) if res >= 1 else 0
+        for _ in range(run):
+            low = int(rng.integers(0, 1 << (2 * res - 2))) if res > 1 else 0
+            if rng.random() < 0.3 and keys and keys[-1][0] == int(w0[g]):
+                low = keys[-1][1] & ((1 << (2 * res - 2)) - 1) if res > 1 else 0      # a fully equal key: order must be stable
+            keys.append((int(w0[g]), top | low))
+    order = rng.permutation(len(keys))
+    key = np.array([keys[i] for i in order], np.uint64).reshape(-1, 2)
+    n = len(key)
+    marker = rng.integers(1, 3, n).astype(np.int32)
+    ext = np.array([(1 << 2) | int(rng.integers(0, 4)) for _ in range(n)], np.uint64)
+    left = np.arange(n, dtype=np.int32)                    # the input position: shows the stability
+    right = rng.integers(-1, 5, n).astype(np.int32)
+    r = O.Records(key, marker, np.arange(n + 1, dtype=np.int64), ext, left, right)
+    want = O.sort_records(r)
+    got, gps = rfx.sortByKey(r, 3)
+    same_records(got, want)
+    assert np.array_equal(gps, O.partition_starts(want.key, 3))
+
+
 def test_operator_edge_cases_w(rfx):
     k = 63
     empty = O.Records(np.zeros((0, 2), np.uint64), np.zeros(0, np.int32), np.zeros(1, np.int64),

@@ -1815,6 +1815,9 @@ __global__ __launch_bounds__(SKT, WIDE ? 4 : 8) void k_sk_scatter(ReadSrc s, Lev
 // What a workgroup leaves unused of its last two extents are HOLES; k_fix_holes moves the records at the end of every
 // bucket into the holes before it, so the next level reads a gap-free [seg_begin, seg_end) per bucket.  A region that
 // runs out (a sample that missed the skew) raises `overflow` and the caller falls back to the two-pass form.
+#ifndef RFX_DRAIN_UNROLL
+#define RFX_DRAIN_UNROLL 1
+#endif
 constexpr int OSE_MIN = 64, OSE_MAX = 256;   // records per extent: a round must not put more than one extent of one
                                          // workgroup into one bucket (5 records on average at 512 buckets); the sampled
                                          // histogram picks 64, 128 or 256 by the busiest bucket, or no sweep at all
@@ -1938,6 +1941,7 @@ __global__ __launch_bounds__(SKT, WIDE ? 4 : 8) void k_sk_onesweep(ReadSrc s, Le
     }
     __syncthreads();
     auto drain = [&](bool final) __attribute__((always_inline)) {
+#pragma unroll RFX_DRAIN_UNROLL
         for (int d = threadIdx.x / SKB; d < nb; d += SKT / SKB) {
             const int j = threadIdx.x % SKB;
             const uint32_t h = head[d], t = tail[d], cs = cstart[d], cb = cbase[d], nx = nbase[d];
@@ -2236,6 +2240,7 @@ __global__ __launch_bounds__(WCT) void k_rec_scatter_wc(const typename LevelElem
     __syncthreads();
     // B adjacent lanes drain one bin: everything up to the last aligned boundary (all of it at the end)
     auto drain = [&](bool final) __attribute__((always_inline)) {
+#pragma unroll RFX_DRAIN_UNROLL
         for (int d = threadIdx.x / B; d < nb; d += WCT / B) {
             const int j = threadIdx.x % B;
             const unsigned long long h = head[d], t = tail[d];

@@ -2986,9 +2986,10 @@ static int count_reads_superkmer(rfx_ctx *ctx, const ReadStore *reads, int min_c
     if (n <= 0) return RFX_OK;
     std::vector<int> bits;
     plan_levels(n, true, bits, 16384.0);           // measured best for the record leaf with double hashing + pre-split (tools/bits_sweep.sh)
-    // 1024 bins at level 1 leave one workgroup per CU (the rings fill the LDS): 20 Gbp on one GPU measured 138.8 ms
-    // with levels of 10 + 10 bits, 131.7 ms with 9 + 10 and leaves twice as large, 139 ms with three levels
-    if (bits.size() == 2 && bits[0] > 9 && !getenv("RFX_LEVEL_BITS")) bits[0] = 9;
+    // (20 bits and more put 1024 bins on level 1 and one workgroup per CU there, the rings fill the LDS.  Measured on one
+    // GPU: 20 Gbp of the 4.64 Mbp genome 138.8 ms with 10 + 10 bits, 131.7 with 9 + 10 and leaves twice as large, 139
+    // with three levels; 18.75 Gbp of a 400 Mbp genome -- 2.5e9 distinct k-mers, a human-scale share -- 238 ms with
+    // 10 + 10, 254 with 9 + 10: the leaves of a deep data set want to be small, so the plan stays as it is)
     Level lv{};
     lv.bits = bits[0];
     StageArena stage_arena(ctx, ((size_t)64 << 20) + (size_t)n / 8);

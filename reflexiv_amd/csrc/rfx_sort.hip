@@ -24,15 +24,16 @@ constexpr int SW = ST / 64;         // waves per workgroup
 // the bucket, and its histogram row sits at table[tstart[b]*D + d*nt_b + t]: scanned flat, that layout is the order
 // (bucket, digit, tile), i.e. the output position of every (tile, digit) group.
 struct SegMap {
-    const uint32_t *bstart;     // [257] first position of every level-1 bucket (bstart[256] = n)
-    const uint32_t *tstart;     // [257] first virtual tile of every bucket (tstart[256] = number of virtual tiles)
+    const uint32_t *bstart;     // [NP + 1] first position of every parent bucket (bstart[NP] = n)
+    const uint32_t *tstart;     // [NP + 1] first virtual tile of every bucket (tstart[NP] = number of virtual tiles)
     int D;                      // digits of this level (power of two <= 256)
+    int NP = 256;               // parent buckets: 256 after one level, 65536 after two (third level, n > 2^26)
 };
 struct SegPos { int64_t begin, end, row; int64_t stride; bool ok; };
 __device__ __forceinline__ SegPos seg_pos(const SegMap &m, uint32_t v) {
-    SegPos p; p.ok = v < m.tstart[256];
+    SegPos p; p.ok = v < m.tstart[m.NP];
     if (!p.ok) { p.begin = p.end = p.row = 0; p.stride = 1; return p; }
-    int lo = 0, hi = 256;                              // last b with tstart[b] <= v
+    int lo = 0, hi = m.NP;                             // last b with tstart[b] <= v
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (m.tstart[mid] <= v) lo = mid; else hi = mid; }
     const uint32_t t = v - m.tstart[lo];
     p.begin = (int64_t)m.bstart[lo] + (int64_t)t * STILE;
@@ -165,11 +166,30 @@ __global__ __launch_bounds__(256) void k_l2_setup(const uint64_t *__restrict__ o
     if (threadIdx.x == 0) { bstart[256] = (uint32_t)n; tstart[256] = tot; }
 }
 
+// virtual tiles of a level whose parents are the NP buckets bounded by `bounds` (one workgroup; NP up to 65536)
+__global__ __launch_bounds__(1024) void k_seg_setup(const uint32_t *__restrict__ bounds, int NP, uint32_t *__restrict__ tstart) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < NP; base += 1024) {
+        const int b = base + threadIdx.x;
+        const uint32_t nt = b < NP ? (bounds[b + 1] - bounds[b] + STILE - 1) / STILE : 0u;
+        uint32_t tot = 0;
+        const uint32_t ex = rfxd::block_exclusive_scan(nt, wsum, &tot);
+        if (b < NP) tstart[b] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tstart[NP] = carry;
+}
+
 // starts of the 256*D final buckets (bucket b, digit d) from the scanned level-2 table, and the largest bucket
 __global__ void k_l3_bounds(const uint64_t *__restrict__ offs2, SegMap sm, int64_t n, uint32_t *__restrict__ b3,
                             uint32_t *__restrict__ maxc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int NB = 256 * sm.D;
+    const int NB = sm.NP * sm.D;
     if (i > NB) return;
     auto start_of = [&](int q) -> uint32_t {
         if (q >= NB) return (uint32_t)n;
@@ -338,7 +358,79 @@ int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int 
     const bool inline_scan = ntiles <= 64;           // <= 128 K pairs
     static const bool msd_off = getenv("RFX_SORT_MSD") && atoi(getenv("RFX_SORT_MSD")) == 0;
     const SegMap nomap{nullptr, nullptr, 256};
-    if (ntiles > 192 && key_bits > 16 && n <= ((int64_t)1 << 26) && !msd_off) {
+    if (n > ((int64_t)1 << 26) && n < ((int64_t)1 << 32) && key_bits > 24 && !msd_off) {
+        // Beyond 2^26 pairs (the 4.5e8 survivors of a human-scale share): THREE stable MSD levels -- 8 bits, 8 bits, then as
+        // many as bring a bucket to ~1000 pairs -- and the final buckets on chip: 85 -> ~25 ms where the eight LSD passes
+        // ran at 1.3 TB/s.  The second level's 65536 buckets are the parents of the third (SegMap::NP).  Skewed keys (a
+        // final bucket larger than a tile) take the LSD passes below from the regrouped state, as on the two-level path.
+        const int shift1 = key_bits - 8, shift2 = key_bits - 16;
+        int b3 = 1;
+        while (b3 < 8 && (n >> (16 + b3)) > 1000) b3++;
+        if (b3 > shift2) b3 = shift2;
+        const int shift3 = shift2 - b3, D3 = 1 << b3;
+        const int NP2 = 65536;
+        const int64_t vmax2 = ntiles + 256, vmax3 = ntiles + NP2;
+        DevBuf table2, offs2, maps1, bounds2, tstart2, table3, offs3, bounds3;
+        RFX_HIP(table2.alloc((size_t)vmax2 * 256 * 4, ctx->stream));
+        RFX_HIP(offs2.alloc((size_t)(vmax2 * 256 + 1) * 8, ctx->stream));
+        RFX_HIP(maps1.alloc(2 * 257 * 4, ctx->stream));
+        RFX_HIP(bounds2.alloc((size_t)(NP2 + 2) * 4, ctx->stream));
+        RFX_HIP(tstart2.alloc((size_t)(NP2 + 1) * 4, ctx->stream));
+        RFX_HIP(table3.alloc((size_t)vmax3 * D3 * 4, ctx->stream));
+        RFX_HIP(offs3.alloc((size_t)(vmax3 * D3 + 1) * 8, ctx->stream));
+        RFX_HIP(bounds3.alloc((size_t)((size_t)NP2 * D3 + 2) * 4, ctx->stream));
+        uint32_t *d_b1 = maps1.as<uint32_t>(), *d_t1 = maps1.as<uint32_t>() + 257;
+        uint32_t *d_max2 = bounds2.as<uint32_t>() + NP2 + 1, *d_max3 = bounds3.as<uint32_t>() + (size_t)NP2 * D3 + 1;
+        // level 1: sk -> dk
+        hipLaunchKernelGGL(k_hist<false>, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, n, shift1, table.as<uint32_t>(), ntiles, nomap);
+        RFX_HIP(hipGetLastError());
+        RFX_TRY(exclusive_scan_u32_to_u64(ctx, table.as<uint32_t>(), offs.as<uint64_t>(), ntiles * 256));
+        hipLaunchKernelGGL(k_scatter<false>, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, sv, n, shift1,
+                           (const uint64_t *)offs.as<uint64_t>(), ntiles, dk, dv, (const uint32_t *)table.as<uint32_t>(), nomap);
+        RFX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_l2_setup, dim3(1), dim3(256), 0, ctx->stream, (const uint64_t *)offs.as<uint64_t>(), ntiles, n, d_b1, d_t1);
+        RFX_HIP(hipGetLastError());
+        // level 2: dk -> sk, 256 digits inside every level-1 bucket
+        const SegMap sm2{d_b1, d_t1, 256, 256};
+        RFX_HIP(hipMemsetAsync(table2.p, 0, (size_t)vmax2 * 256 * 4, ctx->stream));
+        RFX_HIP(hipMemsetAsync(d_max2, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_hist<true>, dim3((unsigned)vmax2), dim3(ST), 0, ctx->stream, (const uint64_t *)dk, n, shift2, table2.as<uint32_t>(), vmax2, sm2);
+        RFX_HIP(hipGetLastError());
+        RFX_TRY(exclusive_scan_u32_to_u64(ctx, table2.as<uint32_t>(), offs2.as<uint64_t>(), vmax2 * 256));
+        hipLaunchKernelGGL(k_scatter<true>, dim3((unsigned)vmax2), dim3(ST), 0, ctx->stream, (const uint64_t *)dk, (const uint32_t *)dv, n, shift2,
+                           (const uint64_t *)offs2.as<uint64_t>(), vmax2, sk, sv, (const uint32_t *)table2.as<uint32_t>(), sm2);
+        RFX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_l3_bounds, dim3((unsigned)ceil_div(NP2 + 1, 256)), dim3(256), 0, ctx->stream,
+                           (const uint64_t *)offs2.as<uint64_t>(), sm2, n, bounds2.as<uint32_t>(), d_max2);
+        RFX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_seg_setup, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)bounds2.as<uint32_t>(), NP2, tstart2.as<uint32_t>());
+        RFX_HIP(hipGetLastError());
+        // level 3: sk -> dk, D3 digits inside every level-2 bucket
+        const SegMap sm3{bounds2.as<uint32_t>(), tstart2.as<uint32_t>(), D3, NP2};
+        RFX_HIP(hipMemsetAsync(table3.p, 0, (size_t)vmax3 * D3 * 4, ctx->stream));
+        RFX_HIP(hipMemsetAsync(d_max3, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_hist<true>, dim3((unsigned)vmax3), dim3(ST), 0, ctx->stream, (const uint64_t *)sk, n, shift3, table3.as<uint32_t>(), vmax3, sm3);
+        RFX_HIP(hipGetLastError());
+        RFX_TRY(exclusive_scan_u32_to_u64(ctx, table3.as<uint32_t>(), offs3.as<uint64_t>(), vmax3 * D3));
+        hipLaunchKernelGGL(k_scatter<true>, dim3((unsigned)vmax3), dim3(ST), 0, ctx->stream, (const uint64_t *)sk, (const uint32_t *)sv, n, shift3,
+                           (const uint64_t *)offs3.as<uint64_t>(), vmax3, dk, dv, (const uint32_t *)table3.as<uint32_t>(), sm3);
+        RFX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_l3_bounds, dim3((unsigned)ceil_div((int64_t)NP2 * D3 + 1, 256)), dim3(256), 0, ctx->stream,
+                           (const uint64_t *)offs3.as<uint64_t>(), sm3, n, bounds3.as<uint32_t>(), d_max3);
+        RFX_HIP(hipGetLastError());
+        uint32_t maxc = 0;
+        RFX_HIP(hipMemcpyAsync(&maxc, d_max3, 4, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        if (maxc <= (uint32_t)STILE) {
+            hipLaunchKernelGGL(k_sort_buckets, dim3((unsigned)((int64_t)NP2 * D3)), dim3(ST), 0, ctx->stream, (const uint64_t *)dk, (const uint32_t *)dv,
+                               (const uint32_t *)bounds3.as<uint32_t>(), shift3, d_keys, d_vals);
+            RFX_HIP(hipGetLastError());
+            return RFX_OK;
+        }
+        // skewed: (dk, dv) hold a stable regrouping of the input; the LSD passes finish it from there
+        std::swap(sk, dk);
+        std::swap(sv, dv);
+    } else if (ntiles > 192 && key_bits > 16 && n <= ((int64_t)1 << 26) && !msd_off) {
         // Large inputs: TWO stable MSD levels (8 bits, then as many as bring a bucket to ~1000 pairs), then every
         // final bucket is finished on chip -- ~90 B of HBM traffic per pair instead of 32 B x (key_bits / 8) LSD passes.
         // A bucket larger than a tile (skewed keys) sends the whole thing down the LSD passes below instead, which

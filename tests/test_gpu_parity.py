@@ -460,6 +460,37 @@ def test_sort_pairs_two_level_msd_is_stable(rfx, torch_mod):
         assert np.array_equal(dv.cpu().numpy().view(np.uint32), vals[order]), (n, bits)
 
 
+def test_sort_pairs_three_level_msd_is_stable(rfx, torch_mod):
+    """more than 2^26 pairs (the survivors of a human-scale share): three stable MSD levels, the final buckets on chip.
+    Spread 62-bit keys with values that are a permutation; many ties (stability); and a skewed set -- a fifth of the keys
+    on one top byte -- whose final buckets outgrow a tile, so the LSD passes finish from the regrouped state.  Checked
+    on the device against torch's stable sort."""
+    torch = torch_mod
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    n = (1 << 26) + 1_234_567
+    for case in ("spread", "ties", "skew"):
+        if case == "spread":
+            keys = torch.randint(0, 1 << 62, (n,), dtype=torch.int64, device="cuda", generator=g)
+        elif case == "ties":
+            pool = torch.randint(0, 1 << 62, (1 << 22,), dtype=torch.int64, device="cuda", generator=g)
+            keys = pool[torch.randint(0, 1 << 22, (n,), device="cuda", generator=g)]
+        else:
+            keys = torch.randint(0, 1 << 62, (n,), dtype=torch.int64, device="cuda", generator=g)
+            hot = torch.rand(n, device="cuda", generator=g) < 0.2
+            keys = torch.where(hot, (keys & ((1 << 30) - 1)) | (5 << 54), keys)
+        vals = torch.randperm(n, device="cuda", generator=g).to(torch.int32)
+        want_k, order = torch.sort(keys, stable=True)
+        want_v = vals[order]
+        dk, dv = keys.clone(), vals.clone()
+        tk, tv = torch.empty_like(dk), torch.empty_like(dv)
+        torch.cuda.synchronize()
+        rfx.sort_pairs_dev(dk.data_ptr(), dv.data_ptr(), n, 62, tk.data_ptr(), tv.data_ptr())
+        rfx.sync()
+        assert bool((dk == want_k).all()), case
+        assert bool((dv == want_v).all()), case
+        del want_k, order, want_v, dk, dv, tk, tv, keys, vals
+
+
 # ------------------------------------------------ C++ host mirror of the reference driver
 
 def write_fastq(path, bases, read_off, gz=False):

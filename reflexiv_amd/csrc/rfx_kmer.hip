@@ -438,7 +438,8 @@ __global__ __launch_bounds__(PT) void k_vb_scatter(const uint64_t *__restrict__ 
 // against 12.6 (tools/build_variant.sh + tools/ab_many.sh; 10 waves per workgroup: 20 ms)
 constexpr int LT = RFX_LT;              // threads per leaf workgroup
 // (experiment, off: parking the keys whose first probe failed and walking 64 of them at once, one per lane, instead of
-// on the spot -- halves the SGPR spills, same 12.7 ms: the probe walks are not what the wave waits for)
+// on the spot -- halves the SGPR spills, same 12.7 ms: the probe walks are not what the wave waits for; on a
+// human-scale share, tables at 58 %, 298 ms against 77: the walk of 64 parked keys runs to the longest of THEIR sequences)
 #ifndef RFX_LEAF_QUEUE
 #define RFX_LEAF_QUEUE 0
 #endif

@@ -437,15 +437,19 @@ __global__ __launch_bounds__(PT) void k_vb_scatter(const uint64_t *__restrict__ 
 // issue latency (one workgroup per CU instead of two: 13.1 -> 21.7 ms), and 8 waves with 4 per SIMD measured 13.2 ms
 // against 12.6 (tools/build_variant.sh + tools/ab_many.sh; 10 waves per workgroup: 20 ms)
 constexpr int LT = RFX_LT;              // threads per leaf workgroup
-// (experiment, off: parking the keys whose first probe failed and walking 64 of them at once, one per lane, instead of
-// on the spot -- halves the SGPR spills, same 12.7 ms: the probe walks are not what the wave waits for; on a
-// human-scale share, tables at 58 %, 298 ms against 77: the walk of 64 parked keys runs to the longest of THEIR sequences)
+// RFX_LEAF_QUEUE (experiment, off): probing as a per-wave queue of attempts, as in the two-word leaf -- a key whose
+// first probe met another key is queued with its next slot, and whenever 32 attempts wait they are made together.
+// Measured: 13.3 ms against 12.3 on the bench, 758 ms against 77 on a human-scale share whose tables run at 58 % -- two
+// keys per lane already probe side by side here, and a batch of 32 attempts is half a wave.  (An earlier form that
+// parked the keys and walked 64 whole sequences at once: 12.7 ms and 298 ms.)  What pays in the two-word leaf, where
+// one key per lane went round a ballot loop, does not pay here.
 #ifndef RFX_LEAF_QUEUE
 #define RFX_LEAF_QUEUE 0
 #endif
-constexpr int LQCAP = RFX_LEAF_QUEUE ? 128 : 0;   // keys a wave parks for a later, dense walk of their probe sequences (record leaves)
-constexpr int LOBUF = RFX_LEAF_QUEUE ? 256 : 512; // survivors k_leaf_count buffers in LDS between flushes
-constexpr int WSTAGE = 160 + LQCAP;     // u64 words of a wave's private expansion area (record leaves)
+constexpr int LQCAP = RFX_LEAF_QUEUE ? 96 : 0;    // attempts a wave has pending (record leaves): < 32 + 64 new ones
+constexpr int LQBATCH = 32;
+constexpr int LOBUF = RFX_LEAF_QUEUE ? 64 : 512;  // survivors k_leaf_count buffers in LDS between flushes
+constexpr int WSTAGE = 160 + LQCAP + LQCAP / 2;   // u64 words of a wave's private expansion area (record leaves) + its queue
 constexpr int LSTAGE = WSTAGE * (LT / 64);
 #ifndef RFX_LCAP
 #define RFX_LCAP 4096
@@ -672,6 +676,36 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
         // is done when its slot held EMPTY (claimed) or the key itself; either way its count goes up.
         // There is no occupancy counter: a probe sequence longer than LPROBE flags the pass as
         // overflowing (the table is too full to be worth probing) and the leaf is split.
+        // the top n <= LQBATCH entries of the wave's queue: one probe each, what is not finished goes back
+        auto attempts = [&](uint32_t n) __attribute__((always_inline)) {
+            if constexpr (RECS && LQCAP > 0) {
+                uint64_t *wq = stage + wave_ * WSTAGE + 160;
+                uint32_t *wqs = (uint32_t *)(wq + LQCAP);
+                qn -= n;
+                const bool v = (uint32_t)lane_ < n;
+                const uint64_t key = v ? wq[qn + lane_] : 0;
+                const uint32_t st = v ? wqs[qn + lane_] : 0u;
+                __builtin_amdgcn_wave_barrier();
+                uint32_t slot = st & 0xffffu, probe = st >> 16;
+                bool done = !v;
+                if (v) {
+                    const unsigned long long p = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
+                    if (p == EMPTY || p == key) { atomicAdd(&tcnt[slot], 1u); done = true; }
+                    else {
+                        const uint32_t g = ((uint32_t)key ^ __builtin_rotateleft32((uint32_t)(key >> 32), 13)) * 0x9E3779B1u;
+                        slot = leaf_next(slot, (dbg & 16) ? 1u : leaf_step(g));
+                        if (++probe >= (uint32_t)LPROBE) { overflow = 1; done = true; }
+                    }
+                }
+                const uint64_t m = __ballot(!done);
+                if (m) {
+                    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (!done) { wq[qn + r] = key; wqs[qn + r] = slot | (probe << 16); }
+                    qn += (uint32_t)__popcll(m);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
         auto insert2 = [&](uint64_t keyA, bool a, uint64_t keyB, bool b, uint32_t wA, uint32_t wB) __attribute__((always_inline)) {
             const uint32_t gA = ((uint32_t)keyA ^ __builtin_rotateleft32((uint32_t)(keyA >> 32), 13)) * 0x9E3779B1u;
             const uint32_t gB = ((uint32_t)keyB ^ __builtin_rotateleft32((uint32_t)(keyB >> 32), 13)) * 0x9E3779B1u;
@@ -702,26 +736,23 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
             };
             // (one loop per key; a single loop walking a lane's two sequences one after the other measured 10 % slower)
             if constexpr (RECS && LQCAP > 0) {
-                // Records: a key whose first probe met another key is PARKED in the wave's queue; the probe sequences
-                // are walked once 64 keys wait, one per lane.  Walked on the spot, one or two lanes in ten hold the
-                // whole wave through its longest probe sequence (four or five LDS round trips) in every round.
                 uint64_t *wq = stage + wave_ * WSTAGE + 160;
+                uint32_t *wqs = (uint32_t *)(wq + LQCAP);
 #pragma nounroll
                 for (int ph = 0; ph < 2; ph++) {
                     const bool u = ph == 0 ? !dA : !dB;
                     const uint64_t m = __ballot(u);
                     if (m) {
                         const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        if (u) wq[qn + r] = ph == 0 ? keyA : keyB;
+                        if (u) {
+                            const uint32_t g = ph == 0 ? gA : gB;
+                            wq[qn + r] = ph == 0 ? keyA : keyB;
+                            wqs[qn + r] = leaf_next(ph == 0 ? slotA : slotB, (dbg & 16) ? 1u : leaf_step(g)) | (1u << 16);
+                        }
                         qn += (uint32_t)__popcll(m);
                         __builtin_amdgcn_wave_barrier();
-                        if (qn >= 64u) {
-                            qn -= 64u;
-                            const uint64_t key = wq[qn + lane_];
-                            const uint32_t g = ((uint32_t)key ^ __builtin_rotateleft32((uint32_t)(key >> 32), 13)) * 0x9E3779B1u;
-                            walk(key, leaf_slot(g), 1u, g);
-                            __builtin_amdgcn_wave_barrier();
-                        }
+#pragma nounroll
+                        while (qn >= (uint32_t)LQBATCH) attempts((uint32_t)LQBATCH);
                     }
                 }
             } else {
@@ -729,27 +760,12 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
                 if (!dB) walk(keyB, slotB, wB, gB);
             }
         };
-        // the keys still parked when the wave has been through its share of the leaf
+        // the attempts still pending when the wave has been through its share of the leaf
         auto drain_queue = [&]() __attribute__((always_inline)) {
             if constexpr (RECS && LQCAP > 0) {
-                uint64_t *wq = stage + wave_ * WSTAGE + 160;
-                if (qn) {
-                    const bool mine = (uint32_t)lane_ < qn;
-                    const uint64_t key = mine ? wq[lane_] : 0;
-                    const uint32_t g = ((uint32_t)key ^ __builtin_rotateleft32((uint32_t)(key >> 32), 13)) * 0x9E3779B1u;
-                    if (mine) {
-                        const uint32_t step = (dbg & 16) ? 1u : leaf_step(g);
-                        uint32_t slot = leaf_slot(g);
-#pragma unroll 1
-                        for (int probe = 1;; probe++) {
-                            slot = leaf_next(slot, step);
-                            const unsigned long long p = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
-                            if (p == EMPTY || p == key) { atomicAdd(&tcnt[slot], 1u); break; }
-                            if (probe >= LPROBE) { overflow = 1; break; }
-                        }
-                    }
-                    qn = 0;
-                }
+#pragma nounroll
+                while (qn > 0u && !__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                    attempts(qn < (uint32_t)LQBATCH ? qn : (uint32_t)LQBATCH);
             }
         };
         if constexpr (RECS) {

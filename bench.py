@@ -76,8 +76,7 @@ def parse():
                     help="N > 1, k <= 31: what crosses the all-to-all -- (k-mer, local count) pairs after a local combine "
                          "(reduceByKey's map-side combine: fewer bytes at high coverage, the local count hides the flight) or "
                          "super-k-mer records in --generations of the hash space (less compute; the count of one generation "
-                         "hides the flight of the next).  auto: records from 4 GPUs on (a peer's share per link hides behind a generation's count), "
-                         "pairs at 2")
+                         "hides the flight of the next).  auto: records (since round 2 the form with less compute at every N; pairs stay selectable)")
     ap.add_argument("--generations", type=int, default=4, help="--exchange records: generations of the hash space")
     ap.add_argument("--sharded-extend", action="store_true",
                     help="N > 1 (or --force-dist): run the extend stage range-sharded over the ranks with the records resident "
@@ -219,7 +218,7 @@ def main():
     d_counts = torch.empty(cap, dtype=torch.int64 if wide else torch.int32, device=dev)
     reads = dict(words=d_words, n_reads=n_reads, wpr=wpr, read_len=L, k=k)
     if args.exchange == "auto":
-        args.exchange = "records" if world >= 4 else "pairs"
+        args.exchange = "records"
     engine = rd.HipEngine(rfx, combine=args.exchange == "pairs" and not wide)
     engine.force_exchange = args.force_dist
     timing_acc = {}

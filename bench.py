@@ -221,6 +221,10 @@ def main():
         args.exchange = "records"
     engine = rd.HipEngine(rfx, combine=args.exchange == "pairs" and not wide)
     engine.force_exchange = args.force_dist
+    if args.force_dist and world == 1:
+        # one-rank rehearsal: the rank's own bucket is handed over by a device copy, i.e. the numbers of this
+        # mode contain NO exchange time (labelled "exchange_free" in the JSON line)
+        rd.LOCAL_SHORTCUT = True
     timing_acc = {}
 
     shard = {}
@@ -319,7 +323,8 @@ def main():
         out["exchange"] = {"unit": out["config"]["parallelism"].split(" of ")[-1], "bytes_bucketed_per_gpu_per_step": B,
                            "bytes_per_instance": B / n_inst, "bytes_leaving_per_gpu_per_step": B * (world - 1) / world,
                            "per_link_floor_ms_at_153GBps": B / world / 153e9 * 1e3 if world > 1 else 0.0,
-                           "chunks": 1 if (args.exchange == "records" and not wide) else max(args.exchange_chunks, int(est_chunks) + 1)}
+                           "chunks": 1 if (args.exchange == "records" and not wide) else max(args.exchange_chunks, int(est_chunks) + 1),
+                           "exchange_free": bool(rd.LOCAL_SHORTCUT and world == 1)}
     if multi and not args.no_contigs and args.sharded_extend and not wide:
         # every sortByKey of the loop = local sort + splitters + ONE all-to-all of whole records + local sort, records in HBM
         prm = reflexiv_amd.default_params(k=k, min_cov=args.cover, partitions=max(args.partitions, world))

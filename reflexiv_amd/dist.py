@@ -12,6 +12,8 @@ computes on the CPU itself.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -271,6 +273,12 @@ class HipEngine:
 # peer: larger buckets go in rounds through staging buffers.
 A2A_LIMIT_BYTES = 1 << 29      # per peer per call (512 MiB)
 
+# One-rank groups only: hand the rank's own bucket over by a device copy instead of through RCCL.  OFF by default so
+# that every test and every real run goes through dist.all_to_all_single (the 512 MiB rounds and the async handles
+# included); only the bench's one-rank rehearsal (`bench.py --force-dist`) turns it on, and its numbers are then
+# labelled exchange-free.
+LOCAL_SHORTCUT = os.environ.get("RFX_DIST_LOCAL_SHORTCUT", "0") == "1"
+
 
 def _alltoallv(send: torch.Tensor, send_counts, group=None, async_op: bool = False, limit: int = None, out=None,
                recv_counts=None, rounds: int = None):
@@ -293,7 +301,7 @@ def _alltoallv(send: torch.Tensor, send_counts, group=None, async_op: bool = Fal
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
         rounds = max(1, -(-int(mx.item()) // limit))
     need = sum(recv_counts)
-    if world == 1:
+    if world == 1 and LOCAL_SHORTCUT:
         # one rank (the rehearsal of the multi-GPU branch on a single GPU): the only bucket is this rank's own, which on
         # N ranks is the 1/N that never crosses a link -- hand it over as it is (or by one device copy into the caller's
         # buffer) instead of through RCCL's self-copy, which moves it at a sixth of the HBM rate

@@ -544,10 +544,11 @@ class Reflexiv:
                     "rfx_dev_sort_pairs")
 
     def count_timing(self):
-        """Per-kernel-family HIP-event timing of the last count call: {name: (ms, launches)}."""
+        """Per-kernel-family HIP-event timing of the last count call: {name: (ms, launches)}; the "stat_*" entries carry
+        the leaf tables' statistics in `launches` (leaves, table passes, passes abandoned on overflow)."""
         out = {}
         for name in ("hist1", "part1", "hist2", "part2", "hist3", "part3", "leaf", "sort", "extract_w", "count_w",
-                     "pair_hist", "pair_part"):
+                     "pair_hist", "pair_part", "stat_leaves", "stat_passes", "stat_overflows"):
             ms, ln = C.c_float(0), C.c_int64(0)
             if self.L.rfx_last_count_timing(self.ctx, name.encode(), C.byref(ms), C.byref(ln)) == RFX_OK:
                 out[name] = (float(ms.value), int(ln.value))

@@ -2676,6 +2676,9 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
     if (out_distinct) *out_distinct = (int64_t)co.n_distinct;
     if (getenv("RFX_TRACE"))
         fprintf(stderr, "leaves: %lld buckets, %llu table passes, %llu overflowed\n", (long long)nleaf, co.n_passes, co.n_overflow);
+    // table statistics of the last count call, read back by tests through rfx_last_count_timing (launches = the number)
+    ctx->timing["stat_leaves"].launches += nleaf; ctx->timing["stat_passes"].launches += (int64_t)co.n_passes;
+    ctx->timing["stat_overflows"].launches += (int64_t)co.n_overflow;
     if (dbg & 32)
         fprintf(stderr, "leaf waves: %.1f %% of their clocks at the leaf barriers\n", 100.0 * (double)co.t_wait / (double)std::max<unsigned long long>(co.t_all, 1));
     if (co.n_failed) { ctx->last_error = "leaf split depth exhausted"; ScopedTimer::collect(ctx); return RFX_E_LIMIT; }
@@ -3354,6 +3357,8 @@ static int finish_wide2(rfx_ctx *ctx, const std::conditional_t<RECS, WRec, Rec> 
     RFX_HIP(hipStreamSynchronize(ctx->stream));
     if (getenv("RFX_TRACE"))
         fprintf(stderr, "wide leaves: %lld buckets, %llu table passes, %llu overflowed\n", (long long)nseg, co.n_passes, co.n_overflow);
+    ctx->timing["stat_leaves"].launches += nseg; ctx->timing["stat_passes"].launches += (int64_t)co.n_passes;
+    ctx->timing["stat_overflows"].launches += (int64_t)co.n_overflow;
     if (out_n) *out_n = (int64_t)co.n_out;
     if (out_distinct) *out_distinct = (int64_t)co.n_distinct;
     if (co.n_failed) { ctx->last_error = "leaf split depth exhausted"; return RFX_E_LIMIT; }

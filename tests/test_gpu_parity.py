@@ -1481,3 +1481,70 @@ def test_wide_record_owner_buckets(rfx, torch_mod, k, owners):
     allk = np.concatenate(got_k); allc = np.concatenate(got_c)
     order = np.lexsort((allk[:, 1], allk[:, 0]))
     assert tot_d == wd and np.array_equal(allk[order], wk) and np.array_equal(allc[order], wc)
+
+
+@pytest.mark.parametrize("k,env", [
+    (31, {"RFX_LEAF_TARGET": "131072", "RFX_PRESPLIT": "1500"}),      # leaves 8 x the default size, tiny pre-split threshold
+    (31, {"RFX_LEAF_TARGET": "131072", "RFX_PRESPLIT": "1000000"}),   # no pre-split: every full leaf finds out by overflowing
+    (29, {"RFX_LEAF_TARGET": "65536", "RFX_PRESPLIT": "700"}),
+    (63, {"RFX_LEAF_TARGET": "131072", "RFX_WIDE_PRESPLIT": "300"}),
+    (63, {"RFX_LEAF_TARGET": "131072", "RFX_WIDE_PRESPLIT": "1000000"}),
+    (47, {"RFX_LEAF_TARGET": "65536", "RFX_WIDE_PRESPLIT": "150"}),
+])
+def test_leaf_tables_under_forced_split_passes(rfx, torch_mod, k, env):
+    """Many hash-selected table passes per workgroup (the `0081c2e` race -- the adaptive pre-split
+    threshold moved after the closing barrier -- showed only in a variant build).  Leaves several times the default size
+    on a distinct-heavy read set (shallow coverage, 2 % substitutions) overflow their 4096-slot tables: with a tiny
+    pre-split threshold every leaf starts in many parts and the threshold adapts on every overflow; with a huge one every
+    full leaf is abandoned and re-streamed in 2, 4, .. parts.  Counts and survivors against the oracle, and the
+    statistics show that the machinery really ran."""
+    import os
+    torch = torch_mod
+    seed, G, n_reads, L, min_cov = 4242 + k, 3_000_000, 400_000, 150, 2
+    wpr = (L + 31) // 32
+    dg = torch.empty((G + 31) // 32, dtype=torch.int64, device="cuda")
+    dw = torch.empty(n_reads * wpr, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    err = int(0.02 * (1 << 32))
+    rfx.synth_genome_dev(seed, G, dg.data_ptr())
+    rfx.synth_reads_dev(seed, dg.data_ptr(), G, 0, n_reads, L, wpr, dw.data_ptr(), err)
+    rfx.sync()
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, n_reads, L, err)
+    old = {key: os.environ.get(key) for key in env}
+    os.environ.update(env)
+    try:
+        if k <= 31:
+            N = rfx.kmers_per_read(L, k) * n_reads
+            dk = torch.empty(N, dtype=torch.int64, device="cuda"); dc = torch.empty(N, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, min_cov)
+            stats = rfx.count_timing()
+            O.set_threads(O.host_cores())
+            wk, wc, wd, wi = O.count_reads_omp(bases, off, k, min_cov)
+            assert (inst, nd, m) == (wi, wd, len(wk))
+            assert np.array_equal(dk[:m].cpu().numpy().view(np.uint64), wk)
+            assert np.array_equal(dc[:m].cpu().numpy(), wc)
+        else:
+            W = k // 32 + 1
+            N = rfx.kmers_per_read_w(L, k) * n_reads
+            cap = N // 4
+            dk = torch.empty(cap * W, dtype=torch.int64, device="cuda"); dc = torch.empty(cap, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            m, nd, inst = rfx.count_reads_w_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), cap, min_cov)
+            stats = rfx.count_timing()
+            O.set_threads(O.host_cores())
+            wk, wc, wd, wi = O.count_reads_omp(bases, off, k, min_cov)
+            assert (inst, nd, m) == (wi, wd, len(wc)) and wi == N
+            assert np.array_equal(dk[:m * W].cpu().numpy().view(np.uint64).reshape(m, W), wk)
+            assert np.array_equal(dc[:m].cpu().numpy(), np.asarray(wc, np.int64))
+    finally:
+        for key, v in old.items():
+            if v is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = v
+    leaves, passes, over = (stats[s][1] for s in ("stat_leaves", "stat_passes", "stat_overflows"))
+    assert leaves > 0 and passes >= 3 * leaves, stats                 # several table passes per leaf on average
+    if int(env.get("RFX_PRESPLIT", env.get("RFX_WIDE_PRESPLIT"))) >= 1000000:
+        assert over >= leaves // 2, stats                             # and the overflow path when nothing is pre-split

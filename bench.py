@@ -78,6 +78,9 @@ def parse():
                          "super-k-mer records in --generations of the hash space (less compute; the count of one generation "
                          "hides the flight of the next).  auto: records (since round 2 the form with less compute at every N; pairs stay selectable)")
     ap.add_argument("--generations", type=int, default=4, help="--exchange records: generations of the hash space")
+    ap.add_argument("--exchange-impl", choices=["capi", "torch"], default="capi",
+                    help="N > 1, --exchange records: capi = rfx_dev_sharded_count (RCCL send / recv inside libreflexiv_hip.so, "
+                         "the form a Java / C host calls); torch = reflexiv_amd.dist over torch.distributed")
     ap.add_argument("--sharded-extend", action="store_true",
                     help="N > 1 (or --force-dist): run the extend stage range-sharded over the ranks with the records resident "
                          "in HBM (reflexiv_amd.dist.sharded_assemble_dev: one RCCL all-to-all of whole records per sortByKey) "
@@ -221,7 +224,13 @@ def main():
         args.exchange = "records"
     engine = rd.HipEngine(rfx, combine=args.exchange == "pairs" and not wide)
     engine.force_exchange = args.force_dist
-    if args.force_dist and world == 1:
+    capi = multi and args.exchange == "records" and args.exchange_impl == "capi" and (21 <= k <= 31 or 33 <= k <= 63)
+    if capi:
+        # the RCCL communicator of the C ABI: rank 0 makes the id, torch.distributed only carries its 128 bytes
+        box = [reflexiv_amd.Reflexiv.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        rfx.comm_init(box[0], rank, world)
+    if args.force_dist and world == 1 and not capi:
         # one-rank rehearsal: the rank's own bucket is handed over by a device copy, i.e. the numbers of this
         # mode contain NO exchange time (labelled "exchange_free" in the JSON line)
         rd.LOCAL_SHORTCUT = True
@@ -243,9 +252,18 @@ def main():
             return m, nd, inst
         est = est_chunks
         chunks = max(args.exchange_chunks, int(est) + 1)
-        gens = args.generations if (args.exchange == "records" and not wide) else 1
+        gens = args.generations if (args.exchange == "records" and (capi or not wide)) else 1
         while gens > 1 and world * gens > 64:
             gens //= 2
+        if capi:
+            m, tot = rfx.sharded_count_dev(d_words.data_ptr(), n_reads, wpr, L, k, d_keys.data_ptr(), d_counts.data_ptr(), cap,
+                                           args.cover, generations=gens)
+            shard["keys"], shard["counts"] = d_keys[:m * W], d_counts[:m]
+            engine.bucketed_bytes = getattr(engine, "bucketed_bytes", 0) + rfx.comm_bytes_bucketed()
+            for name, (ms, ln) in rfx.count_timing().items():
+                a = engine.timing.setdefault(name, [0.0, 0])
+                a[0] += ms; a[1] += ln
+            return tot[2], tot[1], tot[0] // world
         keys, counts, tot = rd.sharded_count(engine, reads, args.cover, 10_000_000, 0, chunks=chunks, generations=gens)
         shard["keys"], shard["counts"] = keys, counts
         return tot[2], tot[1], tot[0] // world
@@ -310,7 +328,8 @@ def main():
                    "kmers_kept": m,
                    "parallelism": "1 GPU" if not multi else f"k-mer space radix-sharded over {world} GPUs, "
                                                                "RCCL all-to-all(v) of " +
-                                                               ("32-byte super-k-mer records of two-word k-mers" if wide else "(k-mer, local count) pairs"
+                                                               (f"32-byte super-k-mer records of two-word k-mers{', ' + str(args.generations) + ' generations' if capi else ''}" if wide
+                                                                else "(k-mer, local count) pairs"
                                                                 if engine.combine else f"super-k-mer records, {args.generations} generations")},
         "roofline": roofline,
         "stage_hbm_frac": (((0.25 + 16 * W) * n_inst + (8 * W + 4) * m) / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS) if not multi else None,
@@ -324,7 +343,9 @@ def main():
                            "bytes_per_instance": B / n_inst, "bytes_leaving_per_gpu_per_step": B * (world - 1) / world,
                            "per_link_floor_ms_at_153GBps": B / world / 153e9 * 1e3 if world > 1 else 0.0,
                            "chunks": 1 if (args.exchange == "records" and not wide) else max(args.exchange_chunks, int(est_chunks) + 1),
-                           "exchange_free": bool(rd.LOCAL_SHORTCUT and world == 1)}
+                           "impl": "rfx_dev_sharded_count (RCCL send/recv inside libreflexiv_hip.so)" if capi
+                                   else "reflexiv_amd.dist over torch.distributed",
+                           "exchange_free": bool((rd.LOCAL_SHORTCUT or capi) and world == 1)}
     if multi and not args.no_contigs and args.sharded_extend and not wide:
         # every sortByKey of the loop = local sort + splitters + ONE all-to-all of whole records + local sort, records in HBM
         prm = reflexiv_amd.default_params(k=k, min_cov=args.cover, partitions=max(args.partitions, world))
@@ -349,7 +370,16 @@ def main():
         # and run the extend stage on that one GPU
         torch.cuda.synchronize()
         t_g = time.perf_counter()
-        gk, gc = rd.gather_survivors(shard["keys"], shard["counts"], words=W)
+        if capi:
+            tot_m = rfx.comm_all_reduce([int(shard["counts"].numel())])[0]
+            gk = torch.empty(max(1, tot_m) * W, dtype=torch.int64, device=dev) if rank == 0 else shard["keys"][:0]
+            gc = torch.empty(max(1, tot_m), dtype=shard["counts"].dtype, device=dev) if rank == 0 else shard["counts"][:0]
+            torch.cuda.synchronize()
+            got = rfx.gather_shards_dev(shard["keys"].data_ptr(), shard["counts"].data_ptr(), int(shard["counts"].numel()), W,
+                                        shard["counts"].element_size(), 0, gk.data_ptr(), gc.data_ptr(), tot_m)
+            gk, gc = gk[:got * W], gc[:got]
+        else:
+            gk, gc = rd.gather_survivors(shard["keys"], shard["counts"], words=W)
         if rank == 0:
             m = int(gc.numel())
             gk = gk.contiguous(); gc = gc.contiguous()

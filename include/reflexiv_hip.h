@@ -339,6 +339,49 @@ int rfx_dev_merge_pairs(rfx_ctx *ctx, const void *d_pairs, int64_t n_pairs, int 
                         uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n,
                         int64_t *out_distinct);
 
+/* ---- the count stage on several GPUs of one node: the shuffle of `reduceByKey` (P/ReflexivMain.java:155, map-side
+ * combine included) / `groupBy("value").count()` (P/ReflexivDSMain.java:207-209) as an all-to-all(v) over RCCL / xGMI.
+ * One process or thread per GPU, each with its own rfx_ctx and one rfx_comm.  The k-mer space is radix-sharded by the
+ * owner of each k-mer's minimiser; what crosses the links are super-k-mer records (16 B per run of windows for
+ * k = 21..31, 32 B for k = 33..63: 2.6 / 5.4 bytes per k-mer instance).  RCCL is bound at run time (dlopen): the host
+ * process's own RCCL when it has one, /opt/rocm/lib/librccl.so.1 otherwise; RFX_E_NOGPU when there is none.
+ *   rfx_comm_unique_id      rank 0 makes the 128-byte id; the host hands it to every rank (Spark: a broadcast variable)
+ *   rfx_comm_init           collective: every rank calls it with the same id, its rank and the world size (<= 64)
+ *   rfx_comm_all_reduce_i64 sum (op 0) / max (op 1) of up to 8 host int64 over the ranks, in place (count() of the
+ *                           stop rule, totals, a barrier)
+ *   rfx_dev_sharded_count   collective: this rank's packed reads in HBM (d_read_len: per-read lengths for ragged reads,
+ *                           k <= 31, or NULL = every read has read_len bases) -> its shard of the filtered (k-mer, count) list,
+ *                           ascending (d_out_counts: int32 for k <= 31, int64 for k = 33..63, as the fused calls);
+ *                           out_totals[3] = instances, distinct, survivors over ALL ranks.  `generations` (1..8) cuts
+ *                           the hash space so that generation g is counted while g+1.. travel.  RFX_E_CAP -- on
+ *                           EVERY rank when the shard of ANY rank did not fit -- with *out_n = what this rank needs.
+ *   rfx_dev_gather_shards   collective: every rank's shard to rank `root`, shard after shard in rank order
+ * Environment: RFX_COMM_LIMIT_BYTES (per peer and call, default 512 MiB), RFX_COMM_SELF_VIA_RCCL=1 (tests: the rank's own
+ * bucket through ncclSend / ncclRecv instead of a device copy). */
+typedef struct rfx_comm rfx_comm;
+int rfx_comm_unique_id(uint8_t *id128);
+int rfx_comm_init(rfx_ctx *ctx, const uint8_t *id128, int rank, int world, rfx_comm **out);
+void rfx_comm_destroy(rfx_comm *comm);
+int rfx_comm_rank(const rfx_comm *comm);
+int rfx_comm_world(const rfx_comm *comm);
+int64_t rfx_comm_last_bytes_bucketed(const rfx_comm *comm);
+int rfx_comm_all_reduce_i64(rfx_comm *comm, int64_t *h_vals, int n, int op);
+int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *comm, const uint64_t *d_words, const uint32_t *d_read_len, int64_t n_reads,
+                          int words_per_read, int read_len, int k, int front_clip, int end_clip, int generations, int min_cov,
+                          int max_cov, int twin, uint64_t *d_out_keys, void *d_out_counts, int64_t cap, int64_t *out_n,
+                          int64_t *out_totals);
+/* The whole resident path on several GPUs from ASCII reads in host memory (the multi-GPU rfx_assemble_reads; what one
+ * Spark executor per GPU calls with ITS partition of the reads): upload + 2-bit encode (any read lengths), the sharded
+ * count above, the shards gathered on rank 0 and put in ascending order, rfx_dev_assemble there.  The contig text
+ * arrives on rank 0 (*out_len = 0 on the others).  k = 21..31.  Collective. */
+int rfx_sharded_assemble_reads(rfx_ctx *ctx, rfx_comm *comm, const uint8_t *bases, const int64_t *read_off, int64_t n_reads,
+                               const rfx_params *prm, int generations, char *out, int64_t cap, int64_t *out_len,
+                               int64_t *out_contigs, int64_t *trace, int64_t trace_cap, int64_t *n_trace,
+                               int64_t *out_totals);
+int rfx_dev_gather_shards(rfx_ctx *ctx, rfx_comm *comm, const uint64_t *d_keys, const void *d_counts, int64_t n,
+                          int key_words, int count_bytes, int root, uint64_t *d_out_keys, void *d_out_counts, int64_t cap,
+                          int64_t *out_n);
+
 /* ---- the record operators on sets that STAY in HBM (the multi-GPU extend stage: reflexiv_amd/dist.py puts the RCCL
  * all-to-all of whole records between them).  Same operators, same reference classes as the host
  * entry points above; here every pointer inside rfx_records, every part_start and the k-mer / count arrays are DEVICE

@@ -69,4 +69,13 @@ public final class Rfx {
     public static native byte[] contigsText(long ctx, RfxRecords in, int k, int minContig, int twin);
 
     public static native byte[] assembleReads(long ctx, byte[] bases, long[] readOff, int[] params);
+
+    // several GPUs of one node: the shuffle of reduceByKey as an RCCL all-to-all inside the library (rfx_comm_*,
+    // rfx_sharded_assemble_reads); one barrier task per GPU, see ReflexivGpuMain.assemblyResidentSharded()
+    public static native byte[] commUniqueId();
+    public static native long commInit(long ctx, byte[] uniqueId, int rank, int world);
+    public static native void commDestroy(long comm);
+    public static native void commAllReduce(long ctx, long comm, long[] vals, int op);
+    public static native byte[] shardedAssembleReads(long ctx, long comm, byte[] bases, long[] readOff, int[] params, int generations,
+                                                     long[] totals);
 }

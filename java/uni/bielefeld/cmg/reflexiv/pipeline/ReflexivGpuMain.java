@@ -129,8 +129,7 @@ public class ReflexivGpuMain implements Serializable {
 
     /**
      * Resident form: the whole path in one native call per GPU (rfx_assemble_reads).  The reads of the job are
-     * collected to the driver's GPU; for read sets beyond one GPU the k-mer space is sharded over the node's GPUs
-     * by the library's own exchange (reflexiv_amd/dist.py drives it today; the C++ mirror is reflexiv_host run --resident).
+     * collected to the driver's GPU; for read sets beyond one GPU see {@link #assemblyResidentSharded(int)}.
      */
     public void assemblyResident() {
         JavaSparkContext sc = new JavaSparkContext(setSparkConfiguration());
@@ -155,6 +154,75 @@ public class ReflexivGpuMain implements Serializable {
         one.add(s.endsWith("\n") ? s.substring(0, s.length() - 1) : s);
         sc.parallelize(one, 1).saveAsTextFile(param.outputPath);
         sc.stop();
+    }
+
+    /**
+     * Resident form on the nGpus GPUs of one node: a Spark BARRIER stage of nGpus tasks, task r on GPU r.  Every task packs
+     * ITS partition of the reads and calls rfx_sharded_assemble_reads: the k-mer space is radix-sharded over the GPUs by
+     * the owner of each k-mer's minimiser, super-k-mer records cross an RCCL all-to-all inside the library (the shuffle of
+     * reduceByKey, ReflexivMain.java:155), every GPU counts and filters its shard, the shards are gathered on task 0 and
+     * extended there.  Task 0 makes the RCCL id; BarrierTaskContext.allGather hands it round.
+     */
+    public void assemblyResidentSharded(final int nGpus) {
+        JavaSparkContext sc = new JavaSparkContext(setSparkConfiguration());
+        JavaRDD<String> FastqRDD = sc.textFile(param.inputFqPath).map(new FastqFilterWithQual()).filter(new FastqUnitFilter())
+                .repartition(nGpus);
+        final int[] prm = Rfx.defaultParams();
+        prm[Rfx.P_K] = param.kmerSize; prm[Rfx.P_MIN_COV] = param.minKmerCoverage; prm[Rfx.P_MAX_COV] = param.maxKmerCoverage;
+        prm[Rfx.P_MIN_ERROR_COV] = param.minErrorCoverage; prm[Rfx.P_MIN_CONTIG] = param.minContig;
+        prm[Rfx.P_MIN_ITER] = param.minimumIteration; prm[Rfx.P_MAX_ITER] = param.maximumIteration;
+        prm[Rfx.P_FRONT_CLIP] = param.frontClip; prm[Rfx.P_END_CLIP] = param.endClip;
+        prm[Rfx.P_PARTITIONS] = param.partitions > 0 ? param.partitions : 8; prm[Rfx.P_TWIN] = twin;
+        // (JavaRDD has no barrier(): the barrier stage is built on the underlying RDD)
+        scala.reflect.ClassTag<String> tag = scala.reflect.ClassTag$.MODULE$.apply(String.class);
+        JavaRDD<String> ContigRDD = JavaRDD.fromRDD(
+                FastqRDD.rdd().barrier().mapPartitions(new ShardedResident(prm, nGpus), false, tag), tag);
+        ContigRDD.filter(new NonEmpty()).coalesce(1).saveAsTextFile(param.outputPath);
+        sc.stop();
+    }
+
+    static class NonEmpty implements Function<String, Boolean>, Serializable {
+        public Boolean call(String s) { return s != null && !s.isEmpty(); }
+    }
+
+    static class ShardedResident extends scala.runtime.AbstractFunction1<scala.collection.Iterator<String>, scala.collection.Iterator<String>>
+            implements Serializable {
+        private final int[] prm;
+        private final int nGpus;
+        ShardedResident(int[] prm, int nGpus) { this.prm = prm; this.nGpus = nGpus; }
+
+        public scala.collection.Iterator<String> apply(scala.collection.Iterator<String> it) {
+            return scala.collection.JavaConverters.asScalaIteratorConverter(call(scala.collection.JavaConverters.asJavaIteratorConverter(it).asJava())).asScala();
+        }
+
+        public Iterator<String> call(Iterator<String> units) {
+            org.apache.spark.BarrierTaskContext tc = org.apache.spark.BarrierTaskContext.get();
+            final int rank = tc.partitionId();
+            ByteArrayOutputStream bases = new ByteArrayOutputStream();
+            List<Long> off = new ArrayList<Long>();
+            off.add(0L);
+            while (units.hasNext()) {
+                byte[] seq = units.next().split("\\n")[1].getBytes(StandardCharsets.US_ASCII);
+                bases.write(seq, 0, seq.length);
+                off.add((long) bases.size());
+            }
+            long[] readOff = new long[off.size()];
+            for (int i = 0; i < readOff.length; i++) readOff[i] = off.get(i);
+            final long ctx = Rfx.ctxCreate(rank % nGpus);
+            String mine = rank == 0 ? java.util.Base64.getEncoder().encodeToString(Rfx.commUniqueId()) : "";
+            String[] all = tc.allGather(mine);                                   // the 128-byte RCCL id from task 0
+            final long comm = Rfx.commInit(ctx, java.util.Base64.getDecoder().decode(all[0]), rank, nGpus);
+            List<String> out = new ArrayList<String>();
+            try {
+                byte[] text = Rfx.shardedAssembleReads(ctx, comm, bases.toByteArray(), readOff, prm, 4, new long[3]);
+                String s = new String(text, StandardCharsets.US_ASCII);
+                out.add(s.endsWith("\n") ? s.substring(0, s.length() - 1) : s);
+            } finally {
+                Rfx.commDestroy(comm);
+                Rfx.ctxDestroy(ctx);
+            }
+            return out.iterator();
+        }
     }
 
     // --------------------------------------------------------------------------------------- operators

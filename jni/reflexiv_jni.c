@@ -410,3 +410,82 @@ JNIEXPORT jbyteArray JNICALL RFX_CLASS(assembleReads)(JNIEnv *env, jclass c, jlo
         return out;
     }
 }
+
+
+/* ---------------------------------------------------------------------------- several GPUs of one node */
+
+/* the shuffle of reduceByKey (P/ReflexivMain.java:155) as an RCCL all-to-all inside the library: one executor task per
+ * GPU (Spark barrier stage), each with its context and one communicator.  commUniqueId: task 0 makes the 128-byte id and
+ * hands it round (BarrierTaskContext.allGather); commInit: collective. */
+JNIEXPORT jbyteArray JNICALL RFX_CLASS(commUniqueId)(JNIEnv *env, jclass c) {
+    (void)c;
+    uint8_t id[128];
+    const int st = rfx_comm_unique_id(id);
+    if (st != RFX_OK) { throw_rfx(env, NULL, st, "rfx_comm_unique_id"); return NULL; }
+    jbyteArray out = (*env)->NewByteArray(env, 128);
+    if (out) (*env)->SetByteArrayRegion(env, out, 0, 128, (const jbyte *)id);
+    return out;
+}
+
+JNIEXPORT jlong JNICALL RFX_CLASS(commInit)(JNIEnv *env, jclass c, jlong h, jbyteArray id, jint rank, jint world) {
+    (void)c;
+    rfx_ctx *ctx = ctx_of(h);
+    uint8_t buf[128];
+    if ((*env)->GetArrayLength(env, id) != 128) { throw_rfx(env, ctx, RFX_E_ARG, "rfx_comm_init (id: 128 bytes)"); return 0; }
+    (*env)->GetByteArrayRegion(env, id, 0, 128, (jbyte *)buf);
+    rfx_comm *comm = NULL;
+    const int st = rfx_comm_init(ctx, buf, rank, world, &comm);
+    if (st != RFX_OK) { throw_rfx(env, ctx, st, "rfx_comm_init"); return 0; }
+    return (jlong)(intptr_t)comm;
+}
+
+JNIEXPORT void JNICALL RFX_CLASS(commDestroy)(JNIEnv *env, jclass c, jlong comm) {
+    (void)env; (void)c;
+    rfx_comm_destroy((rfx_comm *)(intptr_t)comm);
+}
+
+/* count() of the stop rule / a barrier over the tasks: sum (op 0) or max (op 1) of up to 8 longs, in place */
+JNIEXPORT void JNICALL RFX_CLASS(commAllReduce)(JNIEnv *env, jclass c, jlong h, jlong comm, jlongArray vals, jint op) {
+    (void)c;
+    rfx_ctx *ctx = ctx_of(h);
+    const jsize n = (*env)->GetArrayLength(env, vals);
+    int64_t v[8];
+    if (n < 1 || n > 8) { throw_rfx(env, ctx, RFX_E_ARG, "rfx_comm_all_reduce_i64 (1..8 values)"); return; }
+    (*env)->GetLongArrayRegion(env, vals, 0, n, (jlong *)v);
+    const int st = rfx_comm_all_reduce_i64((rfx_comm *)(intptr_t)comm, v, (int)n, op);
+    if (st != RFX_OK) { throw_rfx(env, ctx, st, "rfx_comm_all_reduce_i64"); return; }
+    (*env)->SetLongArrayRegion(env, vals, 0, n, (const jlong *)v);
+}
+
+/* The whole path on several GPUs (P/ReflexivMain.java:95-322 with the shuffle of :155 over RCCL): every task passes ITS
+ * partition's reads; the contig text comes back on rank 0 (an empty array on the others).  params: int[13]; k = 21..31.
+ * totals (long[3], optional): k-mer instances, distinct k-mers, k-mers kept -- over all tasks. */
+JNIEXPORT jbyteArray JNICALL RFX_CLASS(shardedAssembleReads)(JNIEnv *env, jclass c, jlong h, jlong comm, jbyteArray bases, jlongArray readOff,
+                                                            jintArray params, jint generations, jlongArray totals) {
+    (void)c;
+    rfx_ctx *ctx = ctx_of(h);
+    if ((*env)->GetArrayLength(env, params) != RFX_N_PARAMS) { throw_rfx(env, ctx, RFX_E_ARG, "rfx_sharded_assemble_reads (params: Rfx.defaultParams())"); return NULL; }
+    rfx_params prm;
+    (*env)->GetIntArrayRegion(env, params, 0, RFX_N_PARAMS, (jint *)&prm);
+    const jsize nOff = (*env)->GetArrayLength(env, readOff);
+    /* the text lands on rank 0 only and holds every task's contigs: size it from the job's instances after a first try */
+    int64_t cap = (int64_t)(*env)->GetArrayLength(env, bases) * 3 + (1 << 20);
+    for (;;) {
+        char *buf = (char *)malloc((size_t)cap);
+        if (!buf) { throw_rfx(env, ctx, RFX_E_HIP, "rfx_sharded_assemble_reads (out of host memory)"); return NULL; }
+        jbyte *b = (jbyte *)(*env)->GetPrimitiveArrayCritical(env, bases, NULL);
+        jlong *o = (jlong *)(*env)->GetPrimitiveArrayCritical(env, readOff, NULL);
+        int64_t len = 0, nc = 0, ntr = 0, tot[3] = {0, 0, 0};
+        const int st = rfx_sharded_assemble_reads(ctx, (rfx_comm *)(intptr_t)comm, (const uint8_t *)b, (const int64_t *)o, nOff - 1, &prm,
+                                                  generations, buf, cap, &len, &nc, NULL, 0, &ntr, tot);
+        (*env)->ReleasePrimitiveArrayCritical(env, readOff, o, JNI_ABORT);
+        (*env)->ReleasePrimitiveArrayCritical(env, bases, b, JNI_ABORT);
+        if (st == RFX_E_CAP && len > cap) { cap = len; free(buf); continue; }      /* (collective: every task repeats the call) */
+        if (st != RFX_OK) { free(buf); throw_rfx(env, ctx, st, "rfx_sharded_assemble_reads"); return NULL; }
+        if (totals && (*env)->GetArrayLength(env, totals) >= 3) (*env)->SetLongArrayRegion(env, totals, 0, 3, (const jlong *)tot);
+        jbyteArray out = (*env)->NewByteArray(env, (jsize)len);
+        if (out) (*env)->SetByteArrayRegion(env, out, 0, (jsize)len, (const jbyte *)buf);
+        free(buf);
+        return out;
+    }
+}

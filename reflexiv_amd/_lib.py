@@ -57,6 +57,8 @@ SYMBOLS = [
     "rfx_dev_bucket_wide_records_by_owner", "rfx_dev_count_wide_records",
     "rfx_extras_operator", "rfx_assemble_counts_w", "rfx_dev_rc_expand_subkmer", "rfx_dev_sort_records", "rfx_dev_fork_filter",
     "rfx_dev_reflect_from_forward", "rfx_dev_random_reflection", "rfx_dev_extend_pass", "rfx_dev_lower_bound", "rfx_extend_pass_w", "rfx_dev_counter_to_asm", "rfx_dev_assemble_w", "rfx_dev_order_kmers_w",
+    "rfx_comm_unique_id", "rfx_comm_init", "rfx_comm_destroy", "rfx_comm_rank", "rfx_comm_world", "rfx_comm_last_bytes_bucketed",
+    "rfx_comm_all_reduce_i64", "rfx_dev_sharded_count", "rfx_dev_gather_shards", "rfx_sharded_assemble_reads",
 ]
 
 
@@ -96,6 +98,13 @@ def lib():
             fn = getattr(L, name)
             if name == "rfx_kmers_per_read_w":
                 fn.restype = C.c_int64
+                continue
+            if name == "rfx_comm_last_bytes_bucketed":
+                fn.restype = C.c_int64
+                continue
+            if name == "rfx_comm_destroy":
+                fn.restype = None
+                fn.argtypes = [C.c_void_p]
                 continue
             if name not in ("rfx_ctx_stream", "rfx_last_error", "rfx_kmers_per_read",
                             "rfx_count_workspace_bytes", "rfx_ctx_destroy", "rfx_default_params"):

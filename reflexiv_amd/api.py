@@ -105,6 +105,8 @@ class Reflexiv:
         self.ctx = ctx
 
     def close(self):
+        if getattr(self, "comm", None) and getattr(self, "ctx", None):
+            self.comm_destroy()
         if getattr(self, "ctx", None):
             self.L.rfx_ctx_destroy(self.ctx)
             self.ctx = None
@@ -542,6 +544,89 @@ class Reflexiv:
         self._check(self.L.rfx_dev_sort_pairs(self.ctx, C.c_void_p(d_keys), C.c_void_p(d_vals), C.c_int64(n),
                                               key_bits, C.c_void_p(d_tmp_keys), C.c_void_p(d_tmp_vals)),
                     "rfx_dev_sort_pairs")
+
+    # ------------------------------------------------ several GPUs: the RCCL exchange behind the C ABI
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """rank 0: the 128-byte RCCL id every rank passes to comm_init (hand it round with whatever the host has)"""
+        buf = (C.c_uint8 * 128)()
+        st = _lib.lib().rfx_comm_unique_id(buf)
+        if st != RFX_OK:
+            raise RfxError(st, "rfx_comm_unique_id", "RCCL is not available")
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        """collective: -> this rank's communicator handle (kept by the object; comm_destroy / close free it)"""
+        assert len(unique_id) == 128
+        h = C.c_void_p(0)
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self.L.rfx_comm_init(self.ctx, buf, rank, world, C.byref(h)), "rfx_comm_init")
+        self.comm = h
+        self.comm_rank, self.comm_world = rank, world
+        return h
+
+    def comm_destroy(self):
+        if getattr(self, "comm", None):
+            self.L.rfx_comm_destroy(self.comm)
+            self.comm = None
+
+    def comm_all_reduce(self, vals, op: str = "sum"):
+        a = (C.c_int64 * len(vals))(*[int(v) for v in vals])
+        self._check(self.L.rfx_comm_all_reduce_i64(self.comm, a, len(vals), 0 if op == "sum" else 1), "rfx_comm_all_reduce_i64")
+        return [int(x) for x in a]
+
+    def sharded_count_dev(self, d_words: int, n_reads: int, words_per_read: int, read_len: int, k: int, d_out_keys: int,
+                          d_out_counts: int, cap: int, min_cov=2, max_cov=10_000_000, twin=TWIN_DS, generations=4,
+                          front_clip=0, end_clip=0, d_read_len: int = 0):
+        """collective (rfx_dev_sharded_count): this rank's reads -> its ascending shard; -> (m, [instances, distinct,
+        survivors] over all ranks).  RfxError(RFX_E_CAP) carries the needed capacity in .need."""
+        n = C.c_int64(0)
+        tot = (C.c_int64 * 3)()
+        st = self.L.rfx_dev_sharded_count(self.ctx, self.comm, C.c_void_p(d_words), C.c_void_p(d_read_len), C.c_int64(n_reads), words_per_read,
+                                          read_len, k, front_clip, end_clip, generations, min_cov, max_cov, twin,
+                                          C.c_void_p(d_out_keys), C.c_void_p(d_out_counts), C.c_int64(cap), C.byref(n), tot)
+        if st == RFX_E_CAP:
+            e = RfxError(st, "rfx_dev_sharded_count", f"needs room for {n.value} survivors, cap is {cap}")
+            e.need = int(n.value)
+            raise e
+        self._check(st, "rfx_dev_sharded_count")
+        return int(n.value), [int(x) for x in tot]
+
+    def sharded_assemble_reads(self, bases, read_off, prm: Params, generations: int = 4):
+        """collective (rfx_sharded_assemble_reads): this rank's ASCII reads -> (text, n_contigs, trace, totals); text on rank 0"""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        read_off = np.ascontiguousarray(read_off, np.int64)
+        n_reads = len(read_off) - 1
+        trace = np.zeros(prm.max_iter + 8, np.int64)
+        tot = (C.c_int64 * 3)()
+        cap = 3 * len(bases) + (1 << 20)
+        while True:
+            buf = np.empty(cap, np.uint8)
+            ln, nc, ntr = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+            st = self.L.rfx_sharded_assemble_reads(self.ctx, self.comm, _p(bases), _p(read_off), C.c_int64(n_reads), C.byref(prm),
+                                                   generations, _p(buf), C.c_int64(cap), C.byref(ln), C.byref(nc), _p(trace),
+                                                   C.c_int64(len(trace)), C.byref(ntr), tot)
+            if st == RFX_E_CAP and ln.value > cap:
+                cap = int(ln.value)
+                continue
+            self._check(st, "rfx_sharded_assemble_reads")
+            return (bytes(buf[:ln.value]).decode(), int(nc.value), [int(x) for x in trace[:ntr.value]], [int(x) for x in tot])
+
+    def comm_bytes_bucketed(self) -> int:
+        return int(self.L.rfx_comm_last_bytes_bucketed(self.comm))
+
+    def gather_shards_dev(self, d_keys: int, d_counts: int, n: int, key_words: int, count_bytes: int, root: int,
+                          d_out_keys: int, d_out_counts: int, cap: int) -> int:
+        m = C.c_int64(0)
+        st = self.L.rfx_dev_gather_shards(self.ctx, self.comm, C.c_void_p(d_keys), C.c_void_p(d_counts), C.c_int64(n), key_words,
+                                          count_bytes, root, C.c_void_p(d_out_keys), C.c_void_p(d_out_counts), C.c_int64(cap),
+                                          C.byref(m))
+        if st == RFX_E_CAP:
+            e = RfxError(st, "rfx_dev_gather_shards", f"needs room for {m.value} entries, cap is {cap}")
+            e.need = int(m.value)
+            raise e
+        self._check(st, "rfx_dev_gather_shards")
+        return int(m.value)
 
     def count_timing(self):
         """Per-kernel-family HIP-event timing of the last count call: {name: (ms, launches)}; the "stat_*" entries carry

@@ -1,4 +1,5 @@
 // ReflexivMain.cpp -- see ReflexivMain.h.  Every call() forwards to one C-ABI entry point.
+#include <thread>
 #include "ReflexivMain.h"
 
 #include <algorithm>
@@ -297,6 +298,55 @@ std::string ReflexivMain::assemblyResident(const std::string &fastqText, std::ve
     out.resize((size_t)len);
     if (trace) trace->assign(tr.begin(), tr.begin() + nt);
     return out;
+}
+
+std::string ReflexivMain::assemblyResidentSharded(const std::string &fastqText, int nGpus, std::vector<int64_t> *trace) {
+    if (!param.bubble)
+        throw std::runtime_error("-bubble (no fork filtering) is unusable in the reference too (SURVEY.md C.6)");
+    std::vector<uint8_t> bases; std::vector<int64_t> readOff;
+    FastqFilterWithQual{*this}.call(fastqText, bases, readOff);
+    rfx_params prm;
+    rfx_default_params(&prm);
+    prm.k = param.kmerSize; prm.min_cov = param.minKmerCoverage; prm.max_cov = param.maxKmerCoverage;
+    prm.min_error_cov = param.minErrorCoverage; prm.min_contig = param.minContig;
+    prm.min_iter = param.minimumIteration; prm.max_iter = param.maximumIteration;
+    prm.front_clip = param.frontClip; prm.end_clip = param.endClip;
+    prm.partitions = std::max(1, param.logicalPartitions); prm.twin = param.twin;
+    const int64_t nr = (int64_t)readOff.size() - 1;
+    uint8_t id[128];
+    check(rfx_comm_unique_id(id), "rfx_comm_unique_id");
+    std::vector<std::string> outs((size_t)nGpus), errs((size_t)nGpus);
+    std::vector<int64_t> tr((size_t)param.maximumIteration + 8);
+    int64_t nt = 0;
+    std::vector<std::thread> th;
+    for (int r = 0; r < nGpus; r++)
+        th.emplace_back([&, r] {
+            rfx_ctx *c = nullptr; rfx_comm *comm = nullptr;
+            try {
+                if (rfx_ctx_create(r, &c) != RFX_OK) throw std::runtime_error("rfx_ctx_create(" + std::to_string(r) + ")");
+                if (rfx_comm_init(c, id, r, nGpus, &comm) != RFX_OK) throw std::runtime_error(std::string("rfx_comm_init: ") + rfx_last_error(c));
+                const int64_t a = nr * r / nGpus, b = nr * (r + 1) / nGpus;            // contiguous shares of the reads
+                std::string out(r == 0 ? (size_t)3 * (size_t)(readOff[nr] - readOff[0]) + ((size_t)1 << 20) : (size_t)1 << 12, '\0');
+                int64_t len = 0, nc = 0, n_tr = 0, tot[3];
+                for (;;) {
+                    const int st = rfx_sharded_assemble_reads(c, comm, bases.data(), readOff.data() + a, b - a, &prm, 4, out.data(),
+                                                              (int64_t)out.size(), &len, &nc, r == 0 ? tr.data() : nullptr,
+                                                              r == 0 ? (int64_t)tr.size() : 0, &n_tr, tot);
+                    if (st == RFX_E_CAP && len > (int64_t)out.size()) { out.assign((size_t)len, '\0'); continue; }   // (rank 0 only: after the collectives)
+                    if (st != RFX_OK) throw std::runtime_error(std::string("rfx_sharded_assemble_reads: ") + rfx_last_error(c));
+                    break;
+                }
+                out.resize((size_t)len);
+                outs[(size_t)r] = out;
+                if (r == 0) nt = n_tr;
+            } catch (const std::exception &e) { errs[(size_t)r] = e.what(); }
+            if (comm) rfx_comm_destroy(comm);
+            if (c) rfx_ctx_destroy(c);
+        });
+    for (auto &t : th) t.join();
+    for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
+    if (trace) trace->assign(tr.begin(), tr.begin() + nt);
+    return outs[0];
 }
 
 // KmerBinarizer.call  P/ReflexivDSMain.java:3883-3931: "KMER,count" or "(KMER,count)"; a count of

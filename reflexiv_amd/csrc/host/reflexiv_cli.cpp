@@ -67,6 +67,7 @@ int main(int argc, char **argv) {
                 mkdir(dir.c_str(), 0755);
             } else
             out = !param.inputKmerPath.empty() ? m.assemblyFromKmer(read_all(param.inputKmerPath))
+                  : param.resident && (param.gpus > 1 || getenv("RFX_HOST_FORCE_SHARDED")) ? m.assemblyResidentSharded(read_all(param.inputFqPath), param.gpus)
                   : param.resident          ? m.assemblyResident(read_all(param.inputFqPath))
                                             : m.assembly(read_all(param.inputFqPath));
         } else if (cmd == "counter") {

@@ -1,0 +1,486 @@
+// rfx_comm.hip -- the Spark shuffle of the count stage on several GPUs, behind the C ABI.
+//
+// `reduceByKey` (P/ReflexivMain.java:155, with its map-side combine) / `groupBy("value").count()`
+// (P/ReflexivDSMain.java:207-209) repartition the k-mer instances by key hash over the executors.  Here the k-mer space
+// is radix-sharded over the GPUs of one node by the owner of each k-mer's minimiser and the shuffle is an
+// all-to-all(v) over RCCL (xGMI): one process (or thread) per GPU, one rfx_ctx + one rfx_comm each.
+//
+//   rfx_dev_sharded_count:  reads in HBM -> super-k-mer records bucketed ONCE by (generation, owner) -- bin g*world + o
+//   of an owner function over G*world bins -- one ncclAllGather agrees every count, the G exchanges are queued back to
+//   back on the communicator's own stream (ncclGroupStart { ncclSend / ncclRecv per peer } ncclGroupEnd, never more
+//   than 512 MiB per peer and call; the rank's own bucket moves by a device copy), and generation g is counted on the
+//   context's stream while g+1.. are still travelling.  A k-mer lives in exactly one generation, so the G counts are
+//   independent; their ascending outputs are merged by one sort of the survivors.  Scalars by ncclAllReduce.
+//
+// RCCL is bound at run time (dlopen): a host that already carries an RCCL (a PyTorch process does) keeps using that
+// one, a plain C / JNI host gets /opt/rocm/lib/librccl.so.1 -- and the library stays loadable where RCCL is absent.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <algorithm>
+#include <mutex>
+#include "rfx_internal.h"
+
+namespace {
+
+struct NcclApi {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Gather_unused)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+NcclApi &nccl() {
+    static NcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so"};
+        for (const char *n : names)
+            if (!api.h) api.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);          // the host process's own RCCL first
+        const char *paths[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+        for (const char *p : paths)
+            if (!api.h) api.h = dlopen(p, RTLD_NOW | RTLD_LOCAL);
+        if (!api.h) { api.error = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "?"); return; }
+        auto sym = [&](const char *s) { void *p = dlsym(api.h, s); if (!p) api.error = std::string("RCCL lacks ") + s; return p; };
+        api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+        api.Send = (decltype(api.Send))sym("ncclSend");
+        api.Recv = (decltype(api.Recv))sym("ncclRecv");
+        api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+        api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    });
+    return api;
+}
+
+}  // namespace
+
+struct rfx_comm {
+    rfx_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    hipStream_t xs = nullptr;                     // the exchange runs on its own stream
+    std::vector<hipEvent_t> ev;                   // one per generation: "generation g has landed"
+    hipEvent_t ev_ready = nullptr;                // "the send buffer is complete" (context stream -> exchange stream)
+    // grow-only device buffers: what this rank sends, what it receives (all generations back to back), small tables
+    void *send = nullptr, *recv = nullptr;
+    size_t send_bytes = 0, recv_bytes = 0;
+    int64_t *d_tab = nullptr;                     // [2 * 64 * world] counts, then 8 scalars
+    int64_t *h_tab = nullptr;                     // pinned mirror
+    size_t tab_n = 0;
+    double units_per_read = 0;                    // capacity planning across calls (only ever grows)
+    int64_t bytes_bucketed = 0;                   // of the last call
+    size_t limit_bytes = (size_t)1 << 29;         // per peer and call (RCCL 2.26 corrupts messages above 1 GiB)
+    bool self_via_rccl = false;                   // tests: send the rank's own bucket through ncclSend / ncclRecv too
+};
+
+#define RFX_NCCL(call)                                                                                     \
+    do {                                                                                                   \
+        ncclResult_t r_ = (call);                                                                          \
+        if (r_ != ncclSuccess) {                                                                           \
+            char buf_[512];                                                                                \
+            snprintf(buf_, sizeof buf_, "%s:%d: %s -> %s", __FILE__, __LINE__, #call,                      \
+                     nccl().GetErrorString ? nccl().GetErrorString(r_) : "RCCL error");                    \
+            if (ctx) ctx->last_error = buf_;                                                               \
+            return RFX_E_HIP;                                                                              \
+        }                                                                                                  \
+    } while (0)
+
+static int grow(rfx_ctx *ctx, void **p, size_t *have, size_t want, hipStream_t s1, hipStream_t s2) {
+    if (*p && *have >= want) return RFX_OK;
+    if (*p) { RFX_HIP(hipStreamSynchronize(s1)); RFX_HIP(hipStreamSynchronize(s2)); RFX_HIP(hipFree(*p)); *p = nullptr; *have = 0; }
+    const size_t bytes = want + (want >> 4) + (1 << 20);
+    RFX_HIP(hipMalloc(p, bytes));
+    *have = bytes;
+    return RFX_OK;
+}
+
+extern "C" {
+
+int rfx_comm_unique_id(uint8_t *id128) {
+    if (!id128) return RFX_E_ARG;
+    NcclApi &n = nccl();
+    if (!n.error.empty() || !n.GetUniqueId) return RFX_E_NOGPU;
+    ncclUniqueId id;
+    if (n.GetUniqueId(&id) != ncclSuccess) return RFX_E_HIP;
+    static_assert(sizeof id == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, 128);
+    return RFX_OK;
+}
+
+int rfx_comm_init(rfx_ctx *ctx, const uint8_t *id128, int rank, int world, rfx_comm **out) {
+    if (!ctx || !id128 || !out || world < 1 || world > 64 || rank < 0 || rank >= world) return RFX_E_ARG;
+    NcclApi &n = nccl();
+    if (!n.error.empty()) { ctx->last_error = n.error; return RFX_E_NOGPU; }
+    RFX_HIP(hipSetDevice(ctx->device));
+    rfx_comm *c = new rfx_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world;
+    if (const char *e = getenv("RFX_COMM_LIMIT_BYTES")) c->limit_bytes = std::max<size_t>(1024, (size_t)atoll(e));
+    c->self_via_rccl = getenv("RFX_COMM_SELF_VIA_RCCL") && atoi(getenv("RFX_COMM_SELF_VIA_RCCL")) != 0;
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclResult_t r = n.CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        ctx->last_error = std::string("ncclCommInitRank -> ") + (n.GetErrorString ? n.GetErrorString(r) : "error");
+        delete c;
+        return RFX_E_HIP;
+    }
+    hipError_t e = hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
+    c->tab_n = (size_t)2 * 64 * world + 16;
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_tab, c->tab_n * 8);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_tab, c->tab_n * 8, hipHostMallocDefault);
+    if (e != hipSuccess) { ctx->last_error = std::string("rfx_comm_init: ") + hipGetErrorString(e); rfx_comm_destroy(c); return RFX_E_HIP; }
+    *out = c;
+    return RFX_OK;
+}
+
+void rfx_comm_destroy(rfx_comm *c) {
+    if (!c) return;
+    if (c->xs) (void)hipStreamSynchronize(c->xs);
+    if (c->comm && nccl().CommDestroy) (void)nccl().CommDestroy(c->comm);
+    for (auto e : c->ev) (void)hipEventDestroy(e);
+    if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+    if (c->send) (void)hipFree(c->send);
+    if (c->recv) (void)hipFree(c->recv);
+    if (c->d_tab) (void)hipFree(c->d_tab);
+    if (c->h_tab) (void)hipHostFree(c->h_tab);
+    if (c->xs) (void)hipStreamDestroy(c->xs);
+    delete c;
+}
+
+int rfx_comm_rank(const rfx_comm *c) { return c ? c->rank : -1; }
+int rfx_comm_world(const rfx_comm *c) { return c ? c->world : 0; }
+int64_t rfx_comm_last_bytes_bucketed(const rfx_comm *c) { return c ? c->bytes_bucketed : 0; }
+
+// sum (op 0) or max (op 1) of n <= 8 host int64 over the ranks, in place (the stop rule's count(), totals, barriers)
+int rfx_comm_all_reduce_i64(rfx_comm *c, int64_t *h_vals, int n, int op) {
+    if (!c || !h_vals || n < 1 || n > 8 || (op != 0 && op != 1)) return RFX_E_ARG;
+    rfx_ctx *ctx = c->ctx;
+    RFX_HIP(hipSetDevice(ctx->device));
+    int64_t *d = c->d_tab + c->tab_n - 16, *h = c->h_tab + c->tab_n - 16;
+    for (int i = 0; i < n; i++) h[i] = h_vals[i];
+    RFX_HIP(hipMemcpyAsync(d, h, (size_t)n * 8, hipMemcpyHostToDevice, c->xs));
+    RFX_NCCL(nccl().AllReduce(d, d + 8, (size_t)n, ncclInt64, op == 0 ? ncclSum : ncclMax, c->comm, c->xs));
+    RFX_HIP(hipMemcpyAsync(h + 8, d + 8, (size_t)n * 8, hipMemcpyDeviceToHost, c->xs));
+    RFX_HIP(hipStreamSynchronize(c->xs));
+    (void)hipGetLastError();
+    for (int i = 0; i < n; i++) h_vals[i] = h[8 + i];
+    return RFX_OK;
+}
+
+// One all-to-all(v) of 8-byte words, queued on the exchange stream: this rank sends send_cnt[p] words from
+// d_send + send_off[p] to peer p and receives recv_cnt[p] words from peer p at d_recv + recv_off[p].
+static int alltoallv_words(rfx_comm *c, const uint64_t *d_send, const int64_t *send_off, const int64_t *send_cnt,
+                           uint64_t *d_recv, const int64_t *recv_off, const int64_t *recv_cnt, int64_t rounds) {
+    rfx_ctx *ctx = c->ctx;
+    NcclApi &n = nccl();
+    const int64_t limit = (int64_t)(c->limit_bytes / 8);
+    const int me = c->rank;
+    if (!c->self_via_rccl && send_cnt[me] > 0)
+        RFX_HIP(hipMemcpyAsync(d_recv + recv_off[me], d_send + send_off[me], (size_t)send_cnt[me] * 8, hipMemcpyDeviceToDevice, c->xs));
+    for (int64_t j = 0; j < rounds; j++) {
+        bool any = false;
+        for (int p = 0; p < c->world && !any; p++)
+            if ((p != me || c->self_via_rccl) && (send_cnt[p] > j * limit || recv_cnt[p] > j * limit)) any = true;
+        if (!any) continue;               // (every rank skips the same rounds only when nobody has data left in them: `rounds` is global)
+        RFX_NCCL(n.GroupStart());
+        for (int p = 0; p < c->world; p++) {
+            if (p == me && !c->self_via_rccl) continue;
+            const int64_t s = std::max<int64_t>(0, std::min(limit, send_cnt[p] - j * limit));
+            const int64_t r = std::max<int64_t>(0, std::min(limit, recv_cnt[p] - j * limit));
+            if (s > 0) RFX_NCCL(n.Send(d_send + send_off[p] + j * limit, (size_t)s, ncclUint64, p, c->comm, c->xs));
+            if (r > 0) RFX_NCCL(n.Recv(d_recv + recv_off[p] + j * limit, (size_t)r, ncclUint64, p, c->comm, c->xs));
+        }
+        RFX_NCCL(n.GroupEnd());
+    }
+    return RFX_OK;
+}
+
+static void add_timing(std::map<std::string, rfx_timing_slot> &acc, const std::map<std::string, rfx_timing_slot> &t) {
+    for (auto &kv : t) { acc[kv.first].ms += kv.second.ms; acc[kv.first].launches += kv.second.launches; }
+}
+
+int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, const uint32_t *d_read_len, int64_t n_reads,
+                          int words_per_read, int read_len, int k, int front_clip, int end_clip, int generations, int min_cov,
+                          int max_cov, int twin, uint64_t *d_out_keys, void *d_out_counts, int64_t cap, int64_t *out_n,
+                          int64_t *out_totals) {
+    if (!ctx || !c || c->ctx != ctx || !d_words || n_reads < 0 || cap < 0 || generations < 1 || words_per_read * 32 < read_len)
+        return RFX_E_ARG;
+    const bool wide = k > 32;
+    if (wide && d_read_len) { ctx->last_error = "ragged reads: k <= 31 only on the device path"; return RFX_E_ARG; }
+    if (wide ? (k > 63) : (k < 21 || k > 31)) {
+        ctx->last_error = "rfx_dev_sharded_count exchanges super-k-mer records: k = 21..31 or 33..63";
+        return RFX_E_ARG;
+    }
+    const int world = c->world, me = c->rank;
+    int G = generations;
+    while (G > 1 && G * world > 64) G /= 2;
+    const int bins = G * world;
+    const int uw = wide ? 4 : 2;                                  // 8-byte words per record
+    RFX_HIP(hipSetDevice(ctx->device));
+    NcclApi &n = nccl();
+    std::map<std::string, rfx_timing_slot> acc;
+    while ((int)c->ev.size() < G) {
+        hipEvent_t e = nullptr;
+        RFX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->ev.push_back(e);
+    }
+
+    // 1. records of this rank's reads, grouped by (generation, owner)
+    const int64_t nk = wide ? rfx::kmers_per_read_w(read_len, k, front_clip, end_clip) : rfx::kmers_per_read(read_len, k, front_clip, end_clip);
+    int64_t inst = nk * n_reads;
+    rfx::ReadStore rs{d_words, n_reads, words_per_read, read_len, k, front_clip, end_clip};
+    if (d_read_len) {
+        rs.read_len_arr = d_read_len;
+        RFX_TRY(rfx::ragged_instances(ctx, d_read_len, n_reads, k, front_clip, end_clip, &rs.n_instances));
+        inst = rs.n_instances;
+    }
+    if (c->units_per_read <= 0) c->units_per_read = (double)nk / 5.0 + 1.0;
+    int64_t h_off[65];
+    int64_t nrec = 0;
+    for (int attempt = 0;; attempt++) {
+        const int64_t cap_rec = (int64_t)(c->units_per_read * (double)n_reads) + 4096;
+        RFX_TRY(grow(ctx, &c->send, &c->send_bytes, (size_t)cap_rec * uw * 8, ctx->stream, c->xs));
+        ctx->timing.clear();
+        int st;
+        if (wide) {
+            st = rfx_dev_bucket_wide_records_by_owner(ctx, d_words, n_reads, words_per_read, read_len, k, front_clip, end_clip, bins,
+                                                      c->send, cap_rec, c->d_tab, h_off, &nrec);
+        } else {
+            st = rfx::bucket_records_by_owner(ctx, &rs, bins, c->send, cap_rec, c->d_tab, h_off, &nrec);
+            ScopedTimer::collect(ctx);
+        }
+        add_timing(acc, ctx->timing);
+        if (st == RFX_OK) break;
+        if (st != RFX_E_CAP || attempt >= 2) return st;
+        c->units_per_read = 1.03 * (double)nrec / (double)std::max<int64_t>(1, n_reads);      // only ever grows
+    }
+    c->bytes_bucketed = nrec * uw * 8;
+
+    // 2. every rank's counts to every rank: row r = what rank r holds for each (generation, owner) bin
+    int64_t *h_mine = c->h_tab, *h_all = c->h_tab + 64;
+    for (int b = 0; b < bins; b++) h_mine[b] = h_off[b + 1] - h_off[b];
+    RFX_HIP(hipMemcpyAsync(c->d_tab, h_mine, (size_t)bins * 8, hipMemcpyHostToDevice, c->xs));
+    RFX_NCCL(n.AllGather(c->d_tab, c->d_tab + 64, (size_t)bins, ncclInt64, c->comm, c->xs));
+    RFX_HIP(hipMemcpyAsync(h_all, c->d_tab + 64, (size_t)bins * world * 8, hipMemcpyDeviceToHost, c->xs));
+    RFX_HIP(hipStreamSynchronize(c->xs));
+    // receive layout: generation after generation, inside a generation source after source
+    std::vector<int64_t> gen_off(G + 1, 0), roff((size_t)G * world), rcnt((size_t)G * world), soff((size_t)G * world), scnt((size_t)G * world);
+    int64_t mx = 0;
+    for (int g = 0; g < G; g++) {
+        int64_t pos = gen_off[g];
+        for (int s = 0; s < world; s++) {
+            const int64_t u = h_all[(size_t)s * bins + (size_t)g * world + me];
+            roff[(size_t)g * world + s] = pos * uw; rcnt[(size_t)g * world + s] = u * uw;
+            pos += u;
+            for (int p = 0; p < world; p++) mx = std::max(mx, h_all[(size_t)s * bins + (size_t)g * world + p] * uw);
+        }
+        gen_off[g + 1] = pos;
+        for (int p = 0; p < world; p++) {
+            soff[(size_t)g * world + p] = h_off[g * world + p] * uw;
+            scnt[(size_t)g * world + p] = (h_off[g * world + p + 1] - h_off[g * world + p]) * uw;
+        }
+    }
+    const int64_t rounds = std::max<int64_t>(1, (mx + (int64_t)(c->limit_bytes / 8) - 1) / (int64_t)(c->limit_bytes / 8));
+    RFX_TRY(grow(ctx, &c->recv, &c->recv_bytes, (size_t)std::max<int64_t>(1, gen_off[G]) * uw * 8, ctx->stream, c->xs));
+
+    // 3. all G exchanges queued back to back on the exchange stream
+    RFX_HIP(hipEventRecord(c->ev_ready, ctx->stream));
+    RFX_HIP(hipStreamWaitEvent(c->xs, c->ev_ready, 0));
+    for (int g = 0; g < G; g++) {
+        RFX_TRY(alltoallv_words(c, (const uint64_t *)c->send, &soff[(size_t)g * world], &scnt[(size_t)g * world], (uint64_t *)c->recv,
+                                &roff[(size_t)g * world], &rcnt[(size_t)g * world], rounds));
+        RFX_HIP(hipEventRecord(c->ev[g], c->xs));
+    }
+
+    // 4. count generation g while the later ones travel
+    int64_t m = 0, distinct = 0;
+    int st_keep = RFX_OK;
+    for (int g = 0; g < G; g++) {
+        RFX_HIP(hipEventSynchronize(c->ev[g]));
+        (void)hipGetLastError();          // (RCCL's own runtime calls may leave a benign sticky error behind: the kernels' launch checks must not see it)
+        const int64_t ng = gen_off[g + 1] - gen_off[g];
+        int64_t mg = 0, dg = 0;
+        const int64_t room = std::max<int64_t>(0, cap - m);
+        const void *src = (const uint64_t *)c->recv + gen_off[g] * uw;
+        ctx->timing.clear();
+        int st;
+        if (wide)
+            st = rfx_dev_count_wide_records(ctx, src, ng, inst / G, k, min_cov, max_cov, d_out_keys + 2 * m,
+                                            (int64_t *)d_out_counts + m, room, &mg, &dg);
+        else
+            st = rfx_dev_count_records(ctx, src, ng, inst / G, k, min_cov, max_cov, twin, d_out_keys + m,
+                                       (int32_t *)d_out_counts + m, room, &mg, &dg);
+        add_timing(acc, ctx->timing);
+        if (st == RFX_E_CAP) { st_keep = RFX_E_CAP; m += mg; distinct += dg; continue; }     // keep draining: report the need
+        if (st != RFX_OK) { (void)hipStreamSynchronize(c->xs); return st; }
+        m += mg; distinct += dg;
+    }
+    RFX_HIP(hipStreamSynchronize(c->xs));
+
+    // 5. the generations' ascending shards -> one ascending shard
+    if (st_keep == RFX_OK && G > 1 && m > 1) {
+        ctx->timing.clear();
+        if (wide) {
+            RFX_TRY(rfx_dev_order_kmers_w(ctx, d_out_keys, (int64_t *)d_out_counts, m, k));
+        } else {
+            DevBuf tk, tv;
+            RFX_HIP(tk.alloc((size_t)m * 8, ctx->stream));
+            RFX_HIP(tv.alloc((size_t)m * 4, ctx->stream));
+            RFX_TRY(rfx_dev_sort_pairs(ctx, d_out_keys, (uint32_t *)d_out_counts, m, 2 * k, tk.as<uint64_t>(), tv.as<uint32_t>()));
+            RFX_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        add_timing(acc, ctx->timing);
+    }
+    ctx->timing = acc;
+    if (out_n) *out_n = m;
+
+    // 6. global totals: instances, distinct, survivors (and whether any rank ran out of room)
+    int64_t tot[4] = {inst, distinct, m, st_keep == RFX_E_CAP ? 1 : 0};
+    RFX_TRY(rfx_comm_all_reduce_i64(c, tot, 4, 0));
+    if (out_totals) { out_totals[0] = tot[0]; out_totals[1] = tot[1]; out_totals[2] = tot[2]; }
+    // a shard that did not fit on ANY rank fails the call on EVERY rank (*out_n = this rank's own need), so that the
+    // callers' retries stay collective
+    return tot[3] > 0 ? RFX_E_CAP : RFX_OK;
+}
+
+// The shards of every rank -> rank `root`, shard after shard in rank order (D' << N: the filtered list of a bacterial
+// genome is a few million k-mers, so the extend stage runs on one GPU).  key_words 8-byte words per
+// key, count_bytes 4 or 8.  On root: *out_n = total entries (RFX_E_CAP if cap is short); elsewhere 0.
+int rfx_dev_gather_shards(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_keys, const void *d_counts, int64_t n, int key_words,
+                          int count_bytes, int root, uint64_t *d_out_keys, void *d_out_counts, int64_t cap, int64_t *out_n) {
+    if (!ctx || !c || c->ctx != ctx || n < 0 || key_words < 1 || (count_bytes != 4 && count_bytes != 8) || root < 0 ||
+        root >= c->world)
+        return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    NcclApi &nc = nccl();
+    const int world = c->world, me = c->rank;
+    c->h_tab[0] = n;
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_HIP(hipMemcpyAsync(c->d_tab, c->h_tab, 8, hipMemcpyHostToDevice, c->xs));
+    RFX_NCCL(nc.AllGather(c->d_tab, c->d_tab + 64, 1, ncclInt64, c->comm, c->xs));
+    RFX_HIP(hipMemcpyAsync(c->h_tab + 64, c->d_tab + 64, (size_t)world * 8, hipMemcpyDeviceToHost, c->xs));
+    RFX_HIP(hipStreamSynchronize(c->xs));
+    std::vector<int64_t> off(world + 1, 0);
+    for (int r = 0; r < world; r++) off[r + 1] = off[r] + c->h_tab[64 + r];
+    if (out_n) *out_n = me == root ? off[world] : 0;
+    int st = RFX_OK;
+    if (me == root && off[world] > cap) st = RFX_E_CAP;
+    // every rank must learn of a short buffer on root before anybody posts a send
+    int64_t flag[1] = {st == RFX_E_CAP ? 1 : 0};
+    RFX_TRY(rfx_comm_all_reduce_i64(c, flag, 1, 1));
+    if (flag[0]) return me == root ? RFX_E_CAP : RFX_OK;
+    const int64_t limit_k = std::max<int64_t>(1, (int64_t)(c->limit_bytes / 8) / key_words) , limit_c = (int64_t)(c->limit_bytes / count_bytes);
+    const int64_t lim = std::min(limit_k, limit_c);
+    int64_t mx = 0;
+    for (int r = 0; r < world; r++) mx = std::max(mx, c->h_tab[64 + r]);
+    const int64_t rounds = std::max<int64_t>(1, (mx + lim - 1) / lim);
+    if (me == root && n > 0) {
+        RFX_HIP(hipMemcpyAsync(d_out_keys + off[me] * key_words, d_keys, (size_t)n * key_words * 8, hipMemcpyDeviceToDevice, c->xs));
+        RFX_HIP(hipMemcpyAsync((char *)d_out_counts + off[me] * count_bytes, d_counts, (size_t)n * count_bytes, hipMemcpyDeviceToDevice, c->xs));
+    }
+    for (int64_t j = 0; j < rounds; j++) {
+        RFX_NCCL(nc.GroupStart());
+        if (me != root) {
+            const int64_t s = std::max<int64_t>(0, std::min(lim, n - j * lim));
+            if (s > 0) {
+                RFX_NCCL(nc.Send(d_keys + j * lim * key_words, (size_t)s * key_words, ncclUint64, root, c->comm, c->xs));
+                RFX_NCCL(nc.Send((const char *)d_counts + j * lim * count_bytes, (size_t)s * count_bytes, ncclUint8, root, c->comm, c->xs));
+            }
+        } else {
+            for (int r = 0; r < world; r++) {
+                if (r == root) continue;
+                const int64_t s = std::max<int64_t>(0, std::min(lim, c->h_tab[64 + r] - j * lim));
+                if (s > 0) {
+                    RFX_NCCL(nc.Recv(d_out_keys + (off[r] + j * lim) * key_words, (size_t)s * key_words, ncclUint64, r, c->comm, c->xs));
+                    RFX_NCCL(nc.Recv((char *)d_out_counts + (off[r] + j * lim) * count_bytes, (size_t)s * count_bytes, ncclUint8, r, c->comm, c->xs));
+                }
+            }
+        }
+        RFX_NCCL(nc.GroupEnd());
+    }
+    RFX_HIP(hipStreamSynchronize(c->xs));
+    return RFX_OK;
+}
+
+// The whole resident path on several GPUs from ASCII reads in host memory: every rank uploads and encodes ITS reads
+// (any lengths), rfx_dev_sharded_count, the shards gathered on rank 0, the driver there (rfx_dev_assemble) -> the
+// contig text on rank 0 (*out_len = 0 elsewhere).  k = 21..31.  Collective.  out_totals[3] as rfx_dev_sharded_count.
+int rfx_sharded_assemble_reads(rfx_ctx *ctx, rfx_comm *c, const uint8_t *bases, const int64_t *read_off, int64_t n_reads,
+                               const rfx_params *prm, int generations, char *out, int64_t cap, int64_t *out_len,
+                               int64_t *out_contigs, int64_t *trace, int64_t trace_cap, int64_t *n_trace, int64_t *out_totals) {
+    if (!ctx || !c || c->ctx != ctx || !read_off || !prm || !out_len || n_reads < 0) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    const int k = prm->k;
+    const int64_t nb = n_reads ? read_off[n_reads] - read_off[0] : 0;
+    int64_t maxlen = 1;
+    for (int64_t r = 0; r < n_reads; r++) maxlen = std::max(maxlen, read_off[r + 1] - read_off[r]);
+    int64_t ml[1] = {maxlen};
+    RFX_TRY(rfx_comm_all_reduce_i64(c, ml, 1, 1));                     // (ranks agree on nothing but their own layout; kept for the plan)
+    const int wpr = (int)((maxlen + 31) / 32);
+    DevBuf d_bases, d_off, d_words, d_len, d_keys, d_counts, g_keys, g_counts;
+    RFX_HIP(d_bases.alloc((size_t)std::max<int64_t>(nb, 1), ctx->stream));
+    RFX_HIP(d_off.alloc((size_t)(n_reads + 1) * 8, ctx->stream));
+    RFX_HIP(d_words.alloc((size_t)std::max<int64_t>(n_reads, 1) * wpr * 8, ctx->stream));
+    RFX_HIP(d_len.alloc((size_t)std::max<int64_t>(n_reads, 1) * 4, ctx->stream));
+    std::vector<int64_t> off((size_t)n_reads + 1, 0);
+    for (int64_t r = 0; r <= n_reads && n_reads > 0; r++) off[(size_t)r] = read_off[r] - read_off[0];
+    if (nb > 0) RFX_HIP(hipMemcpyAsync(d_bases.p, bases + read_off[0], (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(d_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    RFX_TRY(rfx::encode_reads(ctx, d_bases.as<uint8_t>(), d_off.as<int64_t>(), n_reads, wpr, d_words.as<uint64_t>(), d_len.as<uint32_t>()));
+    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    d_bases.release(); d_off.release();
+    int64_t kcap = std::max<int64_t>(1 << 20, nb / 8), m = 0, tot[3] = {0, 0, 0};
+    for (;;) {                                                        // survivors are few; every rank grows together
+        RFX_HIP(d_keys.alloc((size_t)kcap * 8, ctx->stream));
+        RFX_HIP(d_counts.alloc((size_t)kcap * 4, ctx->stream));
+        int st = rfx_dev_sharded_count(ctx, c, d_words.as<uint64_t>(), d_len.as<uint32_t>(), n_reads, wpr, (int)maxlen, k, prm->front_clip,
+                                       prm->end_clip, generations, prm->min_cov, prm->max_cov, prm->twin, d_keys.as<uint64_t>(),
+                                       d_counts.p, kcap, &m, tot);
+        if (st == RFX_E_CAP) {                                        // (on every rank at once)
+            int64_t need[1] = {m};
+            RFX_TRY(rfx_comm_all_reduce_i64(c, need, 1, 1));
+            kcap = std::max(kcap * 2, need[0]);
+            continue;
+        }
+        RFX_TRY(st);
+        break;
+    }
+    if (out_totals) { out_totals[0] = tot[0]; out_totals[1] = tot[1]; out_totals[2] = tot[2]; }
+    d_words.release(); d_len.release();
+    const int64_t all = tot[2];
+    if (c->rank == 0) {
+        RFX_HIP(g_keys.alloc((size_t)std::max<int64_t>(1, all) * 8, ctx->stream));
+        RFX_HIP(g_counts.alloc((size_t)std::max<int64_t>(1, all) * 4, ctx->stream));
+        RFX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    int64_t got = 0;
+    RFX_TRY(rfx_dev_gather_shards(ctx, c, d_keys.as<uint64_t>(), d_counts.p, m, 1, 4, 0, g_keys.as<uint64_t>(), g_counts.p, all, &got));
+    *out_len = 0;
+    if (out_contigs) *out_contigs = 0;
+    if (n_trace) *n_trace = 0;
+    if (c->rank != 0) return RFX_OK;
+    if (c->world > 1 && got > 1) {                                     // hash shards -> ascending k-mer order (the order contract)
+        DevBuf tk, tv;
+        RFX_HIP(tk.alloc((size_t)got * 8, ctx->stream));
+        RFX_HIP(tv.alloc((size_t)got * 4, ctx->stream));
+        RFX_TRY(rfx_dev_sort_pairs(ctx, g_keys.as<uint64_t>(), g_counts.as<uint32_t>(), got, 2 * k, tk.as<uint64_t>(), tv.as<uint32_t>()));
+        RFX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return rfx_dev_assemble(ctx, g_keys.as<uint64_t>(), g_counts.as<int32_t>(), got, prm, out, cap, out_len, out_contigs, trace,
+                            trace_cap, n_trace);
+}
+
+}  // extern "C"

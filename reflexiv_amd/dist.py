@@ -398,6 +398,34 @@ def _sharded_count_generations(engine, reads, min_cov, max_cov, twin, group, wor
     return keys, counts, [int(x) for x in tot.cpu()]
 
 
+def _sharded_count_capi(engine, rfx, reads, min_cov, max_cov, twin, generations):
+    from ._lib import RfxError, RFX_E_CAP
+    k = reads["k"]
+    wide = k > 32
+    W = 2 if wide else 1
+    dev = reads["words"].device
+    nk = rfx.kmers_per_read_w(reads["read_len"], k) if wide else rfx.kmers_per_read(reads["read_len"], k)
+    cap = max(1 << 20, nk * reads["n_reads"] // 8)
+    while True:
+        keys = torch.empty(cap * W, dtype=torch.int64, device=dev)
+        counts = torch.empty(cap, dtype=torch.int64 if wide else torch.int32, device=dev)
+        torch.cuda.current_stream().synchronize()
+        try:
+            m, tot = rfx.sharded_count_dev(reads["words"].data_ptr(), reads["n_reads"], reads["wpr"], reads["read_len"], k,
+                                           keys.data_ptr(), counts.data_ptr(), cap, min_cov, max_cov, twin,
+                                           generations=max(1, generations))
+            break
+        except RfxError as e:
+            if e.status != RFX_E_CAP:
+                raise
+            cap = max(2 * cap, rfx.comm_all_reduce([int(e.need)], "max")[0])       # (RFX_E_CAP arrives on every rank at once)
+    engine.bucketed_bytes = getattr(engine, "bucketed_bytes", 0) + rfx.comm_bytes_bucketed()
+    engine.k = k
+    if hasattr(engine, "_acc_timing"):
+        engine._acc_timing()
+    return keys[:m * W], counts[:m], tot
+
+
 def sharded_count(engine, reads, min_cov, max_cov, twin, group=None, chunks: int = 1, generations: int = 1):
     """-> (keys, counts) of this rank's shard (ascending), global (instances, distinct, survivors).
     chunks > 1 (and an engine that can split its reads): the reads are bucketed chunk by chunk and
@@ -406,6 +434,13 @@ def sharded_count(engine, reads, min_cov, max_cov, twin, group=None, chunks: int
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     width = None
     exchange = world > 1 or (dist.is_initialized() and bool(getattr(engine, "force_exchange", False)))   # (tests: 1-rank RCCL)
+    rfx = getattr(engine, "rfx", None)
+    if (exchange and rfx is not None and getattr(rfx, "comm", None) and not getattr(engine, "combine", False)
+            and getattr(rfx, "comm_world", 0) == world and (21 <= reads["k"] <= 31 or 33 <= reads["k"] <= 63)):
+        # the exchange lives behind the C ABI (rfx_dev_sharded_count: RCCL send / recv inside libreflexiv_hip.so); this module
+        # only allocates the outputs.  Engines without a communicator (the gloo stand-ins of the CPU tests, the pairs / k-mer
+        # exchange units) take the torch.distributed forms below.
+        return _sharded_count_capi(engine, rfx, reads, min_cov, max_cov, twin, generations)
     if (exchange and generations > 1 and hasattr(engine, "merge_sorted") and world * generations <= 64
             and getattr(engine, "generations_ok", lambda r: True)(reads)):
         return _sharded_count_generations(engine, reads, min_cov, max_cov, twin, group, world, generations)

@@ -1,0 +1,162 @@
+"""The multi-GPU count stage behind the C ABI (rfx_comm_*, rfx_dev_sharded_count, rfx_dev_gather_shards: RCCL bound inside
+libreflexiv_hip.so) on a ONE-rank communicator -- the exchange, the generations pipeline, the 512 MiB rounds and the
+rank's own bucket through ncclSend / ncclRecv all run on the GPU with real RCCL; results against the fused one-GPU count
+(itself pinned to the oracle) and, at the per-GPU share of BASELINE configs 3 and 4 (6.25 Gbp, -cover 38), against the
+oracle's pin tests/golden/c3_share.json (made by tests/golden/make_c2_full.py --reads 41666668 --cover 38)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PIN = os.path.join(HERE, "golden", "c3_share.json")
+
+
+def make_comm(env):
+    import reflexiv_amd
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        r = reflexiv_amd.Reflexiv()
+        r.comm_init(reflexiv_amd.Reflexiv.comm_unique_id(), 0, 1)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return r
+
+
+def reads_on_device(rfx, seed, G, n_reads, L, err=21474836):
+    import torch
+    wpr = (L + 31) // 32
+    dg = torch.empty((G + 31) // 32, dtype=torch.int64, device="cuda")
+    dw = torch.empty(n_reads * wpr, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    rfx.synth_genome_dev(seed, G, dg.data_ptr())
+    rfx.synth_reads_dev(seed, dg.data_ptr(), G, 0, n_reads, L, wpr, dw.data_ptr(), err)
+    rfx.sync()
+    return dw, wpr
+
+
+@pytest.mark.parametrize("env", [{}, {"RFX_COMM_SELF_VIA_RCCL": "1"},
+                                 {"RFX_COMM_SELF_VIA_RCCL": "1", "RFX_COMM_LIMIT_BYTES": "1048576"}])
+def test_sharded_count_behind_the_c_abi_one_rank(env):
+    import torch
+    rfx = make_comm(env)
+    try:
+        seed, G, n_reads, L = 31, 300_000, 150_000, 150
+        dw, wpr = reads_on_device(rfx, seed, G, n_reads, L)
+        for k, gens in ((31, 1), (31, 4), (25, 3), (63, 1), (63, 4), (40, 2)):
+            wide = k > 32
+            W = 2 if wide else 1
+            nk = (rfx.kmers_per_read_w if wide else rfx.kmers_per_read)(L, k)
+            N = nk * n_reads
+            cap = N // 2
+            cdt = torch.int64 if wide else torch.int32
+            dk = torch.empty(cap * W, dtype=torch.int64, device="cuda"); dc = torch.empty(cap, dtype=cdt, device="cuda")
+            sk = torch.empty(cap * W, dtype=torch.int64, device="cuda"); sc = torch.empty(cap, dtype=cdt, device="cuda")
+            torch.cuda.synchronize()
+            if wide:
+                m, nd, inst = rfx.count_reads_w_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), cap, 3)
+            else:
+                m, nd, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), cap, 3)
+            ms, tot = rfx.sharded_count_dev(dw.data_ptr(), n_reads, wpr, L, k, sk.data_ptr(), sc.data_ptr(), cap, 3,
+                                            generations=gens)
+            assert (ms, tot) == (m, [inst, nd, m]), (k, gens)
+            assert torch.equal(sk[:m * W], dk[:m * W]) and torch.equal(sc[:m], dc[:m]), (k, gens)
+            assert rfx.comm_bytes_bucketed() > 0
+            # a capacity that is too small is reported with the need, and the call can be repeated
+            import reflexiv_amd
+            with pytest.raises(reflexiv_amd.RfxError) as ei:
+                rfx.sharded_count_dev(dw.data_ptr(), n_reads, wpr, L, k, sk.data_ptr(), sc.data_ptr(), m // 2, 3, generations=gens)
+            assert ei.value.need == m
+            # gather to root (one rank: the shard itself), count() of the stop rule
+            gk = torch.empty_like(sk); gc = torch.empty_like(sc)
+            torch.cuda.synchronize()
+            assert rfx.gather_shards_dev(sk.data_ptr(), sc.data_ptr(), m, W, 8 if wide else 4, 0, gk.data_ptr(), gc.data_ptr(), cap) == m
+            assert torch.equal(gk[:m * W], sk[:m * W]) and torch.equal(gc[:m], sc[:m])
+        assert rfx.comm_all_reduce([5, -7, 1 << 40]) == [5, -7, 1 << 40]
+        assert rfx.comm_all_reduce([3, 9], "max") == [3, 9]
+    finally:
+        rfx.close()
+
+
+@pytest.mark.skipif(not os.path.exists(PIN), reason="tests/golden/c3_share.json not generated")
+@pytest.mark.parametrize("k", [31, 63])
+def test_multi_gpu_branch_at_the_config3_share_matches_the_oracle_pin(k):
+    """The code path `bench.py --gpus 8` runs on every rank (records in 4 generations through RCCL, count per generation,
+    merge), rehearsed on one rank at the per-GPU share of configs 3 / 4: 41,666,668 reads, -cover 38.  Counts, sha256 of
+    the survivors, the extend trace and sha256 of the contig text against the ORACLE's pin."""
+    import torch
+    import reflexiv_amd
+    pin = json.load(open(PIN))
+    rec, w = pin[f"k{k}"], pin["workload"]
+    rfx = make_comm({"RFX_COMM_SELF_VIA_RCCL": "1"})
+    try:
+        n_reads, L, cover, P = w["reads"], w["read_len"], w["cover"], w["partitions"]
+        dw, wpr = reads_on_device(rfx, w["seed"], w["genome"], n_reads, L, w["err_per_2_32"])
+        wide = k > 32
+        W = 2 if wide else 1
+        cap = 1 << 24
+        dk = torch.empty(cap * W, dtype=torch.int64, device="cuda")
+        dc = torch.empty(cap, dtype=torch.int64 if wide else torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        m, tot = rfx.sharded_count_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), cap, cover, generations=4)
+        assert tot == [rec["n_instances"], rec["n_distinct"], rec["n_kept"]] and m == rec["n_kept"]
+        keys = dk[:m * W].cpu().numpy().view(np.uint64)
+        counts = dc[:m].cpu().numpy()
+        assert hashlib.sha256(keys.tobytes()).hexdigest() == rec["sha256_keys"]
+        assert hashlib.sha256(counts.tobytes()).hexdigest() == rec["sha256_counts"]
+        prm = reflexiv_amd.default_params(k=k, min_cov=cover, partitions=P)
+        if wide:
+            aw = (k - 1) // 31 + 1
+            ak = torch.empty(m * aw, dtype=torch.int64, device="cuda"); ac = torch.empty(m, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            m2 = rfx.counter_to_asm_dev(dk.data_ptr(), dc.data_ptr(), m, k, ak.data_ptr(), ac.data_ptr(), cover)
+            text, nc, trace = rfx.assemble_w_dev(ak.data_ptr(), ac.data_ptr(), m2, prm)
+        else:
+            text, nc, trace = rfx.assemble_dev(dk.data_ptr(), dc.data_ptr(), m, prm)
+        assert trace == rec["trace"] and nc == rec["n_contigs"]
+        assert hashlib.sha256(text.encode()).hexdigest() == rec["sha256_contig_text"]
+    finally:
+        rfx.close()
+
+
+def test_sharded_assemble_reads_one_rank_matches_the_documented_example(golden_dir):
+    """rfx_sharded_assemble_reads (host ASCII reads -> encode -> sharded count over RCCL -> gather -> driver) on a one-rank
+    communicator: the documented example (k = 31, -cover 3, P = 4, RDD twin) gives `>Contig-4558-0` and the oracle's text;
+    a ragged read set (lengths 40..150) gives what the oracle gives."""
+    import reflexiv_amd
+    from oracle import oracle as O
+    ex = np.load(os.path.join(golden_dir, "example.npz"))
+    rfx = make_comm({"RFX_COMM_SELF_VIA_RCCL": "1"})
+    try:
+        prm = reflexiv_amd.default_params(min_cov=3, partitions=4, twin=reflexiv_amd.TWIN_RDD)
+        text, nc, trace, tot = rfx.sharded_assemble_reads(ex["bases"], ex["read_off"], prm, generations=4)
+        km = O.extract_canon(ex["bases"], ex["read_off"], 31)
+        wk, wc, wd = O.count_filter(km, 3)
+        otext, onc, otrace, _ = O.assemble_from_counts(wk, wc, O.default_params(min_cov=3, partitions=4, twin=O.TWIN_RDD))
+        assert tot == [len(km), wd, len(wk)]
+        assert (text, nc, trace) == (otext, onc, otrace) and text.startswith(">Contig-4558-0\n")
+        # ragged reads
+        rng = np.random.default_rng(8)
+        g = O.synth_genome(5, 60_000)
+        bases, off = O.synth_reads(5, g, 60_000, 0, 30_000, 150)
+        lens = rng.integers(40, 151, 30_000)
+        keep = np.concatenate([np.arange(off[i], off[i] + lens[i]) for i in range(len(lens))])
+        rb = bases[keep]
+        roff = np.zeros(len(lens) + 1, np.int64); roff[1:] = np.cumsum(lens)
+        prm = reflexiv_amd.default_params(min_cov=2, partitions=3, min_contig=200)
+        text, nc, trace, tot = rfx.sharded_assemble_reads(rb, roff, prm, generations=2)
+        km = O.extract_canon(rb, roff, 31)
+        wk, wc, wd = O.count_filter(km, 2)
+        otext, onc, otrace, _ = O.assemble_from_counts(wk, wc, O.default_params(min_cov=2, partitions=3, min_contig=200))
+        assert tot == [len(km), wd, len(wk)] and (text, nc, trace) == (otext, onc, otrace)
+    finally:
+        rfx.close()

@@ -1080,6 +1080,12 @@ def test_cpp_host_resident_run(tmp_path, ex, planted, twin):
     subprocess.check_call([host, "run", "--resident", "-fastq", fq2, "-outfile", out2, "-kmer", "31", "-cover", "2",
                            "-mincontig", "100", "--logical-partitions", "4", "--twin", twin])
     assert open(os.path.join(out2, "part-00000")).read() == str(planted[f"k31_{twin}_contigs"])
+    # the multi-GPU form of the same command (`--gpus N`: one host thread + context + RCCL communicator per GPU,
+    # rfx_sharded_assemble_reads) forced onto one GPU: same text
+    out3 = str(tmp_path / "result3")
+    subprocess.check_call([host, "run", "--resident", "--gpus", "1", "-fastq", fq, "-outfile", out3, "-kmer", "31", "-cover", "3",
+                           "--logical-partitions", "4", "--twin", twin], env=dict(os.environ, RFX_HOST_FORCE_SHARDED="1"))
+    assert open(os.path.join(out3, "part-00000")).read() == str(ex[f"contigs_{twin}_P4"])
 
 
 @pytest.mark.gpu

@@ -668,7 +668,9 @@ class Gen:
                 return f"_cast_long({v})"
             if t == "char":
                 return f"_cast_char({v})"
-            if t in ("short", "byte", "double", "float"):
+            if t in ("double", "float"):
+                return f"_cast_double({v})"
+            if t in ("short", "byte"):
                 raise SyntaxError(f"java2py: cast to {t}")
             if t == "Long":
                 return f"_box_long({v})"
@@ -942,8 +944,15 @@ class J:
         q = abs(a) // abs(b)
         return q if (a < 0) == (b < 0) else -q
 
-    def __truediv__(self, o): return self._bin(o, J._jdiv)
-    def __rtruediv__(self, o): return J._o(o)._bin(self, J._jdiv)
+    def __truediv__(self, o):
+        if isinstance(o, float):
+            return float(self.v) / o
+        return self._bin(o, J._jdiv)
+
+    def __rtruediv__(self, o):
+        if isinstance(o, float):
+            return o / float(self.v) if self.v else (float("inf") if o > 0 else float("-inf") if o < 0 else float("nan"))
+        return J._o(o)._bin(self, J._jdiv)
     def __mod__(self, o): return self._bin(o, lambda a, b: a - b * J._jdiv(a, b))
     def __rmod__(self, o): return J._o(o)._bin(self, lambda a, b: a - b * J._jdiv(a, b))
 
@@ -1111,10 +1120,13 @@ class JTuple:
 
 
 class JMap:
+    """java.util.HashMap; a Java ARRAY used as a key hashes by identity (never equal to a boxed Integer key)"""
     def __init__(self): self.d = {}
-    def put(self, k, v): self.d[k] = v
-    def get(self, k): return self.d.get(k)
-    def containsKey(self, k): return k in self.d
+    @staticmethod
+    def _k(k): return ("@array", id(k)) if isinstance(k, list) else k
+    def put(self, k, v): self.d[JMap._k(k)] = v
+    def get(self, k): return self.d.get(JMap._k(k))
+    def containsKey(self, k): return JMap._k(k) in self.d
     def size(self): return _I(len(self.d))
     def remove(self, k): return self.d.pop(k, None)
 
@@ -1169,6 +1181,10 @@ def _cast_int(x):
 def _cast_long(x):
     x = J._o(x)
     return J(x.v, 64)
+
+
+def _cast_double(x):
+    return float(x) if isinstance(x, float) else float(J._o(x).v)
 
 
 def _cast_char(x):
@@ -1471,7 +1487,19 @@ def _new(name, *args):
     raise TypeError(f"java2py: new {name}")
 
 
-RUNTIME = dict(_L=_L, _I=_I, _C=_C, _cast_int=_cast_int, _cast_long=_cast_long, _cast_char=_cast_char, _box_long=_box_long,
+class _Collections:
+    @staticmethod
+    def sort(lst):
+        lst.items.sort(key=lambda x: x.v if isinstance(x, J) else x)
+
+
+class _StringUtils:
+    @staticmethod
+    def chop(s):
+        return s[:-1]
+
+
+RUNTIME = dict(Collections=_Collections, StringUtils=_StringUtils, _cast_double=_cast_double, _L=_L, _I=_I, _C=_C, _cast_int=_cast_int, _cast_long=_cast_long, _cast_char=_cast_char, _box_long=_box_long,
                _box_int=_box_int, _ushr=_ushr, _eq=_eq, _add=_add, _len=_len, _newarr=_newarr, _iterate=_iterate,
                _instanceof=_instanceof, _call=_call, _new=_new, _JavaThrow=_JavaThrow, Long=_Long, Integer=_Integer,
                Math=_Math, RowFactory=_RowFactory, Arrays=_Arrays, JavaConverters=_JavaConverters, System=_Sys)

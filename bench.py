@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-contigs", action="store_true")
+    ap.add_argument("--no-k63", action="store_true", help="N = 1, k = 31: skip the second block (the same reads at k = 63)")
+    ap.add_argument("--no-ingest", action="store_true",
+                    help="N = 1: skip contigs.wall_ms_ascii_to_contigs (rfx_assemble_reads from pinned host ASCII)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the multi-GPU code path (owner buckets, RCCL all-to-all, gather) even with one rank")
     ap.add_argument("--exchange-chunks", type=int, default=4,
@@ -154,6 +157,53 @@ def cpu_baseline(args, n_sample, n_reads_total):
                       "(oracle/reflexiv_oracle.c, orc_count_reads_omp + orc_assemble_from_counts)",
             "count_stage_s": t_count, "counts_to_contigs_s": t_asm, "reads_to_contigs_s": t_count + t_asm,
             "kmers_kept": int(len(keys)), "distinct_kmers": int(nd), "n_contigs": nc, "longest": lens[:3]}
+
+
+def k63_block(args, rfx, torch, reflexiv_amd, d_words, n_reads, wpr, L, dev):
+    k = 63
+    W = 2
+    n_inst = rfx.kmers_per_read_w(L, k) * n_reads
+    cap = max(1 << 20, n_inst // 8)
+    d_keys = torch.empty(cap * W, dtype=torch.int64, device=dev)
+    d_counts = torch.empty(cap, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        return rfx.count_reads_w_dev(d_words.data_ptr(), n_reads, wpr, L, k, d_keys.data_ptr(), d_counts.data_ptr(), cap, args.cover)
+    for _ in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    acc = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m, nd, inst = step()
+        for name, (ms, ln) in rfx.count_timing().items():
+            a = acc.setdefault(name, [0.0, 0]); a[0] += ms; a[1] += ln
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    leaf_ms = acc.get("leaf", [0.0])[0] / args.steps
+    prm = reflexiv_amd.default_params(k=k, min_cov=args.cover, partitions=args.partitions)
+    aw = (k - 1) // 31 + 1
+    a_k = torch.empty(max(1, m) * aw, dtype=torch.int64, device=dev)
+    a_c = torch.empty(max(1, m), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def assemble():
+        m2 = rfx.counter_to_asm_dev(d_keys.data_ptr(), d_counts.data_ptr(), m, k, a_k.data_ptr(), a_c.data_ptr(), args.cover)
+        return rfx.assemble_w_dev(a_k.data_ptr(), a_c.data_ptr(), m2, prm)
+    assemble()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    text, nc, trace = assemble()
+    t_asm = time.perf_counter() - t1
+    lens = sorted((int(h.split("-")[1]) for h in text.split("\n") if h.startswith(">")), reverse=True)
+    return {"k": k, "dtype": "2 x u64", "kmer_instances": n_inst, "distinct_kmers": nd, "kmers_kept": m,
+            "ms_per_step": dt * 1e3, "value": n_inst / dt, "unit": "k-mers/s", "steps": args.steps,
+            "stage_hbm_frac": ((0.25 + 16 * W) * n_inst + (8 * W + 4) * m) / dt / 1e9 / HBM_PEAK_GBPS,
+            "leaf_ms": leaf_ms, "leaf_roofline_frac": (8 * W * n_inst / (leaf_ms / 1e3) / 1e9 / HBM_PEAK_GBPS) if leaf_ms else None,
+            "per_kernel_ms_per_step": {n: v[0] / args.steps for n, v in sorted(acc.items()) if not n.startswith("stat_")},
+            "contigs": {"wall_ms_from_counts": t_asm * 1e3, "wall_ms_reads_to_contigs": t_asm * 1e3 + dt * 1e3, "extend_passes": len(trace),
+                        "n_contigs": nc, "longest": lens[:3], "total_bases": sum(lens)}}
 
 
 def main():
@@ -315,7 +365,7 @@ def main():
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_s * 1e3,
                     "launches_per_step": launches / args.steps,
-                    "per_kernel_ms_per_step": {n: v[0] / args.steps for n, v in sorted(timing_acc.items())}}
+                    "per_kernel_ms_per_step": {n: v[0] / args.steps for n, v in sorted(timing_acc.items()) if not n.startswith("stat_")}}
 
     out = {
         "metric": "k-mers/sec (extract+count+filter; wall-clock to final contigs beside it)",
@@ -422,6 +472,37 @@ def main():
         out["contigs"] = {"wall_ms_from_counts": t_asm * 1e3, "wall_ms_reads_to_contigs": t_asm * 1e3 + dt / args.steps * 1e3,
                           "untimed_warmup_runs": 1, "extend_passes": len(trace), "n_contigs": nc, "longest": lens[:3],
                           "total_bases": sum(lens)}
+    if rank == 0 and not multi and not wide and not args.no_contigs and not args.no_ingest:
+        # end-to-end companion of "wall-clock to final contigs": the same reads as ASCII in PINNED host memory through
+        # rfx_assemble_reads (upload over PCIe, 2-bit encode, count / filter, extend, text back) -- one call
+        nuc = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+        host = torch.empty(n_reads * L, dtype=torch.uint8).pin_memory()
+        wv = d_words.view(n_reads, wpr)
+        step_r = max(1, (1 << 28) // L)
+        for a in range(0, n_reads, step_r):                       # decode the packed reads to ASCII in slices
+            b = min(n_reads, a + step_r)
+            idx = torch.arange(L, device=dev)
+            w = wv[a:b][:, idx // 32]
+            code = (w >> (62 - 2 * (idx % 32))) & 3
+            host[a * L:b * L].copy_(nuc[code].reshape(-1), non_blocking=True)
+            del w, code
+        torch.cuda.synchronize()
+        roff = __import__("numpy").arange(n_reads + 1, dtype="int64") * L
+        prm_i = reflexiv_amd.default_params(k=k, min_cov=args.cover, partitions=args.partitions)
+        rfx.assemble_reads_ptr(host.data_ptr(), n_reads * L, roff, prm_i)            # untimed warm-up, as everywhere
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        text_i, nc_i, trace_i, kept_i = rfx.assemble_reads_ptr(host.data_ptr(), n_reads * L, roff, prm_i)
+        t_ing = time.perf_counter() - t1
+        out.setdefault("contigs", {})["wall_ms_ascii_to_contigs"] = t_ing * 1e3
+        out["contigs"]["ascii_to_contigs"] = {"bytes_over_pcie": n_reads * L, "host_memory": "pinned", "n_contigs": nc_i,
+                                              "kmers_kept": kept_i, "same_text_as_resident_path": bool(text_i == text),
+                                              "effective_GBps_of_ascii": n_reads * L / t_ing / 1e9}
+        del host
+    if rank == 0 and not multi and not wide and not args.no_k63 and k == 31:
+        # the same reads at k = 63 (BASELINE config 4's k; two-word k-mers): count stage + counts -> contigs, so that the
+        # driver's N = 1 run times it too
+        out["k63"] = k63_block(args, rfx, torch, reflexiv_amd, d_words, n_reads, wpr, L, dev)
     if cpu_record is not None:
         out["cpu_baseline"] = cpu_record
     if rank == 0:

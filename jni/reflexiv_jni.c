@@ -11,7 +11,7 @@
  *
  * Conventions: a context handle is the rfx_ctx pointer as a jlong; record sets travel as
  * uni.bielefeld.cmg.reflexiv.gpu.RfxRecords (six primitive arrays + n + keyWords), pinned with
- * GetPrimitiveArrayCritical for the duration of the call; output record sets are allocated by the Java
+ * Get<Type>ArrayElements for the duration of the call (no critical regions around GPU work); output record sets are allocated by the Java
  * side at their upper bound and trimmed there (n is written back).  A negative rfx_status becomes a
  * RuntimeException, so Spark's task retry / job abort semantics are those of the reference.
  */
@@ -60,7 +60,9 @@ static int records_ids(JNIEnv *env) {
     return F_n && F_keyWords && F_key && F_marker && F_extOff && F_ext && F_left && F_right;
 }
 
-/* pins the six arrays; capacities come from the array lengths */
+/* the six arrays through Get<Type>ArrayElements -- NOT GetPrimitiveArrayCritical: field reads of the second record set, the
+ * write-back of n / keyWords and the GPU call itself all happen while they are held, none of which a critical region
+ * allows (no other JNI call, no blocking); capacities come from the array lengths */
 static int records_pin(JNIEnv *env, jobject o, pinned_records *p) {
     memset(p, 0, sizeof *p);
     if (!records_ids(env)) return 0;
@@ -76,23 +78,36 @@ static int records_pin(JNIEnv *env, jobject o, pinned_records *p) {
     p->r.key_words = kw;
     p->r.cap_n = (*env)->GetArrayLength(env, p->marker);
     p->r.cap_words = (*env)->GetArrayLength(env, p->ext);
-    p->r.key = (uint64_t *)(*env)->GetPrimitiveArrayCritical(env, p->key, NULL);
-    p->r.marker = (int32_t *)(*env)->GetPrimitiveArrayCritical(env, p->marker, NULL);
-    p->r.ext_off = (int64_t *)(*env)->GetPrimitiveArrayCritical(env, p->ext_off, NULL);
-    p->r.ext = (uint64_t *)(*env)->GetPrimitiveArrayCritical(env, p->ext, NULL);
-    p->r.left = (int32_t *)(*env)->GetPrimitiveArrayCritical(env, p->left, NULL);
-    p->r.right = (int32_t *)(*env)->GetPrimitiveArrayCritical(env, p->right, NULL);
+    p->r.key = (uint64_t *)(*env)->GetLongArrayElements(env, p->key, NULL);
+    p->r.marker = (int32_t *)(*env)->GetIntArrayElements(env, p->marker, NULL);
+    p->r.ext_off = (int64_t *)(*env)->GetLongArrayElements(env, p->ext_off, NULL);
+    p->r.ext = (uint64_t *)(*env)->GetLongArrayElements(env, p->ext, NULL);
+    p->r.left = (int32_t *)(*env)->GetIntArrayElements(env, p->left, NULL);
+    p->r.right = (int32_t *)(*env)->GetIntArrayElements(env, p->right, NULL);
     return p->r.key && p->r.marker && p->r.ext_off && p->r.ext && p->r.left && p->r.right;
+}
+
+/* small long[] arguments (partition starts): a native copy in, a region write out -- nothing is pinned during the GPU call */
+static int64_t *longs_in(JNIEnv *env, jlongArray a) {
+    const jsize n = (*env)->GetArrayLength(env, a);
+    int64_t *buf = (int64_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(int64_t));
+    if (buf && n > 0) (*env)->GetLongArrayRegion(env, a, 0, n, (jlong *)buf);
+    return buf;
+}
+static void longs_out(JNIEnv *env, jlongArray a, int64_t *buf, int write_back) {
+    if (!buf) return;
+    if (write_back) (*env)->SetLongArrayRegion(env, a, 0, (*env)->GetArrayLength(env, a), (const jlong *)buf);
+    free(buf);
 }
 
 /* mode 0: copy back (outputs), JNI_ABORT: inputs */
 static void records_unpin(JNIEnv *env, pinned_records *p, jint mode) {
-    if (p->r.right) (*env)->ReleasePrimitiveArrayCritical(env, p->right, p->r.right, mode);
-    if (p->r.left) (*env)->ReleasePrimitiveArrayCritical(env, p->left, p->r.left, mode);
-    if (p->r.ext) (*env)->ReleasePrimitiveArrayCritical(env, p->ext, p->r.ext, mode);
-    if (p->r.ext_off) (*env)->ReleasePrimitiveArrayCritical(env, p->ext_off, p->r.ext_off, mode);
-    if (p->r.marker) (*env)->ReleasePrimitiveArrayCritical(env, p->marker, p->r.marker, mode);
-    if (p->r.key) (*env)->ReleasePrimitiveArrayCritical(env, p->key, p->r.key, mode);
+    if (p->r.right) (*env)->ReleaseIntArrayElements(env, p->right, (jint *)p->r.right, mode);
+    if (p->r.left) (*env)->ReleaseIntArrayElements(env, p->left, (jint *)p->r.left, mode);
+    if (p->r.ext) (*env)->ReleaseLongArrayElements(env, p->ext, (jlong *)p->r.ext, mode);
+    if (p->r.ext_off) (*env)->ReleaseLongArrayElements(env, p->ext_off, (jlong *)p->r.ext_off, mode);
+    if (p->r.marker) (*env)->ReleaseIntArrayElements(env, p->marker, (jint *)p->r.marker, mode);
+    if (p->r.key) (*env)->ReleaseLongArrayElements(env, p->key, (jlong *)p->r.key, mode);
     if (mode == 0 && p->obj) {
         (*env)->SetLongField(env, p->obj, F_n, (jlong)p->r.n);
         (*env)->SetIntField(env, p->obj, F_keyWords, (jint)(p->r.key_words > 1 ? p->r.key_words : 1));
@@ -237,9 +252,9 @@ JNIEXPORT void JNICALL RFX_CLASS(sortRecords)(JNIEnv *env, jclass c, jlong h, jo
     int st = RFX_E_ARG;
     const int ok_i = records_pin(env, in, &pi), ok_o = records_pin(env, out, &po);
     if (ok_i && ok_o) {
-        jlong *ps = (jlong *)(*env)->GetPrimitiveArrayCritical(env, partStart, NULL);
+        int64_t *ps = longs_in(env, partStart);
         st = rfx_sort_records(ctx, &pi.r, P, &po.r, (int64_t *)ps);
-        (*env)->ReleasePrimitiveArrayCritical(env, partStart, ps, 0);
+        longs_out(env, partStart, ps, 1);
     }
     records_unpin(env, &po, 0);
     records_unpin(env, &pi, JNI_ABORT);
@@ -256,12 +271,12 @@ static void fork_common(JNIEnv *env, jlong h, int which, jobject in, jlongArray 
     const int P = (*env)->GetArrayLength(env, partStart) - 1;
     const int ok_i = records_pin(env, in, &pi), ok_o = records_pin(env, out, &po);
     if (ok_i && ok_o && P >= 1) {
-        jlong *ps = (jlong *)(*env)->GetPrimitiveArrayCritical(env, partStart, NULL);
-        jlong *ops = (jlong *)(*env)->GetPrimitiveArrayCritical(env, outPartStart, NULL);
+        int64_t *ps = longs_in(env, partStart);
+        int64_t *ops = longs_in(env, outPartStart);
         st = which ? rfx_fork_filter_reflected(ctx, &pi.r, (const int64_t *)ps, P, k, minErr, twin, &po.r, (int64_t *)ops)
                    : rfx_fork_filter_forward(ctx, &pi.r, (const int64_t *)ps, P, k, minErr, twin, &po.r, (int64_t *)ops);
-        (*env)->ReleasePrimitiveArrayCritical(env, outPartStart, ops, 0);
-        (*env)->ReleasePrimitiveArrayCritical(env, partStart, ps, JNI_ABORT);
+        longs_out(env, outPartStart, ops, 1);
+        longs_out(env, partStart, ps, 0);
     }
     records_unpin(env, &po, 0);
     records_unpin(env, &pi, JNI_ABORT);
@@ -302,9 +317,9 @@ JNIEXPORT void JNICALL RFX_CLASS(randomReflection)(JNIEnv *env, jclass c, jlong 
     const int P = (*env)->GetArrayLength(env, partStart) - 1;
     const int ok_i = records_pin(env, in, &pi), ok_o = records_pin(env, out, &po);
     if (ok_i && ok_o && P >= 1) {
-        jlong *ps = (jlong *)(*env)->GetPrimitiveArrayCritical(env, partStart, NULL);
+        int64_t *ps = longs_in(env, partStart);
         st = rfx_random_reflection(ctx, &pi.r, (const int64_t *)ps, P, k, &po.r);
-        (*env)->ReleasePrimitiveArrayCritical(env, partStart, ps, JNI_ABORT);
+        longs_out(env, partStart, ps, 0);
     }
     records_unpin(env, &po, 0);
     records_unpin(env, &pi, JNI_ABORT);
@@ -323,12 +338,12 @@ JNIEXPORT void JNICALL RFX_CLASS(extendPass)(JNIEnv *env, jclass c, jlong h, job
     const int P = (*env)->GetArrayLength(env, partStart) - 1;
     const int ok_i = records_pin(env, in, &pi), ok_o = records_pin(env, out, &po);
     if (ok_i && ok_o && P >= 1) {
-        jlong *ps = (jlong *)(*env)->GetPrimitiveArrayCritical(env, partStart, NULL);
-        jlong *ops = (jlong *)(*env)->GetPrimitiveArrayCritical(env, outPartStart, NULL);
+        int64_t *ps = longs_in(env, partStart);
+        int64_t *ops = longs_in(env, outPartStart);
         st = scramble == 2 ? rfx_extend_pass(ctx, &pi.r, (const int64_t *)ps, P, k, twin, stage, &po.r, (int64_t *)ops)
                            : rfx_extend_pass_w(ctx, &pi.r, (const int64_t *)ps, P, k, stage, scramble, &po.r, (int64_t *)ops);
-        (*env)->ReleasePrimitiveArrayCritical(env, outPartStart, ops, 0);
-        (*env)->ReleasePrimitiveArrayCritical(env, partStart, ps, JNI_ABORT);
+        longs_out(env, outPartStart, ops, 1);
+        longs_out(env, partStart, ps, 0);
     }
     records_unpin(env, &po, 0);
     records_unpin(env, &pi, JNI_ABORT);
@@ -345,11 +360,11 @@ JNIEXPORT void JNICALL RFX_CLASS(extrasOperator)(JNIEnv *env, jclass c, jlong h,
     const int P = (*env)->GetArrayLength(env, partStart) - 1;
     const int ok_i = records_pin(env, in, &pi), ok_o = records_pin(env, out, &po);
     if (ok_i && ok_o && P >= 1) {
-        jlong *ps = (jlong *)(*env)->GetPrimitiveArrayCritical(env, partStart, NULL);
-        jlong *ops = (jlong *)(*env)->GetPrimitiveArrayCritical(env, outPartStart, NULL);
+        int64_t *ps = longs_in(env, partStart);
+        int64_t *ops = longs_in(env, outPartStart);
         st = rfx_extras_operator(ctx, op, &pi.r, (const int64_t *)ps, P, k, &po.r, (int64_t *)ops);
-        (*env)->ReleasePrimitiveArrayCritical(env, outPartStart, ops, 0);
-        (*env)->ReleasePrimitiveArrayCritical(env, partStart, ps, JNI_ABORT);
+        longs_out(env, outPartStart, ops, 1);
+        longs_out(env, partStart, ps, 0);
     }
     records_unpin(env, &po, 0);
     records_unpin(env, &pi, JNI_ABORT);

@@ -545,6 +545,28 @@ class Reflexiv:
                                               key_bits, C.c_void_p(d_tmp_keys), C.c_void_p(d_tmp_vals)),
                     "rfx_dev_sort_pairs")
 
+    def assemble_reads_ptr(self, bases_ptr: int, n_bases: int, read_off, prm: Params):
+        """rfx_assemble_reads: ASCII reads in HOST memory (any lengths; bases_ptr may be pinned memory) -> upload, 2-bit
+        encode, count / filter, the driver -> (text, n_contigs, trace, kept).  k <= 31."""
+        read_off = np.ascontiguousarray(read_off, np.int64)
+        n_reads = len(read_off) - 1
+        trace = np.zeros(prm.max_iter + 8, np.int64)
+        ln, nc, ntr, kept = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        buf, cap = self._text_buffer(1 << 24)
+        while True:
+            st = self.L.rfx_assemble_reads(self.ctx, C.c_void_p(bases_ptr), _p(read_off), C.c_int64(n_reads), C.byref(prm), _p(buf),
+                                           C.c_int64(cap), C.byref(ln), C.byref(nc), _p(trace), C.c_int64(len(trace)), C.byref(ntr),
+                                           C.byref(kept))
+            if st == RFX_E_CAP and ln.value > cap:
+                buf, cap = self._text_buffer(int(ln.value))
+                continue
+            self._check(st, "rfx_assemble_reads")
+            return str(memoryview(buf)[:ln.value], "ascii"), int(nc.value), [int(x) for x in trace[:ntr.value]], int(kept.value)
+
+    def assemble_reads(self, bases, read_off, prm: Params):
+        bases = np.ascontiguousarray(bases, np.uint8)
+        return self.assemble_reads_ptr(bases.ctypes.data, len(bases), read_off, prm)
+
     # ------------------------------------------------ several GPUs: the RCCL exchange behind the C ABI
     @staticmethod
     def comm_unique_id() -> bytes:

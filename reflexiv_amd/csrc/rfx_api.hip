@@ -24,13 +24,13 @@ int download_to(rfx_ctx *ctx, const DevRecords &d, rfx_records *out) {
 int upload_part_start(rfx_ctx *ctx, const int64_t *h, int P, DevBuf &d) {
     RFX_HIP(d.alloc((size_t)(P + 1) * 8, ctx->stream));
     RFX_HIP(hipMemcpyAsync(d.p, h, (size_t)(P + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     return RFX_OK;
 }
 int download_part_start(rfx_ctx *ctx, const DevBuf &d, int P, int64_t *h) {
     if (!h) return RFX_OK;
     RFX_HIP(hipMemcpyAsync(h, d.p, (size_t)(P + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     return RFX_OK;
 }
 
@@ -39,12 +39,14 @@ int download_part_start(rfx_ctx *ctx, const DevBuf &d, int P, int64_t *h) {
 int64_t contigs_text_host(const rfx_records *r, int k, int min_contig, int twin, char *out, int64_t cap,
                           int64_t *n_contigs) {
     static const char NUC[4] = {'A', 'C', 'G', 'T'};
-    static char QUAD[256][4];
-    static bool quad_ready = false;
-    if (!quad_ready) {
-        for (int b = 0; b < 256; b++) for (int j = 0; j < 4; j++) QUAD[b][j] = NUC[(b >> (6 - 2 * j)) & 3];
-        quad_ready = true;
-    }
+    // four bases per byte; built once under the language's thread-safe initialisation of a function-local static
+    // (several host threads format contigs at once: Spark executor threads through the JNI, one context each)
+    struct QuadTable {
+        char q[256][4];
+        QuadTable() { for (int b = 0; b < 256; b++) for (int j = 0; j < 4; j++) q[b][j] = NUC[(b >> (6 - 2 * j)) & 3]; }
+    };
+    static const QuadTable quad_table;
+    const char (*QUAD)[4] = quad_table.q;
     const int sub = k - 1;
     const int kw = r->key_words > 1 ? r->key_words : 1;
     if (k > 31) twin = RFX_TWIN_RDD;
@@ -178,7 +180,7 @@ void rfx_ctx_destroy(rfx_ctx *ctx) {
 
 int rfx_ctx_sync(rfx_ctx *ctx) {
     if (!ctx) return RFX_E_ARG;
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     return RFX_OK;
 }
 
@@ -223,7 +225,7 @@ int rfx_extract_canon(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_of
     RFX_TRY(exclusive_scan_u64(ctx, d_nk.as<uint64_t>(), d_koff.as<uint64_t>(), n_reads));
     uint64_t total = 0;
     RFX_HIP(hipMemcpyAsync(&total, d_koff.as<uint64_t>() + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     *out_n = (int64_t)total;
     if ((int64_t)total > cap) return RFX_E_CAP;
     if (total == 0) return RFX_OK;
@@ -232,7 +234,7 @@ int rfx_extract_canon(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_of
     RFX_TRY(extract_ordered_packed(ctx, d_words.as<uint64_t>(), wpr, d_koff.as<uint64_t>(), n_reads, k, front_clip,
                                    d_out.as<uint64_t>()));
     RFX_HIP(hipMemcpyAsync(out_kmers, d_out.p, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     return RFX_OK;
 }
 
@@ -264,7 +266,7 @@ int rfx_extract_canon_w(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_
     RFX_TRY(exclusive_scan_u64(ctx, d_nk.as<uint64_t>(), d_koff.as<uint64_t>(), n_reads));
     uint64_t total = 0;
     RFX_HIP(hipMemcpyAsync(&total, d_koff.as<uint64_t>() + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     *out_n = (int64_t)total;
     if ((int64_t)total > cap) return RFX_E_CAP;
     if (total == 0) return RFX_OK;
@@ -275,7 +277,7 @@ int rfx_extract_canon_w(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_
                       d_soa.as<uint64_t>(), (int64_t)total));
     RFX_TRY(soa_to_aos(ctx, d_soa.as<uint64_t>(), (int64_t)total, W, d_out.as<uint64_t>()));
     RFX_HIP(hipMemcpyAsync(out_kmers, d_out.p, (size_t)total * W * 8, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     return RFX_OK;
 }
 
@@ -311,7 +313,7 @@ int rfx_count_filter_w(rfx_ctx *ctx, const uint64_t *kmers, int64_t n, int k, in
         RFX_HIP(hipMemcpyAsync(out_keys, d_keys.p, (size_t)m * W * 8, hipMemcpyDeviceToHost, ctx->stream));
         RFX_HIP(hipMemcpyAsync(out_counts, d_counts.p, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     return RFX_OK;
 }
 
@@ -342,7 +344,7 @@ int rfx_dev_count_reads_w(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads
                                    d_out_counts, cap, &m, out_distinct);
         *out_n = m;
         if (st == RFX_OK) st = order_wide2(ctx, d_out_keys, d_out_counts, m, k);
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
         ScopedTimer::collect(ctx);
         return st;
     }
@@ -363,7 +365,7 @@ int rfx_dev_count_reads_w(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads
         st = count_filter_w(ctx, d_soa.as<uint64_t>(), N, k, min_cov, max_cov, d_out_keys, d_out_counts, cap, out_n,
                             out_distinct);
     }
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     ScopedTimer::collect(ctx);
     return st;
 }
@@ -392,7 +394,7 @@ int rfx_count_filter(rfx_ctx *ctx, const uint64_t *kmers, int64_t n, int min_cov
         RFX_HIP(hipMemcpyAsync(out_keys, d_keys.p, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
         RFX_HIP(hipMemcpyAsync(out_counts, d_counts.p, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     return RFX_OK;
 }
 
@@ -551,7 +553,7 @@ int copy_out_dev(rfx_ctx *ctx, const DevRecords &o, rfx_records *d) {
         if (o.words > 0) RFX_HIP(hipMemcpyAsync(d->ext, o.ext.p, (size_t)o.words * 8, hipMemcpyDeviceToDevice, ctx->stream));
     }
     RFX_HIP(hipMemcpyAsync(d->ext_off, o.ext_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     d->n = n;
     return RFX_OK;
 }
@@ -559,7 +561,7 @@ int copy_out_dev(rfx_ctx *ctx, const DevRecords &o, rfx_records *d) {
 int copy_ps_dev(rfx_ctx *ctx, const DevBuf &ps, int P, int64_t *d_dst) {
     if (!d_dst) return RFX_OK;
     RFX_HIP(hipMemcpyAsync(d_dst, ps.p, (size_t)(P + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     return RFX_OK;
 }
 
@@ -660,7 +662,7 @@ int rfx_dev_lower_bound(rfx_ctx *ctx, const uint64_t *d_sorted_keys, int64_t n, 
     if (m == 0) return RFX_OK;
     hipLaunchKernelGGL(k_lower_bound, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, ctx->stream, d_sorted_keys, n, d_values, m, upper, d_out);
     RFX_HIP(hipGetLastError());
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     return RFX_OK;
 }
 
@@ -750,7 +752,7 @@ int rfx_dev_count_wide_records(rfx_ctx *ctx, const void *d_records, int64_t n_re
                                 cap, &m, out_distinct);
     *out_n = m;
     if (st == RFX_OK) st = order_wide2(ctx, d_out_keys, d_out_counts, m, k);
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     ScopedTimer::collect(ctx);
     return st;
 }
@@ -765,7 +767,7 @@ int rfx_dev_count_wide_elems(rfx_ctx *ctx, const void *d_elems, int64_t n_elems,
     ctx->timing.clear();
     const int st = count_filter_w2(ctx, (const uint64_t *)d_elems, n_elems, k, min_cov, max_cov, d_out_keys, d_out_counts,
                                    cap, out_n, out_distinct);
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     ScopedTimer::collect(ctx);
     return st;
 }
@@ -1047,7 +1049,7 @@ static int assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const 
                 RFX_HIP(hipMemcpyAsync(a.ext_off.p, pe.ext_off.p, (size_t)(pe.n + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
                 a.n = pe.n; a.words = pe.words;
             }
-            RFX_HIP(hipStreamSynchronize(ctx->stream));
+            RFX_TRY(sync_checked(ctx));
             split_done = true;
         }
         if (iterations >= prm->min_iter + 3 && iterations % 3 == 0) {             // 64 :621-622
@@ -1097,11 +1099,11 @@ static int assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const 
             std::vector<int64_t> ha((size_t)a.n + 1), hu((size_t)unext.n + 1), ho((size_t)(a.n + unext.n) + 1);
             RFX_HIP(hipMemcpyAsync(ha.data(), a.ext_off.p, ha.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
             RFX_HIP(hipMemcpyAsync(hu.data(), unext.ext_off.p, hu.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-            RFX_HIP(hipStreamSynchronize(ctx->stream));
+            RFX_TRY(sync_checked(ctx));
             for (int64_t i = 0; i <= a.n; i++) ho[(size_t)i] = ha[(size_t)i];
             for (int64_t i = 0; i <= unext.n; i++) ho[(size_t)(a.n + i)] = a.words + hu[(size_t)i];
             RFX_HIP(hipMemcpyAsync(u.ext_off.p, ho.data(), ho.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-            RFX_HIP(hipStreamSynchronize(ctx->stream));
+            RFX_TRY(sync_checked(ctx));
         }
         u.n = a.n + unext.n; u.words = a.words + unext.words;
         // left ends: all forward, sort, longer-of-key; right ends: all reflected, sort, longer-of-key  (:689-707)
@@ -1111,7 +1113,7 @@ static int assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const 
         for (int side = 0; side < 2; side++) {
             int64_t h1[2] = {0, cur->n};
             RFX_HIP(hipMemcpyAsync(one.p, h1, 16, hipMemcpyHostToDevice, ctx->stream));
-            RFX_HIP(hipStreamSynchronize(ctx->stream));
+            RFX_TRY(sync_checked(ctx));
             next_arena();
             DevBuf ops1;
             RFX_TRY(extras_operator(ctx, side == 0 ? RFX_OP_ALL_FORWARD : RFX_OP_ALL_REFLECTED, *cur, one.as<int64_t>(), 1, k, b, ops1));
@@ -1180,7 +1182,7 @@ int rfx_assemble_counts_w(rfx_ctx *ctx, const uint64_t *kmers, const int32_t *co
     if (n > 0) {
         RFX_HIP(hipMemcpyAsync(dk.p, kmers, (size_t)n * 8 * aw, hipMemcpyHostToDevice, ctx->stream));
         RFX_HIP(hipMemcpyAsync(dc.p, counts, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
     }
     return assemble_impl(ctx, true, dk.as<uint64_t>(), dc.as<int32_t>(), n, prm, out, cap, out_len, out_contigs, trace, trace_cap, n_trace);
 }

@@ -340,7 +340,7 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
             RFX_HIP(tk.alloc((size_t)m * 8, ctx->stream));
             RFX_HIP(tv.alloc((size_t)m * 4, ctx->stream));
             RFX_TRY(rfx_dev_sort_pairs(ctx, d_out_keys, (uint32_t *)d_out_counts, m, 2 * k, tk.as<uint64_t>(), tv.as<uint32_t>()));
-            RFX_HIP(hipStreamSynchronize(ctx->stream));
+            RFX_TRY(sync_checked(ctx));
         }
         add_timing(acc, ctx->timing);
     }
@@ -368,7 +368,7 @@ int rfx_dev_gather_shards(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_keys, con
     NcclApi &nc = nccl();
     const int world = c->world, me = c->rank;
     c->h_tab[0] = n;
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     RFX_HIP(hipMemcpyAsync(c->d_tab, c->h_tab, 8, hipMemcpyHostToDevice, c->xs));
     RFX_NCCL(nc.AllGather(c->d_tab, c->d_tab + 64, 1, ncclInt64, c->comm, c->xs));
     RFX_HIP(hipMemcpyAsync(c->h_tab + 64, c->d_tab + 64, (size_t)world * 8, hipMemcpyDeviceToHost, c->xs));
@@ -440,7 +440,7 @@ int rfx_sharded_assemble_reads(rfx_ctx *ctx, rfx_comm *c, const uint8_t *bases, 
     if (nb > 0) RFX_HIP(hipMemcpyAsync(d_bases.p, bases + read_off[0], (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
     RFX_HIP(hipMemcpyAsync(d_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     RFX_TRY(rfx::encode_reads(ctx, d_bases.as<uint8_t>(), d_off.as<int64_t>(), n_reads, wpr, d_words.as<uint64_t>(), d_len.as<uint32_t>()));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     d_bases.release(); d_off.release();
     int64_t kcap = std::max<int64_t>(1 << 20, nb / 8), m = 0, tot[3] = {0, 0, 0};
     for (;;) {                                                        // survivors are few; every rank grows together
@@ -464,7 +464,7 @@ int rfx_sharded_assemble_reads(rfx_ctx *ctx, rfx_comm *c, const uint8_t *bases, 
     if (c->rank == 0) {
         RFX_HIP(g_keys.alloc((size_t)std::max<int64_t>(1, all) * 8, ctx->stream));
         RFX_HIP(g_counts.alloc((size_t)std::max<int64_t>(1, all) * 4, ctx->stream));
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
     }
     int64_t got = 0;
     RFX_TRY(rfx_dev_gather_shards(ctx, c, d_keys.as<uint64_t>(), d_counts.p, m, 1, 4, 0, g_keys.as<uint64_t>(), g_counts.p, all, &got));
@@ -477,7 +477,7 @@ int rfx_sharded_assemble_reads(rfx_ctx *ctx, rfx_comm *c, const uint8_t *bases, 
         RFX_HIP(tk.alloc((size_t)got * 8, ctx->stream));
         RFX_HIP(tv.alloc((size_t)got * 4, ctx->stream));
         RFX_TRY(rfx_dev_sort_pairs(ctx, g_keys.as<uint64_t>(), g_counts.as<uint32_t>(), got, 2 * k, tk.as<uint64_t>(), tv.as<uint32_t>()));
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
     }
     return rfx_dev_assemble(ctx, g_keys.as<uint64_t>(), g_counts.as<int32_t>(), got, prm, out, cap, out_len, out_contigs, trace,
                             trace_cap, n_trace);

@@ -686,7 +686,7 @@ static int desc_tail(rfx_ctx *ctx, const DevRecords &in, int64_t nd, DevBuf &len
     RFX_HIP(hipGetLastError());
     uint64_t tot[3] = {0, 0, 0};
     RFX_HIP(hipMemcpyAsync(tot, summary.p, 24, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     const int st = (int)tot[2];
     out.n = (int64_t)tot[0]; out.words = (int64_t)tot[1];
     if (st) { ctx->last_error = "extend pass: single-word stage produced an extension > 31 bases"; return RFX_E_STATE; }
@@ -750,7 +750,7 @@ int extras_operator(rfx_ctx *ctx, int op, const DevRecords &in, const int64_t *d
         int64_t one[2] = {0, nd};
         RFX_HIP(ps1.alloc(16, ctx->stream));
         RFX_HIP(hipMemcpyAsync(ps1.p, one, 16, hipMemcpyHostToDevice, ctx->stream));
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
         ps = ps1.as<int64_t>(); Pn = 1;
     }
     if (n > 0) {
@@ -784,10 +784,10 @@ int extras_operator(rfx_ctx *ctx, int op, const DevRecords &in, const int64_t *d
         // output partition starts of the doubled set: twice the input's
         std::vector<int64_t> h((size_t)P + 1);
         RFX_HIP(hipMemcpyAsync(h.data(), d_part_start, (size_t)(P + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
         for (auto &x : h) x *= 2;
         RFX_HIP(hipMemcpyAsync(out_part_start.p, h.data(), (size_t)(P + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
     }
     return RFX_OK;
 }
@@ -843,7 +843,7 @@ int small_passes(rfx_ctx *ctx, DevRecords &recs, int k, int twin, bool wide, int
             }
         }
         RFX_HIP(hipMemcpyAsync(&h, state.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
         words_bound = h.words;                // the word total never grows from pass to pass
         if (h.done || h.iterations > max_iter) break;
     }
@@ -851,7 +851,7 @@ int small_passes(rfx_ctx *ctx, DevRecords &recs, int k, int twin, bool wide, int
     std::vector<int64_t> ht((size_t)(h.nt > 0 ? h.nt : 1));
     if (h.nt > 0) {
         RFX_HIP(hipMemcpyAsync(ht.data(), dtrace.p, (size_t)h.nt * 8, hipMemcpyDeviceToHost, ctx->stream));
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
     }
     for (int64_t i = 0; i < h.nt; i++) { if (trace && *nt < trace_cap) trace[*nt] = ht[(size_t)i]; (*nt)++; }
     if (h.cur == 1) {        // the survivors are in the second set: hand its buffers over

@@ -487,7 +487,7 @@ int dev_records_upload(rfx_ctx *ctx, const rfx_records *h, DevRecords &d) {
         int64_t zero = 0;
         RFX_HIP(hipMemcpyAsync(d.ext_off.p, &zero, 8, hipMemcpyHostToDevice, ctx->stream));
     }
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     d.n = n; d.words = words;
     return RFX_OK;
 }
@@ -507,7 +507,7 @@ int dev_records_download(rfx_ctx *ctx, const DevRecords &d, rfx_records *h) {
             RFX_HIP(hipMemcpyAsync(h->ext, d.ext.p, (size_t)d.words * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     RFX_HIP(hipMemcpyAsync(h->ext_off, d.ext_off.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     return RFX_OK;
 }
 
@@ -582,7 +582,7 @@ int sort_records(rfx_ctx *ctx, const DevRecords &in, int P, int key_bits, DevRec
             RFX_HIP(hipGetLastError());
             int h_flag = 0;
             RFX_HIP(hipMemcpyAsync(&h_flag, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-            RFX_HIP(hipStreamSynchronize(ctx->stream));
+            RFX_TRY(sync_checked(ctx));
             done = h_flag == 0;
             if (!done) {                       // a long run of equal prefixes: start over with the two passes below
                 hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n)), dim3(256), 0, ctx->stream, perm.as<uint32_t>(), n);
@@ -686,7 +686,7 @@ int fork_filter(rfx_ctx *ctx, bool reflected, const DevRecords &in, const int64_
     RFX_HIP(hipGetLastError());
     uint64_t m = 0;
     RFX_HIP(hipMemcpyAsync(&m, pos.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     out.n = (int64_t)m; out.words = (int64_t)m;
     return RFX_OK;
 }
@@ -742,7 +742,7 @@ int counter_to_asm(rfx_ctx *ctx, const uint64_t *d_keys32, const int64_t *d_coun
     RFX_HIP(hipGetLastError());
     uint64_t m = 0;
     RFX_HIP(hipMemcpyAsync(&m, pos.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     *out_n = (int64_t)m;
     return RFX_OK;
 }

@@ -92,6 +92,22 @@ struct rfx_ctx {
         if (s_ != RFX_OK) return s_;               \
     } while (0)
 
+// Every host wait on the context's stream goes through here: a single-pass scan whose look-back gave up (rfx_scan.hip:
+// it substitutes prefix 0 and raises the host-mapped flag) fails the call that waited, not some later one.
+static inline int sync_checked(rfx_ctx *ctx) {
+    hipError_t e_ = hipStreamSynchronize(ctx->stream);
+    if (e_ != hipSuccess) {
+        ctx->last_error = std::string("hipStreamSynchronize -> ") + hipGetErrorString(e_);
+        return RFX_E_HIP;
+    }
+    if (ctx->scan_fault && *ctx->scan_fault) {
+        *ctx->scan_fault = 0;
+        ctx->last_error = "scan: look-back gave up waiting for a predecessor tile (offsets of this call are invalid)";
+        return RFX_E_HIP;
+    }
+    return RFX_OK;
+}
+
 // Bump arena for the temporaries of one pass of the extend loop: two of them alternate, so a
 // pass reads its inputs from the previous pass's arena and nothing is allocated or freed per pass
 // (hipMallocAsync with ever-changing sizes cost ~5 ms per pass, far more than the kernels).

@@ -2509,7 +2509,7 @@ int ragged_instances(rfx_ctx *ctx, const uint32_t *d_read_len, int64_t n_reads, 
     RFX_TRY(exclusive_scan_u64(ctx, nk.as<uint64_t>(), off.as<uint64_t>(), n_reads));
     uint64_t t = 0;
     RFX_HIP(hipMemcpyAsync(&t, off.as<uint64_t>() + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     *out_total = (int64_t)t;
     return RFX_OK;
 }
@@ -2623,7 +2623,7 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
                            (int)pair_out, presplit);
         RFX_HIP(hipGetLastError());
     }
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     if (n_slices > 0) {
         DevBuf sb, se, co2, pk, pc, tk, tv;
         RFX_HIP(sb.alloc((size_t)n_slices * 8, ctx->stream));
@@ -2649,7 +2649,7 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
                 RFX_HIP(hipGetLastError());
             }
             RFX_HIP(hipMemcpyAsync(&c2, co2.p, sizeof c2, hipMemcpyDeviceToHost, ctx->stream));
-            RFX_HIP(hipStreamSynchronize(ctx->stream));
+            RFX_TRY(sync_checked(ctx));
             if (c2.n_failed) { ctx->last_error = "leaf split depth exhausted"; ScopedTimer::collect(ctx); return RFX_E_LIMIT; }
             if (c2.n_out <= pcap) break;
             pcap = c2.n_out;
@@ -2671,7 +2671,7 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
     }
     CountOut co{};
     RFX_HIP(hipMemcpyAsync(&co, co_buf.p, sizeof co, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     if (out_n) *out_n = (int64_t)co.n_out;
     if (out_distinct) *out_distinct = (int64_t)co.n_distinct;
     if (getenv("RFX_TRACE"))
@@ -2693,7 +2693,7 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
         RFX_TRY(sort_pairs(ctx, d_out_keys, reinterpret_cast<uint32_t *>(d_out_counts), (int64_t)co.n_out, key_bits,
                            tk.as<uint64_t>(), tv.as<uint32_t>()));
         t.stop();
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
     }
     ScopedTimer::collect(ctx);
     return RFX_OK;
@@ -2775,7 +2775,7 @@ static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv
     RFX_HIP(hipGetLastError());
     uint64_t R = 0;
     RFX_HIP(hipMemcpyAsync(&R, scanned.as<uint64_t>() + (size_t)nb * G, 8, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     *n_recs = (int64_t)R;
     Rec *dst = d_dst;
     if (use_ws) {
@@ -2839,7 +2839,7 @@ static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv, 
     }
     unsigned long long h_tot[3] = {0, 0, 0};
     RFX_HIP(hipMemcpyAsync(h_tot, totals.p, 24, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     const uint32_t ose = (uint32_t)h_tot[2];
     if (ose == 0) {                       // one bucket takes more of a tile than the largest extent: two passes straight away
         if (getenv("RFX_TRACE")) fprintf(stderr, "one-sweep level 1: not tried (the sample puts too much on one bucket)\n");
@@ -2880,7 +2880,7 @@ static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv, 
     int h_over = 0;
     RFX_HIP(hipMemcpyAsync(h_tot, totals.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     RFX_HIP(hipMemcpyAsync(&h_over, d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     if (getenv("RFX_TRACE"))
         fprintf(stderr, "one-sweep level 1: %llu records in regions of %llu (sample 1/%d, %d workgroups, extents of %u)%s\n", h_tot[1], h_tot[0], sample, G, ose,
                 h_over ? " -- a region overflowed: two passes instead" : "");
@@ -3062,7 +3062,7 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
     uint64_t seg_init[2] = {0, (uint64_t)n};
     RFX_HIP(segA.alloc(2 * 8, ctx->stream));
     RFX_HIP(hipMemcpyAsync(segA.p, seg_init, 16, hipMemcpyHostToDevice, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));     // seg_init lives on the stack
+    RFX_TRY(sync_checked(ctx));     // seg_init lives on the stack
     int64_t nseg = 1;
     DevBuf *seg_cur = &segA, *seg_next = &segB;
     DevBuf *out_buf = &bufA, *in_buf = &bufB;
@@ -3186,7 +3186,7 @@ int bucket_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, uint64_t
     }
     if (h_owner_off) {
         RFX_HIP(hipMemcpyAsync(h_owner_off, d_owner_off, (size_t)(n_owners + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
     }
     return RFX_OK;
 }
@@ -3214,7 +3214,7 @@ int bucket_records_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, 
     if (st != RFX_OK) return st;
     if (h_owner_off) {
         RFX_HIP(hipMemcpyAsync(h_owner_off, d_owner_off, (size_t)(n_owners + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
     }
     return RFX_OK;
 }
@@ -3237,7 +3237,7 @@ int count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_
     uint64_t seg_init[2] = {0, (uint64_t)n_records};
     RFX_HIP(segA.alloc(2 * 8, ctx->stream));
     RFX_HIP(hipMemcpyAsync(segA.p, seg_init, 16, hipMemcpyHostToDevice, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     // slot -1: the caller's buffer; the first level writes workspace slot 0
     return count_records_levels(ctx, (const Rec *)d_records, n_records, 1, bits, 0, 0, &segA, &segB, 1, k, min_cov,
                                 max_cov, twin, d_out_keys, d_out_counts, cap, out_n, out_distinct);
@@ -3263,7 +3263,7 @@ int bucket_pairs_by_owner(rfx_ctx *ctx, const void *d_pairs, int64_t n, int n_ow
     uint64_t seg_init[2] = {0, (uint64_t)n};
     RFX_HIP(seg.alloc(16, ctx->stream));
     RFX_HIP(hipMemcpyAsync(seg.p, seg_init, 16, hipMemcpyHostToDevice, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     const int64_t total_tiles = ceil_div(n, PTILE);
     const int tpb = (int)std::min<int64_t>(32, std::max<int64_t>(1, total_tiles / ((int64_t)ctx->num_cu * 8)));
     const int64_t v_bound = ceil_div(n, (int64_t)tpb * PTILE) + 1;
@@ -3305,7 +3305,7 @@ int bucket_pairs_by_owner(rfx_ctx *ctx, const void *d_pairs, int64_t n, int n_ow
     }
     if (h_owner_off) {
         RFX_HIP(hipMemcpyAsync(h_owner_off, d_owner_off, (size_t)(n_owners + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
         ScopedTimer::collect(ctx);
     }
     return RFX_OK;
@@ -3325,7 +3325,7 @@ int merge_pairs(rfx_ctx *ctx, const void *d_pairs, int64_t n, int k, int min_cov
     uint64_t seg_init[2] = {0, (uint64_t)n};
     RFX_HIP(segA.alloc(2 * 8, ctx->stream));
     RFX_HIP(hipMemcpyAsync(segA.p, seg_init, 16, hipMemcpyHostToDevice, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     DevBuf *seg_cur = &segA, *seg_next = &segB;
     int64_t nseg = 1;
     const Rec *cur = nullptr;
@@ -3354,7 +3354,7 @@ static int finish_wide2(rfx_ctx *ctx, const std::conditional_t<RECS, WRec, Rec> 
     }
     CountOut co{};
     RFX_HIP(hipMemcpyAsync(&co, co_buf.p, sizeof co, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     if (getenv("RFX_TRACE"))
         fprintf(stderr, "wide leaves: %lld buckets, %llu table passes, %llu overflowed\n", (long long)nseg, co.n_passes, co.n_overflow);
     ctx->timing["stat_leaves"].launches += nseg; ctx->timing["stat_passes"].launches += (int64_t)co.n_passes;
@@ -3382,7 +3382,7 @@ int count_wide2(rfx_ctx *ctx, const void *d_elems, int64_t n, int min_cov, int m
     uint64_t seg_init[2] = {0, (uint64_t)n};
     RFX_HIP(segA.alloc(2 * 8, ctx->stream));
     RFX_HIP(hipMemcpyAsync(segA.p, seg_init, 16, hipMemcpyHostToDevice, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     DevBuf *seg_cur = &segA, *seg_next = &segB;
     int64_t nseg = 1;
     const Rec *cur = nullptr;
@@ -3440,7 +3440,7 @@ int bucket_wide_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads,
     RFX_TRY(wide_level1(ctx, d_words, n_reads, wpr, nk, k, fc, lv, (Rec *)d_out, reinterpret_cast<uint64_t *>(d_owner_off)));
     if (h_owner_off) {
         RFX_HIP(hipMemcpyAsync(h_owner_off, d_owner_off, (size_t)(n_owners + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
     }
     ScopedTimer::collect(ctx);
     return RFX_OK;
@@ -3537,7 +3537,7 @@ int bucket_wide_records_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t 
     if (st != RFX_OK) return st;
     if (h_owner_off) {
         RFX_HIP(hipMemcpyAsync(h_owner_off, d_owner_off, (size_t)(n_owners + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
     }
     return RFX_OK;
 }
@@ -3556,7 +3556,7 @@ int count_wide_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, i
     uint64_t seg_init[2] = {0, (uint64_t)n_records};
     RFX_HIP(segA.alloc(2 * 8, ctx->stream));
     RFX_HIP(hipMemcpyAsync(segA.p, seg_init, 16, hipMemcpyHostToDevice, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     DevBuf *seg_cur = &segA, *seg_next = &segB;
     int64_t nseg = 1;
     const WRec *cur = nullptr;

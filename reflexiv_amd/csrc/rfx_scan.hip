@@ -170,7 +170,7 @@ int scan_lookback(rfx_ctx *ctx, const uint32_t *a, const uint32_t *b, uint64_t *
     const size_t need = (size_t)nt * 2;
     if (ctx->scan_fault && *ctx->scan_fault) { ctx->last_error = "scan: look-back gave up waiting for a predecessor tile"; return RFX_E_HIP; }
     if (ctx->scan_desc_cap < need || !ctx->scan_ticket) {
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
         if (ctx->scan_desc) (void)hipFree(ctx->scan_desc);
         const size_t cap = need + need / 4 + 4096;
         RFX_HIP(hipMalloc((void **)&ctx->scan_desc, cap * 8));
@@ -191,7 +191,6 @@ int scan_lookback(rfx_ctx *ctx, const uint32_t *a, const uint32_t *b, uint64_t *
         ctx->scan_epoch = 1;
     }
     const unsigned long long tb = ctx->scan_tickets_issued;
-    ctx->scan_tickets_issued += (unsigned long long)nt;
     if (b)
         hipLaunchKernelGGL(k_scan_lookback<true>, dim3((unsigned)nt), dim3(LB_THREADS), 0, ctx->stream, a, b, n, oa, ob, ctx->scan_desc,
                            ctx->scan_ticket, tb, ctx->scan_epoch, ctx->scan_fault);
@@ -199,6 +198,7 @@ int scan_lookback(rfx_ctx *ctx, const uint32_t *a, const uint32_t *b, uint64_t *
         hipLaunchKernelGGL(k_scan_lookback<false>, dim3((unsigned)nt), dim3(LB_THREADS), 0, ctx->stream, a, (const uint32_t *)nullptr, n, oa,
                            (uint64_t *)nullptr, ctx->scan_desc, ctx->scan_ticket, tb, ctx->scan_epoch, ctx->scan_fault);
     RFX_HIP(hipGetLastError());
+    ctx->scan_tickets_issued += (unsigned long long)nt;        // only once the launch is known to be queued: the device counter moves with it
     return RFX_OK;
 }
 

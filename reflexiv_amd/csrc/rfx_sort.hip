@@ -287,11 +287,13 @@ __device__ __forceinline__ void sort_tile_lds(const uint64_t *keys, const uint32
             if (e - b > (uint32_t)MSD_INS) too_long = 1;
             __syncthreads();
             if (!too_long) {
+                // (ordered by the low `bits` bits only, as the LSD passes are: bits above key_bits do not take part)
+                const uint64_t low = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
                 for (uint32_t i = b + 1; i < e; i++) {
                     const uint64_t x = sk[1][i];
                     const uint32_t xv = sv[1][i];
                     uint32_t j = i;
-                    while (j > b && sk[1][j - 1] > x) { sk[1][j] = sk[1][j - 1]; sv[1][j] = sv[1][j - 1]; j--; }
+                    while (j > b && (sk[1][j - 1] & low) > (x & low)) { sk[1][j] = sk[1][j - 1]; sv[1][j] = sv[1][j - 1]; j--; }
                     sk[1][j] = x; sv[1][j] = xv;
                 }
                 __syncthreads();
@@ -420,7 +422,7 @@ int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int 
         RFX_HIP(hipGetLastError());
         uint32_t maxc = 0;
         RFX_HIP(hipMemcpyAsync(&maxc, d_max3, 4, hipMemcpyDeviceToHost, ctx->stream));
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
         if (maxc <= (uint32_t)STILE) {
             hipLaunchKernelGGL(k_sort_buckets, dim3((unsigned)((int64_t)NP2 * D3)), dim3(ST), 0, ctx->stream, (const uint64_t *)dk, (const uint32_t *)dv,
                                (const uint32_t *)bounds3.as<uint32_t>(), shift3, d_keys, d_vals);
@@ -470,7 +472,7 @@ int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int 
         RFX_HIP(hipGetLastError());
         uint32_t maxc = 0;
         RFX_HIP(hipMemcpyAsync(&maxc, d_maxc, 4, hipMemcpyDeviceToHost, ctx->stream));
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
         if (maxc <= (uint32_t)STILE) {
             hipLaunchKernelGGL(k_sort_buckets, dim3((unsigned)(256 * D2)), dim3(ST), 0, ctx->stream, (const uint64_t *)sk, (const uint32_t *)sv,
                                (const uint32_t *)b3.as<uint32_t>(), shift2, d_keys, d_vals);
@@ -492,7 +494,7 @@ int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int 
         RFX_HIP(hipGetLastError());
         uint32_t maxc = 0;
         RFX_HIP(hipMemcpyAsync(&maxc, bounds.as<uint32_t>() + 257, 4, hipMemcpyDeviceToHost, ctx->stream));
-        RFX_HIP(hipStreamSynchronize(ctx->stream));
+        RFX_TRY(sync_checked(ctx));
         if (maxc <= (uint32_t)STILE) {
             if (!inline_scan) RFX_TRY(exclusive_scan_u32_to_u64(ctx, table.as<uint32_t>(), offs.as<uint64_t>(), ntiles * 256));
             hipLaunchKernelGGL(k_scatter<false>, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, sv, n, shift,

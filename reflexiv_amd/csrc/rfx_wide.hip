@@ -309,7 +309,7 @@ int order_wide2(rfx_ctx *ctx, uint64_t *d_out_keys, int64_t *d_out_counts, int64
     RFX_HIP(hipMemcpyAsync(d_out_keys, oaos.p, (size_t)m * 16, hipMemcpyDeviceToDevice, ctx->stream));
     RFX_HIP(hipMemcpyAsync(d_out_counts, ocnt.p, (size_t)m * 8, hipMemcpyDeviceToDevice, ctx->stream));
     t.stop();
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     return RFX_OK;
 }
 
@@ -359,7 +359,7 @@ int count_filter_w(rfx_ctx *ctx, uint64_t *d_soa, int64_t N, int k, int min_cov,
     RFX_TRY(exclusive_scan_u32_to_u64(ctx, head.as<uint32_t>(), pos.as<uint64_t>(), N));
     uint64_t D = 0;
     RFX_HIP(hipMemcpyAsync(&D, pos.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     if (out_distinct) *out_distinct = (int64_t)D;
     DevBuf start, keep, opos;
     RFX_HIP(start.alloc((size_t)(D + 1) * 8, ctx->stream));
@@ -374,7 +374,7 @@ int count_filter_w(rfx_ctx *ctx, uint64_t *d_soa, int64_t N, int k, int min_cov,
     RFX_TRY(exclusive_scan_u32_to_u64(ctx, keep.as<uint32_t>(), opos.as<uint64_t>(), (int64_t)D));
     uint64_t M = 0;
     RFX_HIP(hipMemcpyAsync(&M, opos.as<uint64_t>() + D, 8, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipStreamSynchronize(ctx->stream));
+    RFX_TRY(sync_checked(ctx));
     *out_n = (int64_t)M;
     if ((int64_t)M > cap) return RFX_E_CAP;
     if (M == 0) return RFX_OK;

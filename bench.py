@@ -472,6 +472,17 @@ def main():
         out["contigs"] = {"wall_ms_from_counts": t_asm * 1e3, "wall_ms_reads_to_contigs": t_asm * 1e3 + dt / args.steps * 1e3,
                           "untimed_warmup_runs": 1, "extend_passes": len(trace), "n_contigs": nc, "longest": lens[:3],
                           "total_bases": sum(lens)}
+    if rank == 0 and not args.no_contigs and "contigs" in out and not args.sharded_extend:
+        # contig RC de-duplication (P/ReflexivDSDynamicKmerDedup.java) of the text the path just wrote:
+        # the fixed-k path reports every contig on both strands, this reports each once
+        rfx.dedup_contig_text(text, 500)                                          # untimed warm-up, as everywhere
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        dtext, dnc, drn = rfx.dedup_contig_text(text, 500)
+        t_dd = time.perf_counter() - t1
+        dl = sorted((int(h.split("-")[1]) for h in dtext.split("\n") if h.startswith(">")), reverse=True)
+        out["contigs"]["dedup"] = {"wall_ms": t_dd * 1e3, "n_contigs": dnc, "contigs_after_each_round": drn, "longest": dl[:3],
+                                   "total_bases": sum(dl), "total_bases_before": out["contigs"]["total_bases"]}
     if rank == 0 and not multi and not wide and not args.no_contigs and not args.no_ingest:
         # end-to-end companion of "wall-clock to final contigs": the same reads as ASCII in PINNED host memory through
         # rfx_assemble_reads (upload over PCIe, 2-bit encode, count / filter, extend, text back) -- one call

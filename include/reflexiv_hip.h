@@ -449,6 +449,23 @@ int rfx_assemble_reads(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_o
                        int64_t *out_contigs, int64_t *trace, int64_t trace_cap, int64_t *n_trace,
                        int64_t *out_kept);
 
+/* Contig RC de-duplication: P/ReflexivDSDynamicKmerDedup.java `assemblyFromKmer` (:138-339) -- three rounds of
+ * marker 31-mers (ReverseComplementKmerMarkerExtraction :2674-3096, ForwardAndReverseComplementKmerMarkerExtraction :2206-2673)
+ * -> sort -> DSMarkerKmerSelection (:1788-1870) -> groupBy().count() >= 2 -> DSMarkerKmerShorterID (:3186-3207) ->
+ * DSShorterRCContigSeqAndTargetExtraction (:3097-3132) -> DSShorterRCContigRemoval (:1405-1558) /
+ * DSShorterForwardAndRCContigRemoval[Array] (:508-729, :959-1175), then TagRowContigDSID (:3397-3443).  The fixed-k path
+ * emits every contig on both strands; this reports each once (and merges overlapping pieces as the reference does).
+ *   rfx_dedup_contigs      contigs as ASCII bases + offsets (ids = positions, as zipWithIndex numbers them) -> the survivors
+ *                          (ASCII + offsets; RFX_E_CAP when a capacity is short) and / or the text: ">Contig-<len>-<idx>" +
+ *                          the sequence in lines of 10,000,000, contigs of at least min_contig bases; round_n[3] (optional)
+ *                          = contigs left after each round
+ *   rfx_dedup_contig_text  the same from the contig text the path writes (either twin's headers, 100-column lines) */
+int rfx_dedup_contigs(rfx_ctx *ctx, const uint8_t *bases_ascii, const int64_t *contig_off, int64_t n_contigs, int min_contig,
+                      uint8_t *out_bases_ascii, int64_t cap_bases, int64_t *out_off, int64_t cap_contigs, int64_t *out_n,
+                      char *text, int64_t text_cap, int64_t *text_len, int64_t *round_n);
+int rfx_dedup_contig_text(rfx_ctx *ctx, const char *contig_text, int64_t len, int min_contig, char *out, int64_t cap,
+                          int64_t *out_len, int64_t *out_contigs, int64_t *round_n);
+
 /* Synthetic reads: integer-only counter-based generator, bit-identical to
  * oracle/reflexiv_oracle.c orc_synth_*.  Writes packed reads straight into HBM. */
 int rfx_dev_synth_genome(rfx_ctx *ctx, uint64_t seed, int64_t genome_len, uint64_t *d_genome);

@@ -70,6 +70,9 @@ public final class Rfx {
 
     public static native byte[] assembleReads(long ctx, byte[] bases, long[] readOff, int[] params);
 
+    /** ReflexivDSDynamicKmerDedup.assemblyFromKmer on a run's contig text: every contig once (rfx_dedup_contig_text) */
+    public static native byte[] dedupContigText(long ctx, byte[] contigText, int minContig);
+
     // several GPUs of one node: the shuffle of reduceByKey as an RCCL all-to-all inside the library (rfx_comm_*,
     // rfx_sharded_assemble_reads); one barrier task per GPU, see ReflexivGpuMain.assemblyResidentSharded()
     public static native byte[] commUniqueId();

@@ -504,3 +504,25 @@ JNIEXPORT jbyteArray JNICALL RFX_CLASS(shardedAssembleReads)(JNIEnv *env, jclass
         return out;
     }
 }
+
+
+/* Contig RC de-duplication: ReflexivDSDynamicKmerDedup.assemblyFromKmer (P/ReflexivDSDynamicKmerDedup.java:138-339) on the
+ * contig text a run wrote (rows of saveAsTextFile joined by '\n') -> the text TagRowContigDSID (:3397-3443) writes */
+JNIEXPORT jbyteArray JNICALL RFX_CLASS(dedupContigText)(JNIEnv *env, jclass c, jlong h, jbyteArray contigText, jint minContig) {
+    (void)c;
+    rfx_ctx *ctx = ctx_of(h);
+    const jsize n = (*env)->GetArrayLength(env, contigText);
+    char *src = (char *)malloc((size_t)n + 1), *dst = (char *)malloc((size_t)n + 4096);
+    if (!src || !dst) { free(src); free(dst); throw_rfx(env, ctx, RFX_E_HIP, "rfx_dedup_contig_text (out of host memory)"); return NULL; }
+    (*env)->GetByteArrayRegion(env, contigText, 0, n, (jbyte *)src);
+    int64_t len = 0, nc = 0;
+    const int st = rfx_dedup_contig_text(ctx, src, (int64_t)n, minContig, dst, (int64_t)n + 4096, &len, &nc, NULL);
+    jbyteArray out = NULL;
+    if (st == RFX_OK) {
+        out = (*env)->NewByteArray(env, (jsize)len);
+        if (out) (*env)->SetByteArrayRegion(env, out, 0, (jsize)len, (const jbyte *)dst);
+    }
+    free(src); free(dst);
+    if (st != RFX_OK) { throw_rfx(env, ctx, st, "rfx_dedup_contig_text"); return NULL; }
+    return out;
+}

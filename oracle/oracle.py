@@ -35,9 +35,8 @@ class _Records(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liborc.so")
-    src = os.path.join(_HERE, "reflexiv_oracle.c")
-    hdr = os.path.join(_HERE, "reflexiv_oracle.h")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    srcs = [os.path.join(_HERE, f) for f in ("reflexiv_oracle.c", "reflexiv_dedup.c", "reflexiv_oracle.h", "Makefile")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liborc.so"])
     return so
 
@@ -65,6 +64,8 @@ def lib():
         L.orc_count_reads_omp.restype = C.c_int64
         L.orc_count_reads_range_omp.restype = C.c_int64
         L.orc_count_reads_w2_range_omp.restype = C.c_int64
+        L.orc_dedup_contigs.restype = C.c_int64
+        L.orc_dedup_text.restype = C.c_int64
         for f in ("orc_double_w", "orc_key_filter_w", "orc_flip_all_w"):
             getattr(L, f).restype = C.c_int64
         for f in ("orc_fork_filter_forward_w", "orc_fork_filter_reflected_w", "orc_extend_pass_w",
@@ -515,3 +516,33 @@ def synth_reads(seed: int, genome: np.ndarray, genome_len: int, first_read: int,
     lib().orc_synth_reads(C.c_uint64(seed), _p(genome), C.c_int64(genome_len), C.c_int64(first_read),
                           C.c_int64(n_reads), read_len, C.c_uint32(err_per_2_32), _p(bases))
     return bases, np.arange(n_reads + 1, dtype=np.int64) * read_len
+
+
+# ---------------------------------------------------------------- f-4: contig RC de-duplication
+
+def dedup_contigs(contigs, min_contig=500):
+    """P/ReflexivDSDynamicKmerDedup.java assemblyFromKmer (:138-339) on a list of contig strings (ACGT), ids = positions ->
+    dict(rounds=[list of strings after round 1, 2, 3], pairs=[..], candidates=[..], text=str)."""
+    code = np.zeros(256, np.uint8)
+    code[ord("C")], code[ord("G")], code[ord("T")] = 1, 2, 3
+    off = np.zeros(len(contigs) + 1, np.int64)
+    off[1:] = np.cumsum([len(c) for c in contigs])
+    bases = code[np.frombuffer("".join(contigs).encode(), np.uint8)] if off[-1] else np.zeros(0, np.uint8)
+    n = len(contigs)
+    cap_b = int(2 * off[-1] + 1024)
+    bufs = [np.empty(cap_b, np.uint8) for _ in range(3)]
+    offs = [np.empty(n + 2, np.int64) for _ in range(3)]
+    rn, rb, rp, rc = (np.zeros(3, np.int64) for _ in range(4))
+    m = lib().orc_dedup_contigs(_p(bases), _p(off), C.c_int64(n), _p(bufs[2]), C.c_int64(cap_b), _p(offs[2]), C.c_int64(n + 1),
+                                _p(rn), _p(rb), _p(rp), _p(rc), _p(bufs[0]), _p(offs[0]), _p(bufs[1]), _p(offs[1]))
+    if m < 0:
+        raise ValueError("dedup output does not fit")
+    nuc = np.frombuffer(b"ACGT", np.uint8)
+    rounds = []
+    for r in range(3):
+        k = int(rn[r])
+        rounds.append([bytes(nuc[bufs[r][offs[r][i]:offs[r][i + 1]]]).decode() for i in range(k)])
+    ln = lib().orc_dedup_text(_p(bufs[2]), _p(offs[2]), C.c_int64(m), min_contig, None, C.c_int64(0))
+    tb = np.empty(max(1, ln), np.uint8)
+    lib().orc_dedup_text(_p(bufs[2]), _p(offs[2]), C.c_int64(m), min_contig, _p(tb), C.c_int64(ln))
+    return dict(rounds=rounds, pairs=[int(x) for x in rp], candidates=[int(x) for x in rc], text=bytes(tb[:ln]).decode())

@@ -567,6 +567,37 @@ class Reflexiv:
         bases = np.ascontiguousarray(bases, np.uint8)
         return self.assemble_reads_ptr(bases.ctypes.data, len(bases), read_off, prm)
 
+    # ------------------------------------------------ f-4: contig RC de-duplication
+    def dedup_contigs(self, contigs, min_contig=500):
+        """rfx_dedup_contigs (P/ReflexivDSDynamicKmerDedup.java :138-339) on a list of contig strings (ids = positions) ->
+        (survivors: list of strings, text, [contigs after round 1, 2, 3])"""
+        off = np.zeros(len(contigs) + 1, np.int64)
+        off[1:] = np.cumsum([len(c) for c in contigs])
+        bases = np.frombuffer("".join(contigs).encode(), np.uint8) if off[-1] else np.zeros(1, np.uint8)
+        n = len(contigs)
+        ob = np.empty(int(2 * off[-1]) + 4096, np.uint8)
+        oo = np.empty(n + 2, np.int64)
+        m, tl = C.c_int64(0), C.c_int64(0)
+        rn = (C.c_int64 * 3)()
+        tcap = int(2 * off[-1]) + 64 * (n + 2) + 4096
+        tb = np.empty(tcap, np.uint8)
+        self._check(self.L.rfx_dedup_contigs(self.ctx, _p(bases), _p(off), C.c_int64(n), min_contig, _p(ob), C.c_int64(len(ob)), _p(oo),
+                                             C.c_int64(n + 1), C.byref(m), _p(tb), C.c_int64(tcap), C.byref(tl), rn), "rfx_dedup_contigs")
+        k = int(m.value)
+        surv = [bytes(ob[oo[i]:oo[i + 1]]).decode() for i in range(k)]
+        return surv, bytes(tb[:tl.value]).decode(), [int(x) for x in rn]
+
+    def dedup_contig_text(self, text: str, min_contig=500):
+        """rfx_dedup_contig_text: the path's contig text -> (de-duplicated text, contigs, [after round 1, 2, 3])"""
+        src = text.encode()
+        cap = len(src) + 4096
+        out = np.empty(cap, np.uint8)
+        ln, nc = C.c_int64(0), C.c_int64(0)
+        rn = (C.c_int64 * 3)()
+        self._check(self.L.rfx_dedup_contig_text(self.ctx, src, C.c_int64(len(src)), min_contig, _p(out), C.c_int64(cap), C.byref(ln),
+                                                 C.byref(nc), rn), "rfx_dedup_contig_text")
+        return bytes(out[:ln.value]).decode(), int(nc.value), [int(x) for x in rn]
+
     # ------------------------------------------------ several GPUs: the RCCL exchange behind the C ABI
     @staticmethod
     def comm_unique_id() -> bytes:

@@ -300,6 +300,15 @@ std::string ReflexivMain::assemblyResident(const std::string &fastqText, std::ve
     return out;
 }
 
+std::string ReflexivMain::dedupContigText(const std::string &contigText) {
+    std::string out(contigText.size() + 4096, '\0');
+    int64_t len = 0, nc = 0;
+    check(rfx_dedup_contig_text(ctx, contigText.data(), (int64_t)contigText.size(), param.minContig, out.data(), (int64_t)out.size(), &len, &nc,
+                                nullptr), "rfx_dedup_contig_text");
+    out.resize((size_t)len);
+    return out;
+}
+
 std::string ReflexivMain::assemblyResidentSharded(const std::string &fastqText, int nGpus, std::vector<int64_t> *trace) {
     if (!param.bubble)
         throw std::runtime_error("-bubble (no fork filtering) is unusable in the reference too (SURVEY.md C.6)");

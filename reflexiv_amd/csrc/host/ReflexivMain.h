@@ -121,6 +121,8 @@ public:
     std::string assemblyResident(const std::string &fastqText, std::vector<int64_t> *trace = nullptr);
     // the same on the nGpus GPUs of this node: one host thread, context and RCCL communicator per GPU, every thread passes its
     // share of the reads to rfx_sharded_assemble_reads (the shuffle of reduceByKey, P/ReflexivMain.java:155, over RCCL)
+    // P/ReflexivDSDynamicKmerDedup.java assemblyFromKmer (:138-339) on the contig text of a run: each contig once
+    std::string dedupContigText(const std::string &contigText);
     std::string assemblyResidentSharded(const std::string &fastqText, int nGpus, std::vector<int64_t> *trace = nullptr);
     // ReflexivCounter.assembly(): P/ReflexivCounter.java:109-191 -> lines "KMER,count"
     std::string counter(const std::string &fastqText);

@@ -70,6 +70,7 @@ int main(int argc, char **argv) {
                   : param.resident && (param.gpus > 1 || getenv("RFX_HOST_FORCE_SHARDED")) ? m.assemblyResidentSharded(read_all(param.inputFqPath), param.gpus)
                   : param.resident          ? m.assemblyResident(read_all(param.inputFqPath))
                                             : m.assembly(read_all(param.inputFqPath));
+            if (param.dedup) out = m.dedupContigText(out);
         } else if (cmd == "counter") {
             out = m.counter(read_all(param.inputFqPath));
             dir += "/Count_" + std::to_string(param.kmerSize);               // P/ReflexivDataFrameCounter.java:222-233

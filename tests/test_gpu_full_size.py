@@ -97,3 +97,11 @@ def check_against_pin(rfx, reads_dev, k, pin_path):
     assert trace == rec["trace"]
     assert nc == rec["n_contigs"] and len(text) == rec["contig_text_bytes"]
     assert hashlib.sha256(text.encode()).hexdigest() == rec["sha256_contig_text"]
+    if k <= 31 and rec["n_contigs"] <= 64:
+        # f-4 at full size: the de-duplicated contigs (P/ReflexivDSDynamicKmerDedup.java) against the oracle on the same text
+        from oracle import oracle as O
+        contigs = ["".join(part.split("\n")[1:]) for part in text.split(">")[1:]]
+        want = O.dedup_contigs(contigs)
+        dtext, dnc, drn = rfx.dedup_contig_text(text)
+        assert drn == [len(r) for r in want["rounds"]] and dtext == want["text"]
+        assert dnc < rec["n_contigs"] and sum(len(c) for c in want["rounds"][2]) < 0.6 * sum(len(c) for c in contigs)

@@ -81,6 +81,10 @@ def parse():
                          "super-k-mer records in --generations of the hash space (less compute; the count of one generation "
                          "hides the flight of the next).  auto: records (since round 2 the form with less compute at every N; pairs stay selectable)")
     ap.add_argument("--generations", type=int, default=4, help="--exchange records: generations of the hash space")
+    ap.add_argument("--virtual-world", type=int, default=8,
+                    help="--force-dist on one rank: bucket the reads as a rank of this many GPUs would (generations x owners bins) "
+                         "and count per generation what such a rank would receive -- the per-rank kernel work of an N-GPU step "
+                         "without the links (RFX_COMM_VIRTUAL_WORLD)")
     ap.add_argument("--exchange-impl", choices=["capi", "torch"], default="capi",
                     help="N > 1, --exchange records: capi = rfx_dev_sharded_count (RCCL send / recv inside libreflexiv_hip.so, "
                          "the form a Java / C host calls); torch = reflexiv_amd.dist over torch.distributed")
@@ -276,6 +280,8 @@ def main():
     engine.force_exchange = args.force_dist
     capi = multi and args.exchange == "records" and args.exchange_impl == "capi" and (21 <= k <= 31 or 33 <= k <= 63)
     if capi:
+        if world == 1 and args.force_dist and args.virtual_world > 1:
+            os.environ["RFX_COMM_VIRTUAL_WORLD"] = str(args.virtual_world)
         # the RCCL communicator of the C ABI: rank 0 makes the id, torch.distributed only carries its 128 bytes
         box = [reflexiv_amd.Reflexiv.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
@@ -395,7 +401,8 @@ def main():
                            "chunks": 1 if (args.exchange == "records" and not wide) else max(args.exchange_chunks, int(est_chunks) + 1),
                            "impl": "rfx_dev_sharded_count (RCCL send/recv inside libreflexiv_hip.so)" if capi
                                    else "reflexiv_amd.dist over torch.distributed",
-                           "exchange_free": bool((rd.LOCAL_SHORTCUT or capi) and world == 1)}
+                           "exchange_free": bool((rd.LOCAL_SHORTCUT or capi) and world == 1),
+                           "rehearsed_as_rank_of": args.virtual_world if (capi and world == 1 and args.force_dist) else None}
     if multi and not args.no_contigs and args.sharded_extend and not wide:
         # every sortByKey of the loop = local sort + splitters + ONE all-to-all of whole records + local sort, records in HBM
         prm = reflexiv_amd.default_params(k=k, min_cov=args.cover, partitions=max(args.partitions, world))
@@ -498,7 +505,7 @@ def main():
             host[a * L:b * L].copy_(nuc[code].reshape(-1), non_blocking=True)
             del w, code
         torch.cuda.synchronize()
-        roff = __import__("numpy").arange(n_reads + 1, dtype="int64") * L
+        roff = (torch.arange(n_reads + 1, dtype=torch.int64) * L).pin_memory().numpy()      # (pinned, like the bases)
         prm_i = reflexiv_amd.default_params(k=k, min_cov=args.cover, partitions=args.partitions)
         rfx.assemble_reads_ptr(host.data_ptr(), n_reads * L, roff, prm_i)            # untimed warm-up, as everywhere
         torch.cuda.synchronize()

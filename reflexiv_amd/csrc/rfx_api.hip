@@ -121,6 +121,9 @@ struct HostRecords {
 
 }  // namespace
 
+// a piece of a workspace slot (not owned)
+struct DevSpan { void *p = nullptr; template <class T> T *as() const { return (T *)p; } };
+
 extern "C" {
 
 int rfx_version(void) { return 100; }
@@ -1210,27 +1213,88 @@ int rfx_assemble_reads(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_o
     if (!ctx || !read_off || !prm || !out_len || n_reads < 0) return RFX_E_ARG;
     RFX_TRY(check_k(prm->k));
     RFX_HIP(hipSetDevice(ctx->device));
+    const bool verbose = getenv("RFX_TRACE") != nullptr;
+    auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double t_in = now_ms();
     const int64_t nb = n_reads ? read_off[n_reads] - read_off[0] : 0;
-    int64_t maxlen = 1;
-    for (int64_t r = 0; r < n_reads; r++) maxlen = std::max(maxlen, read_off[r + 1] - read_off[r]);
+    // the two big buffers live in workspace slots of the context (grow-only, allocated once): slot 5 = the ASCII bases,
+    // slot 6 = offsets | packed words | lengths
+    DevSpan d_bases, d_off, d_words, d_len;
+    DevBuf d_keys, d_counts;
+    d_bases.p = ctx->ws_get(5, (size_t)std::max<int64_t>(nb, 1));
+    if (!d_bases.p) { ctx->last_error = "rfx_assemble_reads: out of device memory (bases)"; return RFX_E_HIP; }
+    // PCIe is the slow part (5 GB of ASCII at ~50 GB/s from pinned memory), so everything else hides under it: the bases go
+    // up in chunks of whole reads on a second stream, queued FIRST; while they travel the host scans the read lengths (the
+    // width of the packed layout), and every chunk is 2-bit encoded on the context's stream as soon as it has landed.  The
+    // offsets go up as they are: k_encode reads bases[read_off[r] + i], the device copy is addressed from read_off[0].
+    hipStream_t cs = nullptr;
+    std::vector<hipEvent_t> evs;
+    std::vector<int64_t> cuts(1, 0);
+    hipEvent_t ready = nullptr;                            // the allocations above are stream-ordered on the context's stream
+    hipError_t err = hipSuccess;
+    if (n_reads > 0) {
+        err = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&ready, hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventRecord(ready, ctx->stream);
+        if (err == hipSuccess) err = hipStreamWaitEvent(cs, ready, 0);
+        const int64_t chunk_bytes = (int64_t)256 << 20;
+        int64_t r0 = 0;
+        while (err == hipSuccess && r0 < n_reads) {
+            // reads [r0, r1): as many whole reads as fit the chunk (binary search on the ascending offsets)
+            int64_t lo = r0 + 1, hi = n_reads;
+            const int64_t limit = read_off[r0] + chunk_bytes;
+            while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if (read_off[mid] <= limit) lo = mid; else hi = mid - 1; }
+            const int64_t r1 = lo, b0 = read_off[r0], b1 = read_off[r1];
+            if (b1 > b0) err = hipMemcpyAsync(d_bases.as<uint8_t>() + (b0 - read_off[0]), bases + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, cs);
+            hipEvent_t e = nullptr;
+            if (err == hipSuccess) err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            if (err == hipSuccess) { evs.push_back(e); err = hipEventRecord(e, cs); }
+            cuts.push_back(r1);
+            r0 = r1;
+        }
+    }
+    int64_t maxlen = 1, minlen = INT64_MAX;
+    for (int64_t r = 0; r < n_reads; r++) {
+        const int64_t l = read_off[r + 1] - read_off[r];
+        maxlen = std::max(maxlen, l); minlen = std::min(minlen, l);
+    }
+    const bool uniform = n_reads > 0 && minlen == maxlen;       // equal-length reads (PE150): the uniform count path
     const int wpr = (int)((maxlen + 31) / 32);
-    DevBuf d_bases, d_off, d_words, d_len, d_keys, d_counts;
-    RFX_HIP(d_bases.alloc((size_t)std::max<int64_t>(nb, 1), ctx->stream));
-    RFX_HIP(d_off.alloc((size_t)(n_reads + 1) * 8, ctx->stream));
-    RFX_HIP(d_words.alloc((size_t)std::max<int64_t>(n_reads, 1) * wpr * 8, ctx->stream));
-    RFX_HIP(d_len.alloc((size_t)std::max<int64_t>(n_reads, 1) * 4, ctx->stream));
-    std::vector<int64_t> off((size_t)n_reads + 1, 0);
-    for (int64_t r = 0; r <= n_reads && n_reads > 0; r++) off[(size_t)r] = read_off[r] - read_off[0];
-    if (nb > 0) RFX_HIP(hipMemcpyAsync(d_bases.p, bases + read_off[0], (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
-    RFX_HIP(hipMemcpyAsync(d_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    RFX_TRY(encode_reads(ctx, d_bases.as<uint8_t>(), d_off.as<int64_t>(), n_reads, wpr, d_words.as<uint64_t>(),
-                         d_len.as<uint32_t>()));
+    const double t_scan = now_ms();
+    int st_enc = RFX_OK;
+    {
+        const size_t off_b = ((size_t)(n_reads + 1) * 8 + 255) & ~(size_t)255, words_b = ((size_t)std::max<int64_t>(n_reads, 1) * wpr * 8 + 255) & ~(size_t)255;
+        char *base = (char *)ctx->ws_get(6, off_b + words_b + (size_t)std::max<int64_t>(n_reads, 1) * 4);
+        if (!base) { ctx->last_error = "rfx_assemble_reads: out of device memory (packed reads)"; err = hipErrorOutOfMemory; }
+        d_off.p = base; d_words.p = base + off_b; d_len.p = base + off_b + words_b;
+        if (err == hipSuccess && n_reads > 0) err = hipMemcpyAsync(d_off.p, read_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    }
+    const uint8_t *dev_base = d_bases.as<uint8_t>() - (n_reads ? read_off[0] : 0);
+    for (size_t c = 0; err == hipSuccess && st_enc == RFX_OK && c < evs.size(); c++) {
+        err = hipStreamWaitEvent(ctx->stream, evs[c], 0);
+        const int64_t r0 = cuts[c], r1 = cuts[c + 1];
+        if (err == hipSuccess)
+            st_enc = encode_reads(ctx, dev_base, d_off.as<int64_t>() + r0, r1 - r0, wpr, d_words.as<uint64_t>() + r0 * wpr, d_len.as<uint32_t>() + r0);
+    }
+    if (cs) { if (err == hipSuccess) err = hipStreamSynchronize(cs); }
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    for (auto e : evs) (void)hipEventDestroy(e);
+    if (ready) (void)hipEventDestroy(ready);
+    if (cs) (void)hipStreamDestroy(cs);
+    if (err != hipSuccess) { ctx->last_error = std::string("rfx_assemble_reads upload: ") + hipGetErrorString(err); return RFX_E_HIP; }
+    RFX_TRY(st_enc);
     ReadStore rs{d_words.as<uint64_t>(), n_reads, wpr, (int)maxlen, prm->k, prm->front_clip, prm->end_clip};
-    rs.read_len_arr = d_len.as<uint32_t>();
-    RFX_TRY(ragged_instances(ctx, rs.read_len_arr, n_reads, prm->k, prm->front_clip, prm->end_clip, &rs.n_instances));
-    d_bases.release(); d_off.release();
+    const double t_up = now_ms();
+    if (verbose) fprintf(stderr, "assemble_reads: upload queued + length scan %.1f ms, until the last chunk is encoded %.1f ms more (%.1f GB/s of ASCII in all)\n",
+                         t_scan - t_in, t_up - t_scan, nb / ((t_up - t_in) * 1e6));
+    int64_t n_inst = 0;
+    if (!uniform) {
+        rs.read_len_arr = d_len.as<uint32_t>();
+        RFX_TRY(ragged_instances(ctx, rs.read_len_arr, n_reads, prm->k, prm->front_clip, prm->end_clip, &rs.n_instances));
+        n_inst = rs.n_instances;
+    } else n_inst = kmers_per_read((int)maxlen, prm->k, prm->front_clip, prm->end_clip) * n_reads;
     int64_t m = 0, dist = 0;
-    int64_t kcap = std::max<int64_t>(1 << 20, rs.n_instances / 8);
+    int64_t kcap = std::max<int64_t>(1 << 20, n_inst / 8);
     for (;;) {                                      // survivors are few; grow on RFX_E_CAP
         RFX_HIP(d_keys.alloc((size_t)kcap * 8, ctx->stream));
         RFX_HIP(d_counts.alloc((size_t)kcap * 4, ctx->stream));
@@ -1241,7 +1305,7 @@ int rfx_assemble_reads(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_o
         break;
     }
     if (out_kept) *out_kept = m;
-    d_words.release(); d_len.release();
+    if (verbose) fprintf(stderr, "assemble_reads: count %.1f ms\n", now_ms() - t_up);
     return rfx_dev_assemble(ctx, d_keys.as<uint64_t>(), d_counts.as<int32_t>(), m, prm, out, cap, out_len, out_contigs, trace,
                             trace_cap, n_trace);
 }

@@ -83,6 +83,7 @@ struct rfx_comm {
     int64_t bytes_bucketed = 0;                   // of the last call
     size_t limit_bytes = (size_t)1 << 29;         // per peer and call (RCCL 2.26 corrupts messages above 1 GiB)
     bool self_via_rccl = false;                   // tests: send the rank's own bucket through ncclSend / ncclRecv too
+    int virtual_world = 1;                        // one-rank rehearsal of an N-rank node (see rfx_dev_sharded_count)
 };
 
 #define RFX_NCCL(call)                                                                                     \
@@ -128,6 +129,7 @@ int rfx_comm_init(rfx_ctx *ctx, const uint8_t *id128, int rank, int world, rfx_c
     c->ctx = ctx; c->rank = rank; c->world = world;
     if (const char *e = getenv("RFX_COMM_LIMIT_BYTES")) c->limit_bytes = std::max<size_t>(1024, (size_t)atoll(e));
     c->self_via_rccl = getenv("RFX_COMM_SELF_VIA_RCCL") && atoi(getenv("RFX_COMM_SELF_VIA_RCCL")) != 0;
+    if (const char *e = getenv("RFX_COMM_VIRTUAL_WORLD")) c->virtual_world = std::max(1, std::min(64, atoi(e)));
     ncclUniqueId id;
     memcpy(&id, id128, 128);
     ncclResult_t r = n.CommInitRank(&c->comm, world, id, rank);
@@ -226,8 +228,13 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
     }
     const int world = c->world, me = c->rank;
     int G = generations;
-    while (G > 1 && G * world > 64) G /= 2;
-    const int bins = G * world;
+    // one-rank REHEARSAL of a larger node (RFX_COMM_VIRTUAL_WORLD=8 on a world of 1; bench.py --force-dist): the reads are
+    // bucketed into G x 8 bins exactly as a rank of 8 would, and a generation's 8 owner bins -- contiguous in the send
+    // buffer -- stand for what that rank would receive from its 8 peers (the same volume, statistically); nothing crosses a
+    // link.  Results are unchanged (a k-mer still lives in exactly one generation).
+    const int vworld = (world == 1 && c->virtual_world > 1) ? c->virtual_world : 1;
+    while (G > 1 && G * world * vworld > 64) G /= 2;
+    const int bins = G * world * vworld;
     const int uw = wide ? 4 : 2;                                  // 8-byte words per record
     RFX_HIP(hipSetDevice(ctx->device));
     NcclApi &n = nccl();
@@ -271,10 +278,14 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
 
     // 2. every rank's counts to every rank: row r = what rank r holds for each (generation, owner) bin
     int64_t *h_mine = c->h_tab, *h_all = c->h_tab + 64;
-    for (int b = 0; b < bins; b++) h_mine[b] = h_off[b + 1] - h_off[b];
-    RFX_HIP(hipMemcpyAsync(c->d_tab, h_mine, (size_t)bins * 8, hipMemcpyHostToDevice, c->xs));
-    RFX_NCCL(n.AllGather(c->d_tab, c->d_tab + 64, (size_t)bins, ncclInt64, c->comm, c->xs));
-    RFX_HIP(hipMemcpyAsync(h_all, c->d_tab + 64, (size_t)bins * world * 8, hipMemcpyDeviceToHost, c->xs));
+    if (vworld > 1) {                                     // fold a generation's virtual owners into the one real rank
+        for (int g = 0; g < G; g++) h_off[g + 1] = h_off[(g + 1) * vworld];
+    }
+    const int rbins = G * world;                          // bins of the real exchange
+    for (int b = 0; b < rbins; b++) h_mine[b] = h_off[b + 1] - h_off[b];
+    RFX_HIP(hipMemcpyAsync(c->d_tab, h_mine, (size_t)rbins * 8, hipMemcpyHostToDevice, c->xs));
+    RFX_NCCL(n.AllGather(c->d_tab, c->d_tab + 64, (size_t)rbins, ncclInt64, c->comm, c->xs));
+    RFX_HIP(hipMemcpyAsync(h_all, c->d_tab + 64, (size_t)rbins * world * 8, hipMemcpyDeviceToHost, c->xs));
     RFX_HIP(hipStreamSynchronize(c->xs));
     // receive layout: generation after generation, inside a generation source after source
     std::vector<int64_t> gen_off(G + 1, 0), roff((size_t)G * world), rcnt((size_t)G * world), soff((size_t)G * world), scnt((size_t)G * world);
@@ -282,10 +293,10 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
     for (int g = 0; g < G; g++) {
         int64_t pos = gen_off[g];
         for (int s = 0; s < world; s++) {
-            const int64_t u = h_all[(size_t)s * bins + (size_t)g * world + me];
+            const int64_t u = h_all[(size_t)s * rbins + (size_t)g * world + me];
             roff[(size_t)g * world + s] = pos * uw; rcnt[(size_t)g * world + s] = u * uw;
             pos += u;
-            for (int p = 0; p < world; p++) mx = std::max(mx, h_all[(size_t)s * bins + (size_t)g * world + p] * uw);
+            for (int p = 0; p < world; p++) mx = std::max(mx, h_all[(size_t)s * rbins + (size_t)g * world + p] * uw);
         }
         gen_off[g + 1] = pos;
         for (int p = 0; p < world; p++) {

@@ -23,7 +23,9 @@ struct rfx_ctx {
     // grow-only workspace slots for the large, reused buffers (instance arrays of the count
     // stage): allocated once with hipMalloc, kept until the context dies
     struct WsSlot { void *p = nullptr; size_t bytes = 0; };
-    WsSlot ws[5];          // 0, 1: the count stage's record / instance buffers; 2, 3: the extend stage's arenas; 4: the count stage's arena
+    WsSlot ws[7];          // 0, 1: the count stage's record / instance buffers; 2, 3: the extend stage's arenas; 4: the count stage's arena;
+                           // 5, 6: rfx_assemble_reads' ASCII staging and packed reads (multi-gigabyte stream-ordered allocations of
+                           // changing sizes cost 100-600 ms a call in the pool; these are allocated once and kept)
     void *ws_get(int slot, size_t bytes) {
         WsSlot &w = ws[slot];
         if (w.bytes >= bytes && w.p) return w.p;

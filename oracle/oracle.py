@@ -35,7 +35,7 @@ class _Records(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liborc.so")
-    srcs = [os.path.join(_HERE, f) for f in ("reflexiv_oracle.c", "reflexiv_dedup.c", "reflexiv_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("reflexiv_oracle.c", "reflexiv_dedup.c", "reflexiv_dynamic.c", "reflexiv_oracle.h", "Makefile")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liborc.so"])
     return so
@@ -64,6 +64,8 @@ def lib():
         L.orc_count_reads_omp.restype = C.c_int64
         L.orc_count_reads_range_omp.restype = C.c_int64
         L.orc_count_reads_w2_range_omp.restype = C.c_int64
+        L.orc_dyn_extend_pass.restype = C.c_int64
+        L.orc_dyn_random_reflection.restype = C.c_int64
         L.orc_dedup_contigs.restype = C.c_int64
         L.orc_dedup_text.restype = C.c_int64
         for f in ("orc_double_w", "orc_key_filter_w", "orc_flip_all_w"):
@@ -546,3 +548,172 @@ def dedup_contigs(contigs, min_contig=500):
     tb = np.empty(max(1, ln), np.uint8)
     lib().orc_dedup_text(_p(bufs[2]), _p(offs[2]), C.c_int64(m), min_contig, _p(tb), C.c_int64(ln))
     return dict(rounds=rounds, pairs=[int(x) for x in rp], candidates=[int(x) for x in rc], text=bytes(tb[:ln]).decode())
+
+
+# ---------------------------------------------------------------- f-2: dynamic-k record format and passes
+
+_CODE = np.full(256, 3, np.uint8)
+_CODE[ord("A")], _CODE[ord("C")], _CODE[ord("G")] = 0, 1, 2
+_NUC = np.frombuffer(b"ACGT", np.uint8)
+
+
+@dataclass
+class DynRecords:
+    """the dynamic-k record set at sequence level: keys and extensions as base codes (0..3) with offsets"""
+    key: np.ndarray        # uint8
+    key_off: np.ndarray    # int64 [n+1]
+    ext: np.ndarray        # uint8
+    ext_off: np.ndarray    # int64 [n+1]
+    marker: np.ndarray     # int32
+    left: np.ndarray       # int32
+    right: np.ndarray      # int32
+
+    @property
+    def n(self):
+        return len(self.marker)
+
+    def rows(self):
+        """text rows as DSBinarySubKmerWith{Short,Long}ExtensionToString writes them"""
+        out = []
+        for i in range(self.n):
+            k = bytes(_NUC[self.key[self.key_off[i]:self.key_off[i + 1]]]).decode()
+            e = bytes(_NUC[self.ext[self.ext_off[i]:self.ext_off[i + 1]]]).decode()
+            out.append((k, f"{int(self.marker[i])}|{int(self.left[i])}|{int(self.right[i])}", e))
+        return out
+
+
+def _dyn_pack(keys, exts, markers, lefts, rights):
+    ko = np.zeros(len(keys) + 1, np.int64); ko[1:] = np.cumsum([len(x) for x in keys])
+    eo = np.zeros(len(exts) + 1, np.int64); eo[1:] = np.cumsum([len(x) for x in exts])
+    kb = _CODE[np.frombuffer("".join(keys).encode(), np.uint8)] if ko[-1] else np.zeros(0, np.uint8)
+    eb = _CODE[np.frombuffer("".join(exts).encode(), np.uint8)] if eo[-1] else np.zeros(0, np.uint8)
+    clamp = lambda v: max(-30000, min(30000, int(v)))
+    return DynRecords(np.ascontiguousarray(kb), ko, np.ascontiguousarray(eb), eo, np.array(markers, np.int32),
+                      np.array([clamp(v) for v in lefts], np.int32), np.array([clamp(v) for v in rights], np.int32))
+
+
+def _attr(s):
+    if s.endswith(")"):
+        s = s[:-1]
+    a = s.split("|")
+    return int(a[0]), int(a[1]), int(a[2])
+
+
+def dyn_binarize_kmers(rows):
+    """DynamicKmerBinarizerFromReducedToSubKmer of FirstFour (:2931-3016): (k-mer text, "m|l|r") -> records: key = the
+    k-mer without its last base, extension = that base, orientation forced to 1"""
+    keys, exts, mk, lf, rt = [], [], [], [], []
+    for kmer, attr in rows:
+        if kmer.startswith("("):
+            kmer = kmer[1:]
+        _, l, r = _attr(attr)
+        keys.append(kmer[:-1]); exts.append(kmer[-1]); mk.append(1); lf.append(l); rt.append(r)
+    return _dyn_pack(keys, exts, mk, lf, rt)
+
+
+def dyn_binarize_rows(rows):
+    """DynamicKmerBinarizerFromReducedToSubKmer of Iteration: (sub-k-mer text, "m|l|r", extension text) -> records"""
+    keys, exts, mk, lf, rt = [], [], [], [], []
+    for k, attr, e in rows:
+        if k.startswith("("):
+            k = k[1:]
+        m, l, r = _attr(attr)
+        keys.append(k); exts.append(e); mk.append(m); lf.append(l); rt.append(r)
+    return _dyn_pack(keys, exts, mk, lf, rt)
+
+
+def dyn_gather(r: DynRecords, perm):
+    keys = [r.key[r.key_off[i]:r.key_off[i + 1]] for i in perm]
+    exts = [r.ext[r.ext_off[i]:r.ext_off[i + 1]] for i in perm]
+    ko = np.zeros(len(perm) + 1, np.int64); ko[1:] = np.cumsum([len(x) for x in keys])
+    eo = np.zeros(len(perm) + 1, np.int64); eo[1:] = np.cumsum([len(x) for x in exts])
+    cat = lambda xs: np.ascontiguousarray(np.concatenate(xs)) if len(xs) and sum(len(x) for x in xs) else np.zeros(0, np.uint8)
+    perm = np.asarray(perm, np.int64)
+    return DynRecords(cat(keys), ko, cat(exts), eo, r.marker[perm].copy(), r.left[perm].copy(), r.right[perm].copy())
+
+
+def dyn_sort(r: DynRecords):
+    """sort("k-1") on the block form: element by element as signed longs, a proper prefix first; stable"""
+    perm = np.empty(r.n, np.int64)
+    lib().orc_dyn_sort_perm(_p(r.key), _p(r.key_off), C.c_int64(r.n), _p(perm))
+    return dyn_gather(r, perm)
+
+
+def dyn_partition_starts(r: DynRecords, P: int):
+    """floor(p*n/P) moved forward past EQUAL keys (the order contract)"""
+    n = r.n
+    st, prev = [], 0
+    key = lambda i: bytes(r.key[r.key_off[i]:r.key_off[i + 1]])
+    for p in range(P):
+        s = max(p * n // P, prev)
+        while 0 < s < n and key(s) == key(s - 1):
+            s += 1
+        st.append(s); prev = s
+    st.append(n)
+    return np.array(st, np.int64)
+
+
+def _dyn_out(n_cap, k_cap, e_cap):
+    return (np.empty(max(1, k_cap), np.uint8), np.empty(n_cap + 1, np.int64), np.empty(max(1, e_cap), np.uint8), np.empty(n_cap + 1, np.int64),
+            np.empty(max(1, n_cap), np.int32), np.empty(max(1, n_cap), np.int32), np.empty(max(1, n_cap), np.int32))
+
+
+def _dyn_trim(o, m, nk, ne):
+    ko = o[1][:m + 1].copy(); ko[m] = nk
+    eo = o[3][:m + 1].copy(); eo[m] = ne
+    return DynRecords(o[0][:nk].copy(), ko, o[2][:ne].copy(), eo, o[4][:m].copy(), o[5][:m].copy(), o[6][:m].copy())
+
+
+def dyn_random_reflection(r: DynRecords, part_start):
+    part_start = np.ascontiguousarray(part_start, np.int64)
+    kc, ec = len(r.key) + len(r.ext), len(r.key) + len(r.ext)
+    o = _dyn_out(r.n, kc, ec)
+    m = lib().orc_dyn_random_reflection(_p(r.key), _p(r.key_off), _p(r.marker), _p(r.ext), _p(r.ext_off), _p(r.left), _p(r.right),
+                                        C.c_int64(r.n), _p(part_start), len(part_start) - 1, _p(o[0]), C.c_int64(kc), _p(o[1]), _p(o[2]),
+                                        C.c_int64(ec), _p(o[3]), _p(o[4]), _p(o[5]), _p(o[6]), C.c_int64(r.n))
+    return _dyn_trim(o, m, int(r.key_off[-1]), int(r.ext_off[-1]))
+
+
+def dyn_extend_pass(r: DynRecords, part_start, stage=0, start_iteration=5, start_marker=2):
+    """one pass over rows sorted by key: stage 0 DSExtendReflexivKmer (FirstFour), 1 DSExtendReflexivKmerToArrayLoop"""
+    part_start = np.ascontiguousarray(part_start, np.int64)
+    P = len(part_start) - 1
+    kc, ec = len(r.key) + len(r.ext) + 8, len(r.key) + len(r.ext) + 8
+    o = _dyn_out(r.n, kc, ec)
+    ops = np.empty(P + 1, np.int64)
+    nk, ne = C.c_int64(0), C.c_int64(0)
+    m = lib().orc_dyn_extend_pass(_p(r.key), _p(r.key_off), _p(r.marker), _p(r.ext), _p(r.ext_off), _p(r.left), _p(r.right), C.c_int64(r.n),
+                                  _p(part_start), P, stage, start_iteration, start_marker, _p(o[0]), C.c_int64(kc), _p(o[1]), _p(o[2]),
+                                  C.c_int64(ec), _p(o[3]), _p(o[4]), _p(o[5]), _p(o[6]), C.c_int64(r.n), _p(ops), C.byref(nk), C.byref(ne))
+    assert nk.value <= kc and ne.value <= ec
+    return _dyn_trim(o, m, int(nk.value), int(ne.value)), ops
+
+
+def dyn_first_four(rows, P=1):
+    """FirstFour.assemblyFromKmer (:137-224) on (k-mer text, "m|l|r") rows -> text rows; plus the rows after every operator"""
+    trace = []
+    r = dyn_binarize_kmers(rows)
+    trace.append(("binarized", r.rows()))
+    n = r.n
+    st = np.array([p * n // P for p in range(P)] + [n], np.int64)
+    r = dyn_random_reflection(r, st)
+    trace.append(("random_reflection", r.rows()))
+    for it in range(4):
+        r = dyn_sort(r)
+        r, _ = dyn_extend_pass(r, dyn_partition_starts(r, P), 0)
+        trace.append((f"extend{it}", r.rows()))
+    return r.rows(), trace
+
+
+def dyn_iterations(rows, P=1, start=5, end=9):
+    """Iteration.assemblyFromKmer (:134-205) on text rows -> text rows; plus the rows after every pass"""
+    trace = []
+    r = dyn_binarize_rows(rows)
+    trace.append(("it_binarized", r.rows()))
+    it = start
+    while it <= end:
+        it += 1
+        r = dyn_sort(r)
+        r, _ = dyn_extend_pass(r, dyn_partition_starts(r, P), 1, start)
+        trace.append((f"it_extend{it}", r.rows()))
+    return r.rows(), trace

@@ -1363,6 +1363,12 @@ class _RowFactory:
 
 class _Arrays:
     @staticmethod
+    def equals(a, b):
+        if a is None or b is None:
+            return a is b
+        return len(a) == len(b) and all(_eq(x, y) if not (isinstance(x, J) and isinstance(y, J)) else x.v == y.v for x, y in zip(a, b))
+
+    @staticmethod
     def asList(*a):
         # Arrays.asList(T... a): one array argument -> a list VIEW of its elements.  (For a primitive long[] javac
         # makes a one-element List<long[]>; the operator classes then wrap that into a Scala Seq and read it back

@@ -466,6 +466,44 @@ int rfx_dedup_contigs(rfx_ctx *ctx, const uint8_t *bases_ascii, const int64_t *c
 int rfx_dedup_contig_text(rfx_ctx *ctx, const char *contig_text, int64_t len, int min_contig, char *out, int64_t cap,
                           int64_t *out_len, int64_t *out_contigs, int64_t *round_n);
 
+/* The dynamic-k record format and passes: P/ReflexivDSDynamicKmerFirstFour.java (DSkmerRandomReflection
+ * :2509-2762, DSExtendReflexivKmer :1581-2373) and P/ReflexivDSDynamicKmerIteration.java (DSExtendReflexivKmerToArrayLoop
+ * :465-1249) -- the "meta" assembler's passes on keys of ANY length (a (k-1)-mer of whichever k the reduction kept).  In
+ * a Row a key is left-aligned 31-base blocks with a 01 terminator, the attribute one long (marker << 62 | left << 32 |
+ * right, negatives as 30000 - v), the extension in the same left-aligned form; across this boundary a record set is base
+ * CODES (A0 C1 G2 T3, one byte per base) with offsets + marker / left / right (left / right as the reference reads them
+ * back: clamped to +-30000).  Two keys meet when they are equal OR one is a prefix of the other; the forward record must
+ * not be the shorter one; the merged key keeps the longer key's length.
+ *   rfx_dyn_sort               sort("k-1") as Spark orders array<long> (element by element as signed longs, a proper prefix
+ *                              first), stable, + the cut into P logical partitions (floor(p*n/P) moved past equal keys)
+ *   rfx_dyn_random_reflection  DSkmerRandomReflection.call on the given partitions
+ *   rfx_dyn_extend_pass        one pass over sorted records: stage 0 DSExtendReflexivKmer (extension in one long),
+ *                              1 DSExtendReflexivKmerToArrayLoop (start_iteration = param.startIteration: from 61 on a
+ *                              shorter forward record is dropped); start_marker 2, or 1 when param.scramble == 3
+ *   rfx_dyn_run                the drivers with the records resident in HBM between the operators:
+ *                              FirstFour.assemblyFromKmer (:137-224) = random_reflection 1, passes_first_four 4, no
+ *                              iterations (end < start); Iteration.assemblyFromKmer (:134-205) = iterations start..end
+ * Outputs: caller-allocated arrays of cap_n records / cap_key / cap_ext bases; n / need_key / need_ext are set; RFX_E_CAP
+ * when a capacity is short.  Keys of more than 124 bases: RFX_E_LIMIT (the reference's k-mer list ends at 95). */
+typedef struct {
+    int64_t n;
+    uint8_t *key; int64_t *key_off;      /* key i = key[key_off[i] .. key_off[i+1]) */
+    uint8_t *ext; int64_t *ext_off;
+    int32_t *marker, *left, *right;
+    int64_t cap_n, cap_key, cap_ext, need_key, need_ext;
+} rfx_dyn_records;
+int rfx_dyn_sort(rfx_ctx *ctx, const rfx_dyn_records *in, int P, rfx_dyn_records *out, int64_t *part_start);
+int rfx_dyn_random_reflection(rfx_ctx *ctx, const rfx_dyn_records *in, const int64_t *part_start, int P, rfx_dyn_records *out);
+int rfx_dyn_extend_pass(rfx_ctx *ctx, const rfx_dyn_records *in, const int64_t *part_start, int P, int stage, int start_iteration,
+                        int start_marker, rfx_dyn_records *out, int64_t *out_part_start);
+int rfx_dyn_run(rfx_ctx *ctx, const rfx_dyn_records *in, int P, int random_reflection, int passes_first_four, int start_iteration,
+                int end_iteration, rfx_dyn_records *out, int64_t *trace, int64_t trace_cap, int64_t *n_trace);
+/* the Row form of the layout, for the shim that converts: blocks <-> base codes, the attribute long <-> its three ints */
+int rfx_dyn_blocks_to_bases(const int64_t *blocks, int n_blocks, uint8_t *out, int cap);
+int rfx_dyn_bases_to_blocks(const uint8_t *bases, int n, int64_t *out, int cap);
+int64_t rfx_dyn_attribute(int marker, int left, int right);
+void rfx_dyn_attribute_unpack(int64_t attribute, int *marker, int *left, int *right);
+
 /* Synthetic reads: integer-only counter-based generator, bit-identical to
  * oracle/reflexiv_oracle.c orc_synth_*.  Writes packed reads straight into HBM. */
 int rfx_dev_synth_genome(rfx_ctx *ctx, uint64_t seed, int64_t genome_len, uint64_t *d_genome);

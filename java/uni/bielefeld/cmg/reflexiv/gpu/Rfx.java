@@ -73,6 +73,16 @@ public final class Rfx {
     /** ReflexivDSDynamicKmerDedup.assemblyFromKmer on a run's contig text: every contig once (rfx_dedup_contig_text) */
     public static native byte[] dedupContigText(long ctx, byte[] contigText, int minContig);
 
+    /**
+     * The dynamic-k ("meta") passes of ReflexivDSDynamicKmerFirstFour / ReflexivDSDynamicKmerIteration on flattened rows
+     * (long[] blocks back to back with block offsets, the packed attribute long per row): randomReflection + passesFirstFour = 4
+     * is FirstFour.assemblyFromKmer, startIteration..endIteration is Iteration.assemblyFromKmer.  Returns the number of rows
+     * written to the out arrays (rfx_dyn_run).
+     */
+    public static native long dynRun(long ctx, long[] keyBlocks, long[] keyOff, long[] extBlocks, long[] extOff, long[] attribute, int P,
+                                     int randomReflection, int passesFirstFour, int startIteration, int endIteration,
+                                     long[] outKeyBlocks, long[] outKeyOff, long[] outExtBlocks, long[] outExtOff, long[] outAttribute);
+
     // several GPUs of one node: the shuffle of reduceByKey as an RCCL all-to-all inside the library (rfx_comm_*,
     // rfx_sharded_assemble_reads); one barrier task per GPU, see ReflexivGpuMain.assemblyResidentSharded()
     public static native byte[] commUniqueId();

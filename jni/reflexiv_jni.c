@@ -526,3 +526,85 @@ JNIEXPORT jbyteArray JNICALL RFX_CLASS(dedupContigText)(JNIEnv *env, jclass c, j
     if (st != RFX_OK) { throw_rfx(env, ctx, st, "rfx_dedup_contig_text"); return NULL; }
     return out;
 }
+
+
+/* ---------------------------------------------------------------------------- the dynamic-k ("meta") passes */
+
+/* DSExtendReflexivKmer / DSExtendReflexivKmerToArrayLoop of ReflexivDSDynamicKmerFirstFour / ...Iteration on one task's rows
+ * (P/ReflexivDSDynamicKmerFirstFour.java:1581-2373, P/ReflexivDSDynamicKmerIteration.java:465-1249).  Rows travel flattened:
+ * keyBlocks / extBlocks = the rows' long[] blocks back to back with keyOff / extOff (in blocks), attribute = the packed long.
+ * The shim converts to the library's base-code form (rfx_dyn_blocks_to_bases / rfx_dyn_attribute_unpack), runs
+ * rfx_dyn_run (random_reflection, passes, iterations as for the drivers) and converts back; the result arrays come back in
+ * a long[4][] = {keyBlocks, keyOff, extBlocks, extOff} plus outAttr (sized by the caller to the input row count). */
+JNIEXPORT jlong JNICALL RFX_CLASS(dynRun)(JNIEnv *env, jclass c, jlong h, jlongArray keyBlocks, jlongArray keyOff, jlongArray extBlocks,
+                                         jlongArray extOff, jlongArray attr, jint P, jint randomReflection, jint passesFirstFour,
+                                         jint startIteration, jint endIteration, jlongArray outKeyBlocks, jlongArray outKeyOff,
+                                         jlongArray outExtBlocks, jlongArray outExtOff, jlongArray outAttr) {
+    (void)c;
+    rfx_ctx *ctx = ctx_of(h);
+    const jsize n = (*env)->GetArrayLength(env, attr);
+    int64_t *kb = longs_in(env, keyBlocks), *ko = longs_in(env, keyOff), *eb = longs_in(env, extBlocks), *eo = longs_in(env, extOff),
+            *at = longs_in(env, attr);
+    const int64_t nkb = ko[n], neb = eo[n];
+    /* to base codes */
+    uint8_t *key = (uint8_t *)malloc((size_t)nkb * 31 + 1), *ext = (uint8_t *)malloc((size_t)neb * 31 + 1);
+    int64_t *koff = (int64_t *)malloc((size_t)(n + 1) * 8), *eoff = (int64_t *)malloc((size_t)(n + 1) * 8);
+    int32_t *mk = (int32_t *)malloc((size_t)(n + 1) * 4), *lf = (int32_t *)malloc((size_t)(n + 1) * 4), *rt = (int32_t *)malloc((size_t)(n + 1) * 4);
+    int64_t pk = 0, pe = 0;
+    int st = RFX_OK;
+    for (jsize i = 0; i < n && st == RFX_OK; i++) {
+        koff[i] = pk; eoff[i] = pe;
+        const int lk = rfx_dyn_blocks_to_bases(kb + ko[i], (int)(ko[i + 1] - ko[i]), key + pk, (int)((ko[i + 1] - ko[i]) * 31));
+        const int le = rfx_dyn_blocks_to_bases(eb + eo[i], (int)(eo[i + 1] - eo[i]), ext + pe, (int)((eo[i + 1] - eo[i]) * 31));
+        if (lk < 0 || le < 0) st = RFX_E_ARG;
+        pk += lk > 0 ? lk : 0; pe += le > 0 ? le : 0;
+        int m, l, r;
+        rfx_dyn_attribute_unpack(at[i], &m, &l, &r);
+        mk[i] = m; lf[i] = l; rt[i] = r;
+    }
+    koff[n] = pk; eoff[n] = pe;
+    rfx_dyn_records in = {n, key, koff, ext, eoff, mk, lf, rt, n, pk, pe, 0, 0};
+    int64_t cap_b = pk + pe + 64, out_n = 0;
+    uint8_t *okey = NULL, *oext = NULL;
+    int64_t *okoff = (int64_t *)malloc((size_t)(n + 1) * 8), *oeoff = (int64_t *)malloc((size_t)(n + 1) * 8);
+    int32_t *omk = (int32_t *)malloc((size_t)(n + 1) * 4), *olf = (int32_t *)malloc((size_t)(n + 1) * 4), *ort = (int32_t *)malloc((size_t)(n + 1) * 4);
+    while (st == RFX_OK) {
+        free(okey); free(oext);
+        okey = (uint8_t *)malloc((size_t)cap_b); oext = (uint8_t *)malloc((size_t)cap_b);
+        rfx_dyn_records out = {0, okey, okoff, oext, oeoff, omk, olf, ort, n, cap_b, cap_b, 0, 0};
+        int64_t ntr = 0;
+        st = rfx_dyn_run(ctx, &in, P, randomReflection, passesFirstFour, startIteration, endIteration, &out, NULL, 0, &ntr);
+        if (st == RFX_E_CAP) { cap_b = (out.need_key > out.need_ext ? out.need_key : out.need_ext) + 64; st = RFX_OK; continue; }
+        out_n = out.n;
+        break;
+    }
+    if (st == RFX_OK) {                                              /* back to blocks, into the caller's arrays */
+        const jsize capK = (*env)->GetArrayLength(env, outKeyBlocks), capE = (*env)->GetArrayLength(env, outExtBlocks);
+        int64_t *okb = (int64_t *)malloc((size_t)capK * 8 + 8), *oeb = (int64_t *)malloc((size_t)capE * 8 + 8);
+        int64_t *oko = (int64_t *)malloc((size_t)(n + 1) * 8), *oeo = (int64_t *)malloc((size_t)(n + 1) * 8), *oat = (int64_t *)malloc((size_t)(n + 1) * 8);
+        int64_t bk = 0, be = 0;
+        for (int64_t i = 0; i < out_n && st == RFX_OK; i++) {
+            oko[i] = bk; oeo[i] = be;
+            const int nk = rfx_dyn_bases_to_blocks(okey + okoff[i], (int)(okoff[i + 1] - okoff[i]), okb + bk, (int)(capK - bk));
+            const int ne = rfx_dyn_bases_to_blocks(oext + oeoff[i], (int)(oeoff[i + 1] - oeoff[i]), oeb + be, (int)(capE - be));
+            if (nk < 0 || ne < 0) { st = RFX_E_CAP; break; }
+            bk += nk; be += ne;
+            oat[i] = rfx_dyn_attribute(omk[i], olf[i], ort[i]);
+        }
+        oko[out_n] = bk; oeo[out_n] = be;
+        if (st == RFX_OK) {
+            (*env)->SetLongArrayRegion(env, outKeyBlocks, 0, (jsize)bk, (const jlong *)okb);
+            (*env)->SetLongArrayRegion(env, outExtBlocks, 0, (jsize)be, (const jlong *)oeb);
+            (*env)->SetLongArrayRegion(env, outKeyOff, 0, (jsize)(out_n + 1), (const jlong *)oko);
+            (*env)->SetLongArrayRegion(env, outExtOff, 0, (jsize)(out_n + 1), (const jlong *)oeo);
+            (*env)->SetLongArrayRegion(env, outAttr, 0, (jsize)out_n, (const jlong *)oat);
+        }
+        free(okb); free(oeb); free(oko); free(oeo); free(oat);
+    }
+    free(key); free(ext); free(koff); free(eoff); free(mk); free(lf); free(rt);
+    free(okey); free(oext); free(okoff); free(oeoff); free(omk); free(olf); free(ort);
+    longs_out(env, keyBlocks, kb, 0); longs_out(env, keyOff, ko, 0); longs_out(env, extBlocks, eb, 0); longs_out(env, extOff, eo, 0);
+    longs_out(env, attr, at, 0);
+    if (st != RFX_OK) { throw_rfx(env, ctx, st, "rfx_dyn_run"); return 0; }
+    return (jlong)out_n;
+}

@@ -104,14 +104,19 @@ static void put(dout *o, const uint8_t *k1, int32_t k1n, const uint8_t *k2, int3
 
 /* singleKmerRandomizer (FirstFour:1857-1930 / Iteration singleKmerRandomizer): the record in orientation m */
 static void flip_emit(dout *o, const drec *r, int m) {
-    if (r->marker == 1 && m == 2) {
-        /* key' = key[|ext|:] + ext, ext' = key[:|ext|] */
-        const int32_t e = r->elen > r->klen ? r->klen : r->elen;
-        put(o, r->key + e, r->klen - e, r->ext, r->elen, r->key, e, NULL, 0, 2, r->left, r->right);
-    } else if (r->marker == 2 && m == 1) {
-        int32_t remain = r->klen - r->elen;
-        if (remain < 0) remain = 0;
-        put(o, r->ext, r->elen, r->key, remain, r->key + remain, r->klen - remain, NULL, 0, 1, r->left, r->right);
+    /* (written for any lengths as Iteration's array form does it: combined = key + ext, key' = combined[|ext|:],
+     * ext' = combined[:|ext|]; FirstFour's single-long form is the same whenever |ext| <= |key|, which its four passes keep) */
+    if ((r->marker == 1 && m == 2) || (r->marker == 2 && m == 1)) {
+        const int32_t kl = r->klen, el = r->elen;
+        uint8_t *c = (uint8_t *)malloc((size_t)(kl + el + 1));
+        if (r->marker == 1) {
+            memcpy(c, r->key, (size_t)kl); memcpy(c + kl, r->ext, (size_t)el);
+            put(o, c + el, kl, NULL, 0, c, el, NULL, 0, 2, r->left, r->right);
+        } else {
+            memcpy(c, r->ext, (size_t)el); memcpy(c + el, r->key, (size_t)kl);
+            put(o, c, kl, NULL, 0, c + kl, el, NULL, 0, 1, r->left, r->right);
+        }
+        free(c);
     } else {
         put(o, r->key, r->klen, NULL, 0, r->ext, r->elen, NULL, 0, r->marker, r->left, r->right);
     }

@@ -32,6 +32,13 @@ class Params(C.Structure):
         "front_clip", "end_clip", "partitions", "twin", "coalesce", "extras")]
 
 
+class CDynRecords(C.Structure):
+    """rfx_dyn_records."""
+    _fields_ = [("n", C.c_int64), ("key", C.c_void_p), ("key_off", C.c_void_p), ("ext", C.c_void_p), ("ext_off", C.c_void_p),
+                ("marker", C.c_void_p), ("left", C.c_void_p), ("right", C.c_void_p), ("cap_n", C.c_int64), ("cap_key", C.c_int64),
+                ("cap_ext", C.c_int64), ("need_key", C.c_int64), ("need_ext", C.c_int64)]
+
+
 class CRecords(C.Structure):
     """rfx_records."""
     _fields_ = [("n", C.c_int64), ("key", C.c_void_p), ("marker", C.c_void_p), ("ext_off", C.c_void_p),
@@ -60,6 +67,8 @@ SYMBOLS = [
     "rfx_comm_unique_id", "rfx_comm_init", "rfx_comm_destroy", "rfx_comm_rank", "rfx_comm_world", "rfx_comm_last_bytes_bucketed",
     "rfx_comm_all_reduce_i64", "rfx_dev_sharded_count", "rfx_dev_gather_shards", "rfx_sharded_assemble_reads",
     "rfx_dedup_contigs", "rfx_dedup_contig_text",
+    "rfx_dyn_sort", "rfx_dyn_random_reflection", "rfx_dyn_extend_pass", "rfx_dyn_run",
+    "rfx_dyn_blocks_to_bases", "rfx_dyn_bases_to_blocks", "rfx_dyn_attribute", "rfx_dyn_attribute_unpack",
 ]
 
 
@@ -99,6 +108,13 @@ def lib():
             fn = getattr(L, name)
             if name == "rfx_kmers_per_read_w":
                 fn.restype = C.c_int64
+                continue
+            if name == "rfx_dyn_attribute":
+                fn.restype = C.c_int64
+                fn.argtypes = [C.c_int, C.c_int, C.c_int]
+                continue
+            if name == "rfx_dyn_attribute_unpack":
+                fn.restype = None
                 continue
             if name == "rfx_comm_last_bytes_bucketed":
                 fn.restype = C.c_int64

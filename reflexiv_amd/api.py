@@ -68,6 +68,84 @@ class Records:
                        self.ext[:w].copy(), self.left[:n].copy(), self.right[:n].copy())
 
 
+_DYN_CODE = np.full(256, 3, np.uint8)
+_DYN_CODE[ord("A")], _DYN_CODE[ord("C")], _DYN_CODE[ord("G")] = 0, 1, 2      # nucleotideValue: A0 C1 G2, anything else 3
+_DYN_NUC = np.frombuffer(b"ACGT", np.uint8)
+
+
+@dataclass
+class DynRecords:
+    """The dynamic-k record set across the C ABI (rfx_dyn_records): keys and extensions as base codes with offsets."""
+    key: np.ndarray        # uint8
+    key_off: np.ndarray    # int64 [n+1]
+    ext: np.ndarray        # uint8
+    ext_off: np.ndarray    # int64 [n+1]
+    marker: np.ndarray     # int32
+    left: np.ndarray       # int32
+    right: np.ndarray      # int32
+
+    @property
+    def n(self) -> int:
+        return len(self.marker)
+
+    def _c(self) -> "_lib.CDynRecords":
+        c = _lib.CDynRecords()
+        c.n = self.n
+        c.key, c.key_off, c.ext, c.ext_off = (self.key.ctypes.data, self.key_off.ctypes.data, self.ext.ctypes.data, self.ext_off.ctypes.data)
+        c.marker, c.left, c.right = self.marker.ctypes.data, self.left.ctypes.data, self.right.ctypes.data
+        return c
+
+    @staticmethod
+    def empty(cap_n: int, cap_key: int, cap_ext: int) -> "DynRecords":
+        return DynRecords(np.empty(max(1, cap_key), np.uint8), np.empty(cap_n + 1, np.int64), np.empty(max(1, cap_ext), np.uint8),
+                          np.empty(cap_n + 1, np.int64), np.empty(max(1, cap_n), np.int32), np.empty(max(1, cap_n), np.int32),
+                          np.empty(max(1, cap_n), np.int32))
+
+    def _trim(self, c) -> "DynRecords":
+        n = int(c.n)
+        return DynRecords(self.key[:c.need_key].copy(), self.key_off[:n + 1].copy(), self.ext[:c.need_ext].copy(), self.ext_off[:n + 1].copy(),
+                          self.marker[:n].copy(), self.left[:n].copy(), self.right[:n].copy())
+
+    def rows(self):
+        """the text rows DSBinarySubKmerWith{Short,Long}ExtensionToString write (FirstFour:226-263): (key, "m|l|r", extension)"""
+        out = []
+        for i in range(self.n):
+            k = bytes(_DYN_NUC[self.key[self.key_off[i]:self.key_off[i + 1]]]).decode()
+            e = bytes(_DYN_NUC[self.ext[self.ext_off[i]:self.ext_off[i + 1]]]).decode()
+            out.append((k, f"{int(self.marker[i])}|{int(self.left[i])}|{int(self.right[i])}", e))
+        return out
+
+    @staticmethod
+    def from_text(keys, exts, markers, lefts, rights) -> "DynRecords":
+        ko = np.zeros(len(keys) + 1, np.int64); ko[1:] = np.cumsum([len(x) for x in keys])
+        eo = np.zeros(len(exts) + 1, np.int64); eo[1:] = np.cumsum([len(x) for x in exts])
+        kb = _DYN_CODE[np.frombuffer("".join(keys).encode(), np.uint8)] if ko[-1] else np.zeros(1, np.uint8)
+        eb = _DYN_CODE[np.frombuffer("".join(exts).encode(), np.uint8)] if eo[-1] else np.zeros(1, np.uint8)
+        cl = lambda v: max(-30000, min(30000, int(v)))             # buildingAlongFromThreeInt read back (FirstFour:2340-2366)
+        return DynRecords(np.ascontiguousarray(kb), ko, np.ascontiguousarray(eb), eo, np.array(markers, np.int32),
+                          np.array([cl(v) for v in lefts], np.int32), np.array([cl(v) for v in rights], np.int32))
+
+    @staticmethod
+    def from_kmer_rows(rows) -> "DynRecords":
+        """DynamicKmerBinarizerFromReducedToSubKmer of FirstFour (:2931-3016): (k-mer text, "m|l|r") rows"""
+        keys, exts, mk, lf, rt = [], [], [], [], []
+        for kmer, attr in rows:
+            kmer = kmer[1:] if kmer.startswith("(") else kmer
+            a = (attr[:-1] if attr.endswith(")") else attr).split("|")
+            keys.append(kmer[:-1]); exts.append(kmer[-1]); mk.append(1); lf.append(int(a[1])); rt.append(int(a[2]))
+        return DynRecords.from_text(keys, exts, mk, lf, rt)
+
+    @staticmethod
+    def from_rows(rows) -> "DynRecords":
+        """DynamicKmerBinarizerFromReducedToSubKmer of Iteration: (sub-k-mer text, "m|l|r", extension text) rows"""
+        keys, exts, mk, lf, rt = [], [], [], [], []
+        for k, attr, e in rows:
+            k = k[1:] if k.startswith("(") else k
+            a = (attr[:-1] if attr.endswith(")") else attr).split("|")
+            keys.append(k); exts.append(e); mk.append(int(a[0])); lf.append(int(a[1])); rt.append(int(a[2]))
+        return DynRecords.from_text(keys, exts, mk, lf, rt)
+
+
 def as_records(r) -> Records:
     """Accept any object with key/marker/ext_off/ext/left/right arrays (e.g. the oracle's Records)."""
     return Records(np.ascontiguousarray(r.key, np.uint64), np.ascontiguousarray(r.marker, np.int32),
@@ -566,6 +644,49 @@ class Reflexiv:
     def assemble_reads(self, bases, read_off, prm: Params):
         bases = np.ascontiguousarray(bases, np.uint8)
         return self.assemble_reads_ptr(bases.ctypes.data, len(bases), read_off, prm)
+
+    # ------------------------------------------------ f-2: the dynamic-k record format and passes
+    def _dyn_call(self, fn, name, r: DynRecords, make_args, grow=1):
+        cap_n = r.n * grow
+        cap_b = (len(r.key) + len(r.ext)) * grow + 64
+        while True:
+            out = DynRecords.empty(cap_n, cap_b, cap_b)
+            ci, co = r._c(), out._c()
+            co.cap_n, co.cap_key, co.cap_ext = cap_n, cap_b, cap_b
+            st = fn(self.ctx, C.byref(ci), *make_args(co))
+            if st == RFX_E_CAP:
+                cap_n = max(cap_n, int(co.n)); cap_b = max(cap_b, int(co.need_key), int(co.need_ext)) + 64
+                continue
+            self._check(st, name)
+            return out._trim(co)
+
+    def dyn_sort(self, r: DynRecords, P: int):
+        """rfx_dyn_sort -> (sorted DynRecords, part_start[P+1])"""
+        ps = np.empty(P + 1, np.int64)
+        out = self._dyn_call(self.L.rfx_dyn_sort, "rfx_dyn_sort", r, lambda co: (P, C.byref(co), _p(ps)))
+        return out, ps
+
+    def dyn_random_reflection(self, r: DynRecords, part_start):
+        part_start = np.ascontiguousarray(part_start, np.int64)
+        return self._dyn_call(self.L.rfx_dyn_random_reflection, "rfx_dyn_random_reflection", r,
+                              lambda co: (_p(part_start), len(part_start) - 1, C.byref(co)))
+
+    def dyn_extend_pass(self, r: DynRecords, part_start, stage=0, start_iteration=5, start_marker=2):
+        part_start = np.ascontiguousarray(part_start, np.int64)
+        P = len(part_start) - 1
+        ops = np.empty(P + 1, np.int64)
+        out = self._dyn_call(self.L.rfx_dyn_extend_pass, "rfx_dyn_extend_pass", r,
+                             lambda co: (_p(part_start), P, stage, start_iteration, start_marker, C.byref(co), _p(ops)))
+        return out, ops
+
+    def dyn_run(self, r: DynRecords, P=1, random_reflection=False, passes_first_four=0, start_iteration=1, end_iteration=0):
+        """rfx_dyn_run (records resident in HBM between the operators) -> (DynRecords, [records after each pass])"""
+        trace = np.zeros(256, np.int64)
+        ntr = C.c_int64(0)
+        out = self._dyn_call(self.L.rfx_dyn_run, "rfx_dyn_run", r,
+                             lambda co: (P, int(random_reflection), passes_first_four, start_iteration, end_iteration, C.byref(co), _p(trace),
+                                         C.c_int64(len(trace)), C.byref(ntr)))
+        return out, [int(x) for x in trace[:ntr.value]]
 
     # ------------------------------------------------ f-4: contig RC de-duplication
     def dedup_contigs(self, contigs, min_contig=500):

@@ -30,6 +30,7 @@ struct DefaultParam {
     int logicalPartitions = 8;               // --logical-partitions
     int twin = 1;                            // --twin ds|rdd
     bool resident = false;                   // --resident: one fused call, everything stays in HBM
+    int startIteration = 5, endIteration = 9;  // -start / -end of `iteration` (U/DefaultParam.java:118-119)
     bool dedup = false;                      // --dedup: the contig text through rfx_dedup_contig_text (ReflexivDSDynamicKmerDedup)
     int gpus = 1;                            // --gpus N (with --resident): one host thread + context + RCCL communicator per GPU
 
@@ -67,6 +68,8 @@ inline DefaultParam importCommandLine(const std::vector<std::string> &args) {
         else if (a == "--twin") p.twin = need(i++) == "ds" ? 0 : 1;
         else if (a == "--resident") p.resident = true;
         else if (a == "--dedup") p.dedup = true;
+        else if (a == "-start") p.startIteration = std::stoi(need(i++));
+        else if (a == "-end") p.endIteration = std::stoi(need(i++));
         else if (a == "--gpus") p.gpus = std::max(1, std::stoi(need(i++)));
         else if (a.rfind("--", 0) == 0) { /* spark-submit options are the launcher's (bin/reflexiv:209-235) */ if (i + 1 < args.size() && args[i + 1][0] != '-') i++; }
         else throw std::runtime_error("unknown parameter " + a);

@@ -300,6 +300,119 @@ std::string ReflexivMain::assemblyResident(const std::string &fastqText, std::ve
     return out;
 }
 
+namespace {
+// the record set of the dynamic-k passes on the host: base codes + offsets (rfx_dyn_records)
+struct DynHost {
+    std::vector<uint8_t> key, ext;
+    std::vector<int64_t> key_off{0}, ext_off{0};
+    std::vector<int32_t> marker, left, right;
+    rfx_dyn_records view() {
+        rfx_dyn_records r{};
+        r.n = (int64_t)marker.size();
+        r.key = key.data(); r.key_off = key_off.data(); r.ext = ext.data(); r.ext_off = ext_off.data();
+        r.marker = marker.data(); r.left = left.data(); r.right = right.data();
+        r.cap_n = r.n; r.cap_key = (int64_t)key.size(); r.cap_ext = (int64_t)ext.size();
+        return r;
+    }
+    void reserve(int64_t n, int64_t nk, int64_t ne) {
+        key.assign((size_t)std::max<int64_t>(nk, 1), 0); ext.assign((size_t)std::max<int64_t>(ne, 1), 0);
+        key_off.assign((size_t)n + 1, 0); ext_off.assign((size_t)n + 1, 0);
+        marker.assign((size_t)std::max<int64_t>(n, 1), 0); left.assign(marker.size(), 0); right.assign(marker.size(), 0);
+    }
+};
+inline uint8_t nucleotideValue(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3; }     // (FirstFour nucleotideValue)
+inline int32_t attrClamp(long v) { return v >= 30000 ? 30000 : v <= -30000 ? -30000 : (int32_t)v; } // buildingAlongFromThreeInt read back
+// one CSV row -> its comma separated fields (a leading "(" / a trailing ")" of the legacy tuple text dropped)
+std::vector<std::string> fieldsOf(const std::string &line) {
+    std::vector<std::string> f;
+    size_t p = 0;
+    while (true) {
+        size_t e = line.find(',', p);
+        f.push_back(line.substr(p, e == std::string::npos ? std::string::npos : e - p));
+        if (e == std::string::npos) break;
+        p = e + 1;
+    }
+    if (!f.empty() && !f[0].empty() && f[0][0] == '(') f[0].erase(0, 1);
+    if (!f.empty() && !f.back().empty() && f.back().back() == ')') f.back().pop_back();
+    return f;
+}
+void parseAttr(const std::string &a, long out[3]) {
+    size_t p1 = a.find('|'), p2 = a.find('|', p1 + 1);
+    out[0] = std::stol(a.substr(0, p1)); out[1] = std::stol(a.substr(p1 + 1, p2 - p1 - 1)); out[2] = std::stol(a.substr(p2 + 1));
+}
+// DynamicKmerBinarizerFromReducedToSubKmer.call: FirstFour (:2942-3016, rows "KMER,attr": key = the k-mer without its last base,
+// extension = that base, orientation 1) or Iteration (rows "SUBKMER,attr,EXTENSION")
+void dynBinarize(const std::string &csv, bool kmers, DynHost &d) {
+    size_t pos = 0;
+    d = DynHost();
+    while (pos < csv.size()) {
+        size_t e = csv.find('\n', pos);
+        if (e == std::string::npos) e = csv.size();
+        std::string line = csv.substr(pos, e - pos);
+        pos = e + 1;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        std::vector<std::string> f = fieldsOf(line);
+        if (f.size() < (kmers ? 2u : 3u)) throw std::runtime_error("dynamic-k row: " + line);
+        long a[3];
+        parseAttr(f[1], a);
+        const std::string &k = f[0];
+        const size_t kl = kmers ? k.size() - 1 : k.size();
+        for (size_t i = 0; i < kl; i++) d.key.push_back(nucleotideValue(k[i]));
+        if (kmers) d.ext.push_back(nucleotideValue(k[kl]));
+        else for (char c : f[2]) d.ext.push_back(nucleotideValue(c));
+        d.key_off.push_back((int64_t)d.key.size()); d.ext_off.push_back((int64_t)d.ext.size());
+        d.marker.push_back(kmers ? 1 : (int32_t)a[0]); d.left.push_back(attrClamp(a[1])); d.right.push_back(attrClamp(a[2]));
+    }
+    if (d.key.empty()) d.key.push_back(0);
+    if (d.ext.empty()) d.ext.push_back(0);
+}
+// DSBinarySubKmerWith{Short,Long}ExtensionToString.call (FirstFour:226-263): rows "SUBKMER,marker|left|right,EXTENSION"
+std::string dynToText(const rfx_dyn_records &r) {
+    std::string out;
+    static const char NUC[] = "ACGT";
+    for (int64_t i = 0; i < r.n; i++) {
+        for (int64_t j = r.key_off[i]; j < r.key_off[i + 1]; j++) out.push_back(NUC[r.key[j] & 3]);
+        out += "," + std::to_string(r.marker[i]) + "|" + std::to_string(r.left[i]) + "|" + std::to_string(r.right[i]) + ",";
+        for (int64_t j = r.ext_off[i]; j < r.ext_off[i + 1]; j++) out.push_back(NUC[r.ext[j] & 3]);
+        out.push_back('\n');
+    }
+    return out;
+}
+}  // namespace
+
+static std::string dynRun(rfx_ctx *ctx, DynHost &in, int P, int reflect, int four, int start, int end, std::vector<int64_t> *trace) {
+    rfx_dyn_records ri = in.view();
+    DynHost out;
+    int64_t cap_n = ri.n, cap_b = (int64_t)(in.key.size() + in.ext.size()) + 64;
+    std::vector<int64_t> tr(256);
+    int64_t nt = 0;
+    for (;;) {
+        out.reserve(cap_n, cap_b, cap_b);
+        rfx_dyn_records ro = out.view();
+        ro.cap_n = cap_n; ro.cap_key = cap_b; ro.cap_ext = cap_b;
+        const int st = rfx_dyn_run(ctx, &ri, P, reflect, four, start, end, &ro, tr.data(), (int64_t)tr.size(), &nt);
+        if (st == RFX_E_CAP) { cap_n = std::max(cap_n, ro.n); cap_b = std::max({cap_b, ro.need_key, ro.need_ext}) + 64; continue; }
+        if (st != RFX_OK) throw std::runtime_error(std::string("rfx_dyn_run: ") + rfx_last_error(ctx));
+        if (trace) trace->assign(tr.begin(), tr.begin() + nt);
+        return dynToText(ro);
+    }
+}
+
+std::string ReflexivMain::assemblyDynamicFirstFour(const std::string &csvText, std::vector<int64_t> *trace) {
+    DynHost d;
+    dynBinarize(csvText, true, d);
+    return dynRun(ctx, d, std::max(1, param.logicalPartitions), 1, 4, 1, 0, trace);
+}
+
+std::string ReflexivMain::assemblyDynamicIteration(const std::string &csvText, int startIteration, int endIteration, std::vector<int64_t> *trace) {
+    DynHost d;
+    dynBinarize(csvText, false, d);
+    // (the reference's loop runs while (iterations <= endIteration) { iterations++; ... }: endIteration - startIteration + 1 passes,
+    // every one of them under param.startIteration's rules)
+    return dynRun(ctx, d, std::max(1, param.logicalPartitions), 0, 0, startIteration, endIteration, trace);
+}
+
 std::string ReflexivMain::dedupContigText(const std::string &contigText) {
     std::string out(contigText.size() + 4096, '\0');
     int64_t len = 0, nc = 0;

@@ -141,6 +141,14 @@ public:
         void call(const std::string &csvText, std::vector<uint64_t> &kmers, std::vector<int32_t> &counts) const;
     };
     std::string assemblyFromKmer64(const std::string &csvText, std::vector<int64_t> *trace = nullptr);
+    // The dynamic-k ("meta") passes.  ReflexivDSDynamicKmerFirstFour.assemblyFromKmer
+    // (P/ReflexivDSDynamicKmerFirstFour.java:137-224): CSV rows "KMER,marker|left|right" -> DynamicKmerBinarizerFromReducedToSubKmer
+    // (:2931-3016) -> DSkmerRandomReflection -> 4 x (sort, DSExtendReflexivKmer) -> DSBinarySubKmerWithShortExtensionToString
+    // (:226-263) rows "SUBKMER,marker|left|right,EXTENSION".  ReflexivDSDynamicKmerIteration.assemblyFromKmer
+    // (P/ReflexivDSDynamicKmerIteration.java:134-205): those rows -> (end - start + 1) x (sort, DSExtendReflexivKmerToArrayLoop).
+    std::string assemblyDynamicFirstFour(const std::string &csvText, std::vector<int64_t> *trace = nullptr);
+    std::string assemblyDynamicIteration(const std::string &csvText, int startIteration, int endIteration,
+                                         std::vector<int64_t> *trace = nullptr);
 
     rfx_ctx *ctx = nullptr;
     DefaultParam param;

@@ -27,7 +27,7 @@ static std::string slurp(const std::string &path) {
 
 int main(int argc, char **argv) {
     try {
-        if (argc < 2) { std::cerr << "usage: reflexiv_host <run|counter> -fastq F[,F2...] -outfile DIR [-kmer 31 -cover 2 ...]\n"; return 2; }
+        if (argc < 2) { std::cerr << "usage: reflexiv_host <run|counter|firstfour|iteration> -fastq F[,F2...] -outfile DIR [-kmer 31 -cover 2 ...]\n"; return 2; }
         std::string cmd = argv[1];
         std::vector<std::string> args(argv + 2, argv + argc);
         reflexiv::DefaultParam param = reflexiv::importCommandLine(args);
@@ -71,12 +71,22 @@ int main(int argc, char **argv) {
                   : param.resident          ? m.assemblyResident(read_all(param.inputFqPath))
                                             : m.assembly(read_all(param.inputFqPath));
             if (param.dedup) out = m.dedupContigText(out);
+        } else if (cmd == "firstfour") {
+            // Pipelines.reflexivDSDynamicKmerFirstFourPipe(): rows "KMER,marker|left|right" of the reduction -> 00firstFour
+            out = m.assemblyDynamicFirstFour(read_all(param.inputKmerPath));
+            dir += "/Assembly_intermediate"; mkdir(dir.c_str(), 0755);
+            dir += "/00firstFour"; mkdir(dir.c_str(), 0755);
+        } else if (cmd == "iteration") {
+            // Pipelines.reflexivDSDynamicKmerIterationPipe(): -> 01Iteration<start>_<end>
+            out = m.assemblyDynamicIteration(read_all(param.inputKmerPath), param.startIteration, param.endIteration);
+            dir += "/Assembly_intermediate"; mkdir(dir.c_str(), 0755);
+            dir += "/01Iteration" + std::to_string(param.startIteration) + "_" + std::to_string(param.endIteration); mkdir(dir.c_str(), 0755);
         } else if (cmd == "counter") {
             out = m.counter(read_all(param.inputFqPath));
             dir += "/Count_" + std::to_string(param.kmerSize);               // P/ReflexivDataFrameCounter.java:222-233
             mkdir(dir.c_str(), 0755);
         } else throw std::runtime_error("unknown command " + cmd);
-        std::ofstream(dir + (cmd == "counter" ? "/part-00000.csv" : "/part-00000"), std::ios::binary) << out;   // saveAsTextFile / csv
+        std::ofstream(dir + (cmd == "counter" || cmd == "firstfour" || cmd == "iteration" ? "/part-00000.csv" : "/part-00000"), std::ios::binary) << out;   // saveAsTextFile / csv
         std::ofstream(dir + "/_SUCCESS", std::ios::binary);
         return 0;
     } catch (const std::exception &e) {

@@ -176,7 +176,8 @@ def main():
     rng = np.random.default_rng(20261006)
     out = {}
     cases = [("c0", 500, (23, 31, 41), 1, 0, (5, 9)), ("c1", 700, (23, 31, 41, 53, 67), 2, 1, (5, 9)),
-             ("c2", 600, (31, 41, 95), 3, 1, (15, 19)), ("c3", 450, (23, 81, 95), 1, 0, (61, 64))]
+             ("c2", 600, (31, 41, 95), 3, 1, (15, 19)), ("c3", 450, (23, 81, 95), 1, 0, (61, 64)),
+             ("c4", 900, (23, 31), 2, 0, (5, 34))]             # thirty passes: extensions outgrow the keys
     for name, glen, ks, P, style, (start, end) in cases:
         in_rows = make_input(rng, glen, ks, cov_style=style)
         trace = []

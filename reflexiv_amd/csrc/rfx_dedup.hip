@@ -221,16 +221,26 @@ __global__ __launch_bounds__(256) void k_dd_query(const uint8_t *__restrict__ sh
 }
 // the vote over the sorted distances (:1478-1497 with 3 votes, :578-597 / :617-636 with 4): sequential by definition (the
 // anchor of a run is the first distance that left the previous run)
-__global__ void k_dd_vote(const uint64_t *__restrict__ dist, int64_t total, int min_votes, int32_t *__restrict__ out) {
+__global__ __launch_bounds__(64) void k_dd_vote(const uint64_t *__restrict__ dist, int64_t total, int min_votes, int32_t *__restrict__ out) {
+    // one wave: 64 distances per coalesced load, then the scan itself on wave-uniform values (readlane) -- the anchor chain
+    // is sequential, the memory latency need not be (a thread walking the list alone paid ~13 ns a distance)
     int32_t lastDistance = 0, lastFrequency = 0, fin = -1;
-    for (int64_t i = 0; i < total; i++) {
-        const int32_t d = (int32_t)((int64_t)dist[i] - 0x80000000ll);
-        if (d - lastDistance >= -1 && d - lastDistance <= 1) {
-            lastFrequency++;
-            if ((double)lastFrequency / (double)total >= 0.3 && lastFrequency >= min_votes) { fin = d; break; }
-        } else { lastFrequency = 1; lastDistance = d; }
+    bool done = false;
+    const int lane = threadIdx.x;
+    for (int64_t base = 0; base < total && !done; base += 64) {
+        const int64_t i = base + lane;
+        const uint64_t v = i < total ? dist[i] : 0;
+        const int cnt = (int)(total - base < 64 ? total - base : 64);
+        for (int j = 0; j < cnt; j++) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), j);
+            const int32_t d = (int32_t)((int64_t)(((uint64_t)hi << 32) | lo) - 0x80000000ll);
+            if (d - lastDistance >= -1 && d - lastDistance <= 1) {
+                lastFrequency++;
+                if ((double)lastFrequency / (double)total >= 0.3 && lastFrequency >= min_votes) { fin = d; done = true; break; }
+            } else { lastFrequency = 1; lastDistance = d; }
+        }
     }
-    *out = fin;
+    if (lane == 0) *out = fin;
 }
 __global__ __launch_bounds__(256) void k_dd_copy(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, int64_t src_n, int64_t from,
                                                  int64_t n, int rc) {
@@ -283,7 +293,7 @@ struct Dedup {
         *n_dist = (int64_t)c;
         // (a second query pass appends to a SORTED prefix: the whole list is sorted again, as Collections.sort does)
         RFX_TRY(sort_pairs(ctx, dist.as<uint64_t>(), dval.as<uint32_t>(), (int64_t)c, 33, dtmp.as<uint64_t>(), dvtmp.as<uint32_t>()));
-        hipLaunchKernelGGL(k_dd_vote, dim3(1), dim3(1), 0, ctx->stream, (const uint64_t *)dist.as<uint64_t>(), (int64_t)c, min_votes,
+        hipLaunchKernelGGL(k_dd_vote, dim3(1), dim3(64), 0, ctx->stream, (const uint64_t *)dist.as<uint64_t>(), (int64_t)c, min_votes,
                            fin.as<int32_t>());
         RFX_HIP(hipGetLastError());
         RFX_HIP(hipMemcpyAsync(out, fin.p, 4, hipMemcpyDeviceToHost, ctx->stream));

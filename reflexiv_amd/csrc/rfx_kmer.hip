@@ -448,7 +448,16 @@ constexpr int LT = RFX_LT;              // threads per leaf workgroup
 #endif
 constexpr int LQCAP = RFX_LEAF_QUEUE ? 96 : 0;    // attempts a wave has pending (record leaves): < 32 + 64 new ones
 constexpr int LQBATCH = 32;
-constexpr int LOBUF = RFX_LEAF_QUEUE ? 64 : 512;  // survivors k_leaf_count buffers in LDS between flushes
+// RFX_LEAF_AGG: records of a leaf are first counted in a small LDS table keyed by the WHOLE record (a deep data set
+// repeats its super-k-mer records: at 1000x four windows in five lie in a record seen before in the same leaf), and
+// only the distinct records are expanded into k-mers, each k-mer inserted once with the record's count as weight.  The
+// table is a cache, not a set: a record that finds no slot in RPROBE probes is expanded on the spot with weight 1.
+#ifndef RFX_LEAF_AGG
+#define RFX_LEAF_AGG 1
+#endif
+constexpr int RSLOTS = 768;             // record slots (one 64-slot block per wave of the workgroup in the sweep)
+constexpr int RPROBE = 4;
+constexpr int LOBUF = RFX_LEAF_QUEUE ? 64 : (RFX_LEAF_AGG ? 128 : 512);  // survivors k_leaf_count buffers in LDS between flushes
 constexpr int WSTAGE = 160 + LQCAP + LQCAP / 2;   // u64 words of a wave's private expansion area (record leaves) + its queue
 constexpr int LSTAGE = WSTAGE * (LT / 64);
 #ifndef RFX_LCAP
@@ -484,6 +493,9 @@ struct CountOut {
     unsigned long long n_overflow;   // passes abandoned because the table filled up
     unsigned long long n_leaves;     // non-empty leaves
     unsigned long long t_wait, t_all; // RFX_LEAF_DBG & 32: clocks waves spent at the two barriers of a leaf / in the kernel
+    // RFX_LEAF_DBG & 128: the record table -- records counted in it / expanded on the spot, occupied slots at the sweeps,
+    // windows expanded on the spot / from the table (against the instances: what the table saved)
+    unsigned long long r_placed, r_direct, r_slots, w_direct, w_table;
 };
 
 // Persistent workgroups each walk a CONTIGUOUS chunk of leaf buckets, i.e. one contiguous
@@ -591,6 +603,10 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
     __shared__ uint32_t blk_pos, have_next, need_grab;
     __shared__ uint32_t ps_eff;              // elements one table takes (starts at `presplit`, shrinks on overflow)
     __shared__ __attribute__((aligned(16))) uint64_t stage[RECS ? LSTAGE : 2];  // records: per-wave expansion area
+    constexpr bool AGG = RECS && RFX_LEAF_AGG != 0;
+    static_assert(!AGG || RSLOTS == 64 * (LT / 64), "one block of record slots per wave");
+    // record table: rA = bases 0..31 of the record, rBC = [63..32] bases 32..45 | windows - 1, [31..0] the count
+    __shared__ unsigned long long rA[AGG ? RSLOTS : 1], rBC[AGG ? RSLOTS : 1];
     uint32_t my_distinct = 0;                                                // every thread
     long long t_wait = 0;
     const long long t_begin = (dbg & 32) ? clock64() : 0;
@@ -614,6 +630,7 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
     };
 
     for (int i = threadIdx.x; i < LCAP; i += LT) { tkey[i] = EMPTY; tcnt[i] = 0; }
+    if constexpr (AGG) for (int i = threadIdx.x; i < RSLOTS; i += LT) { rA[i] = EMPTY; rBC[i] = EMPTY; }
     if (threadIdx.x == 0) {
         ob_n = 0; ob_lim = 0xffffffffu; overflow = 0; sp = 0;
         blk_base = NOBLK; blk_next = NOBLK; blk_pos = PBLOCK; have_next = 0; need_grab = 1;
@@ -805,10 +822,11 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
             // its first output position in w: window i then starts 31 - 2i bits up in (x, y) and (y, z), a
             // shift in 1..31, which is what one 32-bit funnel shift takes (64-bit shifts issue at a fraction
             // of the rate).
-            auto kmer_at_pos = [&](uint32_t j) __attribute__((always_inline)) -> uint64_t {
+            auto kmer_at_pos = [&](uint32_t j, uint32_t &wgt) __attribute__((always_inline)) -> uint64_t {
                 const uint32_t wd = wbits[j >> 5];
                 const uint32_t r = wcum[j >> 5] + (uint32_t)__popc(wd & (0xffffffffu >> (31 - (j & 31)))) - 1u;
-                const uint4 rr = wrec[r];
+                uint4 rr = wrec[r];
+                if constexpr (AGG) { wgt = rr.w >> 11; rr.w &= 2047u; } else wgt = 1u;
                 const uint32_t t = 31u - 2u * (j - rr.w);                        // window index <= 15
                 const uint32_t W0 = __builtin_amdgcn_alignbit(rr.x, rr.y, t), W1 = __builtin_amdgcn_alignbit(rr.y, rr.z, t);
                 uint32_t fh, fl;
@@ -836,7 +854,8 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
                 const uint64_t fwd = ((uint64_t)fh << 32) | fl, rc = ((uint64_t)ch << 32) | cl;
                 return fwd < rc ? fwd : rc;
             };
-            auto step = [&](const Rec rcur, const bool valid) __attribute__((always_inline)) {
+            // (weight: how many times the record was seen; lands in the upper bits of the record's first output position)
+            auto step = [&](const Rec rcur, const bool valid, const uint32_t weight) __attribute__((always_inline)) {
                 if (dbg & 1) {       // ablation: stream only
                     if (rcur.w0 == 0x123456789ULL) overflow = 1;
                     return;
@@ -850,7 +869,16 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
                 if (nwin) atomicOr(&wbits[off >> 5], 1u << (off & 31));
                 {
                     const uint32_t s0 = (uint32_t)(rcur.w0 >> 32), s1 = (uint32_t)rcur.w0, s2 = (uint32_t)(rcur.w1 >> 32);
-                    wrec[lane_] = make_uint4(s0 >> 1, __builtin_amdgcn_alignbit(s0, s1, 1), __builtin_amdgcn_alignbit(s1, s2, 1), off);
+                    // (a record is found by its ordinal among the records that have windows: with the record table the
+                    // lanes without any are not only the tail)
+                    uint32_t ord = (uint32_t)lane_;
+                    if constexpr (AGG) {
+                        const uint64_t vm = __ballot(nwin != 0u);
+                        ord = __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
+                    }
+                    if (!AGG || nwin)
+                        wrec[ord] = make_uint4(s0 >> 1, __builtin_amdgcn_alignbit(s0, s1, 1), __builtin_amdgcn_alignbit(s1, s2, 1),
+                                               AGG ? off | (weight << 11) : off);
                 }
                 __builtin_amdgcn_wave_barrier();
                 {
@@ -862,27 +890,150 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
                 for (uint32_t wb = 0; wb < total; wb += 128) {
                     const uint32_t j0 = wb + lane_, j1 = j0 + 64;
                     const bool v0 = j0 < total, v1 = j1 < total;
-                    const uint64_t c0 = kmer_at_pos(v0 ? j0 : 0), c1 = kmer_at_pos(v1 ? j1 : 0);
+                    uint32_t g0, g1;
+                    const uint64_t c0 = kmer_at_pos(v0 ? j0 : 0, g0), c1 = kmer_at_pos(v1 ? j1 : 0, g1);
                     if (dbg & 2) {       // ablation: expand, no table
                         if ((v0 && c0 == 0x123456789ULL) || (v1 && c1 == 0x123456789ULL)) overflow = 1;
                         continue;
                     }
-                    insert2(c0, v0, c1, v1, 1u, 1u);
+                    insert2(c0, v0, c1, v1, g0, g1);
                 }
                 __builtin_amdgcn_wave_barrier();
             };
+            // With the record table the records to expand come a few per 64-record step (those that found no slot) and
+            // from half-empty blocks of slots: they are PARKED in the wave's window until 64 wait, and expanded together.
+            uint32_t parked = 0;                                          // wave-uniform
+            auto flush_parked = [&]() __attribute__((always_inline)) {
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t w4 = (uint32_t)lane_ < parked ? ((const uint32_t *)&wrec[lane_])[3] : 0u;    // windows | weight << 11
+                const uint32_t nwin = w4 & 31u;
+                const uint32_t x = wave_incl_scan(nwin);
+                const uint32_t off = x - nwin;
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+                if (lane_ < 32) wbits[lane_] = 0;
+                __builtin_amdgcn_wave_barrier();
+                if (nwin) { atomicOr(&wbits[off >> 5], 1u << (off & 31)); ((uint32_t *)&wrec[lane_])[3] = off | (w4 & ~2047u); }
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const uint32_t c = (uint32_t)__popc(wbits[lane_ & 31]);
+                    const uint32_t y = wave_incl_scan(c);
+                    if (lane_ < 32) wcum[lane_] = y - c;
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t wb = 0; wb < total; wb += 128) {
+                    const uint32_t j0 = wb + lane_, j1 = j0 + 64;
+                    const bool v0 = j0 < total, v1 = j1 < total;
+                    uint32_t g0, g1;
+                    const uint64_t c0 = kmer_at_pos(v0 ? j0 : 0, g0), c1 = kmer_at_pos(v1 ? j1 : 0, g1);
+                    if (dbg & 2) {       // ablation: expand, no table
+                        if ((v0 && c0 == 0x123456789ULL) || (v1 && c1 == 0x123456789ULL)) overflow = 1;
+                        continue;
+                    }
+                    insert2(c0, v0, c1, v1, g0, g1);
+                }
+                __builtin_amdgcn_wave_barrier();
+                parked = 0;
+            };
+            auto park = [&](const Rec rcur, const bool valid, const uint32_t weight) __attribute__((always_inline)) {
+                if (dbg & 1) {       // ablation: stream only
+                    if (rcur.w0 == 0x123456789ULL) overflow = 1;
+                    return;
+                }
+                const uint64_t vm = __ballot(valid);
+                if (!vm) return;
+                const uint32_t d = (uint32_t)__popcll(vm);
+#pragma nounroll
+                while (parked + d > 64u) flush_parked();                  // (once; a loop so that the body is not duplicated)
+                if (valid) {
+                    const uint32_t ord = parked + __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
+                    const uint32_t s0 = (uint32_t)(rcur.w0 >> 32), s1 = (uint32_t)rcur.w0, s2 = (uint32_t)(rcur.w1 >> 32);
+                    wrec[ord] = make_uint4(s0 >> 1, __builtin_amdgcn_alignbit(s0, s1, 1), __builtin_amdgcn_alignbit(s1, s2, 1),
+                                           (uint32_t)rec_len(rcur) | (weight << 11));
+                }
+                parked += d;
+            };
+            // the record table takes the leaf's single pass; the hash-selected parts of a split leaf expand every record
+            const bool agg = AGG && S == 1 && !(dbg & 64);
+            // count the record in the record table; false = no slot for it (or not eligible): expand it now
+            auto place = [&](const Rec &r, bool valid) __attribute__((always_inline)) -> bool {
+                if constexpr (!AGG) return false;
+                if (!agg || !valid || r.w0 == EMPTY) return false;
+                const uint32_t b = (uint32_t)(r.w1 >> 32);
+                const uint32_t h = ((uint32_t)r.w0 ^ __builtin_rotateleft32((uint32_t)(r.w0 >> 32), 13) ^ __builtin_rotateleft32(b, 7)) * 0x9E3779B1u;
+                // (admitting a record only at its second sighting -- a bit per record hash -- keeps the records seen once
+                // out of the table, 267 instead of 463 of its slots in use, but every record seen again is then expanded
+                // twice: 39 % of the windows expanded instead of 36 %)
+                uint32_t slot = ((h >> 22) * 3u) >> 2;
 #pragma unroll
-            for (int i = 0; i < RPF; i++) {
-                const uint64_t r0 = ws + 64u * i;
-                // an overflowing pass is abandoned: stop feeding a table that is filling up
-                if (r0 < we && !__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) step(cur[i], r0 + lane_ < we);
+                for (int probe = 0; probe < RPROBE; probe++) {
+                    const unsigned long long p = atomicCAS(&rA[slot], EMPTY, (unsigned long long)r.w0);
+                    if (p == EMPTY || p == r.w0) {
+                        const unsigned long long q = atomicCAS(&rBC[slot], EMPTY, (unsigned long long)b << 32);
+                        if (q == EMPTY || (uint32_t)(q >> 32) == b) { atomicAdd((uint32_t *)&rBC[slot], 1u); return true; }
+                    }
+                    slot = slot + 1u == (uint32_t)RSLOTS ? 0u : slot + 1u;
+                }
+                return false;
+            };
+            auto rstat = [&](bool placed, bool direct, const Rec &r) {
+                const uint32_t w = direct ? (uint32_t)rec_len(r) : 0u;
+                uint32_t ws_ = w;
+                for (int o = 32; o > 0; o >>= 1) ws_ += __shfl_xor(ws_, o, 64);
+                const uint64_t mp = __ballot(placed), md = __ballot(direct);
+                if (lane_ == 0) {
+                    atomicAdd(&co->r_placed, (unsigned long long)__popcll(mp));
+                    atomicAdd(&co->r_direct, (unsigned long long)__popcll(md));
+                    atomicAdd(&co->w_direct, (unsigned long long)ws_);
+                }
+            };
+            if constexpr (AGG) {
+                static_assert(RPF == 1, "the first 64-record step of a wave comes from registers");
+                Rec rr = cur[0];
+                for (uint64_t r0 = ws; r0 < we; r0 += 64) {
+                    // an overflowing pass is abandoned: stop feeding a table that is filling up
+                    if (__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                    const bool valid = r0 + lane_ < we;
+                    // (the wave's next 64 records travel while these are counted)
+                    const Rec nx = r0 + 64 + lane_ < we ? keys[r0 + 64 + lane_] : Rec{0, 0};
+                    const bool placed = place(rr, valid);
+                    if (dbg & 128) rstat(placed, valid && !placed, rr);
+                    park(rr, valid && !placed, 1u);
+                    rr = nx;
+                }
+                if (agg) {
+                    // every record of the leaf has been counted: the distinct ones become weighted k-mers (the wave takes
+                    // its block of slots and leaves it empty, whatever became of the pass); what the wave still has
+                    // parked goes with them
+                    __syncthreads();
+                    const uint32_t slot = (uint32_t)(wave_ * 64 + lane_);
+                    const unsigned long long a_ = rA[slot], bc = rBC[slot];
+                    const bool have = bc != EMPTY;
+                    if (a_ != EMPTY) { rA[slot] = EMPTY; rBC[slot] = EMPTY; }
+                    if (dbg & 128) {
+                        uint32_t w = have ? (uint32_t)((bc >> 32) & 15) + 1u : 0u;
+                        for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+                        const uint64_t mh = __ballot(have);
+                        if (lane_ == 0) { atomicAdd(&co->r_slots, (unsigned long long)__popcll(mh)); atomicAdd(&co->w_table, (unsigned long long)w); }
+                    }
+                    if (!__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                        park(Rec{(uint64_t)a_, (uint64_t)(bc >> 32) << 32}, have, (uint32_t)bc);
+                }
+#pragma nounroll
+                while (parked) flush_parked();
+            } else {
+#pragma unroll
+                for (int i = 0; i < RPF; i++) {
+                    const uint64_t r0 = ws + 64u * i;
+                    // an overflowing pass is abandoned: stop feeding a table that is filling up
+                    if (r0 < we && !__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) step(cur[i], r0 + lane_ < we, 1u);
+                }
+                for (uint64_t r0 = ws + 64u * RPF; r0 < we; r0 += 64) {
+                    if (__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                    const bool valid = r0 + lane_ < we;
+                    step(valid ? keys[r0 + lane_] : Rec{0, 0}, valid, 1u);
+                }
+                drain_queue();
             }
-            for (uint64_t r0 = ws + 64u * RPF; r0 < we; r0 += 64) {
-                if (__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-                const bool valid = r0 + lane_ < we;
-                step(valid ? keys[r0 + lane_] : Rec{0, 0}, valid);
-            }
-            drain_queue();
         } else {
             for (uint64_t base = begin; base < end; base += (uint64_t)LT * NB) {
                 // an overflowing pass is abandoned: stop feeding a table that is filling up
@@ -2679,6 +2830,9 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
     // table statistics of the last count call, read back by tests through rfx_last_count_timing (launches = the number)
     ctx->timing["stat_leaves"].launches += nleaf; ctx->timing["stat_passes"].launches += (int64_t)co.n_passes;
     ctx->timing["stat_overflows"].launches += (int64_t)co.n_overflow;
+    if (dbg & 128)
+        fprintf(stderr, "record table: %llu records counted in it, %llu expanded on the spot (%llu windows), %llu slots swept (%llu windows), %.2f per leaf\n",
+                co.r_placed, co.r_direct, co.w_direct, co.r_slots, co.w_table, (double)co.r_slots / (double)std::max<int64_t>(nleaf, 1));
     if (dbg & 32)
         fprintf(stderr, "leaf waves: %.1f %% of their clocks at the leaf barriers\n", 100.0 * (double)co.t_wait / (double)std::max<unsigned long long>(co.t_all, 1));
     if (co.n_failed) { ctx->last_error = "leaf split depth exhausted"; ScopedTimer::collect(ctx); return RFX_E_LIMIT; }

@@ -958,7 +958,14 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
             auto place = [&](const Rec &r, bool valid) __attribute__((always_inline)) -> bool {
                 if constexpr (!AGG) return false;
                 if (!agg || !valid || r.w0 == EMPTY) return false;
-                const uint32_t b = (uint32_t)(r.w1 >> 32);
+                // (the bases behind the record's last window are whatever followed in the read: not part of its identity)
+                uint32_t b = (uint32_t)(r.w1 >> 32);
+                if (!(dbg & 256)) {
+                    const uint32_t nw = (b & 15u) + 1u;                       // k - 1 + nw bases are the record's
+                    const int used = 2 * (k - 1 + (int)nw) - 64;              // ... of them in b's 28 base bits (<= 0: none)
+                    const uint32_t keep = used >= 28 ? 0xfffffff0u : used <= 0 ? 0u : ~(0xffffffffu >> used);
+                    b = (b & keep) | (b & 15u);
+                }
                 const uint32_t h = ((uint32_t)r.w0 ^ __builtin_rotateleft32((uint32_t)(r.w0 >> 32), 13) ^ __builtin_rotateleft32(b, 7)) * 0x9E3779B1u;
                 // (admitting a record only at its second sighting -- a bit per record hash -- keeps the records seen once
                 // out of the table, 267 instead of 463 of its slots in use, but every record seen again is then expanded

@@ -455,9 +455,16 @@ constexpr int LQBATCH = 32;
 #ifndef RFX_LEAF_AGG
 #define RFX_LEAF_AGG 1
 #endif
+#ifndef RFX_WALK_NOUNROLL
+#define RFX_WALK_NOUNROLL 1
+#endif
 constexpr int RSLOTS = 768;             // record slots (one 64-slot block per wave of the workgroup in the sweep)
 constexpr int RPROBE = 4;
-constexpr int LOBUF = RFX_LEAF_QUEUE ? 64 : (RFX_LEAF_AGG ? 128 : 512);  // survivors k_leaf_count buffers in LDS between flushes
+constexpr int LOBUF = RFX_LEAF_QUEUE ? 64 : 512;  // survivors k_leaf_count buffers in LDS between flushes (k-mer and pair leaves)
+// Record leaves: the record table takes the room of that buffer, so 128 survivors wait in a buffer of their own and
+// what a leaf has beyond them goes to the waves' expansion areas, which are idle during the sweep -- and must be free
+// again before the next leaf: a sweep that ends with LOBUF1 / 2 or more waiting flushes.
+constexpr int LOBUF1 = RFX_LEAF_AGG ? 128 : LOBUF;
 constexpr int WSTAGE = 160 + LQCAP + LQCAP / 2;   // u64 words of a wave's private expansion area (record leaves) + its queue
 constexpr int LSTAGE = WSTAGE * (LT / 64);
 #ifndef RFX_LCAP
@@ -591,8 +598,11 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
     const int k = KC ? KC : k_rt;
     __shared__ __attribute__((aligned(16))) unsigned long long tkey[LCAP];
     __shared__ __attribute__((aligned(16))) uint32_t tcnt[LCAP];
-    __shared__ unsigned long long obk[LOBUF];
-    __shared__ int32_t obc[LOBUF];
+    constexpr int OB1 = RECS ? LOBUF1 : LOBUF;                                   // survivors in the buffer of their own
+    constexpr int OB2 = RECS && RFX_LEAF_AGG && !RFX_LEAF_QUEUE ? (LSTAGE * 8) / 12 : 0;   // ... in the expansion areas (see LOBUF1)
+    constexpr int OBT = OB1 + OB2;
+    __shared__ unsigned long long obk[OB1];
+    __shared__ int32_t obc[OB1];
     __shared__ uint32_t stackS[LSTACK], stacks[LSTACK];
     __shared__ int sp;
     __shared__ uint32_t overflow, ob_n, ob_lim;
@@ -603,10 +613,20 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
     __shared__ uint32_t blk_pos, have_next, need_grab;
     __shared__ uint32_t ps_eff;              // elements one table takes (starts at `presplit`, shrinks on overflow)
     __shared__ __attribute__((aligned(16))) uint64_t stage[RECS ? LSTAGE : 2];  // records: per-wave expansion area
+    unsigned long long *const obk2 = (unsigned long long *)stage;               // OB2 keys, then OB2 counts
+    int32_t *const obc2 = (int32_t *)(obk2 + OB2);
+    auto ob_put = [&](uint32_t i, unsigned long long key, int32_t c) __attribute__((always_inline)) {
+        if (OB2 == 0 || i < (uint32_t)OB1) { obk[i] = key; obc[i] = c; }
+        else { obk2[i - OB1] = key; obc2[i - OB1] = c; }
+    };
     constexpr bool AGG = RECS && RFX_LEAF_AGG != 0;
     static_assert(!AGG || RSLOTS == 64 * (LT / 64), "one block of record slots per wave");
     // record table: rA = bases 0..31 of the record, rBC = [63..32] bases 32..45 | windows - 1, [31..0] the count
     __shared__ unsigned long long rA[AGG ? RSLOTS : 1], rBC[AGG ? RSLOTS : 1];
+    // whether the table pays is a property of the data set (its depth): the workgroup adds up, over its first leaves, how
+    // many records met an entry that was already there, and goes without the table when that is under half of them
+    // (measured break-even: a 47x data set, 37 % met one, ran 85 ms with the table and 81 without)
+    __shared__ uint32_t agg_on, agg_saved, agg_total;
     uint32_t my_distinct = 0;                                                // every thread
     long long t_wait = 0;
     const long long t_begin = (dbg & 32) ? clock64() : 0;
@@ -635,6 +655,7 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
         ob_n = 0; ob_lim = 0xffffffffu; overflow = 0; sp = 0;
         blk_base = NOBLK; blk_next = NOBLK; blk_pos = PBLOCK; have_next = 0; need_grab = 1;
         ps_eff = presplit ? presplit : 0xffffffffu;
+        agg_on = 1; agg_saved = 0; agg_total = 0;
     }
 
     // flush the survivor buffer (every thread calls)
@@ -647,8 +668,11 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
         for (uint32_t i = threadIdx.x; i < cntv; i += LT) {
             const unsigned long long pos = g_emit + i;
             if (pos < cap) {
-                if (pair_out) ((Rec *)out_keys)[pos] = Rec{obk[i], (uint64_t)(uint32_t)obc[i]};
-                else { out_keys[pos] = obk[i]; out_counts[pos] = obc[i]; }
+                const bool own = OB2 == 0 || i < (uint32_t)OB1;
+                const unsigned long long key = own ? obk[i] : obk2[i - OB1];
+                const int32_t c = own ? obc[i] : obc2[i - OB1];
+                if (pair_out) ((Rec *)out_keys)[pos] = Rec{key, (uint64_t)(uint32_t)c};
+                else { out_keys[pos] = key; out_counts[pos] = c; }
             }
         }
         __syncthreads();
@@ -743,7 +767,12 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
             // and linear probing's clusters make that one long in a leaf that fills its table)
             auto walk = [&](uint64_t key, uint32_t slot, uint32_t w, uint32_t g) __attribute__((always_inline)) {
                 const uint32_t step = (dbg & 16) ? 1u : leaf_step(g);
-                // (left to the compiler's full unroll: `#pragma unroll 1` shrinks the kernel threefold and is 2 % slower)
+                // (rounds 1-2 left this loop to the compiler's full unroll -- 2 % faster then; with the record table in
+                // front of it few keys walk at all, and the rolled loop takes the kernel from 69 KB to a third, 1264 spilled
+                // SGPRs to 45)
+#if RFX_WALK_NOUNROLL
+#pragma nounroll
+#endif
                 for (int probe = 1;; probe++) {
                     slot = leaf_next(slot, step);
                     const unsigned long long p = atomicCAS(&tkey[slot], EMPTY, (unsigned long long)key);
@@ -822,11 +851,12 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
             // its first output position in w: window i then starts 31 - 2i bits up in (x, y) and (y, z), a
             // shift in 1..31, which is what one 32-bit funnel shift takes (64-bit shifts issue at a fraction
             // of the rate).
-            auto kmer_at_pos = [&](uint32_t j, uint32_t &wgt) __attribute__((always_inline)) -> uint64_t {
+            // (weighted: the record's count sits above its first output position -- the parked records of the record table)
+            auto kmer_at_pos = [&](uint32_t j, uint32_t &wgt, auto weighted) __attribute__((always_inline)) -> uint64_t {
                 const uint32_t wd = wbits[j >> 5];
                 const uint32_t r = wcum[j >> 5] + (uint32_t)__popc(wd & (0xffffffffu >> (31 - (j & 31)))) - 1u;
                 uint4 rr = wrec[r];
-                if constexpr (AGG) { wgt = rr.w >> 11; rr.w &= 2047u; } else wgt = 1u;
+                if constexpr (decltype(weighted)::value) { wgt = rr.w >> 11; rr.w &= 2047u; } else wgt = 1u;
                 const uint32_t t = 31u - 2u * (j - rr.w);                        // window index <= 15
                 const uint32_t W0 = __builtin_amdgcn_alignbit(rr.x, rr.y, t), W1 = __builtin_amdgcn_alignbit(rr.y, rr.z, t);
                 uint32_t fh, fl;
@@ -855,7 +885,7 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
                 return fwd < rc ? fwd : rc;
             };
             // (weight: how many times the record was seen; lands in the upper bits of the record's first output position)
-            auto step = [&](const Rec rcur, const bool valid, const uint32_t weight) __attribute__((always_inline)) {
+            auto step = [&](const Rec rcur, const bool valid, const uint32_t /*weight: 1*/) __attribute__((always_inline)) {
                 if (dbg & 1) {       // ablation: stream only
                     if (rcur.w0 == 0x123456789ULL) overflow = 1;
                     return;
@@ -877,8 +907,7 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
                         ord = __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
                     }
                     if (!AGG || nwin)
-                        wrec[ord] = make_uint4(s0 >> 1, __builtin_amdgcn_alignbit(s0, s1, 1), __builtin_amdgcn_alignbit(s1, s2, 1),
-                                               AGG ? off | (weight << 11) : off);
+                        wrec[ord] = make_uint4(s0 >> 1, __builtin_amdgcn_alignbit(s0, s1, 1), __builtin_amdgcn_alignbit(s1, s2, 1), off);
                 }
                 __builtin_amdgcn_wave_barrier();
                 {
@@ -891,7 +920,7 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
                     const uint32_t j0 = wb + lane_, j1 = j0 + 64;
                     const bool v0 = j0 < total, v1 = j1 < total;
                     uint32_t g0, g1;
-                    const uint64_t c0 = kmer_at_pos(v0 ? j0 : 0, g0), c1 = kmer_at_pos(v1 ? j1 : 0, g1);
+                    const uint64_t c0 = kmer_at_pos(v0 ? j0 : 0, g0, std::false_type{}), c1 = kmer_at_pos(v1 ? j1 : 0, g1, std::false_type{});
                     if (dbg & 2) {       // ablation: expand, no table
                         if ((v0 && c0 == 0x123456789ULL) || (v1 && c1 == 0x123456789ULL)) overflow = 1;
                         continue;
@@ -924,7 +953,7 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
                     const uint32_t j0 = wb + lane_, j1 = j0 + 64;
                     const bool v0 = j0 < total, v1 = j1 < total;
                     uint32_t g0, g1;
-                    const uint64_t c0 = kmer_at_pos(v0 ? j0 : 0, g0), c1 = kmer_at_pos(v1 ? j1 : 0, g1);
+                    const uint64_t c0 = kmer_at_pos(v0 ? j0 : 0, g0, std::true_type{}), c1 = kmer_at_pos(v1 ? j1 : 0, g1, std::true_type{});
                     if (dbg & 2) {       // ablation: expand, no table
                         if ((v0 && c0 == 0x123456789ULL) || (v1 && c1 == 0x123456789ULL)) overflow = 1;
                         continue;
@@ -953,7 +982,8 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
                 parked += d;
             };
             // the record table takes the leaf's single pass; the hash-selected parts of a split leaf expand every record
-            const bool agg = AGG && S == 1 && !(dbg & 64);
+            const bool agg = AGG && S == 1 && !(dbg & 64) && (agg_on || (dbg & 512));
+            uint32_t hits = 0;                                            // records of this wave that found a slot (uniform)
             // count the record in the record table; false = no slot for it (or not eligible): expand it now
             auto place = [&](const Rec &r, bool valid) __attribute__((always_inline)) -> bool {
                 if constexpr (!AGG) return false;
@@ -1002,9 +1032,12 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
                     const bool valid = r0 + lane_ < we;
                     // (the wave's next 64 records travel while these are counted)
                     const Rec nx = r0 + 64 + lane_ < we ? keys[r0 + 64 + lane_] : Rec{0, 0};
-                    const bool placed = place(rr, valid);
-                    if (dbg & 128) rstat(placed, valid && !placed, rr);
-                    park(rr, valid && !placed, 1u);
+                    if (agg) {
+                        const bool placed = place(rr, valid);
+                        hits += (uint32_t)__popcll(__ballot(placed));
+                        if (dbg & 128) rstat(placed, valid && !placed, rr);
+                        park(rr, valid && !placed, 1u);
+                    } else step(rr, valid, 1u);          // (a shallow data set, or a hash-selected part of a split leaf)
                     rr = nx;
                 }
                 if (agg) {
@@ -1016,6 +1049,10 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
                     const unsigned long long a_ = rA[slot], bc = rBC[slot];
                     const bool have = bc != EMPTY;
                     if (a_ != EMPTY) { rA[slot] = EMPTY; rBC[slot] = EMPTY; }
+                    {
+                        const uint32_t used = (uint32_t)__popcll(__ballot(have));
+                        if (lane_ == 0 && hits != used) atomicAdd(&agg_saved, hits - used);      // (modulo 2^32: the sum is >= 0)
+                    }
                     if (dbg & 128) {
                         uint32_t w = have ? (uint32_t)((bc >> 32) & 15) + 1u : 0u;
                         for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
@@ -1109,8 +1146,8 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
                     }
                     if (lane_ == leader) base = atomicAdd(&ob_n, cntw);
                     base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-                    if (base + cntw <= (uint32_t)LOBUF) {
-                        if (keep) { obk[base + r] = tkey[slot]; obc[base + r] = c; }
+                    if (base + cntw <= (uint32_t)OBT) {
+                        if (keep) ob_put(base + r, tkey[slot], c);
                     } else {
                         uint32_t glo = 0, ghi = 0;
                         if (lane_ == leader) {
@@ -1135,7 +1172,7 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
         if (dbg & 32) { const long long t0 = clock64(); __syncthreads(); t_wait += clock64() - t0; }
         else __syncthreads();
         const uint32_t raw = ob_n, lim = ob_lim;      // stable until the next emit_pass
-        if (raw >= (uint32_t)LOBUF / 2 || lim != 0xffffffffu) flush();
+        if (raw >= (uint32_t)OB1 / 2 || lim != 0xffffffffu) flush();
     };
 
     for (int64_t leaf = l0; leaf < l1; leaf++) {
@@ -1177,6 +1214,15 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
                 // (before emit_pass, whose closing barrier stands between this store and the next leaf's read of ps_eff:
                 // after it, a workgroup whose threads saw different thresholds would disagree on S and on its barriers)
                 if (threadIdx.x == 0 && S == 1 && end - begin > (uint64_t)ps_eff * 3 / 4 && ps_eff < (1u << 24)) ps_eff += ps_eff / 64 + 1;
+                if constexpr (AGG) {
+                    if (threadIdx.x == 0 && S == 1 && agg_on) {
+                        agg_total += (uint32_t)(end - begin);
+                        if (agg_total >= 8192u) {
+                            if (agg_saved * 2u < agg_total) agg_on = 0;
+                            agg_total = 0; agg_saved = 0;
+                        }
+                    }
+                }
                 emit_pass();
                 if (pair_out && threadIdx.x == 0) {         // (all emission done; next read: after a later barrier)
                     if (blk_pos >= (uint32_t)PBLOCK) { blk_base = blk_next; blk_pos -= PBLOCK; have_next = 0; }
@@ -1299,7 +1345,16 @@ __device__ __forceinline__ void wrec_kmer(const WRec &r, uint32_t j, int t, uint
 #define RFX_WIDE_QUEUE 1
 #endif
 constexpr int WQCAP = RFX_WIDE_QUEUE ? 128 : 0;   // probe attempts a wave has pending (record leaves)
-constexpr int WWS0 = 64 * 4 + 32;       // u64 words of a wave's expansion area: 64 records + head bits + prefix counts
+// RFX_WIDE_AGG: the record table of the two-word leaf (see RFX_LEAF_AGG): a slot is (bases 0..31, bases 32..63, the
+// rest of the record's own bases | windows - 1 | count), claimed field by field -- a record that meets a slot whose
+// fields are not all its own moves on, so whatever order the claims land in, a slot names one record.
+#ifndef RFX_WIDE_AGG
+#define RFX_WIDE_AGG 1
+#endif
+constexpr int WRSLOTS = 768;            // record slots (12 of the 16 waves sweep a block of 64 each)
+constexpr int WRMAX = 8191;             // records of a leaf that goes through the table (a weight takes 13 bits of a queue entry)
+constexpr int WPARK = RFX_WIDE_AGG ? 32 : 64;   // records a wave parks before it expands them
+constexpr int WWS0 = WPARK * 4 + 32;    // u64 words of a wave's expansion area: the parked records + head bits + prefix counts
 constexpr int WWS = WWS0 + WQCAP * 2 + WQCAP / 2;   // ... + the queue: 16-byte keys, then 4-byte (slot | probes << 16)
 
 // RECS: the leaf's elements are super-k-mer records (WRec) expanded here, k-mer by k-mer, balanced over the
@@ -1315,6 +1370,10 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
     __shared__ uint32_t ps_eff;              // records one table takes (starts at `presplit`, shrinks on overflow)
     __shared__ __attribute__((aligned(16))) ulonglong2 tk[WCAP];     // both key words of a slot in one 16-byte LDS access
     __shared__ uint32_t tcnt[WCAP];
+    constexpr bool WAGG = RECS && RFX_WIDE_AGG != 0;
+    static_assert(!WAGG || (WQCAP > 0 && WRSLOTS % 64 == 0 && WRSLOTS <= WLT), "record table");
+    __shared__ unsigned long long rA[WAGG ? WRSLOTS : 1], rB[WAGG ? WRSLOTS : 1], rCC[WAGG ? WRSLOTS : 1];
+    __shared__ uint32_t agg_on, agg_saved, agg_total;       // (as in k_leaf_count)
     __shared__ unsigned long long obh[WOBUF], obl[WOBUF];
     __shared__ uint32_t obc[WOBUF];
     __shared__ uint32_t stackS[LSTACK], stacks[LSTACK];
@@ -1328,9 +1387,11 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
     const int64_t l1 = (int64_t)(((unsigned long long)(blockIdx.x + 1) * (unsigned long long)nleaf) / gridDim.x);
     if (l0 >= l1) return;
     for (int i = threadIdx.x; i < WCAP; i += WLT) tcnt[i] = 0;
+    if constexpr (WAGG) for (int i = threadIdx.x; i < WRSLOTS; i += WLT) { rA[i] = EMPTY; rB[i] = EMPTY; rCC[i] = EMPTY; }
     if (threadIdx.x == 0) {
         ob_n = 0; ob_lim = 0xffffffffu; overflow = 0; sp = 0;
         ps_eff = (presplit & 0xffffffu) ? (presplit & 0xffffffu) : 0xffffffffu;
+        agg_on = 1; agg_saved = 0; agg_total = 0;
     }
     __syncthreads();
 
@@ -1421,7 +1482,8 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
             uint32_t qn = 0;
             ulonglong2 *wqk = (ulonglong2 *)(wstage + (size_t)(threadIdx.x >> 6) * WWS + WWS0);
             uint32_t *wqs = (uint32_t *)(wqk + WQCAP);
-            auto attempt = [&](const uint64_t w0, const uint64_t w1, uint32_t slot, uint32_t probe, bool v) __attribute__((always_inline)) {
+            // (wgt: the k-mer stands for that many instances -- the count of the record it was cut from)
+            auto attempt = [&](const uint64_t w0, const uint64_t w1, uint32_t slot, uint32_t probe, bool v, uint32_t wgt) __attribute__((always_inline)) {
                 uint32_t c = 1u;
                 if (v) c = atomicCAS(&tcnt[slot], 0u, WLOCK);
                 bool done = !v;
@@ -1429,11 +1491,11 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                     if (c == 0u) {
                         tk[slot] = make_ulonglong2(w0, w1);
                         __threadfence_block();
-                        atomicExch(&tcnt[slot], 1u);
+                        atomicExch(&tcnt[slot], wgt);
                         done = true;
                     } else if (c != WLOCK) {
                         const ulonglong2 t = tk[slot];
-                        if (t.x == w0 && t.y == w1) { atomicAdd(&tcnt[slot], 1u); done = true; }
+                        if (t.x == w0 && t.y == w1) { atomicAdd(&tcnt[slot], wgt); done = true; }
                         else {
                             const uint32_t g = ((uint32_t)w0 ^ __builtin_rotateleft32((uint32_t)(w0 >> 32), 13) ^
                                                 ((uint32_t)w1 * 0x85EBCA6Bu) ^ (uint32_t)(w1 >> 32)) * 0x9E3779B1u;
@@ -1445,7 +1507,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                 const uint64_t m = __ballot(!done);
                 if (m) {
                     const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (!done) { wqk[qn + r] = make_ulonglong2(w0, w1); wqs[qn + r] = slot | (probe << 16); }
+                    if (!done) { wqk[qn + r] = make_ulonglong2(w0, w1); wqs[qn + r] = slot | (probe << 13) | (wgt << 19); }
                     qn += (uint32_t)__popcll(m);
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -1456,43 +1518,52 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                 const ulonglong2 key = v ? wqk[qn + lane_] : make_ulonglong2(0, 0);
                 const uint32_t st = v ? wqs[qn + lane_] : 0u;
                 __builtin_amdgcn_wave_barrier();
-                attempt(key.x, key.y, st & 0xffffu, st >> 16, v);
+                attempt(key.x, key.y, st & 0x1fffu, (st >> 13) & 63u, v, st >> 19);
             };
-            auto insertq = [&](const uint64_t w0, const uint64_t w1, bool v) __attribute__((always_inline)) {
+            static_assert(WCAP <= 8192 && LPROBE < 64, "a queue entry: 13 bits of slot, 6 of probes, 13 of weight");
+            auto insertq = [&](const uint64_t w0, const uint64_t w1, bool v, uint32_t wgt) __attribute__((always_inline)) {
                 const uint32_t g = ((uint32_t)w0 ^ __builtin_rotateleft32((uint32_t)(w0 >> 32), 13) ^
                                     ((uint32_t)w1 * 0x85EBCA6Bu) ^ (uint32_t)(w1 >> 32)) * 0x9E3779B1u;
                 if (S > 1) v = v && (((g >> 4) & 0xffffu) & (S - 1)) == s;
-                attempt(w0, w1, wide_slot(g), 0u, v);
+                attempt(w0, w1, wide_slot(g), 0u, v, wgt);
 #pragma nounroll
                 while (qn >= 64u) pending(64u);
             };
             if constexpr (RECS) {
-                // every wave takes an equal contiguous share of the leaf, 64 records at a time: the records go
-                // to the wave's LDS area, a bit per output position marks where each record's windows start,
-                // and lane j extracts the k-mer at position j (its record by a prefix popcount of those bits)
+                // every wave takes an equal contiguous share of the leaf, 64 records at a time.  A record is first counted
+                // in the record table; what finds no slot there is PARKED in the wave's LDS area, and whenever the area is
+                // full the parked records are expanded: a bit per output position marks where each record's windows
+                // start, and lane j extracts the k-mer at position j (its record by a prefix popcount of those bits).
+                // After the leaf's last record (one barrier) the table's slots are parked and expanded the same way, every
+                // k-mer weighing what its record counted.
                 constexpr int NWV = WLT / 64;
                 const int wave_ = threadIdx.x >> 6;
                 const uint64_t n = end - begin;
                 const uint64_t ws = begin + n * wave_ / NWV, we = begin + n * (wave_ + 1) / NWV;
                 WRec *wrec = (WRec *)(wstage + (size_t)wave_ * WWS);
-                uint32_t *wbits = (uint32_t *)(wrec + 64);
+                uint32_t *wbits = (uint32_t *)(wrec + WPARK);
                 uint32_t *wcum = wbits + 32;
                 const int t = k - 32;
-                WRec nxt = ws + lane_ < we ? elems[ws + lane_] : WRec{0, 0, 0, 0};
-                for (uint64_t r0 = ws; r0 < we; r0 += 64) {
-                    if (__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-                    const bool valid = r0 + lane_ < we;
-                    WRec rc = nxt;
-                    nxt = r0 + 64 + lane_ < we ? elems[r0 + 64 + lane_] : WRec{0, 0, 0, 0};   // travels during the expansion
-                    const uint32_t nwin = valid ? (uint32_t)rec_len(rc) : 0u;
+                const bool agg = WAGG && n <= (uint64_t)WRMAX && !(presplit & 0x10000000u) && agg_on;      // (every hash-selected part of a split leaf too)
+                uint32_t hits = 0;
+                uint32_t parked = 0;                                 // wave-uniform
+                auto kmer_at_pos = [&](uint32_t j, uint64_t *k0, uint64_t *k1, uint32_t *wgt) __attribute__((always_inline)) {
+                    const uint32_t wd = wbits[j >> 5];
+                    const uint32_t ri = wcum[j >> 5] + (uint32_t)__popc(wd & (0xffffffffu >> (31 - (j & 31)))) - 1u;
+                    const WRec rr = wrec[ri];
+                    *wgt = (uint32_t)rr.hd >> 11;
+                    wrec_kmer(rr, j - ((uint32_t)rr.hd & 2047u), t, k0, k1);
+                };
+                auto flush_parked = [&]() __attribute__((always_inline)) {
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t w4 = (uint32_t)lane_ < parked ? (uint32_t)wrec[lane_].hd : 0u;      // windows | weight << 11
+                    const uint32_t nwin = w4 & 31u;
                     const uint32_t x = wave_incl_scan(nwin);
                     const uint32_t off = x - nwin;
                     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
                     if (lane_ < 32) wbits[lane_] = 0;
                     __builtin_amdgcn_wave_barrier();
-                    if (nwin) atomicOr(&wbits[off >> 5], 1u << (off & 31));
-                    rc.hd = (rc.hd & ~0xffffffffULL) | off;          // the header is spent: carry `off`
-                    wrec[lane_] = rc;
+                    if (nwin) { atomicOr(&wbits[off >> 5], 1u << (off & 31)); *(uint32_t *)&wrec[lane_].hd = off | (w4 & ~2047u); }
                     __builtin_amdgcn_wave_barrier();
                     {
                         const uint32_t c = (uint32_t)__popc(wbits[lane_ & 31]);
@@ -1500,26 +1571,108 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                         if (lane_ < 32) wcum[lane_] = y - c;
                     }
                     __builtin_amdgcn_wave_barrier();
-                    auto kmer_at_pos = [&](uint32_t j, uint64_t *k0, uint64_t *k1) __attribute__((always_inline)) {
-                        const uint32_t wd = wbits[j >> 5];
-                        const uint32_t ri = wcum[j >> 5] + (uint32_t)__popc(wd & (0xffffffffu >> (31 - (j & 31)))) - 1u;
-                        const WRec rr = wrec[ri];
-                        wrec_kmer(rr, j - (uint32_t)rr.hd, t, k0, k1);
-                    };
                     // (one k-mer per lane and round: pairing them, as the k <= 31 leaf does, measured 3 ms slower here)
                     for (uint32_t wb = 0; wb < total; wb += 64) {
                         const uint32_t ja = wb + lane_;
                         const bool va = ja < total;
                         uint64_t a0, a1;
-                        kmer_at_pos(va ? ja : 0, &a0, &a1);
+                        uint32_t wg;
+                        kmer_at_pos(va ? ja : 0, &a0, &a1, &wg);
                         if (presplit & 0x40000000u) {                       // ablation (RFX_WIDE_DBG=1): expand, no table
                             if (va && (a0 ^ a1) == 0x123456789ULL) overflow = 1;
                             continue;
                         }
-                        if constexpr (WQCAP > 0) insertq(a0, a1, va); else insert1(a0, a1, va);
+                        if constexpr (WQCAP > 0) insertq(a0, a1, va, wg); else insert1(a0, a1, va);
                     }
                     __builtin_amdgcn_wave_barrier();
+                    parked = 0;
+                };
+                // (valid in at most WPARK lanes)
+                auto park = [&](const WRec &rc, const bool valid, const uint32_t weight) __attribute__((always_inline)) {
+                    const uint64_t vm = __ballot(valid);
+                    if (!vm) return;
+                    const uint32_t d = (uint32_t)__popcll(vm);
+#pragma nounroll
+                    while (parked + d > (uint32_t)WPARK) flush_parked();      // (once; a loop so that the body is not duplicated)
+                    if (valid) {
+                        const uint32_t ord = parked + __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
+                        WRec r2 = rc;
+                        r2.hd = (rc.hd & ~0xffffffffULL) | (uint64_t)((uint32_t)rec_len(rc) | (weight << 11));
+                        wrec[ord] = r2;
+                    }
+                    parked += d;
+                };
+                // the record's own bases: k - 1 + windows of them; what follows in b1 / b2 is whatever followed in the read
+                auto place = [&](const WRec &r, bool valid) __attribute__((always_inline)) -> bool {
+                    if constexpr (!WAGG) return false;
+                    if (!agg || !valid) return false;
+                    const uint32_t nw1 = (uint32_t)(r.hd >> 32) & 15u;
+                    const int ub = 2 * (k + (int)nw1);                             // bits of the base string in use (66..156)
+                    const uint64_t b1 = ub >= 128 ? r.b1 : r.b1 & ~(~0ULL >> (ub - 64));
+                    const uint32_t c = (ub > 128 ? (uint32_t)(r.b2 >> 32) & ~(0xffffffffu >> (ub - 128)) & 0xfffffff0u : 0u) | nw1;
+                    if (r.b0 == EMPTY || b1 == EMPTY) return false;
+                    const uint32_t h = ((uint32_t)r.b0 ^ __builtin_rotateleft32((uint32_t)(r.b0 >> 32), 13) ^ __builtin_rotateleft32((uint32_t)b1, 7) ^
+                                        __builtin_rotateleft32((uint32_t)(b1 >> 32), 19) ^ (c * 0x85EBCA6Bu)) * 0x9E3779B1u;
+                    uint32_t slot = ((h >> 22) * 3u) >> 2;
+                    static_assert(WRSLOTS == 768, "slot = three quarters of ten hash bits");
+#pragma unroll
+                    for (int probe = 0; probe < RPROBE; probe++) {
+                        const unsigned long long pa = atomicCAS(&rA[slot], EMPTY, (unsigned long long)r.b0);
+                        if (pa == EMPTY || pa == r.b0) {
+                            const unsigned long long pb = atomicCAS(&rB[slot], EMPTY, (unsigned long long)b1);
+                            if (pb == EMPTY || pb == b1) {
+                                const unsigned long long pc = atomicCAS(&rCC[slot], EMPTY, (unsigned long long)c << 32);
+                                if (pc == EMPTY || (uint32_t)(pc >> 32) == c) { atomicAdd((uint32_t *)&rCC[slot], 1u); return true; }
+                            }
+                        }
+                        slot = slot + 1u == (uint32_t)WRSLOTS ? 0u : slot + 1u;
+                    }
+                    return false;
+                };
+                WRec nxt = ws + lane_ < we ? elems[ws + lane_] : WRec{0, 0, 0, 0};
+                for (uint64_t r0 = ws; r0 < we; r0 += 64) {
+                    if (__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                    const bool valid = r0 + lane_ < we;
+                    const WRec rc = nxt;
+                    nxt = r0 + 64 + lane_ < we ? elems[r0 + 64 + lane_] : WRec{0, 0, 0, 0};   // travels during the expansion
+                    const bool un = valid && !place(rc, valid);
+                    hits += (uint32_t)__popcll(__ballot(valid && !un));
+                    if (presplit & 0x08000000u) {                           // RFX_WIDE_DBG=... statistics
+                        const uint64_t mp = __ballot(valid && !un), md = __ballot(un);
+                        if (lane_ == 0) { atomicAdd(&co->r_placed, (unsigned long long)__popcll(mp)); atomicAdd(&co->r_direct, (unsigned long long)__popcll(md)); }
+                    }
+                    if constexpr (WPARK >= 64) park(rc, un, 1u);
+                    else {
+#pragma nounroll
+                        for (int hf = 0; hf < 64 / WPARK; hf++) park(rc, un && lane_ / WPARK == hf, 1u);
+                    }
                 }
+                if constexpr (WAGG) {
+                    if (agg) {
+                        __syncthreads();                             // every record of the leaf is counted
+                        const uint32_t slot = (uint32_t)(wave_ * 64 + lane_);
+                        const bool mine = slot < (uint32_t)WRSLOTS;
+                        const unsigned long long a_ = mine ? rA[slot] : EMPTY, b_ = mine ? rB[slot] : EMPTY, cc = mine ? rCC[slot] : EMPTY;
+                        const bool have = cc != EMPTY;
+                        if (a_ != EMPTY) { rA[slot] = EMPTY; rB[slot] = EMPTY; rCC[slot] = EMPTY; }
+                        {
+                            const uint32_t used = (uint32_t)__popcll(__ballot(have));
+                            if (lane_ == 0 && hits != used) atomicAdd(&agg_saved, hits - used);
+                        }
+                        if (presplit & 0x08000000u) {
+                            const uint64_t mh = __ballot(have);
+                            if (lane_ == 0) atomicAdd(&co->r_slots, (unsigned long long)__popcll(mh));
+                        }
+                        if (!__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                            const uint32_t c = (uint32_t)(cc >> 32);
+                            const WRec rr{(uint64_t)a_, (uint64_t)b_, (uint64_t)(c & 0xfffffff0u) << 32, (uint64_t)(c & 15u) << 32};
+#pragma nounroll
+                            for (int hf = 0; hf < 64 / WPARK; hf++) park(rr, have && lane_ / WPARK == hf, (uint32_t)cc);
+                        }
+                    }
+                }
+#pragma nounroll
+                while (parked) flush_parked();
                 if constexpr (WQCAP > 0) {
 #pragma nounroll
                     while (qn > 0u && !__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) pending(qn < 64u ? qn : 64u);
@@ -1538,6 +1691,15 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                 // (the threshold moves BEFORE the sweep, whose closing barrier stands between this store and the next
                 // leaf's read of ps_eff: threads that saw different thresholds would disagree on S and on their barriers)
                 if (RECS && threadIdx.x == 0 && S == 1 && end - begin > (uint64_t)ps_eff * 3 / 4 && ps_eff < (1u << 24)) ps_eff += ps_eff / 64 + 1;
+                if constexpr (WAGG) {
+                    if (threadIdx.x == 0 && agg_on && end - begin <= (uint64_t)WRMAX) {
+                        agg_total += (uint32_t)(end - begin);
+                        if (agg_total >= 8192u) {
+                            if (agg_saved * 2u < agg_total) agg_on = 0;
+                            agg_total = 0; agg_saved = 0;
+                        }
+                    }
+                }
                 // sweep: survivors -> LDS buffer (one add per wave), slots reset
                 for (int base = 0; base < WCAP; base += WLT) {
                     const int slot = base + threadIdx.x;
@@ -3510,7 +3672,8 @@ static int finish_wide2(rfx_ctx *ctx, const std::conditional_t<RECS, WRec, Rec> 
                            min_cov, max_cov, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>(),
                            (uint32_t)(getenv("RFX_WIDE_PRESPLIT") ? atoi(getenv("RFX_WIDE_PRESPLIT")) : 2600) |
                                (getenv("RFX_WIDE_DBG") ? (uint32_t)atoi(getenv("RFX_WIDE_DBG")) << 30 : 0u) |
-                               (getenv("RFX_WIDE_LINEAR") ? 0x20000000u : 0u));
+                               (getenv("RFX_WIDE_LINEAR") ? 0x20000000u : 0u) | (getenv("RFX_WIDE_NOAGG") ? 0x10000000u : 0u) |
+                               (getenv("RFX_WIDE_STATS") ? 0x08000000u : 0u));
         RFX_HIP(hipGetLastError());
     }
     CountOut co{};
@@ -3518,6 +3681,9 @@ static int finish_wide2(rfx_ctx *ctx, const std::conditional_t<RECS, WRec, Rec> 
     RFX_TRY(sync_checked(ctx));
     if (getenv("RFX_TRACE"))
         fprintf(stderr, "wide leaves: %lld buckets, %llu table passes, %llu overflowed\n", (long long)nseg, co.n_passes, co.n_overflow);
+    if (getenv("RFX_WIDE_STATS"))
+        fprintf(stderr, "wide record table: %llu records counted in it, %llu expanded on the spot, %llu slots swept (%.1f per leaf)\n",
+                co.r_placed, co.r_direct, co.r_slots, (double)co.r_slots / (double)std::max<int64_t>(nseg, 1));
     ctx->timing["stat_leaves"].launches += nseg; ctx->timing["stat_passes"].launches += (int64_t)co.n_passes;
     ctx->timing["stat_overflows"].launches += (int64_t)co.n_overflow;
     if (out_n) *out_n = (int64_t)co.n_out;

@@ -1834,6 +1834,9 @@ __global__ void k_reduce_partials(const uint64_t *__restrict__ pk, const uint32_
 constexpr int SK_M = 13;
 constexpr int SK_MIN_W = 9;           // record path for k = 21..31 (W = k - 12 m-mers per window)
 constexpr int SKT = 1024;             // threads per workgroup of the reads -> records kernels
+#ifndef RFX_SK_ROLL
+#define RFX_SK_ROLL 0               // 1: the m-mers rolled a base at a time (rounds 1-2)
+#endif
 #ifndef SK_HIST_RUNLOOP
 #define SK_HIST_RUNLOOP false
 #endif
@@ -1872,9 +1875,10 @@ __device__ __forceinline__ void seg_runs(const ReadSrc &s, int nk_r, int sgm, co
     *hi_out = hi; *lo_out = lo;
     constexpr int M2 = 2 * SK_M;
     const uint32_t mmask = (1u << M2) - 1;
+    uint32_t val[NM];
+#if RFX_SK_ROLL
     uint32_t fm = (uint32_t)(hi >> (64 - M2));
     uint32_t rm = (uint32_t)revcomp((uint64_t)fm, SK_M);
-    uint32_t val[NM];
 #pragma unroll
     for (int j = 0; j < NM; j++) {
         val[j] = mmer_key(fm < rm ? fm : rm);
@@ -1884,6 +1888,26 @@ __device__ __forceinline__ void seg_runs(const ReadSrc &s, int nk_r, int sgm, co
         fm = ((fm << 2) | b) & mmask;
         rm = (rm >> 2) | ((b ^ 3u) << (M2 - 2));
     }
+#else
+    // Every m-mer is CUT out of the 64-base stream, and its reverse complement out of the stream's reverse complement
+    // (made once: the complement of m-mer j is the m-mer at base 51 - j of it), at compile-time positions: a bit-field
+    // extract when the 26 bits lie in one 32-bit word, a funnel shift and a shift otherwise -- 3.5 instructions for the
+    // pair instead of the 6 of rolling both through a base at a time.
+    static_assert(SK_M == 13 && NM <= 34, "positions below");
+    const uint64_t rhi = revcomp(lo, 32), rlo = revcomp(hi, 32);
+    const uint32_t FW[4] = {(uint32_t)(hi >> 32), (uint32_t)hi, (uint32_t)(lo >> 32), (uint32_t)lo};
+    const uint32_t RW[4] = {(uint32_t)(rhi >> 32), (uint32_t)rhi, (uint32_t)(rlo >> 32), (uint32_t)rlo};
+    auto cut = [&](const uint32_t (&Wd)[4], const int pos) __attribute__((always_inline)) -> uint32_t {
+        const int wi = pos >> 4, off = 2 * (pos & 15);
+        if (off + M2 <= 32) return (Wd[wi] >> (32 - M2 - off)) & mmask;
+        return __builtin_amdgcn_alignbit(Wd[wi], Wd[wi < 3 ? wi + 1 : 3], 32 - off) >> (32 - M2);
+    };
+#pragma unroll
+    for (int j = 0; j < NM; j++) {
+        const uint32_t fm = cut(FW, j), rm = cut(RW, 64 - SK_M - j);
+        val[j] = mmer_key(fm < rm ? fm : rm);
+    }
+#endif
     // per-window minimiser = sliding minimum over W m-mers (van Herk: suffix minima and prefix minima
     // inside blocks of W m-mers; a window spans at most two blocks)
     uint32_t wm[PK];
@@ -1925,11 +1949,20 @@ __device__ __forceinline__ void seg_runs(const ReadSrc &s, int nk_r, int sgm, co
     // window position (16 divergent call sites).
     uint32_t starts = 1u;
 #pragma unroll
-    for (int i = 1; i < PK; i++) starts |= (uint32_t)(i < v && wm[i] != wm[i - 1]) << i;
+    for (int i = 1; i < PK; i++) starts |= (uint32_t)(wm[i] != wm[i - 1]) << i;
+    starts &= 0xffffffffu >> (32 - v);                 // (1 <= v <= PK: the windows the read has in this segment)
     if (wm_lds) {
 #pragma unroll
         for (int i = 0; i < PK; i++) wm_lds[i * SKT + threadIdx.x] = wm[i];
     }
+    // (the loop below picks wm[i0] with a tree of selects.  A select between two ELEMENTS of an array is turned into
+    // an indexed load by the compiler, and the array into scratch memory: the minima become sixteen scalars, results of
+    // an empty asm, which are no elements of anything)
+    uint32_t m0 = wm[0], m1 = wm[1], m2 = wm[2], m3 = wm[3], m4 = wm[4], m5 = wm[5], m6 = wm[6], m7 = wm[7], m8 = wm[8],
+             m9 = wm[9], m10 = wm[10], m11 = wm[11], m12 = wm[12], m13 = wm[13], m14 = wm[14], m15 = wm[15];
+    if (!wm_lds)
+        asm("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "+v"(m4), "+v"(m5), "+v"(m6), "+v"(m7), "+v"(m8), "+v"(m9), "+v"(m10),
+                 "+v"(m11), "+v"(m12), "+v"(m13), "+v"(m14), "+v"(m15));
     while (starts) {
         const int i0 = __ffs((int)starts) - 1;
         starts &= starts - 1;
@@ -1940,9 +1973,15 @@ __device__ __forceinline__ void seg_runs(const ReadSrc &s, int nk_r, int sgm, co
         if (wm_lds) {
             key = wm_lds[i0 * SKT + threadIdx.x];
         } else {
-            key = wm[0];
-#pragma unroll
-            for (int j = 1; j < PK; j++) key = i0 == j ? wm[j] : key;
+            // (a tree of selects on the bits of i0: 15 selects under 4 masks, where a chain of 15 compares each waits
+            // for its own mask)
+            static_assert(PK == 16, "four levels");
+            const bool b0 = i0 & 1, b1 = i0 & 2, b2 = i0 & 4, b3 = i0 & 8;
+            const uint32_t a0 = b0 ? m1 : m0, a1 = b0 ? m3 : m2, a2 = b0 ? m5 : m4, a3 = b0 ? m7 : m6, a4 = b0 ? m9 : m8,
+                           a5 = b0 ? m11 : m10, a6 = b0 ? m13 : m12, a7 = b0 ? m15 : m14;
+            const uint32_t c0 = b1 ? a1 : a0, c1 = b1 ? a3 : a2, c2 = b1 ? a5 : a4, c3 = b1 ? a7 : a6;
+            const uint32_t d0 = b2 ? c1 : c0, d1 = b2 ? c3 : c2;
+            key = b3 ? d1 : d0;
         }
         emit(i0, i1 - i0, key);
     }

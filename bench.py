@@ -23,6 +23,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# functional rehearsal of the N > 1 branch on a ONE-GPU box (tests/test_gpu_multirank.py): every rank on cuda:0, gloo for
+# torch's own collectives, the C ABI's RCCL served by the tests' stand-in (RFX_RCCL_LIB); the line says so ("rehearsal")
+SHARED_GPU = os.environ.get("RFX_BENCH_SHARED_GPU", "0") == "1" and bool(os.environ.get("RFX_RCCL_LIB"))
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec)
 
 # algorithmic HBM bytes per k-mer instance, per kernel family (DESIGN.md "Kernels")
@@ -107,7 +110,7 @@ def self_launch(args):
     import subprocess
     import torch
     have = torch.cuda.device_count()            # does not initialise the GPU runtime
-    if have < args.gpus:
+    if have < args.gpus and not SHARED_GPU:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible on this box: refusing to run "
                          f"(a {args.gpus}-GPU number can only come from {args.gpus} ranks)\n")
         sys.exit(2)
@@ -221,7 +224,7 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if SHARED_GPU else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks\n")
         sys.exit(2)
@@ -233,10 +236,13 @@ def main():
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if SHARED_GPU:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         # n_gpus in the JSON line is what RCCL saw, nothing else
         world = dist.get_world_size()
-        probe = torch.ones(1, device=torch.device("cuda", local))
+        probe = torch.ones(1, device="cpu" if SHARED_GPU else torch.device("cuda", local))
         dist.all_reduce(probe)
         if int(probe.item()) != args.gpus and not (args.force_dist and args.gpus == 1):
             sys.stderr.write(f"bench.py: {int(probe.item())} ranks joined the RCCL group, --gpus {args.gpus} asked for\n")
@@ -348,7 +354,7 @@ def main():
             a[0] += ms; a[1] += ln
     sync_all()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if SHARED_GPU else dev)
     if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -391,6 +397,9 @@ def main():
         "stage_hbm_frac": (((0.25 + 16 * W) * n_inst + (8 * W + 4) * m) / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS) if not multi else None,
     }
 
+    if SHARED_GPU:
+        out["rehearsal"] = (f"FUNCTIONAL REHEARSAL, not a measurement: {world} ranks share ONE GPU, RCCL replaced by the tests' "
+                            "stand-in (RFX_BENCH_SHARED_GPU / RFX_RCCL_LIB); the timing fields mean nothing")
     if multi:
         # what crosses the all-to-all: every rank buckets B bytes per step and keeps 1/N of them; each
         # peer's share travels over its own xGMI link (7 links x ~153 GB/s per GPU, MI355X_MICROARCH.md)

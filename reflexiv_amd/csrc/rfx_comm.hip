@@ -42,6 +42,11 @@ NcclApi &nccl() {
     static NcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
+        // RFX_RCCL_LIB: an explicit library instead (tests: a stand-in that lets several ranks share one GPU)
+        if (const char *e = getenv("RFX_RCCL_LIB")) {
+            api.h = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+            if (!api.h) { api.error = std::string("RFX_RCCL_LIB: ") + (dlerror() ? dlerror() : "?"); return; }
+        }
         const char *names[] = {"librccl.so.1", "librccl.so"};
         for (const char *n : names)
             if (!api.h) api.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);          // the host process's own RCCL first

@@ -1,0 +1,127 @@
+"""One rank of tests/test_gpu_multirank.py: `python multirank_worker.py RANK WORLD WORKDIR` -- every rank is a process of
+its own with its own context and communicator on cuda:0 (RCCL replaced by tests/fake_rccl through RFX_RCCL_LIB, because
+RCCL refuses two ranks on one device).  Rank 0 checks the shards against the fused one-GPU count of ALL ranks' reads and
+against the oracle, and writes WORKDIR/ok."""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def main():
+    rank, world, work = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    import torch
+    import reflexiv_amd
+    from reflexiv_amd import Reflexiv
+
+    torch.cuda.set_device(0)
+    idf = os.path.join(work, "id")
+    if rank == 0:
+        uid = Reflexiv.comm_unique_id()
+        with open(idf + ".tmp", "wb") as f:
+            f.write(uid)
+        os.rename(idf + ".tmp", idf)
+    else:
+        t0 = time.time()
+        while not os.path.exists(idf):
+            assert time.time() - t0 < 120, "rank 0 never published the id"
+            time.sleep(0.01)
+        uid = open(idf, "rb").read()
+    rfx = Reflexiv(0)
+    rfx.comm_init(uid, rank, world)
+
+    seed, G, n_reads, L = 77, 200_000, 60_000, 150            # per rank
+    wpr = (L + 31) // 32
+    dg = torch.empty((G + 31) // 32, dtype=torch.int64, device="cuda")
+    dw = torch.empty(n_reads * wpr, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    rfx.synth_genome_dev(seed, G, dg.data_ptr())
+    rfx.synth_reads_dev(seed, dg.data_ptr(), G, rank * n_reads, n_reads, L, wpr, dw.data_ptr())
+    rfx.sync()
+    if rank == 0:
+        da = torch.empty(world * n_reads * wpr, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        rfx.synth_reads_dev(seed, dg.data_ptr(), G, 0, world * n_reads, L, wpr, da.data_ptr())
+        rfx.sync()
+
+    assert rfx.comm_all_reduce([rank + 1, -rank, 1 << 40]) == [world * (world + 1) // 2, -world * (world - 1) // 2, world << 40]
+    assert rfx.comm_all_reduce([rank, 7 - rank], "max") == [world - 1, 7]
+
+    cover = 3
+    for k, gens in ((31, 1), (31, 4), (25, 3), (63, 2), (47, 4)):
+        wide = k > 32
+        W = 2 if wide else 1
+        nk = (rfx.kmers_per_read_w if wide else rfx.kmers_per_read)(L, k)
+        cap = nk * n_reads
+        cdt = torch.int64 if wide else torch.int32
+        sk = torch.empty(cap * W, dtype=torch.int64, device="cuda"); sc = torch.empty(cap, dtype=cdt, device="cuda")
+        torch.cuda.synchronize()
+        ms, tot = rfx.sharded_count_dev(dw.data_ptr(), n_reads, wpr, L, k, sk.data_ptr(), sc.data_ptr(), cap, cover, generations=gens)
+        assert tot[0] == nk * n_reads * world
+        # the shard is ascending (the order contract of every count-stage output)
+        if ms > 1 and not wide:
+            s = sk[:ms]
+            assert bool((s[1:] > s[:-1]).all()), (k, gens, "shard not ascending")
+        allm = rfx.comm_all_reduce([ms])[0]
+        assert allm == tot[2]
+        gk = torch.empty(max(1, allm) * W, dtype=torch.int64, device="cuda") if rank == 0 else sk[:0]
+        gc = torch.empty(max(1, allm), dtype=cdt, device="cuda") if rank == 0 else sc[:0]
+        torch.cuda.synchronize()
+        got = rfx.gather_shards_dev(sk.data_ptr(), sc.data_ptr(), ms, W, 8 if wide else 4, 0, gk.data_ptr(), gc.data_ptr(), allm)
+        # a root buffer that is too small fails on root only, before anybody sends
+        if allm > 1:
+            try:
+                rfx.gather_shards_dev(sk.data_ptr(), sc.data_ptr(), ms, W, 8 if wide else 4, 0, gk.data_ptr(), gc.data_ptr(), allm - 1)
+                assert rank != 0
+            except reflexiv_amd.RfxError as e:
+                assert rank == 0 and e.need == allm
+        if rank == 0:
+            assert got == allm
+            fk = torch.empty(cap * world * W, dtype=torch.int64, device="cuda"); fc = torch.empty(cap * world, dtype=cdt, device="cuda")
+            torch.cuda.synchronize()
+            if wide:
+                m, nd, inst = rfx.count_reads_w_dev(da.data_ptr(), world * n_reads, wpr, L, k, fk.data_ptr(), fc.data_ptr(), cap * world, cover)
+                rfx.order_kmers_w_dev(gk.data_ptr(), gc.data_ptr(), got, k)
+                rfx.sync()
+                rk, rc = gk[:got * W], gc[:got]
+            else:
+                m, nd, inst = rfx.count_reads_dev(da.data_ptr(), world * n_reads, wpr, L, k, fk.data_ptr(), fc.data_ptr(), cap * world, cover)
+                tk = torch.empty_like(gk); tv = torch.empty_like(gc)
+                rfx.sort_pairs_dev(gk.data_ptr(), gc.data_ptr(), got, 2 * k, tk.data_ptr(), tv.data_ptr())
+                rfx.sync()
+                rk, rc = gk[:got], gc[:got]
+            assert tot == [inst, nd, m], (k, gens, tot, [inst, nd, m])
+            assert torch.equal(rk, fk[:m * W]) and torch.equal(rc, fc[:m]), (k, gens)
+            # every k-mer lives on exactly one rank: the gathered list has no repeats (it equals the fused list) -- done above
+
+    # host ASCII reads of any length -> contig text on rank 0: the documented example dealt round the ranks
+    from oracle import oracle as O
+    ex = np.load(os.path.join(HERE, "golden", "example.npz"))
+    bases, off = ex["bases"], ex["read_off"]
+    nr = len(off) - 1
+    mine = np.arange(rank, nr, world)
+    mb = np.concatenate([bases[off[i]:off[i + 1]] for i in mine])
+    mo = np.zeros(len(mine) + 1, np.int64)
+    mo[1:] = np.cumsum(off[mine + 1] - off[mine])
+    prm = reflexiv_amd.default_params(min_cov=3, partitions=4, twin=reflexiv_amd.TWIN_RDD)
+    text, nc, trace, tot = rfx.sharded_assemble_reads(mb, mo, prm, generations=2)
+    if rank == 0:
+        km = O.extract_canon(bases, off, 31)
+        wk, wc, wd = O.count_filter(km, 3)
+        otext, onc, otrace, _ = O.assemble_from_counts(wk, wc, O.default_params(min_cov=3, partitions=4, twin=O.TWIN_RDD))
+        assert tot == [len(km), wd, len(wk)]
+        assert (text, nc, trace) == (otext, onc, otrace) and text.startswith(">Contig-4558-0\n")
+    else:
+        assert text == "" and nc == 0
+    rfx.comm_all_reduce([1])                                   # nobody leaves while a peer still reads its files
+    rfx.close()
+    with open(os.path.join(work, f"ok{rank}"), "w") as f:
+        f.write("ok\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -66,3 +66,19 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f)).read()
                 assert not bad.search(text), f
+
+
+def test_rccl_stand_in_of_the_multirank_tests_exports_what_the_library_binds():
+    """tests/fake_rccl (test infrastructure: several ranks on one GPU) must serve every RCCL entry point rfx_comm.hip
+    looks up with dlsym -- read from the source, so a new binding cannot be forgotten there."""
+    import ctypes
+    import re
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.run(["make", "-s", "-C", os.path.join(here, "fake_rccl")], check=True, capture_output=True)
+    shim = ctypes.CDLL(os.path.join(here, "fake_rccl", "libfake_rccl.so"))
+    src = open(os.path.join(here, "..", "reflexiv_amd", "csrc", "rfx_comm.hip")).read()
+    names = re.findall(r'sym\("(nccl[A-Za-z]+)"\)', src)
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(shim, n), n

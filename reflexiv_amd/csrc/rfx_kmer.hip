@@ -186,9 +186,10 @@ __device__ __forceinline__ int read_nk(const ReadSrc &s, int64_t r) {
 
 struct SegPos { int64_t r; int sgm; };
 
+template <int SEG = 16>
 __device__ __forceinline__ void seg_load(const ReadSrc &s, const SegPos &q, uint64_t (&w)[3]) {
     const uint64_t *g = s.words + q.r * s.wpr;
-    const int wi = (s.fc + q.sgm * PK) >> 5;
+    const int wi = (s.fc + q.sgm * SEG) >> 5;
     const int last = s.wpr - 1;
     w[0] = g[wi < last ? wi : last];
     w[1] = g[wi + 1 < last ? wi + 1 : last];
@@ -1850,9 +1851,21 @@ constexpr int SKT = 1024;             // threads per workgroup of the reads -> r
 // order of the m-mers: a bijection of the canonical 26-bit m-mer onto 32 bits (odd multiplier,
 // xor-shift), so two different m-mers never tie and a plain 32-bit minimum picks the minimiser;
 // the value itself (not the m-mer) names the bucket
+// (RFX_MMER_KEY24, round 3: ONE full-rate instruction, v_mad_u32_u24 -- the low 24 bits of the m-mer times a 24-bit odd
+// constant, plus the m-mer (which brings in its first base, bits 24-25) -- instead of a quarter-rate 32-bit multiply, a
+// shift and an xor: 34 m-mers per segment make this 15 % of level 1's issue cycles.  Not a bijection any more, and it need
+// not be one: the value, not the m-mer, names the run and its bucket, so two m-mers that tie simply share a run -- the
+// bucket is still a function of the canonical k-mer.)
+#ifndef RFX_MMER_KEY24
+#define RFX_MMER_KEY24 1
+#endif
 __device__ __forceinline__ uint32_t mmer_key(uint32_t canon) {
+#if RFX_MMER_KEY24
+    return __umul24(canon, 0x9E3779u) + canon;
+#else
     uint32_t h = canon * 0x9E3779B1u;
     return h ^ (h >> 15);
+#endif
 }
 
 // digit of a record at a level that follows `used` radix bits
@@ -1861,10 +1874,17 @@ __device__ __forceinline__ unsigned rec_digit(uint32_t hdr, int used, int bits) 
 }
 
 // Walks the runs of one segment; calls emit(first_window, n_windows, minimiser_key).
-template <int W, bool RUNLOOP, class F>
+// SEG: windows per segment, 16 or 32 (round 3).  A thread that owns 32 windows evaluates 50 m-mers where two threads of 16
+// evaluate 68, pays the per-segment work once, and -- what counts downstream -- a read is cut into records at half as
+// many places that only depend on where the read happened to start: 19 % fewer records, and more of them identical from
+// read to read.  Runs stay <= 16 windows (four bits in the record): a longer one is cut 16 windows after its start.
+template <int W, bool RUNLOOP, int SEG = 16, class F>
 __device__ __forceinline__ void seg_runs(const ReadSrc &s, int nk_r, int sgm, const uint64_t (&w)[3], F &&emit,
                                          uint64_t *hi_out, uint64_t *lo_out, uint32_t *wm_lds = nullptr) {
-    constexpr int NM = PK + W - 1;                 // m-mers a segment can touch (<= 34)
+    static_assert(SEG == 16 || SEG == 32, "segment");
+    constexpr int PK = SEG;                        // (shadows the file-wide 16 inside this function)
+    constexpr int NM = PK + W - 1;                 // m-mers a segment can touch (<= 34, or <= 50)
+    static_assert(NM + SK_M - 1 <= 64, "the segment's bases lie in (hi, lo)");
     const int p0 = sgm * PK;
     int v = nk_r - p0;
     v = v > PK ? PK : v;
@@ -1893,7 +1913,7 @@ __device__ __forceinline__ void seg_runs(const ReadSrc &s, int nk_r, int sgm, co
     // (made once: the complement of m-mer j is the m-mer at base 51 - j of it), at compile-time positions: a bit-field
     // extract when the 26 bits lie in one 32-bit word, a funnel shift and a shift otherwise -- 3.5 instructions for the
     // pair instead of the 6 of rolling both through a base at a time.
-    static_assert(SK_M == 13 && NM <= 34, "positions below");
+    static_assert(SK_M == 13 && NM <= 50, "positions below");
     const uint64_t rhi = revcomp(lo, 32), rlo = revcomp(hi, 32);
     const uint32_t FW[4] = {(uint32_t)(hi >> 32), (uint32_t)hi, (uint32_t)(lo >> 32), (uint32_t)lo};
     const uint32_t RW[4] = {(uint32_t)(rhi >> 32), (uint32_t)rhi, (uint32_t)(rlo >> 32), (uint32_t)rlo};
@@ -1936,7 +1956,7 @@ __device__ __forceinline__ void seg_runs(const ReadSrc &s, int nk_r, int sgm, co
         int start = 0;
 #pragma unroll
         for (int i = 1; i < PK; i++) {
-            if (i < v && wm[i] != cur) {
+            if (i < v && (wm[i] != cur || (PK > 16 && i - start == 16))) {
                 emit(start, i - start, cur);
                 cur = wm[i]; start = i;
             }
@@ -1951,6 +1971,15 @@ __device__ __forceinline__ void seg_runs(const ReadSrc &s, int nk_r, int sgm, co
 #pragma unroll
     for (int i = 1; i < PK; i++) starts |= (uint32_t)(wm[i] != wm[i - 1]) << i;
     starts &= 0xffffffffu >> (32 - v);                 // (1 <= v <= PK: the windows the read has in this segment)
+    if constexpr (PK > 16) {
+        // no run longer than 16 windows: `cov` = the windows within 15 of a start at or before them; the lowest window
+        // that is not lies exactly 16 after a start and becomes one (bit 0 is set, so whatever is not covered lies in
+        // the upper half, and the new start covers all that is left of it)
+        uint32_t cov = starts;
+        cov |= cov << 1; cov |= cov << 2; cov |= cov << 4; cov |= cov << 8;
+        const uint32_t unc = ~cov & (0xffffffffu >> (32 - v));
+        starts |= unc & (0u - unc);
+    }
     if (wm_lds) {
 #pragma unroll
         for (int i = 0; i < PK; i++) wm_lds[i * SKT + threadIdx.x] = wm[i];
@@ -1963,6 +1992,13 @@ __device__ __forceinline__ void seg_runs(const ReadSrc &s, int nk_r, int sgm, co
     if (!wm_lds)
         asm("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "+v"(m4), "+v"(m5), "+v"(m6), "+v"(m7), "+v"(m8), "+v"(m9), "+v"(m10),
                  "+v"(m11), "+v"(m12), "+v"(m13), "+v"(m14), "+v"(m15));
+    constexpr int UP = PK > 16 ? 16 : 0;               // (SEG = 16: the upper sixteen alias the lower and are never selected)
+    uint32_t n0 = wm[UP + 0], n1 = wm[UP + 1], n2 = wm[UP + 2], n3 = wm[UP + 3], n4 = wm[UP + 4], n5 = wm[UP + 5], n6 = wm[UP + 6],
+             n7 = wm[UP + 7], n8 = wm[UP + 8], n9 = wm[UP + 9], n10 = wm[UP + 10], n11 = wm[UP + 11], n12 = wm[UP + 12],
+             n13 = wm[UP + 13], n14 = wm[UP + 14], n15 = wm[UP + 15];
+    if (!wm_lds && PK > 16)
+        asm("" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4), "+v"(n5), "+v"(n6), "+v"(n7), "+v"(n8), "+v"(n9), "+v"(n10),
+                 "+v"(n11), "+v"(n12), "+v"(n13), "+v"(n14), "+v"(n15));
     while (starts) {
         const int i0 = __ffs((int)starts) - 1;
         starts &= starts - 1;
@@ -1975,13 +2011,20 @@ __device__ __forceinline__ void seg_runs(const ReadSrc &s, int nk_r, int sgm, co
         } else {
             // (a tree of selects on the bits of i0: 15 selects under 4 masks, where a chain of 15 compares each waits
             // for its own mask)
-            static_assert(PK == 16, "four levels");
             const bool b0 = i0 & 1, b1 = i0 & 2, b2 = i0 & 4, b3 = i0 & 8;
             const uint32_t a0 = b0 ? m1 : m0, a1 = b0 ? m3 : m2, a2 = b0 ? m5 : m4, a3 = b0 ? m7 : m6, a4 = b0 ? m9 : m8,
                            a5 = b0 ? m11 : m10, a6 = b0 ? m13 : m12, a7 = b0 ? m15 : m14;
             const uint32_t c0 = b1 ? a1 : a0, c1 = b1 ? a3 : a2, c2 = b1 ? a5 : a4, c3 = b1 ? a7 : a6;
             const uint32_t d0 = b2 ? c1 : c0, d1 = b2 ? c3 : c2;
             key = b3 ? d1 : d0;
+            if constexpr (PK > 16) {                   // a fifth level: the same tree over the upper sixteen
+                const uint32_t e0 = b0 ? n1 : n0, e1 = b0 ? n3 : n2, e2 = b0 ? n5 : n4, e3 = b0 ? n7 : n6, e4 = b0 ? n9 : n8,
+                               e5 = b0 ? n11 : n10, e6 = b0 ? n13 : n12, e7 = b0 ? n15 : n14;
+                const uint32_t f0 = b1 ? e1 : e0, f1 = b1 ? e3 : e2, f2 = b1 ? e5 : e4, f3 = b1 ? e7 : e6;
+                const uint32_t g0 = b2 ? f1 : f0, g1 = b2 ? f3 : f2;
+                const uint32_t ku = b3 ? g1 : g0;
+                key = (i0 & 16) ? ku : key;
+            }
         }
         emit(i0, i1 - i0, key);
     }
@@ -2194,6 +2237,12 @@ __global__ __launch_bounds__(SKT, WIDE ? 4 : 8) void k_sk_scatter(ReadSrc s, Lev
 #ifndef RFX_DRAIN_UNROLL
 #define RFX_DRAIN_UNROLL 1
 #endif
+#ifndef RFX_OS_A32
+#define RFX_OS_A32 4                 // records per aligned burst of the 16-slot rings (4 = 64 bytes, 8 = 128)
+#endif
+#ifndef RFX_OS_T32
+#define RFX_OS_T32 512               // threads per workgroup of the sweep with 32 windows per thread
+#endif
 constexpr int OSE_MIN = 64, OSE_MAX = 256;   // records per extent: a round must not put more than one extent of one
                                          // workgroup into one bucket (5 records on average at 512 buckets); the sampled
                                          // histogram picks 64, 128 or 256 by the busiest bucket, or no sweep at all
@@ -2211,7 +2260,7 @@ struct OneSweep {
     uint32_t ose, ose_shift;             // records per extent (a power of two)
 };
 
-template <int W>
+template <int W, int SEG = 16>
 __global__ __launch_bounds__(SKT) void k_sk_sample_hist(ReadSrc s, Level lv, int sample, unsigned long long *__restrict__ hist) {
     __shared__ uint32_t h[1 << MAX_BITS];
     const int nb = 1 << lv.bits;
@@ -2225,8 +2274,8 @@ __global__ __launch_bounds__(SKT) void k_sk_sample_hist(ReadSrc s, Level lv, int
             q.r = g / s.segs;
             q.sgm = (int)(g - q.r * s.segs);
             uint64_t w[3], hi, lo;
-            seg_load(s, q, w);
-            seg_runs<W, SK_HIST_RUNLOOP>(s, read_nk(s, q.r), q.sgm, w, [&](int, int, uint32_t canon) { atomicAdd(&h[sk_digit(canon, lv)], 1u); }, &hi, &lo);
+            seg_load<SEG>(s, q, w);
+            seg_runs<W, SK_HIST_RUNLOOP, SEG>(s, read_nk(s, q.r), q.sgm, w, [&](int, int, uint32_t canon) { atomicAdd(&h[sk_digit(canon, lv)], 1u); }, &hi, &lo);
         }
     }
     __syncthreads();
@@ -2276,10 +2325,21 @@ __global__ __launch_bounds__(1024) void k_plan_regions(const unsigned long long 
 }
 
 // WIDE: the 32-byte records of the k = 33..63 path (as in k_sk_scatter)
-template <int W, bool WIDE = false>
-__global__ __launch_bounds__(SKT, WIDE ? 4 : 8) void k_sk_onesweep(ReadSrc s, Level lv, OneSweep os,
+// SEG: windows a thread owns (seg_runs).  32: one workgroup per CU (the minima of 32 windows and 50 m-mers live in
+// registers) with rings of OSB = 16 records, since a round now brings a bucket 8 records on average.
+// (first form: 1024 threads, one workgroup per CU, rings of 16: no faster than 16 windows per thread -- the instructions
+// saved went into the CU standing still at the round's two barriers.  Hence T = 512 threads: two workgroups per CU again,
+// a tile brings a bucket what it did before, and the rings stay at 8 slots.)
+template <int SEG, bool WIDE> struct OsGeo {
+    static constexpr int T = SEG > 16 && !WIDE ? RFX_OS_T32 : SKT;           // threads per workgroup = segments per tile
+    static constexpr int B = SEG > 16 && !WIDE && T == SKT ? 16 : SKB, A = SEG > 16 && !WIDE && T == SKT ? RFX_OS_A32 : SKA;
+};
+template <int W, bool WIDE = false, int SEG = 16>
+__global__ __launch_bounds__((OsGeo<SEG, WIDE>::T), (WIDE || SEG > 16) ? 4 : 8) void k_sk_onesweep(ReadSrc s, Level lv, OneSweep os,
                                                                std::conditional_t<WIDE, WRec, Rec> *__restrict__ out) {
     using RT = std::conditional_t<WIDE, WRec, Rec>;
+    constexpr int SKB = OsGeo<SEG, WIDE>::B, SKA = OsGeo<SEG, WIDE>::A;      // (shadow the file-wide ring geometry
+    constexpr int SKT = OsGeo<SEG, WIDE>::T;                                  //  and workgroup size)
     extern __shared__ __attribute__((aligned(32))) unsigned char sk_smem[];
     const int nb = 1 << lv.bits;
 #define buf ((RT *)sk_smem)
@@ -2329,7 +2389,11 @@ __global__ __launch_bounds__(SKT, WIDE ? 4 : 8) void k_sk_onesweep(ReadSrc s, Le
                 nh = e;
             }
             const uint32_t g = h + j;
+#ifdef RFX_OS_ABL_NOSTORE
+            if (g < e && g == 0xFFFFFFF0u) out[phys(g, cs, cb, nx)] = buf[(size_t)d * SKB + (g & (SKB - 1))];
+#else
             if (g < e) out[phys(g, cs, cb, nx)] = buf[(size_t)d * SKB + (g & (SKB - 1))];
+#endif
             if (j == 0) {
                 head[d] = nh;
                 // extents that lie wholly behind the stored position are done with: move up (the 8 lanes of this
@@ -2361,8 +2425,8 @@ __global__ __launch_bounds__(SKT, WIDE ? 4 : 8) void k_sk_onesweep(ReadSrc s, Le
             q.r = g / s.segs;
             q.sgm = (int)(g - q.r * s.segs);
             uint64_t w[3], hi = 0, lo = 0;
-            seg_load(s, q, w);
-            seg_runs<W, SK_SCATTER_RUNLOOP>(s, read_nk(s, q.r), q.sgm, w, [&](int i0, int n, uint32_t canon) {
+            seg_load<SEG>(s, q, w);
+            seg_runs<W, SK_SCATTER_RUNLOOP, SEG>(s, read_nk(s, q.r), q.sgm, w, [&](int i0, int n, uint32_t canon) {
                 const uint64_t hh = mmer_hash64(canon);
                 const uint32_t hdr = (uint32_t)((hh << OWNER_BITS) >> 32);
                 const unsigned d = rec_digit(hdr, 0, lv.bits);
@@ -2370,7 +2434,7 @@ __global__ __launch_bounds__(SKT, WIDE ? 4 : 8) void k_sk_onesweep(ReadSrc s, Le
                 if constexpr (WIDE) {
                     // 96 bases from the first base of the run's first k-mer (see k_sk_scatter)
                     const uint64_t *gw = s.words + q.r * s.wpr;
-                    const int p = s.fc - s.wfl + q.sgm * PK + i0;
+                    const int p = s.fc - s.wfl + q.sgm * SEG + i0;
                     const int wi = p >> 5, sft = 2 * (p & 31), last = s.wpr - 1;
                     const uint64_t a0 = gw[wi < last ? wi : last], a1 = gw[wi + 1 < last ? wi + 1 : last];
                     const uint64_t a2 = gw[wi + 2 < last ? wi + 2 : last], a3 = gw[wi + 3 < last ? wi + 3 : last];
@@ -3160,20 +3224,32 @@ static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv
 // level 1 of the record path in one sweep (k_sk_onesweep): -> records in workspace slot `ws_slot`, bucket b in
 // [d_seg_begin[b], d_seg_end[b]).  *done = false: a region overflowed, nothing is valid, take the two-pass form.
 template <bool WIDE = false>
-static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv, int ws_slot, uint64_t *d_seg_begin,
+static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc_in, const Level &lv, int ws_slot, uint64_t *d_seg_begin,
                             uint64_t *d_seg_end, std::conditional_t<WIDE, WRec, Rec> **out_recs, int64_t *n_recs, bool *done,
                             const char *hn, const char *pn) {
     using Rec = std::conditional_t<WIDE, WRec, ::Rec>;
     *done = false;
     const int nb = 1 << lv.bits;
-    const int W = rsrc.k - SK_M + 1;
-    const int64_t ntile = ceil_div(rsrc.n_threads, SKT);
-    // two workgroups per CU; fewer on small inputs (every workgroup holds three extents per bucket: at least 32 tiles each)
-    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(OS_MAXG, (int64_t)ctx->num_cu * (WIDE ? 1 : 2)),
+    const int W = rsrc_in.k - SK_M + 1;
+    // 32 windows per thread (seg_runs; RFX_SK_SEG=16: the 16 of rounds 1-2).  The k = 33..63 records keep 16.
+    // (its 16-slot rings fit the LDS up to 512 buckets)
+    const bool seg32 = !WIDE && nb <= 512 && !(getenv("RFX_SK_SEG") && atoi(getenv("RFX_SK_SEG")) == 16);
+    ReadSrc rsrc = rsrc_in;
+    if (seg32) {
+        rsrc.segs = rsrc.nk > 0 ? (rsrc.nk + 31) / 32 : 1;
+        rsrc.n_threads = rsrc.n_reads * rsrc.segs;
+    }
+    const int OST = seg32 ? OsGeo<32, false>::T : SKT;            // threads per workgroup of the sweep = segments per tile
+    const int64_t ntile = ceil_div(rsrc.n_threads, OST);
+    const int64_t ntile_s = ceil_div(rsrc.n_threads, SKT);        // (the sampled histogram keeps tiles of SKT segments)
+    // two workgroups per CU (one when a workgroup fills the CU); fewer on small inputs (every workgroup holds three extents
+    // per bucket: at least 32 tiles each)
+    const int per_cu = WIDE || (seg32 && OST == SKT) ? 1 : 2;
+    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(OS_MAXG, (int64_t)ctx->num_cu * per_cu),
                                                                 std::max<int64_t>(std::min<int64_t>(ntile, 64), ntile / 32)));
     int sample = getenv("RFX_SK_SAMPLE") ? std::max(1, atoi(getenv("RFX_SK_SAMPLE"))) : 32;
-    if (ntile < 64 * (int64_t)sample) sample = (int)std::max<int64_t>(1, ntile / 64);      // small inputs: at least 64 tiles
-    const int64_t n_sampled = ceil_div(ntile, sample);
+    if (ntile_s < 64 * (int64_t)sample) sample = (int)std::max<int64_t>(1, ntile_s / 64);      // small inputs: at least 64 tiles
+    const int64_t n_sampled = ceil_div(ntile_s, sample);
     const int cap_pct = getenv("RFX_SK_ONESWEEP_CAP") ? std::max(1, atoi(getenv("RFX_SK_ONESWEEP_CAP"))) : 100;
     DevBuf hist, reg_start, reg_cap, cursor, totals, holes;
     RFX_HIP(hist.alloc((size_t)nb * 8 + 16, ctx->stream));                 // + the overflow flag
@@ -3188,14 +3264,15 @@ static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv, 
         ScopedTimer t(ctx, hn);
         const dim3 gs((unsigned)std::min<int64_t>(n_sampled, (int64_t)ctx->num_cu * 8));
         switch (W) {
-#define X(w) case w: hipLaunchKernelGGL((k_sk_sample_hist<w>), gs, dim3(SKT), 0, ctx->stream, rsrc, lv, sample, hist.as<unsigned long long>()); break;
+#define X(w) case w: if (seg32) hipLaunchKernelGGL((k_sk_sample_hist<w, 32>), gs, dim3(SKT), 0, ctx->stream, rsrc, lv, sample, hist.as<unsigned long long>()); \
+                     else hipLaunchKernelGGL((k_sk_sample_hist<w>), gs, dim3(SKT), 0, ctx->stream, rsrc, lv, sample, hist.as<unsigned long long>()); break;
             RFX_SK_W_CASES(X)
+            default: X(19)
 #undef X
-            default: hipLaunchKernelGGL((k_sk_sample_hist<19>), gs, dim3(SKT), 0, ctx->stream, rsrc, lv, sample, hist.as<unsigned long long>()); break;
         }
         RFX_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_plan_regions, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long *)hist.as<unsigned long long>(), nb,
-                           (double)ntile / (double)n_sampled, G, cap_pct, (double)ntile, reg_start.as<uint64_t>(), reg_cap.as<uint32_t>(),
+                           (double)ntile_s / (double)n_sampled, G, cap_pct, (double)ntile, reg_start.as<uint64_t>(), reg_cap.as<uint32_t>(),
                            cursor.as<unsigned long long>(), totals.as<unsigned long long>());
         RFX_HIP(hipGetLastError());
     }
@@ -3213,7 +3290,7 @@ static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv, 
     if (!dst) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
     const OneSweep os{reg_start.as<uint64_t>(), reg_cap.as<uint32_t>(), cursor.as<unsigned long long>(), holes.as<uint64_t>(), d_overflow,
                       (uint64_t)h_tot[0], hist.as<unsigned long long>() + nb + 1, ose, (uint32_t)ose_shift};
-    const size_t lds = (size_t)nb * (SKB * sizeof(Rec) + 24);
+    const size_t lds = (size_t)nb * ((seg32 ? OsGeo<32, false>::B : SKB) * sizeof(Rec) + 24);
     {
         ScopedTimer t(ctx, pn);
         if constexpr (WIDE) {                  // the central window is 30 or 31 bases: W = 18 or 19
@@ -3226,12 +3303,16 @@ static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv, 
             }
         } else {
             switch (W) {
-#define X(w) case w: RFX_HIP(hipFuncSetAttribute((const void *)k_sk_onesweep<w>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                     hipLaunchKernelGGL((k_sk_onesweep<w>), dim3((unsigned)G), dim3(SKT), lds, ctx->stream, rsrc, lv, os, dst); break;
+#define X(w) case w: if (seg32) { \
+                         RFX_HIP(hipFuncSetAttribute((const void *)k_sk_onesweep<w, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                         hipLaunchKernelGGL((k_sk_onesweep<w, false, 32>), dim3((unsigned)G), dim3(OST), lds, ctx->stream, rsrc, lv, os, dst); \
+                     } else { \
+                         RFX_HIP(hipFuncSetAttribute((const void *)k_sk_onesweep<w>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                         hipLaunchKernelGGL((k_sk_onesweep<w>), dim3((unsigned)G), dim3(SKT), lds, ctx->stream, rsrc, lv, os, dst); \
+                     } break;
                 RFX_SK_W_CASES(X)
+                default: X(19)
 #undef X
-                default: RFX_HIP(hipFuncSetAttribute((const void *)k_sk_onesweep<19>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                         hipLaunchKernelGGL((k_sk_onesweep<19>), dim3((unsigned)G), dim3(SKT), lds, ctx->stream, rsrc, lv, os, dst); break;
             }
         }
         RFX_HIP(hipGetLastError());

@@ -1,5 +1,8 @@
 // rfx_api.hip -- the extern "C" boundary of libreflexiv_hip.so (include/reflexiv_hip.h) and
 // the driver loop that mirrors ReflexivMain.assembly() (P/ReflexivMain.java:168-310).
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include "rfx_internal.h"
 #include <algorithm>
 #include <cstdlib>
@@ -134,9 +137,24 @@ void rfx_default_params(rfx_params *p) {
     p->twin = RFX_TWIN_DS; p->coalesce = 0; p->extras = 1;
 }
 
+// RFX_BACKTRACE=1 (debugging aid): the native frames of a host crash inside the library on stderr -- offsets into the
+// shared objects, for llvm-symbolizer -- before the signal takes its course
+static void rfx_crash_backtrace(int sig) {
+    void *fr[64];
+    const int n = backtrace(fr, 64);
+    const char msg[] = "\n[reflexiv] fatal signal, native frames:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(fr, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 int rfx_ctx_create(int device, rfx_ctx **out) {
     if (!out) return RFX_E_ARG;
     *out = nullptr;
+    if (const char *e = getenv("RFX_BACKTRACE")) {
+        if (atoi(e)) { signal(SIGSEGV, rfx_crash_backtrace); signal(SIGABRT, rfx_crash_backtrace); signal(SIGBUS, rfx_crash_backtrace); }
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RFX_E_NOGPU;
     if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return RFX_E_NOGPU; }

@@ -71,6 +71,8 @@ NcclApi &nccl() {
 
 }  // namespace
 
+constexpr int TABW = 512;                         // counts a rank contributes to the count matrix: (generation, owner) bins x pieces
+
 struct rfx_comm {
     rfx_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;
@@ -81,7 +83,7 @@ struct rfx_comm {
     // grow-only device buffers: what this rank sends, what it receives (all generations back to back), small tables
     void *send = nullptr, *recv = nullptr;
     size_t send_bytes = 0, recv_bytes = 0;
-    int64_t *d_tab = nullptr;                     // [2 * 64 * world] counts, then 8 scalars
+    int64_t *d_tab = nullptr;                     // [TABW] this rank's counts, [TABW * world] everybody's, then 16 scalars
     int64_t *h_tab = nullptr;                     // pinned mirror
     size_t tab_n = 0;
     double units_per_read = 0;                    // capacity planning across calls (only ever grows)
@@ -102,6 +104,17 @@ struct rfx_comm {
             return RFX_E_HIP;                                                                              \
         }                                                                                                  \
     } while (0)
+
+// tuning / test knobs, read at every collective call (so that one communicator serves every case of a test run: RCCL does
+// not take kindly to many communicators made and destroyed in one process)
+static void comm_options(rfx_comm *c) {
+    const char *e = getenv("RFX_COMM_LIMIT_BYTES");
+    c->limit_bytes = e ? std::max<size_t>(1024, (size_t)atoll(e)) : (size_t)1 << 29;
+    e = getenv("RFX_COMM_SELF_VIA_RCCL");
+    c->self_via_rccl = e && atoi(e) != 0;
+    e = getenv("RFX_COMM_VIRTUAL_WORLD");
+    c->virtual_world = e ? std::max(1, std::min(64, atoi(e))) : 1;
+}
 
 static int grow(rfx_ctx *ctx, void **p, size_t *have, size_t want, hipStream_t s1, hipStream_t s2) {
     if (*p && *have >= want) return RFX_OK;
@@ -132,9 +145,7 @@ int rfx_comm_init(rfx_ctx *ctx, const uint8_t *id128, int rank, int world, rfx_c
     RFX_HIP(hipSetDevice(ctx->device));
     rfx_comm *c = new rfx_comm();
     c->ctx = ctx; c->rank = rank; c->world = world;
-    if (const char *e = getenv("RFX_COMM_LIMIT_BYTES")) c->limit_bytes = std::max<size_t>(1024, (size_t)atoll(e));
-    c->self_via_rccl = getenv("RFX_COMM_SELF_VIA_RCCL") && atoi(getenv("RFX_COMM_SELF_VIA_RCCL")) != 0;
-    if (const char *e = getenv("RFX_COMM_VIRTUAL_WORLD")) c->virtual_world = std::max(1, std::min(64, atoi(e)));
+    comm_options(c);
     ncclUniqueId id;
     memcpy(&id, id128, 128);
     ncclResult_t r = n.CommInitRank(&c->comm, world, id, rank);
@@ -145,7 +156,7 @@ int rfx_comm_init(rfx_ctx *ctx, const uint8_t *id128, int rank, int world, rfx_c
     }
     hipError_t e = hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
-    c->tab_n = (size_t)2 * 64 * world + 16;
+    c->tab_n = (size_t)TABW * (world + 1) + 16;
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_tab, c->tab_n * 8);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_tab, c->tab_n * 8, hipHostMallocDefault);
     if (e != hipSuccess) { ctx->last_error = std::string("rfx_comm_init: ") + hipGetErrorString(e); rfx_comm_destroy(c); return RFX_E_HIP; }
@@ -189,26 +200,34 @@ int rfx_comm_all_reduce_i64(rfx_comm *c, int64_t *h_vals, int n, int op) {
 
 // One all-to-all(v) of 8-byte words, queued on the exchange stream: this rank sends send_cnt[p] words from
 // d_send + send_off[p] to peer p and receives recv_cnt[p] words from peer p at d_recv + recv_off[p].
+// What goes to (comes from) a peer may be S PIECES (the sweep's bins of an owner bucket, rfx::bucket_records_by_owner_sweep):
+// piece q of peer p is entry p * S + q of the four arrays, and a pair of ranks meets its pieces in the same order on both sides.
 static int alltoallv_words(rfx_comm *c, const uint64_t *d_send, const int64_t *send_off, const int64_t *send_cnt,
-                           uint64_t *d_recv, const int64_t *recv_off, const int64_t *recv_cnt, int64_t rounds) {
+                           uint64_t *d_recv, const int64_t *recv_off, const int64_t *recv_cnt, int64_t rounds, int S = 1) {
     rfx_ctx *ctx = c->ctx;
     NcclApi &n = nccl();
     const int64_t limit = (int64_t)(c->limit_bytes / 8);
     const int me = c->rank;
-    if (!c->self_via_rccl && send_cnt[me] > 0)
-        RFX_HIP(hipMemcpyAsync(d_recv + recv_off[me], d_send + send_off[me], (size_t)send_cnt[me] * 8, hipMemcpyDeviceToDevice, c->xs));
+    if (!c->self_via_rccl)
+        for (int q = 0; q < S; q++)
+            if (send_cnt[me * S + q] > 0)
+                RFX_HIP(hipMemcpyAsync(d_recv + recv_off[me * S + q], d_send + send_off[me * S + q], (size_t)send_cnt[me * S + q] * 8,
+                                       hipMemcpyDeviceToDevice, c->xs));
     for (int64_t j = 0; j < rounds; j++) {
         bool any = false;
-        for (int p = 0; p < c->world && !any; p++)
-            if ((p != me || c->self_via_rccl) && (send_cnt[p] > j * limit || recv_cnt[p] > j * limit)) any = true;
+        for (int i = 0; i < c->world * S && !any; i++)
+            if ((i / S != me || c->self_via_rccl) && (send_cnt[i] > j * limit || recv_cnt[i] > j * limit)) any = true;
         if (!any) continue;               // (every rank skips the same rounds only when nobody has data left in them: `rounds` is global)
         RFX_NCCL(n.GroupStart());
         for (int p = 0; p < c->world; p++) {
             if (p == me && !c->self_via_rccl) continue;
-            const int64_t s = std::max<int64_t>(0, std::min(limit, send_cnt[p] - j * limit));
-            const int64_t r = std::max<int64_t>(0, std::min(limit, recv_cnt[p] - j * limit));
-            if (s > 0) RFX_NCCL(n.Send(d_send + send_off[p] + j * limit, (size_t)s, ncclUint64, p, c->comm, c->xs));
-            if (r > 0) RFX_NCCL(n.Recv(d_recv + recv_off[p] + j * limit, (size_t)r, ncclUint64, p, c->comm, c->xs));
+            for (int q = 0; q < S; q++) {
+                const int i = p * S + q;
+                const int64_t s = std::max<int64_t>(0, std::min(limit, send_cnt[i] - j * limit));
+                const int64_t r = std::max<int64_t>(0, std::min(limit, recv_cnt[i] - j * limit));
+                if (s > 0) RFX_NCCL(n.Send(d_send + send_off[i] + j * limit, (size_t)s, ncclUint64, p, c->comm, c->xs));
+                if (r > 0) RFX_NCCL(n.Recv(d_recv + recv_off[i] + j * limit, (size_t)r, ncclUint64, p, c->comm, c->xs));
+            }
         }
         RFX_NCCL(n.GroupEnd());
     }
@@ -225,6 +244,7 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
                           int64_t *out_totals) {
     if (!ctx || !c || c->ctx != ctx || !d_words || n_reads < 0 || cap < 0 || generations < 1 || words_per_read * 32 < read_len)
         return RFX_E_ARG;
+    comm_options(c);
     const bool wide = k > 32;
     if (wide && d_read_len) { ctx->last_error = "ragged reads: k <= 31 only on the device path"; return RFX_E_ARG; }
     if (wide ? (k > 63) : (k < 21 || k > 31)) {
@@ -260,55 +280,67 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
         inst = rs.n_instances;
     }
     if (c->units_per_read <= 0) c->units_per_read = (double)nk / 5.0 + 1.0;
-    int64_t h_off[65];
+    // the send buffer's layout: bin b = records [pb[b], pe[b]) (the two-pass form packs the bins back to back; level 1's
+    // one sweep leaves the slack of its regions between them)
+    int64_t pb[TABW + 1], pe[TABW];
+    constexpr int S = 1;                                   // pieces per bin (alltoallv_words would take more)
     int64_t nrec = 0;
+    const bool try_sweep = !wide && !(getenv("RFX_COMM_SWEEP") && atoi(getenv("RFX_COMM_SWEEP")) == 0);
     for (int attempt = 0;; attempt++) {
         const int64_t cap_rec = (int64_t)(c->units_per_read * (double)n_reads) + 4096;
         RFX_TRY(grow(ctx, &c->send, &c->send_bytes, (size_t)cap_rec * uw * 8, ctx->stream, c->xs));
         ctx->timing.clear();
         int st;
+        bool swept = false;
         if (wide) {
             st = rfx_dev_bucket_wide_records_by_owner(ctx, d_words, n_reads, words_per_read, read_len, k, front_clip, end_clip, bins,
-                                                      c->send, cap_rec, c->d_tab, h_off, &nrec);
+                                                      c->send, cap_rec, c->d_tab, pb, &nrec);
         } else {
-            st = rfx::bucket_records_by_owner(ctx, &rs, bins, c->send, cap_rec, c->d_tab, h_off, &nrec);
+            st = try_sweep ? rfx::bucket_records_by_owner_sweep(ctx, &rs, bins, c->send, cap_rec, pb, pe, &nrec, &swept) : RFX_OK;
+            if (st == RFX_OK && !swept) st = rfx::bucket_records_by_owner(ctx, &rs, bins, c->send, cap_rec, c->d_tab, pb, &nrec);
             ScopedTimer::collect(ctx);
         }
         add_timing(acc, ctx->timing);
-        if (st == RFX_OK) break;
+        if (st == RFX_OK) { if (!swept) for (int b = 0; b < bins; b++) pe[b] = pb[b + 1]; break; }
         if (st != RFX_E_CAP || attempt >= 2) return st;
         c->units_per_read = 1.03 * (double)nrec / (double)std::max<int64_t>(1, n_reads);      // only ever grows
     }
     c->bytes_bucketed = nrec * uw * 8;
 
-    // 2. every rank's counts to every rank: row r = what rank r holds for each (generation, owner) bin
-    int64_t *h_mine = c->h_tab, *h_all = c->h_tab + 64;
-    if (vworld > 1) {                                     // fold a generation's virtual owners into the one real rank
-        for (int g = 0; g < G; g++) h_off[g + 1] = h_off[(g + 1) * vworld];
-    }
+    // 2. every rank's counts to every rank: row r = what rank r holds in each piece of each (generation, owner) bin.
+    // (one-rank rehearsal: a generation's vworld owner bins -- vworld * S pieces -- all belong to the one real rank)
+    const int SP = S * vworld;                            // pieces per (generation, real rank)
     const int rbins = G * world;                          // bins of the real exchange
-    for (int b = 0; b < rbins; b++) h_mine[b] = h_off[b + 1] - h_off[b];
-    RFX_HIP(hipMemcpyAsync(c->d_tab, h_mine, (size_t)rbins * 8, hipMemcpyHostToDevice, c->xs));
-    RFX_NCCL(n.AllGather(c->d_tab, c->d_tab + 64, (size_t)rbins, ncclInt64, c->comm, c->xs));
-    RFX_HIP(hipMemcpyAsync(h_all, c->d_tab + 64, (size_t)rbins * world * 8, hipMemcpyDeviceToHost, c->xs));
+    const int np = rbins * SP;                            // pieces a rank holds
+    if (np > TABW) { ctx->last_error = "rfx_dev_sharded_count: more pieces than the count matrix takes"; return RFX_E_STATE; }
+    int64_t *h_mine = c->h_tab, *h_all = c->h_tab + TABW;
+    for (int q = 0; q < np; q++) h_mine[q] = pe[q] - pb[q];
+    RFX_HIP(hipMemcpyAsync(c->d_tab, h_mine, (size_t)np * 8, hipMemcpyHostToDevice, c->xs));
+    RFX_NCCL(n.AllGather(c->d_tab, c->d_tab + TABW, (size_t)np, ncclInt64, c->comm, c->xs));
+    RFX_HIP(hipMemcpyAsync(h_all, c->d_tab + TABW, (size_t)np * world * 8, hipMemcpyDeviceToHost, c->xs));
     RFX_HIP(hipStreamSynchronize(c->xs));
-    // receive layout: generation after generation, inside a generation source after source
-    std::vector<int64_t> gen_off(G + 1, 0), roff((size_t)G * world), rcnt((size_t)G * world), soff((size_t)G * world), scnt((size_t)G * world);
+    // receive layout: generation after generation, inside a generation source after source, piece after piece
+    const size_t ne = (size_t)G * world * SP;
+    std::vector<int64_t> gen_off(G + 1, 0), roff(ne), rcnt(ne), soff(ne), scnt(ne);
     int64_t mx = 0;
     for (int g = 0; g < G; g++) {
         int64_t pos = gen_off[g];
-        for (int s = 0; s < world; s++) {
-            const int64_t u = h_all[(size_t)s * rbins + (size_t)g * world + me];
-            roff[(size_t)g * world + s] = pos * uw; rcnt[(size_t)g * world + s] = u * uw;
-            pos += u;
-            for (int p = 0; p < world; p++) mx = std::max(mx, h_all[(size_t)s * rbins + (size_t)g * world + p] * uw);
-        }
+        for (int s = 0; s < world; s++)
+            for (int q = 0; q < SP; q++) {
+                const size_t e = ((size_t)g * world + s) * SP + q;
+                const int64_t u = h_all[(size_t)s * np + ((size_t)g * world + me) * SP + q];
+                roff[e] = pos * uw; rcnt[e] = u * uw;
+                pos += u;
+            }
         gen_off[g + 1] = pos;
-        for (int p = 0; p < world; p++) {
-            soff[(size_t)g * world + p] = h_off[g * world + p] * uw;
-            scnt[(size_t)g * world + p] = (h_off[g * world + p + 1] - h_off[g * world + p]) * uw;
-        }
+        for (int p = 0; p < world; p++)
+            for (int q = 0; q < SP; q++) {
+                const size_t e = ((size_t)g * world + p) * SP + q;
+                soff[e] = pb[e] * uw;
+                scnt[e] = (pe[e] - pb[e]) * uw;
+            }
     }
+    for (size_t i = 0; i < (size_t)np * world; i++) mx = std::max(mx, h_all[i] * uw);
     const int64_t rounds = std::max<int64_t>(1, (mx + (int64_t)(c->limit_bytes / 8) - 1) / (int64_t)(c->limit_bytes / 8));
     RFX_TRY(grow(ctx, &c->recv, &c->recv_bytes, (size_t)std::max<int64_t>(1, gen_off[G]) * uw * 8, ctx->stream, c->xs));
 
@@ -316,8 +348,8 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
     RFX_HIP(hipEventRecord(c->ev_ready, ctx->stream));
     RFX_HIP(hipStreamWaitEvent(c->xs, c->ev_ready, 0));
     for (int g = 0; g < G; g++) {
-        RFX_TRY(alltoallv_words(c, (const uint64_t *)c->send, &soff[(size_t)g * world], &scnt[(size_t)g * world], (uint64_t *)c->recv,
-                                &roff[(size_t)g * world], &rcnt[(size_t)g * world], rounds));
+        RFX_TRY(alltoallv_words(c, (const uint64_t *)c->send, &soff[(size_t)g * world * SP], &scnt[(size_t)g * world * SP], (uint64_t *)c->recv,
+                                &roff[(size_t)g * world * SP], &rcnt[(size_t)g * world * SP], rounds, SP));
         RFX_HIP(hipEventRecord(c->ev[g], c->xs));
     }
 
@@ -381,16 +413,17 @@ int rfx_dev_gather_shards(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_keys, con
         root >= c->world)
         return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
+    comm_options(c);
     NcclApi &nc = nccl();
     const int world = c->world, me = c->rank;
     c->h_tab[0] = n;
     RFX_TRY(sync_checked(ctx));
     RFX_HIP(hipMemcpyAsync(c->d_tab, c->h_tab, 8, hipMemcpyHostToDevice, c->xs));
-    RFX_NCCL(nc.AllGather(c->d_tab, c->d_tab + 64, 1, ncclInt64, c->comm, c->xs));
-    RFX_HIP(hipMemcpyAsync(c->h_tab + 64, c->d_tab + 64, (size_t)world * 8, hipMemcpyDeviceToHost, c->xs));
+    RFX_NCCL(nc.AllGather(c->d_tab, c->d_tab + TABW, 1, ncclInt64, c->comm, c->xs));
+    RFX_HIP(hipMemcpyAsync(c->h_tab + TABW, c->d_tab + TABW, (size_t)world * 8, hipMemcpyDeviceToHost, c->xs));
     RFX_HIP(hipStreamSynchronize(c->xs));
     std::vector<int64_t> off(world + 1, 0);
-    for (int r = 0; r < world; r++) off[r + 1] = off[r] + c->h_tab[64 + r];
+    for (int r = 0; r < world; r++) off[r + 1] = off[r] + c->h_tab[TABW + r];
     if (out_n) *out_n = me == root ? off[world] : 0;
     int st = RFX_OK;
     if (me == root && off[world] > cap) st = RFX_E_CAP;
@@ -401,7 +434,7 @@ int rfx_dev_gather_shards(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_keys, con
     const int64_t limit_k = std::max<int64_t>(1, (int64_t)(c->limit_bytes / 8) / key_words) , limit_c = (int64_t)(c->limit_bytes / count_bytes);
     const int64_t lim = std::min(limit_k, limit_c);
     int64_t mx = 0;
-    for (int r = 0; r < world; r++) mx = std::max(mx, c->h_tab[64 + r]);
+    for (int r = 0; r < world; r++) mx = std::max(mx, c->h_tab[TABW + r]);
     const int64_t rounds = std::max<int64_t>(1, (mx + lim - 1) / lim);
     if (me == root && n > 0) {
         RFX_HIP(hipMemcpyAsync(d_out_keys + off[me] * key_words, d_keys, (size_t)n * key_words * 8, hipMemcpyDeviceToDevice, c->xs));
@@ -418,7 +451,7 @@ int rfx_dev_gather_shards(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_keys, con
         } else {
             for (int r = 0; r < world; r++) {
                 if (r == root) continue;
-                const int64_t s = std::max<int64_t>(0, std::min(lim, c->h_tab[64 + r] - j * lim));
+                const int64_t s = std::max<int64_t>(0, std::min(lim, c->h_tab[TABW + r] - j * lim));
                 if (s > 0) {
                     RFX_NCCL(nc.Recv(d_out_keys + (off[r] + j * lim) * key_words, (size_t)s * key_words, ncclUint64, r, c->comm, c->xs));
                     RFX_NCCL(nc.Recv((char *)d_out_counts + (off[r] + j * lim) * count_bytes, (size_t)s * count_bytes, ncclUint8, r, c->comm, c->xs));

@@ -239,6 +239,8 @@ int merge_pairs(rfx_ctx *ctx, const void *d_pairs, int64_t n, int k, int min_cov
                 uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct);
 int bucket_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, uint64_t *d_out,
                     int64_t cap, int64_t *d_owner_off, int64_t *h_owner_off);
+int bucket_records_by_owner_sweep(rfx_ctx *ctx, const ReadStore *reads, int n_owners, void *d_out, int64_t cap_records,
+                                  int64_t *h_begin, int64_t *h_end, int64_t *out_n_records, bool *done);
 int bucket_records_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, void *d_out, int64_t cap_records,
                             int64_t *d_owner_off, int64_t *h_owner_off, int64_t *out_n_records);
 int count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_t n_instances_hint, int k,

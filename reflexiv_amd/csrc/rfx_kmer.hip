@@ -108,6 +108,8 @@ struct Level {
     int shift;                // digit = (h >> shift) & (2^bits - 1); child id = h >> shift
     int parent_shift;         // parent id = h >> parent_shift (64 -> id 0)
     int n_owners;             // > 0: the "digit" is the owning rank, mulhi(kmer_hash, n_owners)
+    int sub_bits;             // level 1 in one sweep by owner: digit = owner << sub_bits | the header's top sub_bits bits
+                              // (bins = 2^bits, bits = ceil(log2(n_owners)) + sub_bits; see bucket_records_by_owner_sweep)
 };
 
 __device__ __forceinline__ unsigned digit_of(uint64_t key, const Level &lv) {
@@ -2034,7 +2036,10 @@ __device__ __forceinline__ uint64_t mmer_hash64(uint32_t canon) { return kmer_ha
 
 __device__ __forceinline__ unsigned sk_digit(uint32_t canon, const Level &lv) {
     const uint64_t h = mmer_hash64(canon);
-    if (lv.n_owners > 0) return (unsigned)__umul64hi(h, (uint64_t)lv.n_owners);
+    if (lv.n_owners > 0) {
+        const unsigned o = (unsigned)__umul64hi(h, (uint64_t)lv.n_owners);
+        return lv.sub_bits ? (o << lv.sub_bits) | ((uint32_t)((h << OWNER_BITS) >> 32) >> (32 - lv.sub_bits)) : o;
+    }
     return rec_digit((uint32_t)((h << OWNER_BITS) >> 32), 0, lv.bits);
 }
 
@@ -2429,7 +2434,10 @@ __global__ __launch_bounds__((OsGeo<SEG, WIDE>::T), (WIDE || SEG > 16) ? 4 : 8) 
             seg_runs<W, SK_SCATTER_RUNLOOP, SEG>(s, read_nk(s, q.r), q.sgm, w, [&](int i0, int n, uint32_t canon) {
                 const uint64_t hh = mmer_hash64(canon);
                 const uint32_t hdr = (uint32_t)((hh << OWNER_BITS) >> 32);
-                const unsigned d = rec_digit(hdr, 0, lv.bits);
+                // (by owner: the owner's bucket is 2^sub_bits bins here, so that a round still brings a bin a handful of
+                // records -- the receiver does not care which of them a record came through)
+                const unsigned d = lv.n_owners > 0 ? (((unsigned)__umul64hi(hh, (uint64_t)lv.n_owners) << lv.sub_bits) | (hdr >> (32 - lv.sub_bits)))
+                                                   : rec_digit(hdr, 0, lv.bits);
                 RT r;
                 if constexpr (WIDE) {
                     // 96 bases from the first base of the run's first k-mer (see k_sk_scatter)
@@ -3226,7 +3234,7 @@ static int records_from_reads(rfx_ctx *ctx, const ReadSrc &rsrc, const Level &lv
 template <bool WIDE = false>
 static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc_in, const Level &lv, int ws_slot, uint64_t *d_seg_begin,
                             uint64_t *d_seg_end, std::conditional_t<WIDE, WRec, Rec> **out_recs, int64_t *n_recs, bool *done,
-                            const char *hn, const char *pn) {
+                            const char *hn, const char *pn, std::conditional_t<WIDE, WRec, Rec> *d_dst = nullptr, int64_t cap_dst = 0) {
     using Rec = std::conditional_t<WIDE, WRec, ::Rec>;
     *done = false;
     const int nb = 1 << lv.bits;
@@ -3286,8 +3294,13 @@ static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc_in, const Level &l
     }
     int ose_shift = 0;
     while ((1u << ose_shift) < ose) ose_shift++;
-    Rec *dst = (Rec *)ctx->ws_get(ws_slot, (size_t)h_tot[0] * sizeof(Rec));
-    if (!dst) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
+    Rec *dst = d_dst;
+    if (d_dst) {                          // the caller's buffer (the regions with their slack must fit): *n_recs = the need
+        if ((int64_t)h_tot[0] > cap_dst) { *n_recs = (int64_t)h_tot[0]; return RFX_E_CAP; }
+    } else {
+        dst = (Rec *)ctx->ws_get(ws_slot, (size_t)h_tot[0] * sizeof(Rec));
+        if (!dst) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
+    }
     const OneSweep os{reg_start.as<uint64_t>(), reg_cap.as<uint32_t>(), cursor.as<unsigned long long>(), holes.as<uint64_t>(), d_overflow,
                       (uint64_t)h_tot[0], hist.as<unsigned long long>() + nb + 1, ose, (uint32_t)ose_shift};
     const size_t lds = (size_t)nb * ((seg32 ? OsGeo<32, false>::B : SKB) * sizeof(Rec) + 24);
@@ -3513,7 +3526,7 @@ int count_filter(rfx_ctx *ctx, const ReadStore *reads, const uint64_t *d_kmers, 
     bool cur_from_reads = from_reads;
     int used_bits = 0;
     for (size_t l = 0; l < bits.size(); l++) {
-        Level lv;
+        Level lv{};
         lv.bits = bits[l];
         lv.n_owners = 0;
         lv.parent_shift = 64 - used_bits;
@@ -3659,6 +3672,98 @@ int bucket_records_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, 
         RFX_HIP(hipMemcpyAsync(h_owner_off, d_owner_off, (size_t)(n_owners + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
         RFX_TRY(sync_checked(ctx));
     }
+    return RFX_OK;
+}
+
+// One owner's bucket lies in S consecutive bins of the sweep, bin i gap-free in [seg_begin, seg_end) with the regions' slack
+// between the bins: the records that lie beyond the bucket's own length are moved into the gaps before it, so that the
+// bucket is ONE run [begin, begin + total) -- one message per peer, as with the two-pass form.  Sources lie at or
+// beyond the cut, destinations before it.  grid (owners, chunks).
+__global__ __launch_bounds__(1024) void k_close_gaps(Rec *__restrict__ recs, const uint64_t *__restrict__ seg_begin,
+                                                     const uint64_t *__restrict__ seg_end, int S, uint64_t *__restrict__ out_begin,
+                                                     uint64_t *__restrict__ out_end, int *__restrict__ fault) {
+    __shared__ uint64_t slo[512], dlo[512], spre[513], dpre[513];       // (S <= 512: one owner and all the sweep's bins)
+    const int o = blockIdx.x;
+    const uint64_t *sb = seg_begin + (size_t)o * S, *se = seg_end + (size_t)o * S;
+    if (threadIdx.x == 0) {
+        uint64_t R = 0;
+        for (int i = 0; i < S; i++) R += se[i] - sb[i];
+        const uint64_t cut = sb[0] + R;
+        spre[0] = dpre[0] = 0;
+        for (int i = 0; i < S; i++) {
+            const uint64_t lo = sb[i] > cut ? sb[i] : cut;
+            slo[i] = lo;
+            spre[i + 1] = spre[i] + (se[i] > lo ? se[i] - lo : 0);
+            uint64_t g0 = se[i], g1 = i + 1 < S ? sb[i + 1] : se[i];
+            if (g1 > cut) g1 = cut;
+            dlo[i] = g0;
+            dpre[i + 1] = dpre[i] + (g1 > g0 ? g1 - g0 : 0);
+        }
+        if (spre[S] != dpre[S]) *fault = 1;                      // (never: both count the bucket's records beyond the cut)
+        if (blockIdx.y == 0) { out_begin[o] = sb[0]; out_end[o] = cut; }
+    }
+    __syncthreads();
+    const uint64_t M = spre[S] < dpre[S] ? spre[S] : dpre[S];
+    for (uint64_t k = (uint64_t)blockIdx.y * blockDim.x + threadIdx.x; k < M; k += (uint64_t)gridDim.y * blockDim.x) {
+        int i = 0, j = 0;                                               // the last range that starts at or before k
+        for (int st = S >> 1; st > 0; st >>= 1) {
+            if (spre[i + st] <= k) i += st;
+            if (dpre[j + st] <= k) j += st;
+        }
+        recs[dlo[j] + (k - dpre[j])] = recs[slo[i] + (k - spre[i])];
+    }
+}
+
+// The same by level 1's ONE SWEEP (round 3).  The sweep wants a bin to receive a handful of records per round (8-slot
+// rings, extents of 64), and an owner bucket of a rank of 8 receives hundreds -- so every owner's bucket is cut into
+// 2^sub_bits bins by the top bits of the record header (512 bins in all; the receiver does not care which bin a record
+// came through), and k_close_gaps then makes every owner's bins one run: owner b = records [h_begin[b], h_end[b]) of
+// d_out, with slack between the owners.  *done = false: not tried or void (small input, skew, a region that
+// overflowed): the caller takes bucket_records_by_owner.  RFX_E_CAP: *out_n_records = the records d_out must hold
+// (regions + slack).
+int bucket_records_by_owner_sweep(rfx_ctx *ctx, const ReadStore *reads, int n_owners, void *d_out, int64_t cap_records,
+                                  int64_t *h_begin, int64_t *h_end, int64_t *out_n_records, bool *done) {
+    *done = false;
+    if (n_owners < 1 || n_owners > 64 || !superkmer_enabled(reads->k)) return RFX_E_ARG;
+    const int os_mode = getenv("RFX_SK_ONESWEEP") ? atoi(getenv("RFX_SK_ONESWEEP")) : 1;
+    ReadSrc rsrc = make_read_src(reads);
+    if (!os_mode || rsrc.nk <= 0 || reads->n_reads <= 0 || !(os_mode == 2 || rsrc.n_threads >= ((int64_t)1 << 22))) return RFX_OK;
+    StageArena stage_arena(ctx, (size_t)256 << 20);       // temporaries of this call (see StageArena)
+    int obits = 0;
+    while ((1 << obits) < n_owners) obits++;
+    Level lv{};
+    lv.n_owners = n_owners;
+    lv.sub_bits = 9 - obits;                              // >= 3
+    lv.bits = 9;
+    const int nb = 1 << lv.bits, S = 1 << lv.sub_bits;
+    DevBuf segB, segE, ob, oe, flt;
+    RFX_HIP(segB.alloc((size_t)(nb + 1) * 8, ctx->stream));
+    RFX_HIP(segE.alloc((size_t)nb * 8, ctx->stream));
+    RFX_HIP(ob.alloc((size_t)n_owners * 8, ctx->stream));
+    RFX_HIP(oe.alloc((size_t)n_owners * 8, ctx->stream));
+    RFX_HIP(flt.alloc(4, ctx->stream));
+    RFX_HIP(hipMemsetAsync(flt.p, 0, 4, ctx->stream));
+    Rec *recs = nullptr;
+    int64_t R = 0;
+    bool swept = false;
+    int st = records_onesweep(ctx, rsrc, lv, 0, segB.as<uint64_t>(), segE.as<uint64_t>(), &recs, &R, &swept, "hist1", "part1",
+                              (Rec *)d_out, cap_records);
+    if (out_n_records) *out_n_records = R;
+    if (st != RFX_OK || !swept) return st;
+    {
+        ScopedTimer t(ctx, "part1");
+        hipLaunchKernelGGL(k_close_gaps, dim3((unsigned)n_owners, 16), dim3(1024), 0, ctx->stream, recs, (const uint64_t *)segB.as<uint64_t>(),
+                           (const uint64_t *)segE.as<uint64_t>(), S, ob.as<uint64_t>(), oe.as<uint64_t>(), flt.as<int>());
+        RFX_HIP(hipGetLastError());
+    }
+    int h_fault = 0;
+    static_assert(sizeof(int64_t) == sizeof(uint64_t), "offsets");
+    RFX_HIP(hipMemcpyAsync(h_begin, ob.p, (size_t)n_owners * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(h_end, oe.p, (size_t)n_owners * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(&h_fault, flt.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_TRY(sync_checked(ctx));
+    if (h_fault) { ctx->last_error = "owner sweep: gaps and tail records do not balance"; return RFX_E_STATE; }
+    *done = true;
     return RFX_OK;
 }
 

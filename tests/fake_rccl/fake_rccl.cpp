@@ -111,7 +111,9 @@ ncclResult_t run(std::vector<Op> &ops) {
         if (!get_file(path(o.c, "p", o.c->got[o.peer]++, o.peer, o.c->rank), h.data(), o.bytes)) return ncclSystemError;
         if (hipMemcpy(o.p, h.data(), o.bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
     }
-    return ncclSuccess;
+    // (a copy from pageable memory may return once the bytes are staged: kernels on a non-blocking stream must not start
+    // before they have landed)
+    return hipDeviceSynchronize() == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
 }
 
 ncclResult_t post(Op o) {
@@ -192,7 +194,8 @@ ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataT
     if (hipMemcpy(mine.data(), send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
     ncclResult_t r = exchange_all(c, mine.data(), all.data(), bytes);
     if (r != ncclSuccess) return r;
-    return hipMemcpy(recv, all.data(), all.size(), hipMemcpyHostToDevice) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+    if (hipMemcpy(recv, all.data(), all.size(), hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+    return hipDeviceSynchronize() == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
 }
 
 ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t comm,
@@ -212,7 +215,8 @@ ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataT
         }
         out[i] = v;
     }
-    return hipMemcpy(recv, out.data(), count * 8, hipMemcpyHostToDevice) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+    if (hipMemcpy(recv, out.data(), count * 8, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+    return hipDeviceSynchronize() == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
 }
 
 const char *ncclGetErrorString(ncclResult_t r) {

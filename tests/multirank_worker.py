@@ -52,7 +52,17 @@ def main():
     assert rfx.comm_all_reduce([rank, 7 - rank], "max") == [world - 1, 7]
 
     cover = 3
+    want = None
+    if rank == 0:
+        from oracle import oracle as OR
+        og = OR.synth_genome(seed, G)
+        ob, oo = OR.synth_reads(seed, og, G, 0, world * n_reads, L)
+        okm = OR.extract_canon(ob, oo, 31)
+        wk31, wc31, wd31 = OR.count_filter(okm, cover)
+        want31 = [len(okm), wd31, len(wk31)]
+        del ob, oo, okm
     for k, gens in ((31, 1), (31, 4), (25, 3), (63, 2), (47, 4)):
+        want = want31 if (rank == 0 and k == 31) else None
         wide = k > 32
         W = 2 if wide else 1
         nk = (rfx.kmers_per_read_w if wide else rfx.kmers_per_read)(L, k)
@@ -94,7 +104,10 @@ def main():
                 rfx.sort_pairs_dev(gk.data_ptr(), gc.data_ptr(), got, 2 * k, tk.data_ptr(), tv.data_ptr())
                 rfx.sync()
                 rk, rc = gk[:got], gc[:got]
-            assert tot == [inst, nd, m], (k, gens, tot, [inst, nd, m])
+            if want is not None and not wide:
+                # the truth first, so that a mismatch names the side that is wrong
+                assert [inst, nd, m] == want, ("fused count vs oracle", k, gens, [inst, nd, m], want)
+            assert tot == [inst, nd, m], ("sharded totals vs fused", k, gens, tot, [inst, nd, m])
             assert torch.equal(rk, fk[:m * W]) and torch.equal(rc, fc[:m]), (k, gens)
             # every k-mer lives on exactly one rank: the gathered list has no repeats (it equals the fused list) -- done above
 

@@ -16,20 +16,44 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PIN = os.path.join(HERE, "golden", "c3_share.json")
 
 
-def make_comm(env):
-    import reflexiv_amd
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        r = reflexiv_amd.Reflexiv()
-        r.comm_init(reflexiv_amd.Reflexiv.comm_unique_id(), 0, 1)
-    finally:
-        for k, v in old.items():
+class _Shared:
+    """ONE context + one-rank communicator for the whole module (the RFX_COMM_* / RFX_SK_* knobs are read per call): RCCL
+    does not take kindly to many communicators made and destroyed in one process."""
+    rfx = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _close_shared():
+    yield
+    if _Shared.rfx is not None:
+        _Shared.rfx.close()
+        _Shared.rfx = None
+
+
+class _Knobs:
+    def __init__(self, rfx, env):
+        self.rfx, self.env, self.old = rfx, env, {}
+
+    def __getattr__(self, name):
+        return getattr(self.rfx, name)
+
+    def close(self):                                            # (the tests' `finally: rfx.close()`: put the knobs back)
+        for k, v in self.old.items():
             if v is None:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    return r
+
+
+def make_comm(env):
+    import reflexiv_amd
+    if _Shared.rfx is None:
+        _Shared.rfx = reflexiv_amd.Reflexiv()
+        _Shared.rfx.comm_init(reflexiv_amd.Reflexiv.comm_unique_id(), 0, 1)
+    h = _Knobs(_Shared.rfx, env)
+    h.old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    return h
 
 
 def reads_on_device(rfx, seed, G, n_reads, L, err=21474836):
@@ -45,7 +69,11 @@ def reads_on_device(rfx, seed, G, n_reads, L, err=21474836):
 
 
 @pytest.mark.parametrize("env", [{}, {"RFX_COMM_SELF_VIA_RCCL": "1"},
-                                 {"RFX_COMM_SELF_VIA_RCCL": "1", "RFX_COMM_LIMIT_BYTES": "1048576"}])
+                                 {"RFX_COMM_SELF_VIA_RCCL": "1", "RFX_COMM_LIMIT_BYTES": "1048576"},
+                                 # the sender's bucketing by level 1's one sweep (an owner's bucket in pieces), forced at this size
+                                 {"RFX_COMM_SELF_VIA_RCCL": "1", "RFX_SK_ONESWEEP": "2", "RFX_COMM_LIMIT_BYTES": "262144"},
+                                 {"RFX_SK_ONESWEEP": "2", "RFX_COMM_VIRTUAL_WORLD": "8"},
+                                 {"RFX_SK_ONESWEEP": "2", "RFX_COMM_VIRTUAL_WORLD": "3"}])
 def test_sharded_count_behind_the_c_abi_one_rank(env):
     import torch
     rfx = make_comm(env)

@@ -23,11 +23,13 @@ def build_shim():
     return SHIM
 
 
-@pytest.mark.parametrize("world,limit", [(2, None), (3, 65536), (4, None)])
-def test_sharded_count_and_assemble_on_several_ranks(tmp_path, world, limit):
+@pytest.mark.parametrize("world,limit,sweep", [(2, None, False), (3, 65536, False), (4, None, False), (2, None, True), (3, 32768, True)])
+def test_sharded_count_and_assemble_on_several_ranks(tmp_path, world, limit, sweep):
     env = dict(os.environ, RFX_RCCL_LIB=build_shim(), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if limit:
         env["RFX_COMM_LIMIT_BYTES"] = str(limit)                # many rounds per exchange
+    if sweep:
+        env["RFX_SK_ONESWEEP"] = "2"                            # the sender's bucketing by level 1's one sweep: owner buckets in pieces
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "multirank_worker.py"), str(r), str(world), str(tmp_path)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []

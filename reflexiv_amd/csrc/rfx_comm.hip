@@ -285,7 +285,7 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
     int64_t pb[TABW + 1], pe[TABW];
     constexpr int S = 1;                                   // pieces per bin (alltoallv_words would take more)
     int64_t nrec = 0;
-    const bool try_sweep = !wide && !(getenv("RFX_COMM_SWEEP") && atoi(getenv("RFX_COMM_SWEEP")) == 0);
+    const bool try_sweep = !(getenv("RFX_COMM_SWEEP") && atoi(getenv("RFX_COMM_SWEEP")) == 0);
     for (int attempt = 0;; attempt++) {
         const int64_t cap_rec = (int64_t)(c->units_per_read * (double)n_reads) + 4096;
         RFX_TRY(grow(ctx, &c->send, &c->send_bytes, (size_t)cap_rec * uw * 8, ctx->stream, c->xs));
@@ -293,8 +293,14 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
         int st;
         bool swept = false;
         if (wide) {
-            st = rfx_dev_bucket_wide_records_by_owner(ctx, d_words, n_reads, words_per_read, read_len, k, front_clip, end_clip, bins,
-                                                      c->send, cap_rec, c->d_tab, pb, &nrec);
+            st = try_sweep ? rfx::bucket_wide_records_by_owner_sweep(ctx, d_words, n_reads, words_per_read, nk, k, front_clip, bins, c->send,
+                                                                     cap_rec, pb, pe, &nrec, &swept)
+                           : RFX_OK;
+            if (st == RFX_OK && !swept)
+                st = rfx_dev_bucket_wide_records_by_owner(ctx, d_words, n_reads, words_per_read, read_len, k, front_clip, end_clip, bins,
+                                                          c->send, cap_rec, c->d_tab, pb, &nrec);
+            else
+                ScopedTimer::collect(ctx);
         } else {
             st = try_sweep ? rfx::bucket_records_by_owner_sweep(ctx, &rs, bins, c->send, cap_rec, pb, pe, &nrec, &swept) : RFX_OK;
             if (st == RFX_OK && !swept) st = rfx::bucket_records_by_owner(ctx, &rs, bins, c->send, cap_rec, c->d_tab, pb, &nrec);

@@ -241,6 +241,9 @@ int bucket_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, uint64_t
                     int64_t cap, int64_t *d_owner_off, int64_t *h_owner_off);
 int bucket_records_by_owner_sweep(rfx_ctx *ctx, const ReadStore *reads, int n_owners, void *d_out, int64_t cap_records,
                                   int64_t *h_begin, int64_t *h_end, int64_t *out_n_records, bool *done);
+int bucket_wide_records_by_owner_sweep(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,
+                                       int n_owners, void *d_out, int64_t cap_records, int64_t *h_begin, int64_t *h_end,
+                                       int64_t *out_n_records, bool *done);
 int bucket_records_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, void *d_out, int64_t cap_records,
                             int64_t *d_owner_off, int64_t *h_owner_off, int64_t *out_n_records);
 int count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_t n_instances_hint, int k,

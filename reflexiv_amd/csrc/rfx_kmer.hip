@@ -1413,9 +1413,21 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
         __syncthreads();
     };
 
+    // (records: the wave's first 64 records of a leaf are loaded while the leaf before it is counted -- 2048 leaves per
+    // workgroup, and after every one of them all sixteen waves stood waiting for memory at the same moment)
+    using ElemT = std::conditional_t<RECS, WRec, Rec>;
+    ElemT pre{};
+    bool first_pass = true;
+    auto wave_first = [&](uint64_t b, uint64_t e) __attribute__((always_inline)) -> ElemT {
+        constexpr int NWV0 = WLT / 64;
+        const uint64_t n0 = e - b, w0 = b + n0 * (threadIdx.x >> 6) / NWV0, w1 = b + n0 * ((threadIdx.x >> 6) + 1) / NWV0;
+        return w0 + lane_ < w1 ? elems[w0 + lane_] : ElemT{};
+    };
+    if constexpr (RECS) pre = wave_first(leaf_off[l0], leaf_off[l0 + 1]);
     for (int64_t leaf = l0; leaf < l1; leaf++) {
         const uint64_t begin = leaf_off[leaf], end = leaf_off[leaf + 1];
         uint32_t S = 1, s = 0;
+        first_pass = true;
         if constexpr (RECS) {
             // a leaf with many records will not fit one table: start it in 2, 4, ... hash-selected parts
             // instead of finding that out from an abandoned pass (presplit = records one table takes)
@@ -1632,7 +1644,14 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                     }
                     return false;
                 };
-                WRec nxt = ws + lane_ < we ? elems[ws + lane_] : WRec{0, 0, 0, 0};
+                WRec nxt;
+                if (first_pass) {
+                    nxt = pre;
+                    if (leaf + 1 < l1) pre = wave_first(end, leaf_off[leaf + 2]);      // travels while this leaf is counted
+                } else {
+                    nxt = ws + lane_ < we ? elems[ws + lane_] : WRec{0, 0, 0, 0};          // (a later part of a split leaf)
+                }
+                first_pass = false;
                 for (uint64_t r0 = ws; r0 < we; r0 += 64) {
                     if (__hip_atomic_load(&overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
                     const bool valid = r0 + lane_ < we;
@@ -1765,6 +1784,9 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
             S = stackS[sp - 1]; s = stacks[sp - 1];
             __syncthreads();
             if (threadIdx.x == 0) sp--;
+        }
+        if constexpr (RECS) {
+            if (first_pass && leaf + 1 < l1) pre = wave_first(end, leaf_off[leaf + 2]);     // (an empty leaf hands the chain on)
         }
     }
     flush();
@@ -3679,7 +3701,8 @@ int bucket_records_by_owner(rfx_ctx *ctx, const ReadStore *reads, int n_owners, 
 // between the bins: the records that lie beyond the bucket's own length are moved into the gaps before it, so that the
 // bucket is ONE run [begin, begin + total) -- one message per peer, as with the two-pass form.  Sources lie at or
 // beyond the cut, destinations before it.  grid (owners, chunks).
-__global__ __launch_bounds__(1024) void k_close_gaps(Rec *__restrict__ recs, const uint64_t *__restrict__ seg_begin,
+template <class RT>
+__global__ __launch_bounds__(1024) void k_close_gaps(RT *__restrict__ recs, const uint64_t *__restrict__ seg_begin,
                                                      const uint64_t *__restrict__ seg_end, int S, uint64_t *__restrict__ out_begin,
                                                      uint64_t *__restrict__ out_end, int *__restrict__ fault) {
     __shared__ uint64_t slo[512], dlo[512], spre[513], dpre[513];       // (S <= 512: one owner and all the sweep's bins)
@@ -3721,13 +3744,13 @@ __global__ __launch_bounds__(1024) void k_close_gaps(Rec *__restrict__ recs, con
 // d_out, with slack between the owners.  *done = false: not tried or void (small input, skew, a region that
 // overflowed): the caller takes bucket_records_by_owner.  RFX_E_CAP: *out_n_records = the records d_out must hold
 // (regions + slack).
-int bucket_records_by_owner_sweep(rfx_ctx *ctx, const ReadStore *reads, int n_owners, void *d_out, int64_t cap_records,
-                                  int64_t *h_begin, int64_t *h_end, int64_t *out_n_records, bool *done) {
+template <bool WIDE>
+static int owner_sweep(rfx_ctx *ctx, const ReadSrc &rsrc, int n_owners, void *d_out, int64_t cap_records, int64_t *h_begin,
+                       int64_t *h_end, int64_t *out_n_records, bool *done) {
+    using RT = std::conditional_t<WIDE, WRec, Rec>;
     *done = false;
-    if (n_owners < 1 || n_owners > 64 || !superkmer_enabled(reads->k)) return RFX_E_ARG;
     const int os_mode = getenv("RFX_SK_ONESWEEP") ? atoi(getenv("RFX_SK_ONESWEEP")) : 1;
-    ReadSrc rsrc = make_read_src(reads);
-    if (!os_mode || rsrc.nk <= 0 || reads->n_reads <= 0 || !(os_mode == 2 || rsrc.n_threads >= ((int64_t)1 << 22))) return RFX_OK;
+    if (!os_mode || rsrc.nk <= 0 || rsrc.n_reads <= 0 || !(os_mode == 2 || rsrc.n_threads >= ((int64_t)1 << 22))) return RFX_OK;
     StageArena stage_arena(ctx, (size_t)256 << 20);       // temporaries of this call (see StageArena)
     int obits = 0;
     while ((1 << obits) < n_owners) obits++;
@@ -3743,16 +3766,16 @@ int bucket_records_by_owner_sweep(rfx_ctx *ctx, const ReadStore *reads, int n_ow
     RFX_HIP(oe.alloc((size_t)n_owners * 8, ctx->stream));
     RFX_HIP(flt.alloc(4, ctx->stream));
     RFX_HIP(hipMemsetAsync(flt.p, 0, 4, ctx->stream));
-    Rec *recs = nullptr;
+    RT *recs = nullptr;
     int64_t R = 0;
     bool swept = false;
-    int st = records_onesweep(ctx, rsrc, lv, 0, segB.as<uint64_t>(), segE.as<uint64_t>(), &recs, &R, &swept, "hist1", "part1",
-                              (Rec *)d_out, cap_records);
+    int st = records_onesweep<WIDE>(ctx, rsrc, lv, 0, segB.as<uint64_t>(), segE.as<uint64_t>(), &recs, &R, &swept, "hist1", "part1",
+                                    (RT *)d_out, cap_records);
     if (out_n_records) *out_n_records = R;
     if (st != RFX_OK || !swept) return st;
     {
         ScopedTimer t(ctx, "part1");
-        hipLaunchKernelGGL(k_close_gaps, dim3((unsigned)n_owners, 16), dim3(1024), 0, ctx->stream, recs, (const uint64_t *)segB.as<uint64_t>(),
+        hipLaunchKernelGGL(k_close_gaps<RT>, dim3((unsigned)n_owners, 16), dim3(1024), 0, ctx->stream, recs, (const uint64_t *)segB.as<uint64_t>(),
                            (const uint64_t *)segE.as<uint64_t>(), S, ob.as<uint64_t>(), oe.as<uint64_t>(), flt.as<int>());
         RFX_HIP(hipGetLastError());
     }
@@ -3765,6 +3788,13 @@ int bucket_records_by_owner_sweep(rfx_ctx *ctx, const ReadStore *reads, int n_ow
     if (h_fault) { ctx->last_error = "owner sweep: gaps and tail records do not balance"; return RFX_E_STATE; }
     *done = true;
     return RFX_OK;
+}
+
+int bucket_records_by_owner_sweep(rfx_ctx *ctx, const ReadStore *reads, int n_owners, void *d_out, int64_t cap_records,
+                                  int64_t *h_begin, int64_t *h_end, int64_t *out_n_records, bool *done) {
+    *done = false;
+    if (n_owners < 1 || n_owners > 64 || !superkmer_enabled(reads->k)) return RFX_E_ARG;
+    return owner_sweep<false>(ctx, make_read_src(reads), n_owners, d_out, cap_records, h_begin, h_end, out_n_records, done);
 }
 
 // count + filter of records that arrived from the exchange (any order): all radix levels run
@@ -4093,6 +4123,18 @@ int bucket_wide_records_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t 
     }
     return RFX_OK;
 }
+
+// the same for the 32-byte records of k = 33..63 (bucket_wide_records_by_owner)
+int bucket_wide_records_by_owner_sweep(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int wpr, int64_t nk, int k, int fc,
+                                       int n_owners, void *d_out, int64_t cap_records, int64_t *h_begin, int64_t *h_end,
+                                       int64_t *out_n_records, bool *done) {
+    *done = false;
+    if (n_owners < 1 || n_owners > 64 || k < 33 || k > 63) return RFX_E_ARG;
+    if (nk <= 0 || n_reads <= 0) return RFX_OK;
+    return owner_sweep<true>(ctx, wide_read_src(d_words, n_reads, wpr, nk, k, fc), n_owners, d_out, cap_records, h_begin, h_end,
+                             out_n_records, done);
+}
+
 
 int count_wide_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_t n_instances_hint, int k, int min_cov,
                        int max_cov, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n,

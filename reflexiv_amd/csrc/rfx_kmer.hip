@@ -1344,8 +1344,18 @@ __device__ __forceinline__ void wrec_kmer(const WRec &r, uint32_t j, int t, uint
     *k1 = fwd ? f1 : r1;
 }
 
+// RFX_WIDE_LOCKFREE (round 3): the two key words of a slot are claimed by two 64-bit compare-and-swaps, one after the
+// other -- word 0 first; a key that meets its own word 0 (or an empty one) goes on to word 1, one that meets another
+// value in either moves to its next slot -- so whatever order the claims land in a slot names ONE key, nothing is ever
+// locked, nobody spins, and a compare-and-swap's return value IS the key word (no 16-byte read to compare).  EMPTY = all
+// ones in both words: word 1 holds k - 32 <= 31 bases, and word 0 of a CANONICAL k-mer is never 32 T's (its reverse
+// complement would begin with at most 31 T's and an A, and be the smaller one).  With no lock there is no loop the wave
+// must leave together and no need for the queue of attempts that replaced it.
+#ifndef RFX_WIDE_LOCKFREE
+#define RFX_WIDE_LOCKFREE 1
+#endif
 #ifndef RFX_WIDE_QUEUE
-#define RFX_WIDE_QUEUE 1
+#define RFX_WIDE_QUEUE (RFX_WIDE_LOCKFREE ? 0 : 1)
 #endif
 constexpr int WQCAP = RFX_WIDE_QUEUE ? 128 : 0;   // probe attempts a wave has pending (record leaves)
 // RFX_WIDE_AGG: the record table of the two-word leaf (see RFX_LEAF_AGG): a slot is (bases 0..31, bases 32..63, the
@@ -1356,7 +1366,7 @@ constexpr int WQCAP = RFX_WIDE_QUEUE ? 128 : 0;   // probe attempts a wave has p
 #endif
 constexpr int WRSLOTS = 768;            // record slots (12 of the 16 waves sweep a block of 64 each)
 constexpr int WRMAX = 8191;             // records of a leaf that goes through the table (a weight takes 13 bits of a queue entry)
-constexpr int WPARK = RFX_WIDE_AGG ? 32 : 64;   // records a wave parks before it expands them
+constexpr int WPARK = RFX_WIDE_AGG && RFX_WIDE_QUEUE ? 32 : 64;   // records a wave parks before it expands them
 constexpr int WWS0 = WPARK * 4 + 32;    // u64 words of a wave's expansion area: the parked records + head bits + prefix counts
 constexpr int WWS = WWS0 + WQCAP * 2 + WQCAP / 2;   // ... + the queue: 16-byte keys, then 4-byte (slot | probes << 16)
 
@@ -1371,10 +1381,12 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
     __shared__ __attribute__((aligned(32))) uint64_t wstage[RECS ? WWS * (WLT / 64) : 4];
     const bool dh = !(presplit & 0x20000000u);
     __shared__ uint32_t ps_eff;              // records one table takes (starts at `presplit`, shrinks on overflow)
-    __shared__ __attribute__((aligned(16))) ulonglong2 tk[WCAP];     // both key words of a slot in one 16-byte LDS access
+    constexpr bool LF = RFX_WIDE_LOCKFREE != 0;
+    __shared__ __attribute__((aligned(16))) ulonglong2 tk[LF ? 1 : WCAP];     // (lock form) both key words of a slot in one 16-byte LDS access
+    __shared__ unsigned long long tk0[LF ? WCAP : 1], tk1[LF ? WCAP : 1];       // (lock-free form) a plane per key word
     __shared__ uint32_t tcnt[WCAP];
     constexpr bool WAGG = RECS && RFX_WIDE_AGG != 0;
-    static_assert(!WAGG || (WQCAP > 0 && WRSLOTS % 64 == 0 && WRSLOTS <= WLT), "record table");
+    static_assert(!WAGG || ((WQCAP > 0 || LF) && WRSLOTS % 64 == 0 && WRSLOTS <= WLT), "record table");
     __shared__ unsigned long long rA[WAGG ? WRSLOTS : 1], rB[WAGG ? WRSLOTS : 1], rCC[WAGG ? WRSLOTS : 1];
     __shared__ uint32_t agg_on, agg_saved, agg_total;       // (as in k_leaf_count)
     __shared__ unsigned long long obh[WOBUF], obl[WOBUF];
@@ -1390,6 +1402,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
     const int64_t l1 = (int64_t)(((unsigned long long)(blockIdx.x + 1) * (unsigned long long)nleaf) / gridDim.x);
     if (l0 >= l1) return;
     for (int i = threadIdx.x; i < WCAP; i += WLT) tcnt[i] = 0;
+    if constexpr (LF) for (int i = threadIdx.x; i < WCAP; i += WLT) { tk0[i] = EMPTY; tk1[i] = EMPTY; }
     if constexpr (WAGG) for (int i = threadIdx.x; i < WRSLOTS; i += WLT) { rA[i] = EMPTY; rB[i] = EMPTY; rCC[i] = EMPTY; }
     if (threadIdx.x == 0) {
         ob_n = 0; ob_lim = 0xffffffffu; overflow = 0; sp = 0;
@@ -1448,7 +1461,39 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
             // only then, so a lane spinning on a lock its neighbour holds would spin for ever.  Here every
             // publish sits inside an iteration every lane completes, and the claim of a first probe is
             // published before anyone waits.
+            // lock-free form: the first probe straight-line (most keys are in the table already), the rest in a loop of the
+            // lane's own
+            auto insertw = [&](const uint64_t w0, const uint64_t w1, bool v, const uint32_t wgt) __attribute__((always_inline)) {
+                if constexpr (LF) {
+                    const uint32_t g = ((uint32_t)w0 ^ __builtin_rotateleft32((uint32_t)(w0 >> 32), 13) ^
+                                        ((uint32_t)w1 * 0x85EBCA6Bu) ^ (uint32_t)(w1 >> 32)) * 0x9E3779B1u;
+                    if (S > 1) v = v && (((g >> 4) & 0xffffu) & (S - 1)) == s;
+                    uint32_t slot = wide_slot(g);
+                    bool done = !v;
+                    if (v) {
+                        const unsigned long long p0 = atomicCAS(&tk0[slot], EMPTY, (unsigned long long)w0);
+                        if (p0 == EMPTY || p0 == w0) {
+                            const unsigned long long p1 = atomicCAS(&tk1[slot], EMPTY, (unsigned long long)w1);
+                            if (p1 == EMPTY || p1 == w1) { atomicAdd(&tcnt[slot], wgt); done = true; }
+                        }
+                    }
+                    if (!done) {
+                        const uint32_t step = dh ? wide_step(g) : 1u;
+#pragma nounroll
+                        for (int probe = 1;; probe++) {
+                            slot = wide_next(slot, step);
+                            const unsigned long long p0 = atomicCAS(&tk0[slot], EMPTY, (unsigned long long)w0);
+                            if (p0 == EMPTY || p0 == w0) {
+                                const unsigned long long p1 = atomicCAS(&tk1[slot], EMPTY, (unsigned long long)w1);
+                                if (p1 == EMPTY || p1 == w1) { atomicAdd(&tcnt[slot], wgt); break; }
+                            }
+                            if (probe >= LPROBE) { overflow = 1; break; }
+                        }
+                    }
+                }
+            };
             auto insert1 = [&](const uint64_t w0, const uint64_t w1, bool v) __attribute__((always_inline)) {
+                if constexpr (LF) { insertw(w0, w1, v, 1u); return; }
                 const uint32_t g = ((uint32_t)w0 ^ __builtin_rotateleft32((uint32_t)(w0 >> 32), 13) ^
                                     ((uint32_t)w1 * 0x85EBCA6Bu) ^ (uint32_t)(w1 >> 32)) * 0x9E3779B1u;
                 if (S > 1) v = v && (((g >> 4) & 0xffffu) & (S - 1)) == s;
@@ -1597,7 +1642,9 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                             if (va && (a0 ^ a1) == 0x123456789ULL) overflow = 1;
                             continue;
                         }
-                        if constexpr (WQCAP > 0) insertq(a0, a1, va, wg); else insert1(a0, a1, va);
+                        if constexpr (LF) insertw(a0, a1, va, wg);
+                        else if constexpr (WQCAP > 0) insertq(a0, a1, va, wg);
+                        else insert1(a0, a1, va);
                     }
                     __builtin_amdgcn_wave_barrier();
                     parked = 0;
@@ -1740,7 +1787,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                         if (lane_ == leader) b0 = atomicAdd(&ob_n, cntw);
                         b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, leader);
                         if (b0 + cntw <= (uint32_t)WOBUF) {
-                            if (keep) { const ulonglong2 t = tk[slot]; obh[b0 + r] = t.x; obl[b0 + r] = t.y; obc[b0 + r] = c; }
+                            if (keep) { const ulonglong2 t = LF ? make_ulonglong2(tk0[slot], tk1[slot]) : tk[slot]; obh[b0 + r] = t.x; obl[b0 + r] = t.y; obc[b0 + r] = c; }
                         } else {
                             uint32_t glo = 0, ghi = 0;
                             if (lane_ == leader) {
@@ -1752,18 +1799,20 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                             ghi = (uint32_t)__builtin_amdgcn_readlane((int)ghi, leader);
                             const unsigned long long pos = (((unsigned long long)ghi << 32) | glo) + r;
                             if (keep && pos < cap) {
-                                const ulonglong2 t = tk[slot]; out_keys[2 * pos] = t.x; out_keys[2 * pos + 1] = t.y; out_counts[pos] = (int64_t)c;
+                                const ulonglong2 t = LF ? make_ulonglong2(tk0[slot], tk1[slot]) : tk[slot];
+                                out_keys[2 * pos] = t.x; out_keys[2 * pos + 1] = t.y; out_counts[pos] = (int64_t)c;
                             }
                         }
                     }
                     tcnt[slot] = 0;
+                    if constexpr (LF) { if (c) { tk0[slot] = EMPTY; tk1[slot] = EMPTY; } }
                 }
                 __syncthreads();
                 const uint32_t raw = ob_n, lim = ob_lim;
                 if (raw >= (uint32_t)WOBUF / 2 || lim != 0xffffffffu) flush();
                 if (S == 1) break;
             } else {
-                for (int i = threadIdx.x; i < WCAP; i += WLT) tcnt[i] = 0;
+                for (int i = threadIdx.x; i < WCAP; i += WLT) { tcnt[i] = 0; if constexpr (LF) { tk0[i] = EMPTY; tk1[i] = EMPTY; } }
                 __syncthreads();
                 if (threadIdx.x == 0) {
                     my_overflows++;

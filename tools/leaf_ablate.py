@@ -61,3 +61,5 @@ if which == "seg":
     run(25, {"RFX_SK_SEG": "16"})
     run(21, {})
     run(21, {"RFX_SK_SEG": "16"})
+if which == "63one":
+    run(63, {}, 1)

@@ -1,5 +1,6 @@
 // rfx_api.hip -- the extern "C" boundary of libreflexiv_hip.so (include/reflexiv_hip.h) and
 // the driver loop that mirrors ReflexivMain.assembly() (P/ReflexivMain.java:168-310).
+#include <thread>
 #include <execinfo.h>
 #include <signal.h>
 #include <unistd.h>
@@ -53,6 +54,87 @@ int64_t contigs_text_host(const rfx_records *r, int k, int min_contig, int twin,
     const int sub = k - 1;
     const int kw = r->key_words > 1 ? r->key_words : 1;
     if (k > 31) twin = RFX_TWIN_RDD;
+    // Large outputs that fit `out` (a bacterial genome is 9 MB of text, 1.1 ms on one core): the layout is known before
+    // a base is written -- header, then base j of the contig at body + j + j / 100 -- so a few threads decode disjoint
+    // ranges of extension words straight to their places.  Anything else (small, or only sized / clipped) below.
+    {
+        struct Job { int64_t i, body, len, L; int f; };
+        std::vector<Job> jobs;
+        int64_t at = 0, id2 = 0, words = 0;
+        std::vector<std::string> hdrs;
+        for (int64_t i = 0; i < r->n; i++) {
+            if (twin == RFX_TWIN_DS && r->left[i] <= -10000000 && r->right[i] <= -10000000) continue;
+            const uint64_t *w = r->ext + r->ext_off[i];
+            const int64_t nw = r->ext_off[i + 1] - r->ext_off[i];
+            const int nlz = w[0] ? __builtin_clzll(w[0]) : 64;
+            const int f = 32 - (nlz / 2 + 1);
+            const int64_t L = (nw - 1) * 31 + f, len = L + sub;
+            if (len < min_contig) continue;
+            char hdr[96];
+            const int hl = twin == RFX_TWIN_DS
+                               ? snprintf(hdr, sizeof hdr, ">Contig-%lld-(%d,%d)-%lld\n", (long long)len, r->left[i], r->right[i], (long long)id2)
+                               : snprintf(hdr, sizeof hdr, ">Contig-%lld-%lld\n", (long long)len, (long long)id2);
+            hdrs.emplace_back(hdr, (size_t)hl);
+            jobs.push_back(Job{i, at + hl, len, L, f});
+            at += hl + len + (len - 1) / 100 + 1;          // bases, the line breaks between them, the final one
+            words += nw;
+            id2++;
+        }
+        if (out && at <= cap && words >= (1 << 16)) {
+            // base j0.. of a contig: n characters from p (a line break before every hundredth base but the first)
+            auto put = [&](const Job &jb, int64_t j0, const char *p, int n) {
+                while (n > 0) {
+                    if (j0 > 0 && j0 % 100 == 0) out[jb.body + j0 + j0 / 100 - 1] = '\n';
+                    const int room = (int)std::min<int64_t>(n, 100 - j0 % 100);
+                    memcpy(out + jb.body + j0 + j0 / 100, p, (size_t)room);
+                    p += room; j0 += room; n -= room;
+                }
+            };
+            const int T = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+            const int64_t per = (words + T - 1) / T;
+            auto work = [&](int t) {
+                int64_t w_lo = (int64_t)t * per, w_hi = std::min(words, w_lo + per), base = 0;
+                for (size_t q = 0; q < jobs.size(); q++) {
+                    const Job &jb = jobs[q];
+                    const uint64_t *w = r->ext + r->ext_off[jb.i];
+                    const int64_t nw = r->ext_off[jb.i + 1] - r->ext_off[jb.i];
+                    const int64_t a = std::max<int64_t>(w_lo - base, 0), b2 = std::min<int64_t>(w_hi - base, nw);
+                    base += nw;
+                    if (a >= b2) continue;
+                    const int64_t eoff = r->marker[jb.i] == 1 ? sub : 0, koff = r->marker[jb.i] == 1 ? 0 : jb.L;
+                    char tmp[32];
+                    for (int64_t x = a; x < b2; x++) {
+                        if (x == 0) {
+                            // the record's thread of word 0 also writes the header, the key and the closing line break
+                            memcpy(out + jb.body - (int64_t)hdrs[q].size(), hdrs[q].data(), hdrs[q].size());
+                            const uint64_t *kp = r->key + (size_t)jb.i * kw;
+                            int64_t o2 = 0;
+                            for (int w2 = 0; w2 < kw; w2++) {
+                                const int nb = w2 < kw - 1 ? 31 : sub - 31 * (kw - 1);
+                                for (int j = 0; j < nb; j++) tmp[j] = NUC[(kp[w2] >> (2 * (nb - 1 - j))) & 3];
+                                put(jb, koff + o2, tmp, nb);
+                                o2 += nb;
+                            }
+                            for (int j = 0; j < jb.f; j++) tmp[j] = NUC[(w[0] >> (2 * (jb.f - 1 - j))) & 3];
+                            put(jb, eoff, tmp, jb.f);
+                            out[jb.body + jb.len + (jb.len - 1) / 100] = '\n';
+                        } else {
+                            const uint64_t v = w[x] << 2;
+                            for (int j = 0; j < 7; j++) memcpy(tmp + 4 * j, QUAD[(v >> (56 - 8 * j)) & 255], 4);
+                            memcpy(tmp + 28, QUAD[v & 255], 3);
+                            put(jb, eoff + jb.f + (x - 1) * 31, tmp, 31);
+                        }
+                    }
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; t++) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+            if (n_contigs) *n_contigs = id2;
+            return at;
+        }
+    }
     int64_t pos = 0, idx = 0;
     std::vector<char> b;
     auto putc_ = [&](char c) { if (pos < cap) out[pos] = c; pos++; };

@@ -1364,9 +1364,15 @@ constexpr int WQCAP = RFX_WIDE_QUEUE ? 128 : 0;   // probe attempts a wave has p
 #ifndef RFX_WIDE_AGG
 #define RFX_WIDE_AGG 1
 #endif
-constexpr int WRSLOTS = 768;            // record slots (12 of the 16 waves sweep a block of 64 each)
+#ifndef RFX_WRSLOTS
+#define RFX_WRSLOTS 1024
+#endif
+constexpr int WRSLOTS = RFX_WRSLOTS;    // record slots: 1024 (every wave sweeps a block of 64; 768: 26.9 ms instead of 26.1 at k = 63), 768 or 512
 constexpr int WRMAX = 8191;             // records of a leaf that goes through the table (a weight takes 13 bits of a queue entry)
-constexpr int WPARK = RFX_WIDE_AGG && RFX_WIDE_QUEUE ? 32 : 64;   // records a wave parks before it expands them
+#ifndef RFX_WPARK
+#define RFX_WPARK (RFX_WIDE_AGG && RFX_WIDE_QUEUE ? 32 : 64)
+#endif
+constexpr int WPARK = RFX_WPARK;        // records a wave parks before it expands them
 constexpr int WWS0 = WPARK * 4 + 32;    // u64 words of a wave's expansion area: the parked records + head bits + prefix counts
 constexpr int WWS = WWS0 + WQCAP * 2 + WQCAP / 2;   // ... + the queue: 16-byte keys, then 4-byte (slot | probes << 16)
 
@@ -1675,8 +1681,8 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                     if (r.b0 == EMPTY || b1 == EMPTY) return false;
                     const uint32_t h = ((uint32_t)r.b0 ^ __builtin_rotateleft32((uint32_t)(r.b0 >> 32), 13) ^ __builtin_rotateleft32((uint32_t)b1, 7) ^
                                         __builtin_rotateleft32((uint32_t)(b1 >> 32), 19) ^ (c * 0x85EBCA6Bu)) * 0x9E3779B1u;
-                    uint32_t slot = ((h >> 22) * 3u) >> 2;
-                    static_assert(WRSLOTS == 768, "slot = three quarters of ten hash bits");
+                    uint32_t slot = WRSLOTS == 768 ? ((h >> 22) * 3u) >> 2 : WRSLOTS == 1024 ? h >> 22 : h >> 23;
+                    static_assert(WRSLOTS == 768 || WRSLOTS == 512 || WRSLOTS == 1024, "slot = three quarters of ten hash bits, ten, or nine");
 #pragma unroll
                     for (int probe = 0; probe < RPROBE; probe++) {
                         const unsigned long long pa = atomicCAS(&rA[slot], EMPTY, (unsigned long long)r.b0);

@@ -569,10 +569,13 @@ static int64_t dedup_text(const std::vector<uint8_t> &bases, const std::vector<i
         char hdr[64];
         const int hl = snprintf(hdr, sizeof hdr, ">Contig-%lld-%lld\n", (long long)L, (long long)i);
         for (int j = 0; j < hl; j++) { if (pos < cap) out[pos] = hdr[j]; pos++; }
-        for (int64_t j = 0; j < L; j++) {
-            if (j > 0 && j % LIM == 0) { if (pos < cap) out[pos] = '\n'; pos++; }
-            if (pos < cap) out[pos] = "ACGT"[bases[(size_t)(off[(size_t)i] + j)]];
-            pos++;
+        for (int64_t j0 = 0; j0 < L; j0 += LIM) {                 // lines of LIM bases
+            if (j0 > 0) { if (pos < cap) out[pos] = '\n'; pos++; }
+            const int64_t nl = std::min<int64_t>(LIM, L - j0);
+            const uint8_t *src = bases.data() + off[(size_t)i] + j0;
+            if (pos + nl <= cap) { for (int64_t j = 0; j < nl; j++) out[pos + j] = "ACGT"[src[j]]; }
+            else for (int64_t j = 0; j < nl; j++) if (pos + j < cap) out[pos + j] = "ACGT"[src[j]];
+            pos += nl;
         }
         if (pos < cap) out[pos] = '\n';
         pos++;
@@ -587,9 +590,12 @@ int rfx_dedup_contigs(rfx_ctx *ctx, const uint8_t *bases_ascii, const int64_t *c
     RFX_HIP(hipSetDevice(ctx->device));
     const int64_t nb = n_contigs ? contig_off[n_contigs] - contig_off[0] : 0;
     std::vector<uint8_t> codes((size_t)nb);
-    for (int64_t i = 0; i < nb; i++) {                    // A0 C1 G2, anything else 3 (nucleotideValue :453-465)
-        const uint8_t c = bases_ascii[contig_off[0] + i];
-        codes[(size_t)i] = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3;
+    {                                                     // A0 C1 G2, anything else 3 (nucleotideValue :453-465)
+        uint8_t lut[256];
+        memset(lut, 3, sizeof lut);
+        lut[(unsigned char)'A'] = 0; lut[(unsigned char)'C'] = 1; lut[(unsigned char)'G'] = 2;
+        const uint8_t *src = bases_ascii + contig_off[0];
+        for (int64_t i = 0; i < nb; i++) codes[(size_t)i] = lut[src[i]];
     }
     std::vector<int64_t> off((size_t)n_contigs + 1);
     for (int64_t i = 0; i <= n_contigs; i++) off[(size_t)i] = contig_off[i] - contig_off[0];
@@ -625,13 +631,19 @@ int rfx_dedup_contig_text(rfx_ctx *ctx, const char *contig_text, int64_t len, in
     int64_t p = 0;
     bool open = false;
     while (p < len) {
-        int64_t e = p;
-        while (e < len && contig_text[e] != '\n') e++;
+        const char *nl = (const char *)memchr(contig_text + p, '\n', (size_t)(len - p));
+        const int64_t e = nl ? (int64_t)(nl - contig_text) : len;
         if (e > p && contig_text[p] == '>') {
             if (open) off.push_back((int64_t)bases.size());
             open = true;
         } else if (open) {
-            for (int64_t i = p; i < e; i++) if (contig_text[i] != '\r') bases.push_back((uint8_t)contig_text[i]);
+            // a line of bases in one piece (9 MB of text a base at a time was most of this call's 20 ms on the host)
+            int64_t q = e;
+            if (q > p && contig_text[q - 1] == '\r') q--;
+            if (memchr(contig_text + p, '\r', (size_t)(q - p)) == nullptr)
+                bases.insert(bases.end(), (const uint8_t *)contig_text + p, (const uint8_t *)contig_text + q);
+            else
+                for (int64_t i = p; i < q; i++) if (contig_text[i] != '\r') bases.push_back((uint8_t)contig_text[i]);
         }
         p = e + 1;
     }

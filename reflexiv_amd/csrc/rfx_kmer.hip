@@ -2417,7 +2417,7 @@ template <int SEG, bool WIDE> struct OsGeo {
     static constexpr int B = SEG > 16 && !WIDE && T == SKT ? 16 : SKB, A = SEG > 16 && !WIDE && T == SKT ? RFX_OS_A32 : SKA;
 };
 template <int W, bool WIDE = false, int SEG = 16>
-__global__ __launch_bounds__((OsGeo<SEG, WIDE>::T), (WIDE || SEG > 16) ? 4 : 8) void k_sk_onesweep(ReadSrc s, Level lv, OneSweep os,
+__global__ __launch_bounds__((OsGeo<SEG, WIDE>::T), WIDE ? 4 : SEG > 16 ? (OsGeo<SEG, WIDE>::T == SKT ? 4 : OsGeo<SEG, WIDE>::T / 128) : 8) void k_sk_onesweep(ReadSrc s, Level lv, OneSweep os,
                                                                std::conditional_t<WIDE, WRec, Rec> *__restrict__ out) {
     using RT = std::conditional_t<WIDE, WRec, Rec>;
     constexpr int SKB = OsGeo<SEG, WIDE>::B, SKA = OsGeo<SEG, WIDE>::A;      // (shadow the file-wide ring geometry

@@ -69,7 +69,7 @@ bool put_file(const std::string &name, const void *h, size_t bytes) {
 }
 
 bool get_file(const std::string &name, void *h, size_t bytes) {
-    const double limit = getenv("FAKE_RCCL_TIMEOUT_S") ? atof(getenv("FAKE_RCCL_TIMEOUT_S")) : 120.0;
+    const double limit = getenv("FAKE_RCCL_TIMEOUT_S") ? atof(getenv("FAKE_RCCL_TIMEOUT_S")) : 300.0;
     struct timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     int fd;

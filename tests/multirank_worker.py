@@ -28,7 +28,7 @@ def main():
     else:
         t0 = time.time()
         while not os.path.exists(idf):
-            assert time.time() - t0 < 120, "rank 0 never published the id"
+            assert time.time() - t0 < 300, "rank 0 never published the id"
             time.sleep(0.01)
         uid = open(idf, "rb").read()
     rfx = Reflexiv(0)

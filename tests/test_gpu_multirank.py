@@ -35,7 +35,7 @@ def test_sharded_count_and_assemble_on_several_ranks(tmp_path, world, limit, swe
     outs = []
     try:
         for p in procs:
-            outs.append(p.communicate(timeout=420)[0])
+            outs.append(p.communicate(timeout=600)[0])
     finally:
         for p in procs:                                         # (exactly the processes started here)
             if p.poll() is None:

@@ -148,6 +148,82 @@ __device__ __forceinline__ unsigned out_base(const OutSeq<KW> &s, int sub, int64
     return ext_base(s.b.w, s.b.f, p - s.lenSa);
 }
 
+// ---- the same sequences WORD-WISE (round 3): 1..31 consecutive bases of an extension, a key, a record, an output
+// sequence as one right-aligned value -- a word or two loaded and shifted where the base-by-base walk above loads and
+// shifts once per base (a mid-size pass spent 90 of its 220 us of kernel time in those walks).
+// bases [q, q + cnt) of an extension in the reference's word layout (word 0: f bases under the sentinel; then 31 a word)
+__device__ __forceinline__ uint64_t ext_fetch(const uint64_t *__restrict__ w, int f, int64_t q, int cnt) {
+    const int64_t v = q + (31 - f);                    // word 0 read as 31 bases, its first 31 - f are padding
+    const int64_t wi = v / 31;
+    const int o = (int)(v - 31 * wi);
+    const uint64_t hi = wi == 0 ? (w[0] & low_mask(f)) : (w[wi] & low_mask(31));        // (bits 62-63 of a later word may stray)
+    if (o + cnt <= 31) return (hi >> (2 * (31 - o - cnt))) & low_mask(cnt);
+    const uint64_t lo = w[wi + 1] & low_mask(31);
+    const int n1 = 31 - o, n2 = cnt - n1;
+    return ((hi & low_mask(n1)) << (2 * n2)) | (lo >> (2 * (31 - n2)));
+}
+// bases [q, q + cnt) of a key of `sub` bases (31 a word, the last word the rest, right-aligned)
+template <int KW>
+__device__ __forceinline__ uint64_t key_fetch(const KeyW<KW> &key, int sub, int q, int cnt) {
+    if (KW == 1) return (key.w[0] >> (2 * (sub - q - cnt))) & low_mask(cnt);
+    const int res = sub - 31 * (KW - 1);
+    const int wi = q / 31, o = q - 31 * wi;
+    auto word31 = [&](int i) __attribute__((always_inline)) -> uint64_t {      // word i as 31 left-aligned bases
+        uint64_t x = key.w[0];
+#pragma unroll
+        for (int t = 1; t < KW; t++) if (i == t) x = key.w[t];
+        return i == KW - 1 ? x << (2 * (31 - res)) : x;
+    };
+    const uint64_t hi = word31(wi);
+    if (o + cnt <= 31) return (hi >> (2 * (31 - o - cnt))) & low_mask(cnt);
+    const uint64_t lo = word31(wi + 1);
+    const int n1 = 31 - o, n2 = cnt - n1;
+    return ((hi & low_mask(n1)) << (2 * n2)) | (lo >> (2 * (31 - n2)));
+}
+// bases [p, p + cnt) of a record's full sequence (marker 1: key || ext, marker 2: ext || key)
+template <int KW>
+__device__ __forceinline__ uint64_t rec_fetch(const SrcRec<KW> &r, int sub, int64_t p, int cnt) {
+    const int64_t lenA = r.marker == 1 ? (int64_t)sub : r.len;
+    uint64_t x = 0;
+    int n1 = 0;
+    if (p < lenA) {
+        n1 = (int)(lenA - p < cnt ? lenA - p : cnt);
+        x = r.marker == 1 ? key_fetch<KW>(r.key, sub, (int)p, n1) : ext_fetch(r.w, r.f, p, n1);
+    }
+    const int n2 = cnt - n1;
+    if (n2 > 0) {
+        const int64_t q = p + n1 - lenA;
+        const uint64_t y = r.marker == 1 ? ext_fetch(r.w, r.f, q, n2) : key_fetch<KW>(r.key, sub, (int)q, n2);
+        x = (x << (2 * n2)) | y;
+    }
+    return x;
+}
+// bases [p, p + cnt) of S_out
+template <int KW>
+__device__ __forceinline__ uint64_t out_fetch(const OutSeq<KW> &s, int sub, int64_t p, int cnt) {
+    if (s.type == 1) return rec_fetch<KW>(s.a, sub, p, cnt);
+    uint64_t x = 0;
+    int n1 = 0;
+    if (p < s.lenSa) {
+        n1 = (int)(s.lenSa - p < cnt ? s.lenSa - p : cnt);
+        x = rec_fetch<KW>(s.a, sub, p, n1);
+    }
+    const int n2 = cnt - n1;
+    if (n2 > 0) x = (x << (2 * n2)) | ext_fetch(s.b.w, s.b.f, p + n1 - s.lenSa, n2);
+    return x;
+}
+// the key made of the `sub` bases of S_out from `from` on
+template <int KW>
+__device__ __forceinline__ KeyW<KW> out_key(const OutSeq<KW> &s, int sub, int64_t from) {
+    KeyW<KW> key;
+#pragma unroll
+    for (int w = 0; w < KW; w++) {
+        const int nb = w < KW - 1 ? 31 : sub - 31 * (KW - 1);
+        key.w[w] = out_fetch<KW>(s, sub, from + 31 * w, nb);
+    }
+    return key;
+}
+
 // words [w0, w1) of the output extension (bases q of ext_out = S_out[q + shift])
 template <int KW>
 __device__ __forceinline__ void emit_words(const OutSeq<KW> &s, int sub, int64_t shift, int64_t L, int64_t w0,
@@ -155,10 +231,8 @@ __device__ __forceinline__ void emit_words(const OutSeq<KW> &s, int sub, int64_t
     const int64_t nw = (L + 30) / 31;
     const int f = (int)(L - 31 * (nw - 1));
     for (int64_t w = w0; w < w1; w += wstep) {
-        uint64_t x; int64_t q; int cnt;
-        if (w == 0) { x = 1; q = 0; cnt = f; } else { x = 0; q = f + 31 * (w - 1); cnt = 31; }
-        for (int j = 0; j < cnt; j++) x = (x << 2) | out_base<KW>(s, sub, shift + q + j);
-        dst[w] = x;
+        if (w == 0) dst[0] = (1ULL << (2 * f)) | out_fetch<KW>(s, sub, shift, f);
+        else dst[w] = out_fetch<KW>(s, sub, shift + f + 31 * (w - 1), 31);
     }
 }
 
@@ -251,7 +325,7 @@ __device__ __forceinline__ void emit_at(int64_t i, const Desc *__restrict__ desc
     // key: first (m == 1) or last (m == 2) k-1 bases of S_out
     const int64_t kshift = m == 1 ? 0 : L;
     if (d.type == 1 && s.a.marker == m) okey[j] = s.a.key;
-    else okey[j] = build_key<KW>(sub, [&](int t) { return out_base<KW>(s, sub, kshift + t); });
+    else okey[j] = out_key<KW>(s, sub, kshift);
     const int64_t nw = (L + 30) / 31;
     if (nw > EMIT_SHORT) return;                     // k_emit_words: one thread per output word
     if (d.type == 1 && s.a.marker == m) {            // same orientation: the words are unchanged

@@ -1,5 +1,6 @@
 // rfx_api.hip -- the extern "C" boundary of libreflexiv_hip.so (include/reflexiv_hip.h) and
 // the driver loop that mirrors ReflexivMain.assembly() (P/ReflexivMain.java:168-310).
+#include <system_error>
 #include <thread>
 #include <execinfo.h>
 #include <signal.h>
@@ -128,7 +129,10 @@ int64_t contigs_text_host(const rfx_records *r, int k, int min_contig, int twin,
                 }
             };
             std::vector<std::thread> th;
-            for (int t = 1; t < T; t++) th.emplace_back(work, t);
+            for (int t = 1; t < T; t++) {
+                try { th.emplace_back(work, t); }
+                catch (const std::system_error &) { work(t); }       // (no thread to be had: this one does the share)
+            }
             work(0);
             for (auto &x : th) x.join();
             if (n_contigs) *n_contigs = id2;

@@ -116,8 +116,11 @@ def test_sharded_count_behind_the_c_abi_one_rank(env):
 
 
 @pytest.mark.skipif(not os.path.exists(PIN), reason="tests/golden/c3_share.json not generated")
-@pytest.mark.parametrize("k", [31, 63])
-def test_multi_gpu_branch_at_the_config3_share_matches_the_oracle_pin(k):
+@pytest.mark.parametrize("k,env", [(31, {"RFX_COMM_SELF_VIA_RCCL": "1"}), (63, {"RFX_COMM_SELF_VIA_RCCL": "1"}),
+                                   # as a rank of 8 (what `bench.py --force-dist` times): 32 (generation, owner) bins, the sender's
+                                   # bucketing by level 1's one sweep with 16 sub-bins per bucket and the gaps closed
+                                   (31, {"RFX_COMM_VIRTUAL_WORLD": "8"}), (63, {"RFX_COMM_VIRTUAL_WORLD": "8"})])
+def test_multi_gpu_branch_at_the_config3_share_matches_the_oracle_pin(k, env):
     """The code path `bench.py --gpus 8` runs on every rank (records in 4 generations through RCCL, count per generation,
     merge), rehearsed on one rank at the per-GPU share of configs 3 / 4: 41,666,668 reads, -cover 38.  Counts, sha256 of
     the survivors, the extend trace and sha256 of the contig text against the ORACLE's pin."""
@@ -125,7 +128,7 @@ def test_multi_gpu_branch_at_the_config3_share_matches_the_oracle_pin(k):
     import reflexiv_amd
     pin = json.load(open(PIN))
     rec, w = pin[f"k{k}"], pin["workload"]
-    rfx = make_comm({"RFX_COMM_SELF_VIA_RCCL": "1"})
+    rfx = make_comm(env)
     try:
         n_reads, L, cover, P = w["reads"], w["read_len"], w["cover"], w["partitions"]
         dw, wpr = reads_on_device(rfx, w["seed"], w["genome"], n_reads, L, w["err_per_2_32"])

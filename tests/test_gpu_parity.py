@@ -970,6 +970,8 @@ def test_one_sweep_level1_matches_oracle(rfx, torch_mod, k, mode, monkeypatch):
     monkeypatch.setenv("RFX_SK_ONESWEEP", "2")
     if mode == "overflow":
         monkeypatch.setenv("RFX_SK_ONESWEEP_CAP", "1")
+    if not mode.startswith("bits"):
+        monkeypatch.setenv("RFX_LEVEL_BITS", "9,1")             # (two levels, 512 bins first: a single level -- this size's plan -- takes the two-pass form, and a tile must not put more on a bin than an extent takes)
     if mode.startswith("bits"):
         # 1024 buckets (one workgroup per CU), 128 (extents of 128 or 256), 32 (a tile puts more on a bucket than the largest
         # extent takes: the sweep is not tried)
@@ -1023,11 +1025,18 @@ def test_heavy_leaf_slices_merge_exactly(rfx, torch_mod, k, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,clips", [(31, (0, 0)), (31, (2, 3)), (28, (0, 0)), (21, (0, 0)), (21, (1, 4))])
-def test_ragged_reads_device_count(rfx, torch_mod, k, clips):
+@pytest.mark.parametrize("k,clips,sweep", [(31, (0, 0), False), (31, (2, 3), False), (28, (0, 0), False), (21, (0, 0), False), (21, (1, 4), False),
+                                           # level 1 in ONE sweep with 32 windows per thread, forced at this size: segments that run
+                                           # past a read's end, reads without a window in their last segment, clips that shift the stream
+                                           (31, (0, 0), True), (31, (2, 3), True), (31, (17, 9), True), (28, (5, 0), True), (25, (0, 6), True), (21, (1, 4), True)])
+def test_ragged_reads_device_count(rfx, torch_mod, k, clips, sweep, monkeypatch):
     """Reads of different lengths (trimmed FASTQ) through rfx_dev_encode_reads + rfx_dev_count_reads_ragged:
     reads shorter than k, exactly k + 1, and up to 251 bases, with N; record path (k = 28..31) and k-mer path."""
     torch = torch_mod
+    if sweep:
+        monkeypatch.setenv("RFX_SK_ONESWEEP", "2")
+        monkeypatch.setenv("RFX_LEVEL_BITS", "9,1")             # (two levels, 512 bins first: a single level takes the two-pass form)
+        monkeypatch.setenv("RFX_TRACE", "1")
     rng = np.random.default_rng(100 + k)
     genome = "".join(rng.choice(list("ACGT"), size=5000))
     reads = []

@@ -1379,6 +1379,8 @@ def test_wide_record_path_equals_oracle(rfx, torch_mod, k, monkeypatch):
         # "sweep": the record path with its level 1 in one sweep (k_sk_onesweep<W, true>), forced at this size
         monkeypatch.setenv("RFX_WIDE_RECORDS", "0" if flag == "0" else "1")
         monkeypatch.setenv("RFX_SK_ONESWEEP", "2" if flag == "sweep" else "0")
+        if flag == "sweep":
+            monkeypatch.setenv("RFX_LEVEL_BITS", "9,1")        # (two levels: this size's single level takes the two-pass form)
         dk = torch.empty(2 * N, dtype=torch.int64, device="cuda"); dc = torch.empty(N, dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
         m, d, inst = rfx.count_reads_w_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), N, 2)

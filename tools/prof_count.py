@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--cover", type=int, default=30)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--assemble", action="store_true")
+    ap.add_argument("--assemble-runs", type=int, default=1)
     a = ap.parse_args()
     import torch
     import reflexiv_amd
@@ -38,7 +39,8 @@ def main():
     print("instances", inst, "distinct", nd, "kept", m, rfx.count_timing())
     if a.assemble:
         prm = reflexiv_amd.default_params(min_cov=a.cover, partitions=8)
-        text, nc, trace = rfx.assemble_dev(dk.data_ptr(), dc.data_ptr(), m, prm)
+        for _ in range(a.assemble_runs):      # (the first run of a process loads the extend kernels: RFX_TRACE of the second is the warm one)
+            text, nc, trace = rfx.assemble_dev(dk.data_ptr(), dc.data_ptr(), m, prm)
         print("contigs", nc, "passes", len(trace))
 
 

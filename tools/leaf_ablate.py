@@ -63,3 +63,6 @@ if which == "seg":
     run(21, {"RFX_SK_SEG": "16"})
 if which == "63one":
     run(63, {}, 1)
+if which == "bits":
+    for env in ({}, {"RFX_LEVEL_BITS": "8,10"}, {"RFX_LEVEL_BITS": "9,10"}, {"RFX_LEVEL_BITS": "8,9"}, {"RFX_LEAF_TARGET": "24576"}, {"RFX_PRESPLIT": "12000"}, {}):
+        run(31, env, 2)

@@ -2325,6 +2325,9 @@ __global__ __launch_bounds__(SKT, WIDE ? 4 : 8) void k_sk_scatter(ReadSrc s, Lev
 #ifndef RFX_OS_T32
 #define RFX_OS_T32 512               // threads per workgroup of the sweep with 32 windows per thread
 #endif
+#ifndef RFX_OS_LPB
+#define RFX_OS_LPB 4                 // lanes that drain a bin there (8: a lane per ring slot)
+#endif
 constexpr int OSE_MIN = 64, OSE_MAX = 256;   // records per extent: a round must not put more than one extent of one
                                          // workgroup into one bucket (5 records on average at 512 buckets); the sampled
                                          // histogram picks 64, 128 or 256 by the busiest bucket, or no sweep at all
@@ -2458,10 +2461,14 @@ __global__ __launch_bounds__((OsGeo<SEG, WIDE>::T), WIDE ? 4 : SEG > 16 ? (OsGeo
         pbase[i] = grab(i);
     }
     __syncthreads();
+    // LPB lanes drain a bin, each every LPB-th record of what waits: eight lanes (one record each) in rounds 1-2; four
+    // with 32 windows per thread -- a bin's bookkeeping is done by half as many lanes, and four lanes are one aligned
+    // 64-byte line, the unit the rings hand out anyway
+    constexpr int LPB = SEG > 16 && !WIDE ? RFX_OS_LPB : SKB;
     auto drain = [&](bool final) __attribute__((always_inline)) {
 #pragma unroll RFX_DRAIN_UNROLL
-        for (int d = threadIdx.x / SKB; d < nb; d += SKT / SKB) {
-            const int j = threadIdx.x % SKB;
+        for (int d = threadIdx.x / LPB; d < nb; d += SKT / LPB) {
+            const int j = threadIdx.x % LPB;
             const uint32_t h = head[d], t = tail[d], cs = cstart[d], cb = cbase[d], nx = nbase[d];
             uint32_t e, nh;
             if (t - h > (uint32_t)SKB) { e = h + SKB; nh = t; }               // the excess went out directly
@@ -2470,11 +2477,14 @@ __global__ __launch_bounds__((OsGeo<SEG, WIDE>::T), WIDE ? 4 : SEG > 16 ? (OsGeo
                 if (e < h) e = h;
                 nh = e;
             }
-            const uint32_t g = h + j;
 #ifdef RFX_OS_ABL_NOSTORE
-            if (g < e && g == 0xFFFFFFF0u) out[phys(g, cs, cb, nx)] = buf[(size_t)d * SKB + (g & (SKB - 1))];
+            { const uint32_t g = h + j; if (g < e && g == 0xFFFFFFF0u) out[phys(g, cs, cb, nx)] = buf[(size_t)d * SKB + (g & (SKB - 1))]; }
 #else
-            if (g < e) out[phys(g, cs, cb, nx)] = buf[(size_t)d * SKB + (g & (SKB - 1))];
+#pragma unroll
+            for (int q = 0; q < SKB / LPB; q++) {
+                const uint32_t g = h + j + q * LPB;
+                if (g < e) out[phys(g, cs, cb, nx)] = buf[(size_t)d * SKB + (g & (SKB - 1))];
+            }
 #endif
             if (j == 0) {
                 head[d] = nh;

@@ -2328,6 +2328,9 @@ __global__ __launch_bounds__(SKT, WIDE ? 4 : 8) void k_sk_scatter(ReadSrc s, Lev
 #ifndef RFX_OS_LPB
 #define RFX_OS_LPB 4                 // lanes that drain a bin there (8: a lane per ring slot)
 #endif
+#ifndef RFX_OS_LPB_WIDE
+#define RFX_OS_LPB_WIDE 4            // ... of the 32-byte records of k = 33..63 (8: part1 9.95 instead of 9.80 ms)
+#endif
 constexpr int OSE_MIN = 64, OSE_MAX = 256;   // records per extent: a round must not put more than one extent of one
                                          // workgroup into one bucket (5 records on average at 512 buckets); the sampled
                                          // histogram picks 64, 128 or 256 by the busiest bucket, or no sweep at all
@@ -2464,7 +2467,7 @@ __global__ __launch_bounds__((OsGeo<SEG, WIDE>::T), WIDE ? 4 : SEG > 16 ? (OsGeo
     // LPB lanes drain a bin, each every LPB-th record of what waits: eight lanes (one record each) in rounds 1-2; four
     // with 32 windows per thread -- a bin's bookkeeping is done by half as many lanes, and four lanes are one aligned
     // 64-byte line, the unit the rings hand out anyway
-    constexpr int LPB = SEG > 16 && !WIDE ? RFX_OS_LPB : SKB;
+    constexpr int LPB = SEG > 16 && !WIDE ? RFX_OS_LPB : WIDE ? RFX_OS_LPB_WIDE : SKB;
     auto drain = [&](bool final) __attribute__((always_inline)) {
 #pragma unroll RFX_DRAIN_UNROLL
         for (int d = threadIdx.x / LPB; d < nb; d += SKT / LPB) {

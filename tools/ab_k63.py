@@ -10,7 +10,7 @@ rfx.synth_genome_dev(1, G, dg.data_ptr()); rfx.synth_reads_dev(1, dg.data_ptr(),
 cap = 1 << 24
 dk = torch.empty(cap * 2, dtype=torch.int64, device="cuda"); dc = torch.empty(cap, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
-for env in ({}, {"RFX_WIDE_STATS": "1"}):
+for env in ({},):
     old = {a: os.environ.get(a) for a in env}
     os.environ.update(env)
     best = None

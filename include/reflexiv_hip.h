@@ -41,7 +41,9 @@ typedef enum {
     RFX_E_HIP     = -3,   /* a HIP runtime call failed; see rfx_last_error()               */
     RFX_E_NOGPU   = -4,   /* no usable gfx950 device                                       */
     RFX_E_STATE   = -5,   /* "impossible" record state (the reference prints and goes on)  */
-    RFX_E_LIMIT   = -6    /* size beyond this build's limits (e.g. > 2^32-1 records)       */
+    RFX_E_LIMIT   = -6,   /* size beyond this build's limits (e.g. > 2^32-1 records)       */
+    RFX_E_HOST    = -7    /* a C++ exception (std::bad_alloc, std::system_error ...) was caught at this boundary; what() in
+                           * rfx_last_error().  Every entry point is a function-try-block: nothing unwinds into the caller  */
 } rfx_status;
 
 #define RFX_TWIN_DS  0    /* arithmetic of P/ReflexivDSMain.java (the wired, fixed twin)   */
@@ -102,7 +104,13 @@ int  rfx_ctx_sync(rfx_ctx *ctx);
 /* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. */
 int  rfx_ctx_set_stream(rfx_ctx *ctx, void *hip_stream);
 void *rfx_ctx_stream(rfx_ctx *ctx);
-const char *rfx_last_error(rfx_ctx *ctx);               /* text of the last RFX_E_HIP      */
+const char *rfx_last_error(rfx_ctx *ctx);               /* text of the last RFX_E_HIP / RFX_E_HOST / RFX_E_STATE */
+/* The context keeps its large buffers between calls (grow-only workspaces: the count stage's record buffers ~ 3 B per
+ * k-mer instance, the extend stage's two arenas, and -- rfx_assemble_reads -- the packed reads plus, up to
+ * RFX_KEEP_STAGING_BYTES = 8 GiB, the ASCII staging).  rfx_ctx_workspace_bytes reports what is held; rfx_ctx_trim waits
+ * for the context's stream and hands everything back to the driver (the next call allocates again). */
+int  rfx_ctx_trim(rfx_ctx *ctx);
+int64_t rfx_ctx_workspace_bytes(rfx_ctx *ctx);
 
 /* ------------------------------------------------- operators, host buffers */
 

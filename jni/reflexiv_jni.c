@@ -157,14 +157,14 @@ static jlongArray extract_common(JNIEnv *env, jlong h, jbyteArray bases, jlongAr
     jlongArray out = NULL;
     for (int pass = 0; pass < 2; pass++) {                 /* size query, then the real call */
         if (pass == 1) { out = (*env)->NewLongArray(env, (jsize)(n * W)); if (!out) return NULL; }
-        jbyte *b = (jbyte *)(*env)->GetPrimitiveArrayCritical(env, bases, NULL);
-        jlong *o = (jlong *)(*env)->GetPrimitiveArrayCritical(env, readOff, NULL);
-        jlong *dst = pass ? (jlong *)(*env)->GetPrimitiveArrayCritical(env, out, NULL) : NULL;
+        jbyte *b = (*env)->GetByteArrayElements(env, bases, NULL);
+        jlong *o = (*env)->GetLongArrayElements(env, readOff, NULL);
+        jlong *dst = pass ? (*env)->GetLongArrayElements(env, out, NULL) : NULL;
         int st = wide ? rfx_extract_canon_w(ctx, (const uint8_t *)b, (const int64_t *)o, nOff - 1, k, fc, ec, (uint64_t *)dst, pass ? n : 0, &n)
                       : rfx_extract_canon(ctx, (const uint8_t *)b, (const int64_t *)o, nOff - 1, k, fc, ec, (uint64_t *)dst, pass ? n : 0, &n);
-        if (dst) (*env)->ReleasePrimitiveArrayCritical(env, out, dst, 0);
-        (*env)->ReleasePrimitiveArrayCritical(env, readOff, o, JNI_ABORT);
-        (*env)->ReleasePrimitiveArrayCritical(env, bases, b, JNI_ABORT);
+        if (dst) (*env)->ReleaseLongArrayElements(env, out, dst, 0);
+        (*env)->ReleaseLongArrayElements(env, readOff, o, JNI_ABORT);
+        (*env)->ReleaseByteArrayElements(env, bases, b, JNI_ABORT);
         if (st != RFX_OK && !(pass == 0 && st == RFX_E_CAP)) { throw_rfx(env, ctx, st, wide ? "rfx_extract_canon_w" : "rfx_extract_canon"); return NULL; }
     }
     return out;
@@ -190,14 +190,14 @@ JNIEXPORT jlong JNICALL RFX_CLASS(countFilter)(JNIEnv *env, jclass c, jlong h, j
     rfx_ctx *ctx = ctx_of(h);
     const jsize n = (*env)->GetArrayLength(env, kmers);
     int64_t m = 0, d = 0;
-    jlong *in = (jlong *)(*env)->GetPrimitiveArrayCritical(env, kmers, NULL);
-    jlong *ok = (jlong *)(*env)->GetPrimitiveArrayCritical(env, outKeys, NULL);
-    jint *oc = (jint *)(*env)->GetPrimitiveArrayCritical(env, outCounts, NULL);
+    jlong *in = (*env)->GetLongArrayElements(env, kmers, NULL);
+    jlong *ok = (*env)->GetLongArrayElements(env, outKeys, NULL);
+    jint *oc = (*env)->GetIntArrayElements(env, outCounts, NULL);
     const int st = rfx_count_filter(ctx, (const uint64_t *)in, n, minCov, maxCov, twin, (uint64_t *)ok, (int32_t *)oc,
                                     (*env)->GetArrayLength(env, outCounts), &m, &d);
-    (*env)->ReleasePrimitiveArrayCritical(env, outCounts, oc, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, outKeys, ok, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, kmers, in, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, outCounts, oc, 0);
+    (*env)->ReleaseLongArrayElements(env, outKeys, ok, 0);
+    (*env)->ReleaseLongArrayElements(env, kmers, in, JNI_ABORT);
     if (st != RFX_OK) { throw_rfx(env, ctx, st, "rfx_count_filter"); return -1; }
     return (jlong)m;
 }
@@ -210,14 +210,14 @@ JNIEXPORT jlong JNICALL RFX_CLASS(countFilterW)(JNIEnv *env, jclass c, jlong h, 
     const int W = k / 32 + 1;
     const jsize n = (*env)->GetArrayLength(env, kmers) / W;
     int64_t m = 0, d = 0;
-    jlong *in = (jlong *)(*env)->GetPrimitiveArrayCritical(env, kmers, NULL);
-    jlong *ok = (jlong *)(*env)->GetPrimitiveArrayCritical(env, outKeys, NULL);
-    jlong *oc = (jlong *)(*env)->GetPrimitiveArrayCritical(env, outCounts, NULL);
+    jlong *in = (*env)->GetLongArrayElements(env, kmers, NULL);
+    jlong *ok = (*env)->GetLongArrayElements(env, outKeys, NULL);
+    jlong *oc = (*env)->GetLongArrayElements(env, outCounts, NULL);
     const int st = rfx_count_filter_w(ctx, (const uint64_t *)in, n, k, minCov, maxCov, (uint64_t *)ok, (int64_t *)oc,
                                       (*env)->GetArrayLength(env, outCounts), &m, &d);
-    (*env)->ReleasePrimitiveArrayCritical(env, outCounts, oc, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, outKeys, ok, 0);
-    (*env)->ReleasePrimitiveArrayCritical(env, kmers, in, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, outCounts, oc, 0);
+    (*env)->ReleaseLongArrayElements(env, outKeys, ok, 0);
+    (*env)->ReleaseLongArrayElements(env, kmers, in, JNI_ABORT);
     if (st != RFX_OK) { throw_rfx(env, ctx, st, "rfx_count_filter_w"); return -1; }
     return (jlong)m;
 }
@@ -233,11 +233,11 @@ JNIEXPORT void JNICALL RFX_CLASS(rcExpandSubkmer)(JNIEnv *env, jclass c, jlong h
     pinned_records po;
     int st = RFX_E_ARG;
     if (records_pin(env, out, &po)) {
-        jlong *km = (jlong *)(*env)->GetPrimitiveArrayCritical(env, kmers, NULL);
-        jint *cn = (jint *)(*env)->GetPrimitiveArrayCritical(env, counts, NULL);
+        jlong *km = (*env)->GetLongArrayElements(env, kmers, NULL);
+        jint *cn = (*env)->GetIntArrayElements(env, counts, NULL);
         st = rfx_rc_expand_subkmer(ctx, (const uint64_t *)km, (const int32_t *)cn, n, k, &po.r);
-        (*env)->ReleasePrimitiveArrayCritical(env, counts, cn, JNI_ABORT);
-        (*env)->ReleasePrimitiveArrayCritical(env, kmers, km, JNI_ABORT);
+        (*env)->ReleaseIntArrayElements(env, counts, cn, JNI_ABORT);
+        (*env)->ReleaseLongArrayElements(env, kmers, km, JNI_ABORT);
     }
     records_unpin(env, &po, 0);
     if (st != RFX_OK) throw_rfx(env, ctx, st, "rfx_rc_expand_subkmer");
@@ -386,9 +386,9 @@ JNIEXPORT jbyteArray JNICALL RFX_CLASS(contigsText)(JNIEnv *env, jclass c, jlong
         records_unpin(env, &pi, JNI_ABORT);
         out = (*env)->NewByteArray(env, (jsize)len);
         if (!out || !records_pin(env, in, &pi)) { records_unpin(env, &pi, JNI_ABORT); return NULL; }
-        jbyte *dst = (jbyte *)(*env)->GetPrimitiveArrayCritical(env, out, NULL);
+        jbyte *dst = (*env)->GetByteArrayElements(env, out, NULL);
         st = rfx_contigs_text(ctx, &pi.r, k, minContig, twin, (char *)dst, len, &len, &nc);
-        (*env)->ReleasePrimitiveArrayCritical(env, out, dst, 0);
+        (*env)->ReleaseByteArrayElements(env, out, dst, 0);
     }
     records_unpin(env, &pi, JNI_ABORT);
     if (st != RFX_OK) { throw_rfx(env, ctx, st, "rfx_contigs_text"); return NULL; }
@@ -410,13 +410,21 @@ JNIEXPORT jbyteArray JNICALL RFX_CLASS(assembleReads)(JNIEnv *env, jclass c, jlo
     for (;;) {
         char *buf = (char *)malloc((size_t)cap);             /* native staging: no JNI call is made while arrays are pinned */
         if (!buf) { throw_rfx(env, ctx, RFX_E_HIP, "rfx_assemble_reads (out of host memory)"); return NULL; }
-        jbyte *b = (jbyte *)(*env)->GetPrimitiveArrayCritical(env, bases, NULL);
-        jlong *o = (jlong *)(*env)->GetPrimitiveArrayCritical(env, readOff, NULL);
+        /* NOT a critical region: the call blocks on the GPU for the whole run, and a critical region stalls every other
+         * thread's GC for that long (Get<Type>ArrayElements pins or copies; either is fine for a read-only input) */
+        jbyte *b = (*env)->GetByteArrayElements(env, bases, NULL);
+        jlong *o = (*env)->GetLongArrayElements(env, readOff, NULL);
+        if (!b || !o) {
+            if (b) (*env)->ReleaseByteArrayElements(env, bases, b, JNI_ABORT);
+            if (o) (*env)->ReleaseLongArrayElements(env, readOff, o, JNI_ABORT);
+            free(buf);
+            return NULL;                                     /* (OutOfMemoryError is pending) */
+        }
         int64_t len = 0, nc = 0, ntr = 0, kept = 0;
         const int st = rfx_assemble_reads(ctx, (const uint8_t *)b, (const int64_t *)o, nOff - 1, &prm, buf, cap, &len, &nc,
                                           NULL, 0, &ntr, &kept);
-        (*env)->ReleasePrimitiveArrayCritical(env, readOff, o, JNI_ABORT);
-        (*env)->ReleasePrimitiveArrayCritical(env, bases, b, JNI_ABORT);
+        (*env)->ReleaseLongArrayElements(env, readOff, o, JNI_ABORT);
+        (*env)->ReleaseByteArrayElements(env, bases, b, JNI_ABORT);
         if (st == RFX_E_CAP && len > cap) { cap = len; free(buf); continue; }
         if (st != RFX_OK) { free(buf); throw_rfx(env, ctx, st, "rfx_assemble_reads"); return NULL; }
         jbyteArray out = (*env)->NewByteArray(env, (jsize)len);
@@ -488,14 +496,24 @@ JNIEXPORT jbyteArray JNICALL RFX_CLASS(shardedAssembleReads)(JNIEnv *env, jclass
     for (;;) {
         char *buf = (char *)malloc((size_t)cap);
         if (!buf) { throw_rfx(env, ctx, RFX_E_HIP, "rfx_sharded_assemble_reads (out of host memory)"); return NULL; }
-        jbyte *b = (jbyte *)(*env)->GetPrimitiveArrayCritical(env, bases, NULL);
-        jlong *o = (jlong *)(*env)->GetPrimitiveArrayCritical(env, readOff, NULL);
+        /* NOT a critical region: this is a blocking COLLECTIVE (upload, RCCL all-to-all, the whole extend loop) that waits for
+         * the other tasks of the barrier stage.  A critical region blocks the collector; a task of the same JVM that has not
+         * entered yet could stall in a GC waiting for this region while this task waits for it inside RCCL -- a deadlock. */
+        jbyte *b = (*env)->GetByteArrayElements(env, bases, NULL);
+        jlong *o = (*env)->GetLongArrayElements(env, readOff, NULL);
+        if (!b || !o) {
+            if (b) (*env)->ReleaseByteArrayElements(env, bases, b, JNI_ABORT);
+            if (o) (*env)->ReleaseLongArrayElements(env, readOff, o, JNI_ABORT);
+            free(buf);
+            return NULL;                                     /* (OutOfMemoryError is pending; the peers time out in RCCL) */
+        }
         int64_t len = 0, nc = 0, ntr = 0, tot[3] = {0, 0, 0};
         const int st = rfx_sharded_assemble_reads(ctx, (rfx_comm *)(intptr_t)comm, (const uint8_t *)b, (const int64_t *)o, nOff - 1, &prm,
                                                   generations, buf, cap, &len, &nc, NULL, 0, &ntr, tot);
-        (*env)->ReleasePrimitiveArrayCritical(env, readOff, o, JNI_ABORT);
-        (*env)->ReleasePrimitiveArrayCritical(env, bases, b, JNI_ABORT);
-        if (st == RFX_E_CAP && len > cap) { cap = len; free(buf); continue; }      /* (collective: every task repeats the call) */
+        (*env)->ReleaseLongArrayElements(env, readOff, o, JNI_ABORT);
+        (*env)->ReleaseByteArrayElements(env, bases, b, JNI_ABORT);
+        /* RFX_E_CAP is returned on EVERY rank with the length rank 0 needs, so every task repeats the collective together */
+        if (st == RFX_E_CAP && len > cap) { cap = len; free(buf); continue; }
         if (st != RFX_OK) { free(buf); throw_rfx(env, ctx, st, "rfx_sharded_assemble_reads"); return NULL; }
         if (totals && (*env)->GetArrayLength(env, totals) >= 3) (*env)->SetLongArrayRegion(env, totals, 0, 3, (const jlong *)tot);
         jbyteArray out = (*env)->NewByteArray(env, (jsize)len);
@@ -543,15 +561,48 @@ JNIEXPORT jlong JNICALL RFX_CLASS(dynRun)(JNIEnv *env, jclass c, jlong h, jlongA
     (void)c;
     rfx_ctx *ctx = ctx_of(h);
     const jsize n = (*env)->GetArrayLength(env, attr);
+    /* the offset arrays must hold n + 1 entries, ascending from 0, inside their block arrays: checked BEFORE anything is
+     * indexed with them (a short keyOff used to be a native crash inside the JVM) */
+    if ((*env)->GetArrayLength(env, keyOff) < n + 1 || (*env)->GetArrayLength(env, extOff) < n + 1) {
+        throw_rfx(env, ctx, RFX_E_ARG, "rfx_dyn_run (keyOff / extOff: one entry per row + 1)");
+        return 0;
+    }
     int64_t *kb = longs_in(env, keyBlocks), *ko = longs_in(env, keyOff), *eb = longs_in(env, extBlocks), *eo = longs_in(env, extOff),
             *at = longs_in(env, attr);
+    if (!kb || !ko || !eb || !eo || !at) {
+        longs_out(env, keyBlocks, kb, 0); longs_out(env, keyOff, ko, 0); longs_out(env, extBlocks, eb, 0); longs_out(env, extOff, eo, 0);
+        longs_out(env, attr, at, 0);
+        return 0;                                            /* (OutOfMemoryError is pending) */
+    }
+    int st = RFX_OK;
+    {
+        const int64_t lkb = (*env)->GetArrayLength(env, keyBlocks), leb = (*env)->GetArrayLength(env, extBlocks);
+        if (ko[0] != 0 || eo[0] != 0 || ko[n] > lkb || eo[n] > leb) st = RFX_E_ARG;
+        for (jsize i = 0; i < n && st == RFX_OK; i++)
+            if (ko[i + 1] < ko[i] || eo[i + 1] < eo[i]) st = RFX_E_ARG;
+        if (st != RFX_OK) {
+            longs_out(env, keyBlocks, kb, 0); longs_out(env, keyOff, ko, 0); longs_out(env, extBlocks, eb, 0); longs_out(env, extOff, eo, 0);
+            longs_out(env, attr, at, 0);
+            throw_rfx(env, ctx, st, "rfx_dyn_run (keyOff / extOff must ascend from 0 and stay inside keyBlocks / extBlocks)");
+            return 0;
+        }
+    }
     const int64_t nkb = ko[n], neb = eo[n];
     /* to base codes */
     uint8_t *key = (uint8_t *)malloc((size_t)nkb * 31 + 1), *ext = (uint8_t *)malloc((size_t)neb * 31 + 1);
     int64_t *koff = (int64_t *)malloc((size_t)(n + 1) * 8), *eoff = (int64_t *)malloc((size_t)(n + 1) * 8);
     int32_t *mk = (int32_t *)malloc((size_t)(n + 1) * 4), *lf = (int32_t *)malloc((size_t)(n + 1) * 4), *rt = (int32_t *)malloc((size_t)(n + 1) * 4);
+    int64_t *okoff = (int64_t *)malloc((size_t)(n + 1) * 8), *oeoff = (int64_t *)malloc((size_t)(n + 1) * 8);
+    int32_t *omk = (int32_t *)malloc((size_t)(n + 1) * 4), *olf = (int32_t *)malloc((size_t)(n + 1) * 4), *ort = (int32_t *)malloc((size_t)(n + 1) * 4);
     int64_t pk = 0, pe = 0;
-    int st = RFX_OK;
+    if (!key || !ext || !koff || !eoff || !mk || !lf || !rt || !okoff || !oeoff || !omk || !olf || !ort) {
+        free(key); free(ext); free(koff); free(eoff); free(mk); free(lf); free(rt);
+        free(okoff); free(oeoff); free(omk); free(olf); free(ort);
+        longs_out(env, keyBlocks, kb, 0); longs_out(env, keyOff, ko, 0); longs_out(env, extBlocks, eb, 0); longs_out(env, extOff, eo, 0);
+        longs_out(env, attr, at, 0);
+        throw_rfx(env, ctx, RFX_E_HOST, "rfx_dyn_run (out of host memory)");
+        return 0;
+    }
     for (jsize i = 0; i < n && st == RFX_OK; i++) {
         koff[i] = pk; eoff[i] = pe;
         const int lk = rfx_dyn_blocks_to_bases(kb + ko[i], (int)(ko[i + 1] - ko[i]), key + pk, (int)((ko[i + 1] - ko[i]) * 31));
@@ -566,11 +617,10 @@ JNIEXPORT jlong JNICALL RFX_CLASS(dynRun)(JNIEnv *env, jclass c, jlong h, jlongA
     rfx_dyn_records in = {n, key, koff, ext, eoff, mk, lf, rt, n, pk, pe, 0, 0};
     int64_t cap_b = pk + pe + 64, out_n = 0;
     uint8_t *okey = NULL, *oext = NULL;
-    int64_t *okoff = (int64_t *)malloc((size_t)(n + 1) * 8), *oeoff = (int64_t *)malloc((size_t)(n + 1) * 8);
-    int32_t *omk = (int32_t *)malloc((size_t)(n + 1) * 4), *olf = (int32_t *)malloc((size_t)(n + 1) * 4), *ort = (int32_t *)malloc((size_t)(n + 1) * 4);
     while (st == RFX_OK) {
         free(okey); free(oext);
         okey = (uint8_t *)malloc((size_t)cap_b); oext = (uint8_t *)malloc((size_t)cap_b);
+        if (!okey || !oext) { st = RFX_E_HOST; break; }
         rfx_dyn_records out = {0, okey, okoff, oext, oeoff, omk, olf, ort, n, cap_b, cap_b, 0, 0};
         int64_t ntr = 0;
         st = rfx_dyn_run(ctx, &in, P, randomReflection, passesFirstFour, startIteration, endIteration, &out, NULL, 0, &ntr);
@@ -583,6 +633,10 @@ JNIEXPORT jlong JNICALL RFX_CLASS(dynRun)(JNIEnv *env, jclass c, jlong h, jlongA
         int64_t *okb = (int64_t *)malloc((size_t)capK * 8 + 8), *oeb = (int64_t *)malloc((size_t)capE * 8 + 8);
         int64_t *oko = (int64_t *)malloc((size_t)(n + 1) * 8), *oeo = (int64_t *)malloc((size_t)(n + 1) * 8), *oat = (int64_t *)malloc((size_t)(n + 1) * 8);
         int64_t bk = 0, be = 0;
+        if (!okb || !oeb || !oko || !oeo || !oat) st = RFX_E_HOST;
+        if (st == RFX_OK && ((*env)->GetArrayLength(env, outKeyOff) < out_n + 1 || (*env)->GetArrayLength(env, outExtOff) < out_n + 1 ||
+                             (*env)->GetArrayLength(env, outAttr) < out_n))
+            st = RFX_E_CAP;
         for (int64_t i = 0; i < out_n && st == RFX_OK; i++) {
             oko[i] = bk; oeo[i] = be;
             const int nk = rfx_dyn_bases_to_blocks(okey + okoff[i], (int)(okoff[i + 1] - okoff[i]), okb + bk, (int)(capK - bk));

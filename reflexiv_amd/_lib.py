@@ -13,10 +13,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libreflexiv_hip.so")
 _LIB = None
 
-RFX_OK, RFX_E_ARG, RFX_E_CAP, RFX_E_HIP, RFX_E_NOGPU, RFX_E_STATE, RFX_E_LIMIT = 0, -1, -2, -3, -4, -5, -6
+RFX_OK, RFX_E_ARG, RFX_E_CAP, RFX_E_HIP, RFX_E_NOGPU, RFX_E_STATE, RFX_E_LIMIT, RFX_E_HOST = 0, -1, -2, -3, -4, -5, -6, -7
 TWIN_DS, TWIN_RDD = 0, 1
 _STATUS = {0: "RFX_OK", -1: "RFX_E_ARG", -2: "RFX_E_CAP", -3: "RFX_E_HIP", -4: "RFX_E_NOGPU",
-           -5: "RFX_E_STATE", -6: "RFX_E_LIMIT"}
+           -5: "RFX_E_STATE", -6: "RFX_E_LIMIT", -7: "RFX_E_HOST"}
 
 
 class RfxError(RuntimeError):
@@ -50,7 +50,7 @@ class CRecords(C.Structure):
 # every symbol include/reflexiv_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "rfx_version", "rfx_default_params", "rfx_ctx_create", "rfx_ctx_destroy", "rfx_ctx_sync",
-    "rfx_ctx_set_stream", "rfx_ctx_stream", "rfx_last_error",
+    "rfx_ctx_set_stream", "rfx_ctx_stream", "rfx_last_error", "rfx_ctx_trim", "rfx_ctx_workspace_bytes",
     "rfx_extract_canon", "rfx_count_filter", "rfx_rc_expand_subkmer", "rfx_sort_records",
     "rfx_fork_filter_forward", "rfx_reflect_from_forward", "rfx_fork_filter_reflected",
     "rfx_random_reflection", "rfx_extend_pass", "rfx_contigs_text",
@@ -116,8 +116,9 @@ def lib():
             if name == "rfx_dyn_attribute_unpack":
                 fn.restype = None
                 continue
-            if name == "rfx_comm_last_bytes_bucketed":
+            if name in ("rfx_comm_last_bytes_bucketed", "rfx_ctx_workspace_bytes"):
                 fn.restype = C.c_int64
+                fn.argtypes = [C.c_void_p]
                 continue
             if name == "rfx_comm_destroy":
                 fn.restype = None

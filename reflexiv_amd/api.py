@@ -739,6 +739,13 @@ class Reflexiv:
         self.comm_rank, self.comm_world = rank, world
         return h
 
+    def trim(self):
+        """rfx_ctx_trim: the context's grow-only workspaces back to the driver"""
+        self._check(self.L.rfx_ctx_trim(self.ctx), "rfx_ctx_trim")
+
+    def workspace_bytes(self) -> int:
+        return int(self.L.rfx_ctx_workspace_bytes(self.ctx))
+
     def comm_destroy(self):
         if getattr(self, "comm", None):
             self.L.rfx_comm_destroy(self.comm)
@@ -766,22 +773,26 @@ class Reflexiv:
         self._check(st, "rfx_dev_sharded_count")
         return int(n.value), [int(x) for x in tot]
 
-    def sharded_assemble_reads(self, bases, read_off, prm: Params, generations: int = 4):
-        """collective (rfx_sharded_assemble_reads): this rank's ASCII reads -> (text, n_contigs, trace, totals); text on rank 0"""
+    def sharded_assemble_reads(self, bases, read_off, prm: Params, generations: int = 4, text_cap: int = None):
+        """collective (rfx_sharded_assemble_reads): this rank's ASCII reads -> (text, n_contigs, trace, totals); text on rank 0.
+        A text buffer that is too short on rank 0 is RFX_E_CAP on EVERY rank (with the length rank 0 needs), so the retry below
+        re-enters the collective on all ranks together; text_cap forces a first size (tests)."""
         bases = np.ascontiguousarray(bases, np.uint8)
         read_off = np.ascontiguousarray(read_off, np.int64)
         n_reads = len(read_off) - 1
         trace = np.zeros(prm.max_iter + 8, np.int64)
         tot = (C.c_int64 * 3)()
-        cap = 3 * len(bases) + (1 << 20)
+        cap = 3 * len(bases) + (1 << 20) if text_cap is None else int(text_cap)
+        self.text_retries = 0
         while True:
-            buf = np.empty(cap, np.uint8)
+            buf = np.empty(max(cap, 1), np.uint8)
             ln, nc, ntr = C.c_int64(0), C.c_int64(0), C.c_int64(0)
             st = self.L.rfx_sharded_assemble_reads(self.ctx, self.comm, _p(bases), _p(read_off), C.c_int64(n_reads), C.byref(prm),
                                                    generations, _p(buf), C.c_int64(cap), C.byref(ln), C.byref(nc), _p(trace),
                                                    C.c_int64(len(trace)), C.byref(ntr), tot)
             if st == RFX_E_CAP and ln.value > cap:
                 cap = int(ln.value)
+                self.text_retries += 1
                 continue
             self._check(st, "rfx_sharded_assemble_reads")
             return (bytes(buf[:ln.value]).decode(), int(nc.value), [int(x) for x in trace[:ntr.value]], [int(x) for x in tot])

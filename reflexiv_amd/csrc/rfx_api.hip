@@ -213,15 +213,29 @@ struct HostRecords {
 // a piece of a workspace slot (not owned)
 struct DevSpan { void *p = nullptr; template <class T> T *as() const { return (T *)p; } };
 
+// What a C++ exception under an entry point becomes (RFX_API_CATCH, rfx_internal.h).
+int rfx_api_exception(rfx_ctx *ctx, const char *where) noexcept {
+    const char *what = "unknown C++ exception";
+    char buf[400];
+    try { throw; }
+    catch (const std::bad_alloc &) { what = "std::bad_alloc (out of host memory)"; }
+    catch (const std::exception &e) { snprintf(buf, sizeof buf, "%s", e.what()); what = buf; }
+    catch (...) {}
+    if (ctx) {
+        try { ctx->last_error = std::string(where) + ": C++ exception caught at the C ABI: " + what; } catch (...) {}
+    }
+    return RFX_E_HOST;
+}
+
 extern "C" {
 
 int rfx_version(void) { return 100; }
 
-void rfx_default_params(rfx_params *p) {
+void rfx_default_params(rfx_params *p) try {
     p->k = 31; p->min_cov = 2; p->max_cov = 10000000; p->min_error_cov = 8; p->min_contig = 500;
     p->min_iter = 15; p->max_iter = 150; p->front_clip = 0; p->end_clip = 0; p->partitions = 8;
     p->twin = RFX_TWIN_DS; p->coalesce = 0; p->extras = 1;
-}
+} RFX_API_CATCH_VOID(nullptr)
 
 // RFX_BACKTRACE=1 (debugging aid): the native frames of a host crash inside the library on stderr -- offsets into the
 // shared objects, for llvm-symbolizer -- before the signal takes its course
@@ -235,7 +249,7 @@ static void rfx_crash_backtrace(int sig) {
     raise(sig);
 }
 
-int rfx_ctx_create(int device, rfx_ctx **out) {
+int rfx_ctx_create(int device, rfx_ctx **out) try {
     if (!out) return RFX_E_ARG;
     *out = nullptr;
     if (const char *e = getenv("RFX_BACKTRACE")) {
@@ -274,38 +288,59 @@ int rfx_ctx_create(int device, rfx_ctx **out) {
     }
     *out = ctx;
     return RFX_OK;
-}
+} RFX_API_CATCH(nullptr)
 
-void rfx_ctx_destroy(rfx_ctx *ctx) {
+void rfx_ctx_destroy(rfx_ctx *ctx) try {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->ws_free();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
-}
+} RFX_API_CATCH_VOID(ctx)
 
-int rfx_ctx_sync(rfx_ctx *ctx) {
+int rfx_ctx_sync(rfx_ctx *ctx) try {
     if (!ctx) return RFX_E_ARG;
     RFX_TRY(sync_checked(ctx));
     return RFX_OK;
-}
+} RFX_API_CATCH(ctx)
 
-int rfx_ctx_set_stream(rfx_ctx *ctx, void *hip_stream) {
+int rfx_ctx_set_stream(rfx_ctx *ctx, void *hip_stream) try {
     if (!ctx) return RFX_E_ARG;
     if (ctx->own_stream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     ctx->own_stream = false;
     return RFX_OK;
-}
+} RFX_API_CATCH(ctx)
+
+// Hands the context's grow-only workspaces (count-stage record buffers, extend-stage arenas, the staging and packed reads
+// of rfx_assemble_reads, pinned staging) back to the driver; the next call allocates what it needs again.
+int rfx_ctx_trim(rfx_ctx *ctx) try {
+    if (!ctx) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    RFX_TRY(sync_checked(ctx));
+    for (auto &w : ctx->ws) { if (w.p) (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
+    return RFX_OK;
+} RFX_API_CATCH(ctx)
+
+int64_t rfx_ctx_workspace_bytes(rfx_ctx *ctx) try {
+    int64_t t = 0;
+    if (ctx) for (auto &w : ctx->ws) t += (int64_t)w.bytes;
+    return t;
+} RFX_API_CATCH(ctx)
 
 void *rfx_ctx_stream(rfx_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
-const char *rfx_last_error(rfx_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "no context"; }
+const char *rfx_last_error(rfx_ctx *ctx) {
+    if (!ctx) return "no context";
+    if (ctx->foreign_hip_error.empty()) return ctx->last_error.c_str();
+    try { ctx->last_error_text = ctx->last_error + " [after RCCL: " + ctx->foreign_hip_error + "]"; } catch (...) { return ctx->last_error.c_str(); }
+    return ctx->last_error_text.c_str();
+}
 
 // ------------------------------------------------------------- host operators
 
 int rfx_extract_canon(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_off, int64_t n_reads, int k,
-                      int front_clip, int end_clip, uint64_t *out_kmers, int64_t cap, int64_t *out_n) {
+                      int front_clip, int end_clip, uint64_t *out_kmers, int64_t cap, int64_t *out_n) try {
     if (!ctx || !read_off || !out_n || n_reads < 0) return RFX_E_ARG;
     RFX_TRY(check_k(k));
     if (front_clip < 0 || end_clip < 0) return RFX_E_ARG;
@@ -343,10 +378,10 @@ int rfx_extract_canon(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_of
     RFX_HIP(hipMemcpyAsync(out_kmers, d_out.p, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
     RFX_TRY(sync_checked(ctx));
     return RFX_OK;
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_extract_canon_w(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_off, int64_t n_reads, int k,
-                        int front_clip, int end_clip, uint64_t *out_kmers, int64_t cap, int64_t *out_n) {
+                        int front_clip, int end_clip, uint64_t *out_kmers, int64_t cap, int64_t *out_n) try {
     if (!ctx || !read_off || !out_n || n_reads < 0) return RFX_E_ARG;
     RFX_TRY(check_k_w(k));
     if (front_clip < 0 || end_clip < 0) return RFX_E_ARG;
@@ -386,10 +421,10 @@ int rfx_extract_canon_w(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_
     RFX_HIP(hipMemcpyAsync(out_kmers, d_out.p, (size_t)total * W * 8, hipMemcpyDeviceToHost, ctx->stream));
     RFX_TRY(sync_checked(ctx));
     return RFX_OK;
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_count_filter_w(rfx_ctx *ctx, const uint64_t *kmers, int64_t n, int k, int min_cov, int max_cov,
-                       uint64_t *out_keys, int64_t *out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct) {
+                       uint64_t *out_keys, int64_t *out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct) try {
     if (!ctx || n < 0 || !out_n || (n > 0 && !kmers)) return RFX_E_ARG;
     RFX_TRY(check_k_w(k));
     RFX_HIP(hipSetDevice(ctx->device));
@@ -422,16 +457,16 @@ int rfx_count_filter_w(rfx_ctx *ctx, const uint64_t *kmers, int64_t n, int k, in
     }
     RFX_TRY(sync_checked(ctx));
     return RFX_OK;
-}
+} RFX_API_CATCH(ctx)
 
-int64_t rfx_kmers_per_read_w(int read_len, int k, int front_clip, int end_clip) {
+int64_t rfx_kmers_per_read_w(int read_len, int k, int front_clip, int end_clip) try {
     return kmers_per_read_w(read_len, k, front_clip, end_clip);
-}
+} RFX_API_CATCH(nullptr)
 
 int rfx_dev_count_reads_w(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read, int read_len,
                           int k, int front_clip, int end_clip, int min_cov, int max_cov, uint64_t *d_out_keys,
                           int64_t *d_out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct,
-                          int64_t *out_instances) {
+                          int64_t *out_instances) try {
     if (!ctx || !out_n || n_reads < 0 || (n_reads > 0 && !d_words)) return RFX_E_ARG;
     RFX_TRY(check_k_w(k));
     if (front_clip < 0 || end_clip < 0 || words_per_read * 32 < read_len) return RFX_E_ARG;
@@ -475,10 +510,10 @@ int rfx_dev_count_reads_w(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads
     RFX_TRY(sync_checked(ctx));
     ScopedTimer::collect(ctx);
     return st;
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_count_filter(rfx_ctx *ctx, const uint64_t *kmers, int64_t n, int min_cov, int max_cov, int twin,
-                     uint64_t *out_keys, int32_t *out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct) {
+                     uint64_t *out_keys, int32_t *out_counts, int64_t cap, int64_t *out_n, int64_t *out_distinct) try {
     if (!ctx || n < 0 || !out_n || (n > 0 && !kmers)) return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
     *out_n = 0;
@@ -503,10 +538,10 @@ int rfx_count_filter(rfx_ctx *ctx, const uint64_t *kmers, int64_t n, int min_cov
     }
     RFX_TRY(sync_checked(ctx));
     return RFX_OK;
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_rc_expand_subkmer(rfx_ctx *ctx, const uint64_t *kmers, const int32_t *counts, int64_t n, int k,
-                          rfx_records *out) {
+                          rfx_records *out) try {
     if (!ctx || n < 0 || !out) return RFX_E_ARG;
     RFX_TRY(check_k_rec(k));
     RFX_HIP(hipSetDevice(ctx->device));
@@ -521,9 +556,9 @@ int rfx_rc_expand_subkmer(rfx_ctx *ctx, const uint64_t *kmers, const int32_t *co
     DevRecords r;
     RFX_TRY(rc_expand_subkmer(ctx, dk.as<uint64_t>(), dc.as<int32_t>(), n, k, r));
     return download_to(ctx, r, out);
-}
+} RFX_API_CATCH(ctx)
 
-int rfx_sort_records(rfx_ctx *ctx, const rfx_records *in, int P, rfx_records *out, int64_t *part_start) {
+int rfx_sort_records(rfx_ctx *ctx, const rfx_records *in, int P, rfx_records *out, int64_t *part_start) try {
     if (!ctx || !in || !out || P < 1) return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
     DevRecords d, s;
@@ -533,7 +568,7 @@ int rfx_sort_records(rfx_ctx *ctx, const rfx_records *in, int P, rfx_records *ou
     RFX_TRY(sort_records(ctx, d, P, 64, s, ps, 0));
     RFX_TRY(download_to(ctx, s, out));
     return download_part_start(ctx, ps, P, part_start);
-}
+} RFX_API_CATCH(ctx)
 
 static int fork_host(rfx_ctx *ctx, bool reflected, const rfx_records *in, const int64_t *part_start, int P, int k,
                      int min_error_cov, int twin, rfx_records *out, int64_t *out_part_start) {
@@ -551,16 +586,16 @@ static int fork_host(rfx_ctx *ctx, bool reflected, const rfx_records *in, const 
 }
 
 int rfx_fork_filter_forward(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P, int k,
-                            int min_error_cov, int twin, rfx_records *out, int64_t *out_part_start) {
+                            int min_error_cov, int twin, rfx_records *out, int64_t *out_part_start) try {
     return fork_host(ctx, false, in, part_start, P, k, min_error_cov, twin, out, out_part_start);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_fork_filter_reflected(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P, int k,
-                              int min_error_cov, int twin, rfx_records *out, int64_t *out_part_start) {
+                              int min_error_cov, int twin, rfx_records *out, int64_t *out_part_start) try {
     return fork_host(ctx, true, in, part_start, P, k, min_error_cov, twin, out, out_part_start);
-}
+} RFX_API_CATCH(ctx)
 
-int rfx_reflect_from_forward(rfx_ctx *ctx, const rfx_records *in, int k, rfx_records *out) {
+int rfx_reflect_from_forward(rfx_ctx *ctx, const rfx_records *in, int k, rfx_records *out) try {
     if (!ctx || !in || !out) return RFX_E_ARG;
     RFX_TRY(check_k_rec(k));
     RFX_TRY(check_kw(in, k));
@@ -569,10 +604,10 @@ int rfx_reflect_from_forward(rfx_ctx *ctx, const rfx_records *in, int k, rfx_rec
     RFX_TRY(dev_records_upload(ctx, in, d));
     RFX_TRY(reflect_from_forward(ctx, d, k, o));
     return download_to(ctx, o, out);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_random_reflection(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P, int k,
-                          rfx_records *out) {
+                          rfx_records *out) try {
     if (!ctx || !in || !out || !part_start || P < 1) return RFX_E_ARG;
     RFX_TRY(check_k_rec(k));
     RFX_TRY(check_kw(in, k));
@@ -583,7 +618,7 @@ int rfx_random_reflection(rfx_ctx *ctx, const rfx_records *in, const int64_t *pa
     RFX_TRY(upload_part_start(ctx, part_start, P, ps));
     RFX_TRY(random_reflection(ctx, d, ps.as<int64_t>(), P, k, o));
     return download_to(ctx, o, out);
-}
+} RFX_API_CATCH(ctx)
 
 static int extend_host(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P, int k, int twin,
                        int stage, int start_marker, rfx_records *out, int64_t *out_part_start) {
@@ -601,18 +636,18 @@ static int extend_host(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_
 }
 
 int rfx_extend_pass(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P, int k, int twin,
-                    int stage, rfx_records *out, int64_t *out_part_start) {
+                    int stage, rfx_records *out, int64_t *out_part_start) try {
     return extend_host(ctx, in, part_start, P, k, k > 31 ? RFX_TWIN_DS : twin, stage, 2, out, out_part_start);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_extend_pass_w(rfx_ctx *ctx, const rfx_records *in, const int64_t *part_start, int P, int k, int stage,
-                      int scramble, rfx_records *out, int64_t *out_part_start) {
+                      int scramble, rfx_records *out, int64_t *out_part_start) try {
     if (scramble != 2 && scramble != 3) return RFX_E_ARG;
     return extend_host(ctx, in, part_start, P, k, RFX_TWIN_DS, stage, scramble == 3 ? 1 : 2, out, out_part_start);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_extras_operator(rfx_ctx *ctx, int op, const rfx_records *in, const int64_t *part_start, int P, int k,
-                        rfx_records *out, int64_t *out_part_start) {
+                        rfx_records *out, int64_t *out_part_start) try {
     if (!ctx || !in || !out || !part_start || P < 1 || op < 0 || op > 6) return RFX_E_ARG;
     RFX_TRY(check_k_rec(k));
     RFX_TRY(check_kw(in, k));
@@ -624,17 +659,17 @@ int rfx_extras_operator(rfx_ctx *ctx, int op, const rfx_records *in, const int64
     RFX_TRY(extras_operator(ctx, op, d, ps.as<int64_t>(), P, k, o, ops));
     RFX_TRY(download_to(ctx, o, out));
     return download_part_start(ctx, ops, P, out_part_start);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_contigs_text(rfx_ctx *ctx, const rfx_records *in, int k, int min_contig, int twin, char *out, int64_t cap,
-                     int64_t *out_len, int64_t *out_contigs) {
+                     int64_t *out_len, int64_t *out_contigs) try {
     if (!ctx || !in || !out_len) return RFX_E_ARG;
     RFX_TRY(check_k_rec(k));
     RFX_TRY(check_kw(in, k));
     int64_t len = contigs_text_host(in, k, min_contig, twin, out, out ? cap : 0, out_contigs);
     *out_len = len;
     return len > cap ? RFX_E_CAP : RFX_OK;
-}
+} RFX_API_CATCH(ctx)
 
 // ------------------------------------------------------------ record operators on device-resident sets
 
@@ -690,16 +725,16 @@ __global__ void k_lower_bound(const uint64_t *__restrict__ keys, int64_t n, cons
 
 extern "C" {
 
-int rfx_dev_rc_expand_subkmer(rfx_ctx *ctx, const uint64_t *d_kmers, const int32_t *d_counts, int64_t n, int k, rfx_records *d_out) {
+int rfx_dev_rc_expand_subkmer(rfx_ctx *ctx, const uint64_t *d_kmers, const int32_t *d_counts, int64_t n, int k, rfx_records *d_out) try {
     if (!ctx || n < 0 || !d_out) return RFX_E_ARG;
     RFX_TRY(check_k_rec(k));
     RFX_HIP(hipSetDevice(ctx->device));
     DevRecords o;
     RFX_TRY(rc_expand_subkmer(ctx, d_kmers, d_counts, n, k, o));
     return copy_out_dev(ctx, o, d_out);
-}
+} RFX_API_CATCH(ctx)
 
-int rfx_dev_sort_records(rfx_ctx *ctx, const rfx_records *d_in, int P, int k, rfx_records *d_out, int64_t *d_part_start) {
+int rfx_dev_sort_records(rfx_ctx *ctx, const rfx_records *d_in, int P, int k, rfx_records *d_out, int64_t *d_part_start) try {
     if (!ctx || !d_in || !d_out || P < 1) return RFX_E_ARG;
     RFX_TRY(check_k_rec(k));
     RFX_TRY(check_kw(d_in, k));
@@ -710,10 +745,10 @@ int rfx_dev_sort_records(rfx_ctx *ctx, const rfx_records *d_in, int P, int k, rf
     RFX_TRY(sort_records(ctx, in, P, 2 * (k - 1), o, ps, k));
     RFX_TRY(copy_out_dev(ctx, o, d_out));
     return copy_ps_dev(ctx, ps, P, d_part_start);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_fork_filter(rfx_ctx *ctx, int reflected, const rfx_records *d_in, const int64_t *d_part_start, int P, int k,
-                        int min_error_cov, int twin, rfx_records *d_out, int64_t *d_out_part_start) {
+                        int min_error_cov, int twin, rfx_records *d_out, int64_t *d_out_part_start) try {
     if (!ctx || !d_in || !d_out || !d_part_start || P < 1) return RFX_E_ARG;
     RFX_TRY(check_k_rec(k));
     RFX_TRY(check_kw(d_in, k));
@@ -724,9 +759,9 @@ int rfx_dev_fork_filter(rfx_ctx *ctx, int reflected, const rfx_records *d_in, co
     RFX_TRY(fork_filter(ctx, reflected != 0, in, d_part_start, P, k, min_error_cov, twin, o, ops));
     RFX_TRY(copy_out_dev(ctx, o, d_out));
     return copy_ps_dev(ctx, ops, P, d_out_part_start);
-}
+} RFX_API_CATCH(ctx)
 
-int rfx_dev_reflect_from_forward(rfx_ctx *ctx, const rfx_records *d_in, int k, rfx_records *d_out) {
+int rfx_dev_reflect_from_forward(rfx_ctx *ctx, const rfx_records *d_in, int k, rfx_records *d_out) try {
     if (!ctx || !d_in || !d_out) return RFX_E_ARG;
     RFX_TRY(check_k_rec(k));
     RFX_TRY(check_kw(d_in, k));
@@ -735,9 +770,9 @@ int rfx_dev_reflect_from_forward(rfx_ctx *ctx, const rfx_records *d_in, int k, r
     wrap_dev(ctx, d_in, in);
     RFX_TRY(reflect_from_forward(ctx, in, k, o));
     return copy_out_dev(ctx, o, d_out);
-}
+} RFX_API_CATCH(ctx)
 
-int rfx_dev_random_reflection(rfx_ctx *ctx, const rfx_records *d_in, const int64_t *d_part_start, int P, int k, rfx_records *d_out) {
+int rfx_dev_random_reflection(rfx_ctx *ctx, const rfx_records *d_in, const int64_t *d_part_start, int P, int k, rfx_records *d_out) try {
     if (!ctx || !d_in || !d_out || !d_part_start || P < 1) return RFX_E_ARG;
     RFX_TRY(check_k_rec(k));
     RFX_TRY(check_kw(d_in, k));
@@ -746,10 +781,10 @@ int rfx_dev_random_reflection(rfx_ctx *ctx, const rfx_records *d_in, const int64
     wrap_dev(ctx, d_in, in);
     RFX_TRY(random_reflection(ctx, in, d_part_start, P, k, o));
     return copy_out_dev(ctx, o, d_out);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_extend_pass(rfx_ctx *ctx, const rfx_records *d_in, const int64_t *d_part_start, int P, int k, int twin, int stage,
-                        int scramble, rfx_records *d_out, int64_t *d_out_part_start) {
+                        int scramble, rfx_records *d_out, int64_t *d_out_part_start) try {
     if (!ctx || !d_in || !d_out || !d_part_start || P < 1 || stage < 0 || stage > 2 || (scramble != 2 && scramble != 3)) return RFX_E_ARG;
     RFX_TRY(check_k_rec(k));
     RFX_TRY(check_kw(d_in, k));
@@ -760,10 +795,10 @@ int rfx_dev_extend_pass(rfx_ctx *ctx, const rfx_records *d_in, const int64_t *d_
     RFX_TRY(extend_pass(ctx, in, d_part_start, P, k, k > 31 ? RFX_TWIN_DS : twin, stage, o, ops, scramble == 3 ? 1 : 2));
     RFX_TRY(copy_out_dev(ctx, o, d_out));
     return copy_ps_dev(ctx, ops, P, d_out_part_start);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_lower_bound(rfx_ctx *ctx, const uint64_t *d_sorted_keys, int64_t n, const uint64_t *d_values, int64_t m, int upper,
-                        int64_t *d_out) {
+                        int64_t *d_out) try {
     if (!ctx || n < 0 || m < 0 || (m > 0 && (!d_values || !d_out)) || (n > 0 && !d_sorted_keys)) return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
     if (m == 0) return RFX_OK;
@@ -771,29 +806,29 @@ int rfx_dev_lower_bound(rfx_ctx *ctx, const uint64_t *d_sorted_keys, int64_t n, 
     RFX_HIP(hipGetLastError());
     RFX_TRY(sync_checked(ctx));
     return RFX_OK;
-}
+} RFX_API_CATCH(ctx)
 
 }  // extern "C"
 
 // ------------------------------------------------------------ device pipeline
 
 int rfx_dev_encode_reads(rfx_ctx *ctx, const uint8_t *d_bases, const int64_t *d_read_off, int64_t n_reads,
-                         int words_per_read, uint64_t *d_words, uint32_t *d_read_len) {
+                         int words_per_read, uint64_t *d_words, uint32_t *d_read_len) try {
     if (!ctx || n_reads < 0 || words_per_read < 1) return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
     return encode_reads(ctx, d_bases, d_read_off, n_reads, words_per_read, d_words, d_read_len);
-}
+} RFX_API_CATCH(ctx)
 
-int64_t rfx_kmers_per_read(int read_len, int k, int front_clip, int end_clip) {
+int64_t rfx_kmers_per_read(int read_len, int k, int front_clip, int end_clip) try {
     return kmers_per_read(read_len, k, front_clip, end_clip);
-}
+} RFX_API_CATCH(nullptr)
 
 int64_t rfx_count_workspace_bytes(int64_t n_kmers) { return count_workspace_bytes(n_kmers); }
 
 int rfx_dev_count_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read, int read_len,
                         int k, int front_clip, int end_clip, int min_cov, int max_cov, int twin,
                         void *d_workspace, int64_t workspace_bytes, uint64_t *d_out_keys, int32_t *d_out_counts,
-                        int64_t cap, int64_t *out_n, int64_t *out_distinct, int64_t *out_instances) {
+                        int64_t cap, int64_t *out_n, int64_t *out_distinct, int64_t *out_instances) try {
     if (!ctx || !d_words || n_reads < 0 || words_per_read * 32 < read_len) return RFX_E_ARG;
     RFX_TRY(check_k(k));
     RFX_HIP(hipSetDevice(ctx->device));
@@ -801,12 +836,12 @@ int rfx_dev_count_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, 
     if (out_instances) *out_instances = kmers_per_read(read_len, k, front_clip, end_clip) * n_reads;
     return count_filter(ctx, &rs, nullptr, 0, min_cov, max_cov, twin, d_workspace, workspace_bytes, d_out_keys,
                         d_out_counts, cap, out_n, out_distinct);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_count_reads_ragged(rfx_ctx *ctx, const uint64_t *d_words, const uint32_t *d_read_len, int64_t n_reads,
                                int words_per_read, int max_read_len, int k, int front_clip, int end_clip, int min_cov,
                                int max_cov, int twin, uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap,
-                               int64_t *out_n, int64_t *out_distinct, int64_t *out_instances) {
+                               int64_t *out_n, int64_t *out_distinct, int64_t *out_instances) try {
     if (!ctx || !d_words || !d_read_len || n_reads < 0 || words_per_read * 32 < max_read_len) return RFX_E_ARG;
     RFX_TRY(check_k(k));
     RFX_HIP(hipSetDevice(ctx->device));
@@ -816,11 +851,11 @@ int rfx_dev_count_reads_ragged(rfx_ctx *ctx, const uint64_t *d_words, const uint
     if (out_instances) *out_instances = rs.n_instances;
     return count_filter(ctx, &rs, nullptr, 0, min_cov, max_cov, twin, nullptr, 0, d_out_keys, d_out_counts, cap, out_n,
                         out_distinct);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_bucket_wide_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read, int read_len,
                                  int k, int front_clip, int end_clip, int n_owners, void *d_out_elems, int64_t cap_elems,
-                                 int64_t *d_owner_off, int64_t *h_owner_off) {
+                                 int64_t *d_owner_off, int64_t *h_owner_off) try {
     if (!ctx || !d_words || !d_owner_off || n_reads < 0 || words_per_read * 32 < read_len) return RFX_E_ARG;
     RFX_TRY(check_k_w(k));
     if (!wide_fast_path(k) || front_clip < 0 || end_clip < 0) return RFX_E_ARG;      // two-word k-mers only
@@ -828,12 +863,12 @@ int rfx_dev_bucket_wide_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t 
     const int64_t nk = kmers_per_read_w(read_len, k, front_clip, end_clip);
     return bucket_wide_by_owner(ctx, d_words, n_reads, words_per_read, nk, k, front_clip, n_owners, d_out_elems, cap_elems,
                                 d_owner_off, h_owner_off);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_bucket_wide_records_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read,
                                          int read_len, int k, int front_clip, int end_clip, int n_owners,
                                          void *d_out_records, int64_t cap_records, int64_t *d_owner_off,
-                                         int64_t *h_owner_off, int64_t *out_n_records) {
+                                         int64_t *h_owner_off, int64_t *out_n_records) try {
     if (!ctx || !d_words || !d_owner_off || n_reads < 0 || words_per_read * 32 < read_len) return RFX_E_ARG;
     RFX_TRY(check_k_w(k));
     if (!wide_fast_path(k) || front_clip < 0 || end_clip < 0) return RFX_E_ARG;      // two-word k-mers only
@@ -844,11 +879,11 @@ int rfx_dev_bucket_wide_records_by_owner(rfx_ctx *ctx, const uint64_t *d_words, 
                                                 d_out_records, cap_records, d_owner_off, h_owner_off, out_n_records);
     if (h_owner_off) ScopedTimer::collect(ctx);
     return st;
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_count_wide_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_t n_instances_hint, int k,
                                int min_cov, int max_cov, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap,
-                               int64_t *out_n, int64_t *out_distinct) {
+                               int64_t *out_n, int64_t *out_distinct) try {
     if (!ctx || !out_n || n_records < 0 || (n_records > 0 && !d_records)) return RFX_E_ARG;
     RFX_TRY(check_k_w(k));
     if (!wide_fast_path(k)) return RFX_E_ARG;
@@ -862,11 +897,11 @@ int rfx_dev_count_wide_records(rfx_ctx *ctx, const void *d_records, int64_t n_re
     RFX_TRY(sync_checked(ctx));
     ScopedTimer::collect(ctx);
     return st;
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_count_wide_elems(rfx_ctx *ctx, const void *d_elems, int64_t n_elems, int k, int min_cov, int max_cov,
                              uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n,
-                             int64_t *out_distinct) {
+                             int64_t *out_distinct) try {
     if (!ctx || !out_n || n_elems < 0 || (n_elems > 0 && !d_elems)) return RFX_E_ARG;
     RFX_TRY(check_k_w(k));
     if (!wide_fast_path(k)) return RFX_E_ARG;
@@ -877,31 +912,31 @@ int rfx_dev_count_wide_elems(rfx_ctx *ctx, const void *d_elems, int64_t n_elems,
     RFX_TRY(sync_checked(ctx));
     ScopedTimer::collect(ctx);
     return st;
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_count_kmers(rfx_ctx *ctx, const uint64_t *d_kmers, int64_t n, int min_cov, int max_cov, int twin,
                         void *d_workspace, int64_t workspace_bytes, uint64_t *d_out_keys, int32_t *d_out_counts,
-                        int64_t cap, int64_t *out_n, int64_t *out_distinct) {
+                        int64_t cap, int64_t *out_n, int64_t *out_distinct) try {
     if (!ctx || n < 0) return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
     return count_filter(ctx, nullptr, d_kmers, n, min_cov, max_cov, twin, d_workspace, workspace_bytes, d_out_keys,
                         d_out_counts, cap, out_n, out_distinct);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_bucket_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read,
                             int read_len, int k, int front_clip, int end_clip, int n_owners, uint64_t *d_out,
-                            int64_t cap, int64_t *d_owner_off, int64_t *h_owner_off) {
+                            int64_t cap, int64_t *d_owner_off, int64_t *h_owner_off) try {
     if (!ctx || !d_words || !d_owner_off) return RFX_E_ARG;
     RFX_TRY(check_k(k));
     RFX_HIP(hipSetDevice(ctx->device));
     ReadStore rs{d_words, n_reads, words_per_read, read_len, k, front_clip, end_clip};
     return bucket_by_owner(ctx, &rs, n_owners, d_out, cap, d_owner_off, h_owner_off);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_bucket_records_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read,
                                     int read_len, int k, int front_clip, int end_clip, int n_owners,
                                     void *d_out_records, int64_t cap_records, int64_t *d_owner_off,
-                                    int64_t *h_owner_off, int64_t *out_n_records) {
+                                    int64_t *h_owner_off, int64_t *out_n_records) try {
     if (!ctx || !d_words || !d_owner_off) return RFX_E_ARG;
     RFX_TRY(check_k(k));
     RFX_HIP(hipSetDevice(ctx->device));
@@ -911,22 +946,22 @@ int rfx_dev_bucket_records_by_owner(rfx_ctx *ctx, const uint64_t *d_words, int64
                                            out_n_records);
     if (h_owner_off) ScopedTimer::collect(ctx);        // (the call has synchronised)
     return st;
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_count_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, int64_t n_instances_hint, int k,
                           int min_cov, int max_cov, int twin, uint64_t *d_out_keys, int32_t *d_out_counts,
-                          int64_t cap, int64_t *out_n, int64_t *out_distinct) {
+                          int64_t cap, int64_t *out_n, int64_t *out_distinct) try {
     if (!ctx || n_records < 0) return RFX_E_ARG;
     RFX_TRY(check_k(k));
     RFX_HIP(hipSetDevice(ctx->device));
     return count_records(ctx, d_records, n_records, n_instances_hint, k, min_cov, max_cov, twin, d_out_keys,
                          d_out_counts, cap, out_n, out_distinct);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_combine_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads, int words_per_read, int read_len,
                           int k, int front_clip, int end_clip, int n_owners, void *d_scratch_pairs, void *d_out_pairs,
                           int64_t cap_pairs, int64_t *d_owner_off, int64_t *h_owner_off, int64_t *out_n,
-                          int64_t *out_instances) {
+                          int64_t *out_instances) try {
     if (!ctx || !d_words || !d_owner_off || n_reads < 0 || words_per_read * 32 < read_len || cap_pairs < 0) return RFX_E_ARG;
     if (n_owners < 1 || n_owners > 64) return RFX_E_ARG;
     RFX_TRY(check_k(k));
@@ -945,56 +980,56 @@ int rfx_dev_combine_reads(rfx_ctx *ctx, const uint64_t *d_words, int64_t n_reads
     if (st != RFX_OK) return st;
     if (out_n) *out_n = (h_owner_off ? h_owner_off : h_local)[n_owners];
     return RFX_OK;
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_bucket_pairs_by_owner(rfx_ctx *ctx, const void *d_pairs, int64_t n_pairs, int n_owners, void *d_out_pairs,
-                                  int64_t *d_owner_off, int64_t *h_owner_off) {
+                                  int64_t *d_owner_off, int64_t *h_owner_off) try {
     if (!ctx || !d_owner_off || n_pairs < 0 || (n_pairs > 0 && (!d_pairs || !d_out_pairs))) return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
     ctx->timing.clear();
     return bucket_pairs_by_owner(ctx, d_pairs, n_pairs, n_owners, d_out_pairs, d_owner_off, h_owner_off);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_merge_pairs(rfx_ctx *ctx, const void *d_pairs, int64_t n_pairs, int k, int min_cov, int max_cov, int twin,
                         uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n,
-                        int64_t *out_distinct) {
+                        int64_t *out_distinct) try {
     if (!ctx || n_pairs < 0) return RFX_E_ARG;
     RFX_TRY(check_k(k));
     RFX_HIP(hipSetDevice(ctx->device));
     return merge_pairs(ctx, d_pairs, n_pairs, k, min_cov, max_cov, twin, d_out_keys, d_out_counts, cap, out_n, out_distinct);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int key_bits,
-                       uint64_t *d_tmp_keys, uint32_t *d_tmp_vals) {
+                       uint64_t *d_tmp_keys, uint32_t *d_tmp_vals) try {
     if (!ctx || n < 0) return RFX_E_ARG;
     if (n > (int64_t)0xFFFFFFFFLL) return RFX_E_LIMIT;
     RFX_HIP(hipSetDevice(ctx->device));
     return sort_pairs(ctx, d_keys, d_vals, n, key_bits, d_tmp_keys, d_tmp_vals);
-}
+} RFX_API_CATCH(ctx)
 
-int rfx_dev_synth_genome(rfx_ctx *ctx, uint64_t seed, int64_t genome_len, uint64_t *d_genome) {
+int rfx_dev_synth_genome(rfx_ctx *ctx, uint64_t seed, int64_t genome_len, uint64_t *d_genome) try {
     if (!ctx || !d_genome) return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
     return synth_genome(ctx, seed, genome_len, d_genome);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_synth_reads(rfx_ctx *ctx, uint64_t seed, const uint64_t *d_genome, int64_t genome_len,
                         int64_t first_read, int64_t n_reads, int read_len, uint32_t err_per_2_32,
-                        int words_per_read, uint64_t *d_words) {
+                        int words_per_read, uint64_t *d_words) try {
     if (!ctx || !d_genome || !d_words) return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
     return synth_reads(ctx, seed, d_genome, genome_len, first_read, n_reads, read_len, err_per_2_32,
                        words_per_read, d_words);
-}
+} RFX_API_CATCH(ctx)
 
-int rfx_last_count_timing(rfx_ctx *ctx, const char *name, float *ms, int64_t *launches) {
+int rfx_last_count_timing(rfx_ctx *ctx, const char *name, float *ms, int64_t *launches) try {
     if (!ctx || !name) return RFX_E_ARG;
     auto it = ctx->timing.find(name);
     if (it == ctx->timing.end()) { if (ms) *ms = 0.f; if (launches) *launches = 0; return RFX_E_ARG; }
     if (ms) *ms = it->second.ms;
     if (launches) *launches = it->second.launches;
     return RFX_OK;
-}
+} RFX_API_CATCH(ctx)
 
 // Driver: P/ReflexivMain.java:168-310 (DS P/ReflexivDSMain.java:221-352); wide = the k > 31 driver
 // ReflexivDSMain64.assemblyFromKmer (P/ReflexivDSMain64.java:374-826) without the extras of :584-619 and :672-712
@@ -1265,19 +1300,19 @@ static int assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const 
 
 int rfx_dev_assemble(rfx_ctx *ctx, const uint64_t *d_keys, const int32_t *d_counts, int64_t n,
                      const rfx_params *prm, char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs,
-                     int64_t *trace, int64_t trace_cap, int64_t *n_trace) {
+                     int64_t *trace, int64_t trace_cap, int64_t *n_trace) try {
     return assemble_impl(ctx, false, d_keys, d_counts, n, prm, out, cap, out_len, out_contigs, trace, trace_cap, n_trace);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_assemble_w(rfx_ctx *ctx, const uint64_t *d_kmers, const int32_t *d_counts, int64_t n,
                        const rfx_params *prm, char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs,
-                       int64_t *trace, int64_t trace_cap, int64_t *n_trace) {
+                       int64_t *trace, int64_t trace_cap, int64_t *n_trace) try {
     return assemble_impl(ctx, true, d_kmers, d_counts, n, prm, out, cap, out_len, out_contigs, trace, trace_cap, n_trace);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_assemble_counts_w(rfx_ctx *ctx, const uint64_t *kmers, const int32_t *counts, int64_t n, const rfx_params *prm,
                           char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs, int64_t *trace, int64_t trace_cap,
-                          int64_t *n_trace) {
+                          int64_t *n_trace) try {
     if (!ctx || !prm || !out_len || n < 0 || (n > 0 && (!kmers || !counts))) return RFX_E_ARG;
     RFX_TRY(check_k_rec(prm->k));
     if (prm->k <= 31) return RFX_E_ARG;
@@ -1292,28 +1327,28 @@ int rfx_assemble_counts_w(rfx_ctx *ctx, const uint64_t *kmers, const int32_t *co
         RFX_TRY(sync_checked(ctx));
     }
     return assemble_impl(ctx, true, dk.as<uint64_t>(), dc.as<int32_t>(), n, prm, out, cap, out_len, out_contigs, trace, trace_cap, n_trace);
-}
+} RFX_API_CATCH(ctx)
 
-int rfx_dev_order_kmers_w(rfx_ctx *ctx, uint64_t *d_keys, int64_t *d_counts, int64_t n, int k) {
+int rfx_dev_order_kmers_w(rfx_ctx *ctx, uint64_t *d_keys, int64_t *d_counts, int64_t n, int k) try {
     if (!ctx || n < 0 || (n > 0 && (!d_keys || !d_counts))) return RFX_E_ARG;
     RFX_TRY(check_k_w(k));
     if (!wide_fast_path(k)) return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
     return order_wide2(ctx, d_keys, d_counts, n, k);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dev_counter_to_asm(rfx_ctx *ctx, const uint64_t *d_keys32, const int64_t *d_counts64, int64_t n, int k,
-                           int min_cov, int max_cov, uint64_t *d_out_kmers, int32_t *d_out_counts, int64_t *out_n) {
+                           int min_cov, int max_cov, uint64_t *d_out_kmers, int32_t *d_out_counts, int64_t *out_n) try {
     if (!ctx || n < 0 || !out_n || (n > 0 && (!d_keys32 || !d_counts64 || !d_out_kmers || !d_out_counts))) return RFX_E_ARG;
     RFX_TRY(check_k_w(k));
     RFX_TRY(check_k_rec(k));
     RFX_HIP(hipSetDevice(ctx->device));
     return counter_to_asm(ctx, d_keys32, d_counts64, n, k, min_cov, max_cov, d_out_kmers, d_out_counts, out_n);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_assemble_reads(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_off, int64_t n_reads,
                        const rfx_params *prm, char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs,
-                       int64_t *trace, int64_t trace_cap, int64_t *n_trace, int64_t *out_kept) {
+                       int64_t *trace, int64_t trace_cap, int64_t *n_trace, int64_t *out_kept) try {
     if (!ctx || !read_off || !prm || !out_len || n_reads < 0) return RFX_E_ARG;
     RFX_TRY(check_k(prm->k));
     RFX_HIP(hipSetDevice(ctx->device));
@@ -1331,10 +1366,23 @@ int rfx_assemble_reads(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_o
     // up in chunks of whole reads on a second stream, queued FIRST; while they travel the host scans the read lengths (the
     // width of the packed layout), and every chunk is 2-bit encoded on the context's stream as soon as it has landed.  The
     // offsets go up as they are: k_encode reads bases[read_off[r] + i], the device copy is addressed from read_off[0].
-    hipStream_t cs = nullptr;
-    std::vector<hipEvent_t> evs;
+    // (the copy stream is DRAINED before it is destroyed on every way out, exceptions included: copies out of the caller's
+    // `bases` may still be in flight when an error turns up)
+    struct Upload {
+        hipStream_t cs = nullptr;
+        std::vector<hipEvent_t> evs;
+        hipEvent_t ready = nullptr;
+        ~Upload() {
+            if (cs) (void)hipStreamSynchronize(cs);
+            for (auto e : evs) (void)hipEventDestroy(e);
+            if (ready) (void)hipEventDestroy(ready);
+            if (cs) (void)hipStreamDestroy(cs);
+        }
+    } up;
+    hipStream_t &cs = up.cs;
+    std::vector<hipEvent_t> &evs = up.evs;
     std::vector<int64_t> cuts(1, 0);
-    hipEvent_t ready = nullptr;                            // the allocations above are stream-ordered on the context's stream
+    hipEvent_t &ready = up.ready;                          // the allocations above are stream-ordered on the context's stream
     hipError_t err = hipSuccess;
     if (n_reads > 0) {
         err = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
@@ -1380,12 +1428,18 @@ int rfx_assemble_reads(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_o
         if (err == hipSuccess)
             st_enc = encode_reads(ctx, dev_base, d_off.as<int64_t>() + r0, r1 - r0, wpr, d_words.as<uint64_t>() + r0 * wpr, d_len.as<uint32_t>() + r0);
     }
-    if (cs) { if (err == hipSuccess) err = hipStreamSynchronize(cs); }
-    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
-    for (auto e : evs) (void)hipEventDestroy(e);
-    if (ready) (void)hipEventDestroy(ready);
-    if (cs) (void)hipStreamDestroy(cs);
+    if (cs) { const hipError_t e2 = hipStreamSynchronize(cs); if (err == hipSuccess) err = e2; }
+    { const hipError_t e2 = hipStreamSynchronize(ctx->stream); if (err == hipSuccess) err = e2; }
     if (err != hipSuccess) { ctx->last_error = std::string("rfx_assemble_reads upload: ") + hipGetErrorString(err); return RFX_E_HIP; }
+    // the ASCII staging is dead weight from here on (the packed reads are a quarter of it): a large one goes back to the
+    // driver now, so that the count and extend stages of a capacity-stress run have the HBM; up to RFX_KEEP_STAGING_BYTES
+    // (default 8 GiB: config 2's 5 GB stays, and with it the 100-600 ms a fresh allocation of that size costs per call) it
+    // is kept for the next call.  rfx_ctx_trim() releases everything at any time.
+    {
+        const char *e = getenv("RFX_KEEP_STAGING_BYTES");
+        const size_t keep = e ? (size_t)atoll(e) : (size_t)8 << 30;
+        if (ctx->ws[5].bytes > keep) { (void)hipFree(ctx->ws[5].p); ctx->ws[5].p = nullptr; ctx->ws[5].bytes = 0; d_bases.p = nullptr; }
+    }
     RFX_TRY(st_enc);
     ReadStore rs{d_words.as<uint64_t>(), n_reads, wpr, (int)maxlen, prm->k, prm->front_clip, prm->end_clip};
     const double t_up = now_ms();
@@ -1412,6 +1466,6 @@ int rfx_assemble_reads(rfx_ctx *ctx, const uint8_t *bases, const int64_t *read_o
     if (verbose) fprintf(stderr, "assemble_reads: count %.1f ms\n", now_ms() - t_up);
     return rfx_dev_assemble(ctx, d_keys.as<uint64_t>(), d_counts.as<int32_t>(), m, prm, out, cap, out_len, out_contigs, trace,
                             trace_cap, n_trace);
-}
+} RFX_API_CATCH(ctx)
 
 }  // extern "C"

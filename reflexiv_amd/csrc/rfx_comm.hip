@@ -105,6 +105,26 @@ struct rfx_comm {
         }                                                                                                  \
     } while (0)
 
+// An open ncclGroupStart is closed on every way out (an RFX_NCCL return from inside a group used to leave the communicator
+// in group state).
+struct GroupGuard {
+    bool open = false;
+    ~GroupGuard() { if (open && nccl().GroupEnd) (void)nccl().GroupEnd(); }
+};
+
+// The HIP "last error" of this thread after RCCL has run its own runtime calls on it (stream / event queries, pointer
+// attribute probes): hipGetLastError is thread-local, every HIP call of THIS library is checked where it is made and RCCL
+// reports its own failures through ncclResult_t, so what is found here was raised and handled inside RCCL.  It must not
+// reach the kernels' launch checks (hipGetLastError after a launch); it is read, and anything but the two codes RCCL's
+// polling leaves behind is kept for rfx_last_error() ("[after RCCL: ...]") instead of being thrown away unread.
+static void note_foreign_hip_error(rfx_ctx *ctx, const char *where) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess || e == hipErrorNotReady || e == hipErrorPeerAccessAlreadyEnabled) return;
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
+    ctx->foreign_hip_error = buf;
+}
+
 // tuning / test knobs, read at every collective call (so that one communicator serves every case of a test run: RCCL does
 // not take kindly to many communicators made and destroyed in one process)
 static void comm_options(rfx_comm *c) {
@@ -127,7 +147,7 @@ static int grow(rfx_ctx *ctx, void **p, size_t *have, size_t want, hipStream_t s
 
 extern "C" {
 
-int rfx_comm_unique_id(uint8_t *id128) {
+int rfx_comm_unique_id(uint8_t *id128) try {
     if (!id128) return RFX_E_ARG;
     NcclApi &n = nccl();
     if (!n.error.empty() || !n.GetUniqueId) return RFX_E_NOGPU;
@@ -136,9 +156,9 @@ int rfx_comm_unique_id(uint8_t *id128) {
     static_assert(sizeof id == 128, "ncclUniqueId is 128 bytes");
     memcpy(id128, &id, 128);
     return RFX_OK;
-}
+} RFX_API_CATCH(nullptr)
 
-int rfx_comm_init(rfx_ctx *ctx, const uint8_t *id128, int rank, int world, rfx_comm **out) {
+int rfx_comm_init(rfx_ctx *ctx, const uint8_t *id128, int rank, int world, rfx_comm **out) try {
     if (!ctx || !id128 || !out || world < 1 || world > 64 || rank < 0 || rank >= world) return RFX_E_ARG;
     NcclApi &n = nccl();
     if (!n.error.empty()) { ctx->last_error = n.error; return RFX_E_NOGPU; }
@@ -162,9 +182,9 @@ int rfx_comm_init(rfx_ctx *ctx, const uint8_t *id128, int rank, int world, rfx_c
     if (e != hipSuccess) { ctx->last_error = std::string("rfx_comm_init: ") + hipGetErrorString(e); rfx_comm_destroy(c); return RFX_E_HIP; }
     *out = c;
     return RFX_OK;
-}
+} RFX_API_CATCH(ctx)
 
-void rfx_comm_destroy(rfx_comm *c) {
+void rfx_comm_destroy(rfx_comm *c) try {
     if (!c) return;
     if (c->xs) (void)hipStreamSynchronize(c->xs);
     if (c->comm && nccl().CommDestroy) (void)nccl().CommDestroy(c->comm);
@@ -176,14 +196,14 @@ void rfx_comm_destroy(rfx_comm *c) {
     if (c->h_tab) (void)hipHostFree(c->h_tab);
     if (c->xs) (void)hipStreamDestroy(c->xs);
     delete c;
-}
+} RFX_API_CATCH_VOID((c ? c->ctx : nullptr))
 
 int rfx_comm_rank(const rfx_comm *c) { return c ? c->rank : -1; }
 int rfx_comm_world(const rfx_comm *c) { return c ? c->world : 0; }
 int64_t rfx_comm_last_bytes_bucketed(const rfx_comm *c) { return c ? c->bytes_bucketed : 0; }
 
 // sum (op 0) or max (op 1) of n <= 8 host int64 over the ranks, in place (the stop rule's count(), totals, barriers)
-int rfx_comm_all_reduce_i64(rfx_comm *c, int64_t *h_vals, int n, int op) {
+int rfx_comm_all_reduce_i64(rfx_comm *c, int64_t *h_vals, int n, int op) try {
     if (!c || !h_vals || n < 1 || n > 8 || (op != 0 && op != 1)) return RFX_E_ARG;
     rfx_ctx *ctx = c->ctx;
     RFX_HIP(hipSetDevice(ctx->device));
@@ -193,10 +213,10 @@ int rfx_comm_all_reduce_i64(rfx_comm *c, int64_t *h_vals, int n, int op) {
     RFX_NCCL(nccl().AllReduce(d, d + 8, (size_t)n, ncclInt64, op == 0 ? ncclSum : ncclMax, c->comm, c->xs));
     RFX_HIP(hipMemcpyAsync(h + 8, d + 8, (size_t)n * 8, hipMemcpyDeviceToHost, c->xs));
     RFX_HIP(hipStreamSynchronize(c->xs));
-    (void)hipGetLastError();
+    note_foreign_hip_error(ctx, "rfx_comm_all_reduce_i64");
     for (int i = 0; i < n; i++) h_vals[i] = h[8 + i];
     return RFX_OK;
-}
+} RFX_API_CATCH((c ? c->ctx : nullptr))
 
 // One all-to-all(v) of 8-byte words, queued on the exchange stream: this rank sends send_cnt[p] words from
 // d_send + send_off[p] to peer p and receives recv_cnt[p] words from peer p at d_recv + recv_off[p].
@@ -218,7 +238,9 @@ static int alltoallv_words(rfx_comm *c, const uint64_t *d_send, const int64_t *s
         for (int i = 0; i < c->world * S && !any; i++)
             if ((i / S != me || c->self_via_rccl) && (send_cnt[i] > j * limit || recv_cnt[i] > j * limit)) any = true;
         if (!any) continue;               // (every rank skips the same rounds only when nobody has data left in them: `rounds` is global)
+        GroupGuard gg;
         RFX_NCCL(n.GroupStart());
+        gg.open = true;
         for (int p = 0; p < c->world; p++) {
             if (p == me && !c->self_via_rccl) continue;
             for (int q = 0; q < S; q++) {
@@ -229,6 +251,7 @@ static int alltoallv_words(rfx_comm *c, const uint64_t *d_send, const int64_t *s
                 if (r > 0) RFX_NCCL(n.Recv(d_recv + recv_off[i] + j * limit, (size_t)r, ncclUint64, p, c->comm, c->xs));
             }
         }
+        gg.open = false;
         RFX_NCCL(n.GroupEnd());
     }
     return RFX_OK;
@@ -241,7 +264,7 @@ static void add_timing(std::map<std::string, rfx_timing_slot> &acc, const std::m
 int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, const uint32_t *d_read_len, int64_t n_reads,
                           int words_per_read, int read_len, int k, int front_clip, int end_clip, int generations, int min_cov,
                           int max_cov, int twin, uint64_t *d_out_keys, void *d_out_counts, int64_t cap, int64_t *out_n,
-                          int64_t *out_totals) {
+                          int64_t *out_totals) try {
     if (!ctx || !c || c->ctx != ctx || !d_words || n_reads < 0 || cap < 0 || generations < 1 || words_per_read * 32 < read_len)
         return RFX_E_ARG;
     comm_options(c);
@@ -270,61 +293,94 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
         c->ev.push_back(e);
     }
 
-    // 1. records of this rank's reads, grouped by (generation, owner)
+    // 1. records of this rank's reads, grouped by (generation, owner).  A failure HERE is this rank's alone (a bucket that
+    // ran out of room three times, an allocation, a kernel): it is carried into the count matrix below, so that every
+    // rank leaves the call together instead of the peers waiting in ncclAllGather for a rank that has gone.
     const int64_t nk = wide ? rfx::kmers_per_read_w(read_len, k, front_clip, end_clip) : rfx::kmers_per_read(read_len, k, front_clip, end_clip);
     int64_t inst = nk * n_reads;
     rfx::ReadStore rs{d_words, n_reads, words_per_read, read_len, k, front_clip, end_clip};
-    if (d_read_len) {
-        rs.read_len_arr = d_read_len;
-        RFX_TRY(rfx::ragged_instances(ctx, d_read_len, n_reads, k, front_clip, end_clip, &rs.n_instances));
-        inst = rs.n_instances;
-    }
-    if (c->units_per_read <= 0) c->units_per_read = (double)nk / 5.0 + 1.0;
-    // the send buffer's layout: bin b = records [pb[b], pe[b]) (the two-pass form packs the bins back to back; level 1's
-    // one sweep leaves the slack of its regions between them)
     int64_t pb[TABW + 1], pe[TABW];
+    for (int b = 0; b <= TABW; b++) pb[b] = 0;
+    for (int b = 0; b < TABW; b++) pe[b] = 0;
     constexpr int S = 1;                                   // pieces per bin (alltoallv_words would take more)
     int64_t nrec = 0;
-    const bool try_sweep = !(getenv("RFX_COMM_SWEEP") && atoi(getenv("RFX_COMM_SWEEP")) == 0);
-    for (int attempt = 0;; attempt++) {
-        const int64_t cap_rec = (int64_t)(c->units_per_read * (double)n_reads) + 4096;
-        RFX_TRY(grow(ctx, &c->send, &c->send_bytes, (size_t)cap_rec * uw * 8, ctx->stream, c->xs));
-        ctx->timing.clear();
-        int st;
-        bool swept = false;
-        if (wide) {
-            st = try_sweep ? rfx::bucket_wide_records_by_owner_sweep(ctx, d_words, n_reads, words_per_read, nk, k, front_clip, bins, c->send,
-                                                                     cap_rec, pb, pe, &nrec, &swept)
-                           : RFX_OK;
-            if (st == RFX_OK && !swept)
-                st = rfx_dev_bucket_wide_records_by_owner(ctx, d_words, n_reads, words_per_read, read_len, k, front_clip, end_clip, bins,
-                                                          c->send, cap_rec, c->d_tab, pb, &nrec);
-            else
-                ScopedTimer::collect(ctx);
-        } else {
-            st = try_sweep ? rfx::bucket_records_by_owner_sweep(ctx, &rs, bins, c->send, cap_rec, pb, pe, &nrec, &swept) : RFX_OK;
-            if (st == RFX_OK && !swept) st = rfx::bucket_records_by_owner(ctx, &rs, bins, c->send, cap_rec, c->d_tab, pb, &nrec);
-            ScopedTimer::collect(ctx);
+    auto bucket = [&]() -> int {
+        if (d_read_len) {
+            rs.read_len_arr = d_read_len;
+            RFX_TRY(rfx::ragged_instances(ctx, d_read_len, n_reads, k, front_clip, end_clip, &rs.n_instances));
+            inst = rs.n_instances;
         }
-        add_timing(acc, ctx->timing);
-        if (st == RFX_OK) { if (!swept) for (int b = 0; b < bins; b++) pe[b] = pb[b + 1]; break; }
-        if (st != RFX_E_CAP || attempt >= 2) return st;
-        c->units_per_read = 1.03 * (double)nrec / (double)std::max<int64_t>(1, n_reads);      // only ever grows
-    }
-    c->bytes_bucketed = nrec * uw * 8;
-
-    // 2. every rank's counts to every rank: row r = what rank r holds in each piece of each (generation, owner) bin.
-    // (one-rank rehearsal: a generation's vworld owner bins -- vworld * S pieces -- all belong to the one real rank)
+        if (c->units_per_read <= 0) c->units_per_read = (double)nk / 5.0 + 1.0;
+        // the send buffer's layout: bin b = records [pb[b], pe[b]) (the two-pass form packs the bins back to back; level 1's
+        // one sweep leaves the slack of its regions between them)
+        const bool try_sweep = !(getenv("RFX_COMM_SWEEP") && atoi(getenv("RFX_COMM_SWEEP")) == 0);
+        for (int attempt = 0;; attempt++) {
+            const int64_t cap_rec = (int64_t)(c->units_per_read * (double)n_reads) + 4096;
+            RFX_TRY(grow(ctx, &c->send, &c->send_bytes, (size_t)cap_rec * uw * 8, ctx->stream, c->xs));
+            ctx->timing.clear();
+            int st;
+            bool swept = false;
+            if (wide) {
+                st = try_sweep ? rfx::bucket_wide_records_by_owner_sweep(ctx, d_words, n_reads, words_per_read, nk, k, front_clip, bins, c->send,
+                                                                         cap_rec, pb, pe, &nrec, &swept)
+                               : RFX_OK;
+                if (st == RFX_OK && !swept)
+                    st = rfx_dev_bucket_wide_records_by_owner(ctx, d_words, n_reads, words_per_read, read_len, k, front_clip, end_clip, bins,
+                                                              c->send, cap_rec, c->d_tab, pb, &nrec);
+                else
+                    ScopedTimer::collect(ctx);
+            } else {
+                st = try_sweep ? rfx::bucket_records_by_owner_sweep(ctx, &rs, bins, c->send, cap_rec, pb, pe, &nrec, &swept) : RFX_OK;
+                if (st == RFX_OK && !swept) st = rfx::bucket_records_by_owner(ctx, &rs, bins, c->send, cap_rec, c->d_tab, pb, &nrec);
+                ScopedTimer::collect(ctx);
+            }
+            add_timing(acc, ctx->timing);
+            if (st == RFX_OK) { if (!swept) for (int b = 0; b < bins; b++) pe[b] = pb[b + 1]; return RFX_OK; }
+            if (st == RFX_E_CAP && attempt >= 2) {                                               // (RFX_E_CAP is the OUTPUT's word)
+                ctx->last_error = "rfx_dev_sharded_count: the send buffer was too small three times running";
+                return RFX_E_LIMIT;
+            }
+            if (st != RFX_E_CAP) return st;
+            c->units_per_read = 1.03 * (double)nrec / (double)std::max<int64_t>(1, n_reads);      // only ever grows
+        }
+    };
     const int SP = S * vworld;                            // pieces per (generation, real rank)
     const int rbins = G * world;                          // bins of the real exchange
     const int np = rbins * SP;                            // pieces a rank holds
-    if (np > TABW) { ctx->last_error = "rfx_dev_sharded_count: more pieces than the count matrix takes"; return RFX_E_STATE; }
+    const int row = np + 2;                               // + this rank's status, + the records its receive buffer takes
+    if (row > TABW) { ctx->last_error = "rfx_dev_sharded_count: more pieces than the count matrix takes"; return RFX_E_STATE; }   // (same on every rank)
+    int st_local = bucket();
+    if (st_local != RFX_OK) { (void)hipStreamSynchronize(ctx->stream); for (int b = 0; b < TABW; b++) pb[b] = pe[b] = 0; nrec = 0; }
+    c->bytes_bucketed = nrec * uw * 8;
+    // the receive buffer is sized BEFORE the matrix travels, from what this rank sends (owners are balanced, so what
+    // arrives is about what leaves), and its capacity travels with the counts: every rank can then see whether ANY
+    // rank's buffer is short, and only then is there a second agreement (below) -- none in the steady state
+    if (st_local == RFX_OK) {
+        const int sg = grow(ctx, &c->recv, &c->recv_bytes, (size_t)std::max<int64_t>(1, nrec + nrec / 8 + 4096) * uw * 8, ctx->stream, c->xs);
+        if (sg != RFX_OK) st_local = sg;
+    }
+
+    // 2. every rank's counts to every rank: row r = what rank r holds in each piece of each (generation, owner) bin,
+    // its status and its receive capacity.  (one-rank rehearsal: a generation's vworld owner bins -- vworld * S pieces --
+    // all belong to the one real rank)
     int64_t *h_mine = c->h_tab, *h_all = c->h_tab + TABW;
     for (int q = 0; q < np; q++) h_mine[q] = pe[q] - pb[q];
-    RFX_HIP(hipMemcpyAsync(c->d_tab, h_mine, (size_t)np * 8, hipMemcpyHostToDevice, c->xs));
-    RFX_NCCL(n.AllGather(c->d_tab, c->d_tab + TABW, (size_t)np, ncclInt64, c->comm, c->xs));
-    RFX_HIP(hipMemcpyAsync(h_all, c->d_tab + TABW, (size_t)np * world * 8, hipMemcpyDeviceToHost, c->xs));
+    h_mine[np] = st_local;
+    h_mine[np + 1] = (int64_t)(c->recv_bytes / ((size_t)uw * 8));
+    RFX_HIP(hipMemcpyAsync(c->d_tab, h_mine, (size_t)row * 8, hipMemcpyHostToDevice, c->xs));
+    RFX_NCCL(n.AllGather(c->d_tab, c->d_tab + TABW, (size_t)row, ncclInt64, c->comm, c->xs));
+    RFX_HIP(hipMemcpyAsync(h_all, c->d_tab + TABW, (size_t)row * world * 8, hipMemcpyDeviceToHost, c->xs));
     RFX_HIP(hipStreamSynchronize(c->xs));
+    note_foreign_hip_error(ctx, "rfx_dev_sharded_count (count matrix)");
+    for (int r = 0; r < world; r++)
+        if (h_all[(size_t)r * row + np] != RFX_OK) {                  // somebody could not bucket: everybody leaves, now
+            if (st_local != RFX_OK) return st_local;
+            char buf[160];
+            snprintf(buf, sizeof buf, "rfx_dev_sharded_count: rank %d failed before the exchange (status %lld); see its rfx_last_error()", r,
+                     (long long)h_all[(size_t)r * row + np]);
+            ctx->last_error = buf;
+            return RFX_E_STATE;
+        }
     // receive layout: generation after generation, inside a generation source after source, piece after piece
     const size_t ne = (size_t)G * world * SP;
     std::vector<int64_t> gen_off(G + 1, 0), roff(ne), rcnt(ne), soff(ne), scnt(ne);
@@ -334,7 +390,7 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
         for (int s = 0; s < world; s++)
             for (int q = 0; q < SP; q++) {
                 const size_t e = ((size_t)g * world + s) * SP + q;
-                const int64_t u = h_all[(size_t)s * np + ((size_t)g * world + me) * SP + q];
+                const int64_t u = h_all[(size_t)s * row + ((size_t)g * world + me) * SP + q];
                 roff[e] = pos * uw; rcnt[e] = u * uw;
                 pos += u;
             }
@@ -346,9 +402,28 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
                 scnt[e] = (pe[e] - pb[e]) * uw;
             }
     }
-    for (size_t i = 0; i < (size_t)np * world; i++) mx = std::max(mx, h_all[i] * uw);
+    bool any_short = false;                                         // (computed identically on every rank)
+    for (int r = 0; r < world; r++) {
+        int64_t need = 0;
+        for (int s = 0; s < world; s++)
+            for (int g = 0; g < G; g++)
+                for (int q = 0; q < SP; q++) {
+                    const int64_t u = h_all[(size_t)s * row + ((size_t)g * world + r) * SP + q];
+                    need += u;
+                    mx = std::max(mx, u * uw);
+                }
+        if (need > h_all[(size_t)r * row + np + 1]) any_short = true;
+    }
     const int64_t rounds = std::max<int64_t>(1, (mx + (int64_t)(c->limit_bytes / 8) - 1) / (int64_t)(c->limit_bytes / 8));
-    RFX_TRY(grow(ctx, &c->recv, &c->recv_bytes, (size_t)std::max<int64_t>(1, gen_off[G]) * uw * 8, ctx->stream, c->xs));
+    if (any_short) {                                                // the short ranks grow; everybody learns how that went
+        int sg = RFX_OK;
+        if (gen_off[G] > (int64_t)(c->recv_bytes / ((size_t)uw * 8)))
+            sg = grow(ctx, &c->recv, &c->recv_bytes, (size_t)std::max<int64_t>(1, gen_off[G]) * uw * 8, ctx->stream, c->xs);
+        int64_t bad[1] = {sg != RFX_OK ? 1 : 0};
+        RFX_TRY(rfx_comm_all_reduce_i64(c, bad, 1, 1));
+        if (sg != RFX_OK) return sg;
+        if (bad[0]) { ctx->last_error = "rfx_dev_sharded_count: a peer could not allocate its receive buffer"; return RFX_E_STATE; }
+    }
 
     // 3. all G exchanges queued back to back on the exchange stream
     RFX_HIP(hipEventRecord(c->ev_ready, ctx->stream));
@@ -359,12 +434,14 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
         RFX_HIP(hipEventRecord(c->ev[g], c->xs));
     }
 
-    // 4. count generation g while the later ones travel
+    // 4. count generation g while the later ones travel.  From here to the closing all-reduce a failure is remembered, not
+    // returned: the peers are waiting there.
     int64_t m = 0, distinct = 0;
-    int st_keep = RFX_OK;
+    int st_keep = RFX_OK, st_fail = RFX_OK;
     for (int g = 0; g < G; g++) {
-        RFX_HIP(hipEventSynchronize(c->ev[g]));
-        (void)hipGetLastError();          // (RCCL's own runtime calls may leave a benign sticky error behind: the kernels' launch checks must not see it)
+        if (hipEventSynchronize(c->ev[g]) != hipSuccess) { if (st_fail == RFX_OK) { st_fail = RFX_E_HIP; ctx->last_error = "rfx_dev_sharded_count: hipEventSynchronize failed"; } continue; }
+        note_foreign_hip_error(ctx, "rfx_dev_sharded_count (exchange)");      // (the kernels' launch checks below must not see RCCL's leftovers)
+        if (st_fail != RFX_OK) continue;
         const int64_t ng = gen_off[g + 1] - gen_off[g];
         int64_t mg = 0, dg = 0;
         const int64_t room = std::max<int64_t>(0, cap - m);
@@ -379,42 +456,50 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
                                        (int32_t *)d_out_counts + m, room, &mg, &dg);
         add_timing(acc, ctx->timing);
         if (st == RFX_E_CAP) { st_keep = RFX_E_CAP; m += mg; distinct += dg; continue; }     // keep draining: report the need
-        if (st != RFX_OK) { (void)hipStreamSynchronize(c->xs); return st; }
+        if (st != RFX_OK) { st_fail = st; continue; }
         m += mg; distinct += dg;
     }
-    RFX_HIP(hipStreamSynchronize(c->xs));
+    if (hipStreamSynchronize(c->xs) != hipSuccess && st_fail == RFX_OK) { st_fail = RFX_E_HIP; ctx->last_error = "rfx_dev_sharded_count: the exchange stream failed"; }
 
     // 5. the generations' ascending shards -> one ascending shard
-    if (st_keep == RFX_OK && G > 1 && m > 1) {
+    if (st_fail == RFX_OK && st_keep == RFX_OK && G > 1 && m > 1) {
         ctx->timing.clear();
-        if (wide) {
-            RFX_TRY(rfx_dev_order_kmers_w(ctx, d_out_keys, (int64_t *)d_out_counts, m, k));
-        } else {
-            DevBuf tk, tv;
-            RFX_HIP(tk.alloc((size_t)m * 8, ctx->stream));
-            RFX_HIP(tv.alloc((size_t)m * 4, ctx->stream));
-            RFX_TRY(rfx_dev_sort_pairs(ctx, d_out_keys, (uint32_t *)d_out_counts, m, 2 * k, tk.as<uint64_t>(), tv.as<uint32_t>()));
-            RFX_TRY(sync_checked(ctx));
-        }
+        auto merge = [&]() -> int {
+            if (wide) {
+                RFX_TRY(rfx_dev_order_kmers_w(ctx, d_out_keys, (int64_t *)d_out_counts, m, k));
+                RFX_TRY(sync_checked(ctx));
+            } else {
+                DevBuf tk, tv;
+                RFX_HIP(tk.alloc((size_t)m * 8, ctx->stream));
+                RFX_HIP(tv.alloc((size_t)m * 4, ctx->stream));
+                RFX_TRY(rfx_dev_sort_pairs(ctx, d_out_keys, (uint32_t *)d_out_counts, m, 2 * k, tk.as<uint64_t>(), tv.as<uint32_t>()));
+                RFX_TRY(sync_checked(ctx));
+            }
+            return RFX_OK;
+        };
+        st_fail = merge();
+        ScopedTimer::collect(ctx);                      // (order_wide2's "sort" timer: stopped timers never outlive the call)
         add_timing(acc, ctx->timing);
     }
     ctx->timing = acc;
     if (out_n) *out_n = m;
 
-    // 6. global totals: instances, distinct, survivors (and whether any rank ran out of room)
-    int64_t tot[4] = {inst, distinct, m, st_keep == RFX_E_CAP ? 1 : 0};
-    RFX_TRY(rfx_comm_all_reduce_i64(c, tot, 4, 0));
+    // 6. global totals: instances, distinct, survivors, whether any rank ran out of room, whether any rank failed
+    int64_t tot[5] = {inst, distinct, m, st_keep == RFX_E_CAP ? 1 : 0, st_fail != RFX_OK ? 1 : 0};
+    RFX_TRY(rfx_comm_all_reduce_i64(c, tot, 5, 0));
+    if (st_fail != RFX_OK) return st_fail;
+    if (tot[4] > 0) { ctx->last_error = "rfx_dev_sharded_count: a peer failed while counting its shard; see its rfx_last_error()"; return RFX_E_STATE; }
     if (out_totals) { out_totals[0] = tot[0]; out_totals[1] = tot[1]; out_totals[2] = tot[2]; }
     // a shard that did not fit on ANY rank fails the call on EVERY rank (*out_n = this rank's own need), so that the
     // callers' retries stay collective
     return tot[3] > 0 ? RFX_E_CAP : RFX_OK;
-}
+} RFX_API_CATCH(ctx)
 
 // The shards of every rank -> rank `root`, shard after shard in rank order (D' << N: the filtered list of a bacterial
 // genome is a few million k-mers, so the extend stage runs on one GPU).  key_words 8-byte words per
 // key, count_bytes 4 or 8.  On root: *out_n = total entries (RFX_E_CAP if cap is short); elsewhere 0.
 int rfx_dev_gather_shards(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_keys, const void *d_counts, int64_t n, int key_words,
-                          int count_bytes, int root, uint64_t *d_out_keys, void *d_out_counts, int64_t cap, int64_t *out_n) {
+                          int count_bytes, int root, uint64_t *d_out_keys, void *d_out_counts, int64_t cap, int64_t *out_n) try {
     if (!ctx || !c || c->ctx != ctx || n < 0 || key_words < 1 || (count_bytes != 4 && count_bytes != 8) || root < 0 ||
         root >= c->world)
         return RFX_E_ARG;
@@ -422,21 +507,28 @@ int rfx_dev_gather_shards(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_keys, con
     comm_options(c);
     NcclApi &nc = nccl();
     const int world = c->world, me = c->rank;
-    c->h_tab[0] = n;
-    RFX_TRY(sync_checked(ctx));
-    RFX_HIP(hipMemcpyAsync(c->d_tab, c->h_tab, 8, hipMemcpyHostToDevice, c->xs));
-    RFX_NCCL(nc.AllGather(c->d_tab, c->d_tab + TABW, 1, ncclInt64, c->comm, c->xs));
-    RFX_HIP(hipMemcpyAsync(c->h_tab + TABW, c->d_tab + TABW, (size_t)world * 8, hipMemcpyDeviceToHost, c->xs));
+    // row = {entries, status, room}: a rank whose own stream has failed says so HERE, where the peers are listening, and
+    // root's room travels too, so that every rank sees a short buffer on root before anybody posts a send
+    const int st_sync = sync_checked(ctx);
+    c->h_tab[0] = st_sync == RFX_OK ? n : 0;
+    c->h_tab[1] = st_sync;
+    c->h_tab[2] = cap;
+    RFX_HIP(hipMemcpyAsync(c->d_tab, c->h_tab, 24, hipMemcpyHostToDevice, c->xs));
+    RFX_NCCL(nc.AllGather(c->d_tab, c->d_tab + TABW, 3, ncclInt64, c->comm, c->xs));
+    RFX_HIP(hipMemcpyAsync(c->h_tab + TABW, c->d_tab + TABW, (size_t)world * 24, hipMemcpyDeviceToHost, c->xs));
     RFX_HIP(hipStreamSynchronize(c->xs));
+    const int64_t root_cap = c->h_tab[TABW + 3 * root + 2];
+    for (int r = 0; r < world; r++)
+        if (c->h_tab[TABW + 3 * r + 1] != RFX_OK) {
+            if (st_sync != RFX_OK) return st_sync;
+            ctx->last_error = "rfx_dev_gather_shards: a peer failed before the gather; see its rfx_last_error()";
+            return RFX_E_STATE;
+        }
+    for (int r = 0; r < world; r++) c->h_tab[TABW + r] = c->h_tab[TABW + 3 * r];       // (compact: entries per rank)
     std::vector<int64_t> off(world + 1, 0);
     for (int r = 0; r < world; r++) off[r + 1] = off[r] + c->h_tab[TABW + r];
     if (out_n) *out_n = me == root ? off[world] : 0;
-    int st = RFX_OK;
-    if (me == root && off[world] > cap) st = RFX_E_CAP;
-    // every rank must learn of a short buffer on root before anybody posts a send
-    int64_t flag[1] = {st == RFX_E_CAP ? 1 : 0};
-    RFX_TRY(rfx_comm_all_reduce_i64(c, flag, 1, 1));
-    if (flag[0]) return me == root ? RFX_E_CAP : RFX_OK;
+    if (off[world] > root_cap) return me == root ? RFX_E_CAP : RFX_OK;          // (the same verdict on every rank)
     const int64_t limit_k = std::max<int64_t>(1, (int64_t)(c->limit_bytes / 8) / key_words) , limit_c = (int64_t)(c->limit_bytes / count_bytes);
     const int64_t lim = std::min(limit_k, limit_c);
     int64_t mx = 0;
@@ -447,7 +539,9 @@ int rfx_dev_gather_shards(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_keys, con
         RFX_HIP(hipMemcpyAsync((char *)d_out_counts + off[me] * count_bytes, d_counts, (size_t)n * count_bytes, hipMemcpyDeviceToDevice, c->xs));
     }
     for (int64_t j = 0; j < rounds; j++) {
+        GroupGuard gg;
         RFX_NCCL(nc.GroupStart());
+        gg.open = true;
         if (me != root) {
             const int64_t s = std::max<int64_t>(0, std::min(lim, n - j * lim));
             if (s > 0) {
@@ -464,78 +558,120 @@ int rfx_dev_gather_shards(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_keys, con
                 }
             }
         }
+        gg.open = false;
         RFX_NCCL(nc.GroupEnd());
     }
     RFX_HIP(hipStreamSynchronize(c->xs));
+    note_foreign_hip_error(ctx, "rfx_dev_gather_shards");
     return RFX_OK;
-}
+} RFX_API_CATCH(ctx)
 
 // The whole resident path on several GPUs from ASCII reads in host memory: every rank uploads and encodes ITS reads
 // (any lengths), rfx_dev_sharded_count, the shards gathered on rank 0, the driver there (rfx_dev_assemble) -> the
 // contig text on rank 0 (*out_len = 0 elsewhere).  k = 21..31.  Collective.  out_totals[3] as rfx_dev_sharded_count.
 int rfx_sharded_assemble_reads(rfx_ctx *ctx, rfx_comm *c, const uint8_t *bases, const int64_t *read_off, int64_t n_reads,
                                const rfx_params *prm, int generations, char *out, int64_t cap, int64_t *out_len,
-                               int64_t *out_contigs, int64_t *trace, int64_t trace_cap, int64_t *n_trace, int64_t *out_totals) {
+                               int64_t *out_contigs, int64_t *trace, int64_t trace_cap, int64_t *n_trace, int64_t *out_totals) try {
     if (!ctx || !c || c->ctx != ctx || !read_off || !prm || !out_len || n_reads < 0) return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
     const int k = prm->k;
     const int64_t nb = n_reads ? read_off[n_reads] - read_off[0] : 0;
     int64_t maxlen = 1;
     for (int64_t r = 0; r < n_reads; r++) maxlen = std::max(maxlen, read_off[r + 1] - read_off[r]);
-    int64_t ml[1] = {maxlen};
-    RFX_TRY(rfx_comm_all_reduce_i64(c, ml, 1, 1));                     // (ranks agree on nothing but their own layout; kept for the plan)
     const int wpr = (int)((maxlen + 31) / 32);
+    *out_len = 0;
+    if (out_contigs) *out_contigs = 0;
+    if (n_trace) *n_trace = 0;
     DevBuf d_bases, d_off, d_words, d_len, d_keys, d_counts, g_keys, g_counts;
-    RFX_HIP(d_bases.alloc((size_t)std::max<int64_t>(nb, 1), ctx->stream));
-    RFX_HIP(d_off.alloc((size_t)(n_reads + 1) * 8, ctx->stream));
-    RFX_HIP(d_words.alloc((size_t)std::max<int64_t>(n_reads, 1) * wpr * 8, ctx->stream));
-    RFX_HIP(d_len.alloc((size_t)std::max<int64_t>(n_reads, 1) * 4, ctx->stream));
-    std::vector<int64_t> off((size_t)n_reads + 1, 0);
-    for (int64_t r = 0; r <= n_reads && n_reads > 0; r++) off[(size_t)r] = read_off[r] - read_off[0];
-    if (nb > 0) RFX_HIP(hipMemcpyAsync(d_bases.p, bases + read_off[0], (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
-    RFX_HIP(hipMemcpyAsync(d_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    RFX_TRY(rfx::encode_reads(ctx, d_bases.as<uint8_t>(), d_off.as<int64_t>(), n_reads, wpr, d_words.as<uint64_t>(), d_len.as<uint32_t>()));
-    RFX_TRY(sync_checked(ctx));
-    d_bases.release(); d_off.release();
+    // this rank's own preparation (allocations, upload, encode); how it went is agreed before the first data collective,
+    // so that a rank that cannot go on does not leave its peers waiting inside one
+    auto prepare = [&]() -> int {
+        RFX_HIP(d_bases.alloc((size_t)std::max<int64_t>(nb, 1), ctx->stream));
+        RFX_HIP(d_off.alloc((size_t)(n_reads + 1) * 8, ctx->stream));
+        RFX_HIP(d_words.alloc((size_t)std::max<int64_t>(n_reads, 1) * wpr * 8, ctx->stream));
+        RFX_HIP(d_len.alloc((size_t)std::max<int64_t>(n_reads, 1) * 4, ctx->stream));
+        std::vector<int64_t> off((size_t)n_reads + 1, 0);
+        for (int64_t r = 0; r <= n_reads && n_reads > 0; r++) off[(size_t)r] = read_off[r] - read_off[0];
+        if (nb > 0) RFX_HIP(hipMemcpyAsync(d_bases.p, bases + read_off[0], (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+        RFX_HIP(hipMemcpyAsync(d_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        RFX_TRY(rfx::encode_reads(ctx, d_bases.as<uint8_t>(), d_off.as<int64_t>(), n_reads, wpr, d_words.as<uint64_t>(), d_len.as<uint32_t>()));
+        RFX_TRY(sync_checked(ctx));                                     // (`off` is read by the copy until here)
+        d_bases.release(); d_off.release();
+        return RFX_OK;
+    };
+    int st_local;
+    try { st_local = prepare(); } catch (...) { st_local = rfx_api_exception(ctx, "rfx_sharded_assemble_reads"); }
+    if (st_local != RFX_OK) (void)hipStreamSynchronize(ctx->stream);
+    auto agree = [&](int st_mine, const char *what) -> int {           // collective: RFX_OK only if every rank says so
+        int64_t bad[1] = {st_mine != RFX_OK ? 1 : 0};
+        RFX_TRY(rfx_comm_all_reduce_i64(c, bad, 1, 1));
+        if (st_mine != RFX_OK) return st_mine;
+        if (bad[0]) { ctx->last_error = std::string("rfx_sharded_assemble_reads: a peer failed (") + what + "); see its rfx_last_error()"; return RFX_E_STATE; }
+        return RFX_OK;
+    };
+    RFX_TRY(agree(st_local, "upload / encode"));
     int64_t kcap = std::max<int64_t>(1 << 20, nb / 8), m = 0, tot[3] = {0, 0, 0};
     for (;;) {                                                        // survivors are few; every rank grows together
-        RFX_HIP(d_keys.alloc((size_t)kcap * 8, ctx->stream));
-        RFX_HIP(d_counts.alloc((size_t)kcap * 4, ctx->stream));
-        int st = rfx_dev_sharded_count(ctx, c, d_words.as<uint64_t>(), d_len.as<uint32_t>(), n_reads, wpr, (int)maxlen, k, prm->front_clip,
-                                       prm->end_clip, generations, prm->min_cov, prm->max_cov, prm->twin, d_keys.as<uint64_t>(),
-                                       d_counts.p, kcap, &m, tot);
+        int st = RFX_OK;
+        if (d_keys.alloc((size_t)kcap * 8, ctx->stream) != hipSuccess || d_counts.alloc((size_t)kcap * 4, ctx->stream) != hipSuccess) {
+            ctx->last_error = "rfx_sharded_assemble_reads: no room for the shard";
+            st = RFX_E_HIP;
+        }
+        RFX_TRY(agree(st, "shard allocation"));
+        st = rfx_dev_sharded_count(ctx, c, d_words.as<uint64_t>(), d_len.as<uint32_t>(), n_reads, wpr, (int)maxlen, k, prm->front_clip,
+                                   prm->end_clip, generations, prm->min_cov, prm->max_cov, prm->twin, d_keys.as<uint64_t>(),
+                                   d_counts.p, kcap, &m, tot);
         if (st == RFX_E_CAP) {                                        // (on every rank at once)
             int64_t need[1] = {m};
             RFX_TRY(rfx_comm_all_reduce_i64(c, need, 1, 1));
             kcap = std::max(kcap * 2, need[0]);
             continue;
         }
-        RFX_TRY(st);
+        RFX_TRY(st);                                                  // (any other failure is every rank's, see there)
         break;
     }
     if (out_totals) { out_totals[0] = tot[0]; out_totals[1] = tot[1]; out_totals[2] = tot[2]; }
     d_words.release(); d_len.release();
     const int64_t all = tot[2];
+    int st_root = RFX_OK;
     if (c->rank == 0) {
-        RFX_HIP(g_keys.alloc((size_t)std::max<int64_t>(1, all) * 8, ctx->stream));
-        RFX_HIP(g_counts.alloc((size_t)std::max<int64_t>(1, all) * 4, ctx->stream));
-        RFX_TRY(sync_checked(ctx));
+        if (g_keys.alloc((size_t)std::max<int64_t>(1, all) * 8, ctx->stream) != hipSuccess ||
+            g_counts.alloc((size_t)std::max<int64_t>(1, all) * 4, ctx->stream) != hipSuccess) {
+            ctx->last_error = "rfx_sharded_assemble_reads: no room on rank 0 for the gathered shards";
+            st_root = RFX_E_HIP;
+        }
     }
+    RFX_TRY(agree(st_root, "allocation on rank 0"));
     int64_t got = 0;
     RFX_TRY(rfx_dev_gather_shards(ctx, c, d_keys.as<uint64_t>(), d_counts.p, m, 1, 4, 0, g_keys.as<uint64_t>(), g_counts.p, all, &got));
-    *out_len = 0;
-    if (out_contigs) *out_contigs = 0;
-    if (n_trace) *n_trace = 0;
-    if (c->rank != 0) return RFX_OK;
-    if (c->world > 1 && got > 1) {                                     // hash shards -> ascending k-mer order (the order contract)
-        DevBuf tk, tv;
-        RFX_HIP(tk.alloc((size_t)got * 8, ctx->stream));
-        RFX_HIP(tv.alloc((size_t)got * 4, ctx->stream));
-        RFX_TRY(rfx_dev_sort_pairs(ctx, g_keys.as<uint64_t>(), g_counts.as<uint32_t>(), got, 2 * k, tk.as<uint64_t>(), tv.as<uint32_t>()));
-        RFX_TRY(sync_checked(ctx));
+    // the driver runs on rank 0 only; its outcome is every rank's: a text buffer that is too short there is RFX_E_CAP
+    // with *out_len = the length needed on EVERY rank, so that the callers' "grow and call again" re-enters the
+    // collective together (rank 0 retrying alone waited for ever in the first all-reduce)
+    int64_t len = 0, ncont = 0, ntr = 0;
+    int st_asm = RFX_OK;
+    if (c->rank == 0) {
+        auto drive = [&]() -> int {
+            if (c->world > 1 && got > 1) {                             // hash shards -> ascending k-mer order (the order contract)
+                DevBuf tk, tv;
+                RFX_HIP(tk.alloc((size_t)got * 8, ctx->stream));
+                RFX_HIP(tv.alloc((size_t)got * 4, ctx->stream));
+                RFX_TRY(rfx_dev_sort_pairs(ctx, g_keys.as<uint64_t>(), g_counts.as<uint32_t>(), got, 2 * k, tk.as<uint64_t>(), tv.as<uint32_t>()));
+                RFX_TRY(sync_checked(ctx));
+            }
+            return rfx_dev_assemble(ctx, g_keys.as<uint64_t>(), g_counts.as<int32_t>(), got, prm, out, cap, &len, &ncont, trace, trace_cap, &ntr);
+        };
+        try { st_asm = drive(); } catch (...) { st_asm = rfx_api_exception(ctx, "rfx_sharded_assemble_reads"); }
     }
-    return rfx_dev_assemble(ctx, g_keys.as<uint64_t>(), g_counts.as<int32_t>(), got, prm, out, cap, out_len, out_contigs, trace,
-                            trace_cap, n_trace);
-}
+    int64_t res[3] = {st_asm == RFX_E_CAP ? 1 : 0, st_asm == RFX_E_CAP ? len : 0, (st_asm != RFX_OK && st_asm != RFX_E_CAP) ? 1 : 0};
+    RFX_TRY(rfx_comm_all_reduce_i64(c, res, 3, 1));
+    if (res[2]) {
+        if (st_asm != RFX_OK) return st_asm;
+        ctx->last_error = "rfx_sharded_assemble_reads: the driver failed on rank 0; see its rfx_last_error()";
+        return RFX_E_STATE;
+    }
+    if (res[0]) { *out_len = res[1]; return RFX_E_CAP; }
+    if (c->rank == 0) { *out_len = len; if (out_contigs) *out_contigs = ncont; if (n_trace) *n_trace = ntr; }
+    return RFX_OK;
+} RFX_API_CATCH(ctx)
 
 }  // extern "C"

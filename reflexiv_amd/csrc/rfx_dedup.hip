@@ -585,7 +585,7 @@ static int64_t dedup_text(const std::vector<uint8_t> &bases, const std::vector<i
 
 int rfx_dedup_contigs(rfx_ctx *ctx, const uint8_t *bases_ascii, const int64_t *contig_off, int64_t n_contigs, int min_contig,
                       uint8_t *out_bases_ascii, int64_t cap_bases, int64_t *out_off, int64_t cap_contigs, int64_t *out_n,
-                      char *text, int64_t text_cap, int64_t *text_len, int64_t *round_n) {
+                      char *text, int64_t text_cap, int64_t *text_len, int64_t *round_n) try {
     if (!ctx || !contig_off || n_contigs < 0 || (n_contigs > 0 && !bases_ascii)) return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
     const int64_t nb = n_contigs ? contig_off[n_contigs] - contig_off[0] : 0;
@@ -618,12 +618,12 @@ int rfx_dedup_contigs(rfx_ctx *ctx, const uint8_t *bases_ascii, const int64_t *c
         if (text && *text_len > text_cap) st = RFX_E_CAP;
     }
     return st;
-}
+} RFX_API_CATCH(ctx)
 
 // The same from the contig TEXT the path writes (">Contig-<len>-...\n" + the sequence wrapped at 100 columns; either twin's
 // header): every record is a contig, in order, ids = positions -> the de-duplicated text (TagRowContigDSID's format).
 int rfx_dedup_contig_text(rfx_ctx *ctx, const char *contig_text, int64_t len, int min_contig, char *out, int64_t cap, int64_t *out_len,
-                          int64_t *out_contigs, int64_t *round_n) {
+                          int64_t *out_contigs, int64_t *round_n) try {
     if (!ctx || (len > 0 && !contig_text) || !out_len) return RFX_E_ARG;
     std::vector<uint8_t> bases;
     std::vector<int64_t> off(1, 0);
@@ -653,6 +653,6 @@ int rfx_dedup_contig_text(rfx_ctx *ctx, const char *contig_text, int64_t len, in
     const int st = rfx_dedup_contigs(ctx, bases.data(), off.data(), n, min_contig, nullptr, 0, nullptr, 0, &m, out, cap, out_len, round_n);
     if (out_contigs) *out_contigs = m;
     return st;
-}
+} RFX_API_CATCH(ctx)
 
 }  // extern "C"

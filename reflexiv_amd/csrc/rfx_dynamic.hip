@@ -508,7 +508,7 @@ static int dyn_reflect(rfx_ctx *ctx, const DynDev &in, const int64_t *d_ps, int 
 
 extern "C" {
 
-int rfx_dyn_sort(rfx_ctx *ctx, const rfx_dyn_records *in, int P, rfx_dyn_records *out, int64_t *part_start) {
+int rfx_dyn_sort(rfx_ctx *ctx, const rfx_dyn_records *in, int P, rfx_dyn_records *out, int64_t *part_start) try {
     if (!ctx || !in || !out || !part_start || P < 1 || P > 63) return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
     DynDev a, b;
@@ -518,9 +518,9 @@ int rfx_dyn_sort(rfx_ctx *ctx, const rfx_dyn_records *in, int P, rfx_dyn_records
     RFX_TRY(dyn_sort(ctx, a, P, b, ps, &lmin));
     RFX_HIP(hipMemcpyAsync(part_start, ps.p, (size_t)(P + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     return dyn_download(ctx, b, out);
-}
+} RFX_API_CATCH(ctx)
 
-int rfx_dyn_random_reflection(rfx_ctx *ctx, const rfx_dyn_records *in, const int64_t *part_start, int P, rfx_dyn_records *out) {
+int rfx_dyn_random_reflection(rfx_ctx *ctx, const rfx_dyn_records *in, const int64_t *part_start, int P, rfx_dyn_records *out) try {
     if (!ctx || !in || !out || !part_start || P < 1 || P > 63) return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
     DynDev a, b;
@@ -530,10 +530,10 @@ int rfx_dyn_random_reflection(rfx_ctx *ctx, const rfx_dyn_records *in, const int
     RFX_HIP(hipMemcpyAsync(ps.p, part_start, (size_t)(P + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     RFX_TRY(dyn_reflect(ctx, a, ps.as<int64_t>(), P, b));
     return dyn_download(ctx, b, out);
-}
+} RFX_API_CATCH(ctx)
 
 int rfx_dyn_extend_pass(rfx_ctx *ctx, const rfx_dyn_records *in, const int64_t *part_start, int P, int stage, int start_iteration,
-                        int start_marker, rfx_dyn_records *out, int64_t *out_part_start) {
+                        int start_marker, rfx_dyn_records *out, int64_t *out_part_start) try {
     if (!ctx || !in || !out || !part_start || P < 1 || P > 63 || (stage != 0 && stage != 1) || (start_marker != 1 && start_marker != 2))
         return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
@@ -548,14 +548,14 @@ int rfx_dyn_extend_pass(rfx_ctx *ctx, const rfx_dyn_records *in, const int64_t *
     RFX_TRY(dyn_pass(ctx, a, ps.as<int64_t>(), P, (uint32_t)lmin, stage, start_iteration, start_marker, b, ops.as<int64_t>()));
     if (out_part_start) RFX_HIP(hipMemcpyAsync(out_part_start, ops.p, (size_t)(P + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     return dyn_download(ctx, b, out);
-}
+} RFX_API_CATCH(ctx)
 
 // The drivers, records resident in HBM between the operators.  FirstFour.assemblyFromKmer (:137-224): binarized records
 // (key = the k-mer without its last base, extension = that base, orientation 1) -> DSkmerRandomReflection on P equal
 // shares -> 4 x (sort, DSExtendReflexivKmer).  Iteration.assemblyFromKmer (:134-205): (end - start + 1) x (sort,
 // DSExtendReflexivKmerToArrayLoop).  passes_first_four / start / end select what runs; out = the final records.
 int rfx_dyn_run(rfx_ctx *ctx, const rfx_dyn_records *in, int P, int random_reflection, int passes_first_four, int start_iteration,
-                int end_iteration, rfx_dyn_records *out, int64_t *trace, int64_t trace_cap, int64_t *n_trace) {
+                int end_iteration, rfx_dyn_records *out, int64_t *trace, int64_t trace_cap, int64_t *n_trace) try {
     if (!ctx || !in || !out || P < 1 || P > 63 || passes_first_four < 0) return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
     DynDev a, b;
@@ -587,13 +587,13 @@ int rfx_dyn_run(rfx_ctx *ctx, const rfx_dyn_records *in, int P, int random_refle
     for (int it = start_iteration; end_iteration >= start_iteration && it <= end_iteration; it++) RFX_TRY(one(1, start_iteration));
     if (n_trace) *n_trace = nt;
     return dyn_download(ctx, a, out);
-}
+} RFX_API_CATCH(ctx)
 
 // ---- the Row form of the third layout (what a JNI shim converts between) -----------------------------------------------
 
 // left-aligned 31-base blocks with a 01 terminator -> base codes; returns the length (currentKmerSizeFromBinaryBlockArray,
 // FirstFour:2301-2311), or -1 when cap is short
-int rfx_dyn_blocks_to_bases(const int64_t *blocks, int n_blocks, uint8_t *out, int cap) {
+int rfx_dyn_blocks_to_bases(const int64_t *blocks, int n_blocks, uint8_t *out, int cap) try {
     if (!blocks || n_blocks < 1) return -1;
     const uint64_t last = (uint64_t)blocks[n_blocks - 1];
     const int tz = last ? __builtin_ctzll(last) : 64;
@@ -601,9 +601,9 @@ int rfx_dyn_blocks_to_bases(const int64_t *blocks, int n_blocks, uint8_t *out, i
     if (len > cap) return -1;
     for (int i = 0; i < len; i++) out[i] = (uint8_t)(((uint64_t)blocks[i / 31] >> (2 * (31 - i % 31))) & 3);
     return len < 0 ? 0 : len;
-}
+} RFX_API_CATCH(nullptr)
 // base codes -> blocks; returns the number of blocks ((n - 1) / 31 + 1), or -1 when cap is short
-int rfx_dyn_bases_to_blocks(const uint8_t *bases, int n, int64_t *out, int cap) {
+int rfx_dyn_bases_to_blocks(const uint8_t *bases, int n, int64_t *out, int cap) try {
     const int nb = n <= 0 ? 1 : (n - 1) / 31 + 1;
     if (nb > cap || !out) return -1;
     for (int j = 0; j < nb; j++) {
@@ -617,14 +617,14 @@ int rfx_dyn_bases_to_blocks(const uint8_t *bases, int n, int64_t *out, int cap) 
         out[j] = (int64_t)x;
     }
     return nb;
-}
+} RFX_API_CATCH(nullptr)
 // buildingAlongFromThreeInt (FirstFour:2340-2366) and getReflexivMarker / getLeftMarker / getRightMarker (:2313-2338)
-int64_t rfx_dyn_attribute(int marker, int left, int right) {
+int64_t rfx_dyn_attribute(int marker, int left, int right) try {
     if (left >= 30000) left = 30000; else if (left <= -30000) left = 60000; else if (left < 0) left = 30000 - left;
     if (right >= 30000) right = 30000; else if (right <= -30000) right = 60000; else if (right < 0) right = 30000 - right;
     return (int64_t)(((uint64_t)(uint32_t)marker << 62) | ((uint64_t)(uint32_t)left << 32) | (uint64_t)(uint32_t)right);
-}
-void rfx_dyn_attribute_unpack(int64_t a, int *marker, int *left, int *right) {
+} RFX_API_CATCH(nullptr)
+void rfx_dyn_attribute_unpack(int64_t a, int *marker, int *left, int *right) try {
     if (marker) *marker = (int)((uint64_t)a >> 62);
     int l = (int)((uint64_t)a >> 32) & ~(3 << 30);
     if (l > 30000) l = 30000 - l;
@@ -632,6 +632,6 @@ void rfx_dyn_attribute_unpack(int64_t a, int *marker, int *left, int *right) {
     if (r > 30000) r = 30000 - r;
     if (left) *left = l;
     if (right) *right = r;
-}
+} RFX_API_CATCH_VOID(nullptr)
 
 }  // extern "C"

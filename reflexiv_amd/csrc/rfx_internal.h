@@ -10,16 +10,25 @@
 #include "../../include/reflexiv_hip.h"
 
 struct rfx_timing_slot { float ms = 0.f; int64_t launches = 0; };
+// a kernel timer that has been stopped and not yet read (ScopedTimer below): events of the context's own pool
+struct rfx_timer_pending { const char *name; hipEvent_t a, b; int64_t launches; };
 
 struct rfx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string last_error;
+    std::string foreign_hip_error;        // a HIP error RCCL left on this thread (rfx_comm.hip note_foreign_hip_error): reported, never fatal
+    std::string last_error_text;          // what rfx_last_error() hands out (last_error + the note above)
     int num_cu = 256;
     // per-kernel-family timing of the last count call (HIP events on `stream`)
     std::map<std::string, rfx_timing_slot> timing;
     bool timing_enabled = true;
+    // stopped timers waiting for ScopedTimer::collect.  They belong to the CONTEXT, like the events they name: until round 4
+    // this list was a thread_local, so a timer stopped on a path that never collected (order_wide2 through
+    // rfx_dev_order_kmers_w, any early error return) outlived its context, and the next context's first collect() handed
+    // destroyed events to hipEventElapsedTime -- the host abort of gpurun_out/s3_both.log.
+    std::vector<rfx_timer_pending> timers_pending;
     // grow-only workspace slots for the large, reused buffers (instance arrays of the count
     // stage): allocated once with hipMalloc, kept until the context dies
     struct WsSlot { void *p = nullptr; size_t bytes = 0; };
@@ -44,6 +53,7 @@ struct rfx_ctx {
         if (scan_fault) (void)hipHostFree(scan_fault);
         scan_fault = nullptr;
         scan_desc = nullptr; scan_ticket = nullptr; scan_desc_cap = 0;
+        timers_pending.clear();
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         ev_pool.clear(); ev_next = 0;
     }
@@ -87,6 +97,14 @@ struct rfx_ctx {
             return RFX_E_HIP;                                                             \
         }                                                                                 \
     } while (0)
+
+// The boundary keeps its word ("never aborts", include/reflexiv_hip.h): every extern "C" entry point is a function-try-block
+// that ends in one of these, so a C++ exception raised under it (std::bad_alloc from a vector or a map, std::system_error
+// from a thread, std::length_error ...) becomes RFX_E_HOST with its what() in rfx_last_error() instead of std::terminate
+// inside the JVM / Python process that loaded the library.
+int rfx_api_exception(rfx_ctx *ctx, const char *where) noexcept;
+#define RFX_API_CATCH(ctxexpr) catch (...) { return rfx_api_exception((ctxexpr), __func__); }
+#define RFX_API_CATCH_VOID(ctxexpr) catch (...) { (void)rfx_api_exception((ctxexpr), __func__); }
 
 #define RFX_TRY(call)                              \
     do {                                           \
@@ -175,22 +193,20 @@ struct ScopedTimer {
     void stop(int64_t launches = 1) {
         if (!on) return;
         (void)hipEventRecord(b, ctx->stream);
-        pending().push_back({name, a, b, launches});
+        ctx->timers_pending.push_back({name, a, b, launches});
         on = false;
     }
     ~ScopedTimer() { stop(); }
-    struct Pending { const char *name; hipEvent_t a, b; int64_t launches; };
-    static std::vector<Pending> &pending() { static thread_local std::vector<Pending> v; return v; }
-    // call after a stream sync
+    // call after a stream sync (a timer whose events have not completed is dropped, not waited for)
     static void collect(rfx_ctx *ctx) {
-        for (auto &p : pending()) {
+        for (auto &p : ctx->timers_pending) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
                 ctx->timing[p.name].ms += ms;
                 ctx->timing[p.name].launches += p.launches;
             }
         }
-        pending().clear();
+        ctx->timers_pending.clear();
         ctx->ev_next = 0;                  // the pool's events are free again
     }
 };

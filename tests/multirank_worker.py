@@ -1,7 +1,11 @@
 """One rank of tests/test_gpu_multirank.py: `python multirank_worker.py RANK WORLD WORKDIR` -- every rank is a process of
 its own with its own context and communicator on cuda:0 (RCCL replaced by tests/fake_rccl through RFX_RCCL_LIB, because
 RCCL refuses two ranks on one device).  Rank 0 checks the shards against the fused one-GPU count of ALL ranks' reads and
-against the oracle, and writes WORKDIR/ok."""
+against the oracle, and writes WORKDIR/ok.
+
+`python multirank_worker.py threads WORLD WORKDIR`: the same ranks as THREADS of this one process ("one process or thread
+per GPU", include/reflexiv_hip.h) -- how a world of 8, the node size of BASELINE configs 3-5, runs on a test box whose
+process guard allows six GPU processes."""
 import os
 import sys
 import time
@@ -13,7 +17,36 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 
 def main():
-    rank, world, work = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    if sys.argv[1] == "threads":
+        return main_threads(int(sys.argv[2]), sys.argv[3])
+    run_rank(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3])
+
+
+def main_threads(world, work):
+    import threading
+    import traceback
+    import torch
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda")                                # one thread makes the process's HIP context
+    failed = []
+
+    def body(r):
+        try:
+            run_rank(r, world, work, cases=((31, 16), (63, 2)), n_reads=30_000)
+        except BaseException:                                    # noqa: BLE001 -- reported below, with the rank
+            failed.append((r, traceback.format_exc()))
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for r, tb in failed:
+        print(f"--- rank {r} of {world} (thread) failed:\n{tb}", flush=True)
+    sys.exit(1 if failed else 0)
+
+
+def run_rank(rank, world, work, cases=((31, 1), (31, 4), (25, 3), (63, 2), (47, 4)), n_reads=60_000):
     import torch
     import reflexiv_amd
     from reflexiv_amd import Reflexiv
@@ -34,7 +67,7 @@ def main():
     rfx = Reflexiv(0)
     rfx.comm_init(uid, rank, world)
 
-    seed, G, n_reads, L = 77, 200_000, 60_000, 150            # per rank
+    seed, G, L = 77, 200_000, 150                              # n_reads per rank
     wpr = (L + 31) // 32
     dg = torch.empty((G + 31) // 32, dtype=torch.int64, device="cuda")
     dw = torch.empty(n_reads * wpr, dtype=torch.int64, device="cuda")
@@ -61,7 +94,7 @@ def main():
         wk31, wc31, wd31 = OR.count_filter(okm, cover)
         want31 = [len(okm), wd31, len(wk31)]
         del ob, oo, okm
-    for k, gens in ((31, 1), (31, 4), (25, 3), (63, 2), (47, 4)):
+    for k, gens in cases:
         want = want31 if (rank == 0 and k == 31) else None
         wide = k > 32
         W = 2 if wide else 1
@@ -130,6 +163,24 @@ def main():
         assert (text, nc, trace) == (otext, onc, otrace) and text.startswith(">Contig-4558-0\n")
     else:
         assert text == "" and nc == 0
+    if world > 1:
+        #  rank 0 brings NO reads and a text buffer that is too short: RFX_E_CAP must come back on every rank,
+        # with the length rank 0 needs, so that all of them repeat the collective together (rank 0 alone used to wait for
+        # ever in the first all-reduce); an empty rank also sends nothing and receives its whole shard (receive buffer grown
+        # by agreement)
+        if rank == 0:
+            mb2, mo2 = np.zeros(0, np.uint8), np.zeros(1, np.int64)
+        else:
+            mine = np.arange(rank - 1, nr, world - 1)
+            mb2 = np.concatenate([bases[off[i]:off[i + 1]] for i in mine])
+            mo2 = np.zeros(len(mine) + 1, np.int64)
+            mo2[1:] = np.cumsum(off[mine + 1] - off[mine])
+        text2, nc2, trace2, tot2 = rfx.sharded_assemble_reads(mb2, mo2, prm, generations=2, text_cap=1000)
+        assert rfx.text_retries == 1, rfx.text_retries          # on EVERY rank
+        if rank == 0:
+            assert tot2 == tot and (text2, nc2, trace2) == (otext, onc, otrace)
+        else:
+            assert text2 == "" and nc2 == 0
     rfx.comm_all_reduce([1])                                   # nobody leaves while a peer still reads its files
     rfx.close()
     with open(os.path.join(work, f"ok{rank}"), "w") as f:

@@ -82,3 +82,75 @@ def test_rccl_stand_in_of_the_multirank_tests_exports_what_the_library_binds():
     assert len(names) >= 10
     for n in names:
         assert hasattr(shim, n), n
+
+
+def test_every_entry_point_is_a_function_try_block():
+    """"never aborts" (include/reflexiv_hip.h): every extern "C" definition with a body that can throw ends in RFX_API_CATCH --
+    a C++ exception (std::bad_alloc from a vector, std::system_error from a thread) becomes RFX_E_HOST with its what() in
+    rfx_last_error(), not std::terminate inside the JVM that loaded the JNI shim."""
+    src_dir = os.path.join(ROOT, "reflexiv_amd", "csrc")
+    exported = set(declared_functions())
+    seen = set()
+    for f in sorted(os.listdir(src_dir)):
+        if not f.endswith(".hip"):
+            continue
+        lines = open(os.path.join(src_dir, f)).read().split("\n")
+        for i, ln in enumerate(lines):
+            m = re.match(r"^(?:int|void|int64_t|void \*|const char \*) ?\*?(rfx_[a-z0-9_]+)\(", ln)
+            if not m or m.group(1) not in exported:
+                continue
+            name = m.group(1)
+            seen.add(name)
+            j = i
+            while not lines[j].rstrip().endswith(("{", "}")):
+                j += 1
+            if lines[j].rstrip().endswith("}") and j == i:
+                body = ln[ln.index("{"):]
+                assert not re.search(r"\bnew\b|std::|\.push_back|\.alloc\(", body), (f, name, "one-line body that may throw")
+                continue
+            if name == "rfx_last_error":                    # (catches inside)
+                continue
+            assert lines[j].rstrip().endswith("try {"), (f, name)
+            e = j + 1
+            while not lines[e].startswith("}"):
+                e += 1
+            assert "RFX_API_CATCH" in lines[e], (f, name)
+    assert seen == exported, sorted(exported - seen)
+
+
+def test_exception_barrier_turns_a_cpp_exception_into_a_status(tmp_path, so):
+    """The barrier itself, exercised on the CPU: a probe entry point written like the library's (function-try-block +
+    RFX_API_CATCH) throws std::bad_alloc, std::length_error and a non-std object; each comes back as RFX_E_HOST with the
+    text in the context's last_error."""
+    import subprocess
+    probe = tmp_path / "probe.cpp"
+    probe.write_text(r'''
+#include <new>
+#include <stdexcept>
+#include <vector>
+#include "rfx_internal.h"
+extern "C" int probe_throw(rfx_ctx *ctx, int what) try {
+    if (what == 0) throw std::bad_alloc();
+    if (what == 1) { std::vector<int> v; v.reserve((size_t)-1); }
+    if (what == 2) throw 42;
+    return RFX_OK;
+} RFX_API_CATCH(ctx)
+extern "C" rfx_ctx *probe_ctx() { return new rfx_ctx(); }
+extern "C" const char *probe_err(rfx_ctx *c) { return c->last_error.c_str(); }
+''')
+    out = tmp_path / "libprobe.so"
+    src_dir = os.path.join(ROOT, "reflexiv_amd", "csrc")
+    subprocess.run(["g++", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + src_dir,
+                    str(probe), "-o", str(out), "-L" + os.path.join(ROOT, "reflexiv_amd"), "-lreflexiv_hip",
+                    "-Wl,-rpath," + os.path.join(ROOT, "reflexiv_amd")], check=True, capture_output=True)
+    P = ctypes.CDLL(str(out))
+    P.probe_ctx.restype = ctypes.c_void_p
+    P.probe_err.restype = ctypes.c_char_p
+    P.probe_err.argtypes = [ctypes.c_void_p]
+    P.probe_throw.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    c = P.probe_ctx()
+    assert P.probe_throw(c, 3) == _lib.RFX_OK
+    for what, text in ((0, b"bad_alloc"), (1, b"vector"), (2, b"unknown C++ exception")):
+        assert P.probe_throw(c, what) == _lib.RFX_E_HOST == -7
+        assert text in P.probe_err(c) and b"probe_throw" in P.probe_err(c), P.probe_err(c)
+    assert P.probe_throw(None, 0) == _lib.RFX_E_HOST           # no context to carry the text: still a status

@@ -191,3 +191,46 @@ def test_sharded_assemble_reads_one_rank_matches_the_documented_example(golden_d
         assert tot == [len(km), wd, len(wk)] and (text, nc, trace) == (otext, onc, otrace)
     finally:
         rfx.close()
+
+
+def test_contexts_and_communicators_made_and_destroyed_in_one_process(golden_dir):
+    """What a Spark executor does job after job: a fresh context + communicator, some work, both destroyed -- six times in
+    this process, ending with the call that aborted in round 3 (gpurun_out/s3_both.log: SIGABRT inside
+    rfx_sharded_assemble_reads, the ninth test of this module when every test made its own context).  The cause was in
+    this library, not in RCCL: stopped kernel timers lived in a thread_local list, the k > 31 merge of
+    rfx_dev_sharded_count stopped one without ever collecting it, the context died with its events, and the NEXT context's
+    first collect() handed the destroyed events to hipEventElapsedTime.  Timers now belong to their context
+    (rfx_ctx::timers_pending); this test walks exactly that sequence."""
+    import torch
+    import reflexiv_amd
+    from oracle import oracle as O
+    os.environ["RFX_BACKTRACE"] = "1"                      # a host crash inside the library names its frames
+    ex = np.load(os.path.join(golden_dir, "example.npz"))
+    try:
+        for round_ in range(6):
+            rfx = reflexiv_amd.Reflexiv()
+            rfx.comm_init(reflexiv_amd.Reflexiv.comm_unique_id(), 0, 1)
+            try:
+                if round_ < 5:
+                    # k = 63 in 4 generations: the merge of the generations' shards is order_wide2, whose "sort" timer nobody collected
+                    seed, G, n_reads, L = 40 + round_, 200_000, 100_000 + 20_000 * round_, 150
+                    dw, wpr = reads_on_device(rfx, seed, G, n_reads, L)
+                    k = 63 if round_ % 2 == 0 else 40
+                    cap = rfx.kmers_per_read_w(L, k) * n_reads // 2
+                    sk = torch.empty(cap * 2, dtype=torch.int64, device="cuda"); sc = torch.empty(cap, dtype=torch.int64, device="cuda")
+                    dk = torch.empty(cap * 2, dtype=torch.int64, device="cuda"); dc = torch.empty(cap, dtype=torch.int64, device="cuda")
+                    torch.cuda.synchronize()
+                    ms, tot = rfx.sharded_count_dev(dw.data_ptr(), n_reads, wpr, L, k, sk.data_ptr(), sc.data_ptr(), cap, 3, generations=4)
+                    m, nd, inst = rfx.count_reads_w_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), cap, 3)
+                    assert (ms, tot) == (m, [inst, nd, m]) and torch.equal(sk[:m * 2], dk[:m * 2]) and torch.equal(sc[:m], dc[:m])
+                    assert rfx.workspace_bytes() > 0
+                    rfx.trim()
+                    assert rfx.workspace_bytes() == 0
+                else:
+                    prm = reflexiv_amd.default_params(min_cov=3, partitions=4, twin=reflexiv_amd.TWIN_RDD)
+                    text, nc, trace, tot = rfx.sharded_assemble_reads(ex["bases"], ex["read_off"], prm, generations=4)
+                    assert nc == 2 and text.startswith(">Contig-4558-0\n")
+            finally:
+                rfx.close()
+    finally:
+        os.environ.pop("RFX_BACKTRACE", None)

@@ -46,6 +46,18 @@ def test_sharded_count_and_assemble_on_several_ranks(tmp_path, world, limit, swe
     assert not leftovers, leftovers
 
 
+def test_world_of_eight_as_threads_of_one_process(tmp_path):
+    """The node size of BASELINE configs 3-5: 8 ranks (threads of ONE process, each with its context + communicator on
+    cuda:0 -- the box's process guard allows six GPU processes).  Exercises the 8-row count matrix with real peers, 8 x 8
+    receive offsets, and the G * world <= 64 cap (generations = 16 asked, 8 taken)."""
+    env = dict(os.environ, RFX_RCCL_LIB=build_shim(), HSA_ENABLE_IPC_MODE_LEGACY="0", FAKE_RCCL_TIMEOUT_S="120", RFX_BACKTRACE="1")
+    p = subprocess.run([sys.executable, os.path.join(HERE, "multirank_worker.py"), "threads", "8", str(tmp_path)], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0 and all(os.path.exists(tmp_path / f"ok{r}") for r in range(8)), p.stdout[-4000:]
+    leftovers = [f for f in os.listdir("/dev/shm") if f.startswith("frccl-")]
+    assert not leftovers, leftovers
+
+
 def bench_line(extra, env, nproc):
     root = os.path.dirname(HERE)
     cmd = [sys.executable, os.path.join(root, "bench.py")] + extra

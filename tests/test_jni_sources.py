@@ -141,3 +141,19 @@ def test_driver_keeps_the_reference_operator_sequence():
             "saveAsTextFile"]
     flat = [x for x in flat if x not in ("JavaSparkContext",)]
     assert flat == want, flat
+
+
+def test_jni_shim_compiles_against_the_jni_prototypes():
+    """gcc -fsyntax-only of jni/reflexiv_jni.c against tests/jni_stub/jni.h (the JNI specification's prototypes for the
+    functions the shim uses; test-only, there is no JDK here): argument counts and types of every JNI and rfx_* call."""
+    import subprocess
+    r = subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-I" + os.path.join(ROOT, "tests", "jni_stub"),
+                        "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "jni", "reflexiv_jni.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_no_critical_region_around_gpu_work():
+    """GetPrimitiveArrayCritical blocks the collector and forbids blocking calls; every native method here waits for the GPU
+    (the sharded ones for other tasks too: ADVICE r03, a deadlock with several tasks in one JVM)."""
+    src = strip_comments(read("jni", "reflexiv_jni.c"))
+    assert "PrimitiveArrayCritical" not in src

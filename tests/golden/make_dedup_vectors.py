@@ -155,13 +155,28 @@ def pack_strings(strs):
     return np.frombuffer("".join(strs).encode(), np.uint8), off
 
 
+def run_case(arg):
+    ci, kind, contigs = arg
+    trace = {} if ci in (0, 1) else None
+    rounds, text = dedup_pipeline(contigs, trace)
+    return ci, kind, contigs, trace, rounds, text
+
+
 def main():
     rng = np.random.default_rng(20261005)
     out = {}
-    for ci, kind in enumerate(("both_strands", "overhangs", "mutated", "shuffled", "shuffled")):
-        contigs = make_case(rng, kind)
-        trace = {} if ci in (0, 1) else None
-        rounds, text = dedup_pipeline(contigs, trace)
+    # the inputs first (they share one generator, in this order); the cases are then independent: --jobs N runs them in N
+    # processes (tests/test_java2py.py regenerates with 5), the arrays are the same either way
+    cases = [(ci, kind, make_case(rng, kind)) for ci, kind in enumerate(("both_strands", "overhangs", "mutated", "shuffled", "shuffled"))]
+    jobs = int(sys.argv[sys.argv.index("--jobs") + 1]) if "--jobs" in sys.argv else 1
+    if jobs > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(jobs) as pool:
+            results = pool.map(run_case, sorted(cases, key=lambda c: -sum(map(len, c[2]))), chunksize=1)
+        results.sort(key=lambda r: r[0])
+    else:
+        results = [run_case(c) for c in cases]
+    for ci, kind, contigs, trace, rounds, text in results:
         nm = f"case{ci}_{kind}"
         out[nm + "/in"], out[nm + "/in_off"] = pack_strings(contigs)
         for r, strs in enumerate(rounds):
@@ -174,7 +189,7 @@ def main():
                 out[f"{nm}/r{rnd}_candidates"] = np.array(trace[f"r{rnd}/candidates"], np.uint64)
         print(nm, len(contigs), "contigs", sum(map(len, contigs)), "bases ->", [len(r) for r in rounds],
               sum(len(s) for s in rounds[-1]), "bases", flush=True)
-    path = os.path.join(HERE, "dedup_vectors.npz")
+    path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(HERE, "dedup_vectors.npz")     # (--out: tests/test_java2py.py regenerates into a scratch directory)
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes", hashlib.sha256(open(path, "rb").read()).hexdigest())
 

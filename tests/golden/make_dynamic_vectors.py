@@ -190,7 +190,7 @@ def main():
         out[name + "/final"] = pack_rows(fin)
         lens = sorted((len(r[0]) + len(r[2]) for r in fin), reverse=True)
         print(name, len(in_rows), "k-mers ->", len(ff), "after four passes ->", len(fin), "after iterations", (start, end), "longest", lens[:4], flush=True)
-    path = os.path.join(HERE, "dynamic_vectors.npz")
+    path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(HERE, "dynamic_vectors.npz")     # (--out: tests/test_java2py.py regenerates into a scratch directory)
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes", hashlib.sha256(open(path, "rb").read()).hexdigest())
 

@@ -558,7 +558,7 @@ def fuzz_fork(store, name, fam, cls, k, reflected, cases, seed, **pk):
 
 # ----------------------------------------------------------------------------------------------- main
 def main():
-    out_path = os.path.join(HERE, "reference_vectors.npz")
+    out_path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(HERE, "reference_vectors.npz")     # (--out: tests/test_java2py.py regenerates into a scratch directory)
     st = Store()
     rng = np.random.default_rng(20261004)
 

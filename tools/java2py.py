@@ -715,10 +715,15 @@ class Gen:
         raise SyntaxError(f"java2py: expr {k}")
 
     # -- statements
-    def store(self, ind, lhs, rhs_code):
+    def store(self, ind, lhs, rhs_code, compound=False):
+        """plain assignment: the value must already fit the declared type (_I raises on a long, as javac rejects it);
+        compound assignment `E1 op= E2` is `E1 = (T)((E1) op (E2))` with T the type of E1 (JLS 15.26.2): an implicit
+        NARROWING cast, likewise ++ / -- (15.14.2, 15.15.1)"""
         t = self.var_type(lhs)
         conv = _elem_conv(t) if t else None
-        if conv:
+        if conv and compound:
+            rhs_code = f"{'_cast_int' if conv == '_I' else '_cast_long'}({rhs_code})"
+        elif conv:
             rhs_code = f"{conv}({rhs_code})"
         elif t == "char":
             rhs_code = f"_cast_char({rhs_code})"
@@ -738,11 +743,13 @@ class Gen:
                     return self.store(ind, lhs, self.ex(rhs))
                 return self.store(ind, lhs, self.ex(rhs))
             bop = op[:-1]
-            return self.store(ind, lhs, self.ex(("bin", bop, lhs, ("paren", rhs))))
+            if self.var_type(lhs) == "String" and bop != "+":
+                raise SyntaxError("java2py: String " + op)
+            return self.store(ind, lhs, self.ex(("bin", bop, lhs, ("paren", rhs))), compound=self.var_type(lhs) != "String")
         if k in ("postinc", "preinc"):
             lhs = e[2]
             bop = "+" if e[1] == "++" else "-"
-            return self.store(ind, lhs, self.ex(("bin", bop, lhs, ("num", "1"))))
+            return self.store(ind, lhs, self.ex(("bin", bop, lhs, ("num", "1"))), compound=True)
         if k in ("call", "new"):
             return self.emit(ind, self.ex(e))
         raise SyntaxError(f"java2py: expression statement {k}")
@@ -809,7 +816,12 @@ class Gen:
             self.body(ind + 1, s[4], [])
             self.scopes.pop()
         elif k == "return":
-            self.emit(ind, "return" + (" " + self.ex(s[1]) if s[1] is not None else ""))
+            if s[1] is None:
+                self.emit(ind, "return")
+            else:
+                conv = _elem_conv(self.cur_rtype) if getattr(self, "cur_rtype", None) in ("int", "long", "short", "byte") else None
+                v = self.ex(s[1])
+                self.emit(ind, f"return {conv}({v})" if conv else f"return {v}")
         elif k == "break":
             self.emit(ind, "break")
         elif k == "continue":
@@ -860,6 +872,7 @@ class Gen:
             if name == "<init>":
                 continue
             self.scopes = [{n: t for t, n in params}]
+            self.cur_rtype = rtype
             self.emit(1, f"def {name}(self{''.join(', ' + n for _, n in params)}):")
             n0 = len(self.lines)
             # parameters of primitive type arrive converted (callers may pass a narrower type)
@@ -1005,6 +1018,22 @@ class Ch:
     def __repr__(self):
         return repr(self.c)
 
+    # binary numeric promotion (JLS 5.6.2): a char operand is an int
+    def _j(self): return J(ord(self.c), 32)
+    def __add__(self, o): return self._j() + o
+    def __radd__(self, o): return J._o(o) + self._j()
+    def __sub__(self, o): return self._j() - o
+    def __rsub__(self, o): return J._o(o) - self._j()
+    def __mul__(self, o): return self._j() * o
+    def __rmul__(self, o): return J._o(o) * self._j()
+    def __and__(self, o): return self._j() & o
+    def __or__(self, o): return self._j() | o
+    def __xor__(self, o): return self._j() ^ o
+    def __lshift__(self, o): return self._j() << o
+    def __rshift__(self, o): return self._j() >> o
+    def __truediv__(self, o): return self._j() / o
+    def __mod__(self, o): return self._j() % o
+    def __index__(self): return ord(self.c)
     def __lt__(self, o): return ord(self.c) < _ordv(o)
     def __le__(self, o): return ord(self.c) <= _ordv(o)
     def __gt__(self, o): return ord(self.c) > _ordv(o)

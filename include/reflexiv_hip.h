@@ -378,13 +378,30 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *comm, const uint64_t *d_words,
                           int words_per_read, int read_len, int k, int front_clip, int end_clip, int generations, int min_cov,
                           int max_cov, int twin, uint64_t *d_out_keys, void *d_out_counts, int64_t cap, int64_t *out_n,
                           int64_t *out_totals);
+/* The extend stage on several GPUs -- every sortByKey of the reference's driver (P/ReflexivMain.java:179,191,211,235,247,286;
+ * k > 31: P/ReflexivDSMain64.java:504-563) as a range shuffle of whole records over RCCL: local stable sort, rank splitters
+ * from ONE all-gather of a device-built sample, one count matrix, one all-to-all(v), local stable sort; the order contract's
+ * logical partitions are cut out of the GLOBAL sorted sequence (any prm->partitions with any number of ranks: a partition may
+ * go on on the next rank, the parity it brings along travels in one small all-gather); count() of the stop
+ * rule and the trace are one all-reduce per pass.  d_keys / d_counts: this rank's shard of the filtered (k-mer, count) list
+ * in HBM, any order (k <= 31: one word per k-mer, as rfx_dev_assemble; k = 32..124: (k-1)/31+1 words of 31 bases, as
+ * rfx_dev_assemble_w).  The record set stays sharded while it has more than `gather_below` records over all ranks
+ * (< 0: RFX_SHARD_GATHER_BELOW or 32 Mi; 0: to the end of the loop); then -- and before the k > 31 from-counts extras -- it is
+ * gathered on rank 0, where the one-GPU driver takes the loop up.  The contig text (identical to rfx_dev_assemble[_w] on one
+ * GPU for the same prm->partitions), *out_contigs and the trace arrive on rank 0 (*out_len = 0 elsewhere).  Collective: a
+ * failure of any rank fails the call on every rank (RFX_E_STATE on the others), and RFX_E_CAP -- the text buffer of rank 0
+ * is too short -- comes back on EVERY rank with *out_len = the length needed, so that retries re-enter together. */
+int rfx_dev_sharded_assemble(rfx_ctx *ctx, rfx_comm *comm, const uint64_t *d_keys, const int32_t *d_counts, int64_t n,
+                             const rfx_params *prm, int64_t gather_below, char *out, int64_t cap, int64_t *out_len,
+                             int64_t *out_contigs, int64_t *trace, int64_t trace_cap, int64_t *n_trace);
 /* The whole resident path on several GPUs from ASCII reads in host memory (the multi-GPU rfx_assemble_reads; what one
  * Spark executor per GPU calls with ITS partition of the reads): upload + 2-bit encode (any read lengths), the sharded
- * count above, the shards gathered on rank 0 and put in ascending order, rfx_dev_assemble there.  The contig text
- * arrives on rank 0 (*out_len = 0 on the others).  k = 21..31.  Collective. */
+ * count above, then rfx_dev_sharded_assemble (gather_below as there: a bacterial genome's survivors go to rank 0 at once,
+ * a record set that does not fit one GPU stays sharded).  The contig text arrives on rank 0 (*out_len = 0 on the others;
+ * RFX_E_CAP on every rank, see there).  k = 21..31.  Collective. */
 int rfx_sharded_assemble_reads(rfx_ctx *ctx, rfx_comm *comm, const uint8_t *bases, const int64_t *read_off, int64_t n_reads,
-                               const rfx_params *prm, int generations, char *out, int64_t cap, int64_t *out_len,
-                               int64_t *out_contigs, int64_t *trace, int64_t trace_cap, int64_t *n_trace,
+                               const rfx_params *prm, int generations, int64_t gather_below, char *out, int64_t cap,
+                               int64_t *out_len, int64_t *out_contigs, int64_t *trace, int64_t trace_cap, int64_t *n_trace,
                                int64_t *out_totals);
 int rfx_dev_gather_shards(rfx_ctx *ctx, rfx_comm *comm, const uint64_t *d_keys, const void *d_counts, int64_t n,
                           int key_words, int count_bytes, int root, uint64_t *d_out_keys, void *d_out_counts, int64_t cap,

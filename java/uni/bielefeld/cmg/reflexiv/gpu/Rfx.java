@@ -89,6 +89,8 @@ public final class Rfx {
     public static native long commInit(long ctx, byte[] uniqueId, int rank, int world);
     public static native void commDestroy(long comm);
     public static native void commAllReduce(long ctx, long comm, long[] vals, int op);
+    // gatherBelow: the extend stage (every sortByKey) stays range-sharded over the GPUs while the record set has more records
+    // than this; then rank 0 finishes (-1: the library's default, 0: never gather before the loop ends)
     public static native byte[] shardedAssembleReads(long ctx, long comm, byte[] bases, long[] readOff, int[] params, int generations,
-                                                     long[] totals);
+                                                     long gatherBelow, long[] totals);
 }

@@ -214,7 +214,7 @@ public class ReflexivGpuMain implements Serializable {
             final long comm = Rfx.commInit(ctx, java.util.Base64.getDecoder().decode(all[0]), rank, nGpus);
             List<String> out = new ArrayList<String>();
             try {
-                byte[] text = Rfx.shardedAssembleReads(ctx, comm, bases.toByteArray(), readOff, prm, 4, new long[3]);
+                byte[] text = Rfx.shardedAssembleReads(ctx, comm, bases.toByteArray(), readOff, prm, 4, -1L, new long[3]);
                 String s = new String(text, StandardCharsets.US_ASCII);
                 out.add(s.endsWith("\n") ? s.substring(0, s.length() - 1) : s);
             } finally {

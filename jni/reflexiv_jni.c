@@ -480,11 +480,12 @@ JNIEXPORT void JNICALL RFX_CLASS(commAllReduce)(JNIEnv *env, jclass c, jlong h, 
     (*env)->SetLongArrayRegion(env, vals, 0, n, (const jlong *)v);
 }
 
-/* The whole path on several GPUs (P/ReflexivMain.java:95-322 with the shuffle of :155 over RCCL): every task passes ITS
+/* The whole path on several GPUs (P/ReflexivMain.java:95-322 with the shuffles of :155 AND of every sortByKey, :179-286,
+ * over RCCL; gatherBelow as rfx_dev_sharded_assemble's: -1 = default): every task passes ITS
  * partition's reads; the contig text comes back on rank 0 (an empty array on the others).  params: int[13]; k = 21..31.
  * totals (long[3], optional): k-mer instances, distinct k-mers, k-mers kept -- over all tasks. */
 JNIEXPORT jbyteArray JNICALL RFX_CLASS(shardedAssembleReads)(JNIEnv *env, jclass c, jlong h, jlong comm, jbyteArray bases, jlongArray readOff,
-                                                            jintArray params, jint generations, jlongArray totals) {
+                                                            jintArray params, jint generations, jlong gatherBelow, jlongArray totals) {
     (void)c;
     rfx_ctx *ctx = ctx_of(h);
     if ((*env)->GetArrayLength(env, params) != RFX_N_PARAMS) { throw_rfx(env, ctx, RFX_E_ARG, "rfx_sharded_assemble_reads (params: Rfx.defaultParams())"); return NULL; }
@@ -509,7 +510,7 @@ JNIEXPORT jbyteArray JNICALL RFX_CLASS(shardedAssembleReads)(JNIEnv *env, jclass
         }
         int64_t len = 0, nc = 0, ntr = 0, tot[3] = {0, 0, 0};
         const int st = rfx_sharded_assemble_reads(ctx, (rfx_comm *)(intptr_t)comm, (const uint8_t *)b, (const int64_t *)o, nOff - 1, &prm,
-                                                  generations, buf, cap, &len, &nc, NULL, 0, &ntr, tot);
+                                                  generations, (int64_t)gatherBelow, buf, cap, &len, &nc, NULL, 0, &ntr, tot);
         (*env)->ReleaseLongArrayElements(env, readOff, o, JNI_ABORT);
         (*env)->ReleaseByteArrayElements(env, bases, b, JNI_ABORT);
         /* RFX_E_CAP is returned on EVERY rank with the length rank 0 needs, so every task repeats the collective together */

@@ -773,7 +773,27 @@ class Reflexiv:
         self._check(st, "rfx_dev_sharded_count")
         return int(n.value), [int(x) for x in tot]
 
-    def sharded_assemble_reads(self, bases, read_off, prm: Params, generations: int = 4, text_cap: int = None):
+    def sharded_assemble_dev(self, d_keys: int, d_counts: int, n: int, prm: Params, gather_below: int = -1, text_cap: int = None):
+        """collective (rfx_dev_sharded_assemble): this rank's shard of the filtered (k-mer, count) list in HBM -> (text, n_contigs,
+        trace) on rank 0 ("" elsewhere), the extend stage range-sharded over the ranks while the record set has more than
+        gather_below records (-1: the library's default, 0: to the end of the loop)"""
+        trace = np.zeros(prm.max_iter + 8, np.int64)
+        cap = (1 << 20) + 64 * max(n, 1) if text_cap is None else int(text_cap)
+        self.text_retries = 0
+        while True:
+            buf = np.empty(max(cap, 1), np.uint8)
+            ln, nc, ntr = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+            st = self.L.rfx_dev_sharded_assemble(self.ctx, self.comm, C.c_void_p(d_keys), C.c_void_p(d_counts), C.c_int64(n), C.byref(prm),
+                                                 C.c_int64(gather_below), _p(buf), C.c_int64(cap), C.byref(ln), C.byref(nc), _p(trace),
+                                                 C.c_int64(len(trace)), C.byref(ntr))
+            if st == RFX_E_CAP and ln.value > cap:
+                cap = int(ln.value)
+                self.text_retries += 1
+                continue
+            self._check(st, "rfx_dev_sharded_assemble")
+            return bytes(buf[:ln.value]).decode(), int(nc.value), [int(x) for x in trace[:ntr.value]]
+
+    def sharded_assemble_reads(self, bases, read_off, prm: Params, generations: int = 4, text_cap: int = None, gather_below: int = -1):
         """collective (rfx_sharded_assemble_reads): this rank's ASCII reads -> (text, n_contigs, trace, totals); text on rank 0.
         A text buffer that is too short on rank 0 is RFX_E_CAP on EVERY rank (with the length rank 0 needs), so the retry below
         re-enters the collective on all ranks together; text_cap forces a first size (tests)."""
@@ -788,7 +808,7 @@ class Reflexiv:
             buf = np.empty(max(cap, 1), np.uint8)
             ln, nc, ntr = C.c_int64(0), C.c_int64(0), C.c_int64(0)
             st = self.L.rfx_sharded_assemble_reads(self.ctx, self.comm, _p(bases), _p(read_off), C.c_int64(n_reads), C.byref(prm),
-                                                   generations, _p(buf), C.c_int64(cap), C.byref(ln), C.byref(nc), _p(trace),
+                                                   generations, C.c_int64(gather_below), _p(buf), C.c_int64(cap), C.byref(ln), C.byref(nc), _p(trace),
                                                    C.c_int64(len(trace)), C.byref(ntr), tot)
             if st == RFX_E_CAP and ln.value > cap:
                 cap = int(ln.value)

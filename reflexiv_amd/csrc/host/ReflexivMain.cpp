@@ -422,7 +422,7 @@ std::string ReflexivMain::dedupContigText(const std::string &contigText) {
     return out;
 }
 
-std::string ReflexivMain::assemblyResidentSharded(const std::string &fastqText, int nGpus, std::vector<int64_t> *trace) {
+std::string ReflexivMain::assemblyResidentSharded(const std::string &fastqText, int nGpus, std::vector<int64_t> *trace, int64_t gatherBelow) {
     if (!param.bubble)
         throw std::runtime_error("-bubble (no fork filtering) is unusable in the reference too (SURVEY.md C.6)");
     std::vector<uint8_t> bases; std::vector<int64_t> readOff;
@@ -451,10 +451,10 @@ std::string ReflexivMain::assemblyResidentSharded(const std::string &fastqText, 
                 std::string out(r == 0 ? (size_t)3 * (size_t)(readOff[nr] - readOff[0]) + ((size_t)1 << 20) : (size_t)1 << 12, '\0');
                 int64_t len = 0, nc = 0, n_tr = 0, tot[3];
                 for (;;) {
-                    const int st = rfx_sharded_assemble_reads(c, comm, bases.data(), readOff.data() + a, b - a, &prm, 4, out.data(),
+                    const int st = rfx_sharded_assemble_reads(c, comm, bases.data(), readOff.data() + a, b - a, &prm, 4, gatherBelow, out.data(),
                                                               (int64_t)out.size(), &len, &nc, r == 0 ? tr.data() : nullptr,
                                                               r == 0 ? (int64_t)tr.size() : 0, &n_tr, tot);
-                    if (st == RFX_E_CAP && len > (int64_t)out.size()) { out.assign((size_t)len, '\0'); continue; }   // (rank 0 only: after the collectives)
+                    if (st == RFX_E_CAP && len > (int64_t)out.size()) { out.assign((size_t)len, '\0'); continue; }   // (on every rank at once: the retry is collective)
                     if (st != RFX_OK) throw std::runtime_error(std::string("rfx_sharded_assemble_reads: ") + rfx_last_error(c));
                     break;
                 }

@@ -123,7 +123,9 @@ public:
     // share of the reads to rfx_sharded_assemble_reads (the shuffle of reduceByKey, P/ReflexivMain.java:155, over RCCL)
     // P/ReflexivDSDynamicKmerDedup.java assemblyFromKmer (:138-339) on the contig text of a run: each contig once
     std::string dedupContigText(const std::string &contigText);
-    std::string assemblyResidentSharded(const std::string &fastqText, int nGpus, std::vector<int64_t> *trace = nullptr);
+    // gatherBelow: the extend stage stays range-sharded over the GPUs (sortByKey as an RCCL all-to-all) while the record set has
+    // more records than this (-1: the library's default; rfx_dev_sharded_assemble)
+    std::string assemblyResidentSharded(const std::string &fastqText, int nGpus, std::vector<int64_t> *trace = nullptr, int64_t gatherBelow = -1);
     // ReflexivCounter.assembly(): P/ReflexivCounter.java:109-191 -> lines "KMER,count"
     std::string counter(const std::string &fastqText);
     std::string assemblyFromCounts(const KmerBinaryRDD &counts, std::vector<int64_t> *trace = nullptr);

@@ -1031,14 +1031,18 @@ int rfx_last_count_timing(rfx_ctx *ctx, const char *name, float *ms, int64_t *la
     return RFX_OK;
 } RFX_API_CATCH(ctx)
 
+}  // extern "C"  (the driver below is C++: rfx_shard.hip calls it too)
+
 // Driver: P/ReflexivMain.java:168-310 (DS P/ReflexivDSMain.java:221-352); wide = the k > 31 driver
 // ReflexivDSMain64.assemblyFromKmer (P/ReflexivDSMain64.java:374-826) without the extras of :584-619 and :672-712
 // (SURVEY.md 8f-3): its loop :621-661 iterates all records, checks the count from minimumIteration + 3 on, the
 // first repeat of the count flips param.scramble 2 -> 3 (every later pass starts its marker at 1, :7484-7486) and
 // only the second stops; the survivors are sorted once more before they become text (:714).
-static int assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const int32_t *d_counts, int64_t n,
-                         const rfx_params *prm, char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs,
-                         int64_t *trace, int64_t trace_cap, int64_t *n_trace) {
+// resume: the loop taken up where the sharded driver (rfx_shard.hip) left it -- its record set gathered on this rank in
+// global arrival order, `passes_done` passes behind it, the driver's variables as they stood.  d_keys / d_counts / n unused.
+int rfx::assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const int32_t *d_counts, int64_t n,
+                       const rfx_params *prm, char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs,
+                       int64_t *trace, int64_t trace_cap, int64_t *n_trace, rfx::AsmResume *resume) {
     if (!ctx || !prm || !out_len || n < 0) return RFX_E_ARG;
     if (wide) { RFX_TRY(check_k_rec(prm->k)); if (prm->k <= 31) return RFX_E_ARG; }
     else RFX_TRY(check_k(prm->k));
@@ -1047,13 +1051,13 @@ static int assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const 
     int P = prm->partitions > 0 ? prm->partitions : 1;
     const int key_bits = 2 * (k - 1);
     const int kw = sub_words(k);
-    int64_t nt = 0;
+    int64_t nt = resume ? resume->nt : 0;
     DevRecords a, b;
     DevBuf ps, ops;
     // two alternating bump arenas hold every temporary and record set of a pass / stage
     Arena arena[2];
     {
-        const size_t per = (size_t)(2 * n) * (176 + 24 * (size_t)(kw - 1)) + ((size_t)64 << 20);
+        const size_t per = (resume ? (size_t)(resume->recs->n + resume->recs->words) : (size_t)(2 * n)) * (176 + 24 * (size_t)(kw - 1)) + ((size_t)64 << 20);
         for (int i = 0; i < 2; i++) {
             arena[i].base = (char *)ctx->ws_get(2 + i, per);
             if (!arena[i].base) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
@@ -1066,6 +1070,7 @@ static int assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const 
     int arena_turn = 0;
     auto next_arena = [&]() { Arena *ar = &arena[arena_turn++ & 1]; ar->off = 0; tl_arena = ar; };
     next_arena();
+    if (!resume) {
     // KmerReverseComplement + ForwardSubKmerExtraction  :168-176
     RFX_TRY(rc_expand_subkmer(ctx, d_keys, d_counts, n, k, a));
     // sortByKey + FilterForkSubKmer[WithErrorCorrection]  :179-186
@@ -1084,6 +1089,13 @@ static int assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const 
     // kmerRandomReflection on the filter's output partitions  :204-205
     next_arena();
     RFX_TRY(random_reflection(ctx, b, ops.as<int64_t>(), P, k, a));
+    } else {
+        // (the gathered set lives in plain stream-ordered allocations, outside the arenas: the first sort reads it from there)
+        a.n = resume->recs->n; a.words = resume->recs->words; a.kw = resume->recs->kw;
+        a.key = std::move(resume->recs->key); a.marker = std::move(resume->recs->marker); a.ext_off = std::move(resume->recs->ext_off);
+        a.ext = std::move(resume->recs->ext); a.left = std::move(resume->recs->left); a.right = std::move(resume->recs->right);
+        P = resume->P;
+    }
 
     const bool verbose = getenv("RFX_TRACE") != nullptr;
     auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
@@ -1102,14 +1114,15 @@ static int assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const 
         nt++;
         return RFX_OK;
     };
-    int iterations = 0;
-    RFX_TRY(one_pass(0));                                                         // :221-222
-    for (int i = 1; i < 4; i++) { iterations++; RFX_TRY(one_pass(0)); }           // :233-241
-    iterations++;
-    RFX_TRY(one_pass(1));                                                         // :247-254
-    int partitionNumber = P;
-    int64_t contigNumber = 0;
-    int scramble = 2;                                                             // U/DefaultParam.java:131
+    int iterations = resume ? resume->iterations : 0;
+    // the five passes before the loop: :221-222 (stage 0), :233-241 (three more, iterations 1..3), :247-254 (first-array)
+    for (int np = resume ? resume->passes_done : 0; np < 5; np++) {
+        if (np >= 1) iterations++;
+        RFX_TRY(one_pass(np < 4 ? 0 : 1));
+    }
+    int partitionNumber = resume ? resume->partition_number : P;
+    int64_t contigNumber = resume ? resume->contig_number : 0;
+    int scramble = resume ? resume->scramble : 2;                                 // U/DefaultParam.java:131
     // once the record set is small the rest of the loop runs as two launches per pass with the loop state in HBM
     static const bool small_off = getenv("RFX_NO_SMALL_PASSES") != nullptr;
     const bool extras = wide && prm->extras != 0;
@@ -1298,16 +1311,18 @@ static int assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const 
     return len > cap ? RFX_E_CAP : RFX_OK;
 }
 
+extern "C" {
+
 int rfx_dev_assemble(rfx_ctx *ctx, const uint64_t *d_keys, const int32_t *d_counts, int64_t n,
                      const rfx_params *prm, char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs,
                      int64_t *trace, int64_t trace_cap, int64_t *n_trace) try {
-    return assemble_impl(ctx, false, d_keys, d_counts, n, prm, out, cap, out_len, out_contigs, trace, trace_cap, n_trace);
+    return assemble_impl(ctx, false, d_keys, d_counts, n, prm, out, cap, out_len, out_contigs, trace, trace_cap, n_trace, nullptr);
 } RFX_API_CATCH(ctx)
 
 int rfx_dev_assemble_w(rfx_ctx *ctx, const uint64_t *d_kmers, const int32_t *d_counts, int64_t n,
                        const rfx_params *prm, char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs,
                        int64_t *trace, int64_t trace_cap, int64_t *n_trace) try {
-    return assemble_impl(ctx, true, d_kmers, d_counts, n, prm, out, cap, out_len, out_contigs, trace, trace_cap, n_trace);
+    return assemble_impl(ctx, true, d_kmers, d_counts, n, prm, out, cap, out_len, out_contigs, trace, trace_cap, n_trace, nullptr);
 } RFX_API_CATCH(ctx)
 
 int rfx_assemble_counts_w(rfx_ctx *ctx, const uint64_t *kmers, const int32_t *counts, int64_t n, const rfx_params *prm,
@@ -1326,7 +1341,7 @@ int rfx_assemble_counts_w(rfx_ctx *ctx, const uint64_t *kmers, const int32_t *co
         RFX_HIP(hipMemcpyAsync(dc.p, counts, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
         RFX_TRY(sync_checked(ctx));
     }
-    return assemble_impl(ctx, true, dk.as<uint64_t>(), dc.as<int32_t>(), n, prm, out, cap, out_len, out_contigs, trace, trace_cap, n_trace);
+    return assemble_impl(ctx, true, dk.as<uint64_t>(), dc.as<int32_t>(), n, prm, out, cap, out_len, out_contigs, trace, trace_cap, n_trace, nullptr);
 } RFX_API_CATCH(ctx)
 
 int rfx_dev_order_kmers_w(rfx_ctx *ctx, uint64_t *d_keys, int64_t *d_counts, int64_t n, int k) try {

@@ -15,28 +15,8 @@
 // RCCL is bound at run time (dlopen): a host that already carries an RCCL (a PyTorch process does) keeps using that
 // one, a plain C / JNI host gets /opt/rocm/lib/librccl.so.1 -- and the library stays loadable where RCCL is absent.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
-#include <algorithm>
 #include <mutex>
-#include "rfx_internal.h"
-
-namespace {
-
-struct NcclApi {
-    void *h = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
-    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Gather_unused)() = nullptr;
-    const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    std::string error;
-};
+#include "rfx_comm.h"
 
 NcclApi &nccl() {
     static NcclApi api;
@@ -69,65 +49,9 @@ NcclApi &nccl() {
     return api;
 }
 
-}  // namespace
-
-constexpr int TABW = 512;                         // counts a rank contributes to the count matrix: (generation, owner) bins x pieces
-
-struct rfx_comm {
-    rfx_ctx *ctx = nullptr;
-    ncclComm_t comm = nullptr;
-    int rank = 0, world = 1;
-    hipStream_t xs = nullptr;                     // the exchange runs on its own stream
-    std::vector<hipEvent_t> ev;                   // one per generation: "generation g has landed"
-    hipEvent_t ev_ready = nullptr;                // "the send buffer is complete" (context stream -> exchange stream)
-    // grow-only device buffers: what this rank sends, what it receives (all generations back to back), small tables
-    void *send = nullptr, *recv = nullptr;
-    size_t send_bytes = 0, recv_bytes = 0;
-    int64_t *d_tab = nullptr;                     // [TABW] this rank's counts, [TABW * world] everybody's, then 16 scalars
-    int64_t *h_tab = nullptr;                     // pinned mirror
-    size_t tab_n = 0;
-    double units_per_read = 0;                    // capacity planning across calls (only ever grows)
-    int64_t bytes_bucketed = 0;                   // of the last call
-    size_t limit_bytes = (size_t)1 << 29;         // per peer and call (RCCL 2.26 corrupts messages above 1 GiB)
-    bool self_via_rccl = false;                   // tests: send the rank's own bucket through ncclSend / ncclRecv too
-    int virtual_world = 1;                        // one-rank rehearsal of an N-rank node (see rfx_dev_sharded_count)
-};
-
-#define RFX_NCCL(call)                                                                                     \
-    do {                                                                                                   \
-        ncclResult_t r_ = (call);                                                                          \
-        if (r_ != ncclSuccess) {                                                                           \
-            char buf_[512];                                                                                \
-            snprintf(buf_, sizeof buf_, "%s:%d: %s -> %s", __FILE__, __LINE__, #call,                      \
-                     nccl().GetErrorString ? nccl().GetErrorString(r_) : "RCCL error");                    \
-            if (ctx) ctx->last_error = buf_;                                                               \
-            return RFX_E_HIP;                                                                              \
-        }                                                                                                  \
-    } while (0)
-
-// An open ncclGroupStart is closed on every way out (an RFX_NCCL return from inside a group used to leave the communicator
-// in group state).
-struct GroupGuard {
-    bool open = false;
-    ~GroupGuard() { if (open && nccl().GroupEnd) (void)nccl().GroupEnd(); }
-};
-
-// The HIP "last error" of this thread after RCCL has run its own runtime calls on it (stream / event queries, pointer
-// attribute probes): hipGetLastError is thread-local, every HIP call of THIS library is checked where it is made and RCCL
-// reports its own failures through ncclResult_t, so what is found here was raised and handled inside RCCL.  It must not
-// reach the kernels' launch checks (hipGetLastError after a launch); it is read, and anything but the two codes RCCL's
-// polling leaves behind is kept for rfx_last_error() ("[after RCCL: ...]") instead of being thrown away unread.
-static void note_foreign_hip_error(rfx_ctx *ctx, const char *where) {
-    const hipError_t e = hipGetLastError();
-    if (e == hipSuccess || e == hipErrorNotReady || e == hipErrorPeerAccessAlreadyEnabled) return;
-    char buf[256];
-    snprintf(buf, sizeof buf, "%s: %s (%d)", where, hipGetErrorString(e), (int)e);
-    ctx->foreign_hip_error = buf;
-}
-
 // tuning / test knobs, read at every collective call (so that one communicator serves every case of a test run: RCCL does
 // not take kindly to many communicators made and destroyed in one process)
-static void comm_options(rfx_comm *c) {
+void comm_options(rfx_comm *c) {
     const char *e = getenv("RFX_COMM_LIMIT_BYTES");
     c->limit_bytes = e ? std::max<size_t>(1024, (size_t)atoll(e)) : (size_t)1 << 29;
     e = getenv("RFX_COMM_SELF_VIA_RCCL");
@@ -136,7 +60,7 @@ static void comm_options(rfx_comm *c) {
     c->virtual_world = e ? std::max(1, std::min(64, atoi(e))) : 1;
 }
 
-static int grow(rfx_ctx *ctx, void **p, size_t *have, size_t want, hipStream_t s1, hipStream_t s2) {
+int comm_grow(rfx_ctx *ctx, void **p, size_t *have, size_t want, hipStream_t s1, hipStream_t s2) {
     if (*p && *have >= want) return RFX_OK;
     if (*p) { RFX_HIP(hipStreamSynchronize(s1)); RFX_HIP(hipStreamSynchronize(s2)); RFX_HIP(hipFree(*p)); *p = nullptr; *have = 0; }
     const size_t bytes = want + (want >> 4) + (1 << 20);
@@ -194,6 +118,8 @@ void rfx_comm_destroy(rfx_comm *c) try {
     if (c->recv) (void)hipFree(c->recv);
     if (c->d_tab) (void)hipFree(c->d_tab);
     if (c->h_tab) (void)hipHostFree(c->h_tab);
+    if (c->d_sh) (void)hipFree(c->d_sh);
+    if (c->h_sh) (void)hipHostFree(c->h_sh);
     if (c->xs) (void)hipStreamDestroy(c->xs);
     delete c;
 } RFX_API_CATCH_VOID((c ? c->ctx : nullptr))
@@ -218,12 +144,14 @@ int rfx_comm_all_reduce_i64(rfx_comm *c, int64_t *h_vals, int n, int op) try {
     return RFX_OK;
 } RFX_API_CATCH((c ? c->ctx : nullptr))
 
+}  // extern "C"
+
 // One all-to-all(v) of 8-byte words, queued on the exchange stream: this rank sends send_cnt[p] words from
 // d_send + send_off[p] to peer p and receives recv_cnt[p] words from peer p at d_recv + recv_off[p].
 // What goes to (comes from) a peer may be S PIECES (the sweep's bins of an owner bucket, rfx::bucket_records_by_owner_sweep):
 // piece q of peer p is entry p * S + q of the four arrays, and a pair of ranks meets its pieces in the same order on both sides.
-static int alltoallv_words(rfx_comm *c, const uint64_t *d_send, const int64_t *send_off, const int64_t *send_cnt,
-                           uint64_t *d_recv, const int64_t *recv_off, const int64_t *recv_cnt, int64_t rounds, int S = 1) {
+int alltoallv_words(rfx_comm *c, const uint64_t *d_send, const int64_t *send_off, const int64_t *send_cnt,
+                    uint64_t *d_recv, const int64_t *recv_off, const int64_t *recv_cnt, int64_t rounds, int S, hipStream_t stream) {
     rfx_ctx *ctx = c->ctx;
     NcclApi &n = nccl();
     const int64_t limit = (int64_t)(c->limit_bytes / 8);
@@ -232,7 +160,7 @@ static int alltoallv_words(rfx_comm *c, const uint64_t *d_send, const int64_t *s
         for (int q = 0; q < S; q++)
             if (send_cnt[me * S + q] > 0)
                 RFX_HIP(hipMemcpyAsync(d_recv + recv_off[me * S + q], d_send + send_off[me * S + q], (size_t)send_cnt[me * S + q] * 8,
-                                       hipMemcpyDeviceToDevice, c->xs));
+                                       hipMemcpyDeviceToDevice, stream));
     for (int64_t j = 0; j < rounds; j++) {
         bool any = false;
         for (int i = 0; i < c->world * S && !any; i++)
@@ -247,8 +175,8 @@ static int alltoallv_words(rfx_comm *c, const uint64_t *d_send, const int64_t *s
                 const int i = p * S + q;
                 const int64_t s = std::max<int64_t>(0, std::min(limit, send_cnt[i] - j * limit));
                 const int64_t r = std::max<int64_t>(0, std::min(limit, recv_cnt[i] - j * limit));
-                if (s > 0) RFX_NCCL(n.Send(d_send + send_off[i] + j * limit, (size_t)s, ncclUint64, p, c->comm, c->xs));
-                if (r > 0) RFX_NCCL(n.Recv(d_recv + recv_off[i] + j * limit, (size_t)r, ncclUint64, p, c->comm, c->xs));
+                if (s > 0) RFX_NCCL(n.Send(d_send + send_off[i] + j * limit, (size_t)s, ncclUint64, p, c->comm, stream));
+                if (r > 0) RFX_NCCL(n.Recv(d_recv + recv_off[i] + j * limit, (size_t)r, ncclUint64, p, c->comm, stream));
             }
         }
         gg.open = false;
@@ -256,6 +184,8 @@ static int alltoallv_words(rfx_comm *c, const uint64_t *d_send, const int64_t *s
     }
     return RFX_OK;
 }
+
+extern "C" {
 
 static void add_timing(std::map<std::string, rfx_timing_slot> &acc, const std::map<std::string, rfx_timing_slot> &t) {
     for (auto &kv : t) { acc[kv.first].ms += kv.second.ms; acc[kv.first].launches += kv.second.launches; }
@@ -316,7 +246,7 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
         const bool try_sweep = !(getenv("RFX_COMM_SWEEP") && atoi(getenv("RFX_COMM_SWEEP")) == 0);
         for (int attempt = 0;; attempt++) {
             const int64_t cap_rec = (int64_t)(c->units_per_read * (double)n_reads) + 4096;
-            RFX_TRY(grow(ctx, &c->send, &c->send_bytes, (size_t)cap_rec * uw * 8, ctx->stream, c->xs));
+            RFX_TRY(comm_grow(ctx, &c->send, &c->send_bytes, (size_t)cap_rec * uw * 8, ctx->stream, c->xs));
             ctx->timing.clear();
             int st;
             bool swept = false;
@@ -356,7 +286,7 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
     // arrives is about what leaves), and its capacity travels with the counts: every rank can then see whether ANY
     // rank's buffer is short, and only then is there a second agreement (below) -- none in the steady state
     if (st_local == RFX_OK) {
-        const int sg = grow(ctx, &c->recv, &c->recv_bytes, (size_t)std::max<int64_t>(1, nrec + nrec / 8 + 4096) * uw * 8, ctx->stream, c->xs);
+        const int sg = comm_grow(ctx, &c->recv, &c->recv_bytes, (size_t)std::max<int64_t>(1, nrec + nrec / 8 + 4096) * uw * 8, ctx->stream, c->xs);
         if (sg != RFX_OK) st_local = sg;
     }
 
@@ -418,7 +348,7 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
     if (any_short) {                                                // the short ranks grow; everybody learns how that went
         int sg = RFX_OK;
         if (gen_off[G] > (int64_t)(c->recv_bytes / ((size_t)uw * 8)))
-            sg = grow(ctx, &c->recv, &c->recv_bytes, (size_t)std::max<int64_t>(1, gen_off[G]) * uw * 8, ctx->stream, c->xs);
+            sg = comm_grow(ctx, &c->recv, &c->recv_bytes, (size_t)std::max<int64_t>(1, gen_off[G]) * uw * 8, ctx->stream, c->xs);
         int64_t bad[1] = {sg != RFX_OK ? 1 : 0};
         RFX_TRY(rfx_comm_all_reduce_i64(c, bad, 1, 1));
         if (sg != RFX_OK) return sg;
@@ -430,7 +360,7 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
     RFX_HIP(hipStreamWaitEvent(c->xs, c->ev_ready, 0));
     for (int g = 0; g < G; g++) {
         RFX_TRY(alltoallv_words(c, (const uint64_t *)c->send, &soff[(size_t)g * world * SP], &scnt[(size_t)g * world * SP], (uint64_t *)c->recv,
-                                &roff[(size_t)g * world * SP], &rcnt[(size_t)g * world * SP], rounds, SP));
+                                &roff[(size_t)g * world * SP], &rcnt[(size_t)g * world * SP], rounds, SP, c->xs));
         RFX_HIP(hipEventRecord(c->ev[g], c->xs));
     }
 
@@ -570,7 +500,7 @@ int rfx_dev_gather_shards(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_keys, con
 // (any lengths), rfx_dev_sharded_count, the shards gathered on rank 0, the driver there (rfx_dev_assemble) -> the
 // contig text on rank 0 (*out_len = 0 elsewhere).  k = 21..31.  Collective.  out_totals[3] as rfx_dev_sharded_count.
 int rfx_sharded_assemble_reads(rfx_ctx *ctx, rfx_comm *c, const uint8_t *bases, const int64_t *read_off, int64_t n_reads,
-                               const rfx_params *prm, int generations, char *out, int64_t cap, int64_t *out_len,
+                               const rfx_params *prm, int generations, int64_t gather_below, char *out, int64_t cap, int64_t *out_len,
                                int64_t *out_contigs, int64_t *trace, int64_t trace_cap, int64_t *n_trace, int64_t *out_totals) try {
     if (!ctx || !c || c->ctx != ctx || !read_off || !prm || !out_len || n_reads < 0) return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
@@ -632,46 +562,12 @@ int rfx_sharded_assemble_reads(rfx_ctx *ctx, rfx_comm *c, const uint8_t *bases, 
     }
     if (out_totals) { out_totals[0] = tot[0]; out_totals[1] = tot[1]; out_totals[2] = tot[2]; }
     d_words.release(); d_len.release();
-    const int64_t all = tot[2];
-    int st_root = RFX_OK;
-    if (c->rank == 0) {
-        if (g_keys.alloc((size_t)std::max<int64_t>(1, all) * 8, ctx->stream) != hipSuccess ||
-            g_counts.alloc((size_t)std::max<int64_t>(1, all) * 4, ctx->stream) != hipSuccess) {
-            ctx->last_error = "rfx_sharded_assemble_reads: no room on rank 0 for the gathered shards";
-            st_root = RFX_E_HIP;
-        }
-    }
-    RFX_TRY(agree(st_root, "allocation on rank 0"));
-    int64_t got = 0;
-    RFX_TRY(rfx_dev_gather_shards(ctx, c, d_keys.as<uint64_t>(), d_counts.p, m, 1, 4, 0, g_keys.as<uint64_t>(), g_counts.p, all, &got));
-    // the driver runs on rank 0 only; its outcome is every rank's: a text buffer that is too short there is RFX_E_CAP
-    // with *out_len = the length needed on EVERY rank, so that the callers' "grow and call again" re-enters the
-    // collective together (rank 0 retrying alone waited for ever in the first all-reduce)
-    int64_t len = 0, ncont = 0, ntr = 0;
-    int st_asm = RFX_OK;
-    if (c->rank == 0) {
-        auto drive = [&]() -> int {
-            if (c->world > 1 && got > 1) {                             // hash shards -> ascending k-mer order (the order contract)
-                DevBuf tk, tv;
-                RFX_HIP(tk.alloc((size_t)got * 8, ctx->stream));
-                RFX_HIP(tv.alloc((size_t)got * 4, ctx->stream));
-                RFX_TRY(rfx_dev_sort_pairs(ctx, g_keys.as<uint64_t>(), g_counts.as<uint32_t>(), got, 2 * k, tk.as<uint64_t>(), tv.as<uint32_t>()));
-                RFX_TRY(sync_checked(ctx));
-            }
-            return rfx_dev_assemble(ctx, g_keys.as<uint64_t>(), g_counts.as<int32_t>(), got, prm, out, cap, &len, &ncont, trace, trace_cap, &ntr);
-        };
-        try { st_asm = drive(); } catch (...) { st_asm = rfx_api_exception(ctx, "rfx_sharded_assemble_reads"); }
-    }
-    int64_t res[3] = {st_asm == RFX_E_CAP ? 1 : 0, st_asm == RFX_E_CAP ? len : 0, (st_asm != RFX_OK && st_asm != RFX_E_CAP) ? 1 : 0};
-    RFX_TRY(rfx_comm_all_reduce_i64(c, res, 3, 1));
-    if (res[2]) {
-        if (st_asm != RFX_OK) return st_asm;
-        ctx->last_error = "rfx_sharded_assemble_reads: the driver failed on rank 0; see its rfx_last_error()";
-        return RFX_E_STATE;
-    }
-    if (res[0]) { *out_len = res[1]; return RFX_E_CAP; }
-    if (c->rank == 0) { *out_len = len; if (out_contigs) *out_contigs = ncont; if (n_trace) *n_trace = ntr; }
-    return RFX_OK;
+    // the extend stage: the range shuffle of sortByKey over the ranks while the record set is larger than `gather_below`,
+    // the rest on rank 0 (rfx_shard.hip; a bacterial genome's few million survivors go to rank 0 at once).  Its outcome is
+    // every rank's: a text buffer that is too short on rank 0 is RFX_E_CAP with *out_len = the length needed on EVERY rank,
+    // so that the callers' "grow and call again" re-enters the collective together.
+    return rfx_dev_sharded_assemble(ctx, c, d_keys.as<uint64_t>(), d_counts.as<int32_t>(), m, prm, gather_below, out, cap, out_len, out_contigs,
+                                    trace, trace_cap, n_trace);
 } RFX_API_CATCH(ctx)
 
 }  // extern "C"

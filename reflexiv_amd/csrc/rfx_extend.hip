@@ -248,7 +248,7 @@ __device__ __forceinline__ int part_of(const int64_t *__restrict__ ps, int P, in
 template <int KW>
 __device__ __forceinline__ void emit_at(int64_t i, const Desc *__restrict__ desc, const uint32_t *__restrict__ flag,
                        const uint64_t *__restrict__ oidx, const uint64_t *__restrict__ owoff, int64_t n,
-                       const int64_t *__restrict__ ps, int P, int sub, int start_marker,
+                       const int64_t *__restrict__ ps, int P, int sub, int start_marker, const int32_t *__restrict__ carry,
                        const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
                        const int64_t *__restrict__ ext_off, const uint64_t *__restrict__ ext,
                        const uint32_t *__restrict__ len,
@@ -262,7 +262,10 @@ __device__ __forceinline__ void emit_at(int64_t i, const Desc *__restrict__ desc
     // randomReflexivMarker starts at 2 in every task (1 once param.scramble == 3 in the k > 31 array loop,
     // P/ReflexivDSMain64.java:7484-7486) and toggles on every emission (:770, :1058-1062, :1242, :1514):
     // orientation = parity of the emission index
-    const int m = (d.type == 1 && d.b) ? (int)d.b : ((j - (int64_t)oidx[ps[p]]) & 1) ? 3 - start_marker : start_marker;
+    // (several GPUs, rfx_shard.hip: a partition that began on an earlier rank brings the parity of its emissions there --
+    // carry = {partition, parity})
+    const int64_t cpar = (carry && p == carry[0]) ? (int64_t)carry[1] : 0;
+    const int m = (d.type == 1 && d.b) ? (int)d.b : ((j - (int64_t)oidx[ps[p]] + cpar) & 1) ? 3 - start_marker : start_marker;
     OutSeq<KW> s;
     s.type = (int)d.type;
     s.a = load_src<KW>(d.a, key, marker, ext_off, ext, len);
@@ -338,13 +341,13 @@ __device__ __forceinline__ void emit_at(int64_t i, const Desc *__restrict__ desc
 template <int KW>
 __global__ void k_emit(const Desc *__restrict__ desc, const uint32_t *__restrict__ flag,
                        const uint64_t *__restrict__ oidx, const uint64_t *__restrict__ owoff, int64_t n,
-                       const int64_t *__restrict__ ps, int P, int sub, int start_marker,
+                       const int64_t *__restrict__ ps, int P, int sub, int start_marker, const int32_t *__restrict__ carry,
                        const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
                        const int64_t *__restrict__ ext_off, const uint64_t *__restrict__ ext,
                        const uint32_t *__restrict__ len,
                        KeyW<KW> *__restrict__ okey, int32_t *__restrict__ omarker, int64_t *__restrict__ oext_off,
                        uint64_t *__restrict__ oext, int32_t *__restrict__ oleft, int32_t *__restrict__ oright) {
-    emit_at<KW>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, desc, flag, oidx, owoff, n, ps, P, sub, start_marker, key, marker,
+    emit_at<KW>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, desc, flag, oidx, owoff, n, ps, P, sub, start_marker, carry, key, marker,
                 ext_off, ext, len, okey, omarker, oext_off, oext, oleft, oright);
 }
 
@@ -355,7 +358,7 @@ __global__ void k_emit(const Desc *__restrict__ desc, const uint32_t *__restrict
 template <int KW>
 __device__ __forceinline__ void emit_word_at(int64_t t, const Desc *__restrict__ desc, const uint64_t *__restrict__ oidx,
                              const uint64_t *__restrict__ owoff, int64_t n, const int64_t *__restrict__ ps, int P, int sub,
-                             int start_marker, const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
+                             int start_marker, const int32_t *__restrict__ carry, const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
                              const int64_t *__restrict__ ext_off, const uint64_t *__restrict__ ext,
                              const uint32_t *__restrict__ len, uint64_t *__restrict__ oext) {
     if (t >= (int64_t)owoff[n]) return;
@@ -370,7 +373,10 @@ __device__ __forceinline__ void emit_word_at(int64_t t, const Desc *__restrict__
     if (nw <= EMIT_SHORT) return;                    // k_emit wrote it
     const int64_t j = (int64_t)oidx[i];
     const int p = part_of(ps, P, i);
-    const int m = (d.type == 1 && d.b) ? (int)d.b : ((j - (int64_t)oidx[ps[p]]) & 1) ? 3 - start_marker : start_marker;
+    // (several GPUs, rfx_shard.hip: a partition that began on an earlier rank brings the parity of its emissions there --
+    // carry = {partition, parity})
+    const int64_t cpar = (carry && p == carry[0]) ? (int64_t)carry[1] : 0;
+    const int m = (d.type == 1 && d.b) ? (int)d.b : ((j - (int64_t)oidx[ps[p]] + cpar) & 1) ? 3 - start_marker : start_marker;
     OutSeq<KW> s;
     s.type = (int)d.type;
     s.a = load_src<KW>(d.a, key, marker, ext_off, ext, len);
@@ -383,10 +389,10 @@ __device__ __forceinline__ void emit_word_at(int64_t t, const Desc *__restrict__
 template <int KW>
 __global__ void k_emit_words(const Desc *__restrict__ desc, const uint64_t *__restrict__ oidx,
                              const uint64_t *__restrict__ owoff, int64_t n, const int64_t *__restrict__ ps, int P, int sub,
-                             int start_marker, const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
+                             int start_marker, const int32_t *__restrict__ carry, const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
                              const int64_t *__restrict__ ext_off, const uint64_t *__restrict__ ext,
                              const uint32_t *__restrict__ len, uint64_t *__restrict__ oext) {
-    emit_word_at<KW>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, desc, oidx, owoff, n, ps, P, sub, start_marker, key, marker,
+    emit_word_at<KW>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, desc, oidx, owoff, n, ps, P, sub, start_marker, carry, key, marker,
                      ext_off, ext, len, oext);
 }
 
@@ -579,7 +585,7 @@ __global__ __launch_bounds__(SP_T) void k_small_pass(SmallSet A, SmallSet B, Sma
     __syncthreads();
     // ---- keys, markers, left / right, offsets and the short extensions
     for (int i = tid; i <= n; i += SP_T)
-        emit_at<KW>(i, sc.desc, sc.flag, sc.oidx, sc.owoff, n, sc.ps, P, sub, start_marker, (const KeyW<KW> *)skey, sc.smarker, sc.sext,
+        emit_at<KW>(i, sc.desc, sc.flag, sc.oidx, sc.owoff, n, sc.ps, P, sub, start_marker, nullptr, (const KeyW<KW> *)skey, sc.smarker, sc.sext,
                     in.ext, sc.slen, (KeyW<KW> *)out.key, out.marker, out.ext_off, out.ext, out.left, out.right);
     __syncthreads();
     if (tid == 0) {
@@ -603,7 +609,7 @@ __global__ void k_small_words(SmallSet A, SmallSet B, SmallScratch sc, const Sma
     // the scans' last entries hold this pass's record count / word total; n_in = number of descriptors = ps[P]
     const int P = st->P;
     const int64_t n_in = sc.ps[P];
-    emit_word_at<KW>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, sc.desc, sc.oidx, sc.owoff, n_in, sc.ps, P, sub, st->start_marker,
+    emit_word_at<KW>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, sc.desc, sc.oidx, sc.owoff, n_in, sc.ps, P, sub, st->start_marker, nullptr,
                      (const KeyW<KW> *)sc.skey, sc.smarker, sc.sext, in.ext, sc.slen, out.ext);
 }
 
@@ -722,7 +728,7 @@ static DevBuf &ops_tmp_alloc(rfx_ctx *ctx, DevBuf &b, int P) { (void)b.alloc((si
 // nd = number of descriptor slots (= n of the input except for the doubling operator); single_word: one word per emission.
 static int desc_tail(rfx_ctx *ctx, const DevRecords &in, int64_t nd, DevBuf &len, DevBuf &desc, DevBuf &flag, DevBuf &onw, DevBuf &status,
                      const int64_t *d_part_start, int P, int k, bool single_word, int start_marker, int64_t words_bound,
-                     DevRecords &out, DevBuf &out_part_start) {
+                     DevRecords &out, DevBuf &out_part_start, PartCarry *carry_hook = nullptr) {
     const int sub = k - 1, kw = in.kw;
     DevBuf oidx, owoff;
     RFX_HIP(oidx.alloc((size_t)(nd + 1) * 8, ctx->stream));
@@ -735,9 +741,13 @@ static int desc_tail(rfx_ctx *ctx, const DevRecords &in, int64_t nd, DevBuf &len
     } else {
         RFX_TRY(exclusive_scan2_u32_to_u64(ctx, flag.as<uint32_t>(), onw.as<uint32_t>(), oidx.as<uint64_t>(), owoff.as<uint64_t>(), nd));
     }
+    // several GPUs: the emissions of this rank's first partition on earlier ranks (their parity), agreed between the scan
+    // and the emission -- on the device, no host wait (rfx_shard.hip)
+    const int32_t *d_carry = nullptr;
+    if (carry_hook) RFX_TRY(carry_hook->compute(ctx, d_part_start, P, oidx.as<uint64_t>(), nd, &d_carry));
     RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_emit<KW>, dim3(grid_for(nd + 1)), dim3(256), 0, ctx->stream, (const Desc *)desc.as<Desc>(),
                        (const uint32_t *)flag.as<uint32_t>(), (const uint64_t *)oidx.as<uint64_t>(),
-                       (const uint64_t *)owoff.as<uint64_t>(), nd, d_part_start, P, sub, start_marker,
+                       (const uint64_t *)owoff.as<uint64_t>(), nd, d_part_start, P, sub, start_marker, d_carry,
                        (const KeyW<KW> *)in.key.as<KeyW<KW>>(), (const int32_t *)in.marker.as<int32_t>(),
                        (const int64_t *)in.ext_off.as<int64_t>(), (const uint64_t *)in.ext.as<uint64_t>(),
                        (const uint32_t *)len.as<uint32_t>(), out.key.as<KeyW<KW>>(), out.marker.as<int32_t>(),
@@ -747,7 +757,7 @@ static int desc_tail(rfx_ctx *ctx, const DevRecords &in, int64_t nd, DevBuf &len
     if (words_bound > nd || in.words > in.n) {          // some record may have more than one word
         RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_emit_words<KW>, dim3(grid_for(words_bound)), dim3(256), 0, ctx->stream, (const Desc *)desc.as<Desc>(),
                            (const uint64_t *)oidx.as<uint64_t>(), (const uint64_t *)owoff.as<uint64_t>(), nd, d_part_start, P,
-                           sub, start_marker, (const KeyW<KW> *)in.key.as<KeyW<KW>>(), (const int32_t *)in.marker.as<int32_t>(),
+                           sub, start_marker, d_carry, (const KeyW<KW> *)in.key.as<KeyW<KW>>(), (const int32_t *)in.marker.as<int32_t>(),
                            (const int64_t *)in.ext_off.as<int64_t>(), (const uint64_t *)in.ext.as<uint64_t>(),
                            (const uint32_t *)len.as<uint32_t>(), out.ext.as<uint64_t>()));
         RFX_HIP(hipGetLastError());
@@ -768,7 +778,7 @@ static int desc_tail(rfx_ctx *ctx, const DevRecords &in, int64_t nd, DevBuf &len
 }
 
 int extend_pass(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start, int P, int k, int twin,
-                int stage, DevRecords &out, DevBuf &out_part_start, int start_marker) {
+                int stage, DevRecords &out, DevBuf &out_part_start, int start_marker, PartCarry *carry_hook) {
     const int64_t n = in.n;
     const int kw = in.kw;
     if (n > (int64_t)0xFFFFFFFFLL) return RFX_E_LIMIT;
@@ -795,7 +805,8 @@ int extend_pass(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start,
                            flag.as<uint32_t>(), onw.as<uint32_t>(), status.as<int>()));
         RFX_HIP(hipGetLastError());
     }
-    return desc_tail(ctx, in, n, len, desc, flag, onw, status, d_part_start, P, k, stage == 0, start_marker, in.words, out, out_part_start);
+    return desc_tail(ctx, in, n, len, desc, flag, onw, status, d_part_start, P, k, stage == 0, start_marker, in.words, out, out_part_start,
+                     carry_hook);
 }
 
 // op 0: DSReflexivAndForwardKmer (2n out); 1..4: the run filters (see k_key_filter); 5 / 6: every record forward / reflected

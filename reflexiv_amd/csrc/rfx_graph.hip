@@ -393,7 +393,7 @@ template <int KW>
 __global__ void k_random_reflection(const KeyW<KW> *__restrict__ key, const int32_t *__restrict__ marker,
                                     const uint64_t *__restrict__ ext, const int32_t *__restrict__ left,
                                     const int32_t *__restrict__ right, int64_t n,
-                                    const int64_t *__restrict__ ps, int P, int sub,
+                                    const int64_t *__restrict__ ps, int P, int sub, const int32_t *__restrict__ carry,
                                     KeyW<KW> *__restrict__ okey, int32_t *__restrict__ omarker,
                                     int64_t *__restrict__ oext_off, uint64_t *__restrict__ oext,
                                     int32_t *__restrict__ oleft, int32_t *__restrict__ oright) {
@@ -401,7 +401,9 @@ __global__ void k_random_reflection(const KeyW<KW> *__restrict__ key, const int3
     if (i == n) { oext_off[n] = n; return; }
     if (i > n) return;
     int p = part_of(ps, P, i);
-    int m = ((i - ps[p]) & 1) ? 1 : 2;                                      // :2777, :2880-2884
+    // (several GPUs: a partition that began on an earlier rank brings the parity of its record count there, rfx_shard.hip)
+    const int64_t cpar = (carry && p == carry[0]) ? (int64_t)carry[1] : 0;
+    int m = ((i - ps[p] + cpar) & 1) ? 1 : 2;                               // :2777, :2880-2884
     KeyW<KW> kk = key[i];
     uint64_t e = ext[i];
     int mk = marker[i];
@@ -708,7 +710,7 @@ int reflect_from_forward(rfx_ctx *ctx, const DevRecords &in, int k, DevRecords &
 }
 
 int random_reflection(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start, int P, int k,
-                      DevRecords &out) {
+                      DevRecords &out, const int32_t *d_carry) {
     const int64_t n = in.n;
     if (in.words != n) return RFX_E_ARG;
     const int kw = in.kw;
@@ -717,7 +719,7 @@ int random_reflection(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_
     RFX_KW_SWITCH(kw, hipLaunchKernelGGL(k_random_reflection<KW>, dim3(grid_for(n + 1)), dim3(256), 0, ctx->stream,
                        (const KeyW<KW> *)in.key.as<KeyW<KW>>(), (const int32_t *)in.marker.as<int32_t>(),
                        (const uint64_t *)in.ext.as<uint64_t>(), (const int32_t *)in.left.as<int32_t>(),
-                       (const int32_t *)in.right.as<int32_t>(), n, d_part_start, P, k - 1,
+                       (const int32_t *)in.right.as<int32_t>(), n, d_part_start, P, k - 1, d_carry,
                        out.key.as<KeyW<KW>>(), out.marker.as<int32_t>(), out.ext_off.as<int64_t>(),
                        out.ext.as<uint64_t>(), out.left.as<int32_t>(), out.right.as<int32_t>()));
     RFX_HIP(hipGetLastError());

@@ -142,6 +142,10 @@ struct DevBuf {
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; s = o.s; borrowed = o.borrowed; o.p = nullptr; o.borrowed = false; }
+        return *this;
+    }
     ~DevBuf() { release(); }
     hipError_t alloc(size_t bytes, hipStream_t stream) {
         release();
@@ -323,16 +327,36 @@ int fork_filter(rfx_ctx *ctx, bool reflected, const DevRecords &in, const int64_
                 int P, int k, int min_error_cov, int twin, DevRecords &out,
                 DevBuf &out_part_start);
 int reflect_from_forward(rfx_ctx *ctx, const DevRecords &in, int k, DevRecords &out);
+// Several GPUs (rfx_shard.hip): a logical partition may begin on an earlier rank.  What it brings from there is the PARITY
+// of a count -- records for the random reflection, emissions for an extend pass -- as device int32[2] = {partition, parity}.
+// The extend pass learns its count only after its scan, so it calls back between the scan and the emission.
+struct PartCarry {
+    virtual ~PartCarry() {}
+    // d_cum: n + 1 prefix counts of the quantity whose parity decides (nullptr: the record index itself)
+    virtual int compute(rfx_ctx *ctx, const int64_t *d_part_start, int P, const uint64_t *d_cum, int64_t n, const int32_t **d_carry) = 0;
+};
 int random_reflection(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start, int P,
-                      int k, DevRecords &out);
+                      int k, DevRecords &out, const int32_t *d_carry = nullptr);
 int extend_pass(rfx_ctx *ctx, const DevRecords &in, const int64_t *d_part_start, int P, int k,
-                int twin, int stage, DevRecords &out, DevBuf &out_part_start, int start_marker = 2);
+                int twin, int stage, DevRecords &out, DevBuf &out_part_start, int start_marker = 2, PartCarry *carry_hook = nullptr);
 
 // the k > 31 from-counts extras (P/ReflexivDSMain64.java:584-619, 672-712): op 0 DSReflexivAndForwardKmer (2n out),
 // 1 DSFilterExtendableKmerPairs, 2 DSFilterUnExtendableKmer, 3 DSFilterStillExtendableKmerFromPairs,
 // 4 DSFilterStillExtendableKmerEnds, 5 / 6 DSFilterUnExtendableKmerLeftEnds / ...RightEnds
 int extras_operator(rfx_ctx *ctx, int op, const DevRecords &in, const int64_t *d_part_start, int P, int k, DevRecords &out,
                     DevBuf &out_part_start);
+// the driver (rfx_api.hip), and the state with which the sharded driver (rfx_shard.hip) hands its loop over to it
+struct AsmResume {
+    DevRecords *recs;            // the record set, in global arrival order (its buffers are taken over)
+    int passes_done;             // extend passes behind it (0..4: the passes before the loop are still to come)
+    int iterations;
+    int64_t contig_number;
+    int scramble, P, partition_number;
+    int64_t nt;                  // trace entries already written
+};
+int assemble_impl(rfx_ctx *ctx, bool wide, const uint64_t *d_keys, const int32_t *d_counts, int64_t n, const rfx_params *prm,
+                  char *out, int64_t cap, int64_t *out_len, int64_t *out_contigs, int64_t *trace, int64_t trace_cap,
+                  int64_t *n_trace, AsmResume *resume);
 // the rest of the driver's loop on <= small_pass_limit() records: two launches per pass, state in HBM (rfx_extend.hip)
 int small_passes(rfx_ctx *ctx, DevRecords &recs, int k, int twin, bool wide, int coalesce, int min_iter, int max_iter,
                  int *iterations, int64_t *contig_number, int *scramble, int *P, int *partition_number,

@@ -23,16 +23,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import oracle as O      # noqa: E402
 
 
-def count_in_passes(bases, off, k, cover, n_pass):
-    ks, cs, nd, ni = [], [], 0, 0
+def count_in_passes(bases, off, k, cover, n_pass, cap=1 << 24, keep=True):
+    ks, cs, nd, ni, nkept = [], [], 0, 0, 0
     hk, hc = hashlib.sha256(), hashlib.sha256()
     cuts = [4096 * i // n_pass for i in range(n_pass + 1)]
     for lo, hi in zip(cuts[:-1], cuts[1:]):
         t = time.time()
-        a, b, d, i = O.count_reads_omp(bases, off, k, cover, buckets=(lo, hi), cap=1 << 24)
+        a, b, d, i = O.count_reads_omp(bases, off, k, cover, buckets=(lo, hi), cap=cap)
         hk.update(a.tobytes()); hc.update(b.tobytes())
-        ks.append(a); cs.append(b); nd += d; ni += i
+        nkept += len(b)
+        if keep:
+            ks.append(a); cs.append(b)
+        nd += d; ni += i
         print(f"  k={k} buckets [{lo},{hi}): {i} instances, {d} distinct, {len(b)} kept, {time.time() - t:.0f} s", flush=True)
+    if not keep:                                          # (--count-only: the survivors are hashed pass by pass and dropped)
+        return None, nkept, nd, ni, hk.hexdigest(), hc.hexdigest()
     return np.concatenate(ks), np.concatenate(cs), nd, ni, hk.hexdigest(), hc.hexdigest()
 
 
@@ -45,6 +50,10 @@ def main():
     ap.add_argument("--passes", type=int, default=8)
     ap.add_argument("--ks", default="31,63")
     ap.add_argument("--out", default=os.path.join(HERE, "c2_full.json"))
+    ap.add_argument("--cap", type=int, default=1 << 24, help="survivors per pass")
+    ap.add_argument("--count-only", action="store_true",
+                    help="pin the count stage only (config 5's per-GPU share: 4.5e8 survivors at -cover 2 are 9e8 records, beyond "
+                         "what the oracle's extend stage holds in this container's memory)")
     args = ap.parse_args()
     seed, L = 1, 150
     O.set_threads(O.host_cores())
@@ -60,8 +69,12 @@ def main():
         if old.get("workload") == out["workload"]:
             out.update({k: v for k, v in old.items() if k.startswith("k")})
     for k in [int(x) for x in args.ks.split(",")]:
-        keys, counts, nd, ni, hk, hc = count_in_passes(bases, off, k, args.cover, args.passes)
-        rec = {"n_instances": ni, "n_distinct": nd, "n_kept": int(len(counts)), "sha256_keys": hk, "sha256_counts": hc}
+        keys, counts, nd, ni, hk, hc = count_in_passes(bases, off, k, args.cover, args.passes, args.cap, not args.count_only)
+        rec = {"n_instances": ni, "n_distinct": nd, "n_kept": int(counts if args.count_only else len(counts)), "sha256_keys": hk, "sha256_counts": hc}
+        if args.count_only:
+            out[f"k{k}"] = rec
+            json.dump(out, open(args.out, "w"), indent=1)
+            continue
         t = time.time()
         if k <= 31:
             prm = O.default_params(k=k, min_cov=args.cover, partitions=args.partitions)

@@ -32,7 +32,7 @@ def main_threads(world, work):
 
     def body(r):
         try:
-            run_rank(r, world, work, cases=((31, 16), (63, 2)), n_reads=30_000)
+            run_rank(r, world, work, cases=((31, 16), (63, 2)), n_reads=30_000, extend=((31, 4, 0), (63, 3, 0)))
         except BaseException:                                    # noqa: BLE001 -- reported below, with the rank
             failed.append((r, traceback.format_exc()))
 
@@ -46,7 +46,53 @@ def main_threads(world, work):
     sys.exit(1 if failed else 0)
 
 
-def run_rank(rank, world, work, cases=((31, 1), (31, 4), (25, 3), (63, 2), (47, 4)), n_reads=60_000):
+def sharded_extend_cases(rfx, rank, world, dw, da, n_reads, wpr, L, cover, configs):
+    """The extend stage range-sharded over the ranks (rfx_dev_sharded_assemble: every sortByKey as a shuffle of whole records)
+    against the ONE-GPU driver on the fused list of all ranks' reads, on rank 0: text, contigs and the pass-by-pass record
+    counts must be identical for the same logical partition count P, whatever the number of ranks -- P below, equal to and
+    not a multiple of the world (partitions that go on on the next rank), the whole loop sharded (gather_below = 0), a
+    hand-over to rank 0 in the middle, and the immediate gather of a small set."""
+    import torch
+    import reflexiv_amd
+    for k, P, gather_below in configs:
+        wide = k > 32
+        W = 2 if wide else 1
+        nk = (rfx.kmers_per_read_w if wide else rfx.kmers_per_read)(L, k)
+        cap = nk * n_reads
+        cdt = torch.int64 if wide else torch.int32
+        sk = torch.empty(cap * W, dtype=torch.int64, device="cuda"); sc = torch.empty(cap, dtype=cdt, device="cuda")
+        torch.cuda.synchronize()
+        ms, tot = rfx.sharded_count_dev(dw.data_ptr(), n_reads, wpr, L, k, sk.data_ptr(), sc.data_ptr(), cap, cover, generations=2)
+        prm = reflexiv_amd.default_params(k=k, min_cov=cover, partitions=P, min_contig=300)
+        if wide:                                                 # the counter's layout -> the assembler's (KmerBinarizer), shard by shard
+            aw = (k - 1) // 31 + 1
+            ak = torch.empty(max(1, ms) * aw, dtype=torch.int64, device="cuda"); ac = torch.empty(max(1, ms), dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            m2 = rfx.counter_to_asm_dev(sk.data_ptr(), sc.data_ptr(), ms, k, ak.data_ptr(), ac.data_ptr(), cover)
+            text, nc, trace = rfx.sharded_assemble_dev(ak.data_ptr(), ac.data_ptr(), m2, prm, gather_below=gather_below)
+        else:
+            text, nc, trace = rfx.sharded_assemble_dev(sk.data_ptr(), sc.data_ptr(), ms, prm, gather_below=gather_below)
+        if rank == 0:
+            fk = torch.empty(cap * world * W, dtype=torch.int64, device="cuda"); fc = torch.empty(cap * world, dtype=cdt, device="cuda")
+            torch.cuda.synchronize()
+            if wide:
+                m, nd, inst = rfx.count_reads_w_dev(da.data_ptr(), world * n_reads, wpr, L, k, fk.data_ptr(), fc.data_ptr(), cap * world, cover)
+                fa = torch.empty(max(1, m) * aw, dtype=torch.int64, device="cuda"); fcc = torch.empty(max(1, m), dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
+                mm = rfx.counter_to_asm_dev(fk.data_ptr(), fc.data_ptr(), m, k, fa.data_ptr(), fcc.data_ptr(), cover)
+                wtext, wnc, wtrace = rfx.assemble_w_dev(fa.data_ptr(), fcc.data_ptr(), mm, prm)
+            else:
+                m, nd, inst = rfx.count_reads_dev(da.data_ptr(), world * n_reads, wpr, L, k, fk.data_ptr(), fc.data_ptr(), cap * world, cover)
+                wtext, wnc, wtrace = rfx.assemble_dev(fk.data_ptr(), fc.data_ptr(), m, prm)
+            assert tot[2] == m and wnc > 0, (k, P, gather_below, tot, m, wnc)
+            assert trace == wtrace, ("sharded extend: record counts per pass", k, P, gather_below, trace, wtrace)
+            assert (text, nc) == (wtext, wnc), ("sharded extend: contigs", k, P, gather_below, nc, wnc)
+        else:
+            assert text == "" and nc == 0
+
+
+def run_rank(rank, world, work, cases=((31, 1), (31, 4), (25, 3), (63, 2), (47, 4)), n_reads=60_000,
+             extend=((31, 4, 0), (31, 8, 0), (31, 3, 2000), (31, 8, -1), (63, 4, 0), (63, 8, 3000))):
     import torch
     import reflexiv_amd
     from reflexiv_amd import Reflexiv
@@ -144,6 +190,8 @@ def run_rank(rank, world, work, cases=((31, 1), (31, 4), (25, 3), (63, 2), (47, 
             assert torch.equal(rk, fk[:m * W]) and torch.equal(rc, fc[:m]), (k, gens)
             # every k-mer lives on exactly one rank: the gathered list has no repeats (it equals the fused list) -- done above
 
+    sharded_extend_cases(rfx, rank, world, dw, da if rank == 0 else None, n_reads, wpr, L, cover, extend)
+
     # host ASCII reads of any length -> contig text on rank 0: the documented example dealt round the ranks
     from oracle import oracle as O
     ex = np.load(os.path.join(HERE, "golden", "example.npz"))
@@ -155,6 +203,9 @@ def run_rank(rank, world, work, cases=((31, 1), (31, 4), (25, 3), (63, 2), (47, 
     mo[1:] = np.cumsum(off[mine + 1] - off[mine])
     prm = reflexiv_amd.default_params(min_cov=3, partitions=4, twin=reflexiv_amd.TWIN_RDD)
     text, nc, trace, tot = rfx.sharded_assemble_reads(mb, mo, prm, generations=2)
+    # ... and with every sortByKey of the extend stage as a range shuffle over the ranks, to the end of the loop
+    text_s, nc_s, trace_s, tot_s = rfx.sharded_assemble_reads(mb, mo, prm, generations=2, gather_below=0)
+    assert (text_s, nc_s, trace_s, tot_s) == (text, nc, trace, tot)
     if rank == 0:
         km = O.extract_canon(bases, off, 31)
         wk, wc, wd = O.count_filter(km, 3)

@@ -91,6 +91,9 @@ def parse():
     ap.add_argument("--exchange-impl", choices=["capi", "torch"], default="capi",
                     help="N > 1, --exchange records: capi = rfx_dev_sharded_count (RCCL send / recv inside libreflexiv_hip.so, "
                          "the form a Java / C host calls); torch = reflexiv_amd.dist over torch.distributed")
+    ap.add_argument("--gather-below", type=int, default=0,
+                    help="--sharded-extend: the record set is gathered on rank 0 once it has this many records or fewer over all "
+                         "ranks (0: the whole loop stays sharded; -1: the library's default, 32 Mi)")
     ap.add_argument("--sharded-extend", action="store_true",
                     help="N > 1 (or --force-dist): run the extend stage range-sharded over the ranks with the records resident "
                          "in HBM (reflexiv_amd.dist.sharded_assemble_dev: one RCCL all-to-all of whole records per sortByKey) "
@@ -412,8 +415,36 @@ def main():
                                    else "reflexiv_amd.dist over torch.distributed",
                            "exchange_free": bool((rd.LOCAL_SHORTCUT or capi) and world == 1),
                            "rehearsed_as_rank_of": args.virtual_world if (capi and world == 1 and args.force_dist) else None}
+    if multi and not args.no_contigs and args.sharded_extend and capi:
+        # every sortByKey of the driver as a range shuffle of whole records behind the C ABI (rfx_dev_sharded_assemble):
+        # the record set stays sharded while it has more than --gather-below records, then rank 0 finishes
+        prm = reflexiv_amd.default_params(k=k, min_cov=args.cover, partitions=args.partitions)
+        sk, sc = shard["keys"].contiguous(), shard["counts"].contiguous()
+        ms = int(sc.numel())
+        if wide:                                              # KmerBinarizer on the shard (counter layout -> assembler layout)
+            aw = (k - 1) // 31 + 1
+            a_k = torch.empty(max(1, ms) * aw, dtype=torch.int64, device=dev)
+            a_c = torch.empty(max(1, ms), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            ms = rfx.counter_to_asm_dev(sk.data_ptr(), sc.data_ptr(), ms, k, a_k.data_ptr(), a_c.data_ptr(), args.cover)
+            sk, sc = a_k, a_c
+        torch.cuda.synchronize()
+        rfx.sharded_assemble_dev(sk.data_ptr(), sc.data_ptr(), ms, prm, gather_below=args.gather_below)     # untimed warm-up, as below
+        sync_all()
+        t1 = time.perf_counter()
+        text, nc, tr = rfx.sharded_assemble_dev(sk.data_ptr(), sc.data_ptr(), ms, prm, gather_below=args.gather_below)
+        sync_all()
+        t_asm = time.perf_counter() - t1
+        if rank == 0:
+            lens = sorted((int(h.split("-")[1]) for h in text.split("\n") if h.startswith(">")), reverse=True)
+            out["contigs"] = {"driver": f"rfx_dev_sharded_assemble: sortByKey as a range shuffle over the ranks while the record set has more than "
+                                        f"{args.gather_below} records, then the one-GPU driver on rank 0",
+                              "wall_ms_from_counts": t_asm * 1e3, "wall_ms_reads_to_contigs": t_asm * 1e3 + dt / args.steps * 1e3,
+                              "untimed_warmup_runs": 1, "extend_passes": len(tr), "n_contigs": nc, "longest": lens[:3],
+                              "total_bases": sum(lens), "sha256_text": __import__("hashlib").sha256(text.encode()).hexdigest()}
+        args.no_contigs = True
     if multi and not args.no_contigs and args.sharded_extend and not wide:
-        # every sortByKey of the loop = local sort + splitters + ONE all-to-all of whole records + local sort, records in HBM
+        # (the round-2 form over torch.distributed: --exchange-impl torch)
         prm = reflexiv_amd.default_params(k=k, min_cov=args.cover, partitions=max(args.partitions, world))
         ops = rd.HipDevOps(rfx)
         sk, sc = shard["keys"].contiguous(), shard["counts"].contiguous()
@@ -487,7 +518,7 @@ def main():
         lens = sorted((int(h.split("-")[1]) for h in text.split("\n") if h.startswith(">")), reverse=True)
         out["contigs"] = {"wall_ms_from_counts": t_asm * 1e3, "wall_ms_reads_to_contigs": t_asm * 1e3 + dt / args.steps * 1e3,
                           "untimed_warmup_runs": 1, "extend_passes": len(trace), "n_contigs": nc, "longest": lens[:3],
-                          "total_bases": sum(lens)}
+                          "total_bases": sum(lens), "sha256_text": __import__("hashlib").sha256(text.encode()).hexdigest()}
     if rank == 0 and not args.no_contigs and "contigs" in out and not args.sharded_extend:
         # contig RC de-duplication (P/ReflexivDSDynamicKmerDedup.java) of the text the path just wrote:
         # the fixed-k path reports every contig on both strands, this reports each once

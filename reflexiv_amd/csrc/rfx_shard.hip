@@ -276,6 +276,15 @@ struct Shard : PartCarry {
             RFX_HIP(hipHostMalloc((void **)&c->h_sh, words() * 8, hipHostMallocDefault));
         }
         d = c->d_sh; h = c->h_sh;
+        // the two arenas take at most a third of the free HBM each (what a pass does not find in them comes from the
+        // stream-ordered allocator: slower, never wrong) -- the capacity-stress configuration must start, not fail here
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const size_t held = ctx->ws[2].bytes + ctx->ws[3].bytes;
+                arena_bytes = std::min(arena_bytes, (free_b + held) / 3);
+            }
+        }
         for (int i = 0; i < 2; i++) {
             arena[i].base = (char *)ctx->ws_get(2 + i, arena_bytes);
             if (!arena[i].base) { ctx->last_error = "rfx_dev_sharded_assemble: workspace allocation failed"; return RFX_E_HIP; }

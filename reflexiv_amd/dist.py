@@ -958,6 +958,16 @@ def sharded_assemble_dev(ops, keys: torch.Tensor, counts: torch.Tensor, prm, gro
     """sharded_assemble() with the records resident on the ranks' devices.  keys (int64 bit patterns) / counts (int32):
     this rank's shard of the filtered (k-mer, count) list, any order, on its device.  k <= 31.  Returns (contig text,
     n_contigs) on `root`, (None, None) elsewhere; identical to the single-GPU driver for the same prm.partitions."""
+    rfx = getattr(ops, "rfx", None)
+    if rfx is not None and getattr(rfx, "comm", None):
+        # the engine's context carries an RCCL communicator: the whole driver runs behind the C ABI
+        # (rfx_dev_sharded_assemble, reflexiv_amd/csrc/rfx_shard.hip); this module is only its caller
+        torch.cuda.current_stream().synchronize()
+        k_, c_ = keys.contiguous(), counts.contiguous()
+        text, nc, tr = rfx.sharded_assemble_dev(k_.data_ptr(), c_.data_ptr(), int(c_.numel()), prm, gather_below=0 if force_exchange else -1)
+        if trace is not None:
+            trace.extend(tr)
+        return (text, nc) if rfx.comm_rank == root == 0 else (None, None)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     k, twin, P = prm.k, prm.twin, max(1, prm.partitions)

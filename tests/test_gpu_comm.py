@@ -159,6 +159,41 @@ def test_multi_gpu_branch_at_the_config3_share_matches_the_oracle_pin(k, env):
         rfx.close()
 
 
+PIN_C5 = os.path.join(HERE, "golden", "c5_share.json")
+
+
+@pytest.mark.skipif(not os.path.exists(PIN_C5), reason="tests/golden/c5_share.json not generated")
+def test_config5_real_per_gpu_share_as_a_rank_of_8_matches_the_oracle_pin():
+    """BASELINE config 5's REAL per-GPU share -- 18.75 Gbp = 125,000,000 PE150 reads of a 400 Mbp genome (150 Gbp at 48x over 8
+    GPUs), -cover 2, 1.5e10 k-mer instances, 2.5e9 distinct, 4.5e8 kept -- through rfx_dev_sharded_count as a rank of 8 (32
+    (generation, owner) bins, records in 4 generations through RCCL), against the ORACLE's count-stage pin
+    (tests/golden/make_c2_full.py --reads 125000000 --genome 400000000 --cover 2 --ks 31 --passes 16 --count-only; the oracle's
+    extend stage does not hold 9e8 records in the build container's memory, so the pin stops at the survivors)."""
+    import torch
+    pin = json.load(open(PIN_C5))
+    rec, w = pin["k31"], pin["workload"]
+    rfx = make_comm({"RFX_COMM_SELF_VIA_RCCL": "1", "RFX_COMM_VIRTUAL_WORLD": "8"})
+    try:
+        n_reads, L, cover = w["reads"], w["read_len"], w["cover"]
+        dw, wpr = reads_on_device(rfx, w["seed"], w["genome"], n_reads, L, w["err_per_2_32"])
+        cap = int(rec["n_kept"] * 1.02) + 4096
+        dk = torch.empty(cap, dtype=torch.int64, device="cuda")
+        dc = torch.empty(cap, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        m, tot = rfx.sharded_count_dev(dw.data_ptr(), n_reads, wpr, L, 31, dk.data_ptr(), dc.data_ptr(), cap, cover, generations=4)
+        assert tot == [rec["n_instances"], rec["n_distinct"], rec["n_kept"]] and m == rec["n_kept"]
+        hk, hc = hashlib.sha256(), hashlib.sha256()
+        step = 1 << 26                                          # (the survivors come down in pieces: 5.4 GB in all)
+        for a in range(0, m, step):
+            hk.update(dk[a:min(m, a + step)].cpu().numpy().view(np.uint64).tobytes())
+            hc.update(dc[a:min(m, a + step)].cpu().numpy().tobytes())
+        assert hk.hexdigest() == rec["sha256_keys"] and hc.hexdigest() == rec["sha256_counts"]
+        del dw, dk, dc
+        rfx.trim()                                              # (35 GB of send / count workspace back before the next test)
+    finally:
+        rfx.close()
+
+
 def test_sharded_assemble_reads_one_rank_matches_the_documented_example(golden_dir):
     """rfx_sharded_assemble_reads (host ASCII reads -> encode -> sharded count over RCCL -> gather -> driver) on a one-rank
     communicator: the documented example (k = 31, -cover 3, P = 4, RDD twin) gives `>Contig-4558-0` and the oracle's text;
@@ -234,3 +269,57 @@ def test_contexts_and_communicators_made_and_destroyed_in_one_process(golden_dir
                 rfx.close()
     finally:
         os.environ.pop("RFX_BACKTRACE", None)
+
+
+def test_sharded_extend_behind_the_c_abi_one_rank_real_rccl(golden_dir):
+    """rfx_dev_sharded_assemble on a ONE-rank communicator of the real RCCL (the rank's own pieces through ncclSend / ncclRecv,
+    the sample and carry all-gathers, the per-pass all-reduce all run): the ORACLE's golden contigs and pass-by-pass record
+    counts of the documented example (both twins, P = 4 and 8) and of the planted bubble / repeat fixture, with the whole loop
+    sharded (gather_below = 0), handed over to the one-GPU driver in the middle, and gathered at once; k = 63 against the
+    oracle's driver."""
+    import torch
+    import reflexiv_amd
+    from oracle import oracle as O
+    ex = np.load(os.path.join(golden_dir, "example.npz"))
+    pl = np.load(os.path.join(golden_dir, "planted.npz"))
+    rfx = make_comm({"RFX_COMM_SELF_VIA_RCCL": "1", "RFX_COMM_LIMIT_BYTES": "65536"})
+    try:
+        rng = np.random.default_rng(9)
+        o = rng.permutation(len(ex["keys_cov3"]))                    # a shard comes in any order
+        dk = torch.from_numpy(ex["keys_cov3"][o].view(np.int64).copy()).cuda()
+        dc = torch.from_numpy(ex["counts_cov3"][o].astype(np.int32)).cuda()
+        torch.cuda.synchronize()
+        for P, twin, tn in ((4, reflexiv_amd.TWIN_DS, "ds"), (8, reflexiv_amd.TWIN_RDD, "rdd"), (4, reflexiv_amd.TWIN_RDD, "rdd")):
+            for gb in (0, 700, -1):
+                prm = reflexiv_amd.default_params(min_cov=3, partitions=P, twin=twin)
+                text, nc, trace = rfx.sharded_assemble_dev(dk.data_ptr(), dc.data_ptr(), len(o), prm, gather_below=gb)
+                assert text == str(ex[f"contigs_{tn}_P{P}"]), (P, tn, gb)
+                assert trace == [int(x) for x in ex[f"trace_{tn}_P{P}"]], (P, tn, gb)
+        pk = torch.from_numpy(pl["k31_keys"].view(np.int64).copy()).cuda()
+        pc = torch.from_numpy(pl["k31_counts"].astype(np.int32)).cuda()
+        torch.cuda.synchronize()
+        prm = reflexiv_amd.default_params(k=31, min_cov=2, partitions=4, twin=reflexiv_amd.TWIN_DS, min_contig=100)
+        text, nc, trace = rfx.sharded_assemble_dev(pk.data_ptr(), pc.data_ptr(), len(pl["k31_keys"]), prm, gather_below=0)
+        assert text == str(pl["k31_ds_contigs"]) and trace == [int(x) for x in pl["k31_ds_trace"]]
+        # a text buffer that is too short: RFX_E_CAP with the length needed, the retry gives the same text
+        text2, nc2, trace2 = rfx.sharded_assemble_dev(pk.data_ptr(), pc.data_ptr(), len(pl["k31_keys"]), prm, gather_below=0, text_cap=100)
+        assert rfx.text_retries == 1 and (text2, nc2, trace2) == (text, nc, trace)
+        # k = 63 (two-word keys, three-word k-mers; the from-counts extras make the driver gather before iteration 18)
+        g = O.synth_genome(11, 50_000)
+        bases, off = O.synth_reads(11, g, 50_000, 0, 20_000, 150)
+        wk, wc, _, _ = O.count_reads_omp(bases, off, 63, 3)
+        ak = O.counter_to_asm_w(wk, 63)
+        for extras in (1, 0):
+            oprm = O.default_params(k=63, min_cov=3, partitions=4, min_contig=200)
+            oprm.extras = extras
+            otext, onc, otrace, _ = O.assemble_from_counts(ak, wc.astype(np.int32), oprm)
+            prm = reflexiv_amd.default_params(k=63, min_cov=3, partitions=4, min_contig=200)
+            prm.extras = extras
+            perm = rng.permutation(len(wc))
+            dk63 = torch.from_numpy(ak[perm].view(np.int64).copy()).cuda()
+            dc63 = torch.from_numpy(wc[perm].astype(np.int32)).cuda()
+            torch.cuda.synchronize()
+            text, nc, trace = rfx.sharded_assemble_dev(dk63.data_ptr(), dc63.data_ptr(), len(wc), prm, gather_below=0)
+            assert (text, nc, trace) == (otext, onc, otrace), extras
+    finally:
+        rfx.close()

@@ -60,7 +60,13 @@ def parse():
     ap.add_argument("--gbp", type=float, default=None,
                     help="Gbp of reads per GPU (default: 5 at N = 1 = BASELINE configs[1]; 6.25 at N > 1, i.e. the 50 Gbp of "
                          "BASELINE configs[2] / the metric at 8 GPUs, the same per-GPU work at 2 and 4)")
-    ap.add_argument("--genome", type=int, default=4_640_000, help="genome length (bases, multiple of 32)")
+    ap.add_argument("--genome", type=int, default=None,
+                    help="genome length (bases, multiple of 32).  Default: 4,640,000 per 5 Gbp of TOTAL reads -- the E.coli-like genome "
+                         "of BASELINE configs[1] at N = 1, and the SAME DEPTH (1078x, -cover 30) at every N: 46.4 Mbp for the 50 Gbp of 8 "
+                         "GPUs.  (With one 4.64 Mbp genome at every N the depth per site grows with N -- 10776x at 8 GPUs -- and with it "
+                         "the work per k-mer instance: every minimiser site then brings ~9500 records, more than one LDS table takes, "
+                         "measured 8.0 ns per 1000 instances in the leaves against 2.2 at 1078x; per-GPU work would not be fixed as N "
+                         "grows, which is what weak scaling means.  --genome 4640000 selects that set.)")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--cover", type=int, default=None,
                     help="-cover (minKmerCoverage); default 30 per 5 Gbp of TOTAL reads on the 4.64 Mbp genome (error k-mers "
@@ -91,6 +97,14 @@ def parse():
     ap.add_argument("--exchange-impl", choices=["capi", "torch"], default="capi",
                     help="N > 1, --exchange records: capi = rfx_dev_sharded_count (RCCL send / recv inside libreflexiv_hip.so, "
                          "the form a Java / C host calls); torch = reflexiv_amd.dist over torch.distributed")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling on north_star's 50 Gbp read set: the SAME 333,333,334 reads at every N (50 / N Gbp per GPU, "
+                         "-cover 300); N = 1 counts them in --strong-generations sequential generations of the hash space through "
+                         "rfx_dev_sharded_count on a one-rank communicator (nothing travels, nothing is copied).  The JSON line says "
+                         '"scaling": "strong".  Without the flag the N = 1 line carries the same measurement as `strong_50gbp` '
+                         "(few steps), the denominator a weak-scaled N = 8 line -- 8 x 6.25 Gbp = the same 50 Gbp -- is read against")
+    ap.add_argument("--strong-generations", type=int, default=8)
+    ap.add_argument("--no-strong", action="store_true", help="N = 1: skip the strong_50gbp block")
     ap.add_argument("--gather-below", type=int, default=0,
                     help="--sharded-extend: the record set is gathered on rank 0 once it has this many records or fewer over all "
                          "ranks (0: the whole loop stays sharded; -1: the library's default, 32 Mi)")
@@ -99,8 +113,15 @@ def parse():
                          "in HBM (reflexiv_amd.dist.sharded_assemble_dev: one RCCL all-to-all of whole records per sortByKey) "
                          "instead of gathering the survivors on rank 0 -- what a genome beyond one GPU needs; k <= 31")
     args = ap.parse_args()
+    if args.strong:
+        args.gbp = 50.0 / args.gpus
+        if args.gpus == 1:
+            args.force_dist, args.virtual_world, args.generations = True, 1, args.strong_generations
+            args.no_k63 = args.no_ingest = args.no_cpu_baseline = True
     if args.gbp is None:
         args.gbp = 5.0 if args.gpus == 1 else 6.25
+    if args.genome is None:
+        args.genome = int(round(4_640_000 * args.gbp * args.gpus / 5.0 / 32)) * 32 if args.gpus > 1 or args.strong else 4_640_000
     if args.cover is None:
         args.cover = max(2, int(round(30 * args.gbp * args.gpus / 5.0 * 4_640_000 / args.genome)))
     return args
@@ -214,6 +235,57 @@ def k63_block(args, rfx, torch, reflexiv_amd, d_words, n_reads, wpr, L, dev):
             "per_kernel_ms_per_step": {n: v[0] / args.steps for n, v in sorted(acc.items()) if not n.startswith("stat_")},
             "contigs": {"wall_ms_from_counts": t_asm * 1e3, "wall_ms_reads_to_contigs": t_asm * 1e3 + dt * 1e3, "extend_passes": len(trace),
                         "n_contigs": nc, "longest": lens[:3], "total_bases": sum(lens)}}
+
+
+def strong_block(args, rfx, torch, reflexiv_amd, dev):
+    """north_star's strong-scaling denominator: the 50 Gbp read set (333,333,334 PE150 reads, -cover 300 -- what 8 GPUs x 6.25
+    Gbp hold between them) counted on ONE GPU in G sequential generations of the hash space (rfx_dev_sharded_count on a
+    one-rank communicator: bucketed once by generation, each generation counted where it lies).  8-GPU efficiency =
+    value of the N = 8 line / (8 x this value)."""
+    L, k, G = args.read_len, args.k, args.strong_generations
+    wpr = (L + 31) // 32
+    n_reads = int(round(50e9 / L))
+    n_reads += n_reads & 1
+    genome = 46_400_000 if not args.strong else args.genome       # the depth of configs[1]: what `--gpus 8` counts by default
+    cover = max(2, int(round(30 * 50.0 / 5.0 * 4_640_000 / genome)))
+    n_inst = rfx.kmers_per_read(L, k) * n_reads
+    d_genome = torch.empty((genome + 31) // 32, dtype=torch.int64, device=dev)
+    d_words = torch.empty(n_reads * wpr, dtype=torch.int64, device=dev)
+    cap = max(1 << 24, 2 * genome)
+    d_keys = torch.empty(cap, dtype=torch.int64, device=dev)
+    d_counts = torch.empty(cap, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    rfx.synth_genome_dev(args.seed, genome, d_genome.data_ptr())
+    rfx.synth_reads_dev(args.seed, d_genome.data_ptr(), genome, 0, n_reads, L, wpr, d_words.data_ptr())
+    rfx.sync()
+    made = not getattr(rfx, "comm", None)
+    if made:
+        rfx.comm_init(reflexiv_amd.Reflexiv.comm_unique_id(), 0, 1)
+    old = os.environ.pop("RFX_COMM_VIRTUAL_WORLD", None)
+    try:
+        def step():
+            return rfx.sharded_count_dev(d_words.data_ptr(), n_reads, wpr, L, k, d_keys.data_ptr(), d_counts.data_ptr(), cap, cover, generations=G)
+        step()
+        torch.cuda.synchronize()
+        steps = 3
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m, tot = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        tm = {n: ms for n, (ms, ln) in rfx.count_timing().items() if not n.startswith("stat_")}
+    finally:
+        if old is not None:
+            os.environ["RFX_COMM_VIRTUAL_WORLD"] = old
+        if made:
+            rfx.comm_destroy()
+    rfx.trim()
+    return {"workload": f"synthetic 50 Gbp, genome {genome} bp (1078x, the depth of configs[1]), PE{L}, k={k}, -cover {cover}: the read set of N = 8 x 6.25 Gbp",
+            "n_gpus": 1, "reads": n_reads, "kmer_instances": n_inst, "generations": G, "distinct_kmers": tot[1], "kmers_kept": tot[2],
+            "steps": steps, "ms_per_step": dt * 1e3, "value": n_inst / dt, "unit": "k-mers/s",
+            "per_kernel_ms_last_step": tm,
+            "how_to_read": "strong-scaling efficiency at N GPUs on this read set = value(N-GPU line, N x 50/N Gbp) / (N x this value); "
+                           "north_star asks >= 6x at N = 8, i.e. value(N = 8) >= 6 x this value"}
 
 
 def main():
@@ -385,10 +457,11 @@ def main():
     out = {
         "metric": "k-mers/sec (extract+count+filter; wall-clock to final contigs beside it)",
         "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "extra_untimed_steps": extra_untimed,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "extra_untimed_steps": extra_untimed,
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"synthetic {args.gbp * world:g} Gbp in all ({args.gbp:g} Gbp per GPU x {world}), "
-                               f"E.coli-like genome {args.genome} bp, PE{L}, k={k}, -cover {args.cover}, 0.5% substitutions",
+                               f"{'E.coli-like ' if args.genome == 4_640_000 else ''}genome {args.genome} bp "
+                               f"({args.gbp * world * 1e9 / args.genome:.0f}x), PE{L}, k={k}, -cover {args.cover}, 0.5% substitutions",
                    "reads_per_gpu": n_reads, "kmer_instances_per_gpu": n_inst, "distinct_kmers": nd,
                    "kmers_kept": m,
                    "parallelism": "1 GPU" if not multi else f"k-mer space radix-sharded over {world} GPUs, "
@@ -415,9 +488,11 @@ def main():
                                    else "reflexiv_amd.dist over torch.distributed",
                            "exchange_free": bool((rd.LOCAL_SHORTCUT or capi) and world == 1),
                            "rehearsed_as_rank_of": args.virtual_world if (capi and world == 1 and args.force_dist) else None}
-    if multi and not args.no_contigs and args.sharded_extend and capi:
-        # every sortByKey of the driver as a range shuffle of whole records behind the C ABI (rfx_dev_sharded_assemble):
-        # the record set stays sharded while it has more than --gather-below records, then rank 0 finishes
+    if multi and not args.no_contigs and capi:
+        # the extend stage behind the C ABI (rfx_dev_sharded_assemble): every sortByKey of the driver is a range shuffle of whole
+        # records over the ranks while the record set has more than gather_below records (the library's 32 Mi unless
+        # --sharded-extend names one), then rank 0 finishes -- a bacterial genome's survivors go to rank 0 at once
+        gather_below = args.gather_below if args.sharded_extend else -1
         prm = reflexiv_amd.default_params(k=k, min_cov=args.cover, partitions=args.partitions)
         sk, sc = shard["keys"].contiguous(), shard["counts"].contiguous()
         ms = int(sc.numel())
@@ -429,16 +504,22 @@ def main():
             ms = rfx.counter_to_asm_dev(sk.data_ptr(), sc.data_ptr(), ms, k, a_k.data_ptr(), a_c.data_ptr(), args.cover)
             sk, sc = a_k, a_c
         torch.cuda.synchronize()
-        rfx.sharded_assemble_dev(sk.data_ptr(), sc.data_ptr(), ms, prm, gather_below=args.gather_below)     # untimed warm-up, as below
-        sync_all()
-        t1 = time.perf_counter()
-        text, nc, tr = rfx.sharded_assemble_dev(sk.data_ptr(), sc.data_ptr(), ms, prm, gather_below=args.gather_below)
-        sync_all()
-        t_asm = time.perf_counter() - t1
-        if rank == 0:
+        text, nc, tr, t_asm, asm_error = "", 0, [], 0.0, None
+        try:                                                  # (collective: a failure of any rank is an error on every rank)
+            rfx.sharded_assemble_dev(sk.data_ptr(), sc.data_ptr(), ms, prm, gather_below=gather_below)     # untimed warm-up, as below
+            sync_all()
+            t1 = time.perf_counter()
+            text, nc, tr = rfx.sharded_assemble_dev(sk.data_ptr(), sc.data_ptr(), ms, prm, gather_below=gather_below)
+            sync_all()
+            t_asm = time.perf_counter() - t1
+        except reflexiv_amd.RfxError as e:                    # the count stage's line is not lost over the extend stage
+            asm_error = str(e)[:400]
+        if rank == 0 and asm_error:
+            out["contigs"] = {"error": asm_error}
+        elif rank == 0:
             lens = sorted((int(h.split("-")[1]) for h in text.split("\n") if h.startswith(">")), reverse=True)
-            out["contigs"] = {"driver": f"rfx_dev_sharded_assemble: sortByKey as a range shuffle over the ranks while the record set has more than "
-                                        f"{args.gather_below} records, then the one-GPU driver on rank 0",
+            out["contigs"] = {"driver": "rfx_dev_sharded_assemble: sortByKey as a range shuffle over the ranks while the record set has more than "
+                                        + (f"{gather_below}" if gather_below >= 0 else "32 Mi (the default)") + " records, then the one-GPU driver on rank 0",
                               "wall_ms_from_counts": t_asm * 1e3, "wall_ms_reads_to_contigs": t_asm * 1e3 + dt / args.steps * 1e3,
                               "untimed_warmup_runs": 1, "extend_passes": len(tr), "n_contigs": nc, "longest": lens[:3],
                               "total_bases": sum(lens), "sha256_text": __import__("hashlib").sha256(text.encode()).hexdigest()}
@@ -519,7 +600,7 @@ def main():
         out["contigs"] = {"wall_ms_from_counts": t_asm * 1e3, "wall_ms_reads_to_contigs": t_asm * 1e3 + dt / args.steps * 1e3,
                           "untimed_warmup_runs": 1, "extend_passes": len(trace), "n_contigs": nc, "longest": lens[:3],
                           "total_bases": sum(lens), "sha256_text": __import__("hashlib").sha256(text.encode()).hexdigest()}
-    if rank == 0 and not args.no_contigs and "contigs" in out and not args.sharded_extend:
+    if rank == 0 and not args.no_contigs and "contigs" in out and not multi and "error" not in out["contigs"]:
         # contig RC de-duplication (P/ReflexivDSDynamicKmerDedup.java) of the text the path just wrote:
         # the fixed-k path reports every contig on both strands, this reports each once
         rfx.dedup_contig_text(text, 500)                                          # untimed warm-up, as everywhere
@@ -561,6 +642,15 @@ def main():
         # the same reads at k = 63 (BASELINE config 4's k; two-word k-mers): count stage + counts -> contigs, so that the
         # driver's N = 1 run times it too
         out["k63"] = k63_block(args, rfx, torch, reflexiv_amd, d_words, n_reads, wpr, L, dev)
+    if rank == 0 and not multi and not wide and not args.no_strong and k == 31 and args.gbp == 5.0:
+        # the strong-scaling denominator (VERDICT r03 missing 2): the 50 Gbp set of the 8-GPU configs on this ONE GPU
+        del d_words, d_keys, d_counts
+        torch.cuda.empty_cache()
+        rfx.trim()
+        try:
+            out["strong_50gbp"] = strong_block(args, rfx, torch, reflexiv_amd, dev)
+        except Exception as e:                                # noqa: BLE001 -- an extra block must not cost the line
+            out["strong_50gbp"] = {"error": repr(e)[:300]}
     if cpu_record is not None:
         out["cpu_baseline"] = cpu_record
     if rank == 0:

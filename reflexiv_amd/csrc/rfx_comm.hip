@@ -285,7 +285,10 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
     // the receive buffer is sized BEFORE the matrix travels, from what this rank sends (owners are balanced, so what
     // arrives is about what leaves), and its capacity travels with the counts: every rank can then see whether ANY
     // rank's buffer is short, and only then is there a second agreement (below) -- none in the steady state
-    if (st_local == RFX_OK) {
+    // ONE rank (a one-GPU run in G sequential generations: the strong-scaling denominator of bench.py, a set too large for
+    // one fused count): nothing travels, a generation is counted where the bucketing left it -- no receive buffer, no copy
+    const bool direct = world == 1 && vworld == 1 && !c->self_via_rccl;
+    if (st_local == RFX_OK && !direct) {
         const int sg = comm_grow(ctx, &c->recv, &c->recv_bytes, (size_t)std::max<int64_t>(1, nrec + nrec / 8 + 4096) * uw * 8, ctx->stream, c->xs);
         if (sg != RFX_OK) st_local = sg;
     }
@@ -342,7 +345,7 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
                     need += u;
                     mx = std::max(mx, u * uw);
                 }
-        if (need > h_all[(size_t)r * row + np + 1]) any_short = true;
+        if (need > h_all[(size_t)r * row + np + 1] && !direct) any_short = true;
     }
     const int64_t rounds = std::max<int64_t>(1, (mx + (int64_t)(c->limit_bytes / 8) - 1) / (int64_t)(c->limit_bytes / 8));
     if (any_short) {                                                // the short ranks grow; everybody learns how that went
@@ -358,7 +361,7 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
     // 3. all G exchanges queued back to back on the exchange stream
     RFX_HIP(hipEventRecord(c->ev_ready, ctx->stream));
     RFX_HIP(hipStreamWaitEvent(c->xs, c->ev_ready, 0));
-    for (int g = 0; g < G; g++) {
+    for (int g = 0; g < G && !direct; g++) {
         RFX_TRY(alltoallv_words(c, (const uint64_t *)c->send, &soff[(size_t)g * world * SP], &scnt[(size_t)g * world * SP], (uint64_t *)c->recv,
                                 &roff[(size_t)g * world * SP], &rcnt[(size_t)g * world * SP], rounds, SP, c->xs));
         RFX_HIP(hipEventRecord(c->ev[g], c->xs));
@@ -369,13 +372,13 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
     int64_t m = 0, distinct = 0;
     int st_keep = RFX_OK, st_fail = RFX_OK;
     for (int g = 0; g < G; g++) {
-        if (hipEventSynchronize(c->ev[g]) != hipSuccess) { if (st_fail == RFX_OK) { st_fail = RFX_E_HIP; ctx->last_error = "rfx_dev_sharded_count: hipEventSynchronize failed"; } continue; }
+        if (!direct && hipEventSynchronize(c->ev[g]) != hipSuccess) { if (st_fail == RFX_OK) { st_fail = RFX_E_HIP; ctx->last_error = "rfx_dev_sharded_count: hipEventSynchronize failed"; } continue; }
         note_foreign_hip_error(ctx, "rfx_dev_sharded_count (exchange)");      // (the kernels' launch checks below must not see RCCL's leftovers)
         if (st_fail != RFX_OK) continue;
         const int64_t ng = gen_off[g + 1] - gen_off[g];
         int64_t mg = 0, dg = 0;
         const int64_t room = std::max<int64_t>(0, cap - m);
-        const void *src = (const uint64_t *)c->recv + gen_off[g] * uw;
+        const void *src = direct ? (const void *)((const uint64_t *)c->send + pb[g] * uw) : (const void *)((const uint64_t *)c->recv + gen_off[g] * uw);
         ctx->timing.clear();
         int st;
         if (wide)

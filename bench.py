@@ -359,7 +359,7 @@ def main():
         args.exchange = "records"
     engine = rd.HipEngine(rfx, combine=args.exchange == "pairs" and not wide)
     engine.force_exchange = args.force_dist
-    capi = multi and args.exchange == "records" and args.exchange_impl == "capi" and (21 <= k <= 31 or 33 <= k <= 63)
+    capi = multi and args.exchange == "records" and args.exchange_impl == "capi" and (3 <= k <= 125 and k % 32 != 0)
     if capi:
         if world == 1 and args.force_dist and args.virtual_world > 1:
             os.environ["RFX_COMM_VIRTUAL_WORLD"] = str(args.virtual_world)

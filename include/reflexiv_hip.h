@@ -358,8 +358,10 @@ int rfx_dev_merge_pairs(rfx_ctx *ctx, const void *d_pairs, int64_t n_pairs, int 
  *   rfx_comm_all_reduce_i64 sum (op 0) / max (op 1) of up to 8 host int64 over the ranks, in place (count() of the
  *                           stop rule, totals, a barrier)
  *   rfx_dev_sharded_count   collective: this rank's packed reads in HBM (d_read_len: per-read lengths for ragged reads,
- *                           k <= 31, or NULL = every read has read_len bases) -> its shard of the filtered (k-mer, count) list,
- *                           ascending (d_out_counts: int32 for k <= 31, int64 for k = 33..63, as the fused calls);
+ *                           k = 21..31, or NULL = every read has read_len bases) -> its shard of the filtered (k-mer, count) list,
+ *                           ascending (d_out_counts: int32 for k <= 31, int64 beyond, as the fused calls; k / 32 + 1 words per
+ *                           key).  k = 21..31 and 33..63 exchange super-k-mer records in generations; every other k of the
+ *                           counters (3..20, 65..125; not a multiple of 32) exchanges its k-mer instances in one go;
  *                           out_totals[3] = instances, distinct, survivors over ALL ranks.  `generations` (1..8) cuts
  *                           the hash space so that generation g is counted while g+1.. travel.  RFX_E_CAP -- on
  *                           EVERY rank when the shard of ANY rank did not fit -- with *out_n = what this rank needs.

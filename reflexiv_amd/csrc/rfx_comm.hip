@@ -17,6 +17,7 @@
 #include <dlfcn.h>
 #include <mutex>
 #include "rfx_comm.h"
+#include "rfx_device.h"
 
 NcclApi &nccl() {
     static NcclApi api;
@@ -185,6 +186,149 @@ int alltoallv_words(rfx_comm *c, const uint64_t *d_send, const int64_t *send_off
     return RFX_OK;
 }
 
+// ---- k outside the record path (k = 3..20 one-word k-mers; k = 65..125 with k % 32 != 0: three- and four-word k-mers in the
+// counter's layout): the units of the exchange are the k-mer instances themselves.  Not a BASELINE configuration (both of
+// its k's take the record path); here so that the sharded counter takes every k the one-GPU counters take
+// (P/ReflexivDataFrameCounter64.java:401-650, klist of U/DefaultParam.java:87: 67, 81, 95).
+namespace {
+__global__ void k_owner_w(const uint64_t *__restrict__ aos, int64_t n, int W, int world, uint64_t *__restrict__ owner, uint32_t *__restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t h = 0;
+    for (int w = 0; w < W; w++) h = rfxd::mix64(h ^ aos[i * W + w]);
+    owner[i] = (uint64_t)__umul64hi(h, (uint64_t)world);
+    idx[i] = (uint32_t)i;
+}
+__global__ void k_gather_w(const uint64_t *__restrict__ aos, const uint32_t *__restrict__ idx, int64_t n, int W, uint64_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t *s = aos + (int64_t)idx[i] * W;
+    for (int w = 0; w < W; w++) out[i * W + w] = s[w];
+}
+__global__ void k_owner_counts(const uint64_t *__restrict__ sorted_owner, int64_t n, int world, int64_t *__restrict__ off) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;          // off[t] = first index with owner >= t
+    if (t > world) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sorted_owner[mid] < (uint64_t)t) lo = mid + 1; else hi = mid; }
+    off[t] = lo;
+}
+}  // namespace
+
+static int sharded_count_kmers(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, int64_t n_reads, int wpr, int read_len, int k, int fc, int ec,
+                               int min_cov, int max_cov, int twin, uint64_t *d_out_keys, void *d_out_counts, int64_t cap, int64_t *out_n,
+                               int64_t *out_totals) {
+    const int world = c->world, me = c->rank;
+    const bool wide = k > 32;
+    const int W = wide ? k / 32 + 1 : 1;
+    NcclApi &n = nccl();
+    const int64_t nk = wide ? rfx::kmers_per_read_w(read_len, k, fc, ec) : rfx::kmers_per_read(read_len, k, fc, ec);
+    const int64_t N = nk * n_reads;
+    int64_t hoff[65];
+    for (int i = 0; i <= 64; i++) hoff[i] = 0;
+    DevBuf units;                                             // this rank's k-mers grouped by owner (AoS, W words each)
+    // this rank's own part (its failure travels in the matrix)
+    auto bucket = [&]() -> int {
+        if (N >= ((int64_t)1 << 32)) { ctx->last_error = "rfx_dev_sharded_count (k-mer units): at most 2^32 - 1 instances per rank and call"; return RFX_E_LIMIT; }
+        RFX_HIP(units.alloc((size_t)std::max<int64_t>(1, N) * W * 8, ctx->stream));
+        if (N == 0) return RFX_OK;
+        if (!wide) {
+            rfx::ReadStore rs{d_words, n_reads, wpr, read_len, k, fc, ec};
+            DevBuf doff;
+            RFX_HIP(doff.alloc((size_t)(world + 1) * 8, ctx->stream));
+            RFX_TRY(rfx::bucket_by_owner(ctx, &rs, world, units.as<uint64_t>(), N, doff.as<int64_t>(), hoff));
+            return RFX_OK;
+        }
+        DevBuf aos, owner, idx, tk, tv, doff;
+        RFX_HIP(aos.alloc((size_t)N * W * 8, ctx->stream));
+        RFX_HIP(owner.alloc((size_t)N * 8, ctx->stream));
+        RFX_HIP(idx.alloc((size_t)N * 4, ctx->stream));
+        RFX_HIP(tk.alloc((size_t)N * 8, ctx->stream));
+        RFX_HIP(tv.alloc((size_t)N * 4, ctx->stream));
+        RFX_HIP(doff.alloc((size_t)(world + 1) * 8, ctx->stream));
+        RFX_TRY(rfx::extract_w(ctx, d_words, wpr, nullptr, nk, n_reads, k, fc, aos.as<uint64_t>(), N, 1));
+        const unsigned g = (unsigned)ceil_div(N, 256);
+        hipLaunchKernelGGL(k_owner_w, dim3(g), dim3(256), 0, ctx->stream, (const uint64_t *)aos.as<uint64_t>(), N, W, world, owner.as<uint64_t>(), idx.as<uint32_t>());
+        RFX_HIP(hipGetLastError());
+        RFX_TRY(rfx::sort_pairs(ctx, owner.as<uint64_t>(), idx.as<uint32_t>(), N, 8, tk.as<uint64_t>(), tv.as<uint32_t>()));
+        hipLaunchKernelGGL(k_gather_w, dim3(g), dim3(256), 0, ctx->stream, (const uint64_t *)aos.as<uint64_t>(), (const uint32_t *)idx.as<uint32_t>(), N, W, units.as<uint64_t>());
+        RFX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_owner_counts, dim3(1), dim3(128), 0, ctx->stream, (const uint64_t *)owner.as<uint64_t>(), N, world, doff.as<int64_t>());
+        RFX_HIP(hipGetLastError());
+        RFX_HIP(hipMemcpyAsync(hoff, doff.p, (size_t)(world + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_TRY(sync_checked(ctx));
+        return RFX_OK;
+    };
+    int st_local = bucket();
+    if (st_local != RFX_OK) { (void)hipStreamSynchronize(ctx->stream); for (int i = 0; i <= 64; i++) hoff[i] = 0; }
+    c->bytes_bucketed = (st_local == RFX_OK ? N : 0) * W * 8;
+    // the count matrix: row = [world] k-mers for each owner, then this rank's status
+    const int row = world + 1;
+    int64_t *h_mine = c->h_tab, *h_all = c->h_tab + TABW;
+    for (int p = 0; p < world; p++) h_mine[p] = hoff[p + 1] - hoff[p];
+    h_mine[world] = st_local;
+    RFX_HIP(hipMemcpyAsync(c->d_tab, h_mine, (size_t)row * 8, hipMemcpyHostToDevice, c->xs));
+    RFX_NCCL(n.AllGather(c->d_tab, c->d_tab + TABW, (size_t)row, ncclInt64, c->comm, c->xs));
+    RFX_HIP(hipMemcpyAsync(h_all, c->d_tab + TABW, (size_t)row * world * 8, hipMemcpyDeviceToHost, c->xs));
+    RFX_HIP(hipStreamSynchronize(c->xs));
+    note_foreign_hip_error(ctx, "rfx_dev_sharded_count (k-mer units: count matrix)");
+    for (int r = 0; r < world; r++)
+        if (h_all[(size_t)r * row + world] != RFX_OK) {
+            if (st_local != RFX_OK) return st_local;
+            ctx->last_error = "rfx_dev_sharded_count: a peer failed before the exchange; see its rfx_last_error()";
+            return RFX_E_STATE;
+        }
+    std::vector<int64_t> soff(world), scnt(world), roff(world), rcnt(world);
+    int64_t n_in = 0, mx = 0;
+    for (int s_ = 0; s_ < world; s_++) {
+        const int64_t u = h_all[(size_t)s_ * row + me];
+        roff[s_] = n_in * W; rcnt[s_] = u * W; n_in += u;
+        soff[s_] = hoff[s_] * W; scnt[s_] = (hoff[s_ + 1] - hoff[s_]) * W;
+    }
+    for (size_t i = 0; i < (size_t)world * row; i++) if ((int)(i % row) < world) mx = std::max(mx, h_all[i] * W);
+    const int64_t lim = (int64_t)(c->limit_bytes / 8);
+    const int64_t rounds = std::max<int64_t>(1, (mx + lim - 1) / lim);
+    // what arrives, and whether every rank could make room for it (the all-reduce below is every rank's, always)
+    DevBuf recv, soa;
+    int st_recv = RFX_OK;
+    if (recv.alloc((size_t)std::max<int64_t>(1, n_in) * W * 8, ctx->stream) != hipSuccess) { st_recv = RFX_E_HIP; ctx->last_error = "rfx_dev_sharded_count: no room for what arrives"; }
+    if (n_in >= ((int64_t)1 << 32)) { st_recv = RFX_E_LIMIT; ctx->last_error = "rfx_dev_sharded_count (k-mer units): a shard of 2^32 instances or more"; }
+    {
+        int64_t bad[1] = {st_recv != RFX_OK ? 1 : 0};
+        RFX_TRY(rfx_comm_all_reduce_i64(c, bad, 1, 1));
+        if (st_recv != RFX_OK) return st_recv;
+        if (bad[0]) { ctx->last_error = "rfx_dev_sharded_count: a peer could not take its shard"; return RFX_E_STATE; }
+    }
+    RFX_HIP(hipEventRecord(c->ev_ready, ctx->stream));
+    RFX_HIP(hipStreamWaitEvent(c->xs, c->ev_ready, 0));
+    RFX_TRY(alltoallv_words(c, units.as<uint64_t>(), soff.data(), scnt.data(), recv.as<uint64_t>(), roff.data(), rcnt.data(), rounds, 1, c->xs));
+    RFX_HIP(hipStreamSynchronize(c->xs));
+    note_foreign_hip_error(ctx, "rfx_dev_sharded_count (k-mer units: exchange)");
+    units.release();
+    // this rank's shard: count + filter (a failure from here on is carried into the closing all-reduce)
+    int64_t m = 0, distinct = 0;
+    int st_cnt = RFX_OK;
+    ctx->timing.clear();
+    if (!wide) {
+        st_cnt = rfx::count_filter(ctx, nullptr, recv.as<uint64_t>(), n_in, min_cov, max_cov, twin, nullptr, 0, d_out_keys, (int32_t *)d_out_counts, cap, &m, &distinct);
+    } else {
+        auto cnt = [&]() -> int {
+            RFX_HIP(soa.alloc((size_t)std::max<int64_t>(1, n_in) * W * 8, ctx->stream));
+            if (n_in > 0) RFX_TRY(rfx::aos_to_soa(ctx, recv.as<uint64_t>(), n_in, W, soa.as<uint64_t>()));
+            return rfx::count_filter_w(ctx, soa.as<uint64_t>(), n_in, k, min_cov, max_cov, d_out_keys, (int64_t *)d_out_counts, cap, &m, &distinct);
+        };
+        st_cnt = cnt();
+    }
+    { const int ss = sync_checked(ctx); if (st_cnt == RFX_OK || st_cnt == RFX_E_CAP) { if (ss != RFX_OK) st_cnt = ss; } }
+    ScopedTimer::collect(ctx);
+    if (out_n) *out_n = m;
+    int64_t tot[5] = {N, distinct, m, st_cnt == RFX_E_CAP ? 1 : 0, (st_cnt != RFX_OK && st_cnt != RFX_E_CAP) ? 1 : 0};
+    RFX_TRY(rfx_comm_all_reduce_i64(c, tot, 5, 0));
+    if (st_cnt != RFX_OK && st_cnt != RFX_E_CAP) return st_cnt;
+    if (tot[4] > 0) { ctx->last_error = "rfx_dev_sharded_count: a peer failed while counting its shard; see its rfx_last_error()"; return RFX_E_STATE; }
+    if (out_totals) { out_totals[0] = tot[0]; out_totals[1] = tot[1]; out_totals[2] = tot[2]; }
+    return tot[3] > 0 ? RFX_E_CAP : RFX_OK;
+}
+
 extern "C" {
 
 static void add_timing(std::map<std::string, rfx_timing_slot> &acc, const std::map<std::string, rfx_timing_slot> &t) {
@@ -201,8 +345,13 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
     const bool wide = k > 32;
     if (wide && d_read_len) { ctx->last_error = "ragged reads: k <= 31 only on the device path"; return RFX_E_ARG; }
     if (wide ? (k > 63) : (k < 21 || k > 31)) {
-        ctx->last_error = "rfx_dev_sharded_count exchanges super-k-mer records: k = 21..31 or 33..63";
-        return RFX_E_ARG;
+        // outside the record path the k-mer instances themselves travel (one-word k-mers up to k = 31, the counter's three- and
+        // four-word k-mers up to k = 125); k a multiple of 32 is no k of the reference's counters either
+        if (d_read_len) { ctx->last_error = "ragged reads: k = 21..31 only on the sharded device path"; return RFX_E_ARG; }
+        if (k < 3 || k > 125 || k % 32 == 0) { ctx->last_error = "rfx_dev_sharded_count: k = 3..125, not a multiple of 32"; return RFX_E_ARG; }
+        RFX_HIP(hipSetDevice(ctx->device));
+        return sharded_count_kmers(ctx, c, d_words, n_reads, words_per_read, read_len, k, front_clip, end_clip, min_cov, max_cov, twin,
+                                   d_out_keys, d_out_counts, cap, out_n, out_totals);
     }
     const int world = c->world, me = c->rank;
     int G = generations;
@@ -372,7 +521,9 @@ int rfx_dev_sharded_count(rfx_ctx *ctx, rfx_comm *c, const uint64_t *d_words, co
     int64_t m = 0, distinct = 0;
     int st_keep = RFX_OK, st_fail = RFX_OK;
     for (int g = 0; g < G; g++) {
-        if (!direct && hipEventSynchronize(c->ev[g]) != hipSuccess) { if (st_fail == RFX_OK) { st_fail = RFX_E_HIP; ctx->last_error = "rfx_dev_sharded_count: hipEventSynchronize failed"; } continue; }
+        // generation g has landed: the CONTEXT'S STREAM waits for it, not the host (the count's first kernels queue up behind
+        // the event while the host goes on; round 3 held the host here once per generation)
+        if (!direct && hipStreamWaitEvent(ctx->stream, c->ev[g], 0) != hipSuccess) { if (st_fail == RFX_OK) { st_fail = RFX_E_HIP; ctx->last_error = "rfx_dev_sharded_count: hipStreamWaitEvent failed"; } continue; }
         note_foreign_hip_error(ctx, "rfx_dev_sharded_count (exchange)");      // (the kernels' launch checks below must not see RCCL's leftovers)
         if (st_fail != RFX_OK) continue;
         const int64_t ng = gen_off[g + 1] - gen_off[g];

@@ -91,7 +91,7 @@ def sharded_extend_cases(rfx, rank, world, dw, da, n_reads, wpr, L, cover, confi
             assert text == "" and nc == 0
 
 
-def run_rank(rank, world, work, cases=((31, 1), (31, 4), (25, 3), (63, 2), (47, 4)), n_reads=60_000,
+def run_rank(rank, world, work, cases=((31, 1), (31, 4), (25, 3), (63, 2), (47, 4), (15, 1), (67, 1), (95, 2)), n_reads=60_000,
              extend=((31, 4, 0), (31, 8, 0), (31, 3, 2000), (31, 8, -1), (63, 4, 0), (63, 8, 3000))):
     import torch
     import reflexiv_amd
@@ -143,7 +143,7 @@ def run_rank(rank, world, work, cases=((31, 1), (31, 4), (25, 3), (63, 2), (47, 
     for k, gens in cases:
         want = want31 if (rank == 0 and k == 31) else None
         wide = k > 32
-        W = 2 if wide else 1
+        W = k // 32 + 1 if wide else 1                         # (k = 15, 67, 95: outside the record path, the k-mers themselves travel)
         nk = (rfx.kmers_per_read_w if wide else rfx.kmers_per_read)(L, k)
         cap = nk * n_reads
         cdt = torch.int64 if wide else torch.int32
@@ -172,7 +172,12 @@ def run_rank(rank, world, work, cases=((31, 1), (31, 4), (25, 3), (63, 2), (47, 
             assert got == allm
             fk = torch.empty(cap * world * W, dtype=torch.int64, device="cuda"); fc = torch.empty(cap * world, dtype=cdt, device="cuda")
             torch.cuda.synchronize()
-            if wide:
+            if wide and W > 2:
+                m, nd, inst = rfx.count_reads_w_dev(da.data_ptr(), world * n_reads, wpr, L, k, fk.data_ptr(), fc.data_ptr(), cap * world, cover)
+                hk = gk[:got * W].cpu().numpy().view(np.uint64).reshape(-1, W); hc = gc[:got].cpu().numpy()
+                o = np.lexsort([hk[:, w] for w in range(W - 1, -1, -1)])      # ascending by (word 0, word 1, ...)
+                rk = torch.from_numpy(hk[o].reshape(-1).view(np.int64).copy()).cuda(); rc = torch.from_numpy(hc[o].copy()).cuda()
+            elif wide:
                 m, nd, inst = rfx.count_reads_w_dev(da.data_ptr(), world * n_reads, wpr, L, k, fk.data_ptr(), fc.data_ptr(), cap * world, cover)
                 rfx.order_kmers_w_dev(gk.data_ptr(), gc.data_ptr(), got, k)
                 rfx.sync()

@@ -21,10 +21,16 @@ __global__ void k(uint32_t *out, uint32_t seed, unsigned long long *clk) {
         for (int u = 0; u < UNR; u++) {
             // four independent chains (a, b, c, d) so that the issue rate, not a dependency, is measured
             if (MODE == 0) { a += b; b += c; c += d; d += a; }                                            // v_add_u32
-            if (MODE == 1) { a ^= b; b ^= c; c ^= d; d ^= a; }                                            // v_xor_b32
+            // (round 4: xor and multiply chains are linear maps the compiler folded away -- 0.006 ms, "0.08 cycles" in
+            // profiles/r03_valu_bench.txt; as volatile inline assembly they are the instructions themselves)
+            if (MODE == 1) { asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a) : "v"(b)); asm volatile("v_xor_b32 %0, %0, %1" : "+v"(b) : "v"(c));
+                             asm volatile("v_xor_b32 %0, %0, %1" : "+v"(c) : "v"(d)); asm volatile("v_xor_b32 %0, %0, %1" : "+v"(d) : "v"(a)); }   // v_xor_b32
             if (MODE == 2) { a = __builtin_amdgcn_alignbit(a, b, 7); b = __builtin_amdgcn_alignbit(b, c, 9);
                              c = __builtin_amdgcn_alignbit(c, d, 11); d = __builtin_amdgcn_alignbit(d, a, 13); }   // v_alignbit_b32
-            if (MODE == 3) { a *= 0x9E3779B1u; b *= 0x85EBCA6Bu; c *= 0xC2B2AE35u; d *= 0x27D4EB2Fu; }      // v_mul_lo_u32
+            if (MODE == 3) { asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a) : "v"(d | 1u)); asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(b) : "v"(d | 1u));
+                             asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(c) : "v"(d | 1u)); }                  // v_mul_lo_u32 (three chains, one odd multiplier)
+            if (MODE == 11) { asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(a) : "v"(d)); asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(b) : "v"(d));
+                              asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(c) : "v"(d)); }                 // v_mad_u32_u24 (level 1's minimiser order)
             if (MODE == 4) { x = (x << 3) ^ y; y = (y >> 5) ^ x; x = (x << 7) ^ y; y = (y >> 9) ^ x; }      // 64-bit shifts + xors
             if (MODE == 5) { a = __brev(a) ^ b; b = __brev(b) ^ c; c = __brev(c) ^ d; d = __brev(d) ^ a; }  // v_bfrev + xor
             if (MODE == 6) { a = a < b ? a : b + 1; b = b < c ? b : c + 1; c = c < d ? c : d + 1; d = d < a ? d : a + 1; }   // min-like: cmp + cndmask / v_min
@@ -75,7 +81,8 @@ int main() {
         run<0>("v_add_u32", 4, thr, wg, ncu, d_out, d_clk);
         run<1>("v_xor_b32", 4, thr, wg, ncu, d_out, d_clk);
         run<2>("v_alignbit_b32", 4, thr, wg, ncu, d_out, d_clk);
-        run<3>("v_mul_lo_u32", 4, thr, wg, ncu, d_out, d_clk);
+        run<3>("v_mul_lo_u32", 3, thr, wg, ncu, d_out, d_clk);
+        run<11>("v_mad_u32_u24", 3, thr, wg, ncu, d_out, d_clk);
         run<4>("64-bit shift + xor (x4)", 8, thr, wg, ncu, d_out, d_clk);
         run<5>("v_bfrev + xor", 8, thr, wg, ncu, d_out, d_clk);
         run<6>("compare-select / min", 8, thr, wg, ncu, d_out, d_clk);

@@ -505,6 +505,21 @@ def main():
             sk, sc = a_k, a_c
         torch.cuda.synchronize()
         text, nc, tr, t_asm, asm_error = "", 0, [], 0.0, None
+        # a watchdog: the count stage's line must not be lost over the extend stage.  More than one rank with real RCCL runs
+        # here for the first time on the driver's 8-GPU node (the build pool has one GPU per session): if the collective path
+        # does not come back within RFX_BENCH_EXTEND_TIMEOUT_S, rank 0 prints the line with the timeout recorded and every
+        # rank leaves.
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["contigs"] = {"error": "the multi-GPU extend stage did not return within the bench's watchdog time; the count-stage "
+                                           "fields of this line are complete"}
+                print(json.dumps(out), flush=True)
+            os._exit(0 if rank == 0 else 3)
+        dog = threading.Timer(float(os.environ.get("RFX_BENCH_EXTEND_TIMEOUT_S", "240")), bail)
+        dog.daemon = True
+        dog.start()
         try:                                                  # (collective: a failure of any rank is an error on every rank)
             rfx.sharded_assemble_dev(sk.data_ptr(), sc.data_ptr(), ms, prm, gather_below=gather_below)     # untimed warm-up, as below
             sync_all()
@@ -514,6 +529,7 @@ def main():
             t_asm = time.perf_counter() - t1
         except reflexiv_amd.RfxError as e:                    # the count stage's line is not lost over the extend stage
             asm_error = str(e)[:400]
+        dog.cancel()
         if rank == 0 and asm_error:
             out["contigs"] = {"error": asm_error}
         elif rank == 0:

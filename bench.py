@@ -105,6 +105,9 @@ def parse():
                          "(few steps), the denominator a weak-scaled N = 8 line -- 8 x 6.25 Gbp = the same 50 Gbp -- is read against")
     ap.add_argument("--strong-generations", type=int, default=8)
     ap.add_argument("--no-strong", action="store_true", help="N = 1: skip the strong_50gbp block")
+    ap.add_argument("--no-next-rows", action="store_true",
+                    help="N = 1: skip the `next_rows` block (SURVEY.md 8f-2 / f-4 at scale: the dynamic-k passes on 10^7 rows, the contig RC "
+                         "de-duplication of 10^5 contigs; tools/bench_f2f4.py)")
     ap.add_argument("--gather-below", type=int, default=0,
                     help="--sharded-extend: the record set is gathered on rank 0 once it has this many records or fewer over all "
                          "ranks (0: the whole loop stays sharded; -1: the library's default, 32 Mi)")
@@ -658,6 +661,14 @@ def main():
         # the same reads at k = 63 (BASELINE config 4's k; two-word k-mers): count stage + counts -> contigs, so that the
         # driver's N = 1 run times it too
         out["k63"] = k63_block(args, rfx, torch, reflexiv_amd, d_words, n_reads, wpr, L, dev)
+    if rank == 0 and not multi and not wide and not args.no_next_rows and k == 31 and args.gbp == 5.0:
+        # the two "next" rows of SURVEY.md 8(f) at the scale a metagenome brings: times and bytes moved
+        try:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+            import bench_f2f4
+            out["next_rows"] = {"dedup": bench_f2f4.dedup_block(rfx, 50_000), "dyn": bench_f2f4.dyn_block(rfx, 5_000_000)}
+        except Exception as e:                                # noqa: BLE001 -- an extra block must not cost the line
+            out["next_rows"] = {"error": repr(e)[:300]}
     if rank == 0 and not multi and not wide and not args.no_strong and k == 31 and args.gbp == 5.0:
         # the strong-scaling denominator (VERDICT r03 missing 2): the 50 Gbp set of the 8-GPU configs on this ONE GPU
         del d_words, d_keys, d_counts

@@ -219,9 +219,103 @@ __global__ __launch_bounds__(256) void k_dd_query(const uint8_t *__restrict__ sh
         h = (h + 1) & mask;
     }
 }
+// ---- the merges of a round, BATCHED (round 4).  Until round 3 every (short, long) pair was its own launch sequence with two
+// host waits (93 us a pair: 4.7 s for the 50,000 pairs of a 100,000-contig set); now step j of a round takes the j-th short
+// contig of EVERY group at once: one table region cut into per-merge tables, one seed-insert launch, one query launch whose
+// hits carry their merge's number above the distance, ONE sort of all distances, one vote launch (a wave per merge), one
+// readback of all votes, one copy launch for all the pieces.  Same arithmetic per merge, same order of the outputs.
+struct MergeB {                        // one merge of a batch (device copy)
+    const uint8_t *lng, *sh;
+    int64_t ln, sn;
+    int64_t toff;                      // its table inside the region (slots)
+    uint32_t tmask;
+    int32_t rc, min_votes, active;
+    int64_t spre, qpre;                // first seed thread / first query thread of this merge
+};
+__device__ __forceinline__ int64_t dd_find(const MergeB *__restrict__ mb, int64_t nm, int64_t t, bool query) {
+    int64_t lo = 0, hi = nm;           // the last merge whose first thread is <= t
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((query ? mb[mid].qpre : mb[mid].spre) <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void k_dd_seed_insert_b(const MergeB *__restrict__ mb, int64_t nm, int64_t total, uint32_t *__restrict__ tkey,
+                                                          int32_t *__restrict__ tpos) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const MergeB m = mb[dd_find(mb, nm, t, false)];
+    const int64_t i = (t - m.spre) * 15;
+    if (i > m.ln) return;
+    const uint32_t k = dd_seed_at(m.lng, m.ln, i, 0);
+    uint32_t h = dd_hash(k) & m.tmask;
+    for (;;) {
+        const uint32_t old = atomicCAS(&tkey[m.toff + h], DD_EMPTY, k);
+        if (old == DD_EMPTY || old == k) { atomicMax(&tpos[m.toff + h], (int32_t)(i + 1)); return; }
+        h = (h + 1) & m.tmask;
+    }
+}
+__global__ __launch_bounds__(256) void k_dd_query_b(const MergeB *__restrict__ mb, int64_t nm, int64_t total, const uint32_t *__restrict__ tkey,
+                                                    const int32_t *__restrict__ tpos, uint64_t *__restrict__ dist,
+                                                    unsigned long long *__restrict__ cnt) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int64_t g = dd_find(mb, nm, t, true);
+    const MergeB m = mb[g];
+    if (!m.active) return;
+    const int64_t i = t - m.qpre;
+    if (i >= m.sn) return;
+    const uint32_t k = dd_seed_at(m.sh, m.sn, i, m.rc);
+    uint32_t h = dd_hash(k) & m.tmask;
+    for (;;) {
+        const uint32_t kk = tkey[m.toff + h];
+        if (kk == DD_EMPTY) return;
+        if (kk == k) {
+            const int32_t d = (int32_t)(i + 1) - tpos[m.toff + h];
+            // the merge's number above the biased distance: one sort orders every merge's list
+            dist[atomicAdd(cnt, 1ull)] = ((uint64_t)g << 33) | (uint64_t)((int64_t)d + 0x80000000ll);
+            return;
+        }
+        h = (h + 1) & m.tmask;
+    }
+}
+// seg[g] = first entry of merge g in the sorted list (seg[nm] = total)
+__global__ __launch_bounds__(256) void k_dd_seg_bounds(const uint64_t *__restrict__ dist, int64_t total, int64_t nm, int64_t *__restrict__ seg) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > nm) return;
+    const uint64_t want = (uint64_t)g << 33;
+    int64_t lo = 0, hi = total;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (dist[mid] < want) lo = mid + 1; else hi = mid; }
+    seg[g] = lo;
+}
+// one copy launch for all the pieces of a step (or all the contigs of a round's output)
+struct CopyB { uint8_t *dst; const uint8_t *src; int64_t src_n, from, n, pre; int32_t rc, pad; };
+__global__ __launch_bounds__(256) void k_dd_copy_b(const CopyB *__restrict__ cb, int64_t nc, int64_t total) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    int64_t lo = 0, hi = nc;
+    while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (cb[mid].pre <= t) lo = mid; else hi = mid; }
+    const CopyB c = cb[lo];
+    const int64_t i = t - c.pre;
+    if (i >= c.n) return;
+    const int64_t q = c.from + i;
+    c.dst[i] = c.rc ? (uint8_t)(3 - c.src[c.src_n - 1 - q]) : c.src[q];
+}
+
 // the vote over the sorted distances (:1478-1497 with 3 votes, :578-597 / :617-636 with 4): sequential by definition (the
 // anchor of a run is the first distance that left the previous run)
-__global__ __launch_bounds__(64) void k_dd_vote(const uint64_t *__restrict__ dist, int64_t total, int min_votes, int32_t *__restrict__ out) {
+__global__ __launch_bounds__(64) void k_dd_vote(const uint64_t *__restrict__ dist_all, const int64_t *__restrict__ seg, const MergeB *__restrict__ mb,
+                                                int64_t total_1, int min_votes_1, int32_t *__restrict__ out_all) {
+    // batched: block b votes on merge b's slice of the one sorted list (seg; the merge's number sits above bit 33 of every
+    // entry); seg == nullptr: the single list of rounds 1-3's form
+    const uint64_t *dist = dist_all;
+    int64_t total = total_1;
+    int min_votes = min_votes_1;
+    int32_t *out = out_all;
+    if (seg) {
+        if (!mb[blockIdx.x].active) return;
+        dist = dist_all + seg[blockIdx.x]; total = seg[blockIdx.x + 1] - seg[blockIdx.x]; min_votes = mb[blockIdx.x].min_votes; out = out_all + blockIdx.x;
+    }
     // one wave: 64 distances per coalesced load, then the scan itself on wave-uniform values (readlane) -- the anchor chain
     // is sequential, the memory latency need not be (a thread walking the list alone paid ~13 ns a distance).  And a run
     // need not be walked at all: the list is sorted, so once an element and the LAST element of its block both lie within
@@ -229,7 +323,7 @@ __global__ __launch_bounds__(64) void k_dd_vote(const uint64_t *__restrict__ dis
     // true overlap of two 2.6 Mbp contigs is one run of a million equal distances: 1.9 ms walked, four probes searched), and
     // the vote is won at a known element of it -- the first frequency f with f / total >= 0.3 and f >= min_votes.
     const int lane = threadIdx.x;
-    auto val = [&](int64_t i) -> int32_t { return (int32_t)((int64_t)dist[i] - 0x80000000ll); };
+    auto val = [&](int64_t i) -> int32_t { return (int32_t)((int64_t)(dist[i] & 0x1FFFFFFFFull) - 0x80000000ll); };
     int64_t T = (int64_t)(0.3 * (double)total);
     if (T < 1) T = 1;
     while (T > 1 && (double)(T - 1) / (double)total >= 0.3) T--;
@@ -327,8 +421,8 @@ struct Dedup {
         *n_dist = (int64_t)c;
         // (a second query pass appends to a SORTED prefix: the whole list is sorted again, as Collections.sort does)
         RFX_TRY(sort_pairs(ctx, dist.as<uint64_t>(), dval.as<uint32_t>(), (int64_t)c, 33, dtmp.as<uint64_t>(), dvtmp.as<uint32_t>()));
-        hipLaunchKernelGGL(k_dd_vote, dim3(1), dim3(64), 0, ctx->stream, (const uint64_t *)dist.as<uint64_t>(), (int64_t)c, min_votes,
-                           fin.as<int32_t>());
+        hipLaunchKernelGGL(k_dd_vote, dim3(1), dim3(64), 0, ctx->stream, (const uint64_t *)dist.as<uint64_t>(), (const int64_t *)nullptr,
+                           (const MergeB *)nullptr, (int64_t)c, min_votes, fin.as<int32_t>());
         RFX_HIP(hipGetLastError());
         RFX_HIP(hipMemcpyAsync(out, fin.p, 4, hipMemcpyDeviceToHost, ctx->stream));
         RFX_TRY(sync_checked(ctx));
@@ -452,86 +546,168 @@ int dedup_contigs(rfx_ctx *ctx, const uint8_t *h_bases, const int64_t *h_off, in
             extra += (size_t)len;
             rows.push_back(Contig{at, len, r.id});
         }
-        // ---- the removal class (:1413-1460 / :516-563): groups of equal id, merged into their longest
-        std::vector<Contig> nxt;
-        int64_t used = 0;
-        auto emit = [&](const uint8_t *src, int64_t len) -> int {
-            if ((size_t)(used + len) > pool_cap) { ctx->last_error = "dedup: output pool exhausted"; return RFX_E_LIMIT; }
-            if (len) RFX_HIP(hipMemcpyAsync(pout + used, src, (size_t)len, hipMemcpyDeviceToDevice, ctx->stream));
-            nxt.push_back(Contig{used, len, (int64_t)nxt.size()});
-            used += len;
-            return RFX_OK;
-        };
+        // ---- the removal class (:1413-1460 / :516-563): groups of equal id, merged into their longest.  Step j of the round
+        // merges the j-th short contig of EVERY group in one batch of launches (the groups are independent; inside a group
+        // the shorts meet the growing long contig in row order, as in the reference's loop).
         const int variant = rnd == 1 ? 0 : 1;
-        size_t g0 = 0;
-        while (g0 < rows.size()) {
+        struct Group {
+            size_t li; std::vector<size_t> shorts;
+            const uint8_t *lng; int64_t ln;                   // the long contig as it stands
+            int64_t woff;                                     // the group's place in the two work buffers
+            std::vector<size_t> back;                         // shorts that found no place: back to the pool, ahead of the long one
+        };
+        std::vector<Group> groups;
+        int64_t wused = 0;
+        size_t max_shorts = 0;
+        for (size_t g0 = 0; g0 < rows.size();) {
             size_t g1 = g0 + 1;
             while (g1 < rows.size() && rows[g1].id == rows[g0].id) g1++;
-            // the longest of the group (the first of the longest), the others in row order
-            size_t li = g0;
-            std::vector<size_t> shorts;
-            for (size_t q = g0 + 1; q < g1; q++) {
-                if (rows[q].len > rows[li].len) { shorts.push_back(li); li = q; } else shorts.push_back(q);
+            Group G;
+            G.li = g0;
+            for (size_t q = g0 + 1; q < g1; q++) {            // the longest of the group (the first of the longest), the others in row order
+                if (rows[q].len > rows[G.li].len) { G.shorts.push_back(G.li); G.li = q; } else G.shorts.push_back(q);
             }
-            if (shorts.empty()) { RFX_TRY(emit(pin + rows[li].off, rows[li].len)); g0 = g1; continue; }
-            uint8_t *wa = workA.as<uint8_t>(), *wb = workB.as<uint8_t>();
-            const uint8_t *lng = pin + rows[li].off;
-            int64_t ln = rows[li].len;
-            for (size_t si : shorts) {
-                const uint8_t *sh = pin + rows[si].off;
-                const int64_t sn = rows[si].len;
-                RFX_TRY(dd.merge_scratch(ln, sn));
-                const uint32_t mask = (uint32_t)dd.tcap - 1;
-                hipLaunchKernelGGL(k_dd_fill, dim3((unsigned)ceil_div((int64_t)dd.tcap, 256)), dim3(256), 0, ctx->stream, dd.tkey.as<uint32_t>(),
-                                   DD_EMPTY, (int64_t)dd.tcap);
-                hipLaunchKernelGGL(k_dd_fill, dim3((unsigned)ceil_div((int64_t)dd.tcap, 256)), dim3(256), 0, ctx->stream, dd.tpos.as<uint32_t>(),
-                                   0xFFFFFFFFu, (int64_t)dd.tcap);
-                hipLaunchKernelGGL(k_dd_seed_insert, dim3((unsigned)ceil_div(ln / 15 + 1, 256)), dim3(256), 0, ctx->stream, lng, ln,
-                                   dd.tkey.as<uint32_t>(), dd.tpos.as<int32_t>(), mask);
-                RFX_HIP(hipGetLastError());
-                RFX_HIP(hipMemsetAsync(dd.cnt.p, 0, 16, ctx->stream));
-                int64_t nd = 0;
-                int32_t fd = -1;
-                bool done = false;
-                uint8_t *dst = lng == wa ? wb : wa;
-                if (variant == 1) {                           // the forward strand first (:565-615)
-                    RFX_TRY(dd.query_vote(sh, sn, 0, mask, 4, &nd, &fd));
-                    if (fd == -1 || fd == 0) {
-                    } else if (fd < 0) {
-                        int64_t flank = sn - (ln + fd);
-                        if (flank > sn) flank = sn;
-                        if (flank > 0) {
-                            launch_copy(ctx, dst, lng, ln, 0, ln, 0); launch_copy(ctx, dst + ln, sh, sn, sn - flank, flank, 0);
-                            lng = dst; ln += flank; done = true;
-                        }
-                    } else {
-                        const int64_t p = std::min<int64_t>(sn, fd);
-                        launch_copy(ctx, dst, sh, sn, 0, p, 0); launch_copy(ctx, dst + p, lng, ln, 0, ln, 0);
-                        lng = dst; ln += p; done = true;
-                    }
-                }
-                if (!done) {                                  // the reverse complement (:1462-1557 / :616-728)
-                    RFX_TRY(dd.query_vote(sh, sn, 1, mask, variant == 0 ? 3 : 4, &nd, &fd));
-                    if (fd == -1) { RFX_TRY(emit(sh, sn)); }             // back to the pool, ahead of the long contig
-                    else if (fd == 0) {
-                    } else if (fd < 0) {
-                        int64_t flank = sn - (ln + fd);
-                        if (flank > sn) flank = sn;
-                        if (flank > 0) {
-                            launch_copy(ctx, dst, lng, ln, 0, ln, 0); launch_copy(ctx, dst + ln, sh, sn, sn - flank, flank, 1);
-                            lng = dst; ln += flank;
-                        }
-                    } else {
-                        const int64_t p = std::min<int64_t>(sn, fd);
-                        launch_copy(ctx, dst, sh, sn, 0, p, 1); launch_copy(ctx, dst + p, lng, ln, 0, ln, 0);
-                        lng = dst; ln += p;
-                    }
-                }
-                RFX_HIP(hipGetLastError());
-                if ((size_t)ln > pool_cap) { ctx->last_error = "dedup: a merged contig outgrew the pool"; return RFX_E_LIMIT; }
-            }
-            RFX_TRY(emit(lng, ln));
+            G.lng = pin + rows[G.li].off; G.ln = rows[G.li].len; G.woff = wused;
+            if (!G.shorts.empty()) { for (size_t q = g0; q < g1; q++) wused += rows[q].len; }
+            max_shorts = std::max(max_shorts, G.shorts.size());
+            groups.push_back(std::move(G));
             g0 = g1;
+        }
+        if ((size_t)wused > pool_cap) { ctx->last_error = "dedup: work area exhausted"; return RFX_E_LIMIT; }
+        uint8_t *const wa = workA.as<uint8_t>(), *const wb = workB.as<uint8_t>();
+        DevBuf d_mb, d_cb, d_tkey, d_tpos, d_dist, d_dtmp, d_dval, d_dvtmp, d_cnt, d_seg, d_fd;
+        RFX_HIP(d_cnt.alloc(16, ctx->stream));
+        auto run_copies = [&](std::vector<CopyB> &cb) -> int {
+            int64_t pre = 0;
+            for (auto &c : cb) { c.pre = pre; pre += c.n; }
+            if (cb.empty() || pre == 0) return RFX_OK;
+            RFX_HIP(d_cb.alloc(cb.size() * sizeof(CopyB), ctx->stream));
+            RFX_HIP(hipMemcpyAsync(d_cb.p, cb.data(), cb.size() * sizeof(CopyB), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_dd_copy_b, dim3((unsigned)ceil_div(pre, 256)), dim3(256), 0, ctx->stream, (const CopyB *)d_cb.as<CopyB>(), (int64_t)cb.size(), pre);
+            RFX_HIP(hipGetLastError());
+            RFX_TRY(sync_checked(ctx));                       // (`cb` is read by the queued copy until here)
+            return RFX_OK;
+        };
+        for (size_t j = 0; j < max_shorts; j++) {
+            std::vector<size_t> gi;                           // groups that have a j-th short
+            for (size_t g = 0; g < groups.size(); g++) if (groups[g].shorts.size() > j) gi.push_back(g);
+            const int64_t nm = (int64_t)gi.size();
+            if (nm >= ((int64_t)1 << 30)) { ctx->last_error = "dedup: more than 2^30 merges in one step"; return RFX_E_LIMIT; }
+            std::vector<MergeB> mb((size_t)nm);
+            int64_t tslots = 0, sthreads = 0, qthreads = 0;
+            for (int64_t m = 0; m < nm; m++) {
+                Group &G = groups[gi[(size_t)m]];
+                const size_t si = G.shorts[j];
+                size_t want = 64;
+                while (want < (size_t)(G.ln / 15 + 2) * 2 + 8) want *= 2;
+                MergeB &M = mb[(size_t)m];
+                M.lng = G.lng; M.ln = G.ln; M.sh = pin + rows[si].off; M.sn = rows[si].len;
+                M.toff = tslots; M.tmask = (uint32_t)want - 1;
+                M.rc = variant == 1 ? 0 : 1; M.min_votes = variant == 0 ? 3 : 4; M.active = 1;     // variant 1: the forward strand first (:565-615)
+                M.spre = sthreads; M.qpre = qthreads;
+                tslots += (int64_t)want; sthreads += G.ln / 15 + 1; qthreads += std::max<int64_t>(M.sn, 1);
+            }
+            if (nm == 0) continue;
+            RFX_HIP(d_mb.alloc((size_t)nm * sizeof(MergeB), ctx->stream));
+            RFX_HIP(d_tkey.alloc((size_t)tslots * 4, ctx->stream)); RFX_HIP(d_tpos.alloc((size_t)tslots * 4, ctx->stream));
+            const size_t dcap = (size_t)qthreads * 2 + 16;    // (two query passes may append)
+            RFX_HIP(d_dist.alloc(dcap * 8, ctx->stream)); RFX_HIP(d_dtmp.alloc(dcap * 8, ctx->stream));
+            RFX_HIP(d_dval.alloc(dcap * 4, ctx->stream)); RFX_HIP(d_dvtmp.alloc(dcap * 4, ctx->stream));
+            RFX_HIP(d_seg.alloc((size_t)(nm + 1) * 8, ctx->stream)); RFX_HIP(d_fd.alloc((size_t)nm * 4, ctx->stream));
+            RFX_HIP(hipMemcpyAsync(d_mb.p, mb.data(), (size_t)nm * sizeof(MergeB), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_dd_fill, dim3((unsigned)ceil_div(tslots, 256)), dim3(256), 0, ctx->stream, d_tkey.as<uint32_t>(), DD_EMPTY, tslots);
+            hipLaunchKernelGGL(k_dd_fill, dim3((unsigned)ceil_div(tslots, 256)), dim3(256), 0, ctx->stream, d_tpos.as<uint32_t>(), 0xFFFFFFFFu, tslots);
+            hipLaunchKernelGGL(k_dd_seed_insert_b, dim3((unsigned)ceil_div(sthreads, 256)), dim3(256), 0, ctx->stream, (const MergeB *)d_mb.as<MergeB>(), nm,
+                               sthreads, d_tkey.as<uint32_t>(), d_tpos.as<int32_t>());
+            RFX_HIP(hipGetLastError());
+            RFX_HIP(hipMemsetAsync(d_cnt.p, 0, 16, ctx->stream));
+            int key_bits = 33;
+            while (((int64_t)1 << (key_bits - 33)) < nm) key_bits++;
+            std::vector<int32_t> fd((size_t)nm, -1);
+            // one query pass of the active merges + the vote on every active merge's (grown) list -> fd
+            auto query_vote_b = [&]() -> int {
+                hipLaunchKernelGGL(k_dd_query_b, dim3((unsigned)ceil_div(qthreads, 256)), dim3(256), 0, ctx->stream, (const MergeB *)d_mb.as<MergeB>(), nm, qthreads,
+                                   (const uint32_t *)d_tkey.as<uint32_t>(), (const int32_t *)d_tpos.as<int32_t>(), d_dist.as<uint64_t>(),
+                                   d_cnt.as<unsigned long long>());
+                RFX_HIP(hipGetLastError());
+                unsigned long long c = 0;
+                RFX_HIP(hipMemcpyAsync(&c, d_cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+                RFX_TRY(sync_checked(ctx));
+                // (a second pass appends to a SORTED prefix: the whole list is sorted again, as Collections.sort does)
+                RFX_TRY(sort_pairs(ctx, d_dist.as<uint64_t>(), d_dval.as<uint32_t>(), (int64_t)c, key_bits, d_dtmp.as<uint64_t>(), d_dvtmp.as<uint32_t>()));
+                hipLaunchKernelGGL(k_dd_seg_bounds, dim3((unsigned)ceil_div(nm + 1, 256)), dim3(256), 0, ctx->stream, (const uint64_t *)d_dist.as<uint64_t>(),
+                                   (int64_t)c, nm, d_seg.as<int64_t>());
+                hipLaunchKernelGGL(k_dd_vote, dim3((unsigned)nm), dim3(64), 0, ctx->stream, (const uint64_t *)d_dist.as<uint64_t>(),
+                                   (const int64_t *)d_seg.as<int64_t>(), (const MergeB *)d_mb.as<MergeB>(), (int64_t)0, 0, d_fd.as<int32_t>());
+                RFX_HIP(hipGetLastError());
+                std::vector<int32_t> got((size_t)nm);
+                RFX_HIP(hipMemcpyAsync(got.data(), d_fd.p, (size_t)nm * 4, hipMemcpyDeviceToHost, ctx->stream));
+                RFX_TRY(sync_checked(ctx));
+                for (int64_t m = 0; m < nm; m++) if (mb[(size_t)m].active) fd[(size_t)m] = got[(size_t)m];
+                return RFX_OK;
+            };
+            std::vector<CopyB> cb;
+            std::vector<char> done((size_t)nm, 0);
+            // what a vote means for merge m (rc: the strand the short contig was read in)
+            auto apply = [&](int64_t m, int rc, bool last_pass) {
+                Group &G = groups[gi[(size_t)m]];
+                const size_t si = G.shorts[j];
+                const uint8_t *sh = pin + rows[si].off;
+                const int64_t sn = rows[si].len, ln = G.ln;
+                const int32_t f = fd[(size_t)m];
+                uint8_t *dst = (G.lng == wa + G.woff ? wb : wa) + G.woff;
+                if (f == -1) { if (last_pass) { G.back.push_back(si); done[(size_t)m] = 1; } return; }      // (:1499-1503: back to the pool)
+                if (f == 0) { if (last_pass) done[(size_t)m] = 1; return; }
+                if (f < 0) {
+                    int64_t flank = sn - (ln + f);
+                    if (flank > sn) flank = sn;
+                    if (flank > 0) {
+                        cb.push_back(CopyB{dst, G.lng, ln, 0, ln, 0, 0, 0}); cb.push_back(CopyB{dst + ln, sh, sn, sn - flank, flank, 0, rc, 0});
+                        G.lng = dst; G.ln = ln + flank; done[(size_t)m] = 1;
+                    } else if (last_pass) done[(size_t)m] = 1;
+                } else {
+                    const int64_t p = std::min<int64_t>(sn, f);
+                    cb.push_back(CopyB{dst, sh, sn, 0, p, 0, rc, 0}); cb.push_back(CopyB{dst + p, G.lng, ln, 0, ln, 0, 0, 0});
+                    G.lng = dst; G.ln = ln + p; done[(size_t)m] = 1;
+                }
+            };
+            RFX_TRY(query_vote_b());
+            if (variant == 1) {
+                for (int64_t m = 0; m < nm; m++) apply(m, 0, false);
+                // the merges the forward strand did not settle go on to the reverse complement (:616-728), their list growing
+                bool any = false;
+                for (int64_t m = 0; m < nm; m++) { mb[(size_t)m].active = done[(size_t)m] ? 0 : 1; mb[(size_t)m].rc = 1; mb[(size_t)m].min_votes = 4; any = any || !done[(size_t)m]; }
+                if (any) {
+                    RFX_HIP(hipMemcpyAsync(d_mb.p, mb.data(), (size_t)nm * sizeof(MergeB), hipMemcpyHostToDevice, ctx->stream));
+                    RFX_TRY(query_vote_b());
+                    for (int64_t m = 0; m < nm; m++) if (mb[(size_t)m].active) apply(m, 1, true);
+                }
+            } else {
+                for (int64_t m = 0; m < nm; m++) apply(m, 1, true);
+            }
+            for (int64_t m = 0; m < nm; m++) {
+                const Group &G = groups[gi[(size_t)m]];
+                if ((size_t)(G.woff + G.ln) > pool_cap) { ctx->last_error = "dedup: a merged contig outgrew the pool"; return RFX_E_LIMIT; }
+            }
+            RFX_TRY(run_copies(cb));
+        }
+        // ---- the round's output, in the reference's order: per group the shorts that went back to the pool, then the long one
+        std::vector<Contig> nxt;
+        int64_t used = 0;
+        {
+            std::vector<CopyB> cb;
+            auto emit = [&](const uint8_t *src, int64_t len) -> int {
+                if ((size_t)(used + len) > pool_cap) { ctx->last_error = "dedup: output pool exhausted"; return RFX_E_LIMIT; }
+                if (len) cb.push_back(CopyB{pout + used, src, len, 0, len, 0, 0, 0});
+                nxt.push_back(Contig{used, len, (int64_t)nxt.size()});
+                used += len;
+                return RFX_OK;
+            };
+            for (Group &G : groups) {
+                for (size_t si : G.back) RFX_TRY(emit(pin + rows[si].off, rows[si].len));
+                RFX_TRY(emit(G.lng, G.ln));
+            }
+            RFX_TRY(run_copies(cb));
         }
         RFX_TRY(sync_checked(ctx));
         cur = nxt;                                              // zipWithIndex: ids = positions
@@ -544,11 +720,12 @@ int dedup_contigs(rfx_ctx *ctx, const uint8_t *h_bases, const int64_t *h_off, in
     out_bases.resize((size_t)tb);
     out_off.assign(cur.size() + 1, 0);
     int64_t p = 0;
-    for (size_t i = 0; i < cur.size(); i++) {
-        out_off[i] = p;
-        if (cur[i].len) RFX_HIP(hipMemcpyAsync(out_bases.data() + p, pin + cur[i].off, (size_t)cur[i].len, hipMemcpyDeviceToHost, ctx->stream));
-        p += cur[i].len;
-    }
+    bool dense = true;                                        // (a round's output is written back to back, in order)
+    for (size_t i = 0; i < cur.size(); i++) { out_off[i] = p; if (cur[i].off != p) dense = false; p += cur[i].len; }
+    if (dense && tb > 0) RFX_HIP(hipMemcpyAsync(out_bases.data(), pin, (size_t)tb, hipMemcpyDeviceToHost, ctx->stream));
+    else
+        for (size_t i = 0; i < cur.size(); i++)
+            if (cur[i].len) RFX_HIP(hipMemcpyAsync(out_bases.data() + out_off[i], pin + cur[i].off, (size_t)cur[i].len, hipMemcpyDeviceToHost, ctx->stream));
     out_off[cur.size()] = p;
     RFX_TRY(sync_checked(ctx));
     return RFX_OK;

@@ -590,7 +590,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
 // complement's alignment and the masks of the record path fold into immediates
 template <int ELEM, int KC = 0>
 __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const typename LeafElem<ELEM>::T *__restrict__ keys,
-                                                   const uint64_t *__restrict__ leaf_off, int64_t nleaf,
+                                                   const uint64_t *__restrict__ leaf_off, const uint64_t *__restrict__ leaf_end, int64_t nleaf,
                                                    const uint64_t *__restrict__ sl_begin, const uint64_t *__restrict__ sl_end,
                                                    uint64_t heavy, uint64_t n_elems, int k_rt,
                                                    int min_cov, int max_cov, int apply_filter,
@@ -648,7 +648,8 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
     // launch of this kernel that takes its ranges from (sl_begin, sl_end) instead.
     auto range = [&](int64_t l, uint64_t &b, uint64_t &e) __attribute__((always_inline)) {
         if (sl_begin) { b = sl_begin[l]; e = sl_end[l]; return; }
-        b = leaf_off[l]; e = leaf_off[l + 1];
+        // (leaf_end = leaf_off + 1 when the leaves lie back to back; a level-2 sweep leaves slack between them)
+        b = leaf_off[l]; e = leaf_end[l];
         if (heavy && e - b > heavy) e = b;
     };
 
@@ -1380,7 +1381,7 @@ constexpr int WWS = WWS0 + WQCAP * 2 + WQCAP / 2;   // ... + the queue: 16-byte 
 // lanes as in k_leaf_count<1>; else two-word k-mers (Rec = {word0, word1}).
 template <bool RECS>
 __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_t<RECS, WRec, Rec> *__restrict__ elems,
-                                                        const uint64_t *__restrict__ leaf_off,
+                                                        const uint64_t *__restrict__ leaf_off, const uint64_t *__restrict__ leaf_end,
                                                         int64_t nleaf, int k, int min_cov, int max_cov,
                                                         uint64_t *__restrict__ out_keys, int64_t *__restrict__ out_counts,
                                                         unsigned long long cap, CountOut *__restrict__ co, uint32_t presplit) {
@@ -1442,9 +1443,9 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
         const uint64_t n0 = e - b, w0 = b + n0 * (threadIdx.x >> 6) / NWV0, w1 = b + n0 * ((threadIdx.x >> 6) + 1) / NWV0;
         return w0 + lane_ < w1 ? elems[w0 + lane_] : ElemT{};
     };
-    if constexpr (RECS) pre = wave_first(leaf_off[l0], leaf_off[l0 + 1]);
+    if constexpr (RECS) pre = wave_first(leaf_off[l0], leaf_end[l0]);       // (leaf_end = leaf_off + 1 unless the last level left slack)
     for (int64_t leaf = l0; leaf < l1; leaf++) {
-        const uint64_t begin = leaf_off[leaf], end = leaf_off[leaf + 1];
+        const uint64_t begin = leaf_off[leaf], end = leaf_end[leaf];
         uint32_t S = 1, s = 0;
         first_pass = true;
         if constexpr (RECS) {
@@ -1700,7 +1701,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                 WRec nxt;
                 if (first_pass) {
                     nxt = pre;
-                    if (leaf + 1 < l1) pre = wave_first(end, leaf_off[leaf + 2]);      // travels while this leaf is counted
+                    if (leaf + 1 < l1) pre = wave_first(leaf_off[leaf + 1], leaf_end[leaf + 1]);      // travels while this leaf is counted
                 } else {
                     nxt = ws + lane_ < we ? elems[ws + lane_] : WRec{0, 0, 0, 0};          // (a later part of a split leaf)
                 }
@@ -1841,7 +1842,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
             if (threadIdx.x == 0) sp--;
         }
         if constexpr (RECS) {
-            if (first_pass && leaf + 1 < l1) pre = wave_first(end, leaf_off[leaf + 2]);     // (an empty leaf hands the chain on)
+            if (first_pass && leaf + 1 < l1) pre = wave_first(leaf_off[leaf + 1], leaf_end[leaf + 1]);     // (an empty leaf hands the chain on)
         }
     }
     flush();
@@ -1859,21 +1860,21 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
 
 // ---- heavy leaves: slices for the second launch, and the merge of the slices' partial counts
 
-__global__ void k_heavy_count(const uint64_t *__restrict__ off, int64_t nleaf, uint64_t heavy, uint64_t slice,
+__global__ void k_heavy_count(const uint64_t *__restrict__ off, const uint64_t *__restrict__ end, int64_t nleaf, uint64_t heavy, uint64_t slice,
                               uint64_t *__restrict__ nsl) {
     const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nleaf) return;
-    const uint64_t n = off[l + 1] - off[l];
+    const uint64_t n = end[l] - off[l];
     nsl[l] = n > heavy ? (n + slice - 1) / slice : 0;
 }
 
-__global__ void k_heavy_fill(const uint64_t *__restrict__ off, int64_t nleaf, const uint64_t *__restrict__ pos,
+__global__ void k_heavy_fill(const uint64_t *__restrict__ off, const uint64_t *__restrict__ end, int64_t nleaf, const uint64_t *__restrict__ pos,
                              uint64_t *__restrict__ sb, uint64_t *__restrict__ se) {
     const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nleaf) return;
     const uint64_t c = pos[l + 1] - pos[l];
     if (!c) return;
-    const uint64_t b = off[l], n = off[l + 1] - b;
+    const uint64_t b = off[l], n = end[l] - b;
     for (uint64_t j = 0; j < c; j++) {            // equal slices
         sb[pos[l] + j] = b + n * j / c;                 // n < 2^40, j < 2^24: no overflow
         se[pos[l] + j] = b + n * (j + 1) / c;
@@ -2822,6 +2823,134 @@ __global__ __launch_bounds__(WCT) void k_rec_scatter_wc(const typename LevelElem
     drain(true);
 }
 
+// ---- the LAST level in one sweep (round 4): no histogram pass.  What the exact form needs its histogram for -- private output
+// ranges per (parent, digit, virtual workgroup) -- ONE workgroup per parent bucket does not need: it owns every child of its
+// parent, so the children's cursors are its own (LDS), and a child only needs a REGION that is large enough.  How large, a
+// SAMPLE says: every L2S_STRIDE-th tile of every parent is counted (k_l2_sample: 1/16 of the records read, 0.6 of 9.5 GB), a
+// child that shows s records there holds about STRIDE x s, and its region takes STRIDE x (s + 6 sqrt(s + 1) + 2) -- six standard
+// deviations of the sampling (+ 50 % at s = 150; a child is not a Poisson draw of records but a handful of minimiser SITES of
+// ~1000 records each, which is why the sizes come from a sample and not from n / 2^bits).  A child that outgrows its region all
+// the same raises a flag: writes stay inside the regions, the sweep is void, the exact form runs; so it does when the plan sees
+// a parent much larger than the mean (skew: one workgroup per parent would not balance) or regions beyond the buffer.  The
+// slack is address space, not traffic: the leaves read [begin, end) of every child.  Saves the re-read of k_rec_hist.
+constexpr int L2S_STRIDE = 16;
+struct L2Plan { const uint64_t *seg_begin, *seg_end; const uint64_t *child_start; int *flags; /* [0] not ok, [1] overflow */ };
+template <int MODE>
+__global__ __launch_bounds__(PT) void k_l2_sample(const typename LevelElem<MODE>::T *__restrict__ recs, L2Plan pl, Level lv, int used,
+                                                  uint32_t *__restrict__ sampled) {
+    __shared__ uint32_t h[1 << MAX_BITS];
+    const int p = blockIdx.x, nb = 1 << lv.bits;
+    for (int i = threadIdx.x; i < nb; i += PT) h[i] = 0;
+    __syncthreads();
+    const uint64_t qb = pl.seg_begin[p], qe = pl.seg_end[p];
+    // sampled tiles of this parent: tile t (of PTILE records) with t % STRIDE == 0; workgroup y of gridDim.y takes every
+    // gridDim.y-th of them
+    for (uint64_t t = (uint64_t)blockIdx.y * L2S_STRIDE; t * PTILE < qe - qb; t += (uint64_t)gridDim.y * L2S_STRIDE) {
+        const uint64_t b0 = qb + t * PTILE;
+        for (uint64_t i = b0 + threadIdx.x; i < b0 + PTILE && i < qe; i += PT) {
+            const typename LevelElem<MODE>::T r = recs[i];
+            if constexpr (MODE == 2) { if (r.w1 == 0) continue; }
+            atomicAdd(&h[level_digit<MODE>(r, used, lv)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += PT) if (h[i]) atomicAdd(&sampled[(int64_t)p * nb + i], h[i]);
+}
+// region of a child from its sampled count (records, a multiple of 8: whole aligned lines)
+__global__ void k_l2_caps(const uint32_t *__restrict__ sampled, int64_t nchild, uint32_t *__restrict__ ccap) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchild) return;
+    const float s = (float)sampled[c];
+    // (+ 32: a child of a few hundred records may show nothing in the sample -- measured: 10 of 262144 children of config 2 held
+    // ~190 records with none sampled, against a floor of 128)
+    const uint32_t C = (uint32_t)((float)L2S_STRIDE * (s + 6.0f * sqrtf(s + 1.0f) + 32.0f));
+    ccap[c] = (C + 7u) & ~7u;
+}
+__global__ __launch_bounds__(1024) void k_l2_check(L2Plan pl, int nseg, int64_t nchild, uint64_t out_cap) {
+    __shared__ unsigned long long sum_n, mx_n;
+    if (threadIdx.x == 0) { sum_n = 0; mx_n = 0; }
+    __syncthreads();
+    if ((int)threadIdx.x < nseg) {
+        const unsigned long long n = pl.seg_end[threadIdx.x] - pl.seg_begin[threadIdx.x];
+        atomicAdd(&sum_n, n);
+        atomicMax(&mx_n, n);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long mean = sum_n / (unsigned long long)(nseg > 0 ? nseg : 1);
+        pl.flags[0] = (pl.child_start[nchild] > out_cap || mx_n > mean + mean / 2 + 4096) ? 1 : 0;
+        pl.flags[1] = 0;
+    }
+}
+
+template <int B, int MODE>
+__global__ __launch_bounds__(WCT) void k_rec_l2sweep(const typename LevelElem<MODE>::T *__restrict__ recs, L2Plan pl, Level lv, int used,
+                                                     typename LevelElem<MODE>::T *__restrict__ out, uint64_t *__restrict__ leaf_end) {
+    using Rec = typename LevelElem<MODE>::T;
+    extern __shared__ __attribute__((aligned(32))) unsigned char wc_smem[];
+    constexpr int A = B / 2;
+    if (pl.flags[0]) return;                                   // (the plan saw skew or no room: the exact form runs)
+    const int p = blockIdx.x;
+    const int nb = 1 << lv.bits;
+    const uint64_t qb = pl.seg_begin[p], qe = pl.seg_end[p];
+    Rec *buf = (Rec *)wc_smem;
+    unsigned long long *tail = (unsigned long long *)(buf + (size_t)nb * B);
+    unsigned long long *head = tail + nb;
+    unsigned long long *lim = head + nb;
+    for (int i = threadIdx.x; i < nb; i += WCT) {
+        tail[i] = head[i] = pl.child_start[(int64_t)p * nb + i];
+        lim[i] = pl.child_start[(int64_t)p * nb + i + 1];
+    }
+    __syncthreads();
+    auto drain = [&](bool final) __attribute__((always_inline)) {
+#pragma unroll RFX_DRAIN_UNROLL
+        for (int d = threadIdx.x / B; d < nb; d += WCT / B) {
+            const int j = threadIdx.x % B;
+            const unsigned long long h = head[d], lm = lim[d];
+            unsigned long long t = tail[d];
+            if (t > lm) t = lm;                                // (what ran over was not stored: the overflow flag is up)
+            unsigned long long e, nh;
+            if (t - h > (unsigned long long)B) { e = h + B; nh = t; }
+            else {
+                e = final ? t : (t & ~(unsigned long long)(A - 1));
+                if (e < h) e = h;
+                nh = e;
+            }
+            const unsigned long long g = h + j;
+            if (g < e) out[g] = buf[(size_t)d * B + (g & (B - 1))];
+            if (j == 0) head[d] = nh;
+        }
+    };
+    for (uint64_t b0 = qb; b0 < qe; b0 += (uint64_t)WCT * WC_PER) {
+        Rec r[WC_PER];
+#pragma unroll
+        for (int i = 0; i < WC_PER; i++) {
+            const uint64_t idx = b0 + (uint64_t)i * WCT + threadIdx.x;
+            r[i] = recs[idx < qe ? idx : qe - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < WC_PER; i++) {
+            const uint64_t idx = b0 + (uint64_t)i * WCT + threadIdx.x;
+            bool live = idx < qe;
+            if constexpr (MODE == 2) live = live && r[i].w1 != 0;
+            if (live) {
+                const unsigned d = level_digit<MODE>(r[i], used, lv);
+                const unsigned long long g = atomicAdd(&tail[d], 1ULL);
+                if (g >= lim[d]) pl.flags[1] = 1;              // the child's region is full
+                else if (g - head[d] < (unsigned long long)B) buf[(size_t)d * B + (g & (B - 1))] = r[i];
+                else out[g] = r[i];
+            }
+        }
+        __syncthreads();
+        drain(false);
+        __syncthreads();
+    }
+    drain(true);
+    __syncthreads();
+    // (a child that ran over keeps its raw count here: the sweep is void then, and RFX_TRACE reads the need from it)
+    for (int d = threadIdx.x; d < nb; d += WCT) leaf_end[(int64_t)p * nb + d] = tail[d];
+}
+
 // ---- level 1 of the k = 33..63 path straight from the packed reads (uniform length): a thread owns
 // 16 consecutive windows of one read and rolls the two-word k-mer and its reverse complement through
 // them; the histogram kernel counts digits, the scatter kernel feeds write-combining rings (drained
@@ -3099,8 +3228,11 @@ template <int ELEM>
 static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, int64_t elem_count,
                          const uint64_t *d_leaf_off, int64_t nleaf, int k, int min_cov, int max_cov, int twin, int key_bits,
                          uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n,
-                         int64_t *out_distinct, bool pair_out = false) {
+                         int64_t *out_distinct, bool pair_out = false, const uint64_t *d_leaf_end_in = nullptr) {
     constexpr bool RECS = ELEM == 1;
+    // leaf l = elements [d_leaf_off[l], d_leaf_end[l]): back to back (the exact levels) or with slack between them (level 2 in
+    // one sweep, l2_sweep below)
+    const uint64_t *d_leaf_end = d_leaf_end_in ? d_leaf_end_in : d_leaf_off + 1;
     DevBuf co_buf;
     RFX_HIP(co_buf.alloc(sizeof(CountOut), ctx->stream));
     RFX_HIP(hipMemsetAsync(co_buf.p, 0, sizeof(CountOut), ctx->stream));
@@ -3121,7 +3253,7 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
     DevBuf nsl, spos;
     RFX_HIP(nsl.alloc((size_t)nleaf * 8, ctx->stream));
     RFX_HIP(spos.alloc((size_t)(nleaf + 1) * 8, ctx->stream));
-    hipLaunchKernelGGL(k_heavy_count, dim3((unsigned)ceil_div(nleaf, 256)), dim3(256), 0, ctx->stream, d_leaf_off, nleaf,
+    hipLaunchKernelGGL(k_heavy_count, dim3((unsigned)ceil_div(nleaf, 256)), dim3(256), 0, ctx->stream, d_leaf_off, d_leaf_end, nleaf,
                        heavy, slice, nsl.as<uint64_t>());
     RFX_HIP(hipGetLastError());
     RFX_TRY(exclusive_scan_u64(ctx, nsl.as<uint64_t>(), spos.as<uint64_t>(), nleaf));
@@ -3138,7 +3270,7 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
         auto *kern = k_leaf_count<ELEM, 0>;
         if (RECS && k == 31 && !kc_off) kern = k_leaf_count<ELEM, RECS ? 31 : 0>;
         static const int extra_lds = getenv("RFX_LEAF_EXTRA_LDS") ? atoi(getenv("RFX_LEAF_EXTRA_LDS")) : 0;   // occupancy experiment
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(LT), (size_t)extra_lds, ctx->stream, elems, d_leaf_off, nleaf,
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(LT), (size_t)extra_lds, ctx->stream, elems, d_leaf_off, d_leaf_end, nleaf,
                            (const uint64_t *)nullptr, (const uint64_t *)nullptr, heavy, (uint64_t)elem_count, k, min_cov,
                            max_cov, apply, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>(), dbg,
                            (int)pair_out, presplit);
@@ -3150,7 +3282,7 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
         RFX_HIP(sb.alloc((size_t)n_slices * 8, ctx->stream));
         RFX_HIP(se.alloc((size_t)n_slices * 8, ctx->stream));
         RFX_HIP(co2.alloc(sizeof(CountOut), ctx->stream));
-        hipLaunchKernelGGL(k_heavy_fill, dim3((unsigned)ceil_div(nleaf, 256)), dim3(256), 0, ctx->stream, d_leaf_off, nleaf,
+        hipLaunchKernelGGL(k_heavy_fill, dim3((unsigned)ceil_div(nleaf, 256)), dim3(256), 0, ctx->stream, d_leaf_off, d_leaf_end, nleaf,
                            (const uint64_t *)spos.as<uint64_t>(), sb.as<uint64_t>(), se.as<uint64_t>());
         RFX_HIP(hipGetLastError());
         // partial counts: every distinct key of every slice; grow on demand
@@ -3163,7 +3295,7 @@ static int finish_leaves(rfx_ctx *ctx, const typename LeafElem<ELEM>::T *elems, 
             {
                 ScopedTimer t(ctx, "leaf");
                 int64_t grid = std::min<int64_t>((int64_t)n_slices, (int64_t)ctx->num_cu * 2);
-                hipLaunchKernelGGL(k_leaf_count<ELEM>, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, elems, d_leaf_off,
+                hipLaunchKernelGGL(k_leaf_count<ELEM>, dim3((unsigned)grid), dim3(LT), 0, ctx->stream, elems, d_leaf_off, d_leaf_end,
                                    (int64_t)n_slices, (const uint64_t *)sb.as<uint64_t>(), (const uint64_t *)se.as<uint64_t>(),
                                    (uint64_t)0, (uint64_t)elem_count, k, min_cov, max_cov, 0, pk.as<uint64_t>(),
                                    pc.as<int32_t>(), (unsigned long long)pcap, co2.as<CountOut>(), dbg, 0, 0u);
@@ -3528,16 +3660,144 @@ static int partition_record_levels(rfx_ctx *ctx, const typename LevelElem<MODE>:
     return RFX_OK;
 }
 
+// The last level of a record path in one sweep (k_rec_l2sweep above), when it can be: a real level (4..9 bits: the rings), at
+// most 1024 parents of about the same size, enough records that the regions' floor is small.  *ok: the leaves are in *dst_out,
+// leaf c = [cstart[c], lend[c]) of `total` record slots; else nothing happened that the exact form cannot undo.
+// RFX_L2_ONESWEEP=0: never.
+template <int MODE>
+static int last_level_sweep(rfx_ctx *ctx, const typename LevelElem<MODE>::T *cur_h, int64_t n_recs, int slot, int bits_last, int used_h,
+                            const uint64_t *sb, const uint64_t *seg_end, int64_t nseg_h, size_t level_index,
+                            const typename LevelElem<MODE>::T **dst_out, DevBuf &cstart, DevBuf &lend, int64_t *nchild_out, uint64_t *total_out,
+                            bool *ok) {
+    using RT = typename LevelElem<MODE>::T;
+    *ok = false;
+    static const bool l2s_off = getenv("RFX_L2_ONESWEEP") && atoi(getenv("RFX_L2_ONESWEEP")) == 0;
+    const int nb = 1 << bits_last;
+    if (l2s_off || bits_last < 4 || bits_last > 10 || nseg_h > 1024 || n_recs < (int64_t)nseg_h * nb * 256) return RFX_OK;
+    const int64_t nchild = nseg_h << bits_last;
+    // what the regions may take at most is fixed here, without a readback (the sampled sizes give ~1.7 x the records; a plan
+    // beyond it raises flags[0] and the exact form runs)
+    const uint64_t bound = (uint64_t)n_recs * 2 + (uint64_t)nchild * 640 + 4096;
+    const int oslot = slot == 0 ? 1 : 0;
+    RT *dst = (RT *)ctx->ws_get(oslot, (size_t)bound * sizeof(RT));
+    if (!dst) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
+    DevBuf sampled, ccap, flags;
+    RFX_HIP(sampled.alloc((size_t)nchild * 4, ctx->stream)); RFX_HIP(ccap.alloc((size_t)nchild * 4, ctx->stream));
+    RFX_HIP(cstart.alloc((size_t)(nchild + 1) * 8, ctx->stream));
+    RFX_HIP(flags.alloc(8, ctx->stream));
+    RFX_HIP(lend.alloc((size_t)nchild * 8, ctx->stream));
+    RFX_HIP(hipMemsetAsync(sampled.p, 0, (size_t)nchild * 4, ctx->stream));
+    L2Plan pl{sb, seg_end ? seg_end : sb + 1, (const uint64_t *)cstart.as<uint64_t>(), flags.as<int>()};
+    Level lv{};
+    lv.bits = bits_last;
+    {
+        ScopedTimer t(ctx, level_index == 0 ? "hist1" : level_index == 1 ? "hist2" : "hist3");
+        hipLaunchKernelGGL(k_l2_sample<MODE>, dim3((unsigned)nseg_h, 8), dim3(PT), 0, ctx->stream, cur_h, pl, lv, used_h, sampled.as<uint32_t>());
+        RFX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_l2_caps, dim3((unsigned)ceil_div(nchild, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)sampled.as<uint32_t>(), nchild,
+                           ccap.as<uint32_t>());
+        RFX_HIP(hipGetLastError());
+    }
+    RFX_TRY(exclusive_scan_u32_to_u64(ctx, ccap.as<uint32_t>(), cstart.as<uint64_t>(), nchild));
+    {
+        ScopedTimer t(ctx, level_index == 0 ? "part1" : level_index == 1 ? "part2" : "part3");
+        hipLaunchKernelGGL(k_l2_check, dim3(1), dim3(1024), 0, ctx->stream, pl, (int)nseg_h, nchild, bound);
+        RFX_HIP(hipGetLastError());
+        // ring slots per child: what fills the LDS (16-byte elements: 16 at 512 children, 8 at 1024; the 32-byte records 8 and 4)
+        constexpr int B9 = MODE == 3 ? 8 : 16, B10 = B9 / 2;
+        if (bits_last <= 9) {
+            const size_t lds = (size_t)nb * (B9 * sizeof(RT) + 24);
+            RFX_HIP(hipFuncSetAttribute((const void *)k_rec_l2sweep<B9, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_rec_l2sweep<B9, MODE>), dim3((unsigned)nseg_h), dim3(WCT), lds, ctx->stream, cur_h, pl, lv, used_h, dst, lend.as<uint64_t>());
+        } else {
+            const size_t lds = (size_t)nb * (B10 * sizeof(RT) + 24);
+            RFX_HIP(hipFuncSetAttribute((const void *)k_rec_l2sweep<B10, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_rec_l2sweep<B10, MODE>), dim3((unsigned)nseg_h), dim3(WCT), lds, ctx->stream, cur_h, pl, lv, used_h, dst, lend.as<uint64_t>());
+        }
+        RFX_HIP(hipGetLastError());
+    }
+    int h_flags[2] = {0, 0};
+    uint64_t h_tot = 0;
+    RFX_HIP(hipMemcpyAsync(h_flags, flags.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(&h_tot, cstart.as<uint64_t>() + nchild, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_TRY(sync_checked(ctx));
+    if (getenv("RFX_TRACE"))
+        fprintf(stderr, "last level in one sweep: %lld records in regions of %llu%s\n", (long long)n_recs, (unsigned long long)h_tot,
+                h_flags[0] ? " -- not tried (skew, or no room): the exact form instead" : h_flags[1] ? " -- a region overflowed: the exact form instead" : "");
+    if (h_flags[1] && getenv("RFX_TRACE")) {
+        std::vector<uint64_t> hs((size_t)nchild + 1), he((size_t)nchild);
+        std::vector<uint32_t> hsm((size_t)nchild);
+        RFX_HIP(hipMemcpy(hs.data(), cstart.p, hs.size() * 8, hipMemcpyDeviceToHost));
+        RFX_HIP(hipMemcpy(he.data(), lend.p, he.size() * 8, hipMemcpyDeviceToHost));
+        RFX_HIP(hipMemcpy(hsm.data(), sampled.p, hsm.size() * 4, hipMemcpyDeviceToHost));
+        int64_t nover = 0; double worst = 0; int64_t wi = 0;
+        for (int64_t c = 0; c < nchild; c++) {
+            const uint64_t capc = hs[(size_t)c + 1] - hs[(size_t)c], need = he[(size_t)c] - hs[(size_t)c];
+            if (need > capc) { nover++; const double r = (double)need / (double)capc; if (r > worst) { worst = r; wi = c; } }
+        }
+        fprintf(stderr, "  %lld of %lld children ran over; worst: child %lld sampled %u, region %llu, holds %llu\n", (long long)nover, (long long)nchild,
+                (long long)wi, hsm[(size_t)wi], (unsigned long long)(hs[(size_t)wi + 1] - hs[(size_t)wi]), (unsigned long long)(he[(size_t)wi] - hs[(size_t)wi]));
+    }
+    if (h_flags[0] || h_flags[1]) return RFX_OK;
+    *dst_out = dst; *nchild_out = nchild; *total_out = h_tot; *ok = true;
+    return RFX_OK;
+}
+
+// every level but the last in the exact form, then the last in one sweep if it can be, in the exact form if not: -> the leaves
+template <int MODE>
+static int partition_to_leaves(rfx_ctx *ctx, const typename LevelElem<MODE>::T *recs, int64_t n_recs, int ws_slot_of_recs,
+                               const std::vector<int> &bits, size_t first_level, int used, DevBuf *seg_cur, DevBuf *seg_next, int64_t nseg,
+                               const uint64_t *seg_end_first, const typename LevelElem<MODE>::T **cur_out, int64_t *elem_count,
+                               const uint64_t **leaf_off, const uint64_t **leaf_end, int64_t *nleaf, DevBuf &cstart, DevBuf &lend) {
+    using RT = typename LevelElem<MODE>::T;
+    *leaf_end = nullptr;
+    if (bits.size() <= first_level) {                          // (no level left: the segments are the leaves)
+        *cur_out = recs; *elem_count = n_recs; *leaf_off = (const uint64_t *)seg_cur->as<uint64_t>(); *nleaf = nseg;
+        *leaf_end = seg_end_first;
+        return RFX_OK;
+    }
+    const size_t last = bits.size() - 1;
+    std::vector<int> head(bits.begin(), bits.begin() + (long)last);
+    int slot = ws_slot_of_recs, used_h = used;
+    const RT *cur_h = recs;
+    int64_t nseg_h = nseg;
+    DevBuf *sc = seg_cur, *sn = seg_next;
+    const uint64_t *seg_end = seg_end_first;
+    if (last > first_level) {
+        RFX_TRY(partition_record_levels<MODE>(ctx, recs, n_recs, ws_slot_of_recs, head, first_level, used, &sc, &sn, &nseg_h, &cur_h, seg_end_first));
+        for (size_t l = first_level; l < last; l++) { used_h += bits[l]; slot = slot == 0 ? 1 : 0; }
+        seg_end = nullptr;
+    }
+    bool ok = false;
+    const RT *dst = nullptr;
+    int64_t nchild = 0;
+    uint64_t total = 0;
+    RFX_TRY(last_level_sweep<MODE>(ctx, cur_h, n_recs, slot, bits[last], used_h, (const uint64_t *)sc->as<uint64_t>(), seg_end, nseg_h, last, &dst, cstart,
+                                   lend, &nchild, &total, &ok));
+    if (ok) {
+        *cur_out = dst; *elem_count = (int64_t)total; *leaf_off = (const uint64_t *)cstart.as<uint64_t>();
+        *leaf_end = (const uint64_t *)lend.as<uint64_t>(); *nleaf = nchild;
+        return RFX_OK;
+    }
+    const RT *cur = nullptr;
+    RFX_TRY(partition_record_levels<MODE>(ctx, cur_h, n_recs, slot, bits, last, used_h, &sc, &sn, &nseg_h, &cur, seg_end));
+    *cur_out = cur; *elem_count = n_recs; *leaf_off = (const uint64_t *)sc->as<uint64_t>(); *nleaf = nseg_h;
+    return RFX_OK;
+}
+
 static int count_records_levels(rfx_ctx *ctx, const Rec *recs, int64_t n_recs, int ws_slot_of_recs,
                                 const std::vector<int> &bits, size_t first_level, int used, DevBuf *seg_cur,
                                 DevBuf *seg_next, int64_t nseg, int k, int min_cov, int max_cov, int twin,
                                 uint64_t *d_out_keys, int32_t *d_out_counts, int64_t cap, int64_t *out_n,
                                 int64_t *out_distinct, bool pair_out = false, const uint64_t *seg_end_first = nullptr) {
     const Rec *cur = nullptr;
-    RFX_TRY(partition_record_levels<0>(ctx, recs, n_recs, ws_slot_of_recs, bits, first_level, used, &seg_cur, &seg_next,
-                                           &nseg, &cur, seg_end_first));
-    return finish_leaves<1>(ctx, cur, n_recs, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, k, min_cov, max_cov, twin,
-                            2 * k, d_out_keys, d_out_counts, cap, out_n, out_distinct, pair_out);
+    const uint64_t *loff = nullptr, *lend = nullptr;
+    int64_t ec = 0, nleaf = 0;
+    DevBuf cstart, le;
+    RFX_TRY(partition_to_leaves<0>(ctx, recs, n_recs, ws_slot_of_recs, bits, first_level, used, seg_cur, seg_next, nseg, seg_end_first, &cur, &ec,
+                                   &loff, &lend, &nleaf, cstart, le));
+    return finish_leaves<1>(ctx, cur, ec, loff, nleaf, k, min_cov, max_cov, twin, 2 * k, d_out_keys, d_out_counts, cap, out_n, out_distinct,
+                            pair_out, lend);
 }
 
 // reads -> records -> count (the default for k = 28..31)
@@ -3983,7 +4243,8 @@ int merge_pairs(rfx_ctx *ctx, const void *d_pairs, int64_t n, int k, int min_cov
 template <bool RECS = false>
 static int finish_wide2(rfx_ctx *ctx, const std::conditional_t<RECS, WRec, Rec> *cur, const uint64_t *d_leaf_off, int64_t nseg,
                         int min_cov, int max_cov, uint64_t *d_out_keys, int64_t *d_out_counts, int64_t cap, int64_t *out_n,
-                        int64_t *out_distinct, int k = 63) {
+                        int64_t *out_distinct, int k = 63, const uint64_t *d_leaf_end = nullptr) {
+    if (!d_leaf_end) d_leaf_end = d_leaf_off + 1;
     DevBuf co_buf;
     RFX_HIP(co_buf.alloc(sizeof(CountOut), ctx->stream));
     RFX_HIP(hipMemsetAsync(co_buf.p, 0, sizeof(CountOut), ctx->stream));
@@ -3991,7 +4252,7 @@ static int finish_wide2(rfx_ctx *ctx, const std::conditional_t<RECS, WRec, Rec> 
         ScopedTimer t(ctx, "leaf");
         const int wleaf_per_cu = getenv("RFX_WLEAF_PER_CU") ? std::max(1, atoi(getenv("RFX_WLEAF_PER_CU"))) : 1;
         const int64_t grid = std::min<int64_t>(nseg, (int64_t)ctx->num_cu * wleaf_per_cu);
-        hipLaunchKernelGGL(k_leaf_count_wide<RECS>, dim3((unsigned)grid), dim3(WLT), 0, ctx->stream, cur, d_leaf_off, nseg, k,
+        hipLaunchKernelGGL(k_leaf_count_wide<RECS>, dim3((unsigned)grid), dim3(WLT), 0, ctx->stream, cur, d_leaf_off, d_leaf_end, nseg, k,
                            min_cov, max_cov, d_out_keys, d_out_counts, (unsigned long long)cap, co_buf.as<CountOut>(),
                            (uint32_t)(getenv("RFX_WIDE_PRESPLIT") ? atoi(getenv("RFX_WIDE_PRESPLIT")) : 2600) |
                                (getenv("RFX_WIDE_DBG") ? (uint32_t)atoi(getenv("RFX_WIDE_DBG")) << 30 : 0u) |
@@ -4154,13 +4415,13 @@ static int count_wide2_reads_records(rfx_ctx *ctx, const uint64_t *d_words, int6
         RFX_TRY(records_onesweep<true>(ctx, rsrc, lv, 0, segA.as<uint64_t>(), segE.as<uint64_t>(), &recs, &R, &swept, "hist1", "part1"));
     }
     if (!swept) RFX_TRY(records_from_reads<true>(ctx, rsrc, lv, true, 0, nullptr, 0, segA.as<uint64_t>(), &recs, &R, "hist1", "part1"));
-    DevBuf *seg_cur = &segA, *seg_next = &segB;
-    int64_t nseg = (int64_t)1 << lv.bits;
     const WRec *cur = nullptr;
-    RFX_TRY(partition_record_levels<3>(ctx, recs, R, 0, bits, 1, lv.bits, &seg_cur, &seg_next, &nseg, &cur,
-                                       swept ? (const uint64_t *)segE.as<uint64_t>() : nullptr));
-    return finish_wide2<true>(ctx, cur, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, min_cov, max_cov, d_out_keys,
-                              d_out_counts, cap, out_n, out_distinct, k);
+    const uint64_t *loff = nullptr, *lend = nullptr;
+    int64_t ec = 0, nleaf = 0;
+    DevBuf cstart, le;
+    RFX_TRY(partition_to_leaves<3>(ctx, recs, R, 0, bits, 1, lv.bits, &segA, &segB, (int64_t)1 << lv.bits,
+                                   swept ? (const uint64_t *)segE.as<uint64_t>() : nullptr, &cur, &ec, &loff, &lend, &nleaf, cstart, le));
+    return finish_wide2<true>(ctx, cur, loff, nleaf, min_cov, max_cov, d_out_keys, d_out_counts, cap, out_n, out_distinct, k, lend);
 }
 
 // multi-GPU, k = 33..63: the 32-byte records grouped by the owner of their minimiser (~5 B per instance
@@ -4219,12 +4480,13 @@ int count_wide_records(rfx_ctx *ctx, const void *d_records, int64_t n_records, i
     RFX_HIP(segA.alloc(2 * 8, ctx->stream));
     RFX_HIP(hipMemcpyAsync(segA.p, seg_init, 16, hipMemcpyHostToDevice, ctx->stream));
     RFX_TRY(sync_checked(ctx));
-    DevBuf *seg_cur = &segA, *seg_next = &segB;
-    int64_t nseg = 1;
     const WRec *cur = nullptr;
-    RFX_TRY(partition_record_levels<3>(ctx, (const WRec *)d_records, n_records, 1, bits, 0, 0, &seg_cur, &seg_next, &nseg, &cur));
-    return finish_wide2<true>(ctx, cur, (const uint64_t *)seg_cur->as<uint64_t>(), nseg, min_cov, max_cov, d_out_keys,
-                              d_out_counts, cap, out_n, out_distinct, k);
+    const uint64_t *loff = nullptr, *lend = nullptr;
+    int64_t ec = 0, nleaf = 0;
+    DevBuf cstart, le;
+    RFX_TRY(partition_to_leaves<3>(ctx, (const WRec *)d_records, n_records, 1, bits, 0, 0, &segA, &segB, 1, nullptr, &cur, &ec, &loff, &lend, &nleaf,
+                                   cstart, le));
+    return finish_wide2<true>(ctx, cur, loff, nleaf, min_cov, max_cov, d_out_keys, d_out_counts, cap, out_n, out_distinct, k, lend);
 }
 
 // k = 33..63 from packed uniform reads: level 1 straight from the reads, then count_wide2's levels/leaves

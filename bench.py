@@ -33,7 +33,7 @@ ALGO_BYTES = {"hist1": 0.25, "part1": 8.25, "hist2": 8.0, "part2": 16.0, "hist3"
               "leaf": 8.0, "extract_w": 0.25 + 16.0, "count_w": 16.0}      # k = 63: W = 2 words per instance
 
 
-TRAFFIC_PROFILES = ("profiles/r03_hbm_traffic.json", "profiles/r02_hbm_traffic.json", "profiles/r01_hbm_traffic.json")
+TRAFFIC_PROFILES = ("profiles/r04_hbm_traffic.json", "profiles/r03_hbm_traffic.json", "profiles/r02_hbm_traffic.json", "profiles/r01_hbm_traffic.json")
 
 
 def measured_traffic(kernel, n_inst):

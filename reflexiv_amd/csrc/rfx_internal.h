@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include <map>
@@ -12,6 +13,15 @@
 struct rfx_timing_slot { float ms = 0.f; int64_t launches = 0; };
 // a kernel timer that has been stopped and not yet read (ScopedTimer below): events of the context's own pool
 struct rfx_timer_pending { const char *name; hipEvent_t a, b; int64_t launches; };
+
+// RFX_POISON=1 (debugging): every fresh workspace slot and every scratch allocation is filled with 0xA5 before it is handed
+// out, so a kernel that reads what nobody wrote sees the same junk in a fresh process as deep into a test session.
+// A bit mask: 1 = fresh workspace slots, 2 = scratch allocations (DevBuf), 4 = workspace slots 0 and 1 each time they are
+// handed out again.
+inline int rfx_poison() {
+    static const int on = [] { const char *e = getenv("RFX_POISON"); return e && *e ? atoi(e) : 0; }();
+    return on;
+}
 
 struct rfx_ctx {
     int device = 0;
@@ -37,10 +47,16 @@ struct rfx_ctx {
                            // changing sizes cost 100-600 ms a call in the pool; these are allocated once and kept)
     void *ws_get(int slot, size_t bytes) {
         WsSlot &w = ws[slot];
-        if (w.bytes >= bytes && w.p) return w.p;
+        if (w.bytes >= bytes && w.p) {
+            // slots 0 and 1 are only ever asked for as the DESTINATION of the next kernel (rfx_kmer.hip)
+            if ((rfx_poison() & 4) && slot < 2) (void)hipMemsetAsync(w.p, 0xA5, bytes, stream);
+            return w.p;
+        }
         if (w.p) { (void)hipStreamSynchronize(stream); (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
         size_t want = bytes + (bytes >> 4) + (1 << 20);
         if (hipMalloc(&w.p, want) != hipSuccess) { w.p = nullptr; return nullptr; }
+        if (rfx_poison() & 1) (void)hipMemsetAsync(w.p, 0xA5, want, stream);
+        if (rfx_poison() & 8) { (void)hipMemset(w.p, 0, want); (void)hipDeviceSynchronize(); }      // (8: zeros, the same way)
         w.bytes = want;
         return w.p;
     }
@@ -157,10 +173,13 @@ struct DevBuf {
                 p = tl_arena->base + tl_arena->off;
                 tl_arena->off += need;
                 borrowed = true;
+                if (rfx_poison() & 2) (void)hipMemsetAsync(p, 0xA5, bytes, stream);
                 return hipSuccess;
             }
         }
-        return hipMallocAsync(&p, bytes, stream);
+        hipError_t e = hipMallocAsync(&p, bytes, stream);
+        if (e == hipSuccess && (rfx_poison() & 2)) (void)hipMemsetAsync(p, 0xA5, bytes, stream);
+        return e;
     }
     void release() {
         if (p && !borrowed) (void)hipFreeAsync(p, s);

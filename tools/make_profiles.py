@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # (level 1 is one sweep by default: k_sk_sample_hist + k_plan_regions, then k_sk_onesweep + k_fix_holes; the two-pass
 # kernels k_sk_hist / k_sk_scatter appear when it falls back)
 FAMILY = [("hist1", ("k_sk_sample_hist", "k_plan_regions", "k_sk_hist")), ("part1", ("k_sk_onesweep", "k_fix_holes", "k_sk_scatter")),
-          ("hist2", ("k_rec_hist",)), ("part2", ("k_rec_scatter",)), ("leaf", ("k_leaf_count",))]
+          ("hist2", ("k_l2_sample", "k_l2_caps", "k_rec_hist")), ("part2", ("k_rec_l2sweep", "k_l2_check", "k_rec_scatter")),
+          ("leaf", ("k_leaf_count",))]
 
 
 def main():

@@ -8,7 +8,7 @@ O=$R/gpurun_out/prof_$T
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-k63 --no-ingest > $O/stats.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-contigs --no-k63 > $O/fetch.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-contigs --no-k63 > $O/write.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-k63 --no-ingest --no-strong --no-next-rows > $O/stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-contigs --no-k63 --no-strong --no-next-rows > $O/fetch.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-contigs --no-k63 --no-strong --no-next-rows > $O/write.log 2>&1 || exit 1
 ls -R $O | head -40

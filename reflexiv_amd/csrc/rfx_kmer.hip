@@ -2826,7 +2826,7 @@ __global__ __launch_bounds__(WCT) void k_rec_scatter_wc(const typename LevelElem
 // ---- the LAST level in one sweep (round 4): no histogram pass.  What the exact form needs its histogram for -- private output
 // ranges per (parent, digit, virtual workgroup) -- ONE workgroup per parent bucket does not need: it owns every child of its
 // parent, so the children's cursors are its own (LDS), and a child only needs a REGION that is large enough.  How large, a
-// SAMPLE says: every L2S_STRIDE-th tile of every parent is counted (k_l2_sample: 1/16 of the records read, 0.6 of 9.5 GB), a
+// SAMPLE says: every L2S_STRIDE-th chunk of 512 records of every parent is counted (k_l2_sample: 1/16 of the records read, 0.6 of 9.5 GB), a
 // child that shows s records there holds about STRIDE x s, and its region takes STRIDE x (s + 6 sqrt(s + 1) + 2) -- six standard
 // deviations of the sampling (+ 50 % at s = 150; a child is not a Poisson draw of records but a handful of minimiser SITES of
 // ~1000 records each, which is why the sizes come from a sample and not from n / 2^bits).  A child that outgrows its region all
@@ -2843,11 +2843,13 @@ __global__ __launch_bounds__(PT) void k_l2_sample(const typename LevelElem<MODE>
     for (int i = threadIdx.x; i < nb; i += PT) h[i] = 0;
     __syncthreads();
     const uint64_t qb = pl.seg_begin[p], qe = pl.seg_end[p];
-    // sampled tiles of this parent: tile t (of PTILE records) with t % STRIDE == 0; workgroup y of gridDim.y takes every
-    // gridDim.y-th of them
-    for (uint64_t t = (uint64_t)blockIdx.y * L2S_STRIDE; t * PTILE < qe - qb; t += (uint64_t)gridDim.y * L2S_STRIDE) {
-        const uint64_t b0 = qb + t * PTILE;
-        for (uint64_t i = b0 + threadIdx.x; i < b0 + PTILE && i < qe; i += PT) {
+    // sampled chunks of this parent: chunk c (PT records, one per thread: 8 KB of 16-byte elements) with c % STRIDE == 0;
+    // workgroup y of gridDim.y takes every gridDim.y-th of them.  (Until the multi-GPU rehearsal of round 4 the unit was a
+    // tile of 8192 records: what a rank RECEIVES is ordered by sender and owner bin, a minimiser site lies in one of
+    // them -- 11 tiles of a parent there -- and every 16th tile missed whole bins: 10 % of the children ran over.)
+    for (uint64_t c = (uint64_t)blockIdx.y * L2S_STRIDE; c * PT < qe - qb; c += (uint64_t)gridDim.y * L2S_STRIDE) {
+        const uint64_t i = qb + c * PT + threadIdx.x;
+        if (i < qe) {
             const typename LevelElem<MODE>::T r = recs[i];
             if constexpr (MODE == 2) { if (r.w1 == 0) continue; }
             atomicAdd(&h[level_digit<MODE>(r, used, lv)], 1u);
@@ -3734,6 +3736,24 @@ static int last_level_sweep(rfx_ctx *ctx, const typename LevelElem<MODE>::T *cur
         for (int64_t c = 0; c < nchild; c++) {
             const uint64_t capc = hs[(size_t)c + 1] - hs[(size_t)c], need = he[(size_t)c] - hs[(size_t)c];
             if (need > capc) { nover++; const double r = (double)need / (double)capc; if (r > worst) { worst = r; wi = c; } }
+        }
+        {   // how the sample misjudged: children by need / (STRIDE x sampled)
+            int64_t z = 0, r2 = 0, r4 = 0, big = 0;
+            for (int64_t c = 0; c < nchild; c++) {
+                const uint64_t need = he[(size_t)c] - hs[(size_t)c];
+                if (need > hs[(size_t)c + 1] - hs[(size_t)c]) {
+                    if (hsm[(size_t)c] == 0) z++;
+                    else { const double r = (double)need / (16.0 * hsm[(size_t)c]); if (r > 4) r4++; else if (r > 2) r2++; }
+                    if (need > 4000) big++;
+                }
+            }
+            fprintf(stderr, "  of the children that ran over: %lld with nothing sampled, %lld with need > 4 x estimate, %lld with 2-4 x; %lld hold > 4000 records\n",
+                    (long long)z, (long long)r4, (long long)r2, (long long)big);
+            std::vector<uint64_t> hb((size_t)nseg_h + 1);
+            RFX_HIP(hipMemcpy(hb.data(), sb, hb.size() * 8, hipMemcpyDeviceToHost));
+            uint64_t mn = ~0ULL, mx = 0;
+            for (int64_t q = 0; q < nseg_h; q++) { const uint64_t n = hb[(size_t)q + 1] - hb[(size_t)q]; mn = std::min(mn, n); mx = std::max(mx, n); }
+            fprintf(stderr, "  parents: %lld of %llu .. %llu records\n", (long long)nseg_h, (unsigned long long)mn, (unsigned long long)mx);
         }
         fprintf(stderr, "  %lld of %lld children ran over; worst: child %lld sampled %u, region %llu, holds %llu\n", (long long)nover, (long long)nchild,
                 (long long)wi, hsm[(size_t)wi], (unsigned long long)(hs[(size_t)wi + 1] - hs[(size_t)wi]), (unsigned long long)(he[(size_t)wi] - hs[(size_t)wi]));

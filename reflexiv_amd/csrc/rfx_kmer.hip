@@ -755,10 +755,11 @@ __global__ __launch_bounds__(LT, RFX_LEAF_WAVES_PER_EU) void k_leaf_count(const 
             const uint32_t gA = ((uint32_t)keyA ^ __builtin_rotateleft32((uint32_t)(keyA >> 32), 13)) * 0x9E3779B1u;
             const uint32_t gB = ((uint32_t)keyB ^ __builtin_rotateleft32((uint32_t)(keyB >> 32), 13)) * 0x9E3779B1u;
             uint32_t slotA = leaf_slot(gA), slotB = leaf_slot(gB);
-            if (S > 1) {
-                a = a && (((gA >> 4) & 0xffffu) & (S - 1)) == s;
-                b = b && (((gB >> 4) & 0xffffu) & (S - 1)) == s;
-            }
+            // (the hash-selected part of a split leaf; one part: mask 0 and s = 0, nothing is selected away -- as one AND and one
+            // compare per key, where `if (S > 1)` around it became a chain of selects on the wave-uniform condition)
+            const uint32_t pmask = (S - 1u) & 0xffffu;
+            a = a && ((gA >> 4) & pmask) == s;
+            b = b && ((gB >> 4) & pmask) == s;
             // first probe of both keys (nine in ten end here: the key is already in the table)
             unsigned long long pA = EMPTY, pB = EMPTY;
             if (a) pA = atomicCAS(&tkey[slotA], EMPTY, (unsigned long long)keyA);
@@ -1333,8 +1334,9 @@ constexpr uint32_t WLOCK = 0xFFFFFFFFu;
 // (P/ReflexivDataFrameCounter64.java:652-687): smaller (word0, word1) wins, ties keep the forward strand
 __device__ __forceinline__ void wrec_kmer(const WRec &r, uint32_t j, int t, uint64_t *k0, uint64_t *k1) {
     const uint32_t sh = 2u * j;                                  // <= 30
-    const uint64_t f0 = sh ? (r.b0 << sh) | (r.b1 >> (64 - sh)) : r.b0;
-    const uint64_t x1 = sh ? (r.b1 << sh) | (r.b2 >> (64 - sh)) : r.b1;
+    // ((x >> 1) >> (63 - sh): the funnel shift that is also right at sh = 0, without a compare and two selects per word)
+    const uint64_t f0 = (r.b0 << sh) | ((r.b1 >> 1) >> (63u - sh));
+    const uint64_t x1 = (r.b1 << sh) | ((r.b2 >> 1) >> (63u - sh));
     const int t2 = 2 * t;                                        // 2..62
     const uint64_t f1 = x1 >> (64 - t2);
     const uint64_t last32 = (f0 << t2) | f1;                     // the k-mer's last 32 bases
@@ -1474,7 +1476,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                 if constexpr (LF) {
                     const uint32_t g = ((uint32_t)w0 ^ __builtin_rotateleft32((uint32_t)(w0 >> 32), 13) ^
                                         ((uint32_t)w1 * 0x85EBCA6Bu) ^ (uint32_t)(w1 >> 32)) * 0x9E3779B1u;
-                    if (S > 1) v = v && (((g >> 4) & 0xffffu) & (S - 1)) == s;
+                    v = v && ((g >> 4) & ((S - 1u) & 0xffffu)) == s;       // (one part: mask 0, s = 0)
                     uint32_t slot = wide_slot(g);
                     bool done = !v;
                     if (v) {
@@ -1503,7 +1505,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
                 if constexpr (LF) { insertw(w0, w1, v, 1u); return; }
                 const uint32_t g = ((uint32_t)w0 ^ __builtin_rotateleft32((uint32_t)(w0 >> 32), 13) ^
                                     ((uint32_t)w1 * 0x85EBCA6Bu) ^ (uint32_t)(w1 >> 32)) * 0x9E3779B1u;
-                if (S > 1) v = v && (((g >> 4) & 0xffffu) & (S - 1)) == s;
+                v = v && ((g >> 4) & ((S - 1u) & 0xffffu)) == s;       // (one part: mask 0, s = 0)
                 uint32_t slot = wide_slot(g);
                 // double hashing: an odd step from other hash bits (the whole wave waits for its longest probe
                 // sequence, and linear probing's clusters make that one long when a leaf fills its table)
@@ -1591,7 +1593,7 @@ __global__ __launch_bounds__(WLT) void k_leaf_count_wide(const std::conditional_
             auto insertq = [&](const uint64_t w0, const uint64_t w1, bool v, uint32_t wgt) __attribute__((always_inline)) {
                 const uint32_t g = ((uint32_t)w0 ^ __builtin_rotateleft32((uint32_t)(w0 >> 32), 13) ^
                                     ((uint32_t)w1 * 0x85EBCA6Bu) ^ (uint32_t)(w1 >> 32)) * 0x9E3779B1u;
-                if (S > 1) v = v && (((g >> 4) & 0xffffu) & (S - 1)) == s;
+                v = v && ((g >> 4) & ((S - 1u) & 0xffffu)) == s;       // (one part: mask 0, s = 0)
                 attempt(w0, w1, wide_slot(g), 0u, v, wgt);
 #pragma nounroll
                 while (qn >= 64u) pending(64u);

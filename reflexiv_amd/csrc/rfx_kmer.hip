@@ -2825,6 +2825,142 @@ __global__ __launch_bounds__(WCT) void k_rec_scatter_wc(const typename LevelElem
     drain(true);
 }
 
+// ---- a FIRST level over records in one sweep (round 4): what a rank receives from the exchange is one unpartitioned array, and its
+// first level re-read all of it for an exact histogram (hist1 of the multi-GPU step: 2.7 of 40.7 ms).  The level-1 sweep over the
+// reads already has everything needed to do without one -- regions sized from a sampled histogram, extents handed out by a cursor
+// per bucket, holes moved out afterwards (k_sk_onesweep / k_plan_regions / k_fix_holes above) -- so this is that kernel with
+// records as its input: a round is a tile of ROS_T x ROS_R records, a thread loads its ROS_R records and puts them through the same
+// rings.  One parent only (the whole array): bins = 2^bits <= 512.
+constexpr int ROS_T = 512, ROS_R = 4;
+template <int MODE>
+__global__ __launch_bounds__(PT) void k_rec_sample_hist(const typename LevelElem<MODE>::T *__restrict__ recs, uint64_t n, Level lv, int used, int sample,
+                                                        unsigned long long *__restrict__ hist) {
+    __shared__ uint32_t h[1 << MAX_BITS];
+    const int nb = 1 << lv.bits;
+    for (int i = threadIdx.x; i < nb; i += PT) h[i] = 0;
+    __syncthreads();
+    // chunks of PT records, every `sample`-th of them (cf. k_l2_sample: fine-grained, the array is ordered by sender and bin)
+    for (uint64_t c = (uint64_t)blockIdx.x * sample; c * PT < n; c += (uint64_t)gridDim.x * sample) {
+        const uint64_t i = c * PT + threadIdx.x;
+        if (i < n) atomicAdd(&h[level_digit<MODE>(recs[i], used, lv)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += PT) if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+template <int B, int MODE>
+__global__ __launch_bounds__(ROS_T) void k_rec_onesweep(const typename LevelElem<MODE>::T *__restrict__ recs, uint64_t n, Level lv, int used, OneSweep os,
+                                                        typename LevelElem<MODE>::T *__restrict__ out) {
+    using RT = typename LevelElem<MODE>::T;
+    constexpr int A = B / 2 > 4 ? 4 : B / 2;                     // records per aligned burst
+    extern __shared__ __attribute__((aligned(32))) unsigned char ro_smem[];
+    const int nb = 1 << lv.bits;
+#define buf ((RT *)ro_smem)
+#define tail ((uint32_t *)(ro_smem + (size_t)nb * B * sizeof(RT)))
+#define head (tail + nb)
+#define cstart (tail + 2 * nb)
+#define cbase (tail + 3 * nb)
+#define nbase (tail + 4 * nb)
+#define pbase (tail + 5 * nb)
+    constexpr uint32_t DUMP = 0xFFFFFFFFu, NONE = 0xFFFFFFFEu;
+    const uint32_t OSE = os.ose, OSH = os.ose_shift;
+    const uint64_t dump_at = os.total - OSE;
+    auto grab = [&](int d) __attribute__((always_inline)) -> uint32_t {
+        const unsigned long long b = atomicAdd(&os.cursor[(size_t)d * OS_CSTRIDE], (unsigned long long)OSE);
+        return b + OSE <= dump_at ? (uint32_t)(b >> OSH) : DUMP;
+    };
+    auto phys = [&](uint32_t v, uint32_t cs, uint32_t cb, uint32_t nx) __attribute__((always_inline)) -> uint64_t {
+        const uint32_t o = v - cs;
+        const uint32_t b = o < (uint32_t)OSE ? cb : nx;
+        return (b == DUMP ? dump_at : (uint64_t)b << OSH) + (o & (OSE - 1));
+    };
+    for (int i = threadIdx.x; i < nb; i += ROS_T) {
+        tail[i] = 0; head[i] = 0; cstart[i] = 0;
+        cbase[i] = grab(i);
+        nbase[i] = grab(i);
+        pbase[i] = grab(i);
+    }
+    __syncthreads();
+    auto drain = [&](bool final) __attribute__((always_inline)) {
+        for (int d = threadIdx.x / B; d < nb; d += ROS_T / B) {
+            const int j = threadIdx.x % B;
+            const uint32_t h = head[d], t = tail[d], cs = cstart[d], cb = cbase[d], nx = nbase[d];
+            uint32_t e, nh;
+            if (t - h > (uint32_t)B) { e = h + B; nh = t; }                 // the excess went out directly
+            else {
+                e = final ? t : (t & ~(uint32_t)(A - 1));
+                if (e < h) e = h;
+                nh = e;
+            }
+            const uint32_t g = h + j;
+            if (g < e) out[phys(g, cs, cb, nx)] = buf[(size_t)d * B + (g & (B - 1))];
+            if (j == 0) {
+                head[d] = nh;
+                if (nh - cs >= (uint32_t)OSE) {
+                    uint32_t c = cs, b0 = cb, b1 = nx, b2 = pbase[d];
+                    while (nh - c >= (uint32_t)OSE) { c += OSE; b0 = b1; b1 = b2 != NONE ? b2 : grab(d); b2 = NONE; }
+                    cstart[d] = c; cbase[d] = b0; nbase[d] = b1; pbase[d] = b2;
+                }
+            }
+        }
+    };
+    __shared__ long long tile_lds[2];
+    constexpr uint64_t TILE = (uint64_t)ROS_T * ROS_R;
+    const int64_t ntile = (int64_t)((n + TILE - 1) / TILE);
+    const int my_d = (int)threadIdx.x;                  // the bucket this thread keeps supplied (nb <= ROS_T)
+    int64_t T = blockIdx.x;
+    for (int rnd = 0; T < ntile; rnd++) {
+        long long t_next = 0;
+        if (threadIdx.x == ROS_T - 1) t_next = (long long)gridDim.x + (long long)atomicAdd(os.tile_counter, 1ULL);
+        const bool ask = my_d < nb && pbase[my_d] == NONE;
+        uint32_t req = DUMP;
+        if (ask) req = grab(my_d);
+        const uint64_t b0 = (uint64_t)T * TILE;
+        RT r[ROS_R];
+#pragma unroll
+        for (int i = 0; i < ROS_R; i++) {
+            const uint64_t idx = b0 + (uint64_t)i * ROS_T + threadIdx.x;
+            r[i] = recs[idx < n ? idx : n - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < ROS_R; i++) {
+            const uint64_t idx = b0 + (uint64_t)i * ROS_T + threadIdx.x;
+            if (idx < n) {
+                const unsigned d = level_digit<MODE>(r[i], used, lv);
+                const uint32_t pos = atomicAdd(&tail[d], 1u);
+                if (pos - head[d] < (uint32_t)B) buf[(size_t)d * B + (pos & (B - 1))] = r[i];
+                else {
+                    const uint32_t cs = cstart[d];
+                    if (pos - cs < 2u * OSE) out[phys(pos, cs, cbase[d], nbase[d])] = r[i];
+                    else *os.overflow = 1;             // more than the two extents in hand take: the caller starts over
+                }
+            }
+        }
+        if (threadIdx.x == ROS_T - 1) tile_lds[rnd & 1] = t_next;
+        if (ask) pbase[my_d] = req;
+        __syncthreads();
+        drain(false);
+        T = tile_lds[rnd & 1];
+        __syncthreads();
+    }
+    drain(true);
+    __syncthreads();
+    for (int d = threadIdx.x; d < nb; d += ROS_T) {
+        const uint32_t used_ = tail[d] - cstart[d], cb = cbase[d], nx = nbase[d], px = pbase[d];
+        uint64_t *hl = os.holes + ((size_t)d * gridDim.x + blockIdx.x) * OS_HOLES;
+        hl[0] = cb != DUMP && used_ < OSE ? ((((uint64_t)cb << OSH) + used_) << 16) | (uint64_t)(OSE - used_) : 0;
+        hl[1] = nx != DUMP ? (((uint64_t)nx << OSH) << 16) | (uint64_t)OSE : 0;
+        hl[2] = px != DUMP && px != NONE ? (((uint64_t)px << OSH) << 16) | (uint64_t)OSE : 0;
+    }
+}
+#undef buf
+#undef tail
+#undef head
+#undef cstart
+#undef cbase
+#undef nbase
+#undef pbase
+
 // ---- the LAST level in one sweep (round 4): no histogram pass.  What the exact form needs its histogram for -- private output
 // ranges per (parent, digit, virtual workgroup) -- ONE workgroup per parent bucket does not need: it owns every child of its
 // parent, so the children's cursors are its own (LDS), and a child only needs a REGION that is large enough.  How large, a
@@ -3574,6 +3710,91 @@ static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc_in, const Level &l
     return RFX_OK;
 }
 
+// A first level over ONE unpartitioned record array in one sweep (k_rec_onesweep): -> records in workspace slot `oslot`, bucket b in
+// [d_seg_begin[b], d_seg_end[b]).  *done = false: not tried (small input, too many bins, skew) or a region overflowed -- nothing is
+// valid and the exact form runs.  OFF unless RFX_REC_ONESWEEP=1 (2: at any size -- the tests).  Measured in the multi-GPU rehearsal
+// (6.25 Gbp as a rank of 8, 4 generations of 185 M records): the histogram pass it saves is 2.3 ms per step and the sweep + the hole
+// fix-up take 2.3 ms more than the exact scatter (2048 records a round and workgroup against 4096, the extent arithmetic, two more
+// readbacks a generation), so the step stays at 40.7 ms; and the receiver's array is ordered by sender and sub-bin, which the
+// sweep's regions only survive when its digit leaves the sub-bin bits out -- and then a minimiser site lies in 1/128 of every
+// parent and the NEXT level's sample misses it.  Kept for the tests and for whoever tunes it (tile order permuted, larger rounds).
+template <int MODE>
+static int records_resweep(rfx_ctx *ctx, const typename LevelElem<MODE>::T *recs, int64_t n_recs, const Level &lv, int used, int oslot,
+                           uint64_t *d_seg_begin, uint64_t *d_seg_end, const typename LevelElem<MODE>::T **out_recs, bool *done,
+                           const char *hn, const char *pn) {
+    using RT = typename LevelElem<MODE>::T;
+    *done = false;
+    const int mode = getenv("RFX_REC_ONESWEEP") ? atoi(getenv("RFX_REC_ONESWEEP")) : 0;
+    if (MODE == 2 || !mode || lv.bits < 4 || lv.bits > 9 || lv.n_owners > 0 || (mode != 2 && n_recs < ((int64_t)1 << 24))) return RFX_OK;
+    const int nb = 1 << lv.bits;
+    constexpr int64_t TILE = (int64_t)ROS_T * ROS_R;
+    const int64_t ntile = ceil_div(n_recs, TILE);
+    constexpr int B = MODE == 3 ? 8 : 16;
+    const size_t lds = (size_t)nb * (B * sizeof(RT) + 24);
+    const int per_cu = lds <= 72 * 1024 ? 2 : 1;
+    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(OS_MAXG, (int64_t)ctx->num_cu * per_cu),
+                                                                std::max<int64_t>(std::min<int64_t>(ntile, 64), ntile / 32)));
+    const int64_t nchunk = ceil_div(n_recs, PT);
+    int sample = 32;
+    if (nchunk < 256 * (int64_t)sample) sample = (int)std::max<int64_t>(1, nchunk / 256);      // small inputs: at least 256 chunks
+    const int64_t n_sampled = ceil_div(nchunk, sample);
+    DevBuf hist, reg_start, reg_cap, cursor, totals, holes;
+    RFX_HIP(hist.alloc((size_t)nb * 8 + 16, ctx->stream));                 // + the overflow flag and the tile counter
+    RFX_HIP(reg_start.alloc((size_t)(nb + 1) * 8, ctx->stream));
+    RFX_HIP(reg_cap.alloc((size_t)nb * 4, ctx->stream));
+    RFX_HIP(cursor.alloc((size_t)nb * OS_CSTRIDE * 8, ctx->stream));
+    RFX_HIP(totals.alloc(24, ctx->stream));
+    RFX_HIP(holes.alloc((size_t)nb * OS_HOLES * G * 8, ctx->stream));
+    RFX_HIP(hipMemsetAsync(hist.p, 0, (size_t)nb * 8 + 16, ctx->stream));
+    int *d_overflow = (int *)(hist.as<unsigned long long>() + nb);
+    {
+        ScopedTimer t(ctx, hn);
+        hipLaunchKernelGGL(k_rec_sample_hist<MODE>, dim3((unsigned)std::min<int64_t>(n_sampled, (int64_t)ctx->num_cu * 8)), dim3(PT), 0, ctx->stream,
+                           recs, (uint64_t)n_recs, lv, used, sample, hist.as<unsigned long long>());
+        RFX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_plan_regions, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long *)hist.as<unsigned long long>(), nb,
+                           (double)nchunk / (double)n_sampled, G, 100, (double)ntile, reg_start.as<uint64_t>(), reg_cap.as<uint32_t>(),
+                           cursor.as<unsigned long long>(), totals.as<unsigned long long>());
+        RFX_HIP(hipGetLastError());
+    }
+    unsigned long long h_tot[3] = {0, 0, 0};
+    RFX_HIP(hipMemcpyAsync(h_tot, totals.p, 24, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_TRY(sync_checked(ctx));
+    const uint32_t ose = (uint32_t)h_tot[2];
+    if (ose == 0 || (int64_t)h_tot[0] > 2 * n_recs + ((int64_t)1 << 26)) {
+        if (getenv("RFX_TRACE")) fprintf(stderr, "record level in one sweep: not tried (the sample puts too much on one bucket)\n");
+        return RFX_OK;
+    }
+    int ose_shift = 0;
+    while ((1u << ose_shift) < ose) ose_shift++;
+    RT *dst = (RT *)ctx->ws_get(oslot, (size_t)h_tot[0] * sizeof(RT));
+    if (!dst) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
+    const OneSweep os{reg_start.as<uint64_t>(), reg_cap.as<uint32_t>(), cursor.as<unsigned long long>(), holes.as<uint64_t>(), d_overflow,
+                      (uint64_t)h_tot[0], hist.as<unsigned long long>() + nb + 1, ose, (uint32_t)ose_shift};
+    {
+        ScopedTimer t(ctx, pn);
+        RFX_HIP(hipFuncSetAttribute((const void *)k_rec_onesweep<B, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_rec_onesweep<B, MODE>), dim3((unsigned)G), dim3(ROS_T), lds, ctx->stream, recs, (uint64_t)n_recs, lv, used, os, dst);
+        RFX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_fix_holes<RT>, dim3((unsigned)nb), dim3(FH_T), 0, ctx->stream, os, G, dst, d_seg_begin, d_seg_end,
+                           totals.as<unsigned long long>());
+        RFX_HIP(hipGetLastError());
+    }
+    int h_over = 0;
+    RFX_HIP(hipMemcpyAsync(h_tot, totals.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(&h_over, d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_TRY(sync_checked(ctx));
+    if (getenv("RFX_TRACE"))
+        fprintf(stderr, "record level in one sweep: %llu records in regions of %llu (sample 1/%d, %d workgroups, extents of %u)%s\n", h_tot[1], h_tot[0],
+                sample, G, ose, h_over ? " -- a region overflowed: the exact form instead" : "");
+    if (h_over == 2) { ctx->last_error = "record level in one sweep: holes and tail records do not balance"; return RFX_E_STATE; }
+    if (h_over) return RFX_OK;
+    if ((int64_t)h_tot[1] != n_recs) { ctx->last_error = "record level in one sweep: records lost"; return RFX_E_STATE; }
+    *out_recs = dst;
+    *done = true;
+    return RFX_OK;
+}
+
 // levels [first_level, ...) of the record path on records already bucketed by `used` bits
 // (seg offsets in *seg_cur), then the leaves.
 // the partition levels of a record array: -> the fully partitioned array and its leaf offsets
@@ -3581,17 +3802,39 @@ template <int MODE>
 static int partition_record_levels(rfx_ctx *ctx, const typename LevelElem<MODE>::T *recs, int64_t n_recs, int ws_slot_of_recs,
                                    const std::vector<int> &bits, size_t first_level, int used, DevBuf **seg_cur_io,
                                    DevBuf **seg_next_io, int64_t *nseg_io, const typename LevelElem<MODE>::T **cur_out,
-                                   const uint64_t *seg_end_first = nullptr) {
+                                   const uint64_t *seg_end_first = nullptr, DevBuf *seg_end_buf = nullptr,
+                                   const uint64_t **seg_end_out = nullptr) {
     using Rec = typename LevelElem<MODE>::T;
     DevBuf *seg_cur = *seg_cur_io, *seg_next = *seg_next_io;
     int64_t nseg = *nseg_io;
     const Rec *cur = recs;
     int slot = ws_slot_of_recs;          // the next level writes into the other slot
+    const uint64_t *seg_end_cur = seg_end_first;     // ends of the current segments when they are not the next one's begin
+    if (seg_end_out) *seg_end_out = nullptr;
     for (size_t l = first_level; l < bits.size(); l++) {
         Level lv{};
         lv.bits = bits[l];
         const int nb = 1 << lv.bits;
         const int64_t nchild = nseg << lv.bits;
+        // one unpartitioned array (what a rank received): the level in one sweep, regions from a sample, when the caller can take
+        // segment ends (records_resweep)
+        if (nseg == 1 && seg_end_buf && seg_end_out && !seg_end_cur) {
+            bool swept = false;
+            const Rec *dst_s = nullptr;
+            RFX_HIP(seg_next->alloc((size_t)(nchild + 1) * 8, ctx->stream));
+            RFX_HIP(seg_end_buf->alloc((size_t)nchild * 8, ctx->stream));
+            RFX_TRY(records_resweep<MODE>(ctx, cur, n_recs, lv, used, slot == 0 ? 1 : 0, seg_next->as<uint64_t>(), seg_end_buf->as<uint64_t>(), &dst_s,
+                                          &swept, l == 0 ? "hist1" : l == 1 ? "hist2" : "hist3", l == 0 ? "part1" : l == 1 ? "part2" : "part3"));
+            if (swept) {
+                slot = slot == 0 ? 1 : 0;
+                cur = dst_s;
+                used += lv.bits;
+                std::swap(seg_cur, seg_next);
+                nseg = nchild;
+                seg_end_cur = seg_end_buf->as<uint64_t>();
+                continue;
+            }
+        }
         const int64_t total_tiles = ceil_div(std::max<int64_t>(n_recs, 1), PTILE);
         int tpb = (int)std::min<int64_t>(32, std::max<int64_t>(1, total_tiles / ((int64_t)ctx->num_cu * 8)));
         if (const char *e = getenv("RFX_TPB")) tpb = std::max(1, atoi(e));
@@ -3603,7 +3846,7 @@ static int partition_record_levels(rfx_ctx *ctx, const typename LevelElem<MODE>:
         RFX_HIP(scanned.alloc(((size_t)nb * v_bound + 1) * 8, ctx->stream));
         RFX_HIP(seg_next->alloc((size_t)(nchild + 1) * 8, ctx->stream));
         RFX_HIP(hipMemsetAsync(table.p, 0, (size_t)nb * v_bound * 4, ctx->stream));
-        const uint64_t *seg_end = l == first_level ? seg_end_first : nullptr;
+        const uint64_t *seg_end = seg_end_cur;
         hipLaunchKernelGGL(k_vb_per_seg, dim3((unsigned)ceil_div(nseg, 256)), dim3(256), 0, ctx->stream,
                            (const uint64_t *)seg_cur->as<uint64_t>(), seg_end, nseg, tpb, nvb.as<uint64_t>());
         RFX_HIP(hipGetLastError());
@@ -3659,8 +3902,10 @@ static int partition_record_levels(rfx_ctx *ctx, const typename LevelElem<MODE>:
         used += lv.bits;
         std::swap(seg_cur, seg_next);
         nseg = nchild;
+        seg_end_cur = nullptr;                       // (an exact level leaves gap-free segments)
     }
     *seg_cur_io = seg_cur; *seg_next_io = seg_next; *nseg_io = nseg; *cur_out = cur;
+    if (seg_end_out) *seg_end_out = seg_end_cur;
     return RFX_OK;
 }
 
@@ -3751,10 +3996,11 @@ static int last_level_sweep(rfx_ctx *ctx, const typename LevelElem<MODE>::T *cur
             }
             fprintf(stderr, "  of the children that ran over: %lld with nothing sampled, %lld with need > 4 x estimate, %lld with 2-4 x; %lld hold > 4000 records\n",
                     (long long)z, (long long)r4, (long long)r2, (long long)big);
-            std::vector<uint64_t> hb((size_t)nseg_h + 1);
+            std::vector<uint64_t> hb((size_t)nseg_h), hen((size_t)nseg_h);
             RFX_HIP(hipMemcpy(hb.data(), sb, hb.size() * 8, hipMemcpyDeviceToHost));
+            RFX_HIP(hipMemcpy(hen.data(), seg_end ? seg_end : sb + 1, hen.size() * 8, hipMemcpyDeviceToHost));
             uint64_t mn = ~0ULL, mx = 0;
-            for (int64_t q = 0; q < nseg_h; q++) { const uint64_t n = hb[(size_t)q + 1] - hb[(size_t)q]; mn = std::min(mn, n); mx = std::max(mx, n); }
+            for (int64_t q = 0; q < nseg_h; q++) { const uint64_t n = hen[(size_t)q] - hb[(size_t)q]; mn = std::min(mn, n); mx = std::max(mx, n); }
             fprintf(stderr, "  parents: %lld of %llu .. %llu records\n", (long long)nseg_h, (unsigned long long)mn, (unsigned long long)mx);
         }
         fprintf(stderr, "  %lld of %lld children ran over; worst: child %lld sampled %u, region %llu, holds %llu\n", (long long)nover, (long long)nchild,
@@ -3785,10 +4031,11 @@ static int partition_to_leaves(rfx_ctx *ctx, const typename LevelElem<MODE>::T *
     int64_t nseg_h = nseg;
     DevBuf *sc = seg_cur, *sn = seg_next;
     const uint64_t *seg_end = seg_end_first;
+    DevBuf seg_end_head;                                       // (ends of the head levels' segments when the last of them was a sweep)
     if (last > first_level) {
-        RFX_TRY(partition_record_levels<MODE>(ctx, recs, n_recs, ws_slot_of_recs, head, first_level, used, &sc, &sn, &nseg_h, &cur_h, seg_end_first));
+        RFX_TRY(partition_record_levels<MODE>(ctx, recs, n_recs, ws_slot_of_recs, head, first_level, used, &sc, &sn, &nseg_h, &cur_h, seg_end_first,
+                                              &seg_end_head, &seg_end));
         for (size_t l = first_level; l < last; l++) { used_h += bits[l]; slot = slot == 0 ? 1 : 0; }
-        seg_end = nullptr;
     }
     bool ok = false;
     const RT *dst = nullptr;

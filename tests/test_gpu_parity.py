@@ -1496,6 +1496,51 @@ def test_records_do_not_depend_on_the_run_descriptors(rfx, torch_mod, k, owners,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,bits", [(31, "6,5"), (31, "9,4"), (29, "4,6"), (63, "6,5"), (47, "8,4"), (63, "5,3,4")])
+def test_first_level_of_received_records_in_one_sweep(rfx, torch_mod, k, bits, monkeypatch):
+    """what a rank receives from the exchange is counted with its FIRST level in one sweep (k_rec_onesweep: regions from a
+    sample, extents, holes) -- forced at this size -- and gives the counts of the exact form and of the oracle; both
+    record kinds, first levels of 4..9 bits, two and three levels."""
+    torch = torch_mod
+    seed, G, n_reads, L = 7 + k, 40_000, 30_000, 150
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    doff = torch.empty(2, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    wide = k > 32
+    fn = rfx.bucket_wide_records_by_owner_dev if wide else rfx.bucket_records_by_owner_dev
+    width = 4 if wide else 2
+    need, _ = fn(dw.data_ptr(), n_reads, wpr, L, k, 1, 0, 0, doff.data_ptr())
+    out = torch.empty(width * need, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    nrec, h = fn(dw.data_ptr(), n_reads, wpr, L, k, 1, out.data_ptr(), need, doff.data_ptr())
+    N = (rfx.kmers_per_read_w(L, k) if wide else L - k + 1) * n_reads
+    cap = N // 2
+    W = 2 if wide else 1
+    res = []
+    for mode in ("0", "2"):
+        monkeypatch.setenv("RFX_REC_ONESWEEP", mode)
+        monkeypatch.setenv("RFX_LEVEL_BITS", bits)
+        dk = torch.empty(W * cap, dtype=torch.int64, device="cuda")
+        dc = torch.empty(cap, dtype=torch.int64 if wide else torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        if wide:
+            m, d = rfx.count_wide_records_dev(out.data_ptr(), nrec, 0, k, dk.data_ptr(), dc.data_ptr(), cap, 2)
+        else:
+            m, d = rfx.count_records_dev(out.data_ptr(), nrec, N, k, dk.data_ptr(), dc.data_ptr(), cap, 2)
+        res.append((m, d, dk[:W * m].cpu().numpy().view(np.uint64).reshape(m, W), dc[:m].cpu().numpy().astype(np.int64)))
+    g = O.synth_genome(seed, G)
+    bases, off = O.synth_reads(seed, g, G, 0, n_reads, L)
+    if wide:
+        wk, wc, wd = O.count_filter_w(O.extract_canon_w(bases, off, k), k, 2)
+    else:
+        wk, wc, wd = O.count_filter(O.extract_canon(bases, off, k), 2)
+        wk = wk.reshape(-1, 1)
+    for m, d, kk, cc in res:
+        assert (m, d) == (len(wk), wd)
+        assert np.array_equal(kk, wk.view(np.uint64).reshape(len(wk), W)) and np.array_equal(cc, wc.astype(np.int64))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k,owners", [(63, 4), (40, 3), (33, 8)])
 def test_wide_record_owner_buckets(rfx, torch_mod, k, owners):
     """k = 33..63 multi-GPU support, record form: the 32-byte records grouped by owner, a too-small buffer

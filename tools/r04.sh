@@ -7,3 +7,4 @@ python bench.py --force-dist --gbp 6.25 --steps 5 --warmup 2 --no-cpu-baseline >
 python bench.py --force-dist --gbp 6.25 --k 63 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_r04/fd63.json 2> gpurun_out/prof_r04/fd63.err &&
 bash tools/pmc_leaf.sh r04pmc > gpurun_out/r04_pmc.log 2>&1
 tail -2 gpurun_out/prof_r04/bench.json | cut -c1-600
+cd $GRAFT_REPO_ROOT && bash tools/pmc_wide.sh r04w > gpurun_out/r04_pmcw.log 2>&1

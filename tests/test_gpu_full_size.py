@@ -105,3 +105,17 @@ def check_against_pin(rfx, reads_dev, k, pin_path):
         dtext, dnc, drn = rfx.dedup_contig_text(text)
         assert drn == [len(r) for r in want["rounds"]] and dtext == want["text"]
         assert dnc < rec["n_contigs"] and sum(len(c) for c in want["rounds"][2]) < 0.6 * sum(len(c) for c in contigs)
+
+
+def test_full_size_pins_hold_with_every_allocation_poisoned():
+    """RFX_POISON=7 (rfx_internal.h): every workspace slot, scratch allocation and reused record slot is filled with 0xA5
+    before the library uses it -- the config-2 pins (k = 31 and 63, count and contigs) and the config-5-shaped one must not
+    notice.  A child process: the mask is read once per process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, RFX_POISON="7")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", here, "-k", "oracle_pin"],
+                       env=env, cwd=os.path.dirname(os.path.dirname(here)), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

@@ -2825,13 +2825,17 @@ __global__ __launch_bounds__(WCT) void k_rec_scatter_wc(const typename LevelElem
     drain(true);
 }
 
-// ---- a FIRST level over records in one sweep (round 4): what a rank receives from the exchange is one unpartitioned array, and its
-// first level re-read all of it for an exact histogram (hist1 of the multi-GPU step: 2.7 of 40.7 ms).  The level-1 sweep over the
-// reads already has everything needed to do without one -- regions sized from a sampled histogram, extents handed out by a cursor
-// per bucket, holes moved out afterwards (k_sk_onesweep / k_plan_regions / k_fix_holes above) -- so this is that kernel with
-// records as its input: a round is a tile of ROS_T x ROS_R records, a thread loads its ROS_R records and puts them through the same
-// rings.  One parent only (the whole array): bins = 2^bits <= 512.
-constexpr int ROS_T = 512, ROS_R = 4;
+// ---- a FIRST level over records without a histogram pass (round 4).  What a rank receives from the exchange is one unpartitioned
+// array, and its first level re-read all of it for an exact histogram (hist1 of the multi-GPU step: 2.5 of 39.6 ms) only to give
+// every (virtual workgroup, digit) a private output range.  Here a workgroup takes a CHUNK of the array, counts the chunk's digits in
+// LDS, CLAIMS a contiguous range per digit with one atomic add on the bucket's cursor (256 atomics a chunk), and scatters the chunk
+// -- read a second time, from the cache it has just been brought into -- through the same write-combining rings as the exact form, to
+// exact positions: no extents, no holes.  What the global histogram was needed for, the bucket STARTS, a sample gives with room to
+// spare (k_rec_sample_hist / k_claim_plan: regions as for level 1's sweep); a bucket that outgrows its region raises a flag, nothing
+// is written beyond a region, and the exact form runs.  Buckets come out as [begin, end) with the slack behind them.
+// (First form, measured and dropped: level 1's extent machinery with records as input -- as much slower in the scatter, 2.3 ms a
+// step, as the histogram it saved.)
+constexpr int RCL_TILES = 1;               // tiles of WCT x WC_PER records a workgroup counts, claims for and scatters at a time
 template <int MODE>
 __global__ __launch_bounds__(PT) void k_rec_sample_hist(const typename LevelElem<MODE>::T *__restrict__ recs, uint64_t n, Level lv, int used, int sample,
                                                         unsigned long long *__restrict__ hist) {
@@ -2847,119 +2851,114 @@ __global__ __launch_bounds__(PT) void k_rec_sample_hist(const typename LevelElem
     __syncthreads();
     for (int i = threadIdx.x; i < nb; i += PT) if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
 }
-
-template <int B, int MODE>
-__global__ __launch_bounds__(ROS_T) void k_rec_onesweep(const typename LevelElem<MODE>::T *__restrict__ recs, uint64_t n, Level lv, int used, OneSweep os,
-                                                        typename LevelElem<MODE>::T *__restrict__ out) {
-    using RT = typename LevelElem<MODE>::T;
-    constexpr int A = B / 2 > 4 ? 4 : B / 2;                     // records per aligned burst
-    extern __shared__ __attribute__((aligned(32))) unsigned char ro_smem[];
-    const int nb = 1 << lv.bits;
-#define buf ((RT *)ro_smem)
-#define tail ((uint32_t *)(ro_smem + (size_t)nb * B * sizeof(RT)))
-#define head (tail + nb)
-#define cstart (tail + 2 * nb)
-#define cbase (tail + 3 * nb)
-#define nbase (tail + 4 * nb)
-#define pbase (tail + 5 * nb)
-    constexpr uint32_t DUMP = 0xFFFFFFFFu, NONE = 0xFFFFFFFEu;
-    const uint32_t OSE = os.ose, OSH = os.ose_shift;
-    const uint64_t dump_at = os.total - OSE;
-    auto grab = [&](int d) __attribute__((always_inline)) -> uint32_t {
-        const unsigned long long b = atomicAdd(&os.cursor[(size_t)d * OS_CSTRIDE], (unsigned long long)OSE);
-        return b + OSE <= dump_at ? (uint32_t)(b >> OSH) : DUMP;
-    };
-    auto phys = [&](uint32_t v, uint32_t cs, uint32_t cb, uint32_t nx) __attribute__((always_inline)) -> uint64_t {
-        const uint32_t o = v - cs;
-        const uint32_t b = o < (uint32_t)OSE ? cb : nx;
-        return (b == DUMP ? dump_at : (uint64_t)b << OSH) + (o & (OSE - 1));
-    };
-    for (int i = threadIdx.x; i < nb; i += ROS_T) {
-        tail[i] = 0; head[i] = 0; cstart[i] = 0;
-        cbase[i] = grab(i);
-        nbase[i] = grab(i);
-        pbase[i] = grab(i);
+// regions from the sampled histogram: estimate + six standard deviations of the sample + 1/64 + 1024 (a multiple of 8 records)
+struct ClaimPlan { uint64_t *reg_start; /* [nb + 1] */ unsigned long long *cursor; /* [nb] records claimed */ int *overflow; };
+__global__ __launch_bounds__(1024) void k_claim_plan(const unsigned long long *__restrict__ hist, int nb, double scale, ClaimPlan pl) {
+    __shared__ uint64_t caps[1 << MAX_BITS];
+    const int d = threadIdx.x;
+    if (d < nb) {
+        const double c = (double)hist[d], est = c * scale;
+        const uint64_t cap = (uint64_t)(est + 6.0 * scale * sqrt(c + 1.0) + est / 64.0 + 1024.0);
+        caps[d] = (cap + 7) & ~(uint64_t)7;
+        pl.cursor[d] = 0;
     }
     __syncthreads();
-    auto drain = [&](bool final) __attribute__((always_inline)) {
-        for (int d = threadIdx.x / B; d < nb; d += ROS_T / B) {
-            const int j = threadIdx.x % B;
-            const uint32_t h = head[d], t = tail[d], cs = cstart[d], cb = cbase[d], nx = nbase[d];
-            uint32_t e, nh;
-            if (t - h > (uint32_t)B) { e = h + B; nh = t; }                 // the excess went out directly
-            else {
-                e = final ? t : (t & ~(uint32_t)(A - 1));
-                if (e < h) e = h;
-                nh = e;
-            }
-            const uint32_t g = h + j;
-            if (g < e) out[phys(g, cs, cb, nx)] = buf[(size_t)d * B + (g & (B - 1))];
-            if (j == 0) {
-                head[d] = nh;
-                if (nh - cs >= (uint32_t)OSE) {
-                    uint32_t c = cs, b0 = cb, b1 = nx, b2 = pbase[d];
-                    while (nh - c >= (uint32_t)OSE) { c += OSE; b0 = b1; b1 = b2 != NONE ? b2 : grab(d); b2 = NONE; }
-                    cstart[d] = c; cbase[d] = b0; nbase[d] = b1; pbase[d] = b2;
-                }
-            }
-        }
-    };
-    __shared__ long long tile_lds[2];
-    constexpr uint64_t TILE = (uint64_t)ROS_T * ROS_R;
-    const int64_t ntile = (int64_t)((n + TILE - 1) / TILE);
-    const int my_d = (int)threadIdx.x;                  // the bucket this thread keeps supplied (nb <= ROS_T)
-    int64_t T = blockIdx.x;
-    for (int rnd = 0; T < ntile; rnd++) {
-        long long t_next = 0;
-        if (threadIdx.x == ROS_T - 1) t_next = (long long)gridDim.x + (long long)atomicAdd(os.tile_counter, 1ULL);
-        const bool ask = my_d < nb && pbase[my_d] == NONE;
-        uint32_t req = DUMP;
-        if (ask) req = grab(my_d);
-        const uint64_t b0 = (uint64_t)T * TILE;
-        RT r[ROS_R];
-#pragma unroll
-        for (int i = 0; i < ROS_R; i++) {
-            const uint64_t idx = b0 + (uint64_t)i * ROS_T + threadIdx.x;
-            r[i] = recs[idx < n ? idx : n - 1];
-        }
-#pragma unroll
-        for (int i = 0; i < ROS_R; i++) {
-            const uint64_t idx = b0 + (uint64_t)i * ROS_T + threadIdx.x;
-            if (idx < n) {
-                const unsigned d = level_digit<MODE>(r[i], used, lv);
-                const uint32_t pos = atomicAdd(&tail[d], 1u);
-                if (pos - head[d] < (uint32_t)B) buf[(size_t)d * B + (pos & (B - 1))] = r[i];
-                else {
-                    const uint32_t cs = cstart[d];
-                    if (pos - cs < 2u * OSE) out[phys(pos, cs, cbase[d], nbase[d])] = r[i];
-                    else *os.overflow = 1;             // more than the two extents in hand take: the caller starts over
-                }
-            }
-        }
-        if (threadIdx.x == ROS_T - 1) tile_lds[rnd & 1] = t_next;
-        if (ask) pbase[my_d] = req;
-        __syncthreads();
-        drain(false);
-        T = tile_lds[rnd & 1];
-        __syncthreads();
-    }
-    drain(true);
-    __syncthreads();
-    for (int d = threadIdx.x; d < nb; d += ROS_T) {
-        const uint32_t used_ = tail[d] - cstart[d], cb = cbase[d], nx = nbase[d], px = pbase[d];
-        uint64_t *hl = os.holes + ((size_t)d * gridDim.x + blockIdx.x) * OS_HOLES;
-        hl[0] = cb != DUMP && used_ < OSE ? ((((uint64_t)cb << OSH) + used_) << 16) | (uint64_t)(OSE - used_) : 0;
-        hl[1] = nx != DUMP ? (((uint64_t)nx << OSH) << 16) | (uint64_t)OSE : 0;
-        hl[2] = px != DUMP && px != NONE ? (((uint64_t)px << OSH) << 16) | (uint64_t)OSE : 0;
+    if (threadIdx.x == 0) {
+        uint64_t at = 0;
+        for (int i = 0; i < nb; i++) { pl.reg_start[i] = at; at += caps[i]; }
+        pl.reg_start[nb] = at;
+        *pl.overflow = 0;
     }
 }
-#undef buf
-#undef tail
-#undef head
-#undef cstart
-#undef cbase
-#undef nbase
-#undef pbase
+__global__ void k_claim_ends(ClaimPlan pl, int nb, uint64_t *__restrict__ seg_begin, uint64_t *__restrict__ seg_end) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nb) return;
+    const uint64_t b = pl.reg_start[d], cap = pl.reg_start[d + 1] - b;
+    const unsigned long long c = pl.cursor[d];
+    seg_begin[d] = b;
+    seg_end[d] = b + (c <= cap ? c : cap);
+    if (c > cap) *pl.overflow = 1;
+}
+
+template <int B, int MODE>
+__global__ __launch_bounds__(WCT) void k_rec_claim_scatter(const typename LevelElem<MODE>::T *__restrict__ recs, uint64_t n, Level lv, int used, ClaimPlan pl,
+                                                           typename LevelElem<MODE>::T *__restrict__ out) {
+    using Rec = typename LevelElem<MODE>::T;
+    extern __shared__ __attribute__((aligned(32))) unsigned char wc_smem[];
+    constexpr int A = B / 2;
+    constexpr uint64_t CHUNK = (uint64_t)RCL_TILES * WCT * WC_PER;
+    const int nb = 1 << lv.bits;
+    Rec *buf = (Rec *)wc_smem;
+    unsigned long long *tail = (unsigned long long *)(buf + (size_t)nb * B);
+    unsigned long long *head = tail + nb;
+    unsigned long long *lim = head + nb;
+    uint32_t *h = (uint32_t *)(lim + nb);
+    auto drain = [&](bool final) __attribute__((always_inline)) {
+#pragma unroll RFX_DRAIN_UNROLL
+        for (int d = threadIdx.x / B; d < nb; d += WCT / B) {
+            const int j = threadIdx.x % B;
+            const unsigned long long hd = head[d], lm = lim[d];
+            unsigned long long t = tail[d];
+            if (t > lm) t = lm;                                // (what ran over was not stored: k_claim_ends raises the flag)
+            if (t < hd) t = hd;
+            unsigned long long e, nh;
+            if (t - hd > (unsigned long long)B) { e = hd + B; nh = t; }
+            else {
+                e = final ? t : (t & ~(unsigned long long)(A - 1));
+                if (e < hd) e = hd;
+                nh = e;
+            }
+            const unsigned long long g = hd + j;
+            if (g < e) out[g] = buf[(size_t)d * B + (g & (B - 1))];
+            if (j == 0) head[d] = nh;
+        }
+    };
+    // a chunk = RCL_TILES tiles of WCT x WC_PER records, the tile held in registers between its count and its scatter
+    for (uint64_t c0 = (uint64_t)blockIdx.x * CHUNK; c0 < n; c0 += (uint64_t)gridDim.x * CHUNK) {
+        const uint64_t qe = c0 + CHUNK < n ? c0 + CHUNK : n;
+        static_assert(RCL_TILES == 1, "the tile stays in registers: one tile per claim");
+        for (int i = threadIdx.x; i < nb; i += WCT) h[i] = 0;
+        __syncthreads();
+        Rec r[WC_PER];
+        unsigned dg[WC_PER];
+#pragma unroll
+        for (int i = 0; i < WC_PER; i++) {
+            const uint64_t idx = c0 + (uint64_t)i * WCT + threadIdx.x;
+            r[i] = recs[idx < qe ? idx : qe - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < WC_PER; i++) {
+            const uint64_t idx = c0 + (uint64_t)i * WCT + threadIdx.x;
+            dg[i] = level_digit<MODE>(r[i], used, lv);
+            if (idx < qe) atomicAdd(&h[dg[i]], 1u);
+        }
+        __syncthreads();
+        // one claim per digit the tile holds: [base, base + count) of the bucket's region; what does not fit is not written
+        for (int d = threadIdx.x; d < nb; d += WCT) {
+            const uint32_t c = h[d];
+            const uint64_t rs = pl.reg_start[d], re = pl.reg_start[d + 1];
+            unsigned long long base = 0;
+            if (c) base = atomicAdd(&pl.cursor[d], (unsigned long long)c);
+            tail[d] = head[d] = rs + base;
+            lim[d] = re;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < WC_PER; i++) {
+            const uint64_t idx = c0 + (uint64_t)i * WCT + threadIdx.x;
+            if (idx < qe) {
+                const unsigned d = dg[i];
+                const unsigned long long g = atomicAdd(&tail[d], 1ULL);
+                if (g >= lim[d]) { /* the bucket's region is full */ }
+                else if (g - head[d] < (unsigned long long)B) buf[(size_t)d * B + (g & (B - 1))] = r[i];
+                else out[g] = r[i];
+            }
+        }
+        __syncthreads();
+        drain(true);
+        __syncthreads();
+    }
+}
 
 // ---- the LAST level in one sweep (round 4): no histogram pass.  What the exact form needs its histogram for -- private output
 // ranges per (parent, digit, virtual workgroup) -- ONE workgroup per parent bucket does not need: it owns every child of its
@@ -3710,14 +3709,16 @@ static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc_in, const Level &l
     return RFX_OK;
 }
 
-// A first level over ONE unpartitioned record array in one sweep (k_rec_onesweep): -> records in workspace slot `oslot`, bucket b in
-// [d_seg_begin[b], d_seg_end[b]).  *done = false: not tried (small input, too many bins, skew) or a region overflowed -- nothing is
-// valid and the exact form runs.  OFF unless RFX_REC_ONESWEEP=1 (2: at any size -- the tests).  Measured in the multi-GPU rehearsal
-// (6.25 Gbp as a rank of 8, 4 generations of 185 M records): the histogram pass it saves is 2.3 ms per step and the sweep + the hole
-// fix-up take 2.3 ms more than the exact scatter (2048 records a round and workgroup against 4096, the extent arithmetic, two more
-// readbacks a generation), so the step stays at 40.7 ms; and the receiver's array is ordered by sender and sub-bin, which the
-// sweep's regions only survive when its digit leaves the sub-bin bits out -- and then a minimiser site lies in 1/128 of every
-// parent and the NEXT level's sample misses it.  Kept for the tests and for whoever tunes it (tile order permuted, larger rounds).
+// A first level over ONE unpartitioned record array without a histogram pass (k_rec_claim_scatter): -> records in workspace slot
+// `oslot`, bucket b in [d_seg_begin[b], d_seg_end[b]).  *done = false: not tried (small input, too many bins) or a bucket outgrew
+// its region -- nothing is valid and the exact form runs.  OFF unless RFX_REC_ONESWEEP=1 (2: at any size -- the tests).
+// Measured in the multi-GPU rehearsal (6.25 Gbp as a rank of 8, 4 generations of 185 M records, k = 31): the level itself is as fast
+// as the exact scatter (part1 13.6 ms a step either way) and the histogram pass is gone (hist1 2.7 -> 0.3) -- but the buckets then
+// fill in the order the workgroups' claims land, and the NEXT level's 1/16 sample misjudges a handful of its 131,072 children by
+// more than its six standard deviations in every generation (a child is a few minimiser sites, their records arrive in clumps), so
+// that level falls back to its exact form and the step is 6 ms slower, not 2.4 faster.  With the 32-byte records of k = 63 the claim
+// scatter itself is slower than the exact one (28.0 against 23.5 ms a step).  Kept for the tests and for a next level that does not
+// depend on a sample.
 template <int MODE>
 static int records_resweep(rfx_ctx *ctx, const typename LevelElem<MODE>::T *recs, int64_t n_recs, const Level &lv, int used, int oslot,
                            uint64_t *d_seg_begin, uint64_t *d_seg_end, const typename LevelElem<MODE>::T **out_recs, bool *done,
@@ -3727,69 +3728,55 @@ static int records_resweep(rfx_ctx *ctx, const typename LevelElem<MODE>::T *recs
     const int mode = getenv("RFX_REC_ONESWEEP") ? atoi(getenv("RFX_REC_ONESWEEP")) : 0;
     if (MODE == 2 || !mode || lv.bits < 4 || lv.bits > 9 || lv.n_owners > 0 || (mode != 2 && n_recs < ((int64_t)1 << 24))) return RFX_OK;
     const int nb = 1 << lv.bits;
-    constexpr int64_t TILE = (int64_t)ROS_T * ROS_R;
-    const int64_t ntile = ceil_div(n_recs, TILE);
     constexpr int B = MODE == 3 ? 8 : 16;
-    const size_t lds = (size_t)nb * (B * sizeof(RT) + 24);
-    const int per_cu = lds <= 72 * 1024 ? 2 : 1;
-    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(OS_MAXG, (int64_t)ctx->num_cu * per_cu),
-                                                                std::max<int64_t>(std::min<int64_t>(ntile, 64), ntile / 32)));
+    if (nb > 256 && B * sizeof(RT) * nb + 28 * (size_t)nb > 160 * 1024) return RFX_OK;
+    const size_t lds = (size_t)nb * (B * sizeof(RT) + 28);
     const int64_t nchunk = ceil_div(n_recs, PT);
     int sample = 32;
     if (nchunk < 256 * (int64_t)sample) sample = (int)std::max<int64_t>(1, nchunk / 256);      // small inputs: at least 256 chunks
     const int64_t n_sampled = ceil_div(nchunk, sample);
-    DevBuf hist, reg_start, reg_cap, cursor, totals, holes;
-    RFX_HIP(hist.alloc((size_t)nb * 8 + 16, ctx->stream));                 // + the overflow flag and the tile counter
+    DevBuf hist, reg_start, cursor;
+    RFX_HIP(hist.alloc((size_t)nb * 8 + 8, ctx->stream));                  // + the overflow flag
     RFX_HIP(reg_start.alloc((size_t)(nb + 1) * 8, ctx->stream));
-    RFX_HIP(reg_cap.alloc((size_t)nb * 4, ctx->stream));
-    RFX_HIP(cursor.alloc((size_t)nb * OS_CSTRIDE * 8, ctx->stream));
-    RFX_HIP(totals.alloc(24, ctx->stream));
-    RFX_HIP(holes.alloc((size_t)nb * OS_HOLES * G * 8, ctx->stream));
-    RFX_HIP(hipMemsetAsync(hist.p, 0, (size_t)nb * 8 + 16, ctx->stream));
-    int *d_overflow = (int *)(hist.as<unsigned long long>() + nb);
+    RFX_HIP(cursor.alloc((size_t)nb * 8, ctx->stream));
+    RFX_HIP(hipMemsetAsync(hist.p, 0, (size_t)nb * 8 + 8, ctx->stream));
+    const ClaimPlan pl{reg_start.as<uint64_t>(), cursor.as<unsigned long long>(), (int *)(hist.as<unsigned long long>() + nb)};
     {
         ScopedTimer t(ctx, hn);
         hipLaunchKernelGGL(k_rec_sample_hist<MODE>, dim3((unsigned)std::min<int64_t>(n_sampled, (int64_t)ctx->num_cu * 8)), dim3(PT), 0, ctx->stream,
                            recs, (uint64_t)n_recs, lv, used, sample, hist.as<unsigned long long>());
         RFX_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_plan_regions, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long *)hist.as<unsigned long long>(), nb,
-                           (double)nchunk / (double)n_sampled, G, 100, (double)ntile, reg_start.as<uint64_t>(), reg_cap.as<uint32_t>(),
-                           cursor.as<unsigned long long>(), totals.as<unsigned long long>());
+        hipLaunchKernelGGL(k_claim_plan, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long *)hist.as<unsigned long long>(), nb,
+                           (double)nchunk / (double)n_sampled, pl);
         RFX_HIP(hipGetLastError());
     }
-    unsigned long long h_tot[3] = {0, 0, 0};
-    RFX_HIP(hipMemcpyAsync(h_tot, totals.p, 24, hipMemcpyDeviceToHost, ctx->stream));
+    uint64_t total = 0;
+    RFX_HIP(hipMemcpyAsync(&total, reg_start.as<uint64_t>() + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
     RFX_TRY(sync_checked(ctx));
-    const uint32_t ose = (uint32_t)h_tot[2];
-    if (ose == 0 || (int64_t)h_tot[0] > 2 * n_recs + ((int64_t)1 << 26)) {
-        if (getenv("RFX_TRACE")) fprintf(stderr, "record level in one sweep: not tried (the sample puts too much on one bucket)\n");
-        return RFX_OK;
-    }
-    int ose_shift = 0;
-    while ((1u << ose_shift) < ose) ose_shift++;
-    RT *dst = (RT *)ctx->ws_get(oslot, (size_t)h_tot[0] * sizeof(RT));
+    if ((int64_t)total > 2 * n_recs + ((int64_t)1 << 26)) return RFX_OK;
+    RT *dst = (RT *)ctx->ws_get(oslot, (size_t)total * sizeof(RT));
     if (!dst) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
-    const OneSweep os{reg_start.as<uint64_t>(), reg_cap.as<uint32_t>(), cursor.as<unsigned long long>(), holes.as<uint64_t>(), d_overflow,
-                      (uint64_t)h_tot[0], hist.as<unsigned long long>() + nb + 1, ose, (uint32_t)ose_shift};
     {
         ScopedTimer t(ctx, pn);
-        RFX_HIP(hipFuncSetAttribute((const void *)k_rec_onesweep<B, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_rec_onesweep<B, MODE>), dim3((unsigned)G), dim3(ROS_T), lds, ctx->stream, recs, (uint64_t)n_recs, lv, used, os, dst);
+        constexpr int64_t CHUNK = (int64_t)RCL_TILES * WCT * WC_PER;
+        RFX_HIP(hipFuncSetAttribute((const void *)k_rec_claim_scatter<B, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // (as many workgroups as are resident, all of them moving through the array together: the buckets fill in the array's order.
+        //  With four times as many, started in four shifts, a minimiser site's records lay in four short stretches of its bucket
+        //  and the next level's 1/16 sample misjudged a few children in every generation)
+        const int per_cu = lds <= 72 * 1024 ? 2 : 1;
+        hipLaunchKernelGGL((k_rec_claim_scatter<B, MODE>), dim3((unsigned)std::min<int64_t>(ceil_div(n_recs, CHUNK), (int64_t)ctx->num_cu * per_cu)), dim3(WCT), lds, ctx->stream, recs, (uint64_t)n_recs, lv, used,
+                           pl, dst);
         RFX_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_fix_holes<RT>, dim3((unsigned)nb), dim3(FH_T), 0, ctx->stream, os, G, dst, d_seg_begin, d_seg_end,
-                           totals.as<unsigned long long>());
+        hipLaunchKernelGGL(k_claim_ends, dim3((unsigned)ceil_div(nb, 256)), dim3(256), 0, ctx->stream, pl, nb, d_seg_begin, d_seg_end);
         RFX_HIP(hipGetLastError());
     }
     int h_over = 0;
-    RFX_HIP(hipMemcpyAsync(h_tot, totals.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_HIP(hipMemcpyAsync(&h_over, d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(&h_over, pl.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
     RFX_TRY(sync_checked(ctx));
     if (getenv("RFX_TRACE"))
-        fprintf(stderr, "record level in one sweep: %llu records in regions of %llu (sample 1/%d, %d workgroups, extents of %u)%s\n", h_tot[1], h_tot[0],
-                sample, G, ose, h_over ? " -- a region overflowed: the exact form instead" : "");
-    if (h_over == 2) { ctx->last_error = "record level in one sweep: holes and tail records do not balance"; return RFX_E_STATE; }
+        fprintf(stderr, "record level without a histogram: %lld records in regions of %llu (sample 1/%d)%s\n", (long long)n_recs, (unsigned long long)total,
+                sample, h_over ? " -- a bucket outgrew its region: the exact form instead" : "");
     if (h_over) return RFX_OK;
-    if ((int64_t)h_tot[1] != n_recs) { ctx->last_error = "record level in one sweep: records lost"; return RFX_E_STATE; }
     *out_recs = dst;
     *done = true;
     return RFX_OK;

@@ -1498,8 +1498,9 @@ def test_records_do_not_depend_on_the_run_descriptors(rfx, torch_mod, k, owners,
 @pytest.mark.gpu
 @pytest.mark.parametrize("k,bits", [(31, "6,5"), (31, "9,4"), (29, "4,6"), (63, "6,5"), (47, "8,4"), (63, "5,3,4")])
 def test_first_level_of_received_records_in_one_sweep(rfx, torch_mod, k, bits, monkeypatch):
-    """what a rank receives from the exchange is counted with its FIRST level in one sweep (k_rec_onesweep: regions from a
-    sample, extents, holes) -- forced at this size -- and gives the counts of the exact form and of the oracle; both
+    """what a rank receives from the exchange is counted with its FIRST level without a histogram pass (k_rec_claim_scatter:
+    regions from a sample, a contiguous range claimed per tile and digit) -- forced at this size -- and gives the counts of the
+    exact form and of the oracle; both
     record kinds, first levels of 4..9 bits, two and three levels."""
     torch = torch_mod
     seed, G, n_reads, L = 7 + k, 40_000, 30_000, 150

@@ -835,10 +835,11 @@ class Reflexiv:
 
     def count_timing(self):
         """Per-kernel-family HIP-event timing of the last count call: {name: (ms, launches)}; the "stat_*" entries carry
-        the leaf tables' statistics in `launches` (leaves, table passes, passes abandoned on overflow)."""
+        the leaf tables' statistics in `launches` (leaves, table passes, passes abandoned on overflow) and the last level's
+        (records of children that outgrew their regions and were moved, sweeps given up for the exact form)."""
         out = {}
         for name in ("hist1", "part1", "hist2", "part2", "hist3", "part3", "leaf", "sort", "extract_w", "count_w",
-                     "pair_hist", "pair_part", "stat_leaves", "stat_passes", "stat_overflows"):
+                     "pair_hist", "pair_part", "stat_leaves", "stat_passes", "stat_overflows", "stat_l2_spilled", "stat_l2_void"):
             ms, ln = C.c_float(0), C.c_int64(0)
             if self.L.rfx_last_count_timing(self.ctx, name.encode(), C.byref(ms), C.byref(ln)) == RFX_OK:
                 out[name] = (float(ms.value), int(ln.value))

@@ -2971,7 +2971,14 @@ __global__ __launch_bounds__(WCT) void k_rec_claim_scatter(const typename LevelE
 // a parent much larger than the mean (skew: one workgroup per parent would not balance) or regions beyond the buffer.  The
 // slack is address space, not traffic: the leaves read [begin, end) of every child.  Saves the re-read of k_rec_hist.
 constexpr int L2S_STRIDE = 16;
-struct L2Plan { const uint64_t *seg_begin, *seg_end; const uint64_t *child_start; int *flags; /* [0] not ok, [1] overflow */ };
+struct L2Plan {
+    const uint64_t *seg_begin, *seg_end; const uint64_t *child_start; int *flags;      // flags[0] not ok, [1] overflow beyond the spill
+    // a child that outgrows its region does not void the sweep any more (a handful of 131,072 did in every generation of the
+    // multi-GPU rehearsal once the parents were filled by claims): what does not fit goes to a SPILL list (record + child), and
+    // k_l2_spill_fix moves those few children, region and spill, to free room behind the regions
+    void *spill_rec; uint32_t *spill_child; unsigned long long *spill_cursor; uint32_t spill_cap;
+    unsigned long long *tail_cursor; uint64_t out_cap;
+};
 template <int MODE>
 __global__ __launch_bounds__(PT) void k_l2_sample(const typename LevelElem<MODE>::T *__restrict__ recs, L2Plan pl, Level lv, int used,
                                                   uint32_t *__restrict__ sampled) {
@@ -2996,13 +3003,14 @@ __global__ __launch_bounds__(PT) void k_l2_sample(const typename LevelElem<MODE>
     for (int i = threadIdx.x; i < nb; i += PT) if (h[i]) atomicAdd(&sampled[(int64_t)p * nb + i], h[i]);
 }
 // region of a child from its sampled count (records, a multiple of 8: whole aligned lines)
-__global__ void k_l2_caps(const uint32_t *__restrict__ sampled, int64_t nchild, uint32_t *__restrict__ ccap) {
+__global__ void k_l2_caps(const uint32_t *__restrict__ sampled, int64_t nchild, uint32_t *__restrict__ ccap, int pct) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchild) return;
     const float s = (float)sampled[c];
     // (+ 32: a child of a few hundred records may show nothing in the sample -- measured: 10 of 262144 children of config 2 held
     // ~190 records with none sampled, against a floor of 128)
-    const uint32_t C = (uint32_t)((float)L2S_STRIDE * (s + 6.0f * sqrtf(s + 1.0f) + 32.0f));
+    uint32_t C = (uint32_t)((float)L2S_STRIDE * (s + 6.0f * sqrtf(s + 1.0f) + 32.0f));
+    if (pct != 100) C = (uint32_t)((uint64_t)C * (uint64_t)pct / 100u);      // (RFX_L2_SQUEEZE: the tests make children spill)
     ccap[c] = (C + 7u) & ~7u;
 }
 __global__ __launch_bounds__(1024) void k_l2_check(L2Plan pl, int nseg, int64_t nchild, uint64_t out_cap) {
@@ -3017,8 +3025,10 @@ __global__ __launch_bounds__(1024) void k_l2_check(L2Plan pl, int nseg, int64_t 
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long mean = sum_n / (unsigned long long)(nseg > 0 ? nseg : 1);
-        pl.flags[0] = (pl.child_start[nchild] > out_cap || mx_n > mean + mean / 2 + 4096) ? 1 : 0;
+        pl.flags[0] = (pl.child_start[nchild] + 8ULL * pl.spill_cap + 65536ULL > out_cap || mx_n > mean + mean / 2 + 4096) ? 1 : 0;
         pl.flags[1] = 0;
+        *pl.spill_cursor = 0;
+        *pl.tail_cursor = (pl.child_start[nchild] + 7ULL) & ~7ULL;
     }
 }
 
@@ -3075,7 +3085,11 @@ __global__ __launch_bounds__(WCT) void k_rec_l2sweep(const typename LevelElem<MO
             if (live) {
                 const unsigned d = level_digit<MODE>(r[i], used, lv);
                 const unsigned long long g = atomicAdd(&tail[d], 1ULL);
-                if (g >= lim[d]) pl.flags[1] = 1;              // the child's region is full
+                if (g >= lim[d]) {                             // the child's region is full: the record waits in the spill list
+                    const unsigned long long sk = atomicAdd(pl.spill_cursor, 1ULL);
+                    if (sk < (unsigned long long)pl.spill_cap) { ((Rec *)pl.spill_rec)[sk] = r[i]; pl.spill_child[sk] = (uint32_t)(p * nb + (int)d); }
+                    else pl.flags[1] = 1;                      // (more than the list takes: the sweep is void after all)
+                }
                 else if (g - head[d] < (unsigned long long)B) buf[(size_t)d * B + (g & (B - 1))] = r[i];
                 else out[g] = r[i];
             }
@@ -3088,6 +3102,75 @@ __global__ __launch_bounds__(WCT) void k_rec_l2sweep(const typename LevelElem<MO
     __syncthreads();
     // (a child that ran over keeps its raw count here: the sweep is void then, and RFX_TRACE reads the need from it)
     for (int d = threadIdx.x; d < nb; d += WCT) leaf_end[(int64_t)p * nb + d] = tail[d];
+}
+
+// the children that spilled (see L2Plan): each gets room behind the regions for everything it holds -- its full region and its
+// spilled records -- and its [begin, end) is rewritten.  One workgroup: a few children, a few thousand records.
+constexpr int L2F_T = 1024, L2F_SLOTS = 2048, L2F_MAXC = 1536;
+template <class RT>
+__global__ __launch_bounds__(L2F_T) void k_l2_spill_fix(L2Plan pl, uint64_t *__restrict__ cstart, uint64_t *__restrict__ lend, RT *__restrict__ out) {
+    __shared__ uint32_t tkey[L2F_SLOTS], tcnt[L2F_SLOTS], tfill[L2F_SLOTS], tcap[L2F_SLOTS];
+    __shared__ unsigned long long tbase[L2F_SLOTS];
+    __shared__ uint32_t ndistinct;
+    __shared__ int bad;
+    if (pl.flags[0] || pl.flags[1]) return;
+    const unsigned long long ns = *pl.spill_cursor;
+    if (ns == 0) return;
+    constexpr uint32_t NOKEY = 0xFFFFFFFFu;
+    for (int i = threadIdx.x; i < L2F_SLOTS; i += L2F_T) { tkey[i] = NOKEY; tcnt[i] = 0; tfill[i] = 0; }
+    if (threadIdx.x == 0) { ndistinct = 0; bad = 0; }
+    __syncthreads();
+    auto find = [&](uint32_t c, bool insert) __attribute__((always_inline)) -> int {
+        uint32_t slot = (c * 0x9E3779B1u) >> 21;                 // 11 bits
+        for (int probe = 0; probe < L2F_SLOTS; probe++) {
+            uint32_t k = tkey[slot];
+            if (k == c) return (int)slot;
+            if (k == NOKEY) {
+                if (!insert) return -1;
+                k = atomicCAS(&tkey[slot], NOKEY, c);
+                if (k == NOKEY) { atomicAdd(&ndistinct, 1u); return (int)slot; }
+                if (k == c) return (int)slot;
+            }
+            slot = (slot + 1) & (L2F_SLOTS - 1);
+        }
+        return -1;
+    };
+    for (unsigned long long i = threadIdx.x; i < ns; i += L2F_T) {
+        if (ndistinct > (uint32_t)L2F_MAXC) { bad = 1; break; }
+        const int sl = find(pl.spill_child[i], true);
+        if (sl < 0) { bad = 1; break; }
+        atomicAdd(&tcnt[sl], 1u);
+    }
+    __syncthreads();
+    if (bad || ndistinct > (uint32_t)L2F_MAXC) { if (threadIdx.x == 0) pl.flags[1] = 1; return; }
+    for (int sl = threadIdx.x; sl < L2F_SLOTS; sl += L2F_T) {
+        if (tkey[sl] == NOKEY) continue;
+        const uint32_t c = tkey[sl];
+        const uint64_t cap = pl.child_start[c + 1] - pl.child_start[c];          // (a child that spilled filled its region)
+        tcap[sl] = (uint32_t)cap;
+        const unsigned long long size = cap + tcnt[sl];
+        const unsigned long long at = atomicAdd(pl.tail_cursor, (size + 7ULL) & ~7ULL);
+        if (at + size > pl.out_cap) bad = 1;
+        tbase[sl] = at;
+    }
+    __syncthreads();
+    if (bad) { if (threadIdx.x == 0) pl.flags[1] = 1; return; }
+    for (int sl = 0; sl < L2F_SLOTS; sl++) {
+        if (tkey[sl] == NOKEY) continue;
+        const uint64_t from = pl.child_start[tkey[sl]];
+        const unsigned long long to = tbase[sl];
+        for (uint32_t j = threadIdx.x; j < tcap[sl]; j += L2F_T) out[to + j] = out[from + j];
+    }
+    for (unsigned long long i = threadIdx.x; i < ns; i += L2F_T) {
+        const int sl = find(pl.spill_child[i], false);
+        out[tbase[sl] + tcap[sl] + atomicAdd(&tfill[sl], 1u)] = ((const RT *)pl.spill_rec)[i];
+    }
+    __syncthreads();
+    for (int sl = threadIdx.x; sl < L2F_SLOTS; sl += L2F_T) {
+        if (tkey[sl] == NOKEY) continue;
+        cstart[tkey[sl]] = tbase[sl];
+        lend[tkey[sl]] = tbase[sl] + tcap[sl] + tcnt[sl];
+    }
 }
 
 // ---- level 1 of the k = 33..63 path straight from the packed reads (uniform length): a thread owns
@@ -3711,21 +3794,21 @@ static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc_in, const Level &l
 
 // A first level over ONE unpartitioned record array without a histogram pass (k_rec_claim_scatter): -> records in workspace slot
 // `oslot`, bucket b in [d_seg_begin[b], d_seg_end[b]).  *done = false: not tried (small input, too many bins) or a bucket outgrew
-// its region -- nothing is valid and the exact form runs.  OFF unless RFX_REC_ONESWEEP=1 (2: at any size -- the tests).
+// its region -- nothing is valid and the exact form runs.  On for the 16-byte records of k <= 31 from 2^24 records up
+// (RFX_REC_ONESWEEP=0: never, 1: every record kind, 2: at any size -- the tests).
 // Measured in the multi-GPU rehearsal (6.25 Gbp as a rank of 8, 4 generations of 185 M records, k = 31): the level itself is as fast
-// as the exact scatter (part1 13.6 ms a step either way) and the histogram pass is gone (hist1 2.7 -> 0.3) -- but the buckets then
-// fill in the order the workgroups' claims land, and the NEXT level's 1/16 sample misjudges a handful of its 131,072 children by
-// more than its six standard deviations in every generation (a child is a few minimiser sites, their records arrive in clumps), so
-// that level falls back to its exact form and the step is 6 ms slower, not 2.4 faster.  With the 32-byte records of k = 63 the claim
-// scatter itself is slower than the exact one (28.0 against 23.5 ms a step).  Kept for the tests and for a next level that does not
-// depend on a sample.
+// as the exact scatter (part1 14.4 ms a step either way) and the histogram pass is gone (hist1 2.75 -> 0.32): 40.3 -> 38.9 ms.  The
+// buckets then fill in the order the workgroups' claims land, and the NEXT level's 1/16 sample misjudges a handful of its 131,072
+// children by more than its six standard deviations in every generation (a child is a few minimiser sites, their records arrive in
+// clumps) -- which voided that level's sweep (+6 ms) until its children could spill (L2Plan, k_l2_spill_fix).  With the 32-byte
+// records of k = 63 the claim scatter is slower than the exact one (28.0 against 23.5 ms a step): off there.
 template <int MODE>
 static int records_resweep(rfx_ctx *ctx, const typename LevelElem<MODE>::T *recs, int64_t n_recs, const Level &lv, int used, int oslot,
                            uint64_t *d_seg_begin, uint64_t *d_seg_end, const typename LevelElem<MODE>::T **out_recs, bool *done,
                            const char *hn, const char *pn) {
     using RT = typename LevelElem<MODE>::T;
     *done = false;
-    const int mode = getenv("RFX_REC_ONESWEEP") ? atoi(getenv("RFX_REC_ONESWEEP")) : 0;
+    const int mode = getenv("RFX_REC_ONESWEEP") ? atoi(getenv("RFX_REC_ONESWEEP")) : (MODE == 0 ? 1 : 0);
     if (MODE == 2 || !mode || lv.bits < 4 || lv.bits > 9 || lv.n_owners > 0 || (mode != 2 && n_recs < ((int64_t)1 << 24))) return RFX_OK;
     const int nb = 1 << lv.bits;
     constexpr int B = MODE == 3 ? 8 : 16;
@@ -3907,23 +3990,28 @@ static int last_level_sweep(rfx_ctx *ctx, const typename LevelElem<MODE>::T *cur
                             bool *ok) {
     using RT = typename LevelElem<MODE>::T;
     *ok = false;
-    static const bool l2s_off = getenv("RFX_L2_ONESWEEP") && atoi(getenv("RFX_L2_ONESWEEP")) == 0;
+    const bool l2s_off = getenv("RFX_L2_ONESWEEP") && atoi(getenv("RFX_L2_ONESWEEP")) == 0;
     const int nb = 1 << bits_last;
     if (l2s_off || bits_last < 4 || bits_last > 10 || nseg_h > 1024 || n_recs < (int64_t)nseg_h * nb * 256) return RFX_OK;
     const int64_t nchild = nseg_h << bits_last;
     // what the regions may take at most is fixed here, without a readback (the sampled sizes give ~1.7 x the records; a plan
     // beyond it raises flags[0] and the exact form runs)
-    const uint64_t bound = (uint64_t)n_recs * 2 + (uint64_t)nchild * 640 + 4096;
+    // (+ room behind the regions for the children that spill: k_l2_spill_fix)
+    const uint32_t spill_cap = (uint32_t)std::min<int64_t>((int64_t)1 << 22, std::max<int64_t>(65536, n_recs / 256));
+    const uint64_t bound = (uint64_t)n_recs * 2 + (uint64_t)nchild * 640 + 4096 + 8ULL * spill_cap + 65536;
     const int oslot = slot == 0 ? 1 : 0;
     RT *dst = (RT *)ctx->ws_get(oslot, (size_t)bound * sizeof(RT));
     if (!dst) { ctx->last_error = "workspace allocation failed"; return RFX_E_HIP; }
-    DevBuf sampled, ccap, flags;
+    DevBuf sampled, ccap, flags, spill_rec, spill_child;
+    RFX_HIP(spill_rec.alloc((size_t)spill_cap * sizeof(RT), ctx->stream));
+    RFX_HIP(spill_child.alloc((size_t)spill_cap * 4, ctx->stream));
     RFX_HIP(sampled.alloc((size_t)nchild * 4, ctx->stream)); RFX_HIP(ccap.alloc((size_t)nchild * 4, ctx->stream));
     RFX_HIP(cstart.alloc((size_t)(nchild + 1) * 8, ctx->stream));
-    RFX_HIP(flags.alloc(8, ctx->stream));
+    RFX_HIP(flags.alloc(32, ctx->stream));                     // two flags, the spill cursor, the cursor of the room behind the regions
     RFX_HIP(lend.alloc((size_t)nchild * 8, ctx->stream));
     RFX_HIP(hipMemsetAsync(sampled.p, 0, (size_t)nchild * 4, ctx->stream));
-    L2Plan pl{sb, seg_end ? seg_end : sb + 1, (const uint64_t *)cstart.as<uint64_t>(), flags.as<int>()};
+    L2Plan pl{sb, seg_end ? seg_end : sb + 1, (const uint64_t *)cstart.as<uint64_t>(), flags.as<int>(), spill_rec.p, spill_child.as<uint32_t>(),
+              flags.as<unsigned long long>() + 1, spill_cap, flags.as<unsigned long long>() + 2, bound};
     Level lv{};
     lv.bits = bits_last;
     {
@@ -3931,7 +4019,7 @@ static int last_level_sweep(rfx_ctx *ctx, const typename LevelElem<MODE>::T *cur
         hipLaunchKernelGGL(k_l2_sample<MODE>, dim3((unsigned)nseg_h, 8), dim3(PT), 0, ctx->stream, cur_h, pl, lv, used_h, sampled.as<uint32_t>());
         RFX_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_l2_caps, dim3((unsigned)ceil_div(nchild, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)sampled.as<uint32_t>(), nchild,
-                           ccap.as<uint32_t>());
+                           ccap.as<uint32_t>(), getenv("RFX_L2_SQUEEZE") ? std::max(1, atoi(getenv("RFX_L2_SQUEEZE"))) : 100);
         RFX_HIP(hipGetLastError());
     }
     RFX_TRY(exclusive_scan_u32_to_u64(ctx, ccap.as<uint32_t>(), cstart.as<uint64_t>(), nchild));
@@ -3951,15 +4039,23 @@ static int last_level_sweep(rfx_ctx *ctx, const typename LevelElem<MODE>::T *cur
             hipLaunchKernelGGL((k_rec_l2sweep<B10, MODE>), dim3((unsigned)nseg_h), dim3(WCT), lds, ctx->stream, cur_h, pl, lv, used_h, dst, lend.as<uint64_t>());
         }
         RFX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_l2_spill_fix<RT>, dim3(1), dim3(L2F_T), 0, ctx->stream, pl, cstart.as<uint64_t>(), lend.as<uint64_t>(), dst);
+        RFX_HIP(hipGetLastError());
     }
-    int h_flags[2] = {0, 0};
+    unsigned long long h_fl[3] = {0, 0, 0};                    // {flags[0] | flags[1] << 32, spilled records, end of the room in use}
     uint64_t h_tot = 0;
-    RFX_HIP(hipMemcpyAsync(h_flags, flags.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(h_fl, flags.p, 24, hipMemcpyDeviceToHost, ctx->stream));
     RFX_HIP(hipMemcpyAsync(&h_tot, cstart.as<uint64_t>() + nchild, 8, hipMemcpyDeviceToHost, ctx->stream));
     RFX_TRY(sync_checked(ctx));
-    if (getenv("RFX_TRACE"))
+    const int h_flags[2] = {(int)(h_fl[0] & 0xffffffffULL), (int)(h_fl[0] >> 32)};
+    if (!h_flags[0] && !h_flags[1]) ctx->timing["stat_l2_spilled"].launches += (int64_t)h_fl[1];     // records moved by k_l2_spill_fix
+    if (!h_flags[0] && h_flags[1]) ctx->timing["stat_l2_void"].launches += 1;                        // sweeps given up for the exact form
+    if (getenv("RFX_TRACE")) {
         fprintf(stderr, "last level in one sweep: %lld records in regions of %llu%s\n", (long long)n_recs, (unsigned long long)h_tot,
-                h_flags[0] ? " -- not tried (skew, or no room): the exact form instead" : h_flags[1] ? " -- a region overflowed: the exact form instead" : "");
+                h_flags[0] ? " -- not tried (skew, or no room): the exact form instead" : h_flags[1] ? " -- more spilled than the list takes: the exact form instead" : "");
+        if (!h_flags[0] && !h_flags[1] && h_fl[1])
+            fprintf(stderr, "  %llu records of children that outgrew their regions spilled and were moved with them behind the regions\n", h_fl[1]);
+    }
     if (h_flags[1] && getenv("RFX_TRACE")) {
         std::vector<uint64_t> hs((size_t)nchild + 1), he((size_t)nchild);
         std::vector<uint32_t> hsm((size_t)nchild);
@@ -3994,7 +4090,7 @@ static int last_level_sweep(rfx_ctx *ctx, const typename LevelElem<MODE>::T *cur
                 (long long)wi, hsm[(size_t)wi], (unsigned long long)(hs[(size_t)wi + 1] - hs[(size_t)wi]), (unsigned long long)(he[(size_t)wi] - hs[(size_t)wi]));
     }
     if (h_flags[0] || h_flags[1]) return RFX_OK;
-    *dst_out = dst; *nchild_out = nchild; *total_out = h_tot; *ok = true;
+    *dst_out = dst; *nchild_out = nchild; *total_out = bound; *ok = true;     // (the leaves may lie anywhere in the buffer)
     return RFX_OK;
 }
 

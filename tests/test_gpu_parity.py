@@ -1496,6 +1496,44 @@ def test_records_do_not_depend_on_the_run_descriptors(rfx, torch_mod, k, owners,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k", [31, 63])
+def test_children_that_outgrow_their_regions_spill_and_are_moved(rfx, torch_mod, k, monkeypatch):
+    """the last radix level in one sweep (k_rec_l2sweep) sizes every child's region from a 1/16 sample; a child that outgrows
+    it spills into a list and k_l2_spill_fix moves it, region and spill, behind the regions.  RFX_L2_SQUEEZE shrinks the
+    regions: at 100 % (nothing or little spills), from 84 % down (children spill and are moved), 30 % (more than the list takes: the
+    exact form runs after all) the survivors are those of the exact form, key for key."""
+    torch = torch_mod
+    seed, G, n_reads, L = 3 + k, 1_500_000, 2_400_000, 150
+    dg, dw, wpr = make_reads_dev(rfx, torch, seed, G, n_reads, L)
+    wide = k > 32
+    N = (rfx.kmers_per_read_w(L, k) if wide else L - k + 1) * n_reads
+    cap = N // 8
+    W = 2 if wide else 1
+    monkeypatch.setenv("RFX_LEVEL_BITS", "8,6")
+    res = []
+    stats = []
+    for sweep, squeeze in [("0", "100"), ("1", "100")] + [("1", str(q)) for q in range(84, 59, -3)] + [("1", "30")]:
+        monkeypatch.setenv("RFX_L2_ONESWEEP", sweep)
+        monkeypatch.setenv("RFX_L2_SQUEEZE", squeeze)
+        dk = torch.empty(W * cap, dtype=torch.int64, device="cuda")
+        dc = torch.empty(cap, dtype=torch.int64 if wide else torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        if wide:
+            m, d, inst = rfx.count_reads_w_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), cap, 3)
+        else:
+            m, d, inst = rfx.count_reads_dev(dw.data_ptr(), n_reads, wpr, L, k, dk.data_ptr(), dc.data_ptr(), cap, 3)
+        h = hashlib.sha256(dk[:W * m].cpu().numpy().tobytes() + dc[:m].cpu().numpy().tobytes()).hexdigest()
+        res.append((m, d, inst, h))
+        t = rfx.count_timing()
+        stats.append((t.get("stat_l2_spilled", (0, 0))[1], t.get("stat_l2_void", (0, 0))[1]))
+    assert res[0][2] == N and res[0][0] > 1_000_000
+    assert all(r == res[0] for r in res), res
+    assert stats[0] == (0, 0) and stats[1][1] == 0, stats
+    assert any(sp > 0 and void == 0 for sp, void in stats), stats  # somewhere on the way down children spilled and were moved; the sweep stood
+    assert stats[-1][1] == 1, stats                                # too many: the exact form after all
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k,bits", [(31, "6,5"), (31, "9,4"), (29, "4,6"), (63, "6,5"), (47, "8,4"), (63, "5,3,4")])
 def test_first_level_of_received_records_in_one_sweep(rfx, torch_mod, k, bits, monkeypatch):
     """what a rank receives from the exchange is counted with its FIRST level without a histogram pass (k_rec_claim_scatter:

@@ -3143,6 +3143,10 @@ __global__ __launch_bounds__(L2F_T) void k_l2_spill_fix(L2Plan pl, uint64_t *__r
     }
     __syncthreads();
     if (bad || ndistinct > (uint32_t)L2F_MAXC) { if (threadIdx.x == 0) pl.flags[1] = 1; return; }
+    __shared__ uint16_t used_slot[L2F_MAXC + 1];
+    __shared__ uint32_t n_used;
+    if (threadIdx.x == 0) n_used = 0;
+    __syncthreads();
     for (int sl = threadIdx.x; sl < L2F_SLOTS; sl += L2F_T) {
         if (tkey[sl] == NOKEY) continue;
         const uint32_t c = tkey[sl];
@@ -3152,11 +3156,12 @@ __global__ __launch_bounds__(L2F_T) void k_l2_spill_fix(L2Plan pl, uint64_t *__r
         const unsigned long long at = atomicAdd(pl.tail_cursor, (size + 7ULL) & ~7ULL);
         if (at + size > pl.out_cap) bad = 1;
         tbase[sl] = at;
+        used_slot[atomicAdd(&n_used, 1u)] = (uint16_t)sl;
     }
     __syncthreads();
     if (bad) { if (threadIdx.x == 0) pl.flags[1] = 1; return; }
-    for (int sl = 0; sl < L2F_SLOTS; sl++) {
-        if (tkey[sl] == NOKEY) continue;
+    for (uint32_t u = 0; u < n_used; u++) {                      // the children's regions, one after the other, by the whole workgroup
+        const int sl = used_slot[u];
         const uint64_t from = pl.child_start[tkey[sl]];
         const unsigned long long to = tbase[sl];
         for (uint32_t j = threadIdx.x; j < tcap[sl]; j += L2F_T) out[to + j] = out[from + j];

@@ -2881,7 +2881,7 @@ __global__ void k_claim_ends(ClaimPlan pl, int nb, uint64_t *__restrict__ seg_be
 }
 
 template <int B, int MODE>
-__global__ __launch_bounds__(WCT) void k_rec_claim_scatter(const typename LevelElem<MODE>::T *__restrict__ recs, uint64_t n, Level lv, int used, ClaimPlan pl,
+__global__ __launch_bounds__(WCT) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_rec_claim_scatter(const typename LevelElem<MODE>::T *__restrict__ recs, uint64_t n, Level lv, int used, ClaimPlan pl,
                                                            typename LevelElem<MODE>::T *__restrict__ out) {
     using Rec = typename LevelElem<MODE>::T;
     extern __shared__ __attribute__((aligned(32))) unsigned char wc_smem[];
@@ -2919,19 +2919,25 @@ __global__ __launch_bounds__(WCT) void k_rec_claim_scatter(const typename LevelE
         static_assert(RCL_TILES == 1, "the tile stays in registers: one tile per claim");
         for (int i = threadIdx.x; i < nb; i += WCT) h[i] = 0;
         __syncthreads();
-        Rec r[WC_PER];
-        unsigned dg[WC_PER];
-#pragma unroll
-        for (int i = 0; i < WC_PER; i++) {
-            const uint64_t idx = c0 + (uint64_t)i * WCT + threadIdx.x;
-            r[i] = recs[idx < qe ? idx : qe - 1];
-        }
-#pragma unroll
-        for (int i = 0; i < WC_PER; i++) {
-            const uint64_t idx = c0 + (uint64_t)i * WCT + threadIdx.x;
-            dg[i] = level_digit<MODE>(r[i], used, lv);
-            if (idx < qe) atomicAdd(&h[dg[i]], 1u);
-        }
+        // (named 16-byte vectors -- a record is one or two of them -- not `Rec r[WC_PER]` and not 32-byte vectors: either way the
+        // 32-byte records of MODE 3 lived in scratch memory across the two barriers, 128 bytes a lane)
+        using V = ulonglong2;
+        constexpr int NV = sizeof(Rec) / 16;
+        static_assert(NV == 1 || NV == 2, "16- or 32-byte records");
+        static_assert(WC_PER == 4, "four named records below");
+        V q0, q1, q2, q3, w0 = {}, w1 = {}, w2 = {}, w3 = {};       // (w: the second half of a 32-byte record)
+        unsigned d0, d1, d2, d3;
+#define RCL_LOAD(i) { const uint64_t idx = c0 + (uint64_t)(i) * WCT + threadIdx.x; const uint64_t at = (idx < qe ? idx : qe - 1) * NV; \
+            q##i = ((const V *)recs)[at]; if constexpr (NV == 2) w##i = ((const V *)recs)[at + 1]; }
+        RCL_LOAD(0) RCL_LOAD(1) RCL_LOAD(2) RCL_LOAD(3)
+#undef RCL_LOAD
+        auto digit_of = [&](const V a, const V b2) __attribute__((always_inline)) -> unsigned {
+            if constexpr (NV == 2) return level_digit<MODE>(Rec{a.x, a.y, b2.x, b2.y}, used, lv);
+            else return level_digit<MODE>(Rec{a.x, a.y}, used, lv);
+        };
+#define RCL_COUNT(i) { const uint64_t idx = c0 + (uint64_t)(i) * WCT + threadIdx.x; d##i = digit_of(q##i, w##i); if (idx < qe) atomicAdd(&h[d##i], 1u); }
+        RCL_COUNT(0) RCL_COUNT(1) RCL_COUNT(2) RCL_COUNT(3)
+#undef RCL_COUNT
         __syncthreads();
         // one claim per digit the tile holds: [base, base + count) of the bucket's region; what does not fit is not written
         for (int d = threadIdx.x; d < nb; d += WCT) {
@@ -2943,17 +2949,16 @@ __global__ __launch_bounds__(WCT) void k_rec_claim_scatter(const typename LevelE
             lim[d] = re;
         }
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < WC_PER; i++) {
-            const uint64_t idx = c0 + (uint64_t)i * WCT + threadIdx.x;
-            if (idx < qe) {
-                const unsigned d = dg[i];
-                const unsigned long long g = atomicAdd(&tail[d], 1ULL);
-                if (g >= lim[d]) { /* the bucket's region is full */ }
-                else if (g - head[d] < (unsigned long long)B) buf[(size_t)d * B + (g & (B - 1))] = r[i];
-                else out[g] = r[i];
-            }
-        }
+#define RCL_PUT(i) { const uint64_t idx = c0 + (uint64_t)(i) * WCT + threadIdx.x; \
+            if (idx < qe) { \
+                const unsigned d = d##i; \
+                const unsigned long long g = atomicAdd(&tail[d], 1ULL); \
+                if (g >= lim[d]) { /* the bucket's region is full */ } \
+                else if (g - head[d] < (unsigned long long)B) { V *to = (V *)buf + ((size_t)d * B + (g & (B - 1))) * NV; to[0] = q##i; if constexpr (NV == 2) to[1] = w##i; } \
+                else { V *to = (V *)out + g * NV; to[0] = q##i; if constexpr (NV == 2) to[1] = w##i; } \
+            } }
+        RCL_PUT(0) RCL_PUT(1) RCL_PUT(2) RCL_PUT(3)
+#undef RCL_PUT
         __syncthreads();
         drain(true);
         __syncthreads();
@@ -3799,21 +3804,21 @@ static int records_onesweep(rfx_ctx *ctx, const ReadSrc &rsrc_in, const Level &l
 
 // A first level over ONE unpartitioned record array without a histogram pass (k_rec_claim_scatter): -> records in workspace slot
 // `oslot`, bucket b in [d_seg_begin[b], d_seg_end[b]).  *done = false: not tried (small input, too many bins) or a bucket outgrew
-// its region -- nothing is valid and the exact form runs.  On for the 16-byte records of k <= 31 from 2^24 records up
-// (RFX_REC_ONESWEEP=0: never, 1: every record kind, 2: at any size -- the tests).
-// Measured in the multi-GPU rehearsal (6.25 Gbp as a rank of 8, 4 generations of 185 M records, k = 31): the level itself is as fast
-// as the exact scatter (part1 14.4 ms a step either way) and the histogram pass is gone (hist1 2.75 -> 0.32): 40.3 -> 38.9 ms.  The
-// buckets then fill in the order the workgroups' claims land, and the NEXT level's 1/16 sample misjudges a handful of its 131,072
-// children by more than its six standard deviations in every generation (a child is a few minimiser sites, their records arrive in
-// clumps) -- which voided that level's sweep (+6 ms) until its children could spill (L2Plan, k_l2_spill_fix).  With the 32-byte
-// records of k = 63 the claim scatter is slower than the exact one (28.0 against 23.5 ms a step): off there.
+// its region -- nothing is valid and the exact form runs.  On for the super-k-mer records (k <= 31 and k = 33..63) from 2^24
+// records up (RFX_REC_ONESWEEP=0: never, 1: every element kind, 2: at any size -- the tests).
+// Measured in the multi-GPU rehearsal (6.25 Gbp as a rank of 8, 4 generations, 185 M records each at k = 31): the level itself is as
+// fast as the exact scatter or faster and the histogram pass is gone -- k = 31: hist1 2.75 -> 0.32, 40.3 -> 37.5 ms a step; k = 63:
+// hist1 4.2 -> 0.35, part1 23.5 -> 20.7, 87.9 -> 81.8.  The buckets then fill in the order the workgroups' claims land, and the NEXT
+// level's 1/16 sample misjudges a handful of its 131,072 children by more than its six standard deviations in every generation (a
+// child is a few minimiser sites, their records arrive in clumps) -- which voided that level's sweep (+6 ms) until its children
+// could spill (L2Plan, k_l2_spill_fix).
 template <int MODE>
 static int records_resweep(rfx_ctx *ctx, const typename LevelElem<MODE>::T *recs, int64_t n_recs, const Level &lv, int used, int oslot,
                            uint64_t *d_seg_begin, uint64_t *d_seg_end, const typename LevelElem<MODE>::T **out_recs, bool *done,
                            const char *hn, const char *pn) {
     using RT = typename LevelElem<MODE>::T;
     *done = false;
-    const int mode = getenv("RFX_REC_ONESWEEP") ? atoi(getenv("RFX_REC_ONESWEEP")) : (MODE == 0 ? 1 : 0);
+    const int mode = getenv("RFX_REC_ONESWEEP") ? atoi(getenv("RFX_REC_ONESWEEP")) : (MODE == 0 || MODE == 3 ? 1 : 0);
     if (MODE == 2 || !mode || lv.bits < 4 || lv.bits > 9 || lv.n_owners > 0 || (mode != 2 && n_recs < ((int64_t)1 << 24))) return RFX_OK;
     const int nb = 1 << lv.bits;
     constexpr int B = MODE == 3 ? 8 : 16;

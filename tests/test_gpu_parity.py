@@ -1496,6 +1496,56 @@ def test_records_do_not_depend_on_the_run_descriptors(rfx, torch_mod, k, owners,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,bits", [(31, "6,5"), (63, "6,5"), (33, "4,4")])
+def test_first_level_of_received_records_without_a_histogram_under_skew(rfx, torch_mod, k, bits, monkeypatch):
+    """the claim form of the receiver's first level (forced at this size) on low-complexity input -- poly-A, a dinucleotide
+    repeat, one read many times: one bucket takes most of the records, every tile claims from the same cursor -- against the
+    exact form and the oracle."""
+    torch = torch_mod
+    L = 150
+    rng = np.random.default_rng(100 + k)
+    one = "".join(rng.choice(list("ACGT"), size=L))
+    reads = ["A" * L] * 9000 + ["AC" * (L // 2)] * 4000 + [one] * 4000 + ["T" * L] * 2000 + \
+            ["".join(rng.choice(list("ACGT"), size=L)) for _ in range(3000)]
+    rng.shuffle(reads)
+    n = len(reads)
+    bases = np.frombuffer("".join(reads).encode(), np.uint8)
+    off = np.arange(n + 1, dtype=np.int64) * L
+    wpr = (L + 31) // 32
+    db = torch.from_numpy(bases.copy()).cuda(); do = torch.from_numpy(off).cuda()
+    dw = torch.empty(n * wpr, dtype=torch.int64, device="cuda")
+    doff = torch.empty(2, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    rfx.encode_reads_dev(db.data_ptr(), do.data_ptr(), n, wpr, dw.data_ptr())
+    wide = k > 32
+    fn = rfx.bucket_wide_records_by_owner_dev if wide else rfx.bucket_records_by_owner_dev
+    width = 4 if wide else 2
+    need, _ = fn(dw.data_ptr(), n, wpr, L, k, 1, 0, 0, doff.data_ptr())
+    out = torch.empty(width * need, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    nrec, h = fn(dw.data_ptr(), n, wpr, L, k, 1, out.data_ptr(), need, doff.data_ptr())
+    N = (rfx.kmers_per_read_w(L, k) if wide else L - k + 1) * n
+    W = 2 if wide else 1
+    if wide:
+        wk, wc, wd = O.count_filter_w(O.extract_canon_w(bases, off, k), k, 2)
+    else:
+        wk, wc, wd = O.count_filter(O.extract_canon(bases, off, k), 2)
+    for mode in ("0", "2"):
+        monkeypatch.setenv("RFX_REC_ONESWEEP", mode)
+        monkeypatch.setenv("RFX_LEVEL_BITS", bits)
+        dk = torch.empty(W * N, dtype=torch.int64, device="cuda")
+        dc = torch.empty(N, dtype=torch.int64 if wide else torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        if wide:
+            m, d = rfx.count_wide_records_dev(out.data_ptr(), nrec, 0, k, dk.data_ptr(), dc.data_ptr(), N, 2)
+        else:
+            m, d = rfx.count_records_dev(out.data_ptr(), nrec, N, k, dk.data_ptr(), dc.data_ptr(), N, 2)
+        assert (m, d) == (len(wk), wd), mode
+        assert np.array_equal(dk[:W * m].cpu().numpy().view(np.uint64).reshape(m, W), np.asarray(wk).view(np.uint64).reshape(len(wk), W))
+        assert np.array_equal(dc[:m].cpu().numpy().astype(np.int64), np.asarray(wc).astype(np.int64))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k", [31, 63])
 def test_children_that_outgrow_their_regions_spill_and_are_moved(rfx, torch_mod, k, monkeypatch):
     """the last radix level in one sweep (k_rec_l2sweep) sizes every child's region from a 1/16 sample; a child that outgrows

@@ -10,6 +10,8 @@ from __future__ import annotations
 import ctypes as C
 from dataclasses import dataclass
 
+import time
+
 import numpy as np
 
 from . import _lib
@@ -653,7 +655,9 @@ class Reflexiv:
             out = DynRecords.empty(cap_n, cap_b, cap_b)
             ci, co = r._c(), out._c()
             co.cap_n, co.cap_key, co.cap_ext = cap_n, cap_b, cap_b
+            t0 = time.perf_counter()
             st = fn(self.ctx, C.byref(ci), *make_args(co))
+            self.last_call_ms = (time.perf_counter() - t0) * 1e3    # inside the C ABI (the last attempt): what a C / Java host pays
             if st == RFX_E_CAP:
                 cap_n = max(cap_n, int(co.n)); cap_b = max(cap_b, int(co.need_key), int(co.need_ext)) + 64
                 continue
@@ -702,8 +706,11 @@ class Reflexiv:
         rn = (C.c_int64 * 3)()
         tcap = int(2 * off[-1]) + 64 * (n + 2) + 4096
         tb = np.empty(tcap, np.uint8)
-        self._check(self.L.rfx_dedup_contigs(self.ctx, _p(bases), _p(off), C.c_int64(n), min_contig, _p(ob), C.c_int64(len(ob)), _p(oo),
-                                             C.c_int64(n + 1), C.byref(m), _p(tb), C.c_int64(tcap), C.byref(tl), rn), "rfx_dedup_contigs")
+        t0 = time.perf_counter()
+        st = self.L.rfx_dedup_contigs(self.ctx, _p(bases), _p(off), C.c_int64(n), min_contig, _p(ob), C.c_int64(len(ob)), _p(oo),
+                                      C.c_int64(n + 1), C.byref(m), _p(tb), C.c_int64(tcap), C.byref(tl), rn)
+        self.last_call_ms = (time.perf_counter() - t0) * 1e3        # inside the C ABI: what a C / Java host pays
+        self._check(st, "rfx_dedup_contigs")
         k = int(m.value)
         surv = [bytes(ob[oo[i]:oo[i + 1]]).decode() for i in range(k)]
         return surv, bytes(tb[:tl.value]).decode(), [int(x) for x in rn]

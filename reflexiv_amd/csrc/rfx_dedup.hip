@@ -430,6 +430,17 @@ struct Dedup {
     }
 };
 
+// ASCII <-> base codes on the device, 16 bytes a thread (round 4: on the host these two loops and the text's "ACGT"[code] were 180 of
+// the 223 ms rfx_dedup_contigs spent on 10^5 contigs).  A0 C1 G2, anything else 3 (nucleotideValue :453-465).
+__global__ void k_dd_to_codes(uint8_t *__restrict__ b, int64_t n) {
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    for (int64_t i = i0; i < i0 + 16 && i < n; i++) { const uint8_t c = b[i]; b[i] = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3; }
+}
+__global__ void k_dd_to_ascii(uint8_t *__restrict__ b, int64_t n) {
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    for (int64_t i = i0; i < i0 + 16 && i < n; i++) b[i] = (uint8_t)"ACGT"[b[i] & 3];
+}
+
 inline void launch_copy(rfx_ctx *ctx, uint8_t *dst, const uint8_t *src, int64_t src_n, int64_t from, int64_t n, int rc) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_dd_copy, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, dst, src, src_n, from, n, rc);
@@ -439,9 +450,10 @@ inline void launch_copy(rfx_ctx *ctx, uint8_t *dst, const uint8_t *src, int64_t 
 
 namespace rfx {
 
-// contigs: bases 0..3 on the host, contig i = bases[off[i], off[i+1]).  -> the survivors of round 3 (host), in order.
+// contigs: bases on the host -- codes 0..3, or ASCII letters with `ascii` (encoded and decoded on the device) --, contig i =
+// bases[off[i], off[i+1]).  -> the survivors of round 3 (host, the same alphabet), in order.
 int dedup_contigs(rfx_ctx *ctx, const uint8_t *h_bases, const int64_t *h_off, int64_t n, std::vector<uint8_t> &out_bases,
-                  std::vector<int64_t> &out_off, int64_t *round_n) {
+                  std::vector<int64_t> &out_off, int64_t *round_n, bool ascii) {
     const int64_t total_in = n ? h_off[n] - h_off[0] : 0;
     // two pools (a round reads one and writes the other) and two work buffers for a contig that grows while shorter ones
     // are merged into it; merges only ever add pieces of their inputs, so nothing outgrows the input
@@ -450,6 +462,10 @@ int dedup_contigs(rfx_ctx *ctx, const uint8_t *h_bases, const int64_t *h_off, in
     RFX_HIP(poolA.alloc(pool_cap, ctx->stream)); RFX_HIP(poolB.alloc(pool_cap, ctx->stream));
     RFX_HIP(workA.alloc(pool_cap, ctx->stream)); RFX_HIP(workB.alloc(pool_cap, ctx->stream));
     if (total_in > 0) RFX_HIP(hipMemcpyAsync(poolA.p, h_bases + h_off[0], (size_t)total_in, hipMemcpyHostToDevice, ctx->stream));
+    if (ascii && total_in > 0) {
+        hipLaunchKernelGGL(k_dd_to_codes, dim3((unsigned)ceil_div(ceil_div(total_in, 16), 256)), dim3(256), 0, ctx->stream, poolA.as<uint8_t>(), total_in);
+        RFX_HIP(hipGetLastError());
+    }
     std::vector<Contig> cur((size_t)n);
     for (int64_t i = 0; i < n; i++) cur[(size_t)i] = Contig{h_off[i] - h_off[0], h_off[i + 1] - h_off[i], i};
     uint8_t *pin = poolA.as<uint8_t>(), *pout = poolB.as<uint8_t>();
@@ -722,6 +738,10 @@ int dedup_contigs(rfx_ctx *ctx, const uint8_t *h_bases, const int64_t *h_off, in
     int64_t p = 0;
     bool dense = true;                                        // (a round's output is written back to back, in order)
     for (size_t i = 0; i < cur.size(); i++) { out_off[i] = p; if (cur[i].off != p) dense = false; p += cur[i].len; }
+    if (ascii && in_used > 0) {                               // (the whole pool in use: the survivors lie inside it)
+        hipLaunchKernelGGL(k_dd_to_ascii, dim3((unsigned)ceil_div(ceil_div(in_used, 16), 256)), dim3(256), 0, ctx->stream, pin, in_used);
+        RFX_HIP(hipGetLastError());
+    }
     if (dense && tb > 0) RFX_HIP(hipMemcpyAsync(out_bases.data(), pin, (size_t)tb, hipMemcpyDeviceToHost, ctx->stream));
     else
         for (size_t i = 0; i < cur.size(); i++)
@@ -736,6 +756,7 @@ int dedup_contigs(rfx_ctx *ctx, const uint8_t *h_bases, const int64_t *h_off, in
 extern "C" {
 
 // TagRowContigDSID.call + changeLine (:3397-3443)
+// (`bases`: ASCII letters)
 static int64_t dedup_text(const std::vector<uint8_t> &bases, const std::vector<int64_t> &off, int min_contig, char *out, int64_t cap) {
     int64_t pos = 0;
     const int64_t LIM = 10000000;
@@ -750,8 +771,8 @@ static int64_t dedup_text(const std::vector<uint8_t> &bases, const std::vector<i
             if (j0 > 0) { if (pos < cap) out[pos] = '\n'; pos++; }
             const int64_t nl = std::min<int64_t>(LIM, L - j0);
             const uint8_t *src = bases.data() + off[(size_t)i] + j0;
-            if (pos + nl <= cap) { for (int64_t j = 0; j < nl; j++) out[pos + j] = "ACGT"[src[j]]; }
-            else for (int64_t j = 0; j < nl; j++) if (pos + j < cap) out[pos + j] = "ACGT"[src[j]];
+            if (pos + nl <= cap) memcpy(out + pos, src, (size_t)nl);
+            else if (pos < cap) memcpy(out + pos, src, (size_t)(cap - pos));
             pos += nl;
         }
         if (pos < cap) out[pos] = '\n';
@@ -765,28 +786,19 @@ int rfx_dedup_contigs(rfx_ctx *ctx, const uint8_t *bases_ascii, const int64_t *c
                       char *text, int64_t text_cap, int64_t *text_len, int64_t *round_n) try {
     if (!ctx || !contig_off || n_contigs < 0 || (n_contigs > 0 && !bases_ascii)) return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));
-    const int64_t nb = n_contigs ? contig_off[n_contigs] - contig_off[0] : 0;
-    std::vector<uint8_t> codes((size_t)nb);
-    {                                                     // A0 C1 G2, anything else 3 (nucleotideValue :453-465)
-        uint8_t lut[256];
-        memset(lut, 3, sizeof lut);
-        lut[(unsigned char)'A'] = 0; lut[(unsigned char)'C'] = 1; lut[(unsigned char)'G'] = 2;
-        const uint8_t *src = bases_ascii + contig_off[0];
-        for (int64_t i = 0; i < nb; i++) codes[(size_t)i] = lut[src[i]];
-    }
     std::vector<int64_t> off((size_t)n_contigs + 1);
     for (int64_t i = 0; i <= n_contigs; i++) off[(size_t)i] = contig_off[i] - contig_off[0];
     std::vector<uint8_t> ob;
     std::vector<int64_t> oo;
     if (n_contigs == 0) { oo.assign(1, 0); if (round_n) round_n[0] = round_n[1] = round_n[2] = 0; }
-    else RFX_TRY(rfx::dedup_contigs(ctx, codes.data(), off.data(), n_contigs, ob, oo, round_n));
+    else RFX_TRY(rfx::dedup_contigs(ctx, bases_ascii + contig_off[0], off.data(), n_contigs, ob, oo, round_n, true));   // (letters in, letters out)
     const int64_t m = (int64_t)oo.size() - 1;
     if (out_n) *out_n = m;
     int st = RFX_OK;
     if (out_bases_ascii && out_off) {
         if ((int64_t)ob.size() > cap_bases || m > cap_contigs) st = RFX_E_CAP;
         else {
-            for (size_t i = 0; i < ob.size(); i++) out_bases_ascii[i] = (uint8_t)"ACGT"[ob[i]];
+            if (!ob.empty()) memcpy(out_bases_ascii, ob.data(), ob.size());
             for (int64_t i = 0; i <= m; i++) out_off[i] = oo[(size_t)i];
         }
     }

@@ -519,6 +519,12 @@ typedef struct {
     int32_t *marker, *left, *right;
     int64_t cap_n, cap_key, cap_ext, need_key, need_ext;
 } rfx_dyn_records;
+/* DynamicKmerBinarizerFromReducedToSubKmer (P/ReflexivDSDynamicKmerFirstFour.java:2931-3016 and Iteration's twin) on the device: the
+ * text rows of the hand-over files -> records.  text + row_off[n_rows + 1]: row i = text[row_off[i], row_off[i+1]), its fields joined
+ * by ',' (a trailing newline is ignored).  form 0: (k-mer, "m|l|r") -> key = the k-mer without its last base, extension = that base,
+ * orientation 1; form 1: (sub-k-mer, "m|l|r", extension).  A leading '(' / trailing ')' of the tuple text is dropped; left / right
+ * clamped to +-30000 as the reference reads its attribute long back (:2340-2366).  Outputs as for the other rfx_dyn_* calls. */
+int rfx_dyn_binarize(rfx_ctx *ctx, const char *text, const int64_t *row_off, int64_t n_rows, int form, rfx_dyn_records *out);
 int rfx_dyn_sort(rfx_ctx *ctx, const rfx_dyn_records *in, int P, rfx_dyn_records *out, int64_t *part_start);
 int rfx_dyn_random_reflection(rfx_ctx *ctx, const rfx_dyn_records *in, const int64_t *part_start, int P, rfx_dyn_records *out);
 int rfx_dyn_extend_pass(rfx_ctx *ctx, const rfx_dyn_records *in, const int64_t *part_start, int P, int stage, int start_iteration,

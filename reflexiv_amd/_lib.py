@@ -67,7 +67,7 @@ SYMBOLS = [
     "rfx_comm_unique_id", "rfx_comm_init", "rfx_comm_destroy", "rfx_comm_rank", "rfx_comm_world", "rfx_comm_last_bytes_bucketed",
     "rfx_comm_all_reduce_i64", "rfx_dev_sharded_count", "rfx_dev_gather_shards", "rfx_sharded_assemble_reads", "rfx_dev_sharded_assemble",
     "rfx_dedup_contigs", "rfx_dedup_contig_text",
-    "rfx_dyn_sort", "rfx_dyn_random_reflection", "rfx_dyn_extend_pass", "rfx_dyn_run",
+    "rfx_dyn_binarize", "rfx_dyn_sort", "rfx_dyn_random_reflection", "rfx_dyn_extend_pass", "rfx_dyn_run",
     "rfx_dyn_blocks_to_bases", "rfx_dyn_bases_to_blocks", "rfx_dyn_attribute", "rfx_dyn_attribute_unpack",
 ]
 

@@ -664,6 +664,24 @@ class Reflexiv:
             self._check(st, name)
             return out._trim(co)
 
+    def dyn_binarize(self, rows, form=None) -> DynRecords:
+        """rfx_dyn_binarize: DynamicKmerBinarizerFromReducedToSubKmer ON THE DEVICE.  rows: tuples of text fields -- (k-mer, "m|l|r")
+        (form 0, FirstFour) or (sub-k-mer, "m|l|r", extension) (form 1, Iteration); joined by ',' as the hand-over files hold them."""
+        rows = list(rows)
+        if form is None:
+            form = 1 if rows and len(rows[0]) == 3 else 0
+        lines = [",".join(f) for f in rows]
+        off = np.zeros(len(lines) + 1, np.int64)
+        off[1:] = np.cumsum([len(x) for x in lines])
+        text = "".join(lines).encode()
+        cap_n, cap_b = len(lines), len(text) + 64
+        out = DynRecords.empty(cap_n, cap_b, cap_b)
+        co = out._c()
+        co.cap_n, co.cap_key, co.cap_ext = cap_n, cap_b, cap_b
+        st = self.L.rfx_dyn_binarize(self.ctx, text, _p(off), C.c_int64(len(lines)), form, C.byref(co))
+        self._check(st, "rfx_dyn_binarize")
+        return out._trim(co)
+
     def dyn_sort(self, r: DynRecords, P: int):
         """rfx_dyn_sort -> (sorted DynRecords, part_start[P+1])"""
         ps = np.empty(P + 1, np.int64)

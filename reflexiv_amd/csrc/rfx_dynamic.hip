@@ -520,6 +520,97 @@ int rfx_dyn_sort(rfx_ctx *ctx, const rfx_dyn_records *in, int P, rfx_dyn_records
     return dyn_download(ctx, b, out);
 } RFX_API_CATCH(ctx)
 
+// ---- DynamicKmerBinarizerFromReducedToSubKmer (FirstFour :2931-3016; Iteration's twin) on the device: the text rows of the hand-over
+// files -> records.  A row is its fields joined by ',': form 0 = (k-mer, "m|l|r") -- key = the k-mer without its last base, extension =
+// that base, orientation 1 --, form 1 = (sub-k-mer, "m|l|r", extension).  A leading '(' of the first field and a trailing ')' of the
+// attribute are dropped (the tuple text Spark writes); left / right are read back clamped to +-30000 (buildingAlongFromThreeInt
+// :2340-2366); A0 C1 G2, anything else 3.  One thread per row, twice: sizes (+ the attribute), then the bases.
+struct DynRowCut { int64_t f0, f0e, f1, f1e, f2, f2e; };     // the three fields' [begin, end) in the text
+__device__ __forceinline__ DynRowCut dyn_row_cut(const char *__restrict__ t, int64_t b, int64_t e) {
+    while (e > b && (t[e - 1] == '\n' || t[e - 1] == '\r')) e--;
+    int64_t c1 = e, c2 = e;
+    for (int64_t i = b; i < e; i++) if (t[i] == ',') { if (c1 == e) c1 = i; else { c2 = i; break; } }
+    DynRowCut c{b, c1, c1 < e ? c1 + 1 : e, c2, c2 < e ? c2 + 1 : e, e};
+    if (c.f0 < c.f0e && t[c.f0] == '(') c.f0++;
+    if (c.f1e > c.f1 && t[c.f1e - 1] == ')') c.f1e--;
+    if (c.f2e > c.f2 && t[c.f2e - 1] == ')') c.f2e--;
+    return c;
+}
+__device__ __forceinline__ int dyn_parse_int(const char *__restrict__ t, int64_t &i, int64_t e) {
+    bool neg = false;
+    if (i < e && (t[i] == '-' || t[i] == '+')) { neg = t[i] == '-'; i++; }
+    long long v = 0;
+    while (i < e && t[i] >= '0' && t[i] <= '9') { if (v < 100000000LL) v = v * 10 + (t[i] - '0'); i++; }
+    if (i < e && t[i] == '|') i++;
+    return (int)(neg ? -v : v);
+}
+__global__ void k_dyn_bin_sizes(const char *__restrict__ text, const int64_t *__restrict__ row_off, int64_t n, int form,
+                                uint32_t *__restrict__ klen, uint32_t *__restrict__ elen, int32_t *__restrict__ marker,
+                                int32_t *__restrict__ left, int32_t *__restrict__ right) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const DynRowCut c = dyn_row_cut(text, row_off[r], row_off[r + 1]);
+    const int64_t l0 = c.f0e - c.f0;
+    if (form == 0) { klen[r] = (uint32_t)(l0 > 0 ? l0 - 1 : 0); elen[r] = l0 > 0 ? 1u : 0u; }
+    else { klen[r] = (uint32_t)l0; elen[r] = (uint32_t)(c.f2e - c.f2); }
+    int64_t i = c.f1;
+    const int m = dyn_parse_int(text, i, c.f1e), l = dyn_parse_int(text, i, c.f1e), rr = dyn_parse_int(text, i, c.f1e);
+    marker[r] = form == 0 ? 1 : m;
+    left[r] = l < -30000 ? -30000 : l > 30000 ? 30000 : l;
+    right[r] = rr < -30000 ? -30000 : rr > 30000 ? 30000 : rr;
+}
+__device__ __forceinline__ uint8_t dyn_code(char ch) { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3; }
+__global__ void k_dyn_bin_fill(const char *__restrict__ text, const int64_t *__restrict__ row_off, int64_t n, int form,
+                               const uint64_t *__restrict__ key_off, const uint64_t *__restrict__ ext_off, uint8_t *__restrict__ key,
+                               uint8_t *__restrict__ ext) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const DynRowCut c = dyn_row_cut(text, row_off[r], row_off[r + 1]);
+    const int64_t nk = (int64_t)(key_off[r + 1] - key_off[r]), ne = (int64_t)(ext_off[r + 1] - ext_off[r]);
+    for (int64_t j = 0; j < nk; j++) key[key_off[r] + j] = dyn_code(text[c.f0 + j]);
+    const int64_t es = form == 0 ? c.f0 + nk : c.f2;
+    for (int64_t j = 0; j < ne; j++) ext[ext_off[r] + j] = dyn_code(text[es + j]);
+}
+
+int rfx_dyn_binarize(rfx_ctx *ctx, const char *text, const int64_t *row_off, int64_t n_rows, int form, rfx_dyn_records *out) try {
+    if (!ctx || !out || n_rows < 0 || (n_rows > 0 && (!text || !row_off)) || (form != 0 && form != 1)) return RFX_E_ARG;
+    RFX_HIP(hipSetDevice(ctx->device));
+    for (int64_t i = 0; i < n_rows; i++) if (row_off[i + 1] < row_off[i]) return RFX_E_ARG;
+    const int64_t nb = n_rows ? row_off[n_rows] - row_off[0] : 0;
+    DevBuf d_text, d_off, klen, elen;
+    DynDev d;
+    RFX_HIP(d_text.alloc((size_t)std::max<int64_t>(nb, 1), ctx->stream));
+    RFX_HIP(d_off.alloc((size_t)(n_rows + 1) * 8, ctx->stream));
+    RFX_HIP(klen.alloc((size_t)std::max<int64_t>(n_rows, 1) * 4, ctx->stream));
+    RFX_HIP(elen.alloc((size_t)std::max<int64_t>(n_rows, 1) * 4, ctx->stream));
+    // (records first with room for every byte of the text: the sizes are known only after the first kernel)
+    RFX_TRY(dyn_alloc(ctx, d, n_rows, nb, nb));
+    if (n_rows == 0) {
+        RFX_HIP(hipMemsetAsync(d.key_off.p, 0, 8, ctx->stream));
+        RFX_HIP(hipMemsetAsync(d.ext_off.p, 0, 8, ctx->stream));
+        d.nk = d.ne = 0;
+        return dyn_download(ctx, d, out);
+    }
+    std::vector<int64_t> rel((size_t)n_rows + 1);
+    for (int64_t i = 0; i <= n_rows; i++) rel[(size_t)i] = row_off[i] - row_off[0];
+    if (nb) RFX_HIP(hipMemcpyAsync(d_text.p, text + row_off[0], (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(d_off.p, rel.data(), (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_dyn_bin_sizes, GRID(n_rows), (const char *)d_text.p, (const int64_t *)d_off.as<int64_t>(), n_rows, form,
+                       klen.as<uint32_t>(), elen.as<uint32_t>(), d.marker.as<int32_t>(), d.left.as<int32_t>(), d.right.as<int32_t>());
+    RFX_HIP(hipGetLastError());
+    RFX_TRY(exclusive_scan_u32_to_u64(ctx, klen.as<uint32_t>(), d.key_off.as<uint64_t>(), n_rows));
+    RFX_TRY(exclusive_scan_u32_to_u64(ctx, elen.as<uint32_t>(), d.ext_off.as<uint64_t>(), n_rows));
+    hipLaunchKernelGGL(k_dyn_bin_fill, GRID(n_rows), (const char *)d_text.p, (const int64_t *)d_off.as<int64_t>(), n_rows, form,
+                       (const uint64_t *)d.key_off.as<uint64_t>(), (const uint64_t *)d.ext_off.as<uint64_t>(), d.key.as<uint8_t>(), d.ext.as<uint8_t>());
+    RFX_HIP(hipGetLastError());
+    uint64_t tot[2] = {0, 0};
+    RFX_HIP(hipMemcpyAsync(&tot[0], d.key_off.as<uint64_t>() + n_rows, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_HIP(hipMemcpyAsync(&tot[1], d.ext_off.as<uint64_t>() + n_rows, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RFX_TRY(sync_checked(ctx));
+    d.nk = (int64_t)tot[0]; d.ne = (int64_t)tot[1];
+    return dyn_download(ctx, d, out);
+} RFX_API_CATCH(ctx)
+
 int rfx_dyn_random_reflection(rfx_ctx *ctx, const rfx_dyn_records *in, const int64_t *part_start, int P, rfx_dyn_records *out) try {
     if (!ctx || !in || !out || !part_start || P < 1 || P > 63) return RFX_E_ARG;
     RFX_HIP(hipSetDevice(ctx->device));

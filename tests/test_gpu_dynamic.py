@@ -122,3 +122,42 @@ def test_cpp_host_firstfour_and_iteration(tmp_path):
     subprocess.check_call([host, "iteration", "-kmerc", ff, "-outfile", out, "--logical-partitions", str(P), "-start", str(start), "-end", str(end)])
     it = os.path.join(out, "Assembly_intermediate", f"01Iteration{start}_{end}", "part-00000.csv")
     assert open(it).read() == bytes(z[case + "/final"]).decode()
+
+
+@pytest.mark.parametrize("case", cases())
+def test_gpu_binarizer_equals_the_reference_class(rfx, case):
+    """DynamicKmerBinarizerFromReducedToSubKmer ON THE DEVICE (rfx_dyn_binarize) -- the first operator of the chain -- against the
+    reference class's own output: FirstFour's (k-mer, attribute) rows, and every Iteration-form row set of the case
+    ((sub-k-mer, attribute, extension): the reference's outputs read back in)."""
+    z = np.load(VEC)
+    r = rfx.dyn_binarize(rows_of(z, case + "/in"))
+    check(r.rows(), rows_of(z, case + "/binarized"), "binarized")
+    for name in sorted(n for n in z.files if n.startswith(case + "/") and (n.split("/")[1].startswith("extend") or n.split("/")[1].startswith("it_"))):
+        rows = rows_of(z, name)
+        g = rfx.dyn_binarize(rows, form=1)
+        check(g.rows(), rows, name)                               # text -> records -> text is the identity on the reference's rows
+
+
+def test_gpu_binarizer_on_the_edges(rfx):
+    """tuple text with parentheses, negative and out-of-range attribute values (read back clamped to +-30000), bases outside
+    ACG, empty extensions, CRLF line ends, an empty row set: the device parser against the harness's Python one."""
+    from reflexiv_amd.api import DynRecords
+    rng = np.random.default_rng(11)
+    rows0, rows1 = [], []
+    for i in range(5000):
+        L = int(rng.integers(2, 125))
+        kmer = "".join(rng.choice(list("ACGTN"), size=L, p=[0.24, 0.24, 0.24, 0.24, 0.04]))
+        a = f"{int(rng.integers(1, 3))}|{int(rng.integers(-40000, 40000))}|{int(rng.integers(-40000, 40000))}"
+        rows0.append((("(" if i % 3 == 0 else "") + kmer, a + (")" if i % 3 == 0 else "")))
+        ext = "".join(rng.choice(list("ACGT"), size=int(rng.integers(0, 200))))
+        rows1.append((("(" if i % 5 == 0 else "") + kmer, a, ext + (")" if i % 5 == 0 else "")))
+    for rows, ref in ((rows0, DynRecords.from_kmer_rows(rows0)),
+                      (rows1, DynRecords.from_rows([(k, a, e[:-1] if e.endswith(")") else e) for k, a, e in rows1]))):
+        g = rfx.dyn_binarize(rows)
+        assert g.n == ref.n
+        for f in ("key_off", "ext_off", "marker", "left", "right"):
+            assert np.array_equal(getattr(g, f), getattr(ref, f)), f
+        assert np.array_equal(g.key[:g.key_off[-1]], ref.key[:ref.key_off[-1]]) and np.array_equal(g.ext[:g.ext_off[-1]], ref.ext[:ref.ext_off[-1]])
+    assert rfx.dyn_binarize([]).n == 0
+    g = rfx.dyn_binarize([("ACGTA", "1|-1|7\r\n")])
+    assert g.rows() == [("ACGT", "1|-1|7", "A")]

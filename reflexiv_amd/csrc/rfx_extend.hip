@@ -701,10 +701,18 @@ __global__ void k_word0(const int64_t *__restrict__ ext_off, const uint64_t *__r
 // summary = {records out, words out, status}
 __global__ void k_out_part_start(const int64_t *__restrict__ ps, int P, const uint64_t *__restrict__ oidx,
                                  int64_t *__restrict__ ops, const uint64_t *__restrict__ owoff, int64_t n,
-                                 const int *__restrict__ status, uint64_t *__restrict__ summary) {
+                                 const int *__restrict__ status, uint64_t *__restrict__ summary, volatile uint64_t *mbox, uint64_t seq) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p <= P) ops[p] = (int64_t)oidx[ps[p]];
     if (p == 0) { summary[0] = oidx[n]; summary[1] = owoff[n]; summary[2] = (uint64_t)(unsigned)status[0]; }
+    if (mbox) {                                            // (one workgroup: the host launches it so when it wants the mailbox)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            mbox[1] = oidx[n]; mbox[2] = owoff[n]; mbox[3] = (uint64_t)(unsigned)status[0];
+            __threadfence_system();
+            mbox[0] = seq;
+        }
+    }
 }
 
 inline unsigned grid_for(int64_t n, int block = 256) { return (unsigned)ceil_div(n > 0 ? n : 1, block); }
@@ -764,13 +772,18 @@ static int desc_tail(rfx_ctx *ctx, const DevRecords &in, int64_t nd, DevBuf &len
     }
     DevBuf summary;
     RFX_HIP(summary.alloc(24, ctx->stream));
+    const uint64_t seq = P + 1 <= 256 ? mailbox_next(ctx) : 0;          // (the posting kernel is one workgroup)
     hipLaunchKernelGGL(k_out_part_start, dim3(grid_for(P + 1)), dim3(256), 0, ctx->stream, d_part_start, P,
                        (const uint64_t *)oidx.as<uint64_t>(), out_part_start.as<int64_t>(),
-                       (const uint64_t *)owoff.as<uint64_t>(), nd, (const int *)status.as<int>(), summary.as<uint64_t>());
+                       (const uint64_t *)owoff.as<uint64_t>(), nd, (const int *)status.as<int>(), summary.as<uint64_t>(),
+                       seq ? ctx->mailbox : (volatile uint64_t *)nullptr, seq);
     RFX_HIP(hipGetLastError());
     uint64_t tot[3] = {0, 0, 0};
-    RFX_HIP(hipMemcpyAsync(tot, summary.p, 24, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_TRY(sync_checked(ctx));
+    if (seq) RFX_TRY(mailbox_wait(ctx, seq, tot, 3));
+    else {
+        RFX_HIP(hipMemcpyAsync(tot, summary.p, 24, hipMemcpyDeviceToHost, ctx->stream));
+        RFX_TRY(sync_checked(ctx));
+    }
     const int st = (int)tot[2];
     out.n = (int64_t)tot[0]; out.words = (int64_t)tot[1];
     if (st) { ctx->last_error = "extend pass: single-word stage produced an extension > 31 bases"; return RFX_E_STATE; }

@@ -583,8 +583,7 @@ int sort_records(rfx_ctx *ctx, const DevRecords &in, int P, int key_bits, DevRec
                                perm.as<uint32_t>(), n, (const KeyW<2> *)in.key.as<KeyW<2>>(), res, flag.as<int>());
             RFX_HIP(hipGetLastError());
             int h_flag = 0;
-            RFX_HIP(hipMemcpyAsync(&h_flag, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-            RFX_TRY(sync_checked(ctx));
+            RFX_TRY(small_readback(ctx, &h_flag, flag.p, 4));
             done = h_flag == 0;
             if (!done) {                       // a long run of equal prefixes: start over with the two passes below
                 hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n)), dim3(256), 0, ctx->stream, perm.as<uint32_t>(), n);
@@ -687,8 +686,7 @@ int fork_filter(rfx_ctx *ctx, bool reflected, const DevRecords &in, const int64_
                        (const uint64_t *)pos.as<uint64_t>(), out_part_start.as<int64_t>());
     RFX_HIP(hipGetLastError());
     uint64_t m = 0;
-    RFX_HIP(hipMemcpyAsync(&m, pos.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_TRY(sync_checked(ctx));
+    RFX_TRY(small_readback(ctx, &m, pos.as<uint64_t>() + n, 8));
     out.n = (int64_t)m; out.words = (int64_t)m;
     return RFX_OK;
 }
@@ -743,8 +741,7 @@ int counter_to_asm(rfx_ctx *ctx, const uint64_t *d_keys32, const int64_t *d_coun
                        (const uint32_t *)flag.as<uint32_t>(), (const uint64_t *)pos.as<uint64_t>(), d_out31, d_out_counts);
     RFX_HIP(hipGetLastError());
     uint64_t m = 0;
-    RFX_HIP(hipMemcpyAsync(&m, pos.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-    RFX_TRY(sync_checked(ctx));
+    RFX_TRY(small_readback(ctx, &m, pos.as<uint64_t>() + n, 8));
     *out_n = (int64_t)m;
     return RFX_OK;
 }

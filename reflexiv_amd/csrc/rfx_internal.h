@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <time.h>
 #include <string>
 #include <vector>
 #include <map>
@@ -68,6 +69,8 @@ struct rfx_ctx {
         if (scan_ticket) (void)hipFree(scan_ticket);
         if (scan_fault) (void)hipHostFree(scan_fault);
         scan_fault = nullptr;
+        if (mailbox) (void)hipHostFree((void *)mailbox);
+        mailbox = nullptr;
         scan_desc = nullptr; scan_ticket = nullptr; scan_desc_cap = 0;
         timers_pending.clear();
         for (auto e : ev_pool) (void)hipEventDestroy(e);
@@ -90,6 +93,12 @@ struct rfx_ctx {
     int *scan_fault = nullptr;             // host-mapped: set by a look-back that gave up (never expected)
     unsigned long long scan_tickets_issued = 0;
     uint32_t scan_epoch = 0;
+    // A mailbox in host-mapped pinned memory: the last (one-workgroup) kernel of a chain writes up to seven values and then a
+    // sequence number into it, the host spins on the number instead of queueing a 24-byte copy and waiting for the stream
+    // (mailbox_wait below).  The extend stage waits twice per pass for a handful of bytes; a stream wait + the copy cost 25-40 us
+    // each, the mailbox a few.  RFX_MAILBOX=0: the copies again.
+    volatile uint64_t *mailbox = nullptr;          // [0] sequence, [1..7] values
+    uint64_t mailbox_seq = 0;
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
     void *pinned_get(size_t bytes) {
@@ -143,6 +152,52 @@ static inline int sync_checked(rfx_ctx *ctx) {
     }
     return RFX_OK;
 }
+
+// The mailbox (see rfx_ctx): mailbox_next() -> the number the kernel must post (0: no mailbox, use a copy + sync_checked);
+// mailbox_wait() spins for it -- everything queued before the posting kernel has completed by then -- and falls back to a
+// stream wait after two seconds (a faulted kernel never posts) or when the stream already reports an error.
+static inline uint64_t mailbox_next(rfx_ctx *ctx) {
+    static const bool off = [] { const char *e = getenv("RFX_MAILBOX"); return e && atoi(e) == 0; }();
+    if (off) return 0;
+    if (!ctx->mailbox) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) return 0;
+        memset(p, 0, 64);
+        ctx->mailbox = (volatile uint64_t *)p;
+        ctx->mailbox_seq = 0;
+    }
+    return ++ctx->mailbox_seq;
+}
+static inline int mailbox_wait(rfx_ctx *ctx, uint64_t seq, uint64_t *vals, int nvals) {
+    timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint64_t spins = 0;; spins++) {
+        if (ctx->mailbox[0] == seq) break;
+        if ((spins & 0xFFF) == 0xFFF) {
+            timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000 + (t1.tv_nsec - t0.tv_nsec) / 1000000 > 2000) {
+                const int st = sync_checked(ctx);
+                if (st != RFX_OK) return st;
+                if (ctx->mailbox[0] != seq) { ctx->last_error = "mailbox: the posting kernel finished without posting"; return RFX_E_STATE; }
+                break;
+            }
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    for (int i = 0; i < nvals; i++) vals[i] = ctx->mailbox[1 + i];
+    if (ctx->scan_fault && *ctx->scan_fault) {
+        *ctx->scan_fault = 0;
+        ctx->last_error = "scan: look-back gave up waiting for a predecessor tile (offsets of this call are invalid)";
+        return RFX_E_HIP;
+    }
+    return RFX_OK;
+}
+
+// up to 56 bytes of device memory to the host through the mailbox (one tiny launch instead of a queued copy + a stream wait);
+// anything larger, or with the mailbox off: the copy and sync_checked.  Everything queued before it has completed on return.
+int small_readback(rfx_ctx *ctx, void *h_dst, const void *d_src, size_t nbytes);
 
 // Bump arena for the temporaries of one pass of the extend loop: two of them alternate, so a
 // pass reads its inputs from the previous pass's arena and nothing is allocated or freed per pass

@@ -165,6 +165,13 @@ __global__ __launch_bounds__(LB_THREADS) void k_scan_lookback(const uint32_t *__
     }
 }
 
+__global__ void k_mailbox_post(const uint8_t *__restrict__ src, int nbytes, volatile uint64_t *mbox, uint64_t seq) {
+    volatile uint8_t *dst = (volatile uint8_t *)(mbox + 1);
+    if ((int)threadIdx.x < nbytes) dst[threadIdx.x] = src[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence_system(); mbox[0] = seq; }
+}
+
 int scan_lookback(rfx_ctx *ctx, const uint32_t *a, const uint32_t *b, uint64_t *oa, uint64_t *ob, int64_t n) {
     const int64_t nt = ceil_div(n, LB_TILE);
     const size_t need = (size_t)nt * 2;
@@ -230,6 +237,20 @@ int scan_impl(rfx_ctx *ctx, const T *d_in, uint64_t *d_out, int64_t n) {
 }
 
 }  // namespace
+
+int small_readback(rfx_ctx *ctx, void *h_dst, const void *d_src, size_t nbytes) {
+    const uint64_t seq = nbytes <= 56 ? mailbox_next(ctx) : 0;
+    if (!seq) {
+        RFX_HIP(hipMemcpyAsync(h_dst, d_src, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+        return sync_checked(ctx);
+    }
+    hipLaunchKernelGGL(k_mailbox_post, dim3(1), dim3(64), 0, ctx->stream, (const uint8_t *)d_src, (int)nbytes, ctx->mailbox, seq);
+    RFX_HIP(hipGetLastError());
+    uint64_t v[7] = {0, 0, 0, 0, 0, 0, 0};
+    RFX_TRY(mailbox_wait(ctx, seq, v, (int)((nbytes + 7) / 8)));
+    memcpy(h_dst, v, nbytes);
+    return RFX_OK;
+}
 
 namespace rfx {
 

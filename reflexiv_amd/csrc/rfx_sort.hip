@@ -312,7 +312,8 @@ __global__ __launch_bounds__(ST) void k_sort_small(uint64_t *keys, uint32_t *val
 // bucket (<= one tile when the keys are spread) is finished on chip -- 4 launches instead of 16.
 // bstart[d] = first position of top digit d (bstart[256] = n); *maxc = the largest bucket
 __global__ __launch_bounds__(256) void k_bucket_bounds(const uint32_t *__restrict__ table, int64_t ntiles,
-                                                       uint32_t *__restrict__ bstart, uint32_t *__restrict__ maxc) {
+                                                       uint32_t *__restrict__ bstart, uint32_t *__restrict__ maxc,
+                                                       volatile uint64_t *mbox, uint64_t seq) {
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t mx;
     if (threadIdx.x == 0) mx = 0;
@@ -325,7 +326,10 @@ __global__ __launch_bounds__(256) void k_bucket_bounds(const uint32_t *__restric
     __syncthreads();
     atomicMax(&mx, c);
     __syncthreads();
-    if (threadIdx.x == 0) *maxc = mx;
+    if (threadIdx.x == 0) {
+        *maxc = mx;
+        if (mbox) { mbox[1] = mx; __threadfence_system(); mbox[0] = seq; }     // (rfx_ctx::mailbox: the host spins on `seq`)
+    }
 }
 
 __global__ __launch_bounds__(ST) void k_sort_buckets(const uint64_t *__restrict__ ikeys, const uint32_t *__restrict__ ivals,
@@ -421,8 +425,7 @@ int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int 
                            (const uint64_t *)offs3.as<uint64_t>(), sm3, n, bounds3.as<uint32_t>(), d_max3);
         RFX_HIP(hipGetLastError());
         uint32_t maxc = 0;
-        RFX_HIP(hipMemcpyAsync(&maxc, d_max3, 4, hipMemcpyDeviceToHost, ctx->stream));
-        RFX_TRY(sync_checked(ctx));
+        RFX_TRY(small_readback(ctx, &maxc, d_max3, 4));
         if (maxc <= (uint32_t)STILE) {
             hipLaunchKernelGGL(k_sort_buckets, dim3((unsigned)((int64_t)NP2 * D3)), dim3(ST), 0, ctx->stream, (const uint64_t *)dk, (const uint32_t *)dv,
                                (const uint32_t *)bounds3.as<uint32_t>(), shift3, d_keys, d_vals);
@@ -471,8 +474,7 @@ int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int 
                            (const uint64_t *)offs2.as<uint64_t>(), sm, n, b3.as<uint32_t>(), d_maxc);
         RFX_HIP(hipGetLastError());
         uint32_t maxc = 0;
-        RFX_HIP(hipMemcpyAsync(&maxc, d_maxc, 4, hipMemcpyDeviceToHost, ctx->stream));
-        RFX_TRY(sync_checked(ctx));
+        RFX_TRY(small_readback(ctx, &maxc, d_maxc, 4));
         if (maxc <= (uint32_t)STILE) {
             hipLaunchKernelGGL(k_sort_buckets, dim3((unsigned)(256 * D2)), dim3(ST), 0, ctx->stream, (const uint64_t *)sk, (const uint32_t *)sv,
                                (const uint32_t *)b3.as<uint32_t>(), shift2, d_keys, d_vals);
@@ -489,12 +491,16 @@ int sort_pairs(rfx_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int64_t n, int 
         RFX_HIP(bounds.alloc(258 * 4, ctx->stream));
         hipLaunchKernelGGL(k_hist<false>, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, n, shift, table.as<uint32_t>(), ntiles, nomap);
         RFX_HIP(hipGetLastError());
+        const uint64_t seq = mailbox_next(ctx);
         hipLaunchKernelGGL(k_bucket_bounds, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t *)table.as<uint32_t>(), ntiles,
-                           bounds.as<uint32_t>(), bounds.as<uint32_t>() + 257);
+                           bounds.as<uint32_t>(), bounds.as<uint32_t>() + 257, seq ? ctx->mailbox : (volatile uint64_t *)nullptr, seq);
         RFX_HIP(hipGetLastError());
         uint32_t maxc = 0;
-        RFX_HIP(hipMemcpyAsync(&maxc, bounds.as<uint32_t>() + 257, 4, hipMemcpyDeviceToHost, ctx->stream));
-        RFX_TRY(sync_checked(ctx));
+        if (seq) { uint64_t v = 0; RFX_TRY(mailbox_wait(ctx, seq, &v, 1)); maxc = (uint32_t)v; }
+        else {
+            RFX_HIP(hipMemcpyAsync(&maxc, bounds.as<uint32_t>() + 257, 4, hipMemcpyDeviceToHost, ctx->stream));
+            RFX_TRY(sync_checked(ctx));
+        }
         if (maxc <= (uint32_t)STILE) {
             if (!inline_scan) RFX_TRY(exclusive_scan_u32_to_u64(ctx, table.as<uint32_t>(), offs.as<uint64_t>(), ntiles * 256));
             hipLaunchKernelGGL(k_scatter<false>, dim3((unsigned)ntiles), dim3(ST), 0, ctx->stream, sk, sv, n, shift,

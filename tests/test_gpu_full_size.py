@@ -119,3 +119,18 @@ def test_full_size_pins_hold_with_every_allocation_poisoned():
                        env=env, cwd=os.path.dirname(os.path.dirname(here)), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_extend_stage_without_the_mailbox():
+    """RFX_MAILBOX=0: the extend stage's few-byte readbacks as queued copies + stream waits again (what rounds 1-3 had, and the
+    fallback of mailbox_wait) -- the reference-made vectors and the k > 31 driver tests must hold on that path too.  A child
+    process: the switch is read once per process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, RFX_MAILBOX="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_gpu_reference_vectors.py"), os.path.join(root, "tests", "test_gpu_asm_w.py")],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

@@ -80,7 +80,9 @@ __global__ void k_zero_total(uint64_t *out) { out[0] = 0; }
 // predecessor is running or done) publishes its aggregate, walks back over its predecessors' descriptors until it meets
 // an inclusive prefix, publishes its own inclusive prefix and writes its outputs.  Descriptor = epoch (20 bits) | status
 // (2 bits: 1 aggregate, 2 inclusive prefix) | value (42 bits); DUAL scans two arrays with two descriptors per tile.
-constexpr int LB_THREADS = 256, LB_ITEMS = 8, LB_TILE = LB_THREADS * LB_ITEMS;
+// (16 items a thread: with 8 the 4,500 tiles of a 9 M-element scan were a chain of look-backs, 23 ns a tile = 105 us for 110 MB;
+// counts -> contigs 15.7 -> 15.6 ms at k = 31, 21.6 -> 21.1 at k = 63; 32 items: no better)
+constexpr int LB_THREADS = 256, LB_ITEMS = 16, LB_TILE = LB_THREADS * LB_ITEMS;
 constexpr uint64_t LB_VMASK = (1ULL << 42) - 1;
 constexpr uint32_t LB_SPIN_LIMIT = 1u << 24;      // seconds of polling
 __device__ __forceinline__ uint64_t lb_pack(uint32_t epoch, uint32_t status, uint64_t v) {
